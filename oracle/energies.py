@@ -1,0 +1,233 @@
+"""oracle/energies.py — TEST INFRASTRUCTURE ONLY (never imported by the product path stark_amd/).
+
+CPU restatement of the reference's energy *definitions*, one function per potential registry key. Every function
+receives `b`: the potential's bound inputs in the reference's binding order (the order of the `mws.make_*` calls in
+the cited constructor), each entry a list of `stride` scalars (oracle.ad.D2 for DoFs, ndarray[E] otherwise), and returns
+the per-element energy as a D2 (value, gradient, Hessian w.r.t. the element's velocity DoFs).
+
+All DoFs are next-step velocities: x1 = x0 + dt*v1 (stark/src/models/time_integration.cpp:3-11).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import ad
+from .ad import D2, add, cross, det3, dot, frob_sq, inv2, inv3, matmul, norm, normalized, scale, sqnorm, sub, trace, transpose, where
+
+
+def _x1(x0, v1, dt):
+    return [x0[i] + dt * v1[i] for i in range(3)]
+
+
+def _cols_to_matrix(cols):
+    """Matrix whose COLUMNS are the given vectors (reference: Matrix(collect_scalars({..}), {n,3}).transpose())."""
+    return [[cols[j][i] for j in range(len(cols))] for i in range(len(cols[0]))]
+
+
+def _identity(n):
+    return [[1.0 if i == j else 0.0 for j in range(n)] for i in range(n)]
+
+
+def _msub(A, B):
+    return [[A[i][j] - B[i][j] for j in range(len(A[0]))] for i in range(len(A))]
+
+
+def _mscale(s, A):
+    return [[s * A[i][j] for j in range(len(A[0]))] for i in range(len(A))]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# stark/src/models/deformables/point/EnergyLumpedInertia.cpp:12-49
+# bindings: v1*, x0, v0, a, f, volume, density, damping, is_quasistatic, dt, gravity
+def EnergyLumpedInertia(b):
+    v1, x0, v0, a, f, (volume,), (density,), (damping,), (is_quasistatic,), (dt,), gravity = b
+    mass = volume * density
+    x1 = _x1(x0, v1, dt)
+    xhat = [x0[i] + dt * v0[i] for i in range(3)]
+    dev = sub(x1, xhat)
+    dev2 = sub(x1, x0)
+    E_inertia = 0.5 * mass * (dot(dev, dev) / (dt ** 2) + dot(dev2, dev2) * damping / dt)
+    f_ext = [mass * (a[i] + gravity[i]) + f[i] for i in range(3)]
+    E_ext = -dot(f_ext, x1)
+    return E_ext + where(is_quasistatic > 0.5, 0.0, E_inertia)
+
+
+# stark/src/models/deformables/point/EnergyPrescribedPositions.cpp:15-32
+# bindings: v1*, x0, x1_prescribed, k, dt
+def EnergyPrescribedPositions(b):
+    v1, x0, target, (k,), (dt,) = b
+    x1 = _x1(x0, v1, dt)
+    return 0.5 * k * sqnorm(sub(x1, target))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def _stable_neohookean_density(F1, e, nu):
+    # stark/src/models/deformables/volume/EnergyTetStrain.cpp:50-61
+    mu = e / (2.0 * (1.0 + nu))
+    lam = (e * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu))
+    mu_ = 4.0 / 3.0 * mu
+    lam_ = lam + 5.0 / 6.0 * mu
+    detF = det3(F1)
+    Ic = frob_sq(F1)
+    alpha = 1.0 + mu_ / lam_ - mu_ / (4.0 * lam_)
+    return 0.5 * mu_ * (Ic - 3.0) + 0.5 * lam_ * (detF - alpha).powN(2) - 0.5 * mu_ * (Ic + 1.0).log()
+
+
+# stark/src/models/deformables/volume/EnergyTetStrain.cpp:12-78
+# bindings: v1[4]*, x0[4], X[4], scale, e, nu, strain_limit, strain_limit_stiffness, damping, dt
+def EnergyTetStrain(b):
+    v1, x0, X = b[0:4], b[4:8], b[8:12]
+    (scale_,), (e,), (nu,), (strain_limit,), (sl_k,), (damping,), (dt,) = b[12:19]
+    x1 = [_x1(x0[i], v1[i], dt) for i in range(4)]
+    Xs = [scale(scale_, X[i]) for i in range(4)]
+    DX = _cols_to_matrix([sub(Xs[1], Xs[0]), sub(Xs[2], Xs[0]), sub(Xs[3], Xs[0])])
+    DXinv = inv3(DX)
+    Dx1 = _cols_to_matrix([sub(x1[1], x1[0]), sub(x1[2], x1[0]), sub(x1[3], x1[0])])
+    F1 = matmul(Dx1, DXinv)
+    I = _identity(3)
+    E1 = _mscale(0.5, _msub(matmul(transpose(F1), F1), I))
+    vol = det3(DX) / 6.0
+    Dx0 = _cols_to_matrix([sub(x0[1], x0[0]), sub(x0[2], x0[0]), sub(x0[3], x0[0])])
+    F0 = matmul(Dx0, DXinv)
+    E0 = _mscale(0.5, _msub(matmul(transpose(F0), F0), I))
+    dE_dt = [[(E1[i][j] - E0[i][j]) / dt for j in range(3)] for i in range(3)]
+    elastic = _stable_neohookean_density(F1, e, nu)
+    damp = 0.5 * damping * frob_sq(dE_dt)
+    trE = trace(E1)
+    devE = [[E1[i][j] - (trE / 3.0) * I[i][j] for j in range(3)] for i in range(3)]
+    dev_norm = frob_sq(devE).sqrt()
+    largest = trE / 3.0 + np.sqrt(2.0 / 3.0) * dev_norm
+    dl = largest - strain_limit
+    sl = where(dl.v > 0.0, sl_k * dl.powN(3) / 3.0, 0.0)
+    return vol * (elastic + damp + sl)
+
+
+# stark/src/models/deformables/volume/EnergyTetStrain.cpp:80-123
+# bindings: v1[4]*, x0[4], X[4], scale, e, nu, dt
+def EnergyTetStrain_Elasticity_Only(b):
+    v1, x0, X = b[0:4], b[4:8], b[8:12]
+    (scale_,), (e,), (nu,), (dt,) = b[12:16]
+    x1 = [_x1(x0[i], v1[i], dt) for i in range(4)]
+    Xs = [scale(scale_, X[i]) for i in range(4)]
+    DX = _cols_to_matrix([sub(Xs[1], Xs[0]), sub(Xs[2], Xs[0]), sub(Xs[3], Xs[0])])
+    DXinv = inv3(DX)
+    Dx1 = _cols_to_matrix([sub(x1[1], x1[0]), sub(x1[2], x1[0]), sub(x1[3], x1[0])])
+    F1 = matmul(Dx1, DXinv)
+    vol = det3(DX) / 6.0
+    return vol * _stable_neohookean_density(F1, e, nu)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def _triangle_jacobian(x):
+    # stark/src/models/deformables/deformable_tools.cpp:7-21 (rest configuration projected to its own plane)
+    u = normalized(sub(x[1], x[0]))
+    n = cross(u, sub(x[2], x[0]))
+    v = normalized(cross(u, n))
+    P = [u, v]  # 2x3
+    Xp = [[dot(P[r], x[k]) for r in range(2)] for k in range(3)]
+    return _cols_to_matrix([sub(Xp[1], Xp[0]), sub(Xp[2], Xp[0])])  # 2x2
+
+
+def _eigenvalues_sym_2x2(A):
+    # stark/src/models/deformables/deformable_tools.cpp:26-36
+    a, bb, c = A[0][0], A[1][1], A[0][1]
+    delta = (4.0 * c.powN(2) + (a - bb).powN(2)).sqrt()
+    return [0.5 * (a + bb + delta), 0.5 * (a + bb - delta)]
+
+
+def _triangle_common(b, full):
+    v1, x0, X = b[0:3], b[3:6], b[6:9]
+    if full:
+        (scale_,), (thickness,), (e,), (nu,), (damping,), (strain_limit,), (sl_k,), (inflation,), (dt,) = b[9:18]
+    else:
+        (scale_,), (thickness,), (e,), (nu,), (inflation,), (dt,) = b[9:15]
+    x1 = [_x1(x0[i], v1[i], dt) for i in range(3)]
+    Xs = [scale(scale_, X[i]) for i in range(3)]
+    rest_area = 0.5 * norm(cross(sub(Xs[0], Xs[2]), sub(Xs[1], Xs[2])))
+    DXinv = inv2(_triangle_jacobian(Xs))
+    Dx1 = _cols_to_matrix([sub(x1[1], x1[0]), sub(x1[2], x1[0])])  # 3x2
+    F1 = matmul(Dx1, DXinv)  # 3x2
+    C1 = matmul(transpose(F1), F1)
+    mu = e / (2.0 * (1.0 + nu))
+    lam = (e * nu) / ((1.0 + nu) * (1.0 - nu))  # 2D
+    area = 0.5 * norm(cross(sub(x1[0], x1[2]), sub(x1[1], x1[2])))
+    J = area / rest_area
+    Ic = trace(C1)
+    logJ = J.log()
+    elastic = 0.5 * mu * (Ic - 2.0) - mu * logJ + 0.5 * lam * logJ.powN(2)
+    n0 = scale(-1.0, normalized(cross(sub(x0[1], x0[0]), sub(x0[2], x0[0]))))
+    infl = inflation * dot(n0, add(add(x1[0], x1[1]), x1[2])) / 3.0
+    total = elastic + infl
+    if full:
+        I = _identity(2)
+        E1 = _mscale(0.5, _msub(C1, I))
+        Dx0 = _cols_to_matrix([sub(x0[1], x0[0]), sub(x0[2], x0[0])])
+        F0 = matmul(Dx0, DXinv)
+        E0 = _mscale(0.5, _msub(matmul(transpose(F0), F0), I))
+        dE_dt = [[(E1[i][j] - E0[i][j]) / dt for j in range(2)] for i in range(2)]
+        damp = 0.5 * damping * frob_sq(dE_dt)
+        s = _eigenvalues_sym_2x2(E1)
+        sl = 0.0
+        for i in range(2):
+            dl = s[i] - strain_limit
+            sl = sl + where(dl.v > 0.0, sl_k * dl.powN(3) / 3.0, 0.0)
+        total = total + damp + sl
+    return thickness * rest_area * total
+
+
+# stark/src/models/deformables/surface/EnergyTriangleStrain.cpp:13-80
+def EnergyTriangleStrain(b):
+    return _triangle_common(b, True)
+
+
+# stark/src/models/deformables/surface/EnergyTriangleStrain.cpp:82-129
+def EnergyTriangleStrain_Elasticity_Only(b):
+    return _triangle_common(b, False)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+_DS_EPS = 1e-12
+
+
+def _dihedral(x):
+    # stark/src/models/deformables/surface/EnergyDiscreteShells.cpp:12-23
+    e0, e1, e2 = sub(x[1], x[0]), sub(x[2], x[0]), sub(x[3], x[0])
+    n0 = cross(e0, e1)
+    n1 = scale(-1.0, cross(e0, e2))
+    c = (1.0 - _DS_EPS) * dot(normalized(n0), normalized(n1))
+    return c.acos() if isinstance(c, D2) else np.arccos(c)
+
+
+# stark/src/models/deformables/surface/EnergyDiscreteShells.cpp:26-62
+# bindings: v1[4]*, x0[4], rest_angle, rest_edge_length, rest_height, scale, stiffness, damping, dt
+def EnergyDiscreteShells(b):
+    v1, x0 = b[0:4], b[4:8]
+    (rest_angle,), (rest_len,), (rest_h,), (scale_,), (k,), (damping,), (dt,) = b[8:15]
+    x1 = [_x1(x0[i], v1[i], dt) for i in range(4)]
+    ratio = (rest_len * scale_) / (rest_h * scale_)
+    da1 = _dihedral(x1)
+    dd = da1 - rest_angle
+    E_b = k * (dd * dd) * ratio
+    da0 = _dihedral(x0)
+    E_d = damping * 1.0 / dt * (0.5 * da1.powN(2) - da0 * da1) * ratio
+    return E_b + E_d
+
+
+# stark/src/models/deformables/surface/EnergyDiscreteShells.cpp:64-92
+# bindings: v1[4]*, x0[4], K(4), coef, stiffness, dt
+def EnergyBendingFlat(b):
+    v1, x0 = b[0:4], b[4:8]
+    K, (coef,), (k,), (dt,) = b[8:12]
+    x1 = [_x1(x0[i], v1[i], dt) for i in range(4)]
+    P = 0.0
+    for d in range(3):
+        x = [x1[0][d], x1[1][d], x1[2][d], x1[3][d]]
+        Kx = dot(K, x)
+        P = P + 0.5 * k * coef * (Kx * Kx)
+    return P
+
+
+REGISTRY = {f.__name__: f for f in [
+    EnergyLumpedInertia, EnergyPrescribedPositions, EnergyTetStrain, EnergyTetStrain_Elasticity_Only,
+    EnergyTriangleStrain, EnergyTriangleStrain_Elasticity_Only, EnergyDiscreteShells, EnergyBendingFlat,
+]}

@@ -384,32 +384,39 @@ int main(int argc, char** argv)
         return 0;
     }
     if (mode == "traj") {
-        // Newton iterates of `steps` time steps: dofs after every Newton iteration + per-step statistics
+        // Evaluation-point trace of `steps` time steps. SolverCallbacks::run_is_converged short-circuits on its `false`
+        // default (solver_utils.h:51-58) so it cannot be used as a per-iteration hook; before_energy_evaluation runs
+        // before every full evaluation (NewtonsMethod.cpp:101) and before every Armijo energy evaluation (:573), so the
+        // recorded DoF vectors are: iterate k, its line-search trial points, iterate k+1 (= accepted trial), ...
+        // Consecutive duplicates are removed.
         const std::string dir = a.s("out", "/tmp/mistark_traj");
         fs::create_directories(dir);
+        dump_snapshot(sc, dir, a);  // evaluator inputs + stage outputs at the initial state (t = 0, v1 = 0)
         std::vector<std::vector<double>> iterates;
         std::vector<int> iter_step;
         int cur_step = 0;
-        st.callbacks->newton->add_is_converged([&]() {
+        st.callbacks->newton->add_before_energy_evaluation([&]() {
             std::vector<double> u(st.global_potential->get_total_n_dofs());
             st.global_potential->get_dofs(u.data());
+            if (!iterates.empty() && iter_step.back() == cur_step && iterates.back() == u) return;
             iterates.push_back(u);
             iter_step.push_back(cur_step);
-            return false;
         });
-        // Scene inputs at t=0 for the build to construct the identical scene: a snapshot before stepping is not possible
-        // without JIT init, so the first step is run with the callback installed; inputs come from the manifest of `dump steps=0`.
         std::ostringstream man;
         man.precision(17);
         man << "{\"scene\":" << sc.json << ",\"steps\":[";
-        std::vector<double> x_end;
         for (cur_step = 0; cur_step < steps; cur_step++) {
             const double dt_used = st.dt;
             sc.sim->run_one_time_step();
-            // NewtonsMethod stats are private to Stark; read them from the logger series instead
-            auto& lg = *st.context->logger;
             man << (cur_step ? "," : "") << "{\"dt\":" << dt_used << ",\"time\":" << st.current_time << "}";
         }
+        auto& lg = *st.context->logger;
+        man << "],\n\"newton_iterations\":[";
+        { const auto& v = lg.get_int_series("newton_iterations"); for (size_t i = 0; i < v.size(); i++) man << (i ? "," : "") << v[i]; }
+        man << "],\n\"cg_iterations\":[";
+        { const auto& v = lg.get_int_series("cg_iterations"); for (size_t i = 0; i < v.size(); i++) man << (i ? "," : "") << v[i]; }
+        man << "],\n\"ls_bt\":[";
+        { const auto& v = lg.get_int_series("ls_bt"); for (size_t i = 0; i < v.size(); i++) man << (i ? "," : "") << v[i]; }
         man << "],\n\"n_iterates\":" << iterates.size() << ",\"iter_step\":[";
         for (size_t i = 0; i < iter_step.size(); i++) man << (i ? "," : "") << iter_step[i];
         man << "]}\n";
@@ -418,7 +425,10 @@ int main(int argc, char** argv)
         for (size_t i = 0; i < iterates.size(); i++) std::memcpy(&flat[i * nd], iterates[i].data(), nd * sizeof(double));
         npy_f64(dir + "/iterates.npy", flat.data(), { iterates.size(), nd });
         auto& ps = *sc.sim->deformables->point_sets;
-        if (ps.size() > 0) npy_f64(dir + "/x_end.npy", ps.x0.data[0].data(), { (size_t)ps.size(), 3 });
+        if (ps.size() > 0) {
+            npy_f64(dir + "/x_end.npy", ps.x0.data[0].data(), { (size_t)ps.size(), 3 });
+            npy_f64(dir + "/v_end.npy", ps.v0.data[0].data(), { (size_t)ps.size(), 3 });
+        }
         std::ofstream(dir + "/traj.json") << man.str();
         return 0;
     }

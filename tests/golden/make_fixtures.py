@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures under tests/golden/ from the UNMODIFIED reference.
+
+Runs only in the build container (needs /root/reference): `make -C oracle` builds oracle/_ref/ref_harness, which this
+script drives (`prime` then `dump`/`traj`) and whose .npy/.json output it packs into one compressed .npz per fixture.
+The fixtures are data only: evaluator inputs (connectivity tables + bound arrays in the reference's binding order) and
+the reference's stage outputs. Usage: python tests/golden/make_fixtures.py [name ...]
+"""
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+HARNESS = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# name -> (mode, scene, args)
+FIXTURES = {
+    # cfg-2 family (tet beam), elasticity-only and full (damping + strain limiting active)
+    "tetbeam_eo_4x1x1": ("dump", "tetbeam", "nx=4 ny=1 nz=1 eo=1 steps=2 amp=0.05"),
+    "tetbeam_full_4x1x1": ("dump", "tetbeam", "nx=4 ny=1 nz=1 eo=0 steps=2 amp=0.05 strain_damping=0.3 strain_limit=0.02 strain_limit_stiffness=1e4"),
+    "tetbeam_eo_8x2x2": ("dump", "tetbeam", "nx=8 ny=2 nz=2 eo=1 steps=2 amp=0.02"),
+    "tetbeam_softrubber_6x2x2": ("dump", "tetbeam", "nx=6 ny=2 nz=2 eo=0 steps=2 amp=0.02"),
+    # strong perturbation: indefinite element Hessians -> exercises the PSD projection
+    "tetbeam_eo_4x1x1_big": ("dump", "tetbeam", "nx=4 ny=1 nz=1 eo=1 steps=1 amp=1.5"),
+    # cloth family (cfg-1/3 energies without contact)
+    "cloth_flat_6": ("dump", "cloth", "n=6 flat=1 eo=0 steps=2 amp=0.05"),
+    "cloth_shells_6": ("dump", "cloth", "n=6 flat=0 eo=0 steps=2 amp=0.05 bend_stiffness=1e-3 bend_damping=1e-4"),
+    "cloth_eo_infl_5": ("dump", "cloth", "n=5 flat=1 eo=1 steps=2 amp=0.05 inflation=50"),
+    # Newton trajectories (iterates after every Newton iteration)
+    "traj_tetbeam_eo_8x2x2": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=1 steps=3"),
+    "traj_cloth_flat_8": ("traj", "cloth", "n=8 flat=1 eo=0 steps=3"),
+}
+
+
+def run(cmd):
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+
+
+def pack(name):
+    mode, scene, args = FIXTURES[name]
+    args = args.split()
+    tmp = tempfile.mkdtemp(prefix="mistark_fx_")
+    try:
+        scene_args = [a for a in args if not a.startswith(("steps=", "amp="))]
+        run([HARNESS, "prime", scene] + scene_args)
+        run([HARNESS, mode, scene] + args + ["out=" + tmp])
+        data = {}
+        for fn in sorted(os.listdir(tmp)):
+            p = os.path.join(tmp, fn)
+            if fn.endswith(".npy"):
+                data[fn[:-4]] = np.load(p)
+            elif fn.endswith(".json"):
+                txt = open(p).read()
+                json.loads(txt)  # validate
+                data[fn[:-5] + "_json"] = np.frombuffer(txt.encode(), dtype=np.uint8)
+        data["harness_args"] = np.frombuffer((mode + " " + scene + " " + " ".join(args)).encode(), dtype=np.uint8)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
+        print(name, "%.1f KB" % (os.path.getsize(os.path.join(OUT, name + ".npz")) / 1024))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(FIXTURES)
+    for n in names:
+        pack(n)

