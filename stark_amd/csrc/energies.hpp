@@ -1,0 +1,329 @@
+// energies.hpp — the element energies on the hot path, written once against a generic scalar T
+// (T = double for energy-only evaluation, T = HDual for gradient + Hessian; see hdual.hpp).
+//
+// One struct per potential registry key of the reference. `Layout` lists the strides of the bound
+// inputs in the reference's binding order (the order of the mws.make_* calls in the cited constructor), `NB` is the
+// number of 3-DoF blocks and `dof_binding[k]` the binding that provides local DoF block k. Local DoF order follows the
+// reference: DoF sets in registration order, then binding order
+// (symx/src/solver/second_order/SecondOrderCompiledPotential.cpp:10-33).
+// All DoFs are next-step velocities: x1 = x0 + dt v1 (stark/src/models/time_integration.cpp:3-11).
+#pragma once
+#include "hdual.hpp"
+
+namespace mistark {
+
+template <int... S>
+struct Strides
+{
+    static constexpr int NBIND = sizeof...(S);
+    static constexpr int NIN = (S + ...);
+    // f(binding index, stride, offset into the gathered input array)
+    template <class F>
+    MS_HD static void for_each(F&& f)
+    {
+        int o = 0, b = 0;
+        ((f(b, S, o), o += S, b++), ...);
+    }
+    static void strides(int* out)
+    {
+        int b = 0;
+        ((out[b++] = S), ...);
+    }
+};
+
+// Typed view of the gathered inputs of one element. (si, sj): local DoF indices seeded with eps1 / eps2.
+template <class T>
+struct Loader;
+template <>
+struct Loader<double>
+{
+    const double* in;
+    MS_HD double s(int o) const { return in[o]; }
+    MS_HD V3<double> v(int o) const { return {in[o], in[o + 1], in[o + 2]}; }
+    MS_HD V3<double> dof(int o, int) const { return {in[o], in[o + 1], in[o + 2]}; }
+};
+template <>
+struct Loader<HDual>
+{
+    const double* in;
+    int si, sj;
+    MS_HD double s(int o) const { return in[o]; }
+    MS_HD V3<double> v(int o) const { return {in[o], in[o + 1], in[o + 2]}; }
+    MS_HD HDual dofc(int o, int l) const { return HDual(in[o], l == si ? 1.0 : 0.0, l == sj ? 1.0 : 0.0, 0.0); }
+    MS_HD V3<HDual> dof(int o, int k) const { return {dofc(o, 3 * k), dofc(o + 1, 3 * k + 1), dofc(o + 2, 3 * k + 2)}; }
+};
+
+// ======================================================================================================================
+// stark/src/models/deformables/point/EnergyLumpedInertia.cpp:12-49
+// bindings: v1*, x0, v0, a, f, lumped_volume[idx], density[group], damping[group], is_quasistatic[group], dt, gravity
+struct E_LumpedInertia
+{
+    static constexpr const char* name = "EnergyLumpedInertia";
+    using Layout = Strides<3, 3, 3, 3, 3, 1, 1, 1, 1, 1, 3>;
+    static constexpr int NB = 1;
+    static constexpr int dof_binding[NB] = {0};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const V3<T> v1 = L.dof(0, 0);
+        const V3<double> x0 = L.v(3), v0 = L.v(6), a = L.v(9), f = L.v(12);
+        const double volume = L.s(15), density = L.s(16), damping = L.s(17), is_quasistatic = L.s(18), dt = L.s(19);
+        const V3<double> gravity = L.v(20);
+        const double mass = volume * density;
+        const V3<T> x1 = x0 + dt * v1;
+        const V3<double> xhat = x0 + dt * v0;
+        const V3<T> dev = x1 - xhat;
+        const V3<T> dev2 = x1 - x0;
+        const T E_inertia = 0.5 * mass * (dot(dev, dev) * (1.0 / (dt * dt)) + dot(dev2, dev2) * (damping / dt));
+        const V3<double> f_ext = mass * (a + gravity) + f;
+        const T E_ext = -dot(f_ext, x1);
+        return E_ext + select(is_quasistatic > 0.5, T(0.0), E_inertia);
+    }
+};
+
+// stark/src/models/deformables/point/EnergyPrescribedPositions.cpp:15-32
+// bindings: v1*, x0, target[idx], stiffness[group], dt
+struct E_PrescribedPositions
+{
+    static constexpr const char* name = "EnergyPrescribedPositions";
+    using Layout = Strides<3, 3, 3, 1, 1>;
+    static constexpr int NB = 1;
+    static constexpr int dof_binding[NB] = {0};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const V3<T> v1 = L.dof(0, 0);
+        const V3<double> x0 = L.v(3), target = L.v(6);
+        const double k = L.s(9), dt = L.s(10);
+        const V3<T> x1 = x0 + dt * v1;
+        return 0.5 * k * sqnorm(x1 - target);
+    }
+};
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Stable Neo-Hookean density, stark/src/models/deformables/volume/EnergyTetStrain.cpp:50-61
+template <class T>
+MS_HD T stable_neohookean_density(const M3<T>& F, double e, double nu)
+{
+    const double mu = e / (2.0 * (1.0 + nu));
+    const double lambda = (e * nu) / ((1.0 + nu) * (1.0 - 2.0 * nu));
+    const double mu_ = 4.0 / 3.0 * mu;
+    const double lambda_ = lambda + 5.0 / 6.0 * mu;
+    const T detF = det(F);
+    const T Ic = frob_sq(F);
+    const double alpha = 1.0 + mu_ / lambda_ - mu_ / (4.0 * lambda_);
+    return 0.5 * mu_ * (Ic - 3.0) + 0.5 * lambda_ * pow2(detF - alpha) - 0.5 * mu_ * log(Ic + 1.0);
+}
+template <class T>
+MS_HD M3<T> green_strain(const M3<T>& F)
+{
+    M3<T> E = transpose(F) * F;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) E.m[i][j] = 0.5 * (E.m[i][j] - (i == j ? 1.0 : 0.0));
+    return E;
+}
+
+// stark/src/models/deformables/volume/EnergyTetStrain.cpp:80-123
+// bindings: v1[4]*, x0[4], X[4], scale, youngs_modulus, poissons_ratio (all [group]), dt
+struct E_TetStrainEO
+{
+    static constexpr const char* name = "EnergyTetStrain_Elasticity_Only";
+    using Layout = Strides<3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 1, 1>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {0, 1, 2, 3};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double scale = L.s(36), e = L.s(37), nu = L.s(38), dt = L.s(39);
+        V3<T> x1[4];
+        V3<double> Xs[4];
+        for (int i = 0; i < 4; i++) {
+            x1[i] = L.v(12 + 3 * i) + dt * L.dof(3 * i, i);
+            Xs[i] = scale * L.v(24 + 3 * i);
+        }
+        const M3<double> DX = from_cols(Xs[1] - Xs[0], Xs[2] - Xs[0], Xs[3] - Xs[0]);
+        const M3<double> DXinv = inverse(DX);
+        const M3<T> Dx1 = from_cols(x1[1] - x1[0], x1[2] - x1[0], x1[3] - x1[0]);
+        const M3<T> F1 = Dx1 * DXinv;
+        const double vol = det(DX) / 6.0;
+        return vol * stable_neohookean_density(F1, e, nu);
+    }
+};
+
+// stark/src/models/deformables/volume/EnergyTetStrain.cpp:12-78
+// bindings: v1[4]*, x0[4], X[4], scale, e, nu, strain_limit, strain_limit_stiffness, damping (all [group]), dt
+struct E_TetStrain
+{
+    static constexpr const char* name = "EnergyTetStrain";
+    using Layout = Strides<3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {0, 1, 2, 3};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double scale = L.s(36), e = L.s(37), nu = L.s(38), strain_limit = L.s(39), sl_k = L.s(40), damping = L.s(41), dt = L.s(42);
+        V3<T> x1[4];
+        V3<double> x0[4], Xs[4];
+        for (int i = 0; i < 4; i++) {
+            x0[i] = L.v(12 + 3 * i);
+            x1[i] = x0[i] + dt * L.dof(3 * i, i);
+            Xs[i] = scale * L.v(24 + 3 * i);
+        }
+        const M3<double> DX = from_cols(Xs[1] - Xs[0], Xs[2] - Xs[0], Xs[3] - Xs[0]);
+        const M3<double> DXinv = inverse(DX);
+        const M3<T> F1 = from_cols(x1[1] - x1[0], x1[2] - x1[0], x1[3] - x1[0]) * DXinv;
+        const M3<T> E1 = green_strain(F1);
+        const double vol = det(DX) / 6.0;
+        const M3<double> F0 = from_cols(x0[1] - x0[0], x0[2] - x0[0], x0[3] - x0[0]) * DXinv;
+        const M3<double> E0 = green_strain(F0);
+        T dsum = T(0.0);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) dsum = dsum + pow2((E1.m[i][j] - E0.m[i][j]) * (1.0 / dt));
+        const T elastic = stable_neohookean_density(F1, e, nu);
+        const T damp = 0.5 * damping * dsum;
+        // smooth upper-bound proxy of the largest eigenvalue of E (EnergyTetStrain.cpp:66-71)
+        const T trE = trace(E1);
+        M3<T> devE = E1;
+        for (int i = 0; i < 3; i++) devE.m[i][i] = devE.m[i][i] - trE * (1.0 / 3.0);
+        const T dev_sq = frob_sq(devE);
+        const double largest_v = val(trE) / 3.0 + ::sqrt(2.0 / 3.0) * ::sqrt(val(dev_sq));
+        T sl = T(0.0);
+        if (largest_v - strain_limit > 0.0) {
+            const T dl = trE * (1.0 / 3.0) + ::sqrt(2.0 / 3.0) * sqrt(dev_sq) - strain_limit;
+            sl = (sl_k / 3.0) * pow3(dl);
+        }
+        return vol * (elastic + damp + sl);
+    }
+};
+
+// ----------------------------------------------------------------------------------------------------------------------
+// Triangle membrane. stark/src/models/deformables/surface/EnergyTriangleStrain.cpp:13-80 (full), :82-129 (elasticity only)
+// rest Jacobian: deformable_tools.cpp:7-21; eigenvalues_sym_2x2: deformable_tools.cpp:26-36
+// bindings (full): v1[3]*, x0[3], X[3], scale, thickness, e, nu, strain_damping, strain_limit, strain_limit_stiffness, inflation, dt
+// bindings (EO)  : v1[3]*, x0[3], X[3], scale, thickness, e, nu, inflation, dt
+template <bool FULL>
+struct E_TriangleStrainT
+{
+    static constexpr int NB = 3;
+    static constexpr int dof_binding[NB] = {0, 1, 2};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const int p = 27;
+        const double scale = L.s(p), thickness = L.s(p + 1), e = L.s(p + 2), nu = L.s(p + 3);
+        const double damping = FULL ? L.s(p + 4) : 0.0, strain_limit = FULL ? L.s(p + 5) : 0.0, sl_k = FULL ? L.s(p + 6) : 0.0;
+        const double inflation = L.s(FULL ? p + 7 : p + 4), dt = L.s(FULL ? p + 8 : p + 5);
+        V3<T> x1[3];
+        V3<double> x0[3], Xs[3];
+        for (int i = 0; i < 3; i++) {
+            x0[i] = L.v(9 + 3 * i);
+            x1[i] = x0[i] + dt * L.dof(3 * i, i);
+            Xs[i] = scale * L.v(18 + 3 * i);
+        }
+        const double rest_area = 0.5 * norm(cross(Xs[0] - Xs[2], Xs[1] - Xs[2]));
+        // rest configuration projected into its own plane -> 2x2 Jacobian and its inverse
+        const V3<double> u = normalized(Xs[1] - Xs[0]);
+        const V3<double> n = cross(u, Xs[2] - Xs[0]);
+        const V3<double> v = normalized(cross(u, n));
+        const double a00 = dot(u, Xs[1]) - dot(u, Xs[0]), a01 = dot(u, Xs[2]) - dot(u, Xs[0]);
+        const double a10 = dot(v, Xs[1]) - dot(v, Xs[0]), a11 = dot(v, Xs[2]) - dot(v, Xs[0]);
+        const double idet = 1.0 / (a00 * a11 - a01 * a10);
+        const double i00 = a11 * idet, i01 = -a01 * idet, i10 = -a10 * idet, i11 = a00 * idet;
+        // F (3x2) = [x1-x0 | x2-x0] * DXinv
+        const V3<T> d1 = x1[1] - x1[0], d2 = x1[2] - x1[0];
+        const V3<T> f0 = i00 * d1 + i10 * d2, f1 = i01 * d1 + i11 * d2;
+        const T C00 = dot(f0, f0), C01 = dot(f0, f1), C11 = dot(f1, f1);
+        const double mu = e / (2.0 * (1.0 + nu));
+        const double lambda = (e * nu) / ((1.0 + nu) * (1.0 - nu));  // 2D
+        const T area = 0.5 * norm(cross(x1[0] - x1[2], x1[1] - x1[2]));
+        const T J = area * (1.0 / rest_area);
+        const T Ic = C00 + C11;
+        const T logJ = log(J);
+        T density = 0.5 * mu * (Ic - 2.0) - mu * logJ + 0.5 * lambda * pow2(logJ);
+        const V3<double> n0 = -normalized(cross(x0[1] - x0[0], x0[2] - x0[0]));
+        density = density + (inflation / 3.0) * dot(n0, x1[0] + x1[1] + x1[2]);
+        if (FULL) {
+            const T E00 = 0.5 * (C00 - 1.0), E01 = 0.5 * C01, E11 = 0.5 * (C11 - 1.0);
+            const V3<double> e1 = x0[1] - x0[0], e2 = x0[2] - x0[0];
+            const V3<double> g0 = i00 * e1 + i10 * e2, g1 = i01 * e1 + i11 * e2;
+            const double P00 = 0.5 * (dot(g0, g0) - 1.0), P01 = 0.5 * dot(g0, g1), P11 = 0.5 * (dot(g1, g1) - 1.0);
+            const double idt = 1.0 / dt;
+            density = density + 0.5 * damping * (pow2((E00 - P00) * idt) + 2.0 * pow2((E01 - P01) * idt) + pow2((E11 - P11) * idt));
+            // strain limiting on both eigenvalues of E
+            const T disc = 4.0 * pow2(E01) + pow2(E00 - E11);
+            const double sq = ::sqrt(val(disc));
+            const double s0 = 0.5 * (val(E00) + val(E11) + sq), s1 = 0.5 * (val(E00) + val(E11) - sq);
+            if (s0 - strain_limit > 0.0) density = density + (sl_k / 3.0) * pow3(0.5 * (E00 + E11 + sqrt(disc)) - strain_limit);
+            if (s1 - strain_limit > 0.0) density = density + (sl_k / 3.0) * pow3(0.5 * (E00 + E11 - sqrt(disc)) - strain_limit);
+        }
+        return (thickness * rest_area) * density;
+    }
+};
+struct E_TriangleStrain : E_TriangleStrainT<true>
+{
+    static constexpr const char* name = "EnergyTriangleStrain";
+    using Layout = Strides<3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1>;
+};
+struct E_TriangleStrainEO : E_TriangleStrainT<false>
+{
+    static constexpr const char* name = "EnergyTriangleStrain_Elasticity_Only";
+    using Layout = Strides<3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 1, 1, 1, 1>;
+};
+
+// ----------------------------------------------------------------------------------------------------------------------
+// stark/src/models/deformables/surface/EnergyDiscreteShells.cpp:12-23
+template <class T>
+MS_HD T dihedral_angle(const V3<T>* x)
+{
+    const V3<T> e0 = x[1] - x[0], e1 = x[2] - x[0], e2 = x[3] - x[0];
+    const V3<T> n0 = cross(e0, e1);
+    const V3<T> n1 = -cross(e0, e2);
+    return acos((1.0 - 1e-12) * dot(normalized(n0), normalized(n1)));
+}
+// stark/src/models/deformables/surface/EnergyDiscreteShells.cpp:26-62
+// bindings: v1[4]*, x0[4], rest_dihedral_angle[idx], rest_edge_length[idx], rest_height[idx], scale, stiffness, damping ([group]), dt
+struct E_DiscreteShells
+{
+    static constexpr const char* name = "EnergyDiscreteShells";
+    using Layout = Strides<3, 3, 3, 3, 3, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {0, 1, 2, 3};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double rest_angle = L.s(24), rest_len = L.s(25), rest_h = L.s(26), scale = L.s(27), k = L.s(28), damping = L.s(29), dt = L.s(30);
+        V3<T> x1[4];
+        V3<double> x0[4];
+        for (int i = 0; i < 4; i++) {
+            x0[i] = L.v(12 + 3 * i);
+            x1[i] = x0[i] + dt * L.dof(3 * i, i);
+        }
+        const double ratio = (rest_len * scale) / (rest_h * scale);
+        const T da1 = dihedral_angle(x1);
+        const T dd = da1 - rest_angle;
+        const double da0 = dihedral_angle(x0);
+        return k * (dd * dd) * ratio + (damping / dt) * (0.5 * pow2(da1) - da0 * da1) * ratio;
+    }
+};
+// stark/src/models/deformables/surface/EnergyDiscreteShells.cpp:64-92
+// bindings: v1[4]*, x0[4], bergou_K[idx] (4), bergou_coef[idx], stiffness[group], dt
+struct E_BendingFlat
+{
+    static constexpr const char* name = "EnergyBendingFlat";
+    using Layout = Strides<3, 3, 3, 3, 3, 3, 3, 3, 4, 1, 1, 1>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {0, 1, 2, 3};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double coef = L.s(28), k = L.s(29), dt = L.s(30);
+        V3<T> s(T(0.0), T(0.0), T(0.0));
+        for (int i = 0; i < 4; i++) {
+            const V3<T> x1 = L.v(12 + 3 * i) + dt * L.dof(3 * i, i);
+            s = s + L.s(24 + i) * x1;
+        }
+        return (0.5 * k * coef) * sqnorm(s);
+    }
+};
+
+}  // namespace mistark

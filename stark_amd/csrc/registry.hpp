@@ -1,0 +1,13 @@
+// registry.hpp — list of the potentials the engine evaluates, keyed by the reference's registry names.
+#pragma once
+#include "energies.hpp"
+
+#define MISTARK_FOR_EACH_ENERGY(X) \
+    X(E_LumpedInertia)             \
+    X(E_PrescribedPositions)       \
+    X(E_TetStrainEO)               \
+    X(E_TetStrain)                 \
+    X(E_TriangleStrain)            \
+    X(E_TriangleStrainEO)          \
+    X(E_DiscreteShells)            \
+    X(E_BendingFlat)
