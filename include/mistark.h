@@ -1,0 +1,223 @@
+/* mistark.h — C ABI of libmistark.so, the MI355X-native engine behind STARK's per-Newton-step hot path.
+ *
+ * This is the drop-in boundary (SURVEY.md §8b "New C ABI"): plain pointers and sizes, int status returns
+ * (0 = ok, otherwise mistark_last_error()), no exceptions / exit() across the boundary, one host thread per context.
+ * Host buffers are caller-owned (the reference's DataMap lambdas, symx/src/compile/data_maps.h:97-105); device buffers
+ * are library-owned. Each entry point cites the reference interface it replaces.
+ *
+ * Mapping to the reference's registration API (symx/src/solver/GlobalPotential.h:37-70):
+ *   GlobalPotential::add_dof(arr, label)                 -> mistark_add_dof_set
+ *   mws.make_scalar / make_vector / make_matrix(arr,..)  -> mistark_array + one mistark_binding per call, in call order
+ *   GlobalPotential::add_potential(name, conn, lambda)   -> mistark_potential (name selects the hand-written kernel;
+ *                                                           the symbolic lambda is not needed)
+ *   GlobalPotential::get_dofs / set_dofs                 -> mistark_get_dofs / mistark_set_dofs
+ *   SecondOrderCompiledGlobal::evaluate_*                -> mistark_eval
+ *   NewtonsMethod::_project_and_assemble                 -> mistark_assemble / mistark_project
+ *   NewtonsMethod::_solve_linear_system (bsm::solve_pcg) -> mistark_pcg
+ *   NewtonsMethod::solve                                 -> mistark_newton_solve
+ */
+#ifndef MISTARK_H
+#define MISTARK_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mistark_ctx mistark_ctx;
+
+/* ---- context -------------------------------------------------------------------------------------------------- */
+int mistark_create(int device, mistark_ctx** out);
+void mistark_destroy(mistark_ctx* ctx);
+const char* mistark_last_error(mistark_ctx* ctx);
+/* Version / build info string (static storage). */
+const char* mistark_version(void);
+
+/* ---- DoF sets and bound arrays ---------------------------------------------------------------------------------- */
+/* GlobalPotential::add_dof (GlobalPotential.h:55-61): `host` holds n_scalars doubles (3 per DoF block, AoS as
+ * PointDynamics::v1, stark/src/models/deformables/PointDynamics.h:16-23). Sets are concatenated in registration order.
+ * Returns the set index (>= 0) or < 0 on error. The size may be changed later with mistark_resize_dof_set. */
+int mistark_add_dof_set(mistark_ctx* ctx, const char* label, double* host, int64_t n_scalars);
+int mistark_resize_dof_set(mistark_ctx* ctx, int set, double* host, int64_t n_scalars);
+
+/* A bound input array (DataMap, data_maps.h:97-121): n_items x stride doubles, row-major, caller-owned.
+ * Arrays are identified by (host pointer, stride); binding the host pointer of a DoF set yields a view of the DoF
+ * vector. Returns the array id (>= 0). Re-binding an existing (pointer, stride) updates n_items. */
+int mistark_array(mistark_ctx* ctx, const double* host, int64_t n_items, int stride);
+/* Re-point an array id at a (possibly reallocated / resized) host buffer. */
+int mistark_array_rebind(mistark_ctx* ctx, int array, const double* host, int64_t n_items);
+/* host -> device / device -> host copies of one array (all arrays if array < 0). */
+int mistark_upload(mistark_ctx* ctx, int array);
+int mistark_download(mistark_ctx* ctx, int array);
+/* Device-side vector helpers used by the state containers (PointDynamics.cpp:58-78): dst = a*x + b*y (x,y,dst array
+ * ids of equal size; y may be -1), fill. */
+int mistark_array_axpby(mistark_ctx* ctx, int dst, double a, int x, double b, int y);
+int mistark_array_fill(mistark_ctx* ctx, int dst, double value);
+
+/* ---- potentials ----------------------------------------------------------------------------------------------------- */
+typedef struct mistark_binding
+{
+    int32_t array;     /* id from mistark_array */
+    int32_t stride;    /* doubles per item (must match the kernel's expectation) */
+    int32_t conn_col;  /* connectivity column that indexes the array, -1 = global value (item 0) */
+} mistark_binding;
+
+/* GlobalPotential::add_potential(name, LabelledConnectivity<N>&, ...) (GlobalPotential.h:37-52). `name` is the
+ * reference's registry key (e.g. "EnergyTetStrain"); bindings are given in the order of the reference's mws.make_*
+ * calls for that potential. conn: n_elem x conn_stride int32, row-major, copied at call time.
+ * Returns the potential id (>= 0). Calling again with an existing name replaces connectivity and bindings. */
+int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride,
+                      const mistark_binding* bindings, int32_t n_bindings);
+/* Number of potentials known to the engine and their registry names (for the shim's "unknown name" error path). */
+int mistark_n_supported_potentials(void);
+const char* mistark_supported_potential(int i);
+
+/* ---- DoF vector --------------------------------------------------------------------------------------------------- */
+int64_t mistark_ndofs(mistark_ctx* ctx);
+int mistark_get_dofs(mistark_ctx* ctx, double* u_host);        /* GlobalPotential::get_dofs (GlobalPotential.cpp:111-121) */
+int mistark_set_dofs(mistark_ctx* ctx, const double* u_host);  /* GlobalPotential::set_dofs (GlobalPotential.cpp:134-144) */
+/* device DoFs -> the host arrays registered with mistark_add_dof_set, and back */
+int mistark_dofs_to_host_arrays(mistark_ctx* ctx);
+int mistark_dofs_from_host_arrays(mistark_ctx* ctx);
+
+/* ---- evaluation ----------------------------------------------------------------------------------------------------- */
+enum { MISTARK_EVAL_P = 0, MISTARK_EVAL_P_G = 1, MISTARK_EVAL_P_G_H = 2 };
+/* SecondOrderCompiledGlobal::evaluate_P / _P__dP_du / _P__dP_du__local_d2P_du2 (SecondOrderCompiledGlobal.cpp:72-142).
+ * E: total energy; grad_host (may be NULL): ndofs doubles. Element Hessians stay on the device. */
+int mistark_eval(mistark_ctx* ctx, int mode, double* E, double* grad_host);
+/* Parity access: element Hessians of one potential, n_elem x (3 NB) x (3 NB) row-major doubles, and the global block
+ * rows n_elem x NB (ElementHessians::HessianView, ElementHessians.h:33-39). Either pointer may be NULL. */
+int mistark_get_element_hessians(mistark_ctx* ctx, int potential, double* values, int32_t* block_rows, int32_t* nb_out);
+int mistark_get_element_energies(mistark_ctx* ctx, int potential, double* values);
+
+/* ---- projection + assembly ------------------------------------------------------------------------------------------ */
+/* ElementHessians::project_to_PD_inplace__all / project_to_PD_for_update__selectively (ElementHessians.cpp:48-67,79-182;
+ * project_to_PD.cpp:12-32). active_blocks: NULL = all elements, else ndofs/3 flags; only not-yet-projected elements
+ * touching an active block are projected. Returns counts through the out-pointers (may be NULL). */
+int mistark_project(mistark_ctx* ctx, double eps, int mirroring, const uint8_t* active_blocks, int64_t* n_projected_now,
+                    int64_t* n_changed_now);
+/* Same selection rule evaluated on the device from the current gradient: block active iff max|grad_block| >= threshold
+ * (NewtonsMethod.cpp:314-323). all_active_out: 1 if every block was active. */
+int mistark_project_by_gradient(mistark_ctx* ctx, double eps, int mirroring, double threshold, int* all_active_out,
+                                int64_t* n_projected_now);
+/* ElementHessians::assemble_global (ElementHessians.cpp:224-256): element blocks -> float 3x3-block CSR. */
+int mistark_assemble(mistark_ctx* ctx);
+/* Parity access to the assembled matrix (BlockedSparseMatrix::to_triplets): block CSR, vals row-major 3x3 floats. */
+int mistark_get_bsr(mistark_ctx* ctx, int64_t* n_block_rows, int64_t* nnzb, int64_t* row_ptr, int32_t* cols, float* vals);
+/* Probes: y = A x (BlockedSparseMatrix::spmxv_from_ptr), z = M^-1 x (prepare/apply_preconditioning). Host vectors. */
+int mistark_spmv(mistark_ctx* ctx, const double* x_host, double* y_host);
+int mistark_apply_preconditioner(mistark_ctx* ctx, const double* x_host, double* z_host);
+
+/* ---- linear solve --------------------------------------------------------------------------------------------------- */
+typedef struct mistark_pcg_info
+{
+    int32_t converged;
+    int32_t n_iterations;
+    int32_t found_indefiniteness;
+    int32_t reserved;
+    double error;
+} mistark_pcg_info;
+/* bsm::solve_pcg (BlockedSparseMatrix/solve_pcg.h:83-232) with x0 = 0 and rhs = -grad of the last evaluation
+ * (NewtonsMethod.cpp:392,431-446). The solution stays on the device as the Newton step `du`; du_host may be NULL. */
+int mistark_pcg(mistark_ctx* ctx, double abs_tol, double rel_tol, int max_iter, int stop_on_indefiniteness, double* du_host,
+                mistark_pcg_info* info);
+/* Same with an explicit host rhs (parity tests). */
+int mistark_pcg_rhs(mistark_ctx* ctx, const double* rhs_host, double abs_tol, double rel_tol, int max_iter,
+                    int stop_on_indefiniteness, double* x_host, mistark_pcg_info* info);
+
+/* ---- Newton's method -------------------------------------------------------------------------------------------------- */
+/* symx::SolverReturn (symx/src/solver/solver_utils.h:15-26) */
+enum
+{
+    MISTARK_SUCCESSFUL = 0,
+    MISTARK_RUNNING = 1,
+    MISTARK_INVALID_INITIAL_STATE = 2,
+    MISTARK_TOO_MANY_ITERATIONS = 3,
+    MISTARK_TOO_MANY_ARMIJO_ITERATIONS = 4,
+    MISTARK_LINEAR_SYSTEM_SOLVE_FAILURE = 5,
+    MISTARK_TOO_MANY_INVALID_INTERMEDIATE_ITERATIONS = 6,
+    MISTARK_STEP_DOES_NOT_DESCEND = 7,
+    MISTARK_INVALID_CONVERGED_STATE = 8
+};
+/* symx::ProjectionToPD (solver_utils.h:137-143) */
+enum { MISTARK_PROJ_NEWTON = 0, MISTARK_PROJ_PROJECTED_NEWTON = 1, MISTARK_PROJ_ON_DEMAND = 2, MISTARK_PROJ_PROGRESSIVE = 3 };
+
+/* symx::NewtonSettings (solver_utils.h:173-259) with STARK's overrides as defaults (stark/src/core/Settings.cpp:43-50) */
+typedef struct mistark_newton_settings
+{
+    int32_t max_iterations;
+    int32_t min_iterations;
+    double residual_tolerance_abs;
+    double residual_tolerance_rel;
+    double step_tolerance;
+    int32_t max_iterations_as_success;
+    double step_cap;
+    int32_t enable_armijo_backtracking;
+    double line_search_armijo_beta;
+    int32_t max_backtracking_armijo_iterations;
+    int32_t max_backtracking_invalid_state_iterations;
+    int32_t projection_mode;
+    double projection_eps;
+    int32_t project_to_pd_use_mirroring;
+    int32_t project_on_demand_countdown;
+    double ppn_tightening_factor;
+    double ppn_release_factor;
+    int32_t cg_max_iterations;
+    double cg_abs_tolerance;
+    double cg_rel_tolerance;
+    int32_t cg_stop_on_indefiniteness;
+    double bailout_residual;
+} mistark_newton_settings;
+void mistark_newton_default_settings(mistark_newton_settings* s);
+
+/* NewtonsMethod::SolveStats (NewtonsMethod.h:32-43) + wall-clock per stage (the reference's Logger timers) */
+typedef struct mistark_newton_stats
+{
+    int32_t newton_iterations;
+    int32_t cg_iterations;
+    int32_t ls_cap_iterations;
+    int32_t ls_max_iterations;
+    int32_t ls_inv_iterations;
+    int32_t ls_bt_iterations;
+    int64_t n_hessians;
+    int64_t n_projected_hessians;
+    double projected_hessians_ratio;
+    int32_t n_linear_solves;
+    int32_t n_evaluations;
+    double t_eval_pgh;
+    double t_eval_p;
+    double t_project;
+    double t_assembly;
+    double t_linear_solve;
+    double t_callbacks;
+    double t_total;
+} mistark_newton_stats;
+
+/* symx::SolverCallbacks (solver_utils.h:29-117). Any pointer may be NULL. Callbacks run on the calling thread; they may
+ * call mistark_* functions on the same context (e.g. download positions, update contact connectivity). */
+typedef struct mistark_newton_callbacks
+{
+    void* user;
+    void (*before_energy_evaluation)(void* user);
+    int (*is_initial_state_valid)(void* user);
+    int (*is_intermediate_state_valid)(void* user);
+    void (*on_intermediate_state_invalid)(void* user);
+    void (*on_armijo_fail)(void* user);
+    int (*is_converged)(void* user);
+    int (*is_converged_state_valid)(void* user);
+    double (*max_allowed_step)(void* user);
+} mistark_newton_callbacks;
+
+/* NewtonsMethod::solve (NewtonsMethod.cpp:28-252). Returns a MISTARK_* SolverReturn code (>= 0) or < 0 on engine error. */
+int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settings, const mistark_newton_callbacks* callbacks,
+                         mistark_newton_stats* stats);
+
+/* ---- timers ------------------------------------------------------------------------------------------------------- */
+/* Average duration in ms of the SpMV kernel over the launches since the last reset, measured with HIP events on the
+ * engine's stream; n = number of launches measured. Used by bench.py for the roofline figure. */
+int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n, double* bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,118 @@
+"""ctypes binding of libmistark.so (include/mistark.h). The library is built in-tree by `__graft_entry__.build()` /
+`make -C stark_amd/csrc`; there is NO CPU fallback: loading fails loudly if the shared object is missing, and
+`Engine()` fails loudly if no MI355X is visible."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmistark.so")
+
+EVAL_P, EVAL_P_G, EVAL_P_G_H = 0, 1, 2
+PROJ_NEWTON, PROJ_PROJECTED_NEWTON, PROJ_ON_DEMAND, PROJ_PROGRESSIVE = 0, 1, 2, 3
+SOLVER_RETURN = ["Successful", "Running", "InvalidInitialState", "TooManyIterations", "TooManyArmijoIterations", "LinearSystemSolveFailure",
+                 "TooManyInvalidIntermediateIterations", "StepDoesNotDescend", "InvalidConvergedState"]
+
+
+class Binding(C.Structure):
+    _fields_ = [("array", C.c_int32), ("stride", C.c_int32), ("conn_col", C.c_int32)]
+
+
+class PcgInfo(C.Structure):
+    _fields_ = [("converged", C.c_int32), ("n_iterations", C.c_int32), ("found_indefiniteness", C.c_int32), ("reserved", C.c_int32), ("error", C.c_double)]
+
+
+class NewtonSettings(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int32), ("min_iterations", C.c_int32), ("residual_tolerance_abs", C.c_double), ("residual_tolerance_rel", C.c_double),
+        ("step_tolerance", C.c_double), ("max_iterations_as_success", C.c_int32), ("step_cap", C.c_double), ("enable_armijo_backtracking", C.c_int32),
+        ("line_search_armijo_beta", C.c_double), ("max_backtracking_armijo_iterations", C.c_int32), ("max_backtracking_invalid_state_iterations", C.c_int32),
+        ("projection_mode", C.c_int32), ("projection_eps", C.c_double), ("project_to_pd_use_mirroring", C.c_int32), ("project_on_demand_countdown", C.c_int32),
+        ("ppn_tightening_factor", C.c_double), ("ppn_release_factor", C.c_double), ("cg_max_iterations", C.c_int32), ("cg_abs_tolerance", C.c_double),
+        ("cg_rel_tolerance", C.c_double), ("cg_stop_on_indefiniteness", C.c_int32), ("bailout_residual", C.c_double),
+    ]
+
+
+class NewtonStats(C.Structure):
+    _fields_ = [
+        ("newton_iterations", C.c_int32), ("cg_iterations", C.c_int32), ("ls_cap_iterations", C.c_int32), ("ls_max_iterations", C.c_int32),
+        ("ls_inv_iterations", C.c_int32), ("ls_bt_iterations", C.c_int32), ("n_hessians", C.c_int64), ("n_projected_hessians", C.c_int64),
+        ("projected_hessians_ratio", C.c_double), ("n_linear_solves", C.c_int32), ("n_evaluations", C.c_int32), ("t_eval_pgh", C.c_double),
+        ("t_eval_p", C.c_double), ("t_project", C.c_double), ("t_assembly", C.c_double), ("t_linear_solve", C.c_double), ("t_callbacks", C.c_double),
+        ("t_total", C.c_double),
+    ]
+
+
+VOIDCB = C.CFUNCTYPE(None, C.c_void_p)
+INTCB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+DBLCB = C.CFUNCTYPE(C.c_double, C.c_void_p)
+
+
+class NewtonCallbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("before_energy_evaluation", VOIDCB), ("is_initial_state_valid", INTCB), ("is_intermediate_state_valid", INTCB),
+                ("on_intermediate_state_invalid", VOIDCB), ("on_armijo_fail", VOIDCB), ("is_converged", INTCB), ("is_converged_state_valid", INTCB),
+                ("max_allowed_step", DBLCB)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libmistark.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the hot path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    p, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.mistark_version.restype = C.c_char_p
+    L.mistark_last_error.restype = C.c_char_p
+    L.mistark_last_error.argtypes = [p]
+    L.mistark_create.argtypes = [C.c_int, C.POINTER(p)]
+    L.mistark_destroy.argtypes = [p]
+    L.mistark_destroy.restype = None
+    L.mistark_supported_potential.restype = C.c_char_p
+    L.mistark_supported_potential.argtypes = [C.c_int]
+    L.mistark_add_dof_set.argtypes = [p, C.c_char_p, p, i64]
+    L.mistark_resize_dof_set.argtypes = [p, C.c_int, p, i64]
+    L.mistark_array.argtypes = [p, p, i64, C.c_int]
+    L.mistark_array_rebind.argtypes = [p, C.c_int, p, i64]
+    L.mistark_upload.argtypes = [p, C.c_int]
+    L.mistark_download.argtypes = [p, C.c_int]
+    L.mistark_array_axpby.argtypes = [p, C.c_int, dbl, C.c_int, dbl, C.c_int]
+    L.mistark_array_fill.argtypes = [p, C.c_int, dbl]
+    L.mistark_potential.argtypes = [p, C.c_char_p, p, i32, i32, C.POINTER(Binding), i32]
+    L.mistark_ndofs.argtypes = [p]
+    L.mistark_ndofs.restype = i64
+    L.mistark_get_dofs.argtypes = [p, p]
+    L.mistark_set_dofs.argtypes = [p, p]
+    L.mistark_dofs_to_host_arrays.argtypes = [p]
+    L.mistark_dofs_from_host_arrays.argtypes = [p]
+    L.mistark_eval.argtypes = [p, C.c_int, C.POINTER(dbl), p]
+    L.mistark_get_element_hessians.argtypes = [p, C.c_int, p, p, C.POINTER(i32)]
+    L.mistark_get_element_energies.argtypes = [p, C.c_int, p]
+    L.mistark_project.argtypes = [p, dbl, C.c_int, p, C.POINTER(i64), C.POINTER(i64)]
+    L.mistark_project_by_gradient.argtypes = [p, dbl, C.c_int, dbl, C.POINTER(C.c_int), C.POINTER(i64)]
+    L.mistark_assemble.argtypes = [p]
+    L.mistark_get_bsr.argtypes = [p, C.POINTER(i64), C.POINTER(i64), p, p, p]
+    L.mistark_spmv.argtypes = [p, p, p]
+    L.mistark_apply_preconditioner.argtypes = [p, p, p]
+    L.mistark_pcg.argtypes = [p, dbl, dbl, C.c_int, C.c_int, p, C.POINTER(PcgInfo)]
+    L.mistark_pcg_rhs.argtypes = [p, p, dbl, dbl, C.c_int, C.c_int, p, C.POINTER(PcgInfo)]
+    L.mistark_newton_default_settings.argtypes = [C.POINTER(NewtonSettings)]
+    L.mistark_newton_default_settings.restype = None
+    L.mistark_newton_solve.argtypes = [p, C.POINTER(NewtonSettings), C.POINTER(NewtonCallbacks), C.POINTER(NewtonStats)]
+    L.mistark_spmv_timing.argtypes = [p, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl)]
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Every entry point include/mistark.h declares (used by the CPU-side load test)."""
+    import re
+    hdr = open(os.path.join(os.path.dirname(_HERE), "include", "mistark.h")).read()
+    return sorted(set(re.findall(r"\b(mistark_[a-z0-9_]+)\s*\(", hdr)))

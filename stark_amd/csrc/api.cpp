@@ -1,0 +1,498 @@
+// api.cpp — extern "C" entry points of libmistark.so (see include/mistark.h for the contract and reference citations).
+#include <algorithm>
+#include <cstring>
+
+#include "engine.hpp"
+
+using namespace mistark;
+
+#define API_BEGIN        \
+    if (!ctx) return -1; \
+    int _ret = 0;        \
+    (void)_ret;          \
+    try {
+#define API_END(ret)                   \
+    }                                  \
+    catch (const std::exception& e)    \
+    {                                  \
+        ctx->c.last_error = e.what();  \
+        return -1;                     \
+    }                                  \
+    return ret;
+
+extern "C" {
+
+const char* mistark_version(void) { return "mistark 0.1 (gfx950, HIP)"; }
+
+int mistark_create(int device, mistark_ctx** out)
+{
+    if (!out) return -1;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -2;  // no GPU: the product path fails loudly, there is no CPU fallback
+    if (device < 0 || device >= n) return -3;
+    if (hipSetDevice(device) != hipSuccess) return -4;
+    mistark_ctx* ctx = new mistark_ctx();
+    ctx->c.device = device;
+    if (hipStreamCreateWithFlags(&ctx->c.stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return -5;
+    }
+    *out = ctx;
+    return 0;
+}
+void mistark_destroy(mistark_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->c.device);
+    (void)hipStreamSynchronize(ctx->c.stream);
+    delete ctx;
+}
+const char* mistark_last_error(mistark_ctx* ctx) { return ctx ? ctx->c.last_error.c_str() : "null context"; }
+
+int mistark_n_supported_potentials(void) { return n_kinds(); }
+const char* mistark_supported_potential(int i) { return (i >= 0 && i < n_kinds()) ? kind_name(i) : nullptr; }
+
+int mistark_add_dof_set(mistark_ctx* ctx, const char* label, double* host, int64_t n_scalars)
+{
+    API_BEGIN
+    if (n_scalars % 3 != 0) throw Error("DoF set size must be a multiple of 3");
+    DofSet s;
+    s.label = label ? label : "";
+    s.host = host;
+    s.n = n_scalars;
+    ctx->c.dof_sets.push_back(s);
+    ctx->c.layout_dirty = true;
+    _ret = (int)ctx->c.dof_sets.size() - 1;
+    API_END(_ret)
+}
+int mistark_resize_dof_set(mistark_ctx* ctx, int set, double* host, int64_t n_scalars)
+{
+    API_BEGIN
+    if (set < 0 || set >= (int)ctx->c.dof_sets.size()) throw Error("bad DoF set");
+    if (n_scalars % 3 != 0) throw Error("DoF set size must be a multiple of 3");
+    Context& c = ctx->c;
+    const double* old = c.dof_sets[set].host;
+    c.dof_sets[set].host = host;
+    c.dof_sets[set].n = n_scalars;
+    for (auto& a : c.arrays)
+        if (a.dof_set == set) {
+            a.host = host;
+            a.n_items = n_scalars / a.stride;
+        }
+    (void)old;
+    c.ndofs = -1;  // force re-upload of the DoF vector
+    c.layout_dirty = true;
+    API_END(0)
+}
+
+int mistark_array(mistark_ctx* ctx, const double* host, int64_t n_items, int stride)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (stride <= 0) throw Error("bad stride");
+    for (size_t i = 0; i < c.arrays.size(); i++) {
+        if (c.arrays[i].host == host && c.arrays[i].stride == stride) {
+            if (c.arrays[i].n_items != n_items) {
+                c.arrays[i].n_items = n_items;
+                c.arrays[i].need_upload = true;
+                c.layout_dirty = true;
+            }
+            return (int)i;
+        }
+    }
+    c.arrays.emplace_back();
+    Array& a = c.arrays.back();
+    a.host = host;
+    a.n_items = n_items;
+    a.stride = stride;
+    for (size_t s = 0; s < c.dof_sets.size(); s++)
+        if ((const double*)c.dof_sets[s].host == host) {
+            a.dof_set = (int)s;
+            if (c.dof_sets[s].n != n_items * stride) throw Error("array bound on a DoF set must cover the whole set");
+        }
+    c.layout_dirty = true;
+    _ret = (int)c.arrays.size() - 1;
+    API_END(_ret)
+}
+int mistark_array_rebind(mistark_ctx* ctx, int array, const double* host, int64_t n_items)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (array < 0 || array >= (int)c.arrays.size()) throw Error("bad array id");
+    Array& a = c.arrays[array];
+    if (a.dof_set >= 0) throw Error("use mistark_resize_dof_set for DoF arrays");
+    a.host = host;
+    a.n_items = n_items;
+    a.need_upload = true;
+    c.layout_dirty = true;
+    API_END(0)
+}
+static void upload_one(Context& c, Array& a)
+{
+    if (a.dof_set >= 0) {
+        const DofSet& s = c.dof_sets[a.dof_set];
+        if (s.n > 0) MS_CHECK(hipMemcpyAsync(c.u.p + s.offset, s.host, s.n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    } else {
+        const size_t n = (size_t)a.n_items * a.stride;
+        if (n > 0) MS_CHECK(hipMemcpyAsync(a.dev, a.host, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    }
+    a.need_upload = false;
+}
+int mistark_upload(mistark_ctx* ctx, int array)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (c.layout_dirty) {
+        // sizes may have changed: mark and let prepare() do the copy
+        if (array < 0) for (auto& a : c.arrays) a.need_upload = true;
+        else if (array < (int)c.arrays.size()) c.arrays[array].need_upload = true;
+        else throw Error("bad array id");
+        prepare(c);
+        if (array < 0) for (auto& a : c.arrays) upload_one(c, a);
+        else upload_one(c, c.arrays[array]);
+    } else {
+        if (array < 0) for (auto& a : c.arrays) upload_one(c, a);
+        else if (array < (int)c.arrays.size()) upload_one(c, c.arrays[array]);
+        else throw Error("bad array id");
+    }
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    API_END(0)
+}
+static void download_one(Context& c, Array& a)
+{
+    const size_t n = (size_t)a.n_items * a.stride;
+    if (n > 0) MS_CHECK(hipMemcpyAsync(const_cast<double*>(a.host), a.dev, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+}
+int mistark_download(mistark_ctx* ctx, int array)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    if (array < 0) for (auto& a : c.arrays) download_one(c, a);
+    else if (array < (int)c.arrays.size()) download_one(c, c.arrays[array]);
+    else throw Error("bad array id");
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    API_END(0)
+}
+int mistark_array_axpby(mistark_ctx* ctx, int dst, double a, int x, double b, int y)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    const int na = (int)c.arrays.size();
+    if (dst < 0 || dst >= na || x < 0 || x >= na || y >= na) throw Error("bad array id");
+    const int64_t n = c.arrays[dst].n_items * c.arrays[dst].stride;
+    if (c.arrays[x].n_items * c.arrays[x].stride != n || (y >= 0 && c.arrays[y].n_items * c.arrays[y].stride != n)) throw Error("axpby: size mismatch");
+    vec_axpby(c, c.arrays[dst].dev, a, c.arrays[x].dev, b, y >= 0 ? c.arrays[y].dev : nullptr, n);
+    API_END(0)
+}
+int mistark_array_fill(mistark_ctx* ctx, int dst, double value)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    if (dst < 0 || dst >= (int)c.arrays.size()) throw Error("bad array id");
+    vec_fill(c, c.arrays[dst].dev, value, c.arrays[dst].n_items * c.arrays[dst].stride);
+    API_END(0)
+}
+
+int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    const int kind = find_kind(name);
+    if (kind < 0) throw Error(std::string("unknown potential '") + name + "' (no MI355X kernel registered under this name)");
+    if (n_bindings != kind_nbind(kind)) throw Error(std::string("potential '") + name + "': expected " + std::to_string(kind_nbind(kind)) + " bindings, got " + std::to_string(n_bindings));
+    int strides[MAX_BIND];
+    kind_strides(kind, strides);
+    for (int b = 0; b < n_bindings; b++) {
+        if (bindings[b].array < 0 || bindings[b].array >= (int)c.arrays.size()) throw Error(std::string("potential '") + name + "': bad array id in binding " + std::to_string(b));
+        if (bindings[b].stride != strides[b] || c.arrays[bindings[b].array].stride != strides[b])
+            throw Error(std::string("potential '") + name + "': binding " + std::to_string(b) + " must have stride " + std::to_string(strides[b]));
+        if (bindings[b].conn_col >= conn_stride) throw Error(std::string("potential '") + name + "': connectivity column out of range");
+    }
+    if (n_elem < 0 || conn_stride <= 0) throw Error("bad connectivity shape");
+    Potential* P = nullptr;
+    int id = -1;
+    for (size_t i = 0; i < c.pots.size(); i++)
+        if (c.pots[i].name == name) {
+            P = &c.pots[i];
+            id = (int)i;
+        }
+    if (!P) {
+        c.pots.emplace_back();
+        P = &c.pots.back();
+        id = (int)c.pots.size() - 1;
+    }
+    P->name = name;
+    P->kind = kind;
+    P->NB = kind_nb(kind);
+    P->n_elem = n_elem;
+    P->conn_stride = conn_stride;
+    P->conn_host.assign(conn, conn + (size_t)n_elem * conn_stride);
+    P->bindings.assign(bindings, bindings + n_bindings);
+    P->conn_dirty = true;
+    c.layout_dirty = true;
+    _ret = id;
+    API_END(_ret)
+}
+
+int64_t mistark_ndofs(mistark_ctx* ctx)
+{
+    if (!ctx) return -1;
+    int64_t n = 0;
+    for (auto& s : ctx->c.dof_sets) n += s.n;
+    return n;
+}
+int mistark_get_dofs(mistark_ctx* ctx, double* u_host)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    MS_CHECK(hipMemcpyAsync(u_host, c.u.p, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    API_END(0)
+}
+int mistark_set_dofs(mistark_ctx* ctx, const double* u_host)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    MS_CHECK(hipMemcpyAsync(c.u.p, u_host, (size_t)c.ndofs * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    API_END(0)
+}
+int mistark_dofs_to_host_arrays(mistark_ctx* ctx)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    for (auto& s : c.dof_sets)
+        if (s.n > 0) MS_CHECK(hipMemcpyAsync(s.host, c.u.p + s.offset, s.n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    API_END(0)
+}
+int mistark_dofs_from_host_arrays(mistark_ctx* ctx)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    for (auto& s : c.dof_sets)
+        if (s.n > 0) MS_CHECK(hipMemcpyAsync(c.u.p + s.offset, s.host, s.n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    API_END(0)
+}
+
+int mistark_eval(mistark_ctx* ctx, int mode, double* E, double* grad_host)
+{
+    API_BEGIN
+    if (mode < 0 || mode > 2) throw Error("bad eval mode");
+    eval(ctx->c, mode, E, grad_host);
+    API_END(0)
+}
+int mistark_get_element_hessians(mistark_ctx* ctx, int potential, double* values, int32_t* block_rows, int32_t* nb_out)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
+    if (!c.have_hessians) throw Error("no element Hessians");
+    Potential& P = c.pots[potential];
+    const int NB = P.NB, n = 3 * NB;
+    if (nb_out) *nb_out = NB;
+    if (values && P.n_elem > 0) {
+        std::vector<double> tmp((size_t)P.n_elem * n * n);
+        MS_CHECK(hipMemcpyAsync(tmp.data(), c.elemH.p + P.h_off, tmp.size() * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+        for (int e = 0; e < P.n_elem; e++)
+            for (int a = 0; a < NB; a++)
+                for (int b = 0; b < NB; b++)
+                    for (int i = 0; i < 3; i++)
+                        for (int j = 0; j < 3; j++)
+                            values[((size_t)e * n + 3 * a + i) * n + 3 * b + j] = tmp[(size_t)e * n * n + (a * NB + b) * 9 + i * 3 + j];
+    }
+    if (block_rows) {
+        for (int e = 0; e < P.n_elem; e++)
+            for (int k = 0; k < NB; k++) block_rows[(size_t)e * NB + k] = P.args.dof_row_off[k] + P.conn_host[(size_t)e * P.conn_stride + P.args.dof_col[k]];
+    }
+    API_END(0)
+}
+int mistark_get_element_energies(mistark_ctx* ctx, int potential, double* values)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
+    Potential& P = c.pots[potential];
+    if (P.n_elem > 0) {
+        MS_CHECK(hipMemcpyAsync(values, c.elemE.p + P.e_off, (size_t)P.n_elem * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+    }
+    API_END(0)
+}
+
+int mistark_project(mistark_ctx* ctx, double eps, int mirroring, const uint8_t* active_blocks, int64_t* n_projected_now, int64_t* n_changed_now)
+{
+    API_BEGIN
+    project(ctx->c, eps, mirroring, active_blocks, false, 0.0, nullptr, n_projected_now, n_changed_now);
+    API_END(0)
+}
+int mistark_project_by_gradient(mistark_ctx* ctx, double eps, int mirroring, double threshold, int* all_active_out, int64_t* n_projected_now)
+{
+    API_BEGIN
+    project(ctx->c, eps, mirroring, nullptr, true, threshold, all_active_out, n_projected_now, nullptr);
+    API_END(0)
+}
+int mistark_assemble(mistark_ctx* ctx)
+{
+    API_BEGIN
+    assemble(ctx->c);
+    build_preconditioner(ctx->c);
+    MS_CHECK(hipStreamSynchronize(ctx->c.stream));
+    API_END(0)
+}
+int mistark_get_bsr(mistark_ctx* ctx, int64_t* n_block_rows, int64_t* nnzb, int64_t* row_ptr, int32_t* cols, float* vals)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    if (n_block_rows) *n_block_rows = c.nbr;
+    if (nnzb) *nnzb = c.nnzb;
+    if (row_ptr) MS_CHECK(hipMemcpyAsync(row_ptr, c.row_ptr.p, ((size_t)c.nbr + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
+    std::vector<uint32_t> cw;
+    std::vector<float> tv;
+    if (cols) {
+        cw.resize((size_t)c.ntiles * 64);
+        MS_CHECK(hipMemcpyAsync(cw.data(), c.colw.p, cw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+    }
+    if (vals) {
+        if (!c.have_matrix) throw Error("matrix not assembled");
+        tv.resize((size_t)c.ntiles * 576);
+        MS_CHECK(hipMemcpyAsync(tv.data(), c.vals.p, tv.size() * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    }
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    if (cols)
+        for (int64_t s = 0; s < c.nnzb; s++) cols[s] = (int32_t)(cw[s] & 0x7fffffffu);
+    if (vals)
+        for (int64_t s = 0; s < c.nnzb; s++) {
+            const size_t base = (size_t)(s >> 6) * 576;
+            const size_t lane = (size_t)(s & 63);
+            for (int k = 0; k < 9; k++) {
+                const size_t idx = k < 4 ? base + lane * 4 + k : (k < 8 ? base + 256 + lane * 4 + (k - 4) : base + 512 + lane);
+                vals[(size_t)s * 9 + k] = tv[idx];
+            }
+        }
+    API_END(0)
+}
+int mistark_spmv(mistark_ctx* ctx, const double* x_host, double* y_host)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (!c.have_matrix) throw Error("matrix not assembled");
+    MS_CHECK(hipMemcpyAsync(c.tmp_a.p, x_host, (size_t)c.ndofs * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    spmv_device(c, c.tmp_a.p, c.tmp_b.p, nullptr, nullptr, true);
+    MS_CHECK(hipMemcpyAsync(y_host, c.tmp_b.p, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    API_END(0)
+}
+int mistark_apply_preconditioner(mistark_ctx* ctx, const double* x_host, double* z_host)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (!c.have_matrix) throw Error("matrix not assembled");
+    build_preconditioner(c);
+    // z = M^-1 x on the host from the device-built float inverse (parity probe only; the solver applies it on the device)
+    std::vector<float> d((size_t)c.nbr * 9);
+    MS_CHECK(hipMemcpyAsync(d.data(), c.dinv.p, d.size() * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    for (int64_t r = 0; r < c.nbr; r++)
+        for (int i = 0; i < 3; i++) {
+            double s = 0.0;
+            for (int j = 0; j < 3; j++) s += (double)d[9 * r + 3 * i + j] * x_host[3 * r + j];
+            z_host[3 * r + i] = s;
+        }
+    API_END(0)
+}
+
+int mistark_pcg(mistark_ctx* ctx, double abs_tol, double rel_tol, int max_iter, int stop_on_indefiniteness, double* du_host, mistark_pcg_info* info)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    vec_neg(c, c.tmp_a.p, c.grad.p, c.ndofs);
+    pcg(c, c.tmp_a.p, abs_tol, rel_tol, max_iter, stop_on_indefiniteness, info);
+    if (du_host) {
+        MS_CHECK(hipMemcpyAsync(du_host, c.du.p, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+    }
+    API_END(0)
+}
+int mistark_pcg_rhs(mistark_ctx* ctx, const double* rhs_host, double abs_tol, double rel_tol, int max_iter, int stop_on_indefiniteness, double* x_host, mistark_pcg_info* info)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    MS_CHECK(hipMemcpyAsync(c.tmp_a.p, rhs_host, (size_t)c.ndofs * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    pcg(c, c.tmp_a.p, abs_tol, rel_tol, max_iter, stop_on_indefiniteness, info);
+    if (x_host) {
+        MS_CHECK(hipMemcpyAsync(x_host, c.du.p, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+    }
+    API_END(0)
+}
+
+void mistark_newton_default_settings(mistark_newton_settings* s)
+{
+    if (!s) return;
+    // symx::NewtonSettings defaults (solver_utils.h:173-259) with STARK's overrides (stark/src/core/Settings.cpp:43-50)
+    s->max_iterations = 2147483647;
+    s->min_iterations = 0;
+    s->residual_tolerance_abs = 1e-6;
+    s->residual_tolerance_rel = 0.0;
+    s->step_tolerance = 1e-3;
+    s->max_iterations_as_success = 0;
+    s->step_cap = 1e300 * 1e300;  // +inf
+    s->enable_armijo_backtracking = 1;
+    s->line_search_armijo_beta = 1e-4;
+    s->max_backtracking_armijo_iterations = 20;
+    s->max_backtracking_invalid_state_iterations = 8;
+    s->projection_mode = MISTARK_PROJ_PROGRESSIVE;
+    s->projection_eps = 1e-10;
+    s->project_to_pd_use_mirroring = 0;
+    s->project_on_demand_countdown = 4;
+    s->ppn_tightening_factor = 0.5;
+    s->ppn_release_factor = 2.0;
+    s->cg_max_iterations = 10000;
+    s->cg_abs_tolerance = 1e-12;
+    s->cg_rel_tolerance = 1e-4;
+    s->cg_stop_on_indefiniteness = 1;
+    s->bailout_residual = 1e-10;
+}
+
+int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settings, const mistark_newton_callbacks* callbacks, mistark_newton_stats* stats)
+{
+    API_BEGIN
+    mistark_newton_settings s;
+    if (settings) s = *settings;
+    else mistark_newton_default_settings(&s);
+    mistark_newton_stats st{};
+    const int r = newton_solve(ctx->c, s, callbacks, st);
+    if (stats) *stats = st;
+    return r;
+    API_END(0)
+}
+
+int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n, double* bytes_per_launch)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (avg_ms) *avg_ms = c.spmv_n > 0 ? c.spmv_ms_sum / (double)c.spmv_n : 0.0;
+    if (n) *n = c.spmv_n;
+    // algorithmic bytes of one SpMV: nnzb*(9*4+4) + (nbr+1)*8 + 2*(3*nbr)*8
+    if (bytes_per_launch) *bytes_per_launch = (double)c.nnzb * 40.0 + ((double)c.nbr + 1.0) * 8.0 + 48.0 * (double)c.nbr;
+    if (reset) {
+        c.spmv_ms_sum = 0.0;
+        c.spmv_n = 0;
+        c.time_spmv = reset > 0;
+    }
+    API_END(0)
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// engine.hpp — internal declarations of the MI355X engine (not part of the C ABI; see include/mistark.h).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/mistark.h"
+
+namespace mistark {
+
+struct Error : std::runtime_error
+{
+    using std::runtime_error::runtime_error;
+};
+
+#define MS_CHECK(expr)                                                                                                   \
+    do {                                                                                                                 \
+        hipError_t _e = (expr);                                                                                          \
+        if (_e != hipSuccess) {                                                                                          \
+            throw ::mistark::Error(std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+        }                                                                                                                \
+    } while (0)
+
+// Growable device buffer
+template <class T>
+struct DevBuf
+{
+    T* p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), cap(o.cap)
+    {
+        o.p = nullptr;
+        o.cap = 0;
+    }
+    DevBuf& operator=(DevBuf&& o) noexcept
+    {
+        if (this != &o) {
+            if (p) (void)hipFree(p);
+            p = o.p;
+            cap = o.cap;
+            o.p = nullptr;
+            o.cap = 0;
+        }
+        return *this;
+    }
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    void ensure(size_t n)
+    {
+        if (n <= cap) return;
+        if (p) MS_CHECK(hipFree(p));
+        p = nullptr;
+        size_t want = n + n / 8 + 64;
+        MS_CHECK(hipMalloc((void**)&p, want * sizeof(T)));
+        cap = want;
+    }
+};
+
+constexpr int MAX_BIND = 24;
+constexpr int MAX_NB = 5;
+
+// Kernel argument block of one potential (device pointers)
+struct PotArgs
+{
+    const double* arr[MAX_BIND];
+    int conn_col[MAX_BIND];
+    const int32_t* conn;
+    int conn_stride;
+    int n_elem;
+    int dof_col[MAX_NB];      // connectivity column providing the node of local DoF block k
+    int dof_row_off[MAX_NB];  // first block row of the DoF set of local DoF block k
+};
+
+struct DofSet
+{
+    std::string label;
+    double* host = nullptr;
+    int64_t n = 0;       // scalars
+    int64_t offset = 0;  // first scalar in the flat DoF vector
+};
+
+struct Array
+{
+    const double* host = nullptr;
+    int64_t n_items = 0;
+    int stride = 0;
+    int dof_set = -1;         // >= 0: view into the DoF vector
+    DevBuf<double> own;       // storage when not a view
+    double* dev = nullptr;    // resolved at prepare()
+    bool need_upload = true;
+};
+
+struct Potential
+{
+    std::string name;
+    int kind = -1;
+    int NB = 0;
+    int n_elem = 0;
+    int conn_stride = 0;
+    std::vector<int32_t> conn_host;
+    DevBuf<int32_t> conn;
+    std::vector<mistark_binding> bindings;
+    PotArgs args{};
+    size_t e_off = 0;   // first element in the element-energy pool
+    size_t h_off = 0;   // first double in the element-Hessian pool
+    size_t k_off = 0;   // first key in the pattern key list
+    bool conn_dirty = true;
+};
+
+struct PcgCtrl
+{
+    int done;
+    int converged;
+    int indef;
+    int n_iter;
+    double error;
+    double bb;
+    double rz[2];
+};
+
+struct Context
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+
+    std::vector<DofSet> dof_sets;
+    std::vector<Array> arrays;
+    std::vector<Potential> pots;
+    bool layout_dirty = true;   // DoF sizes / arrays / potentials changed -> prepare()
+    bool pattern_dirty = true;  // connectivity changed -> rebuild sparsity pattern
+
+    int64_t ndofs = 0, nbr = 0;
+    DevBuf<double> u, grad, du, r, z, p, q, tmp_a, tmp_b;
+    size_t n_elem_total = 0, hess_total = 0;
+    DevBuf<double> elemE, elemH;
+    DevBuf<uint8_t> is_projected, active_blocks;
+    bool have_hessians = false;
+
+    // sparsity pattern
+    size_t n_keys = 0;
+    DevBuf<uint64_t> keys, keys_alt;
+    DevBuf<uint32_t> kidx, kidx_alt;
+    DevBuf<uint32_t> slot_of_src;  // per element block -> BSR slot
+    DevBuf<uint32_t> scan;
+    DevBuf<uint8_t> cub_tmp;
+    int64_t nnzb = 0, ntiles = 0;
+    DevBuf<uint32_t> colw;          // bit31 = last block of its row, bits 0..30 = block column
+    DevBuf<int32_t> tile_first_row, diag_slot, row_cnt;
+    DevBuf<int64_t> row_ptr;
+    DevBuf<float> vals;             // tiles of 64 blocks: float4 q0[64], float4 q1[64], float s[64]
+    DevBuf<float> dinv;             // 9 floats per block row
+    bool have_matrix = false;
+
+    // reductions / PCG
+    DevBuf<double> partials;        // 4 x MAX_PARTIALS
+    DevBuf<PcgCtrl> ctrl;
+    DevBuf<int64_t> counters;
+    double* h_scratch = nullptr;    // pinned host scratch
+    size_t h_scratch_n = 0;
+
+    // SpMV timing
+    bool time_spmv = false;
+    std::vector<hipEvent_t> ev;
+    double spmv_ms_sum = 0.0;
+    int64_t spmv_n = 0;
+
+    // statistics of the last evaluation
+    int64_t n_projected_total = 0;
+
+    ~Context();
+};
+
+// host-side kernels launchers (kernels.hip)
+void prepare(Context& c);
+void eval(Context& c, int mode, double* E, double* grad_host);
+void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active,
+             int64_t* n_projected_now, int64_t* n_changed_now);
+void assemble(Context& c);
+void build_preconditioner(Context& c);
+void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed);
+void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info);
+double reduce_max_abs(Context& c, const double* v, int64_t n);
+double reduce_dot(Context& c, const double* a, const double* b, int64_t n);
+void vec_axpby(Context& c, double* dst, double a, const double* x, double b, const double* y, int64_t n);
+void vec_fill(Context& c, double* dst, double v, int64_t n);
+void vec_neg(Context& c, double* dst, const double* x, int64_t n);
+int find_kind(const char* name);
+int kind_nb(int kind);
+int kind_nbind(int kind);
+void kind_strides(int kind, int* out);
+void kind_dof_bindings(int kind, int* out);
+const char* kind_name(int kind);
+int n_kinds();
+
+int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_newton_callbacks* cb, mistark_newton_stats& st);
+
+}  // namespace mistark
+
+struct mistark_ctx
+{
+    mistark::Context c;
+};

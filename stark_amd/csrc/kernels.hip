@@ -1,0 +1,1043 @@
+// kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the per-Newton-step hot path and their launchers.
+//
+//   element evaluation   : lane-per-(i,j) hyper-dual evaluation of the energy expressions (energies.hpp)
+//   pattern build        : (block row, block col) keys -> radix sort -> unique -> 64-block tiles
+//   assembly             : element 3x3 blocks -> float BSR tiles (float atomics), block-Jacobi inverse
+//   SpMV                 : one wavefront per 64-block tile, coalesced 16-B loads, in-wave segmented reduction
+//   PCG                  : 3 fused kernels per iteration, device-resident convergence control
+//   PSD projection       : per-element cyclic Jacobi eigen-decomposition
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "engine.hpp"
+#include "registry.hpp"
+
+namespace mistark {
+
+constexpr int BLOCK = 256;
+constexpr int MAX_PARTIALS = 1024;   // max grid of any kernel that emits per-block partial sums
+constexpr int VEC_GRID = 512;
+
+static inline int grid_for(int64_t n, int per_block = BLOCK, int cap = 1 << 30)
+{
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ======================================================================================================================
+// Potential registry
+// ======================================================================================================================
+struct KindInfo
+{
+    const char* name;
+    int NB, NBIND, NIN;
+    int strides[MAX_BIND];
+    int dofb[MAX_NB];
+};
+static std::vector<KindInfo> make_kinds()
+{
+    std::vector<KindInfo> v;
+#define X(En)                                                             \
+    {                                                                     \
+        KindInfo k{};                                                     \
+        k.name = En::name;                                                \
+        k.NB = En::NB;                                                    \
+        k.NBIND = En::Layout::NBIND;                                      \
+        k.NIN = En::Layout::NIN;                                          \
+        static_assert(En::Layout::NBIND <= MAX_BIND, "too many bindings"); \
+        static_assert(En::NB <= MAX_NB, "too many DoF blocks");           \
+        En::Layout::strides(k.strides);                                   \
+        for (int i = 0; i < En::NB; i++) k.dofb[i] = En::dof_binding[i];  \
+        v.push_back(k);                                                   \
+    }
+    MISTARK_FOR_EACH_ENERGY(X)
+#undef X
+    return v;
+}
+static const std::vector<KindInfo>& kinds()
+{
+    static const std::vector<KindInfo> k = make_kinds();
+    return k;
+}
+int n_kinds() { return (int)kinds().size(); }
+const char* kind_name(int kind) { return kinds()[kind].name; }
+int find_kind(const char* name)
+{
+    for (int i = 0; i < n_kinds(); i++)
+        if (std::strcmp(kinds()[i].name, name) == 0) return i;
+    return -1;
+}
+int kind_nb(int kind) { return kinds()[kind].NB; }
+int kind_nbind(int kind) { return kinds()[kind].NBIND; }
+void kind_strides(int kind, int* out) { std::memcpy(out, kinds()[kind].strides, sizeof(int) * kinds()[kind].NBIND); }
+void kind_dof_bindings(int kind, int* out) { std::memcpy(out, kinds()[kind].dofb, sizeof(int) * kinds()[kind].NB); }
+
+// ======================================================================================================================
+// Element evaluation
+// ======================================================================================================================
+template <class En>
+__device__ __forceinline__ void gather_inputs(const PotArgs& a, int e, double* in)
+{
+    const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
+    En::Layout::for_each([&](int b, int S, int o) {
+        const int col = a.conn_col[b];
+        const size_t idx = col < 0 ? 0 : (size_t)ce[col];
+        const double* src = a.arr[b] + idx * S;
+#pragma unroll
+        for (int c = 0; c < S; c++) in[o + c] = src[c];
+    });
+}
+
+// Energy only: one lane per element
+template <class En>
+__global__ __launch_bounds__(BLOCK) void k_eval_p(PotArgs a, double* __restrict__ elemE)
+{
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= a.n_elem) return;
+    double in[En::Layout::NIN];
+    gather_inputs<En>(a, e, in);
+    Loader<double> L{in};
+    elemE[e] = En::energy(L);
+}
+
+// Energy + gradient + Hessian: one lane per (element, i<=j) pair of local DoFs.
+// Element Hessians are stored block-major: H[e][a][b][3][3] (a, b local DoF blocks) so that assembly reads 72 contiguous bytes.
+template <class En, bool STORE_H>
+__global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
+{
+    constexpr int NB = En::NB, n = 3 * NB, NP = n * (n + 1) / 2;
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (long long)a.n_elem * NP) return;
+    const int e = (int)(t / NP);
+    int rem = (int)(t - (long long)e * NP);
+    const bool first = rem == 0;
+    int i = 0;
+    while (rem >= n - i) {
+        rem -= n - i;
+        i++;
+    }
+    const int j = i + rem;
+    if (!STORE_H && i != j) return;
+    double in[En::Layout::NIN];
+    gather_inputs<En>(a, e, in);
+    Loader<HDual> L{in, i, j};
+    const HDual r = En::energy(L);
+    const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
+    if (STORE_H) {
+        double* H = elemH + (size_t)e * n * n;
+        H[(ba * NB + bb) * 9 + ii * 3 + jj] = r.ab;
+        H[(bb * NB + ba) * 9 + jj * 3 + ii] = r.ab;
+    }
+    if (i == j) {
+        const int row = a.dof_row_off[ba] + a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];
+        atomicAdd(&grad[3 * (size_t)row + ii], r.a);
+    }
+    if (first) elemE[e] = r.v;
+}
+
+template <class En>
+static void launch_eval(Context& c, Potential& P, int mode)
+{
+    if (P.n_elem == 0) return;
+    constexpr int n = 3 * En::NB, NP = n * (n + 1) / 2;
+    double* E = c.elemE.p + P.e_off;
+    if (mode == MISTARK_EVAL_P) {
+        hipLaunchKernelGGL((k_eval_p<En>), dim3(grid_for(P.n_elem)), dim3(BLOCK), 0, c.stream, P.args, E);
+    } else if (mode == MISTARK_EVAL_P_G) {
+        hipLaunchKernelGGL((k_eval_pgh<En, false>), dim3(grid_for((int64_t)P.n_elem * NP)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
+    } else {
+        hipLaunchKernelGGL((k_eval_pgh<En, true>), dim3(grid_for((int64_t)P.n_elem * NP)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
+    }
+}
+
+static void launch_eval_kind(Context& c, Potential& P, int mode)
+{
+    int k = 0;
+#define X(En)                               \
+    if (P.kind == k) { launch_eval<En>(c, P, mode); return; } \
+    k++;
+    MISTARK_FOR_EACH_ENERGY(X)
+#undef X
+    throw Error("unknown potential kind");
+}
+
+// ======================================================================================================================
+// Reductions and vector helpers
+// ======================================================================================================================
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_down(v, d, 64));
+    return v;
+}
+// Sum over the 256 threads of a block; result valid in every thread. Deterministic.
+__device__ __forceinline__ double block_sum(double v, double* sm /*[4]*/)
+{
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ double block_max(double v, double* sm)
+{
+    v = wave_max(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[w] = v;
+    __syncthreads();
+    return fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
+}
+// Deterministic sum of `n` per-block partials, computed redundantly by every block that needs the scalar.
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int n, double* sm)
+{
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += BLOCK) s += part[i];
+    return block_sum(s, sm);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_sum(const double* __restrict__ v, int64_t n, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) s += v[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(BLOCK) void k_dot(const double* __restrict__ a, const double* __restrict__ b, int64_t n, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) s += a[i] * b[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(BLOCK) void k_max_abs(const double* __restrict__ v, int64_t n, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) s = fmax(s, fabs(v[i]));
+    s = block_max(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(BLOCK) void k_axpby(double* __restrict__ dst, double a, const double* __restrict__ x, double b, const double* __restrict__ y, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = a * x[i] + (y ? b * y[i] : 0.0);
+}
+__global__ __launch_bounds__(BLOCK) void k_fill(double* __restrict__ dst, double v, int64_t n)
+{
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = v;
+}
+
+static double* host_scratch(Context& c, size_t n)
+{
+    if (c.h_scratch_n < n) {
+        if (c.h_scratch) (void)hipHostFree(c.h_scratch);
+        MS_CHECK(hipHostMalloc((void**)&c.h_scratch, std::max<size_t>(n, 4096) * sizeof(double)));
+        c.h_scratch_n = std::max<size_t>(n, 4096);
+    }
+    return c.h_scratch;
+}
+static void fetch_partials(Context& c, int n, double* out_host, const double* part_dev)
+{
+    MS_CHECK(hipMemcpyAsync(out_host, part_dev, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+}
+double reduce_max_abs(Context& c, const double* v, int64_t n)
+{
+    const int g = grid_for(n, BLOCK, VEC_GRID);
+    hipLaunchKernelGGL(k_max_abs, dim3(g), dim3(BLOCK), 0, c.stream, v, n, c.partials.p);
+    double* h = host_scratch(c, MAX_PARTIALS);
+    fetch_partials(c, g, h, c.partials.p);
+    double m = 0.0;
+    for (int i = 0; i < g; i++) m = std::max(m, h[i]);
+    return m;
+}
+double reduce_dot(Context& c, const double* a, const double* b, int64_t n)
+{
+    const int g = grid_for(n, BLOCK, VEC_GRID);
+    hipLaunchKernelGGL(k_dot, dim3(g), dim3(BLOCK), 0, c.stream, a, b, n, c.partials.p);
+    double* h = host_scratch(c, MAX_PARTIALS);
+    fetch_partials(c, g, h, c.partials.p);
+    double s = 0.0;
+    for (int i = 0; i < g; i++) s += h[i];
+    return s;
+}
+static double reduce_sum(Context& c, const double* v, int64_t n)
+{
+    const int g = grid_for(n, BLOCK, VEC_GRID);
+    hipLaunchKernelGGL(k_sum, dim3(g), dim3(BLOCK), 0, c.stream, v, n, c.partials.p);
+    double* h = host_scratch(c, MAX_PARTIALS);
+    fetch_partials(c, g, h, c.partials.p);
+    double s = 0.0;
+    for (int i = 0; i < g; i++) s += h[i];
+    return s;
+}
+void vec_axpby(Context& c, double* dst, double a, const double* x, double b, const double* y, int64_t n)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_axpby, dim3(grid_for(n, BLOCK, 2048)), dim3(BLOCK), 0, c.stream, dst, a, x, b, y, n);
+}
+void vec_fill(Context& c, double* dst, double v, int64_t n)
+{
+    if (n == 0) return;
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(n, BLOCK, 2048)), dim3(BLOCK), 0, c.stream, dst, v, n);
+}
+void vec_neg(Context& c, double* dst, const double* x, int64_t n) { vec_axpby(c, dst, -1.0, x, 0.0, nullptr, n); }
+
+// ======================================================================================================================
+// prepare(): DoF layout, device arrays, kernel argument blocks, sparsity pattern
+// ======================================================================================================================
+__global__ __launch_bounds__(BLOCK) void k_keys(PotArgs a, int NB, uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t k_off)
+{
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    const int nn = NB * NB;
+    if (t >= (long long)a.n_elem * nn) return;
+    const int e = (int)(t / nn);
+    const int ab = (int)(t - (long long)e * nn);
+    const int ba = ab / NB, bb = ab - ba * NB;
+    const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
+    const uint64_t ra = a.dof_row_off[ba] + ce[a.dof_col[ba]];
+    const uint64_t rb = a.dof_row_off[bb] + ce[a.dof_col[bb]];
+    keys[k_off + t] = ra * nbr + rb;
+    idx[k_off + t] = k_off + (uint32_t)t;
+}
+__global__ __launch_bounds__(BLOCK) void k_diag_keys(uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t k_off)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= nbr) return;
+    keys[k_off + r] = r * nbr + r;
+    idx[k_off + r] = k_off + (uint32_t)r;
+}
+__global__ __launch_bounds__(BLOCK) void k_heads(const uint64_t* __restrict__ keys, size_t n, uint32_t* __restrict__ head)
+{
+    const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    head[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1u : 0u;
+}
+// scan = inclusive prefix of heads. slot = scan-1.
+__global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ scan, size_t n,
+                                                 uint64_t nbr, uint32_t* __restrict__ slot_of_src, uint32_t* __restrict__ colw, int32_t* __restrict__ row_cnt,
+                                                 int32_t* __restrict__ diag_slot, int32_t* __restrict__ tile_first_row)
+{
+    const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t slot = scan[k] - 1;
+    slot_of_src[idx[k]] = slot;
+    const bool head = (k == 0 || keys[k] != keys[k - 1]);
+    if (head) {
+        const uint64_t key = keys[k];
+        const uint32_t row = (uint32_t)(key / nbr), col = (uint32_t)(key % nbr);
+        // last block of its row <=> the next distinct key belongs to another row
+        size_t k2 = k + 1;
+        while (k2 < n && keys[k2] == key) k2++;
+        const bool tail = (k2 >= n) || (uint32_t)(keys[k2] / nbr) != row;
+        colw[slot] = col | (tail ? 0x80000000u : 0u);
+        atomicAdd(&row_cnt[row], 1);
+        if (row == col) diag_slot[row] = (int32_t)slot;
+        if ((slot & 63u) == 0) tile_first_row[slot >> 6] = (int32_t)row;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_rowptr_from_excl(const int32_t* __restrict__ excl, const int32_t* __restrict__ cnt, int64_t nbr, int64_t* __restrict__ row_ptr)
+{
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r > nbr) return;
+    row_ptr[r] = r == nbr ? (int64_t)excl[nbr - 1] + cnt[nbr - 1] : (int64_t)excl[r];
+}
+
+static void build_pattern(Context& c)
+{
+    size_t nk = 0;
+    for (auto& P : c.pots) {
+        P.k_off = nk;
+        nk += (size_t)P.n_elem * P.NB * P.NB;
+    }
+    const size_t diag_off = nk;
+    nk += (size_t)c.nbr;
+    if (nk >= (1ull << 32)) throw Error("pattern too large for 32-bit source indices");
+    c.n_keys = nk;
+    c.keys.ensure(nk);
+    c.keys_alt.ensure(nk);
+    c.kidx.ensure(nk);
+    c.kidx_alt.ensure(nk);
+    c.slot_of_src.ensure(nk);
+    c.scan.ensure(nk);
+    for (auto& P : c.pots) {
+        if (P.n_elem == 0) continue;
+        hipLaunchKernelGGL(k_keys, dim3(grid_for((int64_t)P.n_elem * P.NB * P.NB)), dim3(BLOCK), 0, c.stream, P.args, P.NB, (uint64_t)c.nbr, c.keys.p, c.kidx.p,
+                           (uint32_t)P.k_off);
+    }
+    hipLaunchKernelGGL(k_diag_keys, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, (uint64_t)c.nbr, c.keys.p, c.kidx.p, (uint32_t)diag_off);
+    // sort (key, source) pairs
+    int bits = 1;
+    while ((1ull << bits) < (uint64_t)c.nbr * (uint64_t)c.nbr && bits < 64) bits++;
+    size_t tmp_bytes = 0;
+    hipcub::DoubleBuffer<uint64_t> dk(c.keys.p, c.keys_alt.p);
+    hipcub::DoubleBuffer<uint32_t> dv(c.kidx.p, c.kidx_alt.p);
+    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dk, dv, (int)nk, 0, bits, c.stream));
+    c.cub_tmp.ensure(tmp_bytes);
+    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(c.cub_tmp.p, tmp_bytes, dk, dv, (int)nk, 0, bits, c.stream));
+    const uint64_t* skeys = dk.Current();
+    const uint32_t* sidx = dv.Current();
+    uint32_t* heads = (uint32_t*)(dv.Current() == c.kidx.p ? c.kidx_alt.p : c.kidx.p);  // the other value buffer is free now
+    hipLaunchKernelGGL(k_heads, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, nk, heads);
+    size_t tmp2 = 0;
+    MS_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp2, heads, c.scan.p, (int)nk, c.stream));
+    c.cub_tmp.ensure(tmp2);
+    MS_CHECK(hipcub::DeviceScan::InclusiveSum(c.cub_tmp.p, tmp2, heads, c.scan.p, (int)nk, c.stream));
+    uint32_t nnzb32 = 0;
+    MS_CHECK(hipMemcpyAsync(&nnzb32, c.scan.p + (nk - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    c.nnzb = nnzb32;
+    c.ntiles = (c.nnzb + 63) / 64;
+    c.colw.ensure((size_t)c.ntiles * 64);
+    c.tile_first_row.ensure((size_t)c.ntiles);
+    c.diag_slot.ensure((size_t)c.nbr);
+    c.row_cnt.ensure((size_t)c.nbr + 1);
+    c.row_ptr.ensure((size_t)c.nbr + 1);
+    c.vals.ensure((size_t)c.ntiles * 576);
+    c.dinv.ensure((size_t)c.nbr * 9);
+    MS_CHECK(hipMemsetAsync(c.row_cnt.p, 0, ((size_t)c.nbr + 1) * sizeof(int32_t), c.stream));
+    MS_CHECK(hipMemsetAsync(c.colw.p, 0, (size_t)c.ntiles * 64 * sizeof(uint32_t), c.stream));
+    hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, c.scan.p, nk, (uint64_t)c.nbr, c.slot_of_src.p, c.colw.p, c.row_cnt.p,
+                       c.diag_slot.p, c.tile_first_row.p);
+    // row_ptr = exclusive scan of the per-row block counts
+    int32_t* excl = (int32_t*)heads;  // reuse
+    size_t tmp3 = 0;
+    MS_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp3, c.row_cnt.p, excl, (int)c.nbr, c.stream));
+    c.cub_tmp.ensure(tmp3);
+    MS_CHECK(hipcub::DeviceScan::ExclusiveSum(c.cub_tmp.p, tmp3, c.row_cnt.p, excl, (int)c.nbr, c.stream));
+    hipLaunchKernelGGL(k_rowptr_from_excl, dim3(grid_for(c.nbr + 1)), dim3(BLOCK), 0, c.stream, excl, c.row_cnt.p, c.nbr, c.row_ptr.p);
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    c.pattern_dirty = false;
+    c.have_matrix = false;
+}
+
+void prepare(Context& c)
+{
+    if (!c.layout_dirty && !c.pattern_dirty) return;
+    if (c.layout_dirty) {
+        // DoF layout
+        int64_t off = 0;
+        for (auto& s : c.dof_sets) {
+            if (s.n % 3 != 0) throw Error("DoF set '" + s.label + "' size is not a multiple of 3");
+            s.offset = off;
+            off += s.n;
+        }
+        const bool resized = off != c.ndofs;
+        c.ndofs = off;
+        c.nbr = off / 3;
+        if (c.ndofs == 0) throw Error("no degrees of freedom");
+        const size_t n = (size_t)c.ndofs;
+        c.u.ensure(n); c.grad.ensure(n); c.du.ensure(n); c.r.ensure(n); c.z.ensure(n); c.p.ensure(n); c.q.ensure(n); c.tmp_a.ensure(n); c.tmp_b.ensure(n);
+        c.partials.ensure(4 * MAX_PARTIALS);
+        c.ctrl.ensure(1);
+        c.counters.ensure(8);
+        c.active_blocks.ensure((size_t)c.nbr);
+        if (resized) {
+            for (auto& s : c.dof_sets)
+                if (s.n > 0) MS_CHECK(hipMemcpyAsync(c.u.p + s.offset, s.host, s.n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+            c.pattern_dirty = true;
+        }
+        // arrays
+        for (auto& a : c.arrays) {
+            if (a.dof_set >= 0) {
+                a.dev = c.u.p + c.dof_sets[a.dof_set].offset;
+                a.need_upload = false;
+            } else {
+                const size_t na = (size_t)a.n_items * a.stride;
+                a.own.ensure(std::max<size_t>(na, 1));
+                a.dev = a.own.p;
+                if (a.need_upload && na > 0) {
+                    MS_CHECK(hipMemcpyAsync(a.dev, a.host, na * sizeof(double), hipMemcpyHostToDevice, c.stream));
+                    a.need_upload = false;
+                }
+            }
+        }
+        // potentials
+        size_t e_off = 0, h_off = 0;
+        for (auto& P : c.pots) {
+            P.e_off = e_off;
+            P.h_off = h_off;
+            e_off += (size_t)P.n_elem;
+            h_off += (size_t)P.n_elem * 9 * P.NB * P.NB;
+            if (P.conn_dirty) {
+                P.conn.ensure(std::max<size_t>(P.conn_host.size(), 1));
+                if (!P.conn_host.empty())
+                    MS_CHECK(hipMemcpyAsync(P.conn.p, P.conn_host.data(), P.conn_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+                P.conn_dirty = false;
+                c.pattern_dirty = true;
+            }
+            PotArgs& A = P.args;
+            std::memset(&A, 0, sizeof(A));
+            A.conn = P.conn.p;
+            A.conn_stride = P.conn_stride;
+            A.n_elem = P.n_elem;
+            int dofb[MAX_NB];
+            kind_dof_bindings(P.kind, dofb);
+            for (size_t b = 0; b < P.bindings.size(); b++) {
+                const Array& arr = c.arrays[P.bindings[b].array];
+                A.arr[b] = arr.dev;
+                A.conn_col[b] = P.bindings[b].conn_col;
+            }
+            for (int k = 0; k < P.NB; k++) {
+                const mistark_binding& bd = P.bindings[dofb[k]];
+                const Array& arr = c.arrays[bd.array];
+                if (arr.dof_set < 0) throw Error("potential '" + P.name + "': binding " + std::to_string(dofb[k]) + " must be a DoF array");
+                A.dof_col[k] = bd.conn_col;
+                A.dof_row_off[k] = (int)(c.dof_sets[arr.dof_set].offset / 3);
+            }
+        }
+        c.n_elem_total = e_off;
+        c.hess_total = h_off;
+        c.elemE.ensure(std::max<size_t>(e_off, 1));
+        c.elemH.ensure(std::max<size_t>(h_off, 1));
+        c.is_projected.ensure(std::max<size_t>(e_off, 1));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+        c.layout_dirty = false;
+        c.have_hessians = false;
+    }
+    if (c.pattern_dirty) build_pattern(c);
+}
+
+// ======================================================================================================================
+// eval()
+// ======================================================================================================================
+void eval(Context& c, int mode, double* E, double* grad_host)
+{
+    prepare(c);
+    if (mode != MISTARK_EVAL_P) MS_CHECK(hipMemsetAsync(c.grad.p, 0, (size_t)c.ndofs * sizeof(double), c.stream));
+    for (auto& P : c.pots) launch_eval_kind(c, P, mode);
+    if (mode == MISTARK_EVAL_P_G_H) {
+        MS_CHECK(hipMemsetAsync(c.is_projected.p, 0, c.n_elem_total, c.stream));
+        c.have_hessians = true;
+        c.n_projected_total = 0;
+    }
+    const double e = c.n_elem_total ? reduce_sum(c, c.elemE.p, (int64_t)c.n_elem_total) : 0.0;
+    if (E) *E = e;
+    if (grad_host && mode != MISTARK_EVAL_P) {
+        MS_CHECK(hipMemcpyAsync(grad_host, c.grad.p, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+    }
+}
+
+// ======================================================================================================================
+// PSD projection: cyclic Jacobi eigen-decomposition per element (n = 3 NB <= 15)
+// ======================================================================================================================
+template <int NB>
+__global__ __launch_bounds__(64) void k_project(double* __restrict__ elemH, int n_elem, PotArgs a, uint8_t* __restrict__ is_projected, const uint8_t* __restrict__ active_blocks,
+                                                double eps, int mirroring, int64_t* __restrict__ counters)
+{
+    constexpr int n = 3 * NB;
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    if (e >= n_elem) return;
+    if (is_projected[e]) return;
+    if (active_blocks) {
+        bool touch = false;
+        const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
+        for (int k = 0; k < NB; k++) touch = touch || active_blocks[a.dof_row_off[k] + ce[a.dof_col[k]]];
+        if (!touch) return;
+    }
+    is_projected[e] = 1;
+    atomicAdd((unsigned long long*)&counters[0], 1ull);
+    double A[n][n], V[n][n];
+    double* H = elemH + (size_t)e * n * n;
+    for (int ba = 0; ba < NB; ba++)
+        for (int bb = 0; bb < NB; bb++)
+            for (int ii = 0; ii < 3; ii++)
+                for (int jj = 0; jj < 3; jj++) A[3 * ba + ii][3 * bb + jj] = H[(ba * NB + bb) * 9 + ii * 3 + jj];
+    double fro = 0.0;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            V[i][j] = i == j ? 1.0 : 0.0;
+            fro += A[i][j] * A[i][j];
+        }
+    if (fro == 0.0) {
+        // zero matrix: every eigenvalue (0) is below eps
+    }
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) off += A[p][q] * A[p][q];
+        if (2.0 * off <= 1e-30 * fro) break;
+        for (int p = 0; p < n - 1; p++) {
+            for (int q = p + 1; q < n; q++) {
+                const double apq = A[p][q];
+                if (fabs(apq) < 1e-300) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                for (int k = 0; k < n; k++) {
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = cs * akp - sn * akq;
+                    A[k][q] = sn * akp + cs * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = cs * apk - sn * aqk;
+                    A[q][k] = sn * apk + cs * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = cs * vkp - sn * vkq;
+                    V[k][q] = sn * vkp + cs * vkq;
+                }
+            }
+        }
+    }
+    bool changed = false;
+    double lam[n];
+    for (int i = 0; i < n; i++) {
+        lam[i] = A[i][i];
+        if (lam[i] < eps) {
+            changed = true;
+            lam[i] = mirroring ? -lam[i] : eps;
+        }
+    }
+    if (!changed) return;
+    atomicAdd((unsigned long long*)&counters[1], 1ull);
+    for (int ba = 0; ba < NB; ba++)
+        for (int bb = 0; bb < NB; bb++)
+            for (int ii = 0; ii < 3; ii++)
+                for (int jj = 0; jj < 3; jj++) {
+                    const int i = 3 * ba + ii, j = 3 * bb + jj;
+                    double s = 0.0;
+                    for (int k = 0; k < n; k++) s += V[i][k] * lam[k] * V[j][k];
+                    H[(ba * NB + bb) * 9 + ii * 3 + jj] = s;
+                }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restrict__ grad, int64_t nbr, double thr, uint8_t* __restrict__ active, int64_t* __restrict__ counters)
+{
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= nbr) return;
+    const double m = fmax(fabs(grad[3 * r]), fmax(fabs(grad[3 * r + 1]), fabs(grad[3 * r + 2])));
+    const bool act = m >= thr;
+    active[r] = act ? 1 : 0;
+    if (!act) atomicAdd((unsigned long long*)&counters[2], 1ull);
+}
+
+void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active, int64_t* n_projected_now,
+             int64_t* n_changed_now)
+{
+    if (!c.have_hessians) throw Error("project: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
+    MS_CHECK(hipMemsetAsync(c.counters.p, 0, 8 * sizeof(int64_t), c.stream));
+    const uint8_t* act = nullptr;
+    if (by_gradient) {
+        hipLaunchKernelGGL(k_active_blocks, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.grad.p, c.nbr, threshold, c.active_blocks.p, c.counters.p);
+        act = c.active_blocks.p;
+    } else if (active_host) {
+        MS_CHECK(hipMemcpyAsync(c.active_blocks.p, active_host, (size_t)c.nbr, hipMemcpyHostToDevice, c.stream));
+        act = c.active_blocks.p;
+    }
+    for (auto& P : c.pots) {
+        if (P.n_elem == 0) continue;
+        double* H = c.elemH.p + P.h_off;
+        uint8_t* ip = c.is_projected.p + P.e_off;
+        const dim3 g(grid_for(P.n_elem, 64)), b(64);
+        switch (P.NB) {
+            case 1: hipLaunchKernelGGL((k_project<1>), g, b, 0, c.stream, H, P.n_elem, P.args, ip, act, eps, mirroring, c.counters.p); break;
+            case 2: hipLaunchKernelGGL((k_project<2>), g, b, 0, c.stream, H, P.n_elem, P.args, ip, act, eps, mirroring, c.counters.p); break;
+            case 3: hipLaunchKernelGGL((k_project<3>), g, b, 0, c.stream, H, P.n_elem, P.args, ip, act, eps, mirroring, c.counters.p); break;
+            case 4: hipLaunchKernelGGL((k_project<4>), g, b, 0, c.stream, H, P.n_elem, P.args, ip, act, eps, mirroring, c.counters.p); break;
+            case 5: hipLaunchKernelGGL((k_project<5>), g, b, 0, c.stream, H, P.n_elem, P.args, ip, act, eps, mirroring, c.counters.p); break;
+            default: throw Error("project: unsupported block count");
+        }
+    }
+    int64_t h[8];
+    MS_CHECK(hipMemcpyAsync(h, c.counters.p, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    c.n_projected_total += h[0];
+    if (n_projected_now) *n_projected_now = h[0];
+    if (n_changed_now) *n_changed_now = h[1];
+    if (all_active) *all_active = by_gradient ? (h[2] == 0) : (active_host == nullptr);
+}
+
+// ======================================================================================================================
+// Assembly: element 3x3 blocks -> float BSR tiles
+// ======================================================================================================================
+__device__ __forceinline__ size_t tile_val_index(uint32_t slot, int comp)
+{
+    const size_t base = (size_t)(slot >> 6) * 576;
+    const uint32_t lane = slot & 63u;
+    if (comp < 4) return base + lane * 4 + comp;
+    if (comp < 8) return base + 256 + lane * 4 + (comp - 4);
+    return base + 512 + lane;
+}
+__global__ __launch_bounds__(BLOCK) void k_assemble(const double* __restrict__ elemH, int64_t n_blocks_total, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals)
+{
+    // one lane per (element block, component): 9 consecutive lanes read 72 contiguous bytes
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_blocks_total * 9) return;
+    const int64_t blk = t / 9;
+    const int comp = (int)(t - blk * 9);
+    const uint32_t slot = slot_of_src[blk];
+    atomicAdd(&vals[tile_val_index(slot, comp)], (float)elemH[t]);
+}
+__global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __restrict__ vals, const int32_t* __restrict__ diag_slot, int64_t nbr, float* __restrict__ dinv)
+{
+    // closed-form inverse of a SYMMETRIC 3x3 in float, reciprocal of the determinant through double
+    // (BlockedSparseMatrix.h:1198-1214)
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= nbr) return;
+    const uint32_t s = (uint32_t)diag_slot[r];
+    float m[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) m[k] = vals[tile_val_index(s, k)];
+    const float tmp0 = m[4] * m[8];
+    const float tmp1 = m[5] * m[5];
+    const float tmp2 = m[2] * m[5];
+    const float tmp3 = m[1] * m[1];
+    const float tmp4 = m[2] * m[2];
+    const float det = m[0] * tmp0 - m[0] * tmp1 + 2 * m[1] * tmp2 - m[4] * tmp4 - m[8] * tmp3;
+    const float tmp5 = (float)(1.0 / (double)det);
+    float* o = dinv + 9 * r;
+    o[8] = tmp5 * (m[0] * m[4] - tmp3);
+    o[4] = tmp5 * (m[0] * m[8] - tmp4);
+    o[0] = tmp5 * (tmp0 - tmp1);
+    o[3] = -tmp5 * (m[1] * m[8] - tmp2);
+    o[1] = o[3];
+    o[6] = tmp5 * (m[1] * m[5] - m[4] * m[2]);
+    o[2] = o[6];
+    o[7] = -tmp5 * (m[0] * m[5] - m[1] * m[2]);
+    o[5] = o[7];
+}
+
+void assemble(Context& c)
+{
+    if (!c.have_hessians) throw Error("assemble: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
+    MS_CHECK(hipMemsetAsync(c.vals.p, 0, (size_t)c.ntiles * 576 * sizeof(float), c.stream));
+    const int64_t nblk = (int64_t)(c.hess_total / 9);
+    if (nblk > 0) hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, nblk, c.slot_of_src.p, c.vals.p);
+    c.have_matrix = true;
+}
+void build_preconditioner(Context& c)
+{
+    if (!c.have_matrix) throw Error("preconditioner: matrix not assembled");
+    hipLaunchKernelGGL(k_block_diag_inverse, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.vals.p, c.diag_slot.p, c.nbr, c.dinv.p);
+}
+
+// ======================================================================================================================
+// SpMV  y = A x  (+ optional fused dot  pdot . y  -> per-block partials)
+// One wavefront per tile of 64 consecutive 3x3 blocks (CSR order). Values are laid out per tile as
+// float4 q0[64] | float4 q1[64] | float s[64] so that every load instruction of a wave is a fully coalesced
+// 1 KiB (dwordx4) or 256 B (dword) request: 36 B per block, no padding. Column word: bit 31 marks the last block of a row.
+// Rows are reduced inside the wave by a segmented shuffle scan; rows that straddle tiles are finished with atomics
+// on a pre-zeroed y.
+// ======================================================================================================================
+__global__ __launch_bounds__(BLOCK) void k_spmv(const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int32_t* __restrict__ tile_first_row, int64_t nnzb,
+                                                int64_t ntiles, const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ pdot,
+                                                double* __restrict__ partials, const PcgCtrl* __restrict__ ctrl)
+{
+    if (ctrl && ctrl->done) return;
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double acc = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+        const int64_t s = t * 64 + lane;
+        const bool valid = s < nnzb;
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+        bool tail = false;
+        if (valid) {
+            const uint32_t w = colw[s];
+            tail = (w >> 31) != 0;
+            const size_t col = w & 0x7fffffffu;
+            const float4* q = reinterpret_cast<const float4*>(vals + (size_t)t * 576);
+            const float4 a = q[lane];
+            const float4 b = q[64 + lane];
+            const float cc = vals[(size_t)t * 576 + 512 + lane];
+            const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
+            y0 = (double)a.x * x0 + (double)a.y * x1 + (double)a.z * x2;
+            y1 = (double)a.w * x0 + (double)b.x * x1 + (double)b.y * x2;
+            y2 = (double)b.z * x0 + (double)b.w * x1 + (double)cc * x2;
+        }
+        const bool seg_end = !valid || tail || lane == 63;
+        const unsigned long long ends = __ballot(seg_end);
+        const unsigned long long tails = __ballot(valid && tail);
+        const unsigned long long heads = (ends << 1) | 1ull;
+        const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+        const int start = 63 - __clzll(heads & le);
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double u0 = __shfl_up(y0, d, 64), u1 = __shfl_up(y1, d, 64), u2 = __shfl_up(y2, d, 64);
+            if (lane - d >= start) {
+                y0 += u0;
+                y1 += u1;
+                y2 += u2;
+            }
+        }
+        if (valid && seg_end) {
+            const int row = tile_first_row[t] + __popcll(tails & ((1ull << lane) - 1ull));
+            // the first segment continues a row begun in the previous tile iff the block before this tile is not a row end
+            const bool cont_prev = (start == 0) && (t > 0) && ((colw[t * 64 - 1] >> 31) == 0);
+            double* yr = y + 3 * (size_t)row;
+            if (cont_prev || !tail) {
+                atomicAdd(yr, y0);
+                atomicAdd(yr + 1, y1);
+                atomicAdd(yr + 2, y2);
+            } else {
+                yr[0] = y0;
+                yr[1] = y1;
+                yr[2] = y2;
+            }
+            if (pdot) {
+                const double* pr = pdot + 3 * (size_t)row;
+                acc += pr[0] * y0 + pr[1] * y1 + pr[2] * y2;
+            }
+        }
+    }
+    if (partials) {
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+    }
+}
+
+static int spmv_grid(const Context& c) { return (int)std::min<int64_t>(std::max<int64_t>((c.ntiles + 3) / 4, 1), MAX_PARTIALS); }
+
+void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed)
+{
+    MS_CHECK(hipMemsetAsync(y, 0, (size_t)c.ndofs * sizeof(double), c.stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed && c.time_spmv) {
+        MS_CHECK(hipEventCreate(&e0));
+        MS_CHECK(hipEventCreate(&e1));
+        MS_CHECK(hipEventRecord(e0, c.stream));
+    }
+    hipLaunchKernelGGL(k_spmv, dim3(spmv_grid(c)), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, x, y, pdot, partials,
+                       (const PcgCtrl*)nullptr);
+    if (e0) {
+        MS_CHECK(hipEventRecord(e1, c.stream));
+        c.ev.push_back(e0);
+        c.ev.push_back(e1);
+    }
+}
+
+// ======================================================================================================================
+// PCG (BlockedSparseMatrix/solve_pcg.h:83-232), x0 = 0. Iteration k = 1..max_iter is three launches:
+//   k_spmv      q = A p, partial p.q
+//   k_pcg_step  alpha = rz/pAp; x += alpha p; r -= alpha q; z = M^-1 r; partial r.r, r.z      (indefiniteness test)
+//   k_pcg_dir   error = sqrt(rr/bb); convergence test; beta = rz'/rz; p = z + beta p
+// Scalars never leave the device inside the loop; `ctrl->done` turns the remaining launches of a batch into no-ops.
+// ======================================================================================================================
+__global__ __launch_bounds__(BLOCK) void k_pcg_init(const double* __restrict__ b, const float* __restrict__ dinv, int64_t nbr, double* __restrict__ x, double* __restrict__ r,
+                                                    double* __restrict__ z, double* __restrict__ p, double* __restrict__ part_bb, double* __restrict__ part_rz)
+{
+    __shared__ double sm[4];
+    double bb = 0.0, rz = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x; row < nbr; row += (int64_t)gridDim.x * BLOCK) {
+        const double r0 = b[3 * row], r1 = b[3 * row + 1], r2 = b[3 * row + 2];
+        const float* d = dinv + 9 * row;
+        // column-major-agnostic: the inverse is symmetric
+        const double z0 = (double)d[0] * r0 + (double)d[1] * r1 + (double)d[2] * r2;
+        const double z1 = (double)d[3] * r0 + (double)d[4] * r1 + (double)d[5] * r2;
+        const double z2 = (double)d[6] * r0 + (double)d[7] * r1 + (double)d[8] * r2;
+        x[3 * row] = 0.0; x[3 * row + 1] = 0.0; x[3 * row + 2] = 0.0;
+        r[3 * row] = r0; r[3 * row + 1] = r1; r[3 * row + 2] = r2;
+        z[3 * row] = z0; z[3 * row + 1] = z1; z[3 * row + 2] = z2;
+        p[3 * row] = z0; p[3 * row + 1] = z1; p[3 * row + 2] = z2;
+        bb += r0 * r0 + r1 * r1 + r2 * r2;
+        rz += r0 * z0 + r1 * z1 + r2 * z2;
+    }
+    bb = block_sum(bb, sm);
+    rz = block_sum(rz, sm);
+    if (threadIdx.x == 0) {
+        part_bb[blockIdx.x] = bb;
+        part_rz[blockIdx.x] = rz;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_pcg_init2(const double* __restrict__ part_bb, const double* __restrict__ part_rz, int nparts, double abs_tol, PcgCtrl* __restrict__ ctrl)
+{
+    __shared__ double sm[4];
+    const double bb = sum_partials(part_bb, nparts, sm);
+    const double rz = sum_partials(part_rz, nparts, sm);
+    if (threadIdx.x == 0) {
+        ctrl->bb = bb;
+        ctrl->rz[1] = rz;
+        ctrl->rz[0] = 0.0;
+        ctrl->indef = 0;
+        ctrl->n_iter = 0;
+        ctrl->converged = 0;
+        ctrl->done = 0;
+        ctrl->error = 1.0;  // r = b  =>  error_0 = 1
+        if (bb < abs_tol * abs_tol) {  // zero right-hand side (solve_pcg.h:125-131)
+            ctrl->done = 1;
+            ctrl->converged = 1;
+            ctrl->error = 0.0;
+        } else if (1.0 < abs_tol) {    // initial residual already below tolerance (:150-156)
+            ctrl->done = 1;
+            ctrl->converged = 1;
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, const double* __restrict__ part_pq, int n_pq, const float* __restrict__ dinv, int64_t nbr,
+                                                    const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ x, double* __restrict__ r,
+                                                    double* __restrict__ z, double* __restrict__ part_rr, double* __restrict__ part_rz, PcgCtrl* __restrict__ ctrl)
+{
+    if (ctrl->done) return;
+    __shared__ double sm[4];
+    const double pAp = sum_partials(part_pq, n_pq, sm);
+    const double rz = ctrl->rz[k & 1];
+    if (pAp <= 0.0) {
+        if (stop_on_indef) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) {
+                ctrl->indef = 1;
+                ctrl->n_iter = k;
+                ctrl->converged = 0;
+                ctrl->done = 2;  // becomes visible to the next kernel
+            }
+            // all blocks take the same decision: leave x untouched
+            if (threadIdx.x == 0) {
+                part_rr[blockIdx.x] = 0.0;
+                part_rz[blockIdx.x] = 0.0;
+            }
+            return;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->indef = 1;
+    }
+    const double alpha = rz / pAp;
+    double rr = 0.0, rzn = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x; row < nbr; row += (int64_t)gridDim.x * BLOCK) {
+        const size_t i = 3 * (size_t)row;
+        const double r0 = r[i] - alpha * q[i], r1 = r[i + 1] - alpha * q[i + 1], r2 = r[i + 2] - alpha * q[i + 2];
+        x[i] += alpha * p[i];
+        x[i + 1] += alpha * p[i + 1];
+        x[i + 2] += alpha * p[i + 2];
+        r[i] = r0; r[i + 1] = r1; r[i + 2] = r2;
+        const float* d = dinv + 9 * row;
+        const double z0 = (double)d[0] * r0 + (double)d[1] * r1 + (double)d[2] * r2;
+        const double z1 = (double)d[3] * r0 + (double)d[4] * r1 + (double)d[5] * r2;
+        const double z2 = (double)d[6] * r0 + (double)d[7] * r1 + (double)d[8] * r2;
+        z[i] = z0; z[i + 1] = z1; z[i + 2] = z2;
+        rr += r0 * r0 + r1 * r1 + r2 * r2;
+        rzn += r0 * z0 + r1 * z1 + r2 * z2;
+    }
+    rr = block_sum(rr, sm);
+    rzn = block_sum(rzn, sm);
+    if (threadIdx.x == 0) {
+        part_rr[blockIdx.x] = rr;
+        part_rz[blockIdx.x] = rzn;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double rel_tol, const double* __restrict__ part_rr, const double* __restrict__ part_rz, int nparts,
+                                                   int64_t n, const double* __restrict__ z, double* __restrict__ p, PcgCtrl* __restrict__ ctrl)
+{
+    const int done = ctrl->done;
+    if (done == 1) return;
+    if (done == 2) {  // indefiniteness stop decided in k_pcg_step of this iteration
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->done = 1;
+        return;
+    }
+    __shared__ double sm[4];
+    const double rr = sum_partials(part_rr, nparts, sm);
+    const double rz_new = sum_partials(part_rz, nparts, sm);
+    const double error = sqrt(rr / ctrl->bb);
+    const bool conv = error < abs_tol || error / 1.0 < rel_tol;  // error_0 = 1 for x0 = 0
+    if (conv) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctrl->error = error;
+            ctrl->n_iter = k;
+            ctrl->converged = 1;
+            ctrl->done = 1;
+        }
+        return;
+    }
+    const double beta = rz_new / ctrl->rz[k & 1];
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) p[i] = z[i] + beta * p[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctrl->rz[(k + 1) & 1] = rz_new;
+        ctrl->error = error;
+        ctrl->n_iter = k;
+    }
+}
+
+static void drain_spmv_events(Context& c, int n_valid_pairs)
+{
+    // events were recorded as (start, stop) pairs; only the first n_valid_pairs belong to real iterations
+    for (size_t i = 0; i + 1 < c.ev.size(); i += 2) {
+        if ((int)(i / 2) < n_valid_pairs) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c.ev[i], c.ev[i + 1]) == hipSuccess) {
+                c.spmv_ms_sum += ms;
+                c.spmv_n++;
+            }
+        }
+        (void)hipEventDestroy(c.ev[i]);
+        (void)hipEventDestroy(c.ev[i + 1]);
+    }
+    c.ev.clear();
+}
+
+void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
+{
+    if (!c.have_matrix) throw Error("pcg: matrix not assembled");
+    build_preconditioner(c);
+    const int gv = grid_for(c.nbr, BLOCK, VEC_GRID);
+    const int gs = spmv_grid(c);
+    double* part_pq = c.partials.p;
+    double* part_rr = c.partials.p + MAX_PARTIALS;
+    double* part_rz = c.partials.p + 2 * MAX_PARTIALS;
+    double* part_bb = c.partials.p + 3 * MAX_PARTIALS;
+    hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(BLOCK), 0, c.stream, rhs_dev, c.dinv.p, c.nbr, c.du.p, c.r.p, c.z.p, c.p.p, part_bb, part_rz);
+    hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, part_bb, part_rz, gv, abs_tol, c.ctrl.p);
+    PcgCtrl h{};
+    int k = 1;
+    int batch = 8;
+    bool finished = false;
+    while (!finished) {
+        const int k_end = std::min(max_iter, k + batch - 1);
+        const int k_begin = k;
+        for (; k <= k_end; k++) {
+            MS_CHECK(hipMemsetAsync(c.q.p, 0, (size_t)c.ndofs * sizeof(double), c.stream));
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (c.time_spmv) {
+                MS_CHECK(hipEventCreate(&e0));
+                MS_CHECK(hipEventCreate(&e1));
+                MS_CHECK(hipEventRecord(e0, c.stream));
+            }
+            hipLaunchKernelGGL(k_spmv, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p);
+            if (e0) {
+                MS_CHECK(hipEventRecord(e1, c.stream));
+                c.ev.push_back(e0);
+                c.ev.push_back(e1);
+            }
+            hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, c.p.p, c.q.p, c.du.p, c.r.p, c.z.p, part_rr,
+                               part_rz, c.ctrl.p);
+            hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p);
+        }
+        MS_CHECK(hipMemcpyAsync(&h, c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+        const int executed = h.done ? std::max(0, h.n_iter - k_begin + 1) : (k_end - k_begin + 1);
+        if (c.time_spmv) drain_spmv_events(c, executed);
+        if (h.done || k > max_iter) finished = true;
+        batch = std::min(batch * 2, 64);
+    }
+    if (info) {
+        info->converged = h.done ? h.converged : 0;
+        info->n_iterations = h.done ? h.n_iter : max_iter;
+        info->found_indefiniteness = h.indef;
+        info->error = h.error;
+        info->reserved = 0;
+    }
+}
+
+Context::~Context()
+{
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (h_scratch) (void)hipHostFree(h_scratch);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+}  // namespace mistark

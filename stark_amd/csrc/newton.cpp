@@ -1,0 +1,262 @@
+// newton.cpp — host control flow of Newton's method over the device engine.
+//
+// Mirrors symx::NewtonsMethod::solve (symx/src/solver/NewtonsMethod.cpp:28-252), _project_and_assemble (:254-352),
+// _increase/_decrease_projection (:354-386), _solve_linear_system (:388-457) and _line_search_inplace (:459-641):
+// same decisions in the same order, every vector stays on the device, only scalars cross PCIe.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <limits>
+
+#include "engine.hpp"
+
+namespace mistark {
+
+namespace {
+struct Timer
+{
+    double& acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit Timer(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~Timer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
+int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_newton_callbacks* cb, mistark_newton_stats& st)
+{
+    Timer t_total(st.t_total);
+    prepare(c);
+    const int64_t ndofs = c.ndofs;
+    auto sync = [&]() { MS_CHECK(hipStreamSynchronize(c.stream)); };
+    auto call_void = [&](void (*f)(void*)) {
+        if (cb && f) {
+            Timer t(st.t_callbacks);
+            sync();
+            f(cb->user);
+        }
+    };
+    auto call_bool = [&](int (*f)(void*), bool def) -> bool {
+        if (cb && f) {
+            Timer t(st.t_callbacks);
+            sync();
+            return f(cb->user) != 0;
+        }
+        return def;
+    };
+
+    double E0 = 0.0, du_dot_grad = 0.0, res_0 = std::numeric_limits<double>::max();
+    int result = MISTARK_RUNNING;
+    int pdn_countdown = 0;
+    double ppn_threshold = -1.0;
+
+    if (!call_bool(cb ? cb->is_initial_state_valid : nullptr, true)) result = MISTARK_INVALID_INITIAL_STATE;
+
+    int it = -1;
+    while (result == MISTARK_RUNNING) {
+        it++;
+        if (it == s.max_iterations) {
+            result = s.max_iterations_as_success ? MISTARK_SUCCESSFUL : MISTARK_TOO_MANY_ITERATIONS;
+            break;
+        }
+        call_void(cb ? cb->before_energy_evaluation : nullptr);
+        {
+            Timer t(st.t_eval_pgh);
+            eval(c, MISTARK_EVAL_P_G_H, &E0, nullptr);
+            st.n_evaluations++;
+        }
+        const double residual = reduce_max_abs(c, c.grad.p, ndofs);  // default residual: ||grad||_inf (solver_utils.h:28)
+        if (it == 0) res_0 = residual;
+        if (residual < s.bailout_residual) {
+            result = MISTARK_SUCCESSFUL;
+            break;
+        }
+        if (it >= s.min_iterations) {
+            if (residual < s.residual_tolerance_abs) {
+                result = MISTARK_SUCCESSFUL;
+                break;
+            }
+            if (it > 0 && residual / res_0 < s.residual_tolerance_rel) {
+                result = MISTARK_SUCCESSFUL;
+                break;
+            }
+        }
+
+        bool assembled = false;  // "hess == nullptr" in the reference
+        bool solved = false;
+        while (!solved) {
+            // ---- _project_and_assemble ------------------------------------------------------------------------
+            bool all_projected = false;
+            if (s.projection_mode == MISTARK_PROJ_PROGRESSIVE && !assembled) {
+                Timer t(st.t_assembly);
+                assemble(c);
+                assembled = true;
+            }
+            bool reassemble = !assembled;
+            {
+                Timer t(st.t_project);
+                switch (s.projection_mode) {
+                    case MISTARK_PROJ_NEWTON: break;
+                    case MISTARK_PROJ_PROJECTED_NEWTON: {
+                        int64_t np = 0;
+                        project(c, s.projection_eps, s.project_to_pd_use_mirroring, nullptr, false, 0.0, nullptr, &np, nullptr);
+                        all_projected = true;
+                        reassemble = reassemble || np > 0;
+                        break;
+                    }
+                    case MISTARK_PROJ_ON_DEMAND:
+                        if (pdn_countdown > 0) {
+                            int64_t np = 0;
+                            project(c, s.projection_eps, s.project_to_pd_use_mirroring, nullptr, false, 0.0, nullptr, &np, nullptr);
+                            all_projected = true;
+                            reassemble = reassemble || np > 0;
+                        }
+                        break;
+                    case MISTARK_PROJ_PROGRESSIVE:
+                        if (ppn_threshold > 0.0) {
+                            if (ppn_threshold < 1e-12) ppn_threshold = 0.0;
+                            int all_active = 0;
+                            int64_t np = 0;
+                            project(c, s.projection_eps, s.project_to_pd_use_mirroring, nullptr, true, ppn_threshold, &all_active, &np, nullptr);
+                            all_projected = all_active != 0;
+                            reassemble = reassemble || np > 0;
+                        }
+                        break;
+                    default: throw Error("unknown projection mode");
+                }
+            }
+            if (reassemble) {
+                // update_global adds (projected - original) blocks (ElementHessians.cpp:258-294); re-scattering the
+                // stored element Hessians gives the same matrix
+                Timer t(st.t_assembly);
+                assemble(c);
+                assembled = true;
+            }
+
+            // ---- _solve_linear_system ---------------------------------------------------------------------------
+            mistark_pcg_info info{};
+            {
+                Timer t(st.t_linear_solve);
+                const double forcing = std::min(1e-2, residual * std::min(0.5, std::sqrt(residual)));
+                const double abs_tol = std::max(forcing, s.cg_abs_tolerance);
+                vec_neg(c, c.tmp_a.p, c.grad.p, ndofs);
+                pcg(c, c.tmp_a.p, abs_tol, s.cg_rel_tolerance, s.cg_max_iterations, s.cg_stop_on_indefiniteness, &info);
+                st.cg_iterations += info.n_iterations;
+                st.n_linear_solves++;
+            }
+            const bool ok = info.converged != 0;
+            const bool can_project_more = (s.projection_mode != MISTARK_PROJ_NEWTON) && !all_projected;
+            if (!ok && !can_project_more) {
+                result = MISTARK_LINEAR_SYSTEM_SOLVE_FAILURE;
+                break;
+            }
+            bool descends = false;
+            if (ok) {
+                du_dot_grad = reduce_dot(c, c.du.p, c.grad.p, ndofs);
+                descends = du_dot_grad < 0.0;
+                if (!descends && !can_project_more) {
+                    result = MISTARK_STEP_DOES_NOT_DESCEND;
+                    break;
+                }
+            }
+            if (ok && descends) {
+                solved = true;
+                break;
+            }
+            // _increase_projection
+            if (s.projection_mode == MISTARK_PROJ_ON_DEMAND) pdn_countdown = s.project_on_demand_countdown;
+            else if (s.projection_mode == MISTARK_PROJ_PROGRESSIVE) {
+                if (ppn_threshold < 0.0) ppn_threshold = residual;  // = grad.cwiseAbs().maxCoeff()
+                ppn_threshold *= s.ppn_tightening_factor;
+            }
+        }
+        if (result != MISTARK_RUNNING) break;
+
+        // _decrease_projection
+        if (s.projection_mode == MISTARK_PROJ_ON_DEMAND) pdn_countdown--;
+        else if (s.projection_mode == MISTARK_PROJ_PROGRESSIVE) ppn_threshold *= s.ppn_release_factor;
+
+        st.n_hessians += (int64_t)c.n_elem_total;
+        st.n_projected_hessians += c.n_projected_total;
+
+        double du_max = reduce_max_abs(c, c.du.p, ndofs);
+        if (it >= s.min_iterations && du_max < s.step_tolerance) {
+            result = MISTARK_SUCCESSFUL;
+            break;
+        }
+
+        // ---- _line_search_inplace ---------------------------------------------------------------------------------
+        {
+            double* u0 = c.tmp_b.p;  // dofs_before_ls
+            MS_CHECK(hipMemcpyAsync(u0, c.u.p, (size_t)ndofs * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
+            auto apply = [&](double step) { vec_axpby(c, c.u.p, 1.0, u0, step, c.du.p, ndofs); };
+            double retraction = 1.0;
+            if (du_max > s.step_cap) {
+                retraction *= s.step_cap / du_max;
+                vec_axpby(c, c.du.p, retraction, c.du.p, 0.0, nullptr, ndofs);
+                du_max = s.step_cap;
+                st.ls_cap_iterations++;
+            }
+            double max_step = 1.0;
+            if (cb && cb->max_allowed_step) {
+                Timer t(st.t_callbacks);
+                sync();
+                max_step = std::min(1.0, cb->max_allowed_step(cb->user));
+            }
+            if (max_step < 1.0) {
+                retraction *= max_step;
+                vec_axpby(c, c.du.p, max_step, c.du.p, 0.0, nullptr, ndofs);
+                du_max *= max_step;
+                st.ls_max_iterations++;
+            }
+            double step = 1.0;
+            apply(step);
+            int inv_it = 0;
+            for (; inv_it < s.max_backtracking_invalid_state_iterations; ++inv_it) {
+                if (call_bool(cb ? cb->is_intermediate_state_valid : nullptr, true)) break;
+                step *= 0.5;
+                apply(step);
+                st.ls_inv_iterations++;
+            }
+            if (inv_it == s.max_backtracking_invalid_state_iterations) {
+                call_void(cb ? cb->on_intermediate_state_invalid : nullptr);
+                result = MISTARK_TOO_MANY_INVALID_INTERMEDIATE_ITERATIONS;
+            } else if (s.enable_armijo_backtracking) {
+                const double expected = s.line_search_armijo_beta * du_dot_grad * retraction;
+                double E_threshold = E0 + expected * step;
+                double E1 = 0.0;
+                int k = 0;
+                for (; k < s.max_backtracking_armijo_iterations; ++k) {
+                    call_void(cb ? cb->before_energy_evaluation : nullptr);
+                    {
+                        Timer t(st.t_eval_p);
+                        eval(c, MISTARK_EVAL_P, &E1, nullptr);
+                        st.n_evaluations++;
+                    }
+                    if (E1 < E_threshold) break;
+                    step *= 0.5;
+                    apply(step);
+                    E_threshold = E0 + expected * step;
+                    st.ls_bt_iterations++;
+                }
+                if (k == s.max_backtracking_armijo_iterations) {
+                    call_void(cb ? cb->on_armijo_fail : nullptr);
+                    result = MISTARK_TOO_MANY_ARMIJO_ITERATIONS;
+                }
+            }
+        }
+        // user convergence (NewtonsMethod.cpp:221)
+        if (it >= s.min_iterations && call_bool(cb ? cb->is_converged : nullptr, false)) {
+            result = MISTARK_SUCCESSFUL;
+            break;
+        }
+    }
+    if (result == MISTARK_SUCCESSFUL) {
+        if (!call_bool(cb ? cb->is_converged_state_valid : nullptr, true)) result = MISTARK_INVALID_CONVERGED_STATE;
+    }
+    st.newton_iterations = it;
+    if (st.n_hessians > 0) st.projected_hessians_ratio = (double)st.n_projected_hessians / (double)st.n_hessians;
+    sync();
+    return result;
+}
+
+}  // namespace mistark

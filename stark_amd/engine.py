@@ -1,0 +1,178 @@
+"""Thin object wrapper over the C ABI: mirrors the reference's registration calls
+(symx::GlobalPotential::add_dof / add_potential, symx/src/solver/GlobalPotential.h:37-70) one to one."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Engine:
+    def __init__(self, device: int = 0):
+        self.L = capi.lib()
+        h = C.c_void_p()
+        rc = self.L.mistark_create(device, C.byref(h))
+        if rc != 0:
+            raise EngineError("mistark_create failed (%d): no MI355X visible / HIP runtime error; the hot path has no CPU fallback" % rc)
+        self.h = h
+        self._keep = []          # host buffers must outlive the context (caller-owned memory contract)
+        self._array_ids = {}
+        self.potential_ids = {}
+
+    def close(self):
+        if self.h:
+            self.L.mistark_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise EngineError(self.L.mistark_last_error(self.h).decode())
+        return rc
+
+    # ---- registration ------------------------------------------------------------------------------------------------
+    def add_dof_set(self, label: str, arr: np.ndarray) -> int:
+        assert arr.dtype == np.float64 and arr.flags.c_contiguous
+        self._keep.append(arr)
+        return self._ck(self.L.mistark_add_dof_set(self.h, label.encode(), arr.ctypes.data, arr.size))
+
+    def array(self, arr: np.ndarray, stride: int | None = None) -> int:
+        assert arr.dtype == np.float64 and arr.flags.c_contiguous
+        if stride is None:
+            stride = 1 if arr.ndim == 1 else arr.shape[-1]
+        n_items = arr.size // stride
+        self._keep.append(arr)
+        return self._ck(self.L.mistark_array(self.h, arr.ctypes.data, n_items, stride))
+
+    def potential(self, name: str, conn: np.ndarray, bindings) -> int:
+        """bindings: list of (array_id, stride, conn_col) in the reference's mws.make_* order."""
+        conn = np.ascontiguousarray(conn, dtype=np.int32)
+        if conn.ndim != 2:
+            raise ValueError("conn must be [n_elem, stride]")
+        b = (capi.Binding * len(bindings))(*[capi.Binding(a, s, c) for a, s, c in bindings])
+        pid = self._ck(self.L.mistark_potential(self.h, name.encode(), conn.ctypes.data if conn.size else None, conn.shape[0], conn.shape[1], b, len(bindings)))
+        self.potential_ids[name] = pid
+        return pid
+
+    def upload(self, array: int = -1):
+        self._ck(self.L.mistark_upload(self.h, array))
+
+    def download(self, array: int = -1):
+        self._ck(self.L.mistark_download(self.h, array))
+
+    def axpby(self, dst, a, x, b=0.0, y=-1):
+        self._ck(self.L.mistark_array_axpby(self.h, dst, a, x, b, y))
+
+    def fill(self, dst, v):
+        self._ck(self.L.mistark_array_fill(self.h, dst, v))
+
+    # ---- DoFs ------------------------------------------------------------------------------------------------------------
+    @property
+    def ndofs(self) -> int:
+        return int(self.L.mistark_ndofs(self.h))
+
+    def get_dofs(self) -> np.ndarray:
+        u = np.zeros(self.ndofs)
+        self._ck(self.L.mistark_get_dofs(self.h, u.ctypes.data))
+        return u
+
+    def set_dofs(self, u: np.ndarray):
+        u = np.ascontiguousarray(u, dtype=np.float64)
+        assert u.size == self.ndofs
+        self._ck(self.L.mistark_set_dofs(self.h, u.ctypes.data))
+
+    def dofs_to_host(self):
+        self._ck(self.L.mistark_dofs_to_host_arrays(self.h))
+
+    def dofs_from_host(self):
+        self._ck(self.L.mistark_dofs_from_host_arrays(self.h))
+
+    # ---- stages ------------------------------------------------------------------------------------------------------------
+    def eval(self, mode=capi.EVAL_P_G_H, want_grad=True):
+        E = C.c_double()
+        g = np.zeros(self.ndofs) if (want_grad and mode != capi.EVAL_P) else None
+        self._ck(self.L.mistark_eval(self.h, mode, C.byref(E), g.ctypes.data if g is not None else None))
+        return E.value, g
+
+    def element_hessians(self, pot: int, n_elem: int):
+        nb = C.c_int32()
+        self._ck(self.L.mistark_get_element_hessians(self.h, pot, None, None, C.byref(nb)))
+        n = 3 * nb.value
+        H = np.zeros((n_elem, n, n))
+        rows = np.zeros((n_elem, nb.value), dtype=np.int32)
+        self._ck(self.L.mistark_get_element_hessians(self.h, pot, H.ctypes.data, rows.ctypes.data, C.byref(nb)))
+        return H, rows
+
+    def element_energies(self, pot: int, n_elem: int):
+        E = np.zeros(n_elem)
+        self._ck(self.L.mistark_get_element_energies(self.h, pot, E.ctypes.data))
+        return E
+
+    def project(self, eps=1e-10, mirroring=False, active_blocks=None):
+        npj, nch = C.c_int64(), C.c_int64()
+        ab = None
+        if active_blocks is not None:
+            ab = np.ascontiguousarray(active_blocks, dtype=np.uint8)
+        self._ck(self.L.mistark_project(self.h, eps, int(mirroring), ab.ctypes.data if ab is not None else None, C.byref(npj), C.byref(nch)))
+        return npj.value, nch.value
+
+    def assemble(self):
+        self._ck(self.L.mistark_assemble(self.h))
+
+    def get_bsr(self, with_vals=True):
+        nbr, nnzb = C.c_int64(), C.c_int64()
+        self._ck(self.L.mistark_get_bsr(self.h, C.byref(nbr), C.byref(nnzb), None, None, None))
+        row_ptr = np.zeros(nbr.value + 1, dtype=np.int64)
+        cols = np.zeros(nnzb.value, dtype=np.int32)
+        vals = np.zeros((nnzb.value, 3, 3), dtype=np.float32)
+        self._ck(self.L.mistark_get_bsr(self.h, C.byref(nbr), C.byref(nnzb), row_ptr.ctypes.data, cols.ctypes.data, vals.ctypes.data if with_vals else None))
+        return row_ptr, cols, vals
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros_like(x)
+        self._ck(self.L.mistark_spmv(self.h, x.ctypes.data, y.ctypes.data))
+        return y
+
+    def apply_preconditioner(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        z = np.zeros_like(x)
+        self._ck(self.L.mistark_apply_preconditioner(self.h, x.ctypes.data, z.ctypes.data))
+        return z
+
+    def pcg(self, abs_tol, rel_tol=1e-4, max_iter=10000, stop_on_indef=True, rhs=None):
+        info = capi.PcgInfo()
+        x = np.zeros(self.ndofs)
+        if rhs is None:
+            self._ck(self.L.mistark_pcg(self.h, abs_tol, rel_tol, max_iter, int(stop_on_indef), x.ctypes.data, C.byref(info)))
+        else:
+            rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+            self._ck(self.L.mistark_pcg_rhs(self.h, rhs.ctypes.data, abs_tol, rel_tol, max_iter, int(stop_on_indef), x.ctypes.data, C.byref(info)))
+        return x, info
+
+    def default_newton_settings(self):
+        s = capi.NewtonSettings()
+        self.L.mistark_newton_default_settings(C.byref(s))
+        return s
+
+    def newton_solve(self, settings=None, callbacks=None):
+        st = capi.NewtonStats()
+        s = settings if settings is not None else self.default_newton_settings()
+        rc = self._ck(self.L.mistark_newton_solve(self.h, C.byref(s), C.byref(callbacks) if callbacks is not None else None, C.byref(st)))
+        return capi.SOLVER_RETURN[rc], st
+
+    def spmv_timing(self, reset=0):
+        ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+        self._ck(self.L.mistark_spmv_timing(self.h, reset, C.byref(ms), C.byref(n), C.byref(b)))
+        return ms.value, n.value, b.value
