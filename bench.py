@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""bench.py — Newton-steps/s and ms/linear-solve of the MI355X engine on BASELINE.json's headline workload.
+
+A "step" is ONE NEWTON ITERATION of the hot path (evaluate E/grad/element Hessians -> [project] -> assemble -> block-Jacobi
+PCG -> line search), the reference's `newton_iterations` counter (NewtonsMethod.cpp:243,249). The workload is the 1M-tet
+Neo-Hookean block of configs[3] (generate_tet_grid {44,44,43}, Soft_Rubber, full EnergyTetStrain), bottom face clamped,
+gravity; the IPC contact of that config is not part of this round's path and is named as missing in config.workload.
+Synthetic data only. Inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run, one rank per GPU)
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def build_scene(S, nx, ny, nz, device, eo=False):
+    st = S.default_settings()
+    st.device = device
+    st.mirror_state_to_host = 0      # state stays in HBM between steps
+    sim = S.Simulation(st)
+    p = S.soft_rubber()
+    p.elasticity_only = 1 if eo else 0
+    ps = sim.add_volume_grid("block", (0.0, 0.0, 0.6), (1.0, 1.0, 1.0), (nx, ny, nz), p)
+    sim.prescribe_inside_aabb(ps, (0.0, 0.0, 0.1), (2.0, 2.0, 2e-3), 1e7)
+    return sim
+
+
+def run_newton_steps(sim, S, capi, n_steps):
+    """Runs time steps until exactly n_steps Newton iterations have been executed. Returns (newton, linear_solves, cg, t_linear)."""
+    base = sim.info()
+    n0 = base.total_newton_iterations
+    ls0, cg0, tl0 = base.total_linear_solves, base.total_cg_iterations, base.total_linear_solve_time
+    ns = S.default_settings().newton
+    while True:
+        done = sim.info().total_newton_iterations - n0
+        remaining = n_steps - done
+        if remaining <= 0:
+            break
+        ns.max_iterations = int(remaining)
+        ns.max_iterations_as_success = 1
+        sim.set_newton_settings(ns)
+        if not sim.run_one_step():
+            raise RuntimeError("simulation stopped")
+        if sim.info().total_newton_iterations - n0 == done and sim.info().last_stats.newton_iterations == 0:
+            # a converged time step costs evaluations but no Newton iteration: keep stepping (state advances)
+            continue
+    i = sim.info()
+    return i.total_newton_iterations - n0, i.total_linear_solves - ls0, i.total_cg_iterations - cg0, i.total_linear_solve_time - tl0
+
+
+def cpu_baseline(nx, ny, nz):
+    """The UNMODIFIED reference (oracle/_ref/ref_harness, built by oracle/Makefile) timed on this host's cores."""
+    harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
+    cores = os.cpu_count() or 1
+    threads = max(1, min(cores, 64))
+    if not os.path.exists(harness):
+        return {"value": None, "unit": "Newton-steps/s", "cores": threads, "kind": "reference", "sample": "unavailable: oracle/_ref/ref_harness not built"}
+    args = ["nx=%d" % nx, "ny=%d" % ny, "nz=%d" % nz, "threads=%d" % threads, "codegen=/tmp/mistark_bench_codegen", "outdir=/tmp/mistark_bench_out"]
+    try:
+        subprocess.run([harness, "prime", "tetblock", "nx=2", "ny=2", "nz=2"] + args[3:], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        out = subprocess.run([harness, "time", "tetblock"] + args + ["steps=2", "warmup=1"], check=True, capture_output=True, timeout=900).stdout.decode()
+        line = [l for l in out.splitlines() if l.startswith("{")][-1]
+        r = json.loads(line)
+        return {"value": r["newton_steps_per_s"], "unit": "Newton-steps/s", "cores": threads, "kind": "reference",
+                "sample": "same scene, %d Newton iterations over 2 time steps after 1 warm-up step (pattern build + JIT excluded)" % r["newton_iterations"],
+                "ms_per_linear_solve": r["ms_per_linear_solve"], "wall_s": r["wall_s"]}
+    except Exception as e:  # noqa: BLE001
+        return {"value": None, "unit": "Newton-steps/s", "cores": threads, "kind": "reference", "sample": "failed: %r" % (e,)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--grid", type=str, default="44,44,43", help="hexahedra per dimension (12 tets each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+    nx, ny, nz = [int(v) for v in a.grid.split(",")]
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    sim = build_scene(S, nx, ny, nz, local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up (includes sparsity-pattern construction and first-touch allocations)
+    if a.warmup > 0:
+        run_newton_steps(sim, S, capi, a.warmup)
+    sim.spmv_timing(reset=1)  # start SpMV event timing for the timed region
+    barrier()
+    t0 = time.perf_counter()
+    newton, n_ls, n_cg, t_ls = run_newton_steps(sim, S, capi, a.steps)
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    spmv_ms, spmv_n, spmv_bytes = sim.spmv_timing(reset=-1)
+    info = sim.info()
+
+    if rank == 0:
+        n_tets = 12 * nx * ny * nz
+        achieved = (spmv_bytes / (spmv_ms * 1e-3)) / 1e9 if spmv_ms > 0 else 0.0
+        out = {
+            "metric": "Newton-steps/s",
+            # N>1 this round: independent replicas of the scene, one per GPU (element sharding + RCCL not built yet)
+            "value": world * newton / elapsed,
+            "unit": "Newton-steps/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": 1000.0 * elapsed / max(newton, 1),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "tet block generate_tet_grid{%d,%d,%d} = %d tets / %d DoF, Soft_Rubber stable Neo-Hookean (full EnergyTetStrain) + lumped inertia, "
+                            "bottom face clamped, gravity, dt=1/30; IPC contact of configs[3] NOT included yet" % (nx, ny, nz, n_tets, info.ndofs),
+                "step": "one Newton iteration (eval P+g+H, assembly, block-Jacobi PCG, line search)",
+                "parallelism": "single GPU" if world == 1 else "replicas x%d (no sharding yet)" % world,
+                "projection": "Progressive",
+            },
+            "ms_per_linear_solve": 1000.0 * t_ls / max(n_ls, 1),
+            "cg_iterations_per_solve": n_cg / max(n_ls, 1),
+            "linear_solves": n_ls,
+            "roofline": {
+                "kernel": "k_spmv (3x3-block CSR, float values, double vectors)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": 8000.0,
+                "unit": "GB/s",
+                "frac": achieved / 8000.0,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": spmv_bytes,
+                "avg_launch_ms": spmv_ms,
+                "launches_timed": spmv_n,
+            },
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(nx, ny, nz)
+        else:
+            out["cpu_baseline"] = {"value": None, "unit": "Newton-steps/s", "cores": 0, "kind": "reference", "sample": "skipped (N>1 or --no-cpu-baseline)"}
+        print(json.dumps(out))
+    sim.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+/* mistark_sim.h — C facade over the C++ host mirror (stark_amd/csrc/host/sim.hpp) of the reference's scene API
+ * (stark::Simulation + presets, stark/src/models/Simulation.h:13-42, presets/DeformablesPresets.h). It plays the role
+ * pystark's nanobind module plays for the reference (pystark/cpp/models/pystark_Simulation.cpp:5-23): a language binding
+ * can drive scenes without touching C++. Return values: 0 / >=0 = ok, < 0 = error (mistark_sim_last_error). */
+#ifndef MISTARK_SIM_H
+#define MISTARK_SIM_H
+#include "mistark.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mistark_sim mistark_sim;
+
+typedef struct mistark_sim_settings
+{
+    double gravity[3];
+    double max_time_step_size;
+    int32_t use_adaptive_time_step;
+    double time_step_size_success_multiplier;
+    double time_step_size_lower_bound;
+    int32_t device;
+    int32_t mirror_state_to_host;
+    int32_t enable_output;
+    mistark_newton_settings newton;
+} mistark_sim_settings;
+void mistark_sim_default_settings(mistark_sim_settings* s);
+
+/* EnergyLumpedInertia::Params + EnergyTetStrain::Params (stark::Volume::Params) */
+typedef struct mistark_volume_params
+{
+    double density, inertia_damping;
+    int32_t quasistatic;
+    int32_t elasticity_only;
+    double scale, youngs_modulus, poissons_ratio, strain_damping, strain_limit, strain_limit_stiffness;
+} mistark_volume_params;
+void mistark_volume_params_soft_rubber(mistark_volume_params* p);
+
+/* EnergyLumpedInertia::Params + EnergyTriangleStrain::Params + EnergyDiscreteShells::Params (stark::Surface::Params) */
+typedef struct mistark_surface_params
+{
+    double density, inertia_damping;
+    int32_t quasistatic;
+    int32_t elasticity_only;
+    double scale, thickness, youngs_modulus, poissons_ratio, strain_damping, strain_limit, strain_limit_stiffness, inflation;
+    double bending_stiffness, bending_damping;
+    int32_t flat_rest_angle;
+} mistark_surface_params;
+void mistark_surface_params_cotton_fabric(mistark_surface_params* p);
+
+int mistark_sim_create(const mistark_sim_settings* settings, mistark_sim** out);
+void mistark_sim_destroy(mistark_sim* sim);
+const char* mistark_sim_last_error(mistark_sim* sim);
+
+/* presets->deformables->add_volume_grid / add_volume / add_surface_grid / add_surface: return the point-set index */
+int mistark_sim_add_volume_grid(mistark_sim* sim, const char* label, const double center[3], const double dim[3], const int32_t subdivisions[3], const mistark_volume_params* p);
+int mistark_sim_add_volume(mistark_sim* sim, const char* label, const double* vertices, int64_t n_vertices, const int32_t* tets, int64_t n_tets, const mistark_volume_params* p);
+int mistark_sim_add_surface_grid(mistark_sim* sim, const char* label, const double dim[2], const int32_t subdivisions[2], const mistark_surface_params* p);
+int mistark_sim_add_surface(mistark_sim* sim, const char* label, const double* vertices, int64_t n_vertices, const int32_t* triangles, int64_t n_triangles, const mistark_surface_params* p);
+/* deformables->prescribed_positions->add_inside_aabb: returns the group index */
+int mistark_sim_prescribe_inside_aabb(mistark_sim* sim, int point_set, const double center[3], const double dim[3], double stiffness, double tolerance);
+
+/* Replace the Newton settings used by the following steps (stark::core::Settings::newton). */
+int mistark_sim_set_newton_settings(mistark_sim* sim, const mistark_newton_settings* s);
+/* Stark::run_one_step: 1 = continue, 0 = stop */
+int mistark_sim_run_one_step(mistark_sim* sim);
+
+typedef struct mistark_sim_info
+{
+    double current_time, dt;
+    int32_t current_time_step, last_newton_result;
+    int64_t n_points, ndofs;
+    int64_t total_newton_iterations, total_cg_iterations, total_linear_solves, failed_steps;
+    double total_newton_time, total_linear_solve_time;
+    mistark_newton_stats last_stats;
+} mistark_sim_info;
+int mistark_sim_get_info(mistark_sim* sim, mistark_sim_info* info);
+/* copies of the PointDynamics arrays (3 doubles per point); which: 0 = X, 1 = x0, 2 = v0, 3 = v1 */
+int mistark_sim_get_points(mistark_sim* sim, int which, double* out);
+/* writes x0 / v0 (which: 1, 2) from the caller's buffer and uploads the state */
+int mistark_sim_set_points(mistark_sim* sim, int which, const double* in);
+/* the engine context (valid after the first step or after mistark_sim_prepare) */
+int mistark_sim_prepare(mistark_sim* sim);
+mistark_ctx* mistark_sim_engine(mistark_sim* sim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

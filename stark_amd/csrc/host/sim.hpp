@@ -1,0 +1,421 @@
+// host/sim.hpp — C++ host mirror of the reference's time-step driver, state containers and energy registration
+// classes for the hot path, calling the device engine through the C ABI (include/mistark.h) only.
+//
+// Same class names, Params fields, add(...) signatures, callback hooks and accept/retry/halve-dt policy as
+//   stark::core::Stark / Settings / Callbacks      stark/src/core/{Stark,Settings,Callbacks}.*
+//   stark::PointDynamics, PointSetHandler          stark/src/models/deformables/PointDynamics.*, PointSetHandler.*
+//   stark::EnergyLumpedInertia                     stark/src/models/deformables/point/EnergyLumpedInertia.*
+//   stark::EnergyPrescribedPositions               stark/src/models/deformables/point/EnergyPrescribedPositions.*
+//   stark::EnergyTetStrain                         stark/src/models/deformables/volume/EnergyTetStrain.*
+//   stark::EnergyTriangleStrain                    stark/src/models/deformables/surface/EnergyTriangleStrain.*
+//   stark::EnergyDiscreteShells                    stark/src/models/deformables/surface/EnergyDiscreteShells.*
+//   stark::Deformables, DeformablesPresets, Simulation   stark/src/models/{deformables/Deformables.h,presets/*,Simulation.*}
+// Eigen::Vector3d is replaced by the layout-compatible std::array<double,3> (mistark::Vec3).
+// What differs by design: potentials are registered by name + bound arrays (no symbolic lambda, no JIT), the state
+// lives on the MI355X between callbacks, and host arrays are mirrors refreshed at the documented sync points.
+#pragma once
+#include <array>
+#include <functional>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../../include/mistark.h"
+#include "mesh.hpp"
+
+namespace mistark {
+
+// ---- stark::core::Settings (stark/src/core/Settings.h:10-49, defaults Settings.cpp:43-50) ---------------------------
+struct Settings
+{
+    struct Output
+    {
+        std::string simulation_name = "";
+        bool enable_output = false;  // console line per step (Stark.cpp:182-189)
+    } output;
+    struct Simulation
+    {
+        Vec3 gravity = {0.0, 0.0, -9.81};
+        bool init_frictional_contact = true;
+        double max_time_step_size = 1.0 / 30.0;
+        bool use_adaptive_time_step = true;
+        double time_step_size_success_multiplier = 1.05;
+        double time_step_size_lower_bound = 1e-6;
+    } simulation;
+    mistark_newton_settings newton;
+    struct Execution
+    {
+        double allowed_execution_time = std::numeric_limits<double>::max();
+        double end_simulation_time = std::numeric_limits<double>::max();
+        int device = 0;                   // MI355X ordinal (replaces n_threads)
+        bool mirror_state_to_host = true; // refresh PointDynamics host arrays after every accepted step
+    } execution;
+    Settings() { mistark_newton_default_settings(&newton); }
+};
+
+// ---- stark::core::Callbacks (stark/src/core/Callbacks.h:13-84) + symx::SolverCallbacks (solver_utils.h:29-117) ------
+struct SolverCallbacks
+{
+    std::vector<std::function<void()>> before_energy_evaluation;
+    std::vector<std::function<bool()>> is_initial_state_valid, is_intermediate_state_valid, is_converged, is_converged_state_valid;
+    std::vector<std::function<void()>> on_intermediate_state_invalid, on_armijo_fail;
+    std::vector<std::function<double()>> max_allowed_step;
+    void add_before_energy_evaluation(std::function<void()> f) { before_energy_evaluation.push_back(f); }
+    void add_is_initial_state_valid(std::function<bool()> f) { is_initial_state_valid.push_back(f); }
+    void add_is_intermediate_state_valid(std::function<bool()> f) { is_intermediate_state_valid.push_back(f); }
+    void add_on_intermediate_state_invalid(std::function<void()> f) { on_intermediate_state_invalid.push_back(f); }
+    void add_on_armijo_fail(std::function<void()> f) { on_armijo_fail.push_back(f); }
+    void add_is_converged(std::function<bool()> f) { is_converged.push_back(f); }
+    void add_is_converged_state_valid(std::function<bool()> f) { is_converged_state_valid.push_back(f); }
+    void add_max_allowed_step(std::function<double()> f) { max_allowed_step.push_back(f); }
+};
+struct Callbacks
+{
+    std::shared_ptr<SolverCallbacks> newton = std::make_shared<SolverCallbacks>();
+    std::vector<std::function<void()>> before_simulation, before_time_step, after_time_step, on_time_step_accepted;
+    std::vector<std::function<bool()>> should_continue_execution;
+    void add_before_simulation(std::function<void()> f) { before_simulation.push_back(f); }
+    void add_before_time_step(std::function<void()> f) { before_time_step.push_back(f); }
+    void add_after_time_step(std::function<void()> f) { after_time_step.push_back(f); }
+    void add_on_time_step_accepted(std::function<void()> f) { on_time_step_accepted.push_back(f); }
+    void add_should_continue_execution(std::function<bool()> f) { should_continue_execution.push_back(f); }
+};
+
+// A model that owns host arrays / connectivity and (re)registers them with the engine (the reference's constructors call
+// global_potential->add_potential / add_dof once with lambdas; we call the C ABI with the current pointers and sizes).
+struct Registrable
+{
+    virtual ~Registrable() = default;
+    virtual void register_dofs(mistark_ctx* ctx) {}
+    virtual void register_potentials(mistark_ctx* ctx) {}
+};
+
+// ---- stark::core::Stark (stark/src/core/Stark.h:12-46, Stark.cpp:133-313) ---------------------------------------------
+class Stark
+{
+public:
+    Settings settings;  // (const in the reference; the Newton settings may be replaced between steps here)
+    mistark_ctx* ctx = nullptr;
+    std::shared_ptr<Callbacks> callbacks = std::make_shared<Callbacks>();
+    double current_time = 0.0;
+    int current_time_step = 0;
+    double dt = -1.0;        // bound by address into the potentials, like mws.make_scalar(stark.dt)
+    Vec3 gravity = {0.0, 0.0, -9.81};
+    mistark_newton_stats last_stats{};
+    int last_newton_result = MISTARK_RUNNING;
+    // accumulated over the run (the reference's Logger series)
+    long total_newton_iterations = 0, total_cg_iterations = 0, total_linear_solves = 0, failed_steps = 0;
+    double total_newton_time = 0.0, total_linear_solve_time = 0.0;
+
+    explicit Stark(const Settings& settings);
+    ~Stark();
+    Stark(const Stark&) = delete;
+    bool run_one_step();
+    bool run(double duration, std::function<void()> callback = nullptr);
+    void add_model(Registrable* m) { models.push_back(m); registration_dirty = true; }
+    void mark_registration_dirty() { registration_dirty = true; }
+    int dt_array() const { return dt_array_id; }
+    int gravity_array() const { return gravity_array_id; }
+    void ensure_registered();  // (re)register every model with the engine if anything changed
+    void check(int rc) const;  // throws std::runtime_error with mistark_last_error on rc < 0
+
+private:
+    std::vector<Registrable*> models;
+    bool is_init = false;
+    bool registration_dirty = true;
+    int dt_array_id = -1, gravity_array_id = -1;
+    double dt_uploaded = -1.0;
+    void _initialize();
+};
+
+// ---- stark::PointSetHandler / PointDynamics ------------------------------------------------------------------------------
+class PointDynamics;
+class PointSetHandler
+{
+    int idx = -1;
+    PointDynamics* dyn = nullptr;
+
+public:
+    PointSetHandler() = default;
+    PointSetHandler(PointDynamics* dyn, int idx) : idx(idx), dyn(dyn) {}
+    int get_idx() const { return idx; }
+    bool is_valid() const { return dyn != nullptr; }
+    int get_begin() const;
+    int get_end() const;
+    int size() const;
+    int get_global_index(int local_index) const;
+    template <std::size_t N>
+    std::array<int, N> get_global_indices(const std::array<int, N>& loc) const
+    {
+        std::array<int, N> g;
+        for (std::size_t i = 0; i < N; i++) g[i] = get_global_index(loc[i]);
+        return g;
+    }
+    std::vector<int> all() const;
+    Vec3 get_position(int local_index) const;
+    Vec3 get_rest_position(int local_index) const;
+};
+
+class PointDynamics : public Registrable
+{
+public:
+    // AoS arrays, all point sets concatenated (stark/src/models/deformables/PointDynamics.h:16-23)
+    std::vector<Vec3> X, x0, x1, v0, v1, a, f;
+    std::vector<int> set_begin;  // per set; set i = [set_begin[i], set_begin[i+1])
+    std::vector<std::string> labels;
+    // engine array ids (valid after registration)
+    int id_X = -1, id_x0 = -1, id_v0 = -1, id_v1 = -1, id_a = -1, id_f = -1, dof_set = -1;
+
+    explicit PointDynamics(Stark& stark);
+    PointSetHandler add(const std::vector<Vec3>& x, const std::string& label = "");
+    int size() const { return (int)X.size(); }
+    int get_begin(int s) const { return set_begin[s]; }
+    int get_end(int s) const { return set_begin[s + 1]; }
+    int get_global_index(int s, int local) const { return set_begin[s] + local; }
+    Vec3 get_x1(int global_index, double dt) const { return x0[global_index] + dt * v1[global_index]; }
+    void mirror_to_host();   // device -> host for x0, v0, v1 (x1 recomputed)
+    void upload_state();     // host -> device after the user edited positions / velocities / forces
+    void register_dofs(mistark_ctx* ctx) override;
+
+private:
+    Stark& stark;
+    void _before_time_step();
+    void _on_time_step_accepted();
+};
+using spPointDynamics = std::shared_ptr<PointDynamics>;
+
+// ---- energies ------------------------------------------------------------------------------------------------------------
+#define MISTARK_HANDLER(Model, ParamsT)                                              \
+    struct Handler                                                                   \
+    {                                                                                \
+        Model* model = nullptr;                                                      \
+        int idx = -1;                                                                \
+        Handler() = default;                                                         \
+        Handler(Model* m, int i) : model(m), idx(i) {}                               \
+        int get_idx() const { return idx; }                                          \
+        bool is_valid() const { return model != nullptr; }                           \
+        ParamsT get_params() const { return model->get_params(*this); }              \
+        void set_params(const ParamsT& p) { model->set_params(*this, p); }           \
+    };
+
+class EnergyLumpedInertia : public Registrable
+{
+public:
+    struct Params
+    {
+        double density = 1.0, damping = 0.0;
+        bool quasistatic = false;
+    };
+    MISTARK_HANDLER(EnergyLumpedInertia, Params)
+    EnergyLumpedInertia(Stark& stark, spPointDynamics dyn);
+    Handler add(const PointSetHandler& set, const std::vector<int>& points, const std::vector<double>& lumped_volume, const Params& params);
+    Handler add(const PointSetHandler& set, const std::vector<double>& lumped_volume, const Params& params);
+    Handler add(const PointSetHandler& set, const std::vector<std::array<int, 3>>& triangles, const Params& params);
+    Handler add(const PointSetHandler& set, const std::vector<std::array<int, 4>>& tets, const Params& params);
+    Params get_params(const Handler& h) const;
+    void set_params(const Handler& h, const Params& p);
+    double get_mass(const Handler& h) const;
+    void register_potentials(mistark_ctx* ctx) override;
+
+private:
+    Stark& stark;
+    spPointDynamics dyn;
+    std::vector<std::array<int32_t, 3>> conn;  // idx, glob, group
+    std::vector<double> density, damping, is_quasistatic, lumped_volume;
+    bool params_dirty = true;
+};
+
+class EnergyPrescribedPositions : public Registrable
+{
+public:
+    struct Params
+    {
+        double stiffness = 1e3;
+        double tolerance = std::numeric_limits<double>::max();
+    };
+    MISTARK_HANDLER(EnergyPrescribedPositions, Params)
+    EnergyPrescribedPositions(Stark& stark, spPointDynamics dyn);
+    Handler add(const PointSetHandler& set, const std::vector<int>& points, const Params& params);
+    Handler add_inside_aabb(const PointSetHandler& set, const Vec3& aabb_center, const Vec3& aabb_dim, const Params& params);
+    Params get_params(const Handler& h) const;
+    void set_params(const Handler& h, const Params& p);
+    void set_transformation(const Handler& h, const Vec3& t, const std::array<double, 9>& R);
+    void set_target_position(const Handler& h, int prescribed_idx, const Vec3& t);
+    void register_potentials(mistark_ctx* ctx) override;
+
+private:
+    Stark& stark;
+    spPointDynamics dyn;
+    std::vector<std::array<int32_t, 3>> conn;  // idx, point, group
+    std::vector<Vec3> target_positions, rest_positions;
+    std::vector<double> stiffness, tolerance;
+    std::vector<std::array<int, 2>> group_begin_end;
+    int id_target = -1, id_stiffness = -1;
+    bool targets_dirty = false, stiffness_dirty = false;
+    bool _is_converged_state_valid();
+    void _before_energy_evaluation();
+};
+
+class EnergyTetStrain : public Registrable
+{
+public:
+    struct Params
+    {
+        bool elasticity_only = false;
+        double scale = 1.0, youngs_modulus = 1e3, poissons_ratio = 0.3, damping = 0.0;
+        double strain_limit = std::numeric_limits<double>::max(), strain_limit_stiffness = 1e3;
+    };
+    MISTARK_HANDLER(EnergyTetStrain, Params)
+    EnergyTetStrain(Stark& stark, spPointDynamics dyn);
+    Handler add(const PointSetHandler& set, const std::vector<std::array<int, 4>>& tets, const Params& params);
+    Params get_params(const Handler& h) const;
+    void set_params(const Handler& h, const Params& p);
+    void register_potentials(mistark_ctx* ctx) override;
+
+private:
+    Stark& stark;
+    spPointDynamics dyn;
+    std::vector<std::array<int32_t, 6>> conn_elasticity_only, conn_complete;  // idx, group, i, j, k, l
+    std::vector<char> elasticity_only;
+    std::vector<double> scale, youngs_modulus, poissons_ratio, strain_damping, strain_limit, strain_limit_stiffness;
+};
+
+class EnergyTriangleStrain : public Registrable
+{
+public:
+    struct Params
+    {
+        bool elasticity_only = false;
+        double scale = 1.0, thickness = 1e-3, youngs_modulus = 1e3, poissons_ratio = 0.3, damping = 0.0;
+        double strain_limit = std::numeric_limits<double>::max(), strain_limit_stiffness = 1e3, inflation = 0.0;
+    };
+    MISTARK_HANDLER(EnergyTriangleStrain, Params)
+    EnergyTriangleStrain(Stark& stark, spPointDynamics dyn);
+    Handler add(const PointSetHandler& set, const std::vector<std::array<int, 3>>& triangles, const Params& params);
+    Params get_params(const Handler& h) const;
+    void set_params(const Handler& h, const Params& p);
+    void register_potentials(mistark_ctx* ctx) override;
+
+private:
+    Stark& stark;
+    spPointDynamics dyn;
+    std::vector<std::array<int32_t, 5>> conn_elasticity_only, conn_complete;  // idx, group, i, j, k
+    std::vector<char> elasticity_only;
+    std::vector<double> scale, thickness, youngs_modulus, poissons_ratio, strain_damping, strain_limit, strain_limit_stiffness, inflation;
+};
+
+class EnergyDiscreteShells : public Registrable
+{
+public:
+    struct Params
+    {
+        double scale = 1.0, stiffness = 1e3, damping = 0.0;
+        bool flat_rest_angle = false;
+    };
+    MISTARK_HANDLER(EnergyDiscreteShells, Params)
+    EnergyDiscreteShells(Stark& stark, spPointDynamics dyn);
+    Handler add(const PointSetHandler& set, const std::vector<std::array<int, 3>>& triangles, const Params& params);
+    Params get_params(const Handler& h) const;
+    void set_params(const Handler& h, const Params& p);
+    void register_potentials(mistark_ctx* ctx) override;
+
+private:
+    Stark& stark;
+    spPointDynamics dyn;
+    std::vector<std::array<int32_t, 6>> conn_flat_rest, conn_complete;  // idx, group, v0..v3
+    std::vector<double> scale, bending_stiffness, bending_damping;
+    std::vector<char> flat_rest_angle;
+    // per hinge (indexed by "idx"): the two tables share the index space of their own connectivity
+    std::vector<double> rest_dihedral_angle_rad, rest_edge_length, rest_height;  // complete
+    std::vector<double> bergou_coef;                                             // flat
+    std::vector<std::array<double, 4>> bergou_K;                                 // flat
+};
+
+// ---- stark::Deformables + presets + Simulation ---------------------------------------------------------------------------
+struct Deformables
+{
+    spPointDynamics point_sets;
+    std::shared_ptr<EnergyLumpedInertia> lumped_inertia;
+    std::shared_ptr<EnergyPrescribedPositions> prescribed_positions;
+    std::shared_ptr<EnergyTriangleStrain> triangle_strain;
+    std::shared_ptr<EnergyDiscreteShells> discrete_shells;
+    std::shared_ptr<EnergyTetStrain> tet_strain;
+    Deformables(Stark& stark, spPointDynamics dyn);
+};
+
+namespace Surface {
+struct Params
+{
+    EnergyLumpedInertia::Params inertia;
+    EnergyTriangleStrain::Params strain;
+    EnergyDiscreteShells::Params bending;
+    static Params Cotton_Fabric();  // stark/src/models/presets/deformables_preset_types.cpp:44-58
+};
+struct Handler
+{
+    PointSetHandler point_set;
+    EnergyLumpedInertia::Handler inertia;
+    EnergyTriangleStrain::Handler strain;
+    EnergyDiscreteShells::Handler bending;
+};
+struct VCH
+{
+    std::vector<Vec3> vertices;
+    std::vector<std::array<int, 3>> triangles;
+    Handler handler;
+};
+}  // namespace Surface
+namespace Volume {
+struct Params
+{
+    EnergyLumpedInertia::Params inertia;
+    EnergyTetStrain::Params strain;
+    static Params Soft_Rubber();  // stark/src/models/presets/deformables_preset_types.cpp:70-80
+};
+struct Handler
+{
+    PointSetHandler point_set;
+    EnergyLumpedInertia::Handler inertia;
+    EnergyTetStrain::Handler strain;
+};
+struct VCH
+{
+    std::vector<Vec3> vertices;
+    std::vector<std::array<int, 4>> tets;
+    Handler handler;
+};
+}  // namespace Volume
+
+class DeformablesPresets
+{
+    std::shared_ptr<Deformables> deformables;
+
+public:
+    explicit DeformablesPresets(std::shared_ptr<Deformables> d) : deformables(d) {}
+    Surface::Handler add_surface(const std::string& label, const std::vector<Vec3>& vertices, const std::vector<std::array<int, 3>>& triangles, const Surface::Params& params);
+    Surface::VCH add_surface_grid(const std::string& label, const std::array<double, 2>& dim, const std::array<int, 2>& subdivisions, const Surface::Params& params);
+    Volume::Handler add_volume(const std::string& label, const std::vector<Vec3>& vertices, const std::vector<std::array<int, 4>>& tets, const Volume::Params& params);
+    Volume::VCH add_volume_grid(const std::string& label, const Vec3& dim, const std::array<int, 3>& subdivisions, const Volume::Params& params);
+};
+struct Presets
+{
+    std::shared_ptr<DeformablesPresets> deformables;
+};
+
+class Simulation
+{
+    Stark stark;
+
+public:
+    std::shared_ptr<Deformables> deformables;
+    std::shared_ptr<Presets> presets;
+    explicit Simulation(const Settings& settings);
+    Stark& get_stark() { return stark; }
+    double get_time() const { return stark.current_time; }
+    double get_time_step_size() const { return stark.dt; }
+    void run_one_time_step() { stark.run_one_step(); }
+    void run(double duration, std::function<void()> cb = nullptr) { stark.run(duration, cb); }
+};
+
+}  // namespace mistark

@@ -1,0 +1,265 @@
+// host/sim_capi.cpp — extern "C" facade declared in include/mistark_sim.h
+#include <cstring>
+
+#include "../../../include/mistark_sim.h"
+#include "sim.hpp"
+
+using namespace mistark;
+
+struct mistark_sim
+{
+    std::unique_ptr<Simulation> sim;
+    std::vector<PointSetHandler> sets;
+    std::string last_error;
+};
+
+#define SIM_BEGIN        \
+    if (!s) return -1;   \
+    int _ret = 0;        \
+    (void)_ret;          \
+    try {
+#define SIM_END                      \
+    }                                \
+    catch (const std::exception& e)  \
+    {                                \
+        s->last_error = e.what();    \
+        return -1;                   \
+    }                                \
+    return _ret;
+
+static Volume::Params to_cpp(const mistark_volume_params& p)
+{
+    Volume::Params q;
+    q.inertia.density = p.density;
+    q.inertia.damping = p.inertia_damping;
+    q.inertia.quasistatic = p.quasistatic != 0;
+    q.strain.elasticity_only = p.elasticity_only != 0;
+    q.strain.scale = p.scale;
+    q.strain.youngs_modulus = p.youngs_modulus;
+    q.strain.poissons_ratio = p.poissons_ratio;
+    q.strain.damping = p.strain_damping;
+    q.strain.strain_limit = p.strain_limit;
+    q.strain.strain_limit_stiffness = p.strain_limit_stiffness;
+    return q;
+}
+static Surface::Params to_cpp(const mistark_surface_params& p)
+{
+    Surface::Params q;
+    q.inertia.density = p.density;
+    q.inertia.damping = p.inertia_damping;
+    q.inertia.quasistatic = p.quasistatic != 0;
+    q.strain.elasticity_only = p.elasticity_only != 0;
+    q.strain.scale = p.scale;
+    q.strain.thickness = p.thickness;
+    q.strain.youngs_modulus = p.youngs_modulus;
+    q.strain.poissons_ratio = p.poissons_ratio;
+    q.strain.damping = p.strain_damping;
+    q.strain.strain_limit = p.strain_limit;
+    q.strain.strain_limit_stiffness = p.strain_limit_stiffness;
+    q.strain.inflation = p.inflation;
+    q.bending.scale = p.scale;
+    q.bending.stiffness = p.bending_stiffness;
+    q.bending.damping = p.bending_damping;
+    q.bending.flat_rest_angle = p.flat_rest_angle != 0;
+    return q;
+}
+
+extern "C" {
+
+void mistark_sim_default_settings(mistark_sim_settings* s)
+{
+    if (!s) return;
+    Settings d;
+    for (int i = 0; i < 3; i++) s->gravity[i] = d.simulation.gravity[i];
+    s->max_time_step_size = d.simulation.max_time_step_size;
+    s->use_adaptive_time_step = d.simulation.use_adaptive_time_step;
+    s->time_step_size_success_multiplier = d.simulation.time_step_size_success_multiplier;
+    s->time_step_size_lower_bound = d.simulation.time_step_size_lower_bound;
+    s->device = 0;
+    s->mirror_state_to_host = 1;
+    s->enable_output = 0;
+    s->newton = d.newton;
+}
+void mistark_volume_params_soft_rubber(mistark_volume_params* p)
+{
+    if (!p) return;
+    const Volume::Params q = Volume::Params::Soft_Rubber();
+    p->density = q.inertia.density;
+    p->inertia_damping = q.inertia.damping;
+    p->quasistatic = q.inertia.quasistatic;
+    p->elasticity_only = q.strain.elasticity_only;
+    p->scale = q.strain.scale;
+    p->youngs_modulus = q.strain.youngs_modulus;
+    p->poissons_ratio = q.strain.poissons_ratio;
+    p->strain_damping = q.strain.damping;
+    p->strain_limit = q.strain.strain_limit;
+    p->strain_limit_stiffness = q.strain.strain_limit_stiffness;
+}
+void mistark_surface_params_cotton_fabric(mistark_surface_params* p)
+{
+    if (!p) return;
+    const Surface::Params q = Surface::Params::Cotton_Fabric();
+    p->density = q.inertia.density;
+    p->inertia_damping = q.inertia.damping;
+    p->quasistatic = q.inertia.quasistatic;
+    p->elasticity_only = q.strain.elasticity_only;
+    p->scale = q.strain.scale;
+    p->thickness = q.strain.thickness;
+    p->youngs_modulus = q.strain.youngs_modulus;
+    p->poissons_ratio = q.strain.poissons_ratio;
+    p->strain_damping = q.strain.damping;
+    p->strain_limit = q.strain.strain_limit;
+    p->strain_limit_stiffness = q.strain.strain_limit_stiffness;
+    p->inflation = q.strain.inflation;
+    p->bending_stiffness = q.bending.stiffness;
+    p->bending_damping = q.bending.damping;
+    p->flat_rest_angle = q.bending.flat_rest_angle;
+}
+
+int mistark_sim_create(const mistark_sim_settings* in, mistark_sim** out)
+{
+    if (!out) return -1;
+    *out = nullptr;
+    mistark_sim_settings d;
+    if (in) d = *in;
+    else mistark_sim_default_settings(&d);
+    Settings st;
+    for (int i = 0; i < 3; i++) st.simulation.gravity[i] = d.gravity[i];
+    st.simulation.max_time_step_size = d.max_time_step_size;
+    st.simulation.use_adaptive_time_step = d.use_adaptive_time_step != 0;
+    st.simulation.time_step_size_success_multiplier = d.time_step_size_success_multiplier;
+    st.simulation.time_step_size_lower_bound = d.time_step_size_lower_bound;
+    st.execution.device = d.device;
+    st.execution.mirror_state_to_host = d.mirror_state_to_host != 0;
+    st.output.enable_output = d.enable_output != 0;
+    st.newton = d.newton;
+    auto* s = new mistark_sim();
+    try {
+        s->sim = std::make_unique<Simulation>(st);
+    } catch (const std::exception&) {
+        delete s;
+        return -1;
+    }
+    *out = s;
+    return 0;
+}
+void mistark_sim_destroy(mistark_sim* s) { delete s; }
+const char* mistark_sim_last_error(mistark_sim* s) { return s ? s->last_error.c_str() : "null sim"; }
+
+int mistark_sim_add_volume_grid(mistark_sim* s, const char* label, const double center[3], const double dim[3], const int32_t sub[3], const mistark_volume_params* p)
+{
+    SIM_BEGIN
+    std::vector<Vec3> V;
+    std::vector<std::array<int, 4>> T;
+    generate_tet_grid(V, T, {center[0], center[1], center[2]}, {dim[0], dim[1], dim[2]}, {sub[0], sub[1], sub[2]});
+    auto h = s->sim->presets->deformables->add_volume(label ? label : "", V, T, to_cpp(*p));
+    s->sets.push_back(h.point_set);
+    _ret = (int)s->sets.size() - 1;
+    SIM_END
+}
+int mistark_sim_add_volume(mistark_sim* s, const char* label, const double* v, int64_t nv, const int32_t* t, int64_t nt, const mistark_volume_params* p)
+{
+    SIM_BEGIN
+    std::vector<Vec3> V((size_t)nv);
+    std::vector<std::array<int, 4>> T((size_t)nt);
+    for (int64_t i = 0; i < nv; i++) V[i] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+    for (int64_t i = 0; i < nt; i++) T[i] = {t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]};
+    auto h = s->sim->presets->deformables->add_volume(label ? label : "", V, T, to_cpp(*p));
+    s->sets.push_back(h.point_set);
+    _ret = (int)s->sets.size() - 1;
+    SIM_END
+}
+int mistark_sim_add_surface_grid(mistark_sim* s, const char* label, const double dim[2], const int32_t sub[2], const mistark_surface_params* p)
+{
+    SIM_BEGIN
+    auto vch = s->sim->presets->deformables->add_surface_grid(label ? label : "", {dim[0], dim[1]}, {sub[0], sub[1]}, to_cpp(*p));
+    s->sets.push_back(vch.handler.point_set);
+    _ret = (int)s->sets.size() - 1;
+    SIM_END
+}
+int mistark_sim_add_surface(mistark_sim* s, const char* label, const double* v, int64_t nv, const int32_t* t, int64_t nt, const mistark_surface_params* p)
+{
+    SIM_BEGIN
+    std::vector<Vec3> V((size_t)nv);
+    std::vector<std::array<int, 3>> T((size_t)nt);
+    for (int64_t i = 0; i < nv; i++) V[i] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+    for (int64_t i = 0; i < nt; i++) T[i] = {t[3 * i], t[3 * i + 1], t[3 * i + 2]};
+    auto h = s->sim->presets->deformables->add_surface(label ? label : "", V, T, to_cpp(*p));
+    s->sets.push_back(h.point_set);
+    _ret = (int)s->sets.size() - 1;
+    SIM_END
+}
+int mistark_sim_prescribe_inside_aabb(mistark_sim* s, int ps, const double c[3], const double d[3], double stiffness, double tolerance)
+{
+    SIM_BEGIN
+    if (ps < 0 || ps >= (int)s->sets.size()) throw std::runtime_error("bad point set");
+    EnergyPrescribedPositions::Params p;
+    p.stiffness = stiffness;
+    p.tolerance = tolerance > 0.0 ? tolerance : std::numeric_limits<double>::max();
+    auto h = s->sim->deformables->prescribed_positions->add_inside_aabb(s->sets[ps], {c[0], c[1], c[2]}, {d[0], d[1], d[2]}, p);
+    _ret = h.get_idx();
+    SIM_END
+}
+int mistark_sim_set_newton_settings(mistark_sim* s, const mistark_newton_settings* ns)
+{
+    SIM_BEGIN
+    s->sim->get_stark().settings.newton = *ns;
+    SIM_END
+}
+int mistark_sim_run_one_step(mistark_sim* s)
+{
+    SIM_BEGIN
+    _ret = s->sim->get_stark().run_one_step() ? 1 : 0;
+    SIM_END
+}
+int mistark_sim_prepare(mistark_sim* s)
+{
+    SIM_BEGIN
+    s->sim->get_stark().ensure_registered();
+    SIM_END
+}
+mistark_ctx* mistark_sim_engine(mistark_sim* s) { return s ? s->sim->get_stark().ctx : nullptr; }
+
+int mistark_sim_get_info(mistark_sim* s, mistark_sim_info* info)
+{
+    SIM_BEGIN
+    Stark& st = s->sim->get_stark();
+    info->current_time = st.current_time;
+    info->dt = st.dt;
+    info->current_time_step = st.current_time_step;
+    info->last_newton_result = st.last_newton_result;
+    info->n_points = s->sim->deformables->point_sets->size();
+    info->ndofs = st.ctx ? mistark_ndofs(st.ctx) : 3 * info->n_points;
+    info->total_newton_iterations = st.total_newton_iterations;
+    info->total_cg_iterations = st.total_cg_iterations;
+    info->total_linear_solves = st.total_linear_solves;
+    info->failed_steps = st.failed_steps;
+    info->total_newton_time = st.total_newton_time;
+    info->total_linear_solve_time = st.total_linear_solve_time;
+    info->last_stats = st.last_stats;
+    SIM_END
+}
+int mistark_sim_get_points(mistark_sim* s, int which, double* out)
+{
+    SIM_BEGIN
+    PointDynamics& pd = *s->sim->deformables->point_sets;
+    if (which != 0 && s->sim->get_stark().ctx) pd.mirror_to_host();
+    const std::vector<Vec3>* src = which == 0 ? &pd.X : which == 1 ? &pd.x0 : which == 2 ? &pd.v0 : which == 3 ? &pd.v1 : nullptr;
+    if (!src) throw std::runtime_error("bad array selector");
+    if (!src->empty()) std::memcpy(out, (*src)[0].data(), src->size() * sizeof(Vec3));
+    SIM_END
+}
+int mistark_sim_set_points(mistark_sim* s, int which, const double* in)
+{
+    SIM_BEGIN
+    PointDynamics& pd = *s->sim->deformables->point_sets;
+    std::vector<Vec3>* dst = which == 1 ? &pd.x0 : which == 2 ? &pd.v0 : nullptr;
+    if (!dst) throw std::runtime_error("bad array selector");
+    if (s->sim->get_stark().ctx) pd.mirror_to_host();
+    if (!dst->empty()) std::memcpy((*dst)[0].data(), in, dst->size() * sizeof(Vec3));
+    if (which == 1) pd.x1 = pd.x0;
+    if (s->sim->get_stark().ctx) pd.upload_state();
+    SIM_END
+}
+
+}  // extern "C"

@@ -1,0 +1,172 @@
+"""ctypes binding of the scene-level C facade (include/mistark_sim.h) over the C++ host mirror of stark::Simulation."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+class SimSettings(C.Structure):
+    _fields_ = [("gravity", C.c_double * 3), ("max_time_step_size", C.c_double), ("use_adaptive_time_step", C.c_int32),
+                ("time_step_size_success_multiplier", C.c_double), ("time_step_size_lower_bound", C.c_double), ("device", C.c_int32),
+                ("mirror_state_to_host", C.c_int32), ("enable_output", C.c_int32), ("newton", capi.NewtonSettings)]
+
+
+class VolumeParams(C.Structure):
+    _fields_ = [("density", C.c_double), ("inertia_damping", C.c_double), ("quasistatic", C.c_int32), ("elasticity_only", C.c_int32), ("scale", C.c_double),
+                ("youngs_modulus", C.c_double), ("poissons_ratio", C.c_double), ("strain_damping", C.c_double), ("strain_limit", C.c_double),
+                ("strain_limit_stiffness", C.c_double)]
+
+
+class SurfaceParams(C.Structure):
+    _fields_ = [("density", C.c_double), ("inertia_damping", C.c_double), ("quasistatic", C.c_int32), ("elasticity_only", C.c_int32), ("scale", C.c_double),
+                ("thickness", C.c_double), ("youngs_modulus", C.c_double), ("poissons_ratio", C.c_double), ("strain_damping", C.c_double),
+                ("strain_limit", C.c_double), ("strain_limit_stiffness", C.c_double), ("inflation", C.c_double), ("bending_stiffness", C.c_double),
+                ("bending_damping", C.c_double), ("flat_rest_angle", C.c_int32)]
+
+
+class SimInfo(C.Structure):
+    _fields_ = [("current_time", C.c_double), ("dt", C.c_double), ("current_time_step", C.c_int32), ("last_newton_result", C.c_int32), ("n_points", C.c_int64),
+                ("ndofs", C.c_int64), ("total_newton_iterations", C.c_int64), ("total_cg_iterations", C.c_int64), ("total_linear_solves", C.c_int64),
+                ("failed_steps", C.c_int64), ("total_newton_time", C.c_double), ("total_linear_solve_time", C.c_double), ("last_stats", capi.NewtonStats)]
+
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    L = capi.lib()
+    if not _bound:
+        p = C.c_void_p
+        L.mistark_sim_default_settings.argtypes = [C.POINTER(SimSettings)]
+        L.mistark_sim_default_settings.restype = None
+        L.mistark_volume_params_soft_rubber.argtypes = [C.POINTER(VolumeParams)]
+        L.mistark_volume_params_soft_rubber.restype = None
+        L.mistark_surface_params_cotton_fabric.argtypes = [C.POINTER(SurfaceParams)]
+        L.mistark_surface_params_cotton_fabric.restype = None
+        L.mistark_sim_create.argtypes = [C.POINTER(SimSettings), C.POINTER(p)]
+        L.mistark_sim_destroy.argtypes = [p]
+        L.mistark_sim_destroy.restype = None
+        L.mistark_sim_last_error.argtypes = [p]
+        L.mistark_sim_last_error.restype = C.c_char_p
+        L.mistark_sim_add_volume_grid.argtypes = [p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(VolumeParams)]
+        L.mistark_sim_add_volume.argtypes = [p, C.c_char_p, p, C.c_int64, p, C.c_int64, C.POINTER(VolumeParams)]
+        L.mistark_sim_add_surface_grid.argtypes = [p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(SurfaceParams)]
+        L.mistark_sim_add_surface.argtypes = [p, C.c_char_p, p, C.c_int64, p, C.c_int64, C.POINTER(SurfaceParams)]
+        L.mistark_sim_prescribe_inside_aabb.argtypes = [p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double]
+        L.mistark_sim_run_one_step.argtypes = [p]
+        L.mistark_sim_set_newton_settings.argtypes = [p, C.POINTER(capi.NewtonSettings)]
+        L.mistark_sim_prepare.argtypes = [p]
+        L.mistark_sim_engine.argtypes = [p]
+        L.mistark_sim_engine.restype = p
+        L.mistark_sim_get_info.argtypes = [p, C.POINTER(SimInfo)]
+        L.mistark_sim_get_points.argtypes = [p, C.c_int, p]
+        L.mistark_sim_set_points.argtypes = [p, C.c_int, p]
+        _bound = True
+    return L
+
+
+def default_settings() -> SimSettings:
+    s = SimSettings()
+    _lib().mistark_sim_default_settings(C.byref(s))
+    return s
+
+
+def soft_rubber() -> VolumeParams:
+    p = VolumeParams()
+    _lib().mistark_volume_params_soft_rubber(C.byref(p))
+    return p
+
+
+def cotton_fabric() -> SurfaceParams:
+    p = SurfaceParams()
+    _lib().mistark_surface_params_cotton_fabric(C.byref(p))
+    return p
+
+
+def _d3(v):
+    return (C.c_double * len(v))(*[float(x) for x in v])
+
+
+def _i3(v):
+    return (C.c_int32 * len(v))(*[int(x) for x in v])
+
+
+class SimError(RuntimeError):
+    pass
+
+
+class Simulation:
+    """Mirror of stark::Simulation for the hot-path subset (deformables + presets)."""
+
+    def __init__(self, settings: SimSettings | None = None):
+        self.L = _lib()
+        h = C.c_void_p()
+        s = settings if settings is not None else default_settings()
+        if self.L.mistark_sim_create(C.byref(s), C.byref(h)) != 0:
+            raise SimError("mistark_sim_create failed")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.L.mistark_sim_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise SimError(self.L.mistark_sim_last_error(self.h).decode())
+        return rc
+
+    def add_volume_grid(self, label, center, dim, subdivisions, params: VolumeParams) -> int:
+        return self._ck(self.L.mistark_sim_add_volume_grid(self.h, label.encode(), _d3(center), _d3(dim), _i3(subdivisions), C.byref(params)))
+
+    def add_surface_grid(self, label, dim, subdivisions, params: SurfaceParams) -> int:
+        return self._ck(self.L.mistark_sim_add_surface_grid(self.h, label.encode(), _d3(dim), _i3(subdivisions), C.byref(params)))
+
+    def prescribe_inside_aabb(self, point_set, center, dim, stiffness, tolerance=0.0) -> int:
+        return self._ck(self.L.mistark_sim_prescribe_inside_aabb(self.h, point_set, _d3(center), _d3(dim), stiffness, tolerance))
+
+    def set_newton_settings(self, s: capi.NewtonSettings):
+        self._ck(self.L.mistark_sim_set_newton_settings(self.h, C.byref(s)))
+
+    def run_one_step(self) -> bool:
+        return self._ck(self.L.mistark_sim_run_one_step(self.h)) == 1
+
+    def prepare(self):
+        self._ck(self.L.mistark_sim_prepare(self.h))
+
+    def info(self) -> SimInfo:
+        i = SimInfo()
+        self._ck(self.L.mistark_sim_get_info(self.h, C.byref(i)))
+        return i
+
+    def points(self, which="x0") -> np.ndarray:
+        sel = {"X": 0, "x0": 1, "v0": 2, "v1": 3}[which]
+        n = self.info().n_points
+        out = np.zeros((n, 3))
+        self._ck(self.L.mistark_sim_get_points(self.h, sel, out.ctypes.data))
+        return out
+
+    def set_points(self, which, arr):
+        sel = {"x0": 1, "v0": 2}[which]
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        self._ck(self.L.mistark_sim_set_points(self.h, sel, arr.ctypes.data))
+
+    def engine_handle(self):
+        return C.c_void_p(self.L.mistark_sim_engine(self.h))
+
+    def spmv_timing(self, reset=0):
+        ms, n, b = C.c_double(), C.c_int64(), C.c_double()
+        rc = self.L.mistark_spmv_timing(self.engine_handle(), reset, C.byref(ms), C.byref(n), C.byref(b))
+        if rc < 0:
+            raise SimError("spmv_timing failed")
+        return ms.value, n.value, b.value
