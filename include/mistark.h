@@ -212,6 +212,12 @@ typedef struct mistark_newton_callbacks
 int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settings, const mistark_newton_callbacks* callbacks,
                          mistark_newton_stats* stats);
 
+/* ---- options --------------------------------------------------------------------------------------------------------- */
+/* Engine switches (all default 0): "force_generic" = evaluate every potential through the generic hyper-dual kernels (the
+ * closed-form tet kernels are then cross-checked against them); "atomic_assembly" = scatter assembly with float atomics
+ * instead of the deterministic gather. Returns 0, or < 0 for an unknown name. */
+int mistark_set_option(mistark_ctx* ctx, const char* name, int value);
+
 /* ---- timers ------------------------------------------------------------------------------------------------------- */
 /* Average duration in ms of the SpMV kernel over the launches since the last reset, measured with HIP events on the
  * engine's stream; n = number of launches measured. Used by bench.py for the roofline figure. */

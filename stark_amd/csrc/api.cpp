@@ -309,7 +309,7 @@ int mistark_get_element_hessians(mistark_ctx* ctx, int potential, double* values
                 for (int b = 0; b < NB; b++)
                     for (int i = 0; i < 3; i++)
                         for (int j = 0; j < 3; j++)
-                            values[((size_t)e * n + 3 * a + i) * n + 3 * b + j] = tmp[(size_t)e * n * n + (a * NB + b) * 9 + i * 3 + j];
+                            values[((size_t)e * n + 3 * a + i) * n + 3 * b + j] = tmp[((size_t)(a * NB + b) * P.n_elem + e) * 9 + i * 3 + j];
     }
     if (block_rows) {
         for (int e = 0; e < P.n_elem; e++)
@@ -476,6 +476,16 @@ int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settin
     const int r = newton_solve(ctx->c, s, callbacks, st);
     if (stats) *stats = st;
     return r;
+    API_END(0)
+}
+
+int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
+{
+    API_BEGIN
+    const std::string n = name ? name : "";
+    if (n == "force_generic") ctx->c.force_generic = value != 0;
+    else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;
+    else throw Error("unknown option '" + n + "'");
     API_END(0)
 }
 

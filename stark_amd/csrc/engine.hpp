@@ -151,7 +151,11 @@ struct Context
     DevBuf<uint64_t> keys, keys_alt;
     DevBuf<uint32_t> kidx, kidx_alt;
     DevBuf<uint32_t> slot_of_src;  // per element block -> BSR slot
-    DevBuf<uint32_t> scan;
+    DevBuf<uint32_t> scan, slot_start;
+    const uint32_t* sorted_src = nullptr;  // source (element block) ids in sorted key order (one of kidx / kidx_alt)
+    size_t n_hess_blocks = 0;
+    bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather
+    bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path
     DevBuf<uint8_t> cub_tmp;
     int64_t nnzb = 0, ntiles = 0;
     DevBuf<uint32_t> colw;          // bit31 = last block of its row, bits 0..30 = block column

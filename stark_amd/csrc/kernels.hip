@@ -14,6 +14,7 @@
 
 #include "engine.hpp"
 #include "registry.hpp"
+#include "tet_closed.hpp"
 
 namespace mistark {
 
@@ -106,7 +107,8 @@ __global__ __launch_bounds__(BLOCK) void k_eval_p(PotArgs a, double* __restrict_
 }
 
 // Energy + gradient + Hessian: one lane per (element, i<=j) pair of local DoFs.
-// Element Hessians are stored block-major: H[e][a][b][3][3] (a, b local DoF blocks) so that assembly reads 72 contiguous bytes.
+// Element Hessians are stored per potential as H[a*NB+b][e][3][3]: one 72-byte row-major 3x3 block per (block pair, element);
+// consecutive elements are contiguous (coalescing-friendly stores) and assembly gathers whole 72-byte blocks.
 template <class En, bool STORE_H>
 __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
 {
@@ -129,15 +131,45 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
     const HDual r = En::energy(L);
     const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
     if (STORE_H) {
-        double* H = elemH + (size_t)e * n * n;
-        H[(ba * NB + bb) * 9 + ii * 3 + jj] = r.ab;
-        H[(bb * NB + ba) * 9 + jj * 3 + ii] = r.ab;
+        elemH[((size_t)(ba * NB + bb) * a.n_elem + e) * 9 + ii * 3 + jj] = r.ab;
+        elemH[((size_t)(bb * NB + ba) * a.n_elem + e) * 9 + jj * 3 + ii] = r.ab;
     }
     if (i == j) {
         const int row = a.dof_row_off[ba] + a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];
         atomicAdd(&grad[3 * (size_t)row + ii], r.a);
     }
     if (first) elemE[e] = r.v;
+}
+
+// Closed-form tet kernels (tet_closed.hpp): one lane per tet, 12 gradient atomics, 16 coalescing-friendly block stores
+template <class En, bool FULL, bool STORE_H>
+__global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
+{
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= a.n_elem) return;
+    double in[En::Layout::NIN];
+    gather_inputs<En>(a, e, in);
+    double E, g[12];
+    tet_closed_eval<FULL>(in, E, g, STORE_H ? elemH + (size_t)e * 9 : nullptr, (size_t)a.n_elem * 9, STORE_H);
+    elemE[e] = E;
+    const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const size_t row = (size_t)(a.dof_row_off[k] + ce[a.dof_col[k]]);
+        atomicAdd(&grad[3 * row], g[3 * k]);
+        atomicAdd(&grad[3 * row + 1], g[3 * k + 1]);
+        atomicAdd(&grad[3 * row + 2], g[3 * k + 2]);
+    }
+}
+template <class En, bool FULL>
+static void launch_tet_closed(Context& c, Potential& P, int mode)
+{
+    if (P.n_elem == 0) return;
+    double* E = c.elemE.p + P.e_off;
+    if (mode == MISTARK_EVAL_P_G)
+        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, false>), dim3(grid_for(P.n_elem)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
+    else
+        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, true>), dim3(grid_for(P.n_elem)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
 }
 
 template <class En>
@@ -157,6 +189,10 @@ static void launch_eval(Context& c, Potential& P, int mode)
 
 static void launch_eval_kind(Context& c, Potential& P, int mode)
 {
+    if (mode != MISTARK_EVAL_P && !c.force_generic) {
+        if (P.name == E_TetStrain::name) { launch_tet_closed<E_TetStrain, true>(c, P, mode); return; }
+        if (P.name == E_TetStrainEO::name) { launch_tet_closed<E_TetStrainEO, false>(c, P, mode); return; }
+    }
     int k = 0;
 #define X(En)                               \
     if (P.kind == k) { launch_eval<En>(c, P, mode); return; } \
@@ -311,8 +347,9 @@ __global__ __launch_bounds__(BLOCK) void k_keys(PotArgs a, int NB, uint64_t nbr,
     const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
     const uint64_t ra = a.dof_row_off[ba] + ce[a.dof_col[ba]];
     const uint64_t rb = a.dof_row_off[bb] + ce[a.dof_col[bb]];
-    keys[k_off + t] = ra * nbr + rb;
-    idx[k_off + t] = k_off + (uint32_t)t;
+    const uint32_t src = k_off + (uint32_t)ab * (uint32_t)a.n_elem + (uint32_t)e;  // = index of the element block in the Hessian pool
+    keys[src] = ra * nbr + rb;
+    idx[src] = src;
 }
 __global__ __launch_bounds__(BLOCK) void k_diag_keys(uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t k_off)
 {
@@ -330,14 +367,16 @@ __global__ __launch_bounds__(BLOCK) void k_heads(const uint64_t* __restrict__ ke
 // scan = inclusive prefix of heads. slot = scan-1.
 __global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ scan, size_t n,
                                                  uint64_t nbr, uint32_t* __restrict__ slot_of_src, uint32_t* __restrict__ colw, int32_t* __restrict__ row_cnt,
-                                                 int32_t* __restrict__ diag_slot, int32_t* __restrict__ tile_first_row)
+                                                 int32_t* __restrict__ diag_slot, int32_t* __restrict__ tile_first_row, uint32_t* __restrict__ slot_start)
 {
     const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n) return;
     const uint32_t slot = scan[k] - 1;
     slot_of_src[idx[k]] = slot;
     const bool head = (k == 0 || keys[k] != keys[k - 1]);
+    if (k == n - 1) slot_start[slot + 1] = (uint32_t)n;
     if (head) {
+        slot_start[slot] = (uint32_t)k;
         const uint64_t key = keys[k];
         const uint32_t row = (uint32_t)(key / nbr), col = (uint32_t)(key % nbr);
         // last block of its row <=> the next distinct key belongs to another row
@@ -411,8 +450,11 @@ static void build_pattern(Context& c)
     c.dinv.ensure((size_t)c.nbr * 9);
     MS_CHECK(hipMemsetAsync(c.row_cnt.p, 0, ((size_t)c.nbr + 1) * sizeof(int32_t), c.stream));
     MS_CHECK(hipMemsetAsync(c.colw.p, 0, (size_t)c.ntiles * 64 * sizeof(uint32_t), c.stream));
+    c.slot_start.ensure((size_t)c.nnzb + 1);
     hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, c.scan.p, nk, (uint64_t)c.nbr, c.slot_of_src.p, c.colw.p, c.row_cnt.p,
-                       c.diag_slot.p, c.tile_first_row.p);
+                       c.diag_slot.p, c.tile_first_row.p, c.slot_start.p);
+    c.sorted_src = sidx;
+    c.n_hess_blocks = diag_off;
     // row_ptr = exclusive scan of the per-row block counts
     int32_t* excl = (int32_t*)heads;  // reuse
     size_t tmp3 = 0;
@@ -553,11 +595,12 @@ __global__ __launch_bounds__(64) void k_project(double* __restrict__ elemH, int 
     is_projected[e] = 1;
     atomicAdd((unsigned long long*)&counters[0], 1ull);
     double A[n][n], V[n][n];
-    double* H = elemH + (size_t)e * n * n;
+    double* H = elemH + (size_t)e * 9;
+    const size_t hs = (size_t)n_elem * 9;
     for (int ba = 0; ba < NB; ba++)
         for (int bb = 0; bb < NB; bb++)
             for (int ii = 0; ii < 3; ii++)
-                for (int jj = 0; jj < 3; jj++) A[3 * ba + ii][3 * bb + jj] = H[(ba * NB + bb) * 9 + ii * 3 + jj];
+                for (int jj = 0; jj < 3; jj++) A[3 * ba + ii][3 * bb + jj] = H[(ba * NB + bb) * hs + ii * 3 + jj];
     double fro = 0.0;
     for (int i = 0; i < n; i++)
         for (int j = 0; j < n; j++) {
@@ -615,7 +658,7 @@ __global__ __launch_bounds__(64) void k_project(double* __restrict__ elemH, int 
                     const int i = 3 * ba + ii, j = 3 * bb + jj;
                     double s = 0.0;
                     for (int k = 0; k < n; k++) s += V[i][k] * lam[k] * V[j][k];
-                    H[(ba * NB + bb) * 9 + ii * 3 + jj] = s;
+                    H[(ba * NB + bb) * hs + ii * 3 + jj] = s;
                 }
 }
 
@@ -715,12 +758,36 @@ __global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __res
     o[5] = o[7];
 }
 
+// Gather assembly (default): one lane per (BSR block, component) sums the contributions of that block in the fixed order of
+// the sorted pattern keys: no atomics, deterministic, double accumulation rounded once to float; 9 consecutive lanes read the
+// 72 contiguous bytes of an element block.
+__global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restrict__ elemH, uint32_t n_hess_blocks, const uint32_t* __restrict__ slot_start,
+                                                           const uint32_t* __restrict__ sorted_src, int64_t nnzb, float* __restrict__ vals)
+{
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= nnzb * 9) return;
+    const uint32_t slot = (uint32_t)(t / 9);
+    const int comp = (int)(t - (int64_t)slot * 9);
+    const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1];
+    double acc = 0.0;
+    for (uint32_t k = k0; k < k1; k++) {
+        const uint32_t src = sorted_src[k];
+        if (src < n_hess_blocks) acc += elemH[(size_t)src * 9 + comp];  // (the always-present diagonal keys carry no data)
+    }
+    vals[tile_val_index(slot, comp)] = (float)acc;
+}
+
 void assemble(Context& c)
 {
     if (!c.have_hessians) throw Error("assemble: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
-    MS_CHECK(hipMemsetAsync(c.vals.p, 0, (size_t)c.ntiles * 576 * sizeof(float), c.stream));
     const int64_t nblk = (int64_t)(c.hess_total / 9);
-    if (nblk > 0) hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, nblk, c.slot_of_src.p, c.vals.p);
+    if (c.atomic_assembly) {
+        MS_CHECK(hipMemsetAsync(c.vals.p, 0, (size_t)c.ntiles * 576 * sizeof(float), c.stream));
+        if (nblk > 0) hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, nblk, c.slot_of_src.p, c.vals.p);
+    } else {
+        hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(c.nnzb * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, (uint32_t)c.n_hess_blocks, c.slot_start.p, c.sorted_src,
+                           c.nnzb, c.vals.p);
+    }
     c.have_matrix = true;
 }
 void build_preconditioner(Context& c)

@@ -172,6 +172,9 @@ class Engine:
         rc = self._ck(self.L.mistark_newton_solve(self.h, C.byref(s), C.byref(callbacks) if callbacks is not None else None, C.byref(st)))
         return capi.SOLVER_RETURN[rc], st
 
+    def set_option(self, name: str, value: int):
+        self._ck(self.L.mistark_set_option(self.h, name.encode(), int(value)))
+
     def spmv_timing(self, reset=0):
         ms, n, b = C.c_double(), C.c_int64(), C.c_double()
         self._ck(self.L.mistark_spmv_timing(self.h, reset, C.byref(ms), C.byref(n), C.byref(b)))

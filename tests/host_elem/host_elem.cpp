@@ -3,6 +3,7 @@
 // without a GPU. Not part of the product library.
 #include <cstring>
 #include "../../stark_amd/csrc/registry.hpp"
+#include "../../stark_amd/csrc/tet_closed.hpp"
 
 using namespace mistark;
 
@@ -48,4 +49,20 @@ extern "C" int host_elem_eval(const char* name, const double* in, int n_elem, do
     MISTARK_FOR_EACH_ENERGY(X)
 #undef X
     return -1;
+}
+
+// closed-form tet kernels (stark_amd/csrc/tet_closed.hpp); H returned row-major 12x12 like host_elem_eval
+extern "C" int host_tet_closed_eval(int full, const double* in, int n_elem, double* E, double* g, double* H)
+{
+    const int NIN = full ? E_TetStrain::Layout::NIN : E_TetStrainEO::Layout::NIN;
+    for (int e = 0; e < n_elem; e++) {
+        double Hb[144];
+        if (full) tet_closed_eval<true>(in + (size_t)e * NIN, E[e], g + 12 * (size_t)e, Hb, 9, true);
+        else tet_closed_eval<false>(in + (size_t)e * NIN, E[e], g + 12 * (size_t)e, Hb, 9, true);
+        for (int a = 0; a < 4; a++)
+            for (int b = 0; b < 4; b++)
+                for (int i = 0; i < 3; i++)
+                    for (int k = 0; k < 3; k++) H[((size_t)e * 12 + 3 * a + i) * 12 + 3 * b + k] = Hb[(a * 4 + b) * 9 + 3 * i + k];
+    }
+    return 0;
 }

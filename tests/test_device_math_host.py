@@ -26,6 +26,7 @@ def host_lib():
     lib = ctypes.CDLL(out)
     lib.host_elem_eval.argtypes = [ctypes.c_char_p] + [ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3
     lib.host_elem_info.argtypes = [ctypes.c_char_p] + [ctypes.c_void_p] * 5
+    lib.host_tet_closed_eval.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int] + [ctypes.c_void_p] * 3
     return lib
 
 
@@ -73,5 +74,33 @@ def test_host_build_of_device_energies_matches_reference(host_lib, path):
         np.add.at(gs, idx.reshape(-1), g.reshape(-1))
         # (a gradient that cancels to round-off, e.g. flat cloth bending at rest, is compared on the Hessian's scale)
         assert np.abs(gs - gref).max() <= tol * np.abs(gref).max() + 1e-13 * np.abs(Href).max(), pot.name
+        checked += 1
+    assert checked > 0
+
+
+@pytest.mark.parametrize("path", [p for p in DUMPS if "tet" in os.path.basename(p)], ids=lambda p: os.path.basename(p)[:-4])
+def test_closed_form_tet_matches_reference(host_lib, path):
+    """Hand-derived closed-form tet energy/gradient/Hessian (tet_closed.hpp) vs the reference's generated kernels."""
+    prob, man, z = ev.load_fixture(path)
+    checked = 0
+    for pi, (pot, ref) in enumerate(zip(prob.potentials, man["potentials"])):
+        if not pot.name.startswith("EnergyTetStrain") or pot.conn.shape[0] == 0:
+            continue
+        full = 0 if pot.name.endswith("Elasticity_Only") else 1
+        n_elem = pot.conn.shape[0]
+        inp = gather_inputs(prob, pot)
+        E = np.zeros(n_elem)
+        g = np.zeros((n_elem, 12))
+        H = np.zeros((n_elem, 12, 12))
+        assert host_lib.host_tet_closed_eval(full, inp.ctypes.data, n_elem, E.ctypes.data, g.ctypes.data, H.ctypes.data) == 0
+        assert abs(E.sum() - ref["E"]) <= 1e-11 * max(1.0, np.abs(E).sum())
+        Href = z["p%d_hvals" % pi]
+        assert np.abs(H - Href).max() <= 1e-11 * np.abs(Href).max()
+        o = ev.evaluate_potential(prob, pot)
+        gs = np.zeros(prob.ndofs)
+        idx = (3 * o.block_rows[:, :, None] + np.arange(3)[None, None, :]).reshape(n_elem, 12)
+        np.add.at(gs, idx.reshape(-1), g.reshape(-1))
+        gref = z["p%d_grad" % pi]
+        assert np.abs(gs - gref).max() <= 1e-11 * np.abs(gref).max() + 1e-13 * np.abs(Href).max()
         checked += 1
     assert checked > 0
