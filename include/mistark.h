@@ -222,6 +222,8 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value);
 /* Average duration in ms of the SpMV kernel over the launches since the last reset, measured with HIP events on the
  * engine's stream; n = number of launches measured. Used by bench.py for the roofline figure. */
 int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n, double* bytes_per_launch);
+/* Micro-benchmark: n back-to-back SpMV launches on the currently assembled matrix, average duration in microseconds. */
+int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us);
 
 #ifdef __cplusplus
 }

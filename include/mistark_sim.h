@@ -72,6 +72,8 @@ typedef struct mistark_sim_info
     int64_t n_points, ndofs;
     int64_t total_newton_iterations, total_cg_iterations, total_linear_solves, failed_steps;
     double total_newton_time, total_linear_solve_time;
+    double total_eval_pgh_time, total_eval_p_time, total_project_time, total_assembly_time, total_callback_time, total_step_time;
+    int64_t total_evaluations;
     mistark_newton_stats last_stats;
 } mistark_sim_info;
 int mistark_sim_get_info(mistark_sim* sim, mistark_sim_info* info);

@@ -107,6 +107,7 @@ def lib():
     L.mistark_newton_default_settings.restype = None
     L.mistark_newton_solve.argtypes = [p, C.POINTER(NewtonSettings), C.POINTER(NewtonCallbacks), C.POINTER(NewtonStats)]
     L.mistark_set_option.argtypes = [p, C.c_char_p, C.c_int]
+    L.mistark_spmv_bench.argtypes = [p, C.c_int, C.POINTER(dbl)]
     L.mistark_spmv_timing.argtypes = [p, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl)]
     _lib = L
     return L

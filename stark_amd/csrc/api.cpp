@@ -485,7 +485,17 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     const std::string n = name ? name : "";
     if (n == "force_generic") ctx->c.force_generic = value != 0;
     else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;
+    else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;
+    else if (n == "spmv_variant") ctx->c.spmv_variant = value;
     else throw Error("unknown option '" + n + "'");
+    API_END(0)
+}
+
+int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us)
+{
+    API_BEGIN
+    const double us = spmv_bench(ctx->c, n_launches);
+    if (avg_us) *avg_us = us;
     API_END(0)
 }
 

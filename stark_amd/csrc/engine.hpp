@@ -154,6 +154,8 @@ struct Context
     DevBuf<uint32_t> scan, slot_start;
     const uint32_t* sorted_src = nullptr;  // source (element block) ids in sorted key order (one of kidx / kidx_alt)
     size_t n_hess_blocks = 0;
+    int spmv_variant = 0;          // micro-benchmark ablation variant
+    int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather
     bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path
     DevBuf<uint8_t> cub_tmp;
@@ -164,6 +166,8 @@ struct Context
     DevBuf<float> vals;             // tiles of 64 blocks: float4 q0[64], float4 q1[64], float s[64]
     DevBuf<float> dinv;             // 9 floats per block row
     bool have_matrix = false;
+    bool matrix_current = false;    // the assembled matrix reflects the current element Hessians
+    DevBuf<uint32_t> proj_list;     // element ids selected for projection (per potential, at e_off)
 
     // reductions / PCG
     DevBuf<double> partials;        // 4 x MAX_PARTIALS
@@ -178,6 +182,7 @@ struct Context
     double spmv_ms_sum = 0.0;
     int64_t spmv_n = 0;
 
+    int last_cg_iters = 0;          // iteration count of the previous solve (first-batch predictor)
     // statistics of the last evaluation
     int64_t n_projected_total = 0;
 
@@ -191,6 +196,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
              int64_t* n_projected_now, int64_t* n_changed_now);
 void assemble(Context& c);
 void build_preconditioner(Context& c);
+double spmv_bench(Context& c, int n);
 void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed);
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info);
 double reduce_max_abs(Context& c, const double* v, int64_t n);

@@ -77,6 +77,12 @@ double cb_max_step(void* u) { double s = 1.0; for (auto& f : ((CbCtx*)u)->cb->ma
 
 bool Stark::run_one_step()
 {
+    struct StepTimer
+    {
+        double& acc;
+        double t0;
+        ~StepTimer() { acc += now_s() - t0; }
+    } step_timer{total_step_time, now_s()};
     if (!is_init) _initialize();
     ensure_registered();
     // Stark.cpp:145
@@ -114,6 +120,12 @@ bool Stark::run_one_step()
     total_linear_solves += st.n_linear_solves;
     total_newton_time += st.t_total;
     total_linear_solve_time += st.t_linear_solve;
+    total_eval_pgh_time += st.t_eval_pgh;
+    total_eval_p_time += st.t_eval_p;
+    total_project_time += st.t_project;
+    total_assembly_time += st.t_assembly;
+    total_callback_time += st.t_callbacks;
+    total_evaluations += st.n_evaluations;
 
     if (result == MISTARK_SUCCESSFUL) {
         for (auto& f : callbacks->on_time_step_accepted) f();  // Stark.cpp:164-170

@@ -106,7 +106,9 @@ public:
     int last_newton_result = MISTARK_RUNNING;
     // accumulated over the run (the reference's Logger series)
     long total_newton_iterations = 0, total_cg_iterations = 0, total_linear_solves = 0, failed_steps = 0;
-    double total_newton_time = 0.0, total_linear_solve_time = 0.0;
+    double total_newton_time = 0.0, total_linear_solve_time = 0.0, total_eval_pgh_time = 0.0, total_eval_p_time = 0.0, total_project_time = 0.0,
+           total_assembly_time = 0.0, total_callback_time = 0.0, total_step_time = 0.0;
+    long total_evaluations = 0;
 
     explicit Stark(const Settings& settings);
     ~Stark();

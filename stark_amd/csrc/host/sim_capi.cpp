@@ -236,6 +236,13 @@ int mistark_sim_get_info(mistark_sim* s, mistark_sim_info* info)
     info->failed_steps = st.failed_steps;
     info->total_newton_time = st.total_newton_time;
     info->total_linear_solve_time = st.total_linear_solve_time;
+    info->total_eval_pgh_time = st.total_eval_pgh_time;
+    info->total_eval_p_time = st.total_eval_p_time;
+    info->total_project_time = st.total_project_time;
+    info->total_assembly_time = st.total_assembly_time;
+    info->total_callback_time = st.total_callback_time;
+    info->total_step_time = st.total_step_time;
+    info->total_evaluations = st.total_evaluations;
     info->last_stats = st.last_stats;
     SIM_END
 }

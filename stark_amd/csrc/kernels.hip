@@ -19,7 +19,7 @@
 namespace mistark {
 
 constexpr int BLOCK = 256;
-constexpr int MAX_PARTIALS = 1024;   // max grid of any kernel that emits per-block partial sums
+constexpr int MAX_PARTIALS = 4096;   // max grid of any kernel that emits per-block partial sums
 constexpr int VEC_GRID = 512;
 
 static inline int grid_for(int64_t n, int per_block = BLOCK, int cap = 1 << 30)
@@ -211,6 +211,11 @@ __device__ __forceinline__ double wave_sum(double v)
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
     return v;
 }
+__device__ __forceinline__ double read_lane(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_max(double v)
 {
 #pragma unroll
@@ -386,7 +391,11 @@ __global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ ke
         colw[slot] = col | (tail ? 0x80000000u : 0u);
         atomicAdd(&row_cnt[row], 1);
         if (row == col) diag_slot[row] = (int32_t)slot;
-        if ((slot & 63u) == 0) tile_first_row[slot >> 6] = (int32_t)row;
+        if ((slot & 63u) == 0) {
+            // bit 31: the previous block (last of the previous tile) belongs to the same row
+            const bool cont = k > 0 && (uint32_t)(keys[k - 1] / nbr) == row;
+            tile_first_row[slot >> 6] = (int32_t)(row | (cont ? 0x80000000u : 0u));
+        }
     }
 }
 __global__ __launch_bounds__(BLOCK) void k_rowptr_from_excl(const int32_t* __restrict__ excl, const int32_t* __restrict__ cnt, int64_t nbr, int64_t* __restrict__ row_ptr)
@@ -565,6 +574,7 @@ void eval(Context& c, int mode, double* E, double* grad_host)
     if (mode == MISTARK_EVAL_P_G_H) {
         MS_CHECK(hipMemsetAsync(c.is_projected.p, 0, c.n_elem_total, c.stream));
         c.have_hessians = true;
+        c.matrix_current = false;
         c.n_projected_total = 0;
     }
     const double e = c.n_elem_total ? reduce_sum(c, c.elemE.p, (int64_t)c.n_elem_total) : 0.0;
@@ -576,14 +586,27 @@ void eval(Context& c, int mode, double* E, double* grad_host)
 }
 
 // ======================================================================================================================
-// PSD projection: cyclic Jacobi eigen-decomposition per element (n = 3 NB <= 15)
+// PSD projection (project_to_PD.cpp:12-32; ElementHessians.cpp:48-67,79-182).
+//   k_project_select : marks the not-yet-projected elements that touch an active block row and appends them to a list
+//   k_project_eig    : one WAVEFRONT per listed element: parallel-order cyclic Jacobi on the n x n matrix held in LDS
+//                      (n/2 disjoint rotations per round, lanes own matrix entries), eigenvalues < eps clamped (or mirrored),
+//                      V L V^T rebuilt only if something changed; the difference (projected - original) is added to the
+//                      already assembled float BSR (the reference's update_global, ElementHessians.cpp:258-294).
 // ======================================================================================================================
-template <int NB>
-__global__ __launch_bounds__(64) void k_project(double* __restrict__ elemH, int n_elem, PotArgs a, uint8_t* __restrict__ is_projected, const uint8_t* __restrict__ active_blocks,
-                                                double eps, int mirroring, int64_t* __restrict__ counters)
+// position of component `comp` (row-major 3x3) of BSR block `slot` inside the 64-block tile layout (see SpMV)
+__device__ __forceinline__ size_t tile_val_index(uint32_t slot, int comp)
 {
-    constexpr int n = 3 * NB;
-    const int e = blockIdx.x * 64 + threadIdx.x;
+    const size_t base = (size_t)(slot >> 6) * 576;
+    const uint32_t lane = slot & 63u;
+    if (comp < 4) return base + lane * 4 + comp;
+    if (comp < 8) return base + 256 + lane * 4 + (comp - 4);
+    return base + 512 + lane;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_project_select(int n_elem, PotArgs a, int NB, uint8_t* __restrict__ is_projected, const uint8_t* __restrict__ active_blocks,
+                                                          uint32_t* __restrict__ list, int64_t* __restrict__ counters, int list_counter)
+{
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
     if (e >= n_elem) return;
     if (is_projected[e]) return;
     if (active_blocks) {
@@ -593,73 +616,134 @@ __global__ __launch_bounds__(64) void k_project(double* __restrict__ elemH, int 
         if (!touch) return;
     }
     is_projected[e] = 1;
-    atomicAdd((unsigned long long*)&counters[0], 1ull);
-    double A[n][n], V[n][n];
-    double* H = elemH + (size_t)e * 9;
+    const unsigned long long idx = atomicAdd((unsigned long long*)&counters[list_counter], 1ull);
+    list[idx] = (uint32_t)e;
+}
+
+template <int NB>
+__global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elemH, int n_elem, const uint32_t* __restrict__ list, int n_list, double eps, int mirroring,
+                                                       const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters)
+{
+    constexpr int n = 3 * NB, nn = n * n, m = (n + 1) & ~1;  // m: even number of players of the round-robin schedule
+    __shared__ double sA[4][nn], sV[4][nn], sC[4][m], sS[4][m], sL[4][m];
+    __shared__ int sP[4][m];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= n_list) return;
+    const int e = (int)list[w];
+    double* A = sA[wave];
+    double* V = sV[wave];
     const size_t hs = (size_t)n_elem * 9;
-    for (int ba = 0; ba < NB; ba++)
-        for (int bb = 0; bb < NB; bb++)
-            for (int ii = 0; ii < 3; ii++)
-                for (int jj = 0; jj < 3; jj++) A[3 * ba + ii][3 * bb + jj] = H[(ba * NB + bb) * hs + ii * 3 + jj];
-    double fro = 0.0;
-    for (int i = 0; i < n; i++)
-        for (int j = 0; j < n; j++) {
-            V[i][j] = i == j ? 1.0 : 0.0;
-            fro += A[i][j] * A[i][j];
-        }
-    if (fro == 0.0) {
-        // zero matrix: every eigenvalue (0) is below eps
+    // load (block layout [a*NB+b][e][3][3]) and symmetrise exactly as stored
+    for (int t = lane; t < nn; t += 64) {
+        const int i = t / n, j = t - i * n;
+        const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
+        A[t] = elemH[(size_t)(ba * NB + bb) * hs + (size_t)e * 9 + ii * 3 + jj];
+        V[t] = i == j ? 1.0 : 0.0;
     }
-    for (int sweep = 0; sweep < 60; sweep++) {
+    double fro = 0.0;
+    for (int t = lane; t < nn; t += 64) fro += A[t] * A[t];
+    fro = wave_sum(fro);
+    fro = read_lane(fro, 0);
+    for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0.0;
-        for (int p = 0; p < n; p++)
-            for (int q = p + 1; q < n; q++) off += A[p][q] * A[p][q];
-        if (2.0 * off <= 1e-30 * fro) break;
-        for (int p = 0; p < n - 1; p++) {
-            for (int q = p + 1; q < n; q++) {
-                const double apq = A[p][q];
-                if (fabs(apq) < 1e-300) continue;
-                const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-                for (int k = 0; k < n; k++) {
-                    const double akp = A[k][p], akq = A[k][q];
-                    A[k][p] = cs * akp - sn * akq;
-                    A[k][q] = sn * akp + cs * akq;
+        for (int t = lane; t < nn; t += 64) {
+            const int i = t / n, j = t - i * n;
+            if (i != j) off += A[t] * A[t];
+        }
+        off = wave_sum(off);
+        off = read_lane(off, 0);
+        if (off <= 1e-30 * fro) break;
+        for (int r = 0; r < m - 1; r++) {
+            // ---- rotations of this round: lane k < m/2 owns the pair (p, q)
+            if (lane < m) {
+                sC[wave][lane] = 1.0;
+                sS[wave][lane] = 0.0;
+                sP[wave][lane] = lane;
+            }
+            if (lane < m / 2) {
+                int p, q;
+                if (lane == 0) {
+                    p = m - 1;
+                    q = r;
+                } else {
+                    p = (r + lane) % (m - 1);
+                    q = (r - lane + (m - 1)) % (m - 1);
                 }
-                for (int k = 0; k < n; k++) {
-                    const double apk = A[p][k], aqk = A[q][k];
-                    A[p][k] = cs * apk - sn * aqk;
-                    A[q][k] = sn * apk + cs * aqk;
+                if (p > q) {
+                    const int tmp = p;
+                    p = q;
+                    q = tmp;
                 }
-                for (int k = 0; k < n; k++) {
-                    const double vkp = V[k][p], vkq = V[k][q];
-                    V[k][p] = cs * vkp - sn * vkq;
-                    V[k][q] = sn * vkp + cs * vkq;
+                if (q < n) {
+                    const double apq = A[p * n + q];
+                    if (fabs(apq) > 1e-300) {
+                        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+                        // new[p] = cs old[p] - sn old[q];  new[q] = sn old[p] + cs old[q]
+                        sC[wave][p] = cs;
+                        sS[wave][p] = -sn;
+                        sP[wave][p] = q;
+                        sC[wave][q] = cs;
+                        sS[wave][q] = sn;
+                        sP[wave][q] = p;
+                    }
+                }
+            }
+            // (all LDS operations of one wavefront are performed in program order: no barrier needed inside the wave)
+            // ---- rows: A <- J^T A
+            {
+                double v[(nn + 63) / 64];
+                int c = 0;
+                for (int t = lane; t < nn; t += 64, c++) {
+                    const int i = t / n, j = t - i * n;
+                    v[c] = sC[wave][i] * A[t] + sS[wave][i] * A[sP[wave][i] * n + j];
+                }
+                c = 0;
+                for (int t = lane; t < nn; t += 64, c++) A[t] = v[c];
+            }
+            // ---- columns: A <- A J,  V <- V J
+            {
+                double v[(nn + 63) / 64], u[(nn + 63) / 64];
+                int c = 0;
+                for (int t = lane; t < nn; t += 64, c++) {
+                    const int i = t / n, j = t - i * n;
+                    const int pj = sP[wave][j];
+                    v[c] = sC[wave][j] * A[t] + sS[wave][j] * A[i * n + pj];
+                    u[c] = sC[wave][j] * V[t] + sS[wave][j] * V[i * n + pj];
+                }
+                c = 0;
+                for (int t = lane; t < nn; t += 64, c++) {
+                    A[t] = v[c];
+                    V[t] = u[c];
                 }
             }
         }
     }
-    bool changed = false;
-    double lam[n];
-    for (int i = 0; i < n; i++) {
-        lam[i] = A[i][i];
-        if (lam[i] < eps) {
-            changed = true;
-            lam[i] = mirroring ? -lam[i] : eps;
+    // eigenvalues = diag(A)
+    bool bad = false;
+    if (lane < n) {
+        double l = A[lane * n + lane];
+        if (l < eps) {
+            bad = true;
+            l = mirroring ? -l : eps;
         }
+        sL[wave][lane] = l;
     }
-    if (!changed) return;
-    atomicAdd((unsigned long long*)&counters[1], 1ull);
-    for (int ba = 0; ba < NB; ba++)
-        for (int bb = 0; bb < NB; bb++)
-            for (int ii = 0; ii < 3; ii++)
-                for (int jj = 0; jj < 3; jj++) {
-                    const int i = 3 * ba + ii, j = 3 * bb + jj;
-                    double s = 0.0;
-                    for (int k = 0; k < n; k++) s += V[i][k] * lam[k] * V[j][k];
-                    H[(ba * NB + bb) * hs + ii * 3 + jj] = s;
-                }
+    const bool changed = __ballot(bad) != 0ull;
+    if (lane == 0 && changed) atomicAdd((unsigned long long*)&counters[1], 1ull);
+    if (!changed) return;  // untouched, like the reference (project_to_PD.cpp:25-29)
+    for (int t = lane; t < nn; t += 64) {
+        const int i = t / n, j = t - i * n;
+        double acc = 0.0;
+        for (int k = 0; k < n; k++) acc += V[i * n + k] * sL[wave][k] * V[j * n + k];
+        const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
+        const size_t blk = (size_t)(ba * NB + bb) * n_elem + e;
+        double* dst = elemH + blk * 9 + ii * 3 + jj;
+        if (vals) atomicAdd(&vals[tile_val_index(slot_of_src[blk], ii * 3 + jj)], (float)(acc - *dst));
+        *dst = acc;
+    }
 }
 
 __global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restrict__ grad, int64_t nbr, double thr, uint8_t* __restrict__ active, int64_t* __restrict__ counters)
@@ -676,7 +760,10 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
              int64_t* n_changed_now)
 {
     if (!c.have_hessians) throw Error("project: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
-    MS_CHECK(hipMemsetAsync(c.counters.p, 0, 8 * sizeof(int64_t), c.stream));
+    const int np = (int)c.pots.size();
+    if (np + 4 > 64) throw Error("project: too many potentials");
+    c.counters.ensure(64);
+    MS_CHECK(hipMemsetAsync(c.counters.p, 0, 64 * sizeof(int64_t), c.stream));
     const uint8_t* act = nullptr;
     if (by_gradient) {
         hipLaunchKernelGGL(k_active_blocks, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.grad.p, c.nbr, threshold, c.active_blocks.p, c.counters.p);
@@ -685,40 +772,52 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         MS_CHECK(hipMemcpyAsync(c.active_blocks.p, active_host, (size_t)c.nbr, hipMemcpyHostToDevice, c.stream));
         act = c.active_blocks.p;
     }
-    for (auto& P : c.pots) {
+    // 1) selection: per-potential lists of element ids (counter 4 + potential index)
+    c.proj_list.ensure(std::max<size_t>(c.n_elem_total, 1));
+    for (int pi = 0; pi < np; pi++) {
+        Potential& P = c.pots[pi];
         if (P.n_elem == 0) continue;
+        hipLaunchKernelGGL(k_project_select, dim3(grid_for(P.n_elem)), dim3(BLOCK), 0, c.stream, P.n_elem, P.args, P.NB, c.is_projected.p + P.e_off, act, c.proj_list.p + P.e_off,
+                           c.counters.p, 4 + pi);
+    }
+    int64_t h[64];
+    MS_CHECK(hipMemcpyAsync(h, c.counters.p, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    // 2) eigen-projection, one wavefront per selected element; deltas go straight into the assembled matrix if it is current
+    float* vals = c.matrix_current ? c.vals.p : nullptr;
+    int64_t total = 0;
+    for (int pi = 0; pi < np; pi++) {
+        Potential& P = c.pots[pi];
+        const int nl = (int)h[4 + pi];
+        if (nl == 0) continue;
+        total += nl;
         double* H = c.elemH.p + P.h_off;
-        uint8_t* ip = c.is_projected.p + P.e_off;
-        const dim3 g(grid_for(P.n_elem, 64)), b(64);
+        const uint32_t* list = c.proj_list.p + P.e_off;
+        const uint32_t* sos = c.slot_of_src.p + P.k_off;
+        const dim3 g((nl + 3) / 4), b(BLOCK);
         switch (P.NB) {
-            case 1: hipLaunchKernelGGL((k_project<1>), g, b, 0, c.stream, H, P.n_elem, P.args, ip, act, eps, mirroring, c.counters.p); break;
-            case 2: hipLaunchKernelGGL((k_project<2>), g, b, 0, c.stream, H, P.n_elem, P.args, ip, act, eps, mirroring, c.counters.p); break;
-            case 3: hipLaunchKernelGGL((k_project<3>), g, b, 0, c.stream, H, P.n_elem, P.args, ip, act, eps, mirroring, c.counters.p); break;
-            case 4: hipLaunchKernelGGL((k_project<4>), g, b, 0, c.stream, H, P.n_elem, P.args, ip, act, eps, mirroring, c.counters.p); break;
-            case 5: hipLaunchKernelGGL((k_project<5>), g, b, 0, c.stream, H, P.n_elem, P.args, ip, act, eps, mirroring, c.counters.p); break;
+            case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 2: hipLaunchKernelGGL((k_project_eig<2>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 3: hipLaunchKernelGGL((k_project_eig<3>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 4: hipLaunchKernelGGL((k_project_eig<4>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 5: hipLaunchKernelGGL((k_project_eig<5>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
             default: throw Error("project: unsupported block count");
         }
     }
-    int64_t h[8];
-    MS_CHECK(hipMemcpyAsync(h, c.counters.p, sizeof(h), hipMemcpyDeviceToHost, c.stream));
-    MS_CHECK(hipStreamSynchronize(c.stream));
-    c.n_projected_total += h[0];
-    if (n_projected_now) *n_projected_now = h[0];
-    if (n_changed_now) *n_changed_now = h[1];
+    c.n_projected_total += total;
+    if (n_projected_now) *n_projected_now = total;
+    if (n_changed_now) {
+        int64_t h2[2];
+        MS_CHECK(hipMemcpyAsync(h2, c.counters.p, sizeof(h2), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+        *n_changed_now = h2[1];
+    }
     if (all_active) *all_active = by_gradient ? (h[2] == 0) : (active_host == nullptr);
 }
 
 // ======================================================================================================================
 // Assembly: element 3x3 blocks -> float BSR tiles
 // ======================================================================================================================
-__device__ __forceinline__ size_t tile_val_index(uint32_t slot, int comp)
-{
-    const size_t base = (size_t)(slot >> 6) * 576;
-    const uint32_t lane = slot & 63u;
-    if (comp < 4) return base + lane * 4 + comp;
-    if (comp < 8) return base + 256 + lane * 4 + (comp - 4);
-    return base + 512 + lane;
-}
 __global__ __launch_bounds__(BLOCK) void k_assemble(const double* __restrict__ elemH, int64_t n_blocks_total, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals)
 {
     // one lane per (element block, component): 9 consecutive lanes read 72 contiguous bytes
@@ -789,6 +888,7 @@ void assemble(Context& c)
                            c.nnzb, c.vals.p);
     }
     c.have_matrix = true;
+    c.matrix_current = true;
 }
 void build_preconditioner(Context& c)
 {
@@ -801,10 +901,19 @@ void build_preconditioner(Context& c)
 // One wavefront per tile of 64 consecutive 3x3 blocks (CSR order). Values are laid out per tile as
 // float4 q0[64] | float4 q1[64] | float s[64] so that every load instruction of a wave is a fully coalesced
 // 1 KiB (dwordx4) or 256 B (dword) request: 36 B per block, no padding. Column word: bit 31 marks the last block of a row.
-// Rows are reduced inside the wave by a segmented shuffle scan; rows that straddle tiles are finished with atomics
-// on a pre-zeroed y.
+// Rows are reduced inside the wave by a DPP segmented scan; rows that straddle tiles are carried in registers (see kernel).
 // ======================================================================================================================
-__global__ __launch_bounds__(BLOCK) void k_spmv(const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int32_t* __restrict__ tile_first_row, int64_t nnzb,
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_shr(double v)
+{
+    // v_mov_b32_dpp row_shr:n on both halves; lanes without a source inside their 16-lane row receive 0
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int V>
+__global__ __launch_bounds__(BLOCK) void k_spmv_t(const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int32_t* __restrict__ tile_first_row, int64_t nnzb,
                                                 int64_t ntiles, const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ pdot,
                                                 double* __restrict__ partials, const PcgCtrl* __restrict__ ctrl)
 {
@@ -813,23 +922,49 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(const float* __restrict__ vals, 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double acc = 0.0;
-    for (int64_t t = (int64_t)blockIdx.x * 4 + wave; t < ntiles; t += (int64_t)gridDim.x * 4) {
+    // Each wavefront owns a contiguous range of tiles and every block row whose LAST block lies in that range. A row that
+    // straddles two tiles of the range is carried in registers; for the first row of the range, which usually began in the
+    // previous wavefront's last tile, that tile is re-read as a "ghost" (only its trailing open segment is used) and the
+    // previous wavefront drops its open tail. Every row is written exactly once: no atomics, no zero-fill, deterministic.
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t tpw = (ntiles + n_waves - 1) / n_waves;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t t_begin = gw * tpw, t_end = (t_begin + tpw < ntiles) ? t_begin + tpw : ntiles;
+    int64_t t_lead = t_begin;
+    if (t_begin < t_end) {
+        // walk back while the row continues from the previous tile; stop at the first tile that contains a row end
+        while (t_lead > 0 && tile_first_row[t_lead] < 0) {
+            t_lead--;
+            const uint32_t w = colw[t_lead * 64 + lane];
+            if (__ballot((w >> 31) != 0) != 0ull) break;
+        }
+    }
+    double k0 = 0.0, k1 = 0.0, k2 = 0.0;  // carry into the first segment of the next tile (wave-uniform)
+    for (int64_t t = t_lead; t < t_end; t++) {
+        const bool ghost = t < t_begin;
         const int64_t s = t * 64 + lane;
         const bool valid = s < nnzb;
         double y0 = 0.0, y1 = 0.0, y2 = 0.0;
         bool tail = false;
+        const int32_t tfr_w = tile_first_row[t];   // bit 31: the tile starts inside a row begun in the previous tile
+        const int tfr = tfr_w & 0x7fffffff;
+        const bool tile_cont = tfr_w < 0;
         if (valid) {
             const uint32_t w = colw[s];
             tail = (w >> 31) != 0;
-            const size_t col = w & 0x7fffffffu;
+            const size_t col = (V == 2) ? (size_t)(s % 170000) : (size_t)(w & 0x7fffffffu);
             const float4* q = reinterpret_cast<const float4*>(vals + (size_t)t * 576);
-            const float4 a = q[lane];
-            const float4 b = q[64 + lane];
-            const float cc = vals[(size_t)t * 576 + 512 + lane];
+            const float4 a = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[lane];
+            const float4 b = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[64 + lane];
+            const float cc = (V == 3) ? 1.f : vals[(size_t)t * 576 + 512 + lane];
             const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
             y0 = (double)a.x * x0 + (double)a.y * x1 + (double)a.z * x2;
             y1 = (double)a.w * x0 + (double)b.x * x1 + (double)b.y * x2;
             y2 = (double)b.z * x0 + (double)b.w * x1 + (double)cc * x2;
+        }
+        if (V >= 1 && V <= 3) {  // ablation: loads + block products only
+            acc += y0 + y1 + y2;
+            continue;
         }
         const bool seg_end = !valid || tail || lane == 63;
         const unsigned long long ends = __ballot(seg_end);
@@ -837,30 +972,42 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(const float* __restrict__ vals, 
         const unsigned long long heads = (ends << 1) | 1ull;
         const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
         const int start = 63 - __clzll(heads & le);
+        // segmented inclusive scan without LDS traffic: DPP row shifts inside each 16-lane row, then three scalar carries
+        {
+            const int l16 = lane & 15;
+#define MS_SEG_STEP(D, CTRL)                                                     \
+            {                                                                        \
+                const double u0 = dpp_row_shr<CTRL>(y0), u1 = dpp_row_shr<CTRL>(y1), u2 = dpp_row_shr<CTRL>(y2); \
+                if (l16 >= D && lane - D >= start) { y0 += u0; y1 += u1; y2 += u2; } \
+            }
+            MS_SEG_STEP(1, 0x111)
+            MS_SEG_STEP(2, 0x112)
+            MS_SEG_STEP(4, 0x114)
+            MS_SEG_STEP(8, 0x118)
+#undef MS_SEG_STEP
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const double u0 = __shfl_up(y0, d, 64), u1 = __shfl_up(y1, d, 64), u2 = __shfl_up(y2, d, 64);
-            if (lane - d >= start) {
-                y0 += u0;
-                y1 += u1;
-                y2 += u2;
+            for (int r = 1; r < 4; r++) {
+                const double c0 = read_lane(y0, 16 * r - 1), c1 = read_lane(y1, 16 * r - 1), c2 = read_lane(y2, 16 * r - 1);
+                if ((lane >> 4) == r && start < 16 * r) { y0 += c0; y1 += c1; y2 += c2; }
             }
         }
-        if (valid && seg_end) {
-            const int row = tile_first_row[t] + __popcll(tails & ((1ull << lane) - 1ull));
-            // the first segment continues a row begun in the previous tile iff the block before this tile is not a row end
-            const bool cont_prev = (start == 0) && (t > 0) && ((colw[t * 64 - 1] >> 31) == 0);
+        // first segment: take over the carry of the previous tile processed by this wavefront
+        if (tile_cont && t > t_lead && start == 0) { y0 += k0; y1 += k1; y2 += k2; }
+        // last segment open (the row ends in a later tile): hand it on in registers; at the end of the range the next
+        // wavefront recomputes it from its ghost tile
+        const bool open_end = ((tails >> 63) & 1ull) == 0ull && (t * 64 + 63 < nnzb);
+        if (open_end) { k0 = read_lane(y0, 63); k1 = read_lane(y1, 63); k2 = read_lane(y2, 63); }
+        if (valid && tail && !ghost) {
+            const int row = tfr + __popcll(tails & ((1ull << lane) - 1ull));
             double* yr = y + 3 * (size_t)row;
-            if (cont_prev || !tail) {
-                atomicAdd(yr, y0);
-                atomicAdd(yr + 1, y1);
-                atomicAdd(yr + 2, y2);
+            if (V == 4) {
+                acc += y0 + y1 + y2;
             } else {
                 yr[0] = y0;
                 yr[1] = y1;
                 yr[2] = y2;
             }
-            if (pdot) {
+            if (pdot && V != 6 && V != 4) {
                 const double* pr = pdot + 3 * (size_t)row;
                 acc += pr[0] * y0 + pr[1] * y1 + pr[2] * y2;
             }
@@ -872,24 +1019,50 @@ __global__ __launch_bounds__(BLOCK) void k_spmv(const float* __restrict__ vals, 
     }
 }
 
-static int spmv_grid(const Context& c) { return (int)std::min<int64_t>(std::max<int64_t>((c.ntiles + 3) / 4, 1), MAX_PARTIALS); }
+#define k_spmv k_spmv_t<0>
+static int spmv_grid(const Context& c)
+{
+    const int cap = c.spmv_grid_cap > 0 ? std::min(c.spmv_grid_cap, MAX_PARTIALS) : 1024;  // 16 waves/CU measured best (profiles/)
+    return (int)std::min<int64_t>(std::max<int64_t>((c.ntiles + 3) / 4, 1), cap);
+}
+// Micro-benchmark of the SpMV kernel on the assembled matrix: n back-to-back launches of q = A p (+ fused dot), HIP events
+// around the whole batch on the engine's stream. Returns the average launch duration in microseconds.
+double spmv_bench(Context& c, int n)
+{
+    if (!c.have_matrix) throw Error("spmv_bench: matrix not assembled");
+    hipEvent_t e0, e1;
+    MS_CHECK(hipEventCreate(&e0));
+    MS_CHECK(hipEventCreate(&e1));
+    const int gs = spmv_grid(c);
+    vec_fill(c, c.p.p, 1.0, c.ndofs);
+    for (int w = 0; w < 3; w++)
+        hipLaunchKernelGGL(k_spmv, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr);
+    MS_CHECK(hipEventRecord(e0, c.stream));
+    for (int i = 0; i < n; i++) {
+        switch (c.spmv_variant) {
+            case 1: hipLaunchKernelGGL(k_spmv_t<1>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
+            case 2: hipLaunchKernelGGL(k_spmv_t<2>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
+            case 4: hipLaunchKernelGGL(k_spmv_t<4>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
+            case 5: hipLaunchKernelGGL(k_spmv_t<5>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
+            case 6: hipLaunchKernelGGL(k_spmv_t<6>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
+            case 3: hipLaunchKernelGGL(k_spmv_t<3>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
+            default: hipLaunchKernelGGL(k_spmv, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr);
+        }
+    }
+    MS_CHECK(hipEventRecord(e1, c.stream));
+    MS_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MS_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 1000.0 * ms / n;
+}
 
 void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed)
 {
-    MS_CHECK(hipMemsetAsync(y, 0, (size_t)c.ndofs * sizeof(double), c.stream));
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (timed && c.time_spmv) {
-        MS_CHECK(hipEventCreate(&e0));
-        MS_CHECK(hipEventCreate(&e1));
-        MS_CHECK(hipEventRecord(e0, c.stream));
-    }
+    (void)timed;
     hipLaunchKernelGGL(k_spmv, dim3(spmv_grid(c)), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, x, y, pdot, partials,
                        (const PcgCtrl*)nullptr);
-    if (e0) {
-        MS_CHECK(hipEventRecord(e1, c.stream));
-        c.ev.push_back(e0);
-        c.ev.push_back(e1);
-    }
 }
 
 // ======================================================================================================================
@@ -1030,21 +1203,18 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
     }
 }
 
-static void drain_spmv_events(Context& c, int n_valid_pairs)
+// SpMV timing inside the solver: every SPMV_SAMPLE-th launch is bracketed by a pair of pooled HIP events on the engine's stream
+constexpr int SPMV_SAMPLE = 8;
+static void drain_spmv_events(Context& c, const std::vector<int>& iters, int last_real_iter)
 {
-    // events were recorded as (start, stop) pairs; only the first n_valid_pairs belong to real iterations
-    for (size_t i = 0; i + 1 < c.ev.size(); i += 2) {
-        if ((int)(i / 2) < n_valid_pairs) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c.ev[i], c.ev[i + 1]) == hipSuccess) {
-                c.spmv_ms_sum += ms;
-                c.spmv_n++;
-            }
+    for (size_t i = 0; i < iters.size(); i++) {
+        if (iters[i] > last_real_iter) continue;  // early-exit launch after convergence
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c.ev[2 * i], c.ev[2 * i + 1]) == hipSuccess) {
+            c.spmv_ms_sum += ms;
+            c.spmv_n++;
         }
-        (void)hipEventDestroy(c.ev[i]);
-        (void)hipEventDestroy(c.ev[i + 1]);
     }
-    c.ev.clear();
 }
 
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
@@ -1059,43 +1229,50 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     double* part_bb = c.partials.p + 3 * MAX_PARTIALS;
     hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(BLOCK), 0, c.stream, rhs_dev, c.dinv.p, c.nbr, c.du.p, c.r.p, c.z.p, c.p.p, part_bb, part_rz);
     hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, part_bb, part_rz, gv, abs_tol, c.ctrl.p);
-    PcgCtrl h{};
+    PcgCtrl* h = reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048);  // pinned
+    h->done = 0;
     int k = 1;
-    int batch = 8;
+    // first batch: the iteration count of the previous solve (Newton systems change slowly), then small top-ups;
+    // launches after convergence are device-side no-ops (ctrl->done)
+    int batch = c.last_cg_iters > 0 ? std::max(8, ((c.last_cg_iters + 7) / 8) * 8) : 16;
     bool finished = false;
+    std::vector<int> sampled;
     while (!finished) {
         const int k_end = std::min(max_iter, k + batch - 1);
-        const int k_begin = k;
+        sampled.clear();
         for (; k <= k_end; k++) {
-            MS_CHECK(hipMemsetAsync(c.q.p, 0, (size_t)c.ndofs * sizeof(double), c.stream));
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (c.time_spmv) {
-                MS_CHECK(hipEventCreate(&e0));
-                MS_CHECK(hipEventCreate(&e1));
-                MS_CHECK(hipEventRecord(e0, c.stream));
+            const bool sample = c.time_spmv && (k % SPMV_SAMPLE) == 0;
+            if (sample) {
+                const size_t need = 2 * (sampled.size() + 1);
+                while (c.ev.size() < need) {
+                    hipEvent_t e;
+                    MS_CHECK(hipEventCreate(&e));
+                    c.ev.push_back(e);
+                }
+                MS_CHECK(hipEventRecord(c.ev[2 * sampled.size()], c.stream));
             }
             hipLaunchKernelGGL(k_spmv, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p);
-            if (e0) {
-                MS_CHECK(hipEventRecord(e1, c.stream));
-                c.ev.push_back(e0);
-                c.ev.push_back(e1);
+            if (sample) {
+                MS_CHECK(hipEventRecord(c.ev[2 * sampled.size() + 1], c.stream));
+                sampled.push_back(k);
             }
             hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, c.p.p, c.q.p, c.du.p, c.r.p, c.z.p, part_rr,
                                part_rz, c.ctrl.p);
             hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p);
         }
-        MS_CHECK(hipMemcpyAsync(&h, c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipMemcpyAsync(h, c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost, c.stream));
         MS_CHECK(hipStreamSynchronize(c.stream));
-        const int executed = h.done ? std::max(0, h.n_iter - k_begin + 1) : (k_end - k_begin + 1);
-        if (c.time_spmv) drain_spmv_events(c, executed);
-        if (h.done || k > max_iter) finished = true;
-        batch = std::min(batch * 2, 64);
+        if (c.time_spmv) drain_spmv_events(c, sampled, h->done ? h->n_iter : k_end);
+        if (h->done || k > max_iter) finished = true;
+        batch = 8;
     }
+    const int n_it = h->done ? h->n_iter : max_iter;
+    c.last_cg_iters = n_it;
     if (info) {
-        info->converged = h.done ? h.converged : 0;
-        info->n_iterations = h.done ? h.n_iter : max_iter;
-        info->found_indefiniteness = h.indef;
-        info->error = h.error;
+        info->converged = h->done ? h->converged : 0;
+        info->n_iterations = n_it;
+        info->found_indefiniteness = h->indef;
+        info->error = h->error;
         info->reserved = 0;
     }
 }

@@ -91,7 +91,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                 assemble(c);
                 assembled = true;
             }
-            bool reassemble = !assembled;
+            bool reassemble = !assembled;  // projections performed after assembly update the matrix in place (update_global)
             {
                 Timer t(st.t_project);
                 switch (s.projection_mode) {
@@ -100,7 +100,6 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                         int64_t np = 0;
                         project(c, s.projection_eps, s.project_to_pd_use_mirroring, nullptr, false, 0.0, nullptr, &np, nullptr);
                         all_projected = true;
-                        reassemble = reassemble || np > 0;
                         break;
                     }
                     case MISTARK_PROJ_ON_DEMAND:
@@ -108,7 +107,6 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                             int64_t np = 0;
                             project(c, s.projection_eps, s.project_to_pd_use_mirroring, nullptr, false, 0.0, nullptr, &np, nullptr);
                             all_projected = true;
-                            reassemble = reassemble || np > 0;
                         }
                         break;
                     case MISTARK_PROJ_PROGRESSIVE:
@@ -118,15 +116,12 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                             int64_t np = 0;
                             project(c, s.projection_eps, s.project_to_pd_use_mirroring, nullptr, true, ppn_threshold, &all_active, &np, nullptr);
                             all_projected = all_active != 0;
-                            reassemble = reassemble || np > 0;
                         }
                         break;
                     default: throw Error("unknown projection mode");
                 }
             }
             if (reassemble) {
-                // update_global adds (projected - original) blocks (ElementHessians.cpp:258-294); re-scattering the
-                // stored element Hessians gives the same matrix
                 Timer t(st.t_assembly);
                 assemble(c);
                 assembled = true;

@@ -30,7 +30,9 @@ class SurfaceParams(C.Structure):
 class SimInfo(C.Structure):
     _fields_ = [("current_time", C.c_double), ("dt", C.c_double), ("current_time_step", C.c_int32), ("last_newton_result", C.c_int32), ("n_points", C.c_int64),
                 ("ndofs", C.c_int64), ("total_newton_iterations", C.c_int64), ("total_cg_iterations", C.c_int64), ("total_linear_solves", C.c_int64),
-                ("failed_steps", C.c_int64), ("total_newton_time", C.c_double), ("total_linear_solve_time", C.c_double), ("last_stats", capi.NewtonStats)]
+                ("failed_steps", C.c_int64), ("total_newton_time", C.c_double), ("total_linear_solve_time", C.c_double), ("total_eval_pgh_time", C.c_double),
+                ("total_eval_p_time", C.c_double), ("total_project_time", C.c_double), ("total_assembly_time", C.c_double), ("total_callback_time", C.c_double),
+                ("total_step_time", C.c_double), ("total_evaluations", C.c_int64), ("last_stats", capi.NewtonStats)]
 
 
 _bound = False

@@ -1,0 +1,21 @@
+"""Developer tool: SpMV micro-benchmark sweep on the 1M-tet block matrix (run on the GPU box)."""
+import ctypes as C
+import sys
+
+sys.path.insert(0, ".")
+from bench import build_scene
+from stark_amd import capi
+from stark_amd import sim as S
+
+sim = build_scene(S, 44, 44, 43, 0)
+sim.run_one_step()
+L = capi.lib()
+h = sim.engine_handle()
+_, _, nbytes = sim.spmv_timing()
+for variant in [0, 1]:
+  for cap in [int(a) for a in sys.argv[1:]] or [512, 1024, 2048, 4096]:
+    L.mistark_set_option(h, b"spmv_grid_cap", cap)
+    L.mistark_set_option(h, b"spmv_variant", variant)
+    us = C.c_double()
+    L.mistark_spmv_bench(h, 200, C.byref(us))
+    print("variant=%d grid_cap=%d  %.2f us  %.0f GB/s  (%.1f%% of 8 TB/s)" % (variant, cap, us.value, nbytes / us.value / 1e3, 100 * nbytes / us.value / 1e3 / 8000))
