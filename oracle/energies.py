@@ -227,7 +227,193 @@ def EnergyBendingFlat(b):
     return P
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Rigid bodies. stark/src/models/rigidbodies/rigidbody_transformations.cpp:54-160
+def _quat_to_rotation(q):
+    qw, qx, qy, qz = q
+    tx, ty, tz = 2.0 * qx, 2.0 * qy, 2.0 * qz
+    twx, twy, twz = tx * qw, ty * qw, tz * qw
+    txx, txy, txz = tx * qx, ty * qx, tz * qx
+    tyy, tyz, tzz = ty * qy, tz * qy, tz * qz
+    return [[1.0 - (tyy + tzz), txy - twz, txz + twy],
+            [txy + twz, 1.0 - (txx + tzz), tyz - twx],
+            [txz - twy, tyz + twx, 1.0 - (txx + tyy)]]
+
+
+def _quat_mul(q1, q2):
+    a, b, c, d = q1
+    e, f, g, h = q2
+    return [a * e - b * f - c * g - d * h, b * e + a * f + c * h - d * g, a * g - b * h + c * e + d * f, a * h + b * g - c * f + d * e]
+
+
+def _R1(q0, w1, dt):
+    # quat_time_integration_as_rotation_matrix: normalize(q0 + 0.5 dt (0,w) * q0)
+    w_ = [0.0 * w1[0], w1[0], w1[1], w1[2]]
+    p = _quat_mul(w_, q0)
+    q1 = [q0[i] + 0.5 * dt * p[i] for i in range(4)]
+    n = (q1[0] * q1[0] + q1[1] * q1[1] + q1[2] * q1[2] + q1[3] * q1[3]).sqrt()
+    return _quat_to_rotation([x / n for x in q1])
+
+
+def _matvec(R, x):
+    return [dot(R[i], x) for i in range(3)]
+
+
+def _rb_x1(v1, w1, t0, q0, x_loc, dt):
+    # RigidBodyDynamics::get_x1 (RigidBodyDynamics.cpp:46-62)
+    R1 = _R1(q0, w1, dt)
+    t1 = [t0[i] + dt * v1[i] for i in range(3)]
+    return add(t1, _matvec(R1, x_loc))
+
+
+def _rb_x0(t0, q0, x_loc):
+    return add(t0, _matvec(_quat_to_rotation(q0), x_loc))
+
+
+def _rb_d1(w1, q0, d_loc, dt):
+    return _matvec(_R1(q0, w1, dt), d_loc)
+
+
+# stark/src/models/rigidbodies/EnergyRigidBodyInertia.cpp:13-39
+# bindings: v1*, v0, a, force, mass, linear_damping, is_quasistatic, dt, gravity
+def EnergyRigidBodyInertia_Linear(b):
+    v1, v0, a, f, (m,), (damping,), (is_q,), (dt,), gravity = b
+    dev = sub(v1, v0)
+    E_inertia = 0.5 * m * dot(dev, dev) + 0.5 * m * dot(v1, v1) * damping * dt
+    f_ext = [m * (a[i] + gravity[i]) + f[i] for i in range(3)]
+    E_ext = -1.0 * dt * dot(f_ext, v1)
+    return E_ext + where(is_q > 0.5, 0.0, E_inertia)
+
+
+# stark/src/models/rigidbodies/EnergyRigidBodyInertia.cpp:42-67
+# bindings: w1*, w0, aa, torque, J0_glob(9), angular_damping, is_quasistatic, dt
+def EnergyRigidBodyInertia_Angular(b):
+    w1, w0, aa, t, J, (damping,), (is_q,), (dt,) = b
+    Jm = [[J[3 * i + j] for j in range(3)] for i in range(3)]
+    dev = sub(w1, w0)
+    E_inertia = 0.5 * (dot(dev, _matvec(Jm, dev)) + dot(w1, _matvec(Jm, w1)) * damping * dt)
+    t_ext = add(_matvec(Jm, aa), t)
+    E_ext = -1.0 * dt * dot(t_ext, w1)
+    return E_ext + where(is_q > 0.5, 0.0, E_inertia)
+
+
+# stark/src/models/rigidbodies/EnergyRigidBodyConstraints.cpp:30-45; RigidBodyConstraints.h:110-113
+def rb_constraint_global_points(b):
+    loc, target, (k,), (active,), (dt,), v1, w1, t0, q0 = b
+    p = _rb_x1(v1, w1, t0, q0, loc, dt)
+    return 0.5 * k * sqnorm(sub(target, p)), active
+
+
+# EnergyRigidBodyConstraints.cpp:47-62; RigidBodyConstraints.h:150-153
+def rb_constraint_global_directions(b):
+    d_loc, target, (k,), (active,), (dt,), w1, q0 = b
+    d = _rb_d1(w1, q0, d_loc, dt)
+    return 0.5 * k * sqnorm(sub(target, d)), active
+
+
+# EnergyRigidBodyConstraints.cpp:64-80; RigidBodyConstraints.h:191-194
+def rb_constraint_points(b):
+    a_loc, b_loc, (k,), (active,), (dt,), v1a, w1a, t0a, q0a, v1b, w1b, t0b, q0b = b
+    a1 = _rb_x1(v1a, w1a, t0a, q0a, a_loc, dt)
+    b1 = _rb_x1(v1b, w1b, t0b, q0b, b_loc, dt)
+    return 0.5 * k * sqnorm(sub(b1, a1)), active
+
+
+def _sq_distance_point_line(p, a, b_):
+    # stark/src/models/distances.cpp:61-68
+    ab = sub(b_, a)
+    ap = sub(p, a)
+    e = dot(ap, ab)
+    return dot(ap, ap) - e * e / dot(ab, ab)
+
+
+# EnergyRigidBodyConstraints.cpp:82-99; RigidBodyConstraints.h:228-231
+def rb_constraint_point_on_axis(b):
+    a_loc, da_loc, b_loc, (k,), (active,), (dt,), v1a, w1a, t0a, q0a, v1b, w1b, t0b, q0b = b
+    a1 = _rb_x1(v1a, w1a, t0a, q0a, a_loc, dt)
+    da1 = _rb_d1(w1a, q0a, da_loc, dt)
+    b1 = _rb_x1(v1b, w1b, t0b, q0b, b_loc, dt)
+    return 0.5 * k * _sq_distance_point_line(b1, a1, add(a1, da1)), active
+
+
+# EnergyRigidBodyConstraints.cpp:101-118; RigidBodyConstraints.h:265-268
+def rb_constraint_distances(b):
+    a_loc, b_loc, (target,), (k,), (active,), (dt,), v1a, w1a, t0a, q0a, v1b, w1b, t0b, q0b = b
+    a1 = _rb_x1(v1a, w1a, t0a, q0a, a_loc, dt)
+    b1 = _rb_x1(v1b, w1b, t0b, q0b, b_loc, dt)
+    return 0.5 * k * (target - norm(sub(b1, a1))).powN(2), active
+
+
+# EnergyRigidBodyConstraints.cpp:120-138; RigidBodyConstraints.h:305-311
+def rb_constraint_distance_limits(b):
+    a_loc, b_loc, (dmin,), (dmax,), (k,), (active,), (dt,), v1a, w1a, t0a, q0a, v1b, w1b, t0b, q0b = b
+    a1 = _rb_x1(v1a, w1a, t0a, q0a, a_loc, dt)
+    b1 = _rb_x1(v1b, w1b, t0b, q0b, b_loc, dt)
+    length = norm(sub(b1, a1))
+    E_min = where(length.v < dmin, k * (dmin - length).powN(2) / 2.0, 0.0)
+    E_max = where(length.v > dmax, k * (length - dmax).powN(2) / 2.0, 0.0)
+    return E_min + E_max, active
+
+
+# EnergyRigidBodyConstraints.cpp:140-156; RigidBodyConstraints.h:357-360
+def rb_constraint_directions(b):
+    da_loc, db_loc, (k,), (active,), (dt,), w1a, q0a, w1b, q0b = b
+    da = _rb_d1(w1a, q0a, da_loc, dt)
+    db = _rb_d1(w1b, q0b, db_loc, dt)
+    return 0.5 * k * sqnorm(sub(db, da)), active
+
+
+# EnergyRigidBodyConstraints.cpp:158-175; RigidBodyConstraints.h:409-413
+def rb_constraint_angle_limits(b):
+    da_loc, db_loc, (max_distance,), (k,), (active,), (dt,), w1a, q0a, w1b, q0b = b
+    da = _rb_d1(w1a, q0a, da_loc, dt)
+    db = _rb_d1(w1b, q0b, db_loc, dt)
+    length = norm(sub(db, da))
+    return where(length.v > max_distance, k * (length - max_distance).powN(3) / 3.0, 0.0), active
+
+
+# EnergyRigidBodyConstraints.cpp:177-196; RigidBodyConstraints.h:455-466
+def rb_constraint_damped_spring(b):
+    a_loc, b_loc, (rest,), (k,), (damping,), (active,), (dt,), v1a, w1a, t0a, q0a, v1b, w1b, t0b, q0b = b
+    a1 = _rb_x1(v1a, w1a, t0a, q0a, a_loc, dt)
+    b1 = _rb_x1(v1b, w1b, t0b, q0b, b_loc, dt)
+    a0 = _rb_x0(t0a, q0a, a_loc)
+    b0 = _rb_x0(t0b, q0b, b_loc)
+    l1 = norm(sub(b1, a1))
+    l0 = norm(sub(b0, a0))
+    return 0.5 * k * (l1 - rest).powN(2) + 0.5 * damping * ((l1 - l0) / dt).powN(2), active
+
+
+def _c1_controller(da1, va1, vb1, target_v, max_force, delay, dt):
+    # RigidBodyConstraints.h:54-69
+    v = dot(da1, sub(vb1, va1))
+    k = max_force / delay
+    eps = delay / 2.0
+    dv = v - target_v
+    E_c = 0.5 * k * dv.powN(2) * dt
+    E_r = max_force * (dv - eps) * dt
+    E_l = -1.0 * E_r
+    return where(dv.v < -delay, E_l, where(dv.v < delay, E_c, E_r))
+
+
+# EnergyRigidBodyConstraints.cpp:198-218
+def rb_constraint_linear_velocity(b):
+    da_loc, (target_v,), (max_force,), (delay,), (active,), va1, vb1, wa1, qa0, (dt,) = b
+    da1 = _rb_d1(wa1, qa0, da_loc, dt)
+    return _c1_controller(da1, va1, vb1, target_v, max_force, delay, dt), active
+
+
+# EnergyRigidBodyConstraints.cpp:220-238
+def rb_constraint_angular_velocity(b):
+    da_loc, (target_w,), (max_torque,), (delay,), (active,), wa1, wb1, qa0, (dt,) = b
+    da1 = _rb_d1(wa1, qa0, da_loc, dt)
+    return _c1_controller(da1, wa1, wb1, target_w, max_torque, delay, dt), active
+
+
 REGISTRY = {f.__name__: f for f in [
     EnergyLumpedInertia, EnergyPrescribedPositions, EnergyTetStrain, EnergyTetStrain_Elasticity_Only,
     EnergyTriangleStrain, EnergyTriangleStrain_Elasticity_Only, EnergyDiscreteShells, EnergyBendingFlat,
+    EnergyRigidBodyInertia_Linear, EnergyRigidBodyInertia_Angular, rb_constraint_global_points, rb_constraint_global_directions,
+    rb_constraint_points, rb_constraint_point_on_axis, rb_constraint_distances, rb_constraint_distance_limits, rb_constraint_directions,
+    rb_constraint_angle_limits, rb_constraint_damped_spring, rb_constraint_linear_velocity, rb_constraint_angular_velocity,
 ]}

@@ -175,8 +175,52 @@ static Scene scene_tetblock(const Args& a)
     return sc;
 }
 
+// Chain of rigid boxes exercising every rigid-body potential: box0 fixed (global point + 2 global directions), then one
+// constraint type per link (tests/rb_constraints.cpp and examples/rb_constraint_test_scenes.cpp use the same building blocks)
+static Scene scene_rbchain(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "rbchain");
+    settings.simulation.init_frictional_contact = false;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    auto make_box = [&](double x, double y, double z) {
+        auto [V, T, box] = sim.presets->rigidbodies->add_box("box", 1.0 + 0.1 * x, { 0.1, 0.12, 0.08 });
+        box.rigidbody.set_translation({ x, y, z });
+        box.rigidbody.add_rotation(20.0 * x + 5.0, Eigen::Vector3d(1.0, 0.5, -0.3).normalized());
+        return box.rigidbody;
+    };
+    auto rbs = sim.rigidbodies;
+    rbs->set_default_constraint_stiffness(a.d("rb_stiffness", 1e4));
+    auto b0 = make_box(0.0, 0.0, 0.0);
+    rbs->add_constraint_fix(b0);
+    auto b1 = make_box(0.15, 0.0, 0.0);
+    rbs->add_constraint_point(b0, b1, { 0.07, 0.02, 0.01 });
+    auto b2 = make_box(0.30, 0.02, 0.0);
+    rbs->add_constraint_point_on_axis(b1, b2, { 0.22, 0.0, 0.01 }, Eigen::Vector3d(1.0, 0.2, 0.0).normalized());
+    auto b3 = make_box(0.45, 0.0, 0.03);
+    rbs->add_constraint_distance(b2, b3, { 0.33, 0.0, 0.0 }, { 0.42, 0.01, 0.02 });
+    auto b4 = make_box(0.60, 0.0, 0.0);
+    rbs->add_constraint_distance_limits(b3, b4, { 0.48, 0.0, 0.0 }, { 0.57, 0.0, 0.0 }, 0.08995, 0.09005);
+    rbs->add_constraint_direction(b3, b4, Eigen::Vector3d(0.0, 1.0, 0.2).normalized());
+    auto b5 = make_box(0.75, 0.0, 0.0);
+    rbs->add_constraint_point(b4, b5, { 0.67, 0.0, 0.0 });
+    rbs->add_constraint_angle_limit(b4, b5, Eigen::Vector3d(1.0, 0.0, 0.0), 0.5);
+    auto b6 = make_box(0.90, 0.0, 0.0);
+    rbs->add_constraint_spring(b5, b6, { 0.78, 0.0, 0.0 }, { 0.87, 0.01, 0.0 }, 200.0, 3.0);
+    auto b7 = make_box(1.05, 0.0, 0.0);
+    rbs->add_constraint_point_on_axis(b6, b7, { 0.97, 0.0, 0.0 }, Eigen::Vector3d(1.0, 0.0, 0.0));
+    rbs->add_constraint_linear_velocity(b6, b7, Eigen::Vector3d(1.0, 0.0, 0.0), 0.3, 5.0, 0.05);
+    auto b8 = make_box(1.20, 0.0, 0.0);
+    rbs->add_constraint_hinge(b7, b8, { 1.12, 0.0, 0.0 }, Eigen::Vector3d(0.0, 1.0, 0.0));
+    rbs->add_constraint_angular_velocity(b7, b8, Eigen::Vector3d(0.0, 1.0, 0.0), 1.0, 2.0, 0.1);
+    sc.json = "{\"kind\":\"rbchain\"}";
+    return sc;
+}
+
 static Scene make_scene(const std::string& name, const Args& a)
 {
+    if (name == "rbchain") return scene_rbchain(a);
     if (name == "tetblock") return scene_tetblock(a);
     if (name == "tetbeam") return scene_tetbeam(a);
     if (name == "cloth") return scene_cloth(a);
@@ -416,6 +460,7 @@ int main(int argc, char** argv)
         // Consecutive duplicates are removed.
         const std::string dir = a.s("out", "/tmp/mistark_traj");
         fs::create_directories(dir);
+        st.callbacks->run_before_time_step();  // fills the per-step caches (rigid-body q0_, J0_glob; v1 = 0) the potentials read
         dump_snapshot(sc, dir, a);  // evaluator inputs + stage outputs at the initial state (t = 0, v1 = 0)
         std::vector<std::vector<double>> iterates;
         std::vector<int> iter_step;

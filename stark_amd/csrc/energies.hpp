@@ -8,6 +8,8 @@
 // (symx/src/solver/second_order/SecondOrderCompiledPotential.cpp:10-33).
 // All DoFs are next-step velocities: x1 = x0 + dt v1 (stark/src/models/time_integration.cpp:3-11).
 #pragma once
+#include <type_traits>
+
 #include "hdual.hpp"
 
 namespace mistark {
@@ -325,5 +327,335 @@ struct E_BendingFlat
         return (0.5 * k * coef) * sqnorm(s);
     }
 };
+
+
+// ======================================================================================================================
+// Rigid bodies. Kinematics: stark/src/models/rigidbodies/rigidbody_transformations.cpp:54-160
+//   q1 = normalize(q0 + dt/2 (0,w1) * q0),  x1 = t0 + dt v1 + R(q1) x_loc,  d1 = R(q1) d_loc      (quaternions are (w,x,y,z))
+// Conditional potentials (is_active > 0, EnergyRigidBodyConstraints.cpp:43) expose `active()`.
+// ======================================================================================================================
+template <class T>
+MS_HD M3<T> quat_to_rotation(const T& qw, const T& qx, const T& qy, const T& qz)
+{
+    const T tx = 2.0 * qx, ty = 2.0 * qy, tz = 2.0 * qz;
+    const T twx = tx * qw, twy = ty * qw, twz = tz * qw;
+    const T txx = tx * qx, txy = ty * qx, txz = tz * qx;
+    const T tyy = ty * qy, tyz = tz * qy, tzz = tz * qz;
+    M3<T> R;
+    R.m[0][0] = 1.0 - (tyy + tzz); R.m[0][1] = txy - twz;         R.m[0][2] = txz + twy;
+    R.m[1][0] = txy + twz;         R.m[1][1] = 1.0 - (txx + tzz); R.m[1][2] = tyz - twx;
+    R.m[2][0] = txz - twy;         R.m[2][1] = tyz + twx;         R.m[2][2] = 1.0 - (txx + tyy);
+    return R;
+}
+// R(q1) for the integrated quaternion; q0 = (e,f,g,h) plain doubles at in[o..o+3]
+template <class T>
+MS_HD M3<T> rb_R1(const double* q0, const V3<T>& w, double dt)
+{
+    const double e = q0[0], f = q0[1], g = q0[2], h = q0[3];
+    // (0,w) * q0  (quat_dot_product, rigidbody_transformations.cpp:91-112)
+    const T p0 = -(w.x * f) - w.y * g - w.z * h;
+    const T p1 = w.x * e + w.y * h - w.z * g;
+    const T p2 = -(w.x * h) + w.y * e + w.z * f;
+    const T p3 = w.x * g - w.y * f + w.z * e;
+    const T q0n = e + (0.5 * dt) * p0, q1n = f + (0.5 * dt) * p1, q2n = g + (0.5 * dt) * p2, q3n = h + (0.5 * dt) * p3;
+    const T r = inv(sqrt(q0n * q0n + q1n * q1n + q2n * q2n + q3n * q3n));
+    return quat_to_rotation(q0n * r, q1n * r, q2n * r, q3n * r);
+}
+MS_HD M3<double> rb_R0(const double* q0) { return quat_to_rotation(q0[0], q0[1], q0[2], q0[3]); }
+// bound block of one body as created by RigidBodyDynamics::get_x1: v1*, w1*, t0, q0_ at offsets o, o+3, o+6, o+9 (13 doubles)
+template <class T>
+MS_HD V3<T> rb_point(const Loader<T>& L, int o, int kv, int kw, const V3<double>& x_loc, double dt)
+{
+    const V3<T> v1 = L.dof(o, kv), w1 = L.dof(o + 3, kw);
+    const M3<T> R1 = rb_R1(L.in + o + 9, w1, dt);
+    return (L.v(o + 6) + dt * v1) + R1 * x_loc;
+}
+template <class T>
+MS_HD V3<T> rb_dir(const Loader<T>& L, int ow, int oq, int kw, const V3<double>& d_loc, double dt)
+{
+    return rb_R1(L.in + oq, L.dof(ow, kw), dt) * d_loc;
+}
+MS_HD V3<double> rb_point0(const double* in, int o, const V3<double>& x_loc)
+{
+    const M3<double> R0 = rb_R0(in + o + 9);
+    return V3<double>(in[o + 6], in[o + 7], in[o + 8]) + R0 * x_loc;
+}
+
+// stark/src/models/rigidbodies/EnergyRigidBodyInertia.cpp:13-39
+// bindings: v1*, v0, a, force, mass, linear_damping, is_quasistatic (all [rb]), dt, gravity
+struct E_RBInertiaLinear
+{
+    static constexpr const char* name = "EnergyRigidBodyInertia_Linear";
+    using Layout = Strides<3, 3, 3, 3, 1, 1, 1, 1, 3>;
+    static constexpr int NB = 1;
+    static constexpr int dof_binding[NB] = {0};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const V3<T> v1 = L.dof(0, 0);
+        const V3<double> v0 = L.v(3), a = L.v(6), f = L.v(9), gravity = L.v(16);
+        const double m = L.s(12), damping = L.s(13), is_q = L.s(14), dt = L.s(15);
+        const V3<T> dev = v1 - v0;
+        const T E_inertia = 0.5 * m * dot(dev, dev) + (0.5 * m * damping * dt) * dot(v1, v1);
+        const V3<double> f_ext = m * (a + gravity) + f;
+        const T E_ext = (-dt) * dot(f_ext, v1);
+        return E_ext + select(is_q > 0.5, T(0.0), E_inertia);
+    }
+};
+// stark/src/models/rigidbodies/EnergyRigidBodyInertia.cpp:42-67
+// bindings: w1*, w0, aa, torque, J0_glob (9), angular_damping, is_quasistatic, dt
+struct E_RBInertiaAngular
+{
+    static constexpr const char* name = "EnergyRigidBodyInertia_Angular";
+    using Layout = Strides<3, 3, 3, 3, 9, 1, 1, 1>;
+    static constexpr int NB = 1;
+    static constexpr int dof_binding[NB] = {0};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const V3<T> w1 = L.dof(0, 0);
+        const V3<double> w0 = L.v(3), aa = L.v(6), t = L.v(9);
+        M3<double> J;
+        for (int i = 0; i < 9; i++) J.m[i / 3][i % 3] = L.s(12 + i);
+        const double damping = L.s(21), is_q = L.s(22), dt = L.s(23);
+        const V3<T> dev = w1 - w0;
+        const T E_inertia = 0.5 * (dot(dev, J * dev) + dot(w1, J * w1) * (damping * dt));
+        const V3<double> t_ext = J * aa + t;
+        const T E_ext = (-dt) * dot(t_ext, w1);
+        return E_ext + select(is_q > 0.5, T(0.0), E_inertia);
+    }
+};
+
+#define MISTARK_ACTIVE_AT(OFF) \
+    static constexpr bool COND = true; \
+    MS_HD static bool active(const double* in) { return in[OFF] > 0.0; }
+
+// EnergyRigidBodyConstraints.cpp:30-45. bindings: loc, target_glob, stiffness, is_active ([idx]), dt, {v1*, w1*, t0, q0_}[rb]
+struct E_RBGlobalPoints
+{
+    static constexpr const char* name = "rb_constraint_global_points";
+    using Layout = Strides<3, 3, 1, 1, 1, 3, 3, 3, 4>;
+    static constexpr int NB = 2;
+    static constexpr int dof_binding[NB] = {5, 6};
+    MISTARK_ACTIVE_AT(7)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double k = L.s(6), dt = L.s(8);
+        const V3<T> p = rb_point(L, 9, 0, 1, L.v(0), dt);
+        return 0.5 * k * sqnorm(L.v(3) - p);
+    }
+};
+// EnergyRigidBodyConstraints.cpp:47-62. bindings: d_loc, target_d_glob, stiffness, is_active, dt, w1*[rb], q0_[rb]
+struct E_RBGlobalDirections
+{
+    static constexpr const char* name = "rb_constraint_global_directions";
+    using Layout = Strides<3, 3, 1, 1, 1, 3, 4>;
+    static constexpr int NB = 1;
+    static constexpr int dof_binding[NB] = {5};
+    MISTARK_ACTIVE_AT(7)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double k = L.s(6), dt = L.s(8);
+        const V3<T> d = rb_dir(L, 9, 12, 0, L.v(0), dt);
+        return 0.5 * k * sqnorm(L.v(3) - d);
+    }
+};
+// Two-body constraints: body blocks {v1*, w1*, t0, q0_} of a then b. Local DoF order (sets first): v1_a, v1_b, w1_a, w1_b.
+// EnergyRigidBodyConstraints.cpp:64-80. bindings: a_loc, b_loc, stiffness, is_active, dt, body a, body b
+struct E_RBPoints
+{
+    static constexpr const char* name = "rb_constraint_points";
+    using Layout = Strides<3, 3, 1, 1, 1, 3, 3, 3, 4, 3, 3, 3, 4>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {5, 9, 6, 10};
+    MISTARK_ACTIVE_AT(7)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double k = L.s(6), dt = L.s(8);
+        const V3<T> a1 = rb_point(L, 9, 0, 2, L.v(0), dt);
+        const V3<T> b1 = rb_point(L, 22, 1, 3, L.v(3), dt);
+        return 0.5 * k * sqnorm(b1 - a1);
+    }
+};
+template <class T>
+MS_HD T sq_distance_point_line(const V3<T>& p, const V3<T>& a, const V3<T>& b)
+{
+    // stark/src/models/distances.cpp:61-68
+    const V3<T> ab = b - a, ap = p - a;
+    const T e = dot(ap, ab);
+    return dot(ap, ap) - e * e * inv(dot(ab, ab));
+}
+// EnergyRigidBodyConstraints.cpp:82-99. bindings: a_loc, da_loc, b_loc, stiffness, is_active, dt, body a, body b
+struct E_RBPointOnAxis
+{
+    static constexpr const char* name = "rb_constraint_point_on_axis";
+    using Layout = Strides<3, 3, 3, 1, 1, 1, 3, 3, 3, 4, 3, 3, 3, 4>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {6, 10, 7, 11};
+    MISTARK_ACTIVE_AT(10)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double k = L.s(9), dt = L.s(11);
+        const V3<T> a1 = rb_point(L, 12, 0, 2, L.v(0), dt);
+        const V3<T> da1 = rb_dir(L, 15, 21, 2, L.v(3), dt);
+        const V3<T> b1 = rb_point(L, 25, 1, 3, L.v(6), dt);
+        return 0.5 * k * sq_distance_point_line(b1, a1, a1 + da1);
+    }
+};
+// EnergyRigidBodyConstraints.cpp:101-118. bindings: a_loc, b_loc, target_distance, stiffness, is_active, dt, body a, body b
+struct E_RBDistances
+{
+    static constexpr const char* name = "rb_constraint_distances";
+    using Layout = Strides<3, 3, 1, 1, 1, 1, 3, 3, 3, 4, 3, 3, 3, 4>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {6, 10, 7, 11};
+    MISTARK_ACTIVE_AT(8)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double target = L.s(6), k = L.s(7), dt = L.s(9);
+        const V3<T> a1 = rb_point(L, 10, 0, 2, L.v(0), dt);
+        const V3<T> b1 = rb_point(L, 23, 1, 3, L.v(3), dt);
+        return 0.5 * k * pow2(target - norm(b1 - a1));
+    }
+};
+// EnergyRigidBodyConstraints.cpp:120-138. bindings: a_loc, b_loc, min_distance, max_distance, stiffness, is_active, dt, body a, body b
+struct E_RBDistanceLimits
+{
+    static constexpr const char* name = "rb_constraint_distance_limits";
+    using Layout = Strides<3, 3, 1, 1, 1, 1, 1, 3, 3, 3, 4, 3, 3, 3, 4>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {7, 11, 8, 12};
+    MISTARK_ACTIVE_AT(9)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double dmin = L.s(6), dmax = L.s(7), k = L.s(8), dt = L.s(10);
+        const V3<T> a1 = rb_point(L, 11, 0, 2, L.v(0), dt);
+        const V3<T> b1 = rb_point(L, 24, 1, 3, L.v(3), dt);
+        const T length = norm(b1 - a1);
+        T E = T(0.0);
+        if (val(length) < dmin) E = E + (0.5 * k) * pow2(dmin - length);
+        if (val(length) > dmax) E = E + (0.5 * k) * pow2(length - dmax);
+        return E;
+    }
+};
+// EnergyRigidBodyConstraints.cpp:140-156. bindings: da_loc, db_loc, stiffness, is_active, dt, w1_a*, q0_a, w1_b*, q0_b
+struct E_RBDirections
+{
+    static constexpr const char* name = "rb_constraint_directions";
+    using Layout = Strides<3, 3, 1, 1, 1, 3, 4, 3, 4>;
+    static constexpr int NB = 2;
+    static constexpr int dof_binding[NB] = {5, 7};
+    MISTARK_ACTIVE_AT(7)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double k = L.s(6), dt = L.s(8);
+        const V3<T> da = rb_dir(L, 9, 12, 0, L.v(0), dt);
+        const V3<T> db = rb_dir(L, 16, 19, 1, L.v(3), dt);
+        return 0.5 * k * sqnorm(db - da);
+    }
+};
+// EnergyRigidBodyConstraints.cpp:158-175. bindings: da_loc, db_loc, max_distance, stiffness, is_active, dt, w1_a*, q0_a, w1_b*, q0_b
+struct E_RBAngleLimits
+{
+    static constexpr const char* name = "rb_constraint_angle_limits";
+    using Layout = Strides<3, 3, 1, 1, 1, 1, 3, 4, 3, 4>;
+    static constexpr int NB = 2;
+    static constexpr int dof_binding[NB] = {6, 8};
+    MISTARK_ACTIVE_AT(8)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double maxd = L.s(6), k = L.s(7), dt = L.s(9);
+        const V3<T> da = rb_dir(L, 10, 13, 0, L.v(0), dt);
+        const V3<T> db = rb_dir(L, 17, 20, 1, L.v(3), dt);
+        const T length = norm(db - da);
+        if (val(length) > maxd) return (k / 3.0) * pow3(length - maxd);
+        return T(0.0);
+    }
+};
+// EnergyRigidBodyConstraints.cpp:177-196. bindings: a_loc, b_loc, rest_length, stiffness, damping, is_active, dt, body a, body b
+struct E_RBDampedSpring
+{
+    static constexpr const char* name = "rb_constraint_damped_spring";
+    using Layout = Strides<3, 3, 1, 1, 1, 1, 1, 3, 3, 3, 4, 3, 3, 3, 4>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {7, 11, 8, 12};
+    MISTARK_ACTIVE_AT(9)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double rest = L.s(6), k = L.s(7), damping = L.s(8), dt = L.s(10);
+        const V3<T> a1 = rb_point(L, 11, 0, 2, L.v(0), dt);
+        const V3<T> b1 = rb_point(L, 24, 1, 3, L.v(3), dt);
+        const V3<double> a0 = rb_point0(L.in, 11, L.v(0)), b0 = rb_point0(L.in, 24, L.v(3));
+        const T l1 = norm(b1 - a1);
+        const double l0 = norm(b0 - a0);
+        return 0.5 * k * pow2(l1 - rest) + 0.5 * damping * pow2((l1 - l0) * (1.0 / dt));
+    }
+};
+// RigidBodyConstraints.h:54-69 (C1 controller, analogous to C1 friction)
+template <class T>
+MS_HD T c1_controller_energy(const V3<T>& da1, const V3<T>& va1, const V3<T>& vb1, double target, double max_force, double delay, double dt)
+{
+    const T v = dot(da1, vb1 - va1);
+    const double k = max_force / delay, eps = delay / 2.0;
+    const T dv = v - target;
+    if (val(dv) < -delay) return (-max_force * dt) * (dv - eps);
+    if (val(dv) < delay) return (0.5 * k * dt) * pow2(dv);
+    return (max_force * dt) * (dv - eps);
+}
+// EnergyRigidBodyConstraints.cpp:198-218. bindings: da_loc, target_v, max_force, delay, is_active, v1_a*, v1_b*, w1_a*, q0_a, dt
+struct E_RBLinearVelocity
+{
+    static constexpr const char* name = "rb_constraint_linear_velocity";
+    using Layout = Strides<3, 1, 1, 1, 1, 3, 3, 3, 4, 1>;
+    static constexpr int NB = 3;
+    static constexpr int dof_binding[NB] = {5, 6, 7};
+    MISTARK_ACTIVE_AT(6)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double target = L.s(3), max_force = L.s(4), delay = L.s(5), dt = L.s(20);
+        const V3<T> va1 = L.dof(7, 0), vb1 = L.dof(10, 1);
+        const V3<T> da1 = rb_dir(L, 13, 16, 2, L.v(0), dt);
+        return c1_controller_energy(da1, va1, vb1, target, max_force, delay, dt);
+    }
+};
+// EnergyRigidBodyConstraints.cpp:220-238. bindings: da_loc, target_w, max_torque, delay, is_active, w1_a*, w1_b*, q0_a, dt
+struct E_RBAngularVelocity
+{
+    static constexpr const char* name = "rb_constraint_angular_velocity";
+    using Layout = Strides<3, 1, 1, 1, 1, 3, 3, 4, 1>;
+    static constexpr int NB = 2;
+    static constexpr int dof_binding[NB] = {5, 6};
+    MISTARK_ACTIVE_AT(6)
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double target = L.s(3), max_torque = L.s(4), delay = L.s(5), dt = L.s(17);
+        const V3<T> wa1 = L.dof(7, 0), wb1 = L.dof(10, 1);
+        const V3<T> da1 = rb_dir(L, 7, 13, 0, L.v(0), dt);
+        return c1_controller_energy(da1, wa1, wb1, target, max_torque, delay, dt);
+    }
+};
+
+// element condition: potentials without one are always active
+template <class En, class = void>
+struct HasCond : std::false_type {};
+template <class En>
+struct HasCond<En, std::void_t<decltype(En::COND)>> : std::true_type {};
+template <class En>
+MS_HD bool element_active(const double* in)
+{
+    if constexpr (HasCond<En>::value) return En::active(in);
+    else return true;
+}
 
 }  // namespace mistark

@@ -102,6 +102,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_p(PotArgs a, double* __restrict_
     if (e >= a.n_elem) return;
     double in[En::Layout::NIN];
     gather_inputs<En>(a, e, in);
+    if (!element_active<En>(in)) {  // conditional potential, element switched off (SecondOrderCompiledPotential.cpp:185-197)
+        elemE[e] = 0.0;
+        return;
+    }
     Loader<double> L{in};
     elemE[e] = En::energy(L);
 }
@@ -127,14 +131,15 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
     if (!STORE_H && i != j) return;
     double in[En::Layout::NIN];
     gather_inputs<En>(a, e, in);
+    const bool on = element_active<En>(in);
     Loader<HDual> L{in, i, j};
-    const HDual r = En::energy(L);
+    const HDual r = on ? En::energy(L) : HDual(0.0);
     const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
     if (STORE_H) {
         elemH[((size_t)(ba * NB + bb) * a.n_elem + e) * 9 + ii * 3 + jj] = r.ab;
         elemH[((size_t)(bb * NB + ba) * a.n_elem + e) * 9 + jj * 3 + ii] = r.ab;
     }
-    if (i == j) {
+    if (i == j && on) {
         const int row = a.dof_row_off[ba] + a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];
         atomicAdd(&grad[3 * (size_t)row + ii], r.a);
     }

@@ -10,4 +10,17 @@
     X(E_TriangleStrain)            \
     X(E_TriangleStrainEO)          \
     X(E_DiscreteShells)            \
-    X(E_BendingFlat)
+    X(E_BendingFlat)               \
+    X(E_RBInertiaLinear)           \
+    X(E_RBInertiaAngular)          \
+    X(E_RBGlobalPoints)            \
+    X(E_RBGlobalDirections)        \
+    X(E_RBPoints)                  \
+    X(E_RBPointOnAxis)             \
+    X(E_RBDistances)               \
+    X(E_RBDistanceLimits)          \
+    X(E_RBDirections)              \
+    X(E_RBAngleLimits)             \
+    X(E_RBDampedSpring)            \
+    X(E_RBLinearVelocity)          \
+    X(E_RBAngularVelocity)

@@ -32,6 +32,9 @@ FIXTURES = {
     "cloth_flat_6": ("dump", "cloth", "n=6 flat=1 eo=0 steps=2 amp=0.05"),
     "cloth_shells_6": ("dump", "cloth", "n=6 flat=0 eo=0 steps=2 amp=0.05 bend_stiffness=1e-3 bend_damping=1e-4"),
     "cloth_eo_infl_5": ("dump", "cloth", "n=5 flat=1 eo=1 steps=2 amp=0.05 inflation=50"),
+    # rigid bodies: chain of boxes exercising the 2 inertia + 11 constraint potentials
+    "rbchain": ("dump", "rbchain", "steps=2 amp=0.3"),
+    "traj_rbchain": ("traj", "rbchain", "steps=3"),
     # Newton trajectories (iterates after every Newton iteration)
     "traj_tetbeam_eo_8x2x2": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=1 steps=3"),
     "traj_cloth_flat_8": ("traj", "cloth", "n=8 flat=1 eo=0 steps=3"),
