@@ -410,6 +410,192 @@ def rb_constraint_angular_velocity(b):
     return _c1_controller(da1, wa1, wb1, target_w, max_torque, delay, dt), active
 
 
+# ----------------------------------------------------------------------------------------------------------------------
+# IPC contact + friction. stark/src/models/interactions/EnergyFrictionalContact.cpp
+# Every potential is a sequence of symbol-getter groups (:1358-1423) read in binding order, followed by a tail.
+class _Cur:
+    def __init__(self, b):
+        self.b = b
+        self.i = 0
+
+    def take(self, n=1):
+        r = self.b[self.i:self.i + n]
+        self.i += n
+        return r
+
+    def scalar(self):
+        return self.take()[0][0]
+
+    def d_x1(self, k):      # _get_d_x1 (:1393-1399): v1[k]*, x0[k], dt
+        v1 = self.take(k)
+        x0 = self.take(k)
+        dt = self.scalar()
+        return [_x1(x0[i], v1[i], dt) for i in range(k)]
+
+    def d_v1(self, k):      # _get_d_v1 (:1389-1392)
+        return self.take(k)
+
+    def rest(self, k):      # _get_d_X / _get_rb_X
+        return self.take(k)
+
+    def rb(self, k, vel):   # _get_rb_x1 / _get_rb_v1 (:1358-1369): dt, x_loc[k], v1*, w1*, t0, q0_
+        dt = self.scalar()
+        xl = self.take(k)
+        v1, w1, t0, q0 = self.take(4)
+        R1 = _R1(q0, w1, dt)
+        out = []
+        for i in range(k):
+            r = _matvec(R1, xl[i])
+            if vel:
+                out.append(add(v1, cross(w1, r)))   # global_point_velocity_in_rigid_body
+            else:
+                out.append(add([t0[j] + dt * v1[j] for j in range(3)], r))
+        return out
+
+
+def _distance_point_point(p, q):
+    return sqnorm(sub(p, q)).sqrt()
+
+
+def _distance_point_line(p, a, b_):
+    return _sq_distance_point_line(p, a, b_).sqrt()
+
+
+def _distance_point_plane(p, a, b_, c):
+    # stark/src/models/distances.cpp:69-77
+    n = normalized(cross(sub(a, c), sub(b_, c)))
+    d = dot(sub(p, a), n)
+    return (d * d).sqrt()
+
+
+def _distance_line_line(a, b_, p, q):
+    # stark/src/models/distances.cpp:83-89
+    n = cross(sub(b_, a), sub(q, p))
+    l = dot(sub(p, a), n)
+    return (l * l / sqnorm(n)).sqrt()
+
+
+def _barrier(d, dhat, k):
+    return k * (dhat - d).powN(3) / 3.0       # cubic (:1225-1237)
+
+
+def _mollifier(ea, eb, ra, rb_):
+    # :1251-1259
+    eps_x = 1e-3 * sqnorm(sub(ra[0], ra[1])) * sqnorm(sub(rb_[0], rb_[1]))
+    x = sqnorm(cross(sub(ea[1], ea[0]), sub(eb[1], eb[0])))
+    r = x / eps_x
+    f = (-1.0 * r + 2.0) * r
+    return where(x.v > eps_x, 1.0, f)
+
+
+def _pt_contact(A, KA, B, KB, DIST):
+    def f(b):
+        c = _Cur(b)
+        a = c.d_x1(KA) if A == "d" else c.rb(KA, False)
+        bb = c.d_x1(KB) if B == "d" else c.rb(KB, False)
+        dhat = c.scalar() + c.scalar()
+        k = c.scalar()
+        if DIST == 0:
+            d = _distance_point_point(a[0], bb[0])
+        elif DIST == 1:
+            d = _distance_point_line(a[0], bb[0], bb[1])
+        elif DIST == 2:
+            d = _distance_point_plane(a[0], bb[0], bb[1], bb[2])
+        elif DIST == 3:
+            d = _distance_point_line(bb[0], a[0], a[1])
+        else:
+            d = _distance_point_plane(bb[0], a[0], a[1], a[2])
+        return _barrier(d, dhat, k)
+    return f
+
+
+def _ee_contact(A, PA, B, PB, DIST):
+    def side(c, S, P):
+        e = c.d_x1(2) if S == "d" else c.rb(2, False)
+        r = c.rest(2)
+        p = None
+        if P:
+            p = (c.d_x1(1) if S == "d" else c.rb(1, False))[0]
+        return e, r, p
+
+    def f(b):
+        c = _Cur(b)
+        ea, ra, p = side(c, A, PA)
+        eb, rb_, q = side(c, B, PB)
+        k = c.scalar()
+        dhat = c.scalar() + c.scalar()
+        if DIST == 0:
+            d = _distance_point_point(p, q)
+        elif DIST == 1:
+            d = _distance_point_line(p, eb[0], eb[1])
+        elif DIST == 2:
+            d = _distance_line_line(ea[0], ea[1], eb[0], eb[1])
+        else:
+            d = _distance_point_line(q, ea[0], ea[1])
+        return _mollifier(ea, eb, ra, rb_) * _barrier(d, dhat, k)
+    return f
+
+
+def _friction(A, KA, B, KB, KIND):
+    nbary = 0 if KIND == 0 else (3 if KIND in (2, 5) else 2)
+
+    def f(b):
+        c = _Cur(b)
+        a = c.d_v1(KA) if A == "d" else c.rb(KA, True)
+        bb = c.d_v1(KB) if B == "d" else c.rb(KB, True)
+        bary = c.take()[0] if nbary else None
+
+        def comb(pts, n):
+            acc = scale(bary[0], pts[0])
+            for i in range(1, n):
+                acc = add(acc, scale(bary[i], pts[i]))
+            return acc
+        if KIND == 0:
+            v = sub(bb[0], a[0])
+        elif KIND == 1:
+            v = sub(comb(bb, 2), a[0])
+        elif KIND == 2:
+            v = sub(comb(bb, 3), a[0])
+        elif KIND == 3:
+            va = add(a[0], scale(bary[0], sub(a[1], a[0])))
+            vb = add(bb[0], scale(bary[1], sub(bb[1], bb[0])))
+            v = sub(vb, va)
+        elif KIND == 4:
+            v = sub(comb(a, 2), bb[0])
+        else:
+            v = sub(comb(a, 3), bb[0])
+        # _friction_potential (:1260-1278), C0
+        T = c.take()[0]
+        mu, fn, epsv, dt = c.scalar(), c.scalar(), c.scalar(), c.scalar()
+        ut0 = dot(T[0:3], v) * dt + 1.13e-9
+        ut1 = dot(T[3:6], v) * dt - 1.07e-9
+        u = (ut0 * ut0 + ut1 * ut1).sqrt()
+        epsu = dt * epsv
+        k = mu * fn / epsu
+        eps = mu * fn / (2.0 * k)
+        return where(u.v < epsu, 0.5 * k * u.powN(2), mu * fn * (u - eps))
+    return f
+
+
+_CONTACT = {
+    "contact_d_d_pt_pp_cubic": _pt_contact("d", 1, "d", 1, 0), "contact_d_d_pt_pe_cubic": _pt_contact("d", 1, "d", 2, 1),
+    "contact_d_d_pt_pt_cubic": _pt_contact("d", 1, "d", 3, 2), "contact_d_d_ee_pp_cubic": _ee_contact("d", True, "d", True, 0),
+    "contact_d_d_ee_pe_cubic": _ee_contact("d", True, "d", False, 1), "contact_d_d_ee_ee_cubic": _ee_contact("d", False, "d", False, 2),
+    "contact_rb_rb_pt_pp_cubic": _pt_contact("rb", 1, "rb", 1, 0), "contact_rb_rb_pt_pe_cubic": _pt_contact("rb", 1, "rb", 2, 1),
+    "contact_rb_rb_pt_pt_cubic": _pt_contact("rb", 1, "rb", 3, 2), "contact_rb_rb_ee_pp_cubic": _ee_contact("rb", True, "rb", True, 0),
+    "contact_rb_rb_ee_pe_cubic": _ee_contact("rb", True, "rb", False, 1), "contact_rb_rb_ee_ee_cubic": _ee_contact("rb", False, "rb", False, 2),
+    "contact_rb_d_pt_pp_cubic": _pt_contact("rb", 1, "d", 1, 0), "contact_rb_d_pt_pe_cubic": _pt_contact("rb", 1, "d", 2, 1),
+    "contact_rb_d_pt_pt_cubic": _pt_contact("rb", 1, "d", 3, 2), "contact_rb_d_pt_ep_cubic": _pt_contact("rb", 2, "d", 1, 3),
+    "contact_rb_d_pt_tp_cubic": _pt_contact("rb", 3, "d", 1, 4), "contact_rb_d_ee_pp_cubic": _ee_contact("rb", True, "d", True, 0),
+    "contact_rb_d_ee_pe_cubic": _ee_contact("rb", True, "d", False, 1), "contact_rb_d_ee_ee_cubic": _ee_contact("rb", False, "d", False, 2),
+    "contact_rb_d_ee_ep_cubic": _ee_contact("rb", False, "d", True, 3),
+    "friction_d_d_pp_C0": _friction("d", 1, "d", 1, 0), "friction_d_d_pe_C0": _friction("d", 1, "d", 2, 1), "friction_d_d_pt_C0": _friction("d", 1, "d", 3, 2),
+    "friction_d_d_ee_C0": _friction("d", 2, "d", 2, 3), "friction_rb_rb_pp_C0": _friction("rb", 1, "rb", 1, 0), "friction_rb_rb_pe_C0": _friction("rb", 1, "rb", 2, 1),
+    "friction_rb_rb_pt_C0": _friction("rb", 1, "rb", 3, 2), "friction_rb_rb_ee_C0": _friction("rb", 2, "rb", 2, 3), "friction_rb_d_pp_C0": _friction("rb", 1, "d", 1, 0),
+    "friction_rb_d_pe_C0": _friction("rb", 1, "d", 2, 1), "friction_rb_d_pt_C0": _friction("rb", 1, "d", 3, 2), "friction_rb_d_ee_C0": _friction("rb", 2, "d", 2, 3),
+    "friction_rb_d_ep_C0": _friction("rb", 2, "d", 1, 4), "friction_rb_d_tp_C0": _friction("rb", 3, "d", 1, 5),
+}
+
 REGISTRY = {f.__name__: f for f in [
     EnergyLumpedInertia, EnergyPrescribedPositions, EnergyTetStrain, EnergyTetStrain_Elasticity_Only,
     EnergyTriangleStrain, EnergyTriangleStrain_Elasticity_Only, EnergyDiscreteShells, EnergyBendingFlat,
@@ -417,3 +603,4 @@ REGISTRY = {f.__name__: f for f in [
     rb_constraint_points, rb_constraint_point_on_axis, rb_constraint_distances, rb_constraint_distance_limits, rb_constraint_directions,
     rb_constraint_angle_limits, rb_constraint_damped_spring, rb_constraint_linear_velocity, rb_constraint_angular_velocity,
 ]}
+REGISTRY.update(_CONTACT)

@@ -218,8 +218,58 @@ static Scene scene_rbchain(const Args& a)
     return sc;
 }
 
+// Contact zoo: a fixed rigid box, a cloth hovering over it inside the contact distance, a second rigid box and a soft
+// tet block over the cloth, a third rigid box beside the first. IPC contact + friction between every pair.
+static Scene scene_contactmix(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "contactmix");
+    settings.simulation.init_frictional_contact = true;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const double th = a.d("thickness", 0.01);
+    const double gap = a.d("gap", 0.012);
+    auto gp = stark::EnergyFrictionalContact::GlobalParams();
+    gp.default_contact_thickness = th;
+    gp.min_contact_stiffness = a.d("kmin", 1e5);
+    gp.friction_stick_slide_threshold = a.d("epsv", 0.1);
+    sim.interactions->contact->set_global_params(gp);
+    const int n = a.i("n", 6);
+
+    auto [bV, bT, boxA] = sim.presets->rigidbodies->add_box("boxA", 1.0, 0.3);
+    sim.rigidbodies->add_constraint_fix(boxA.rigidbody);
+
+    auto cm = stark::Surface::Params::Cotton_Fabric();
+    auto [cV, cT, cloth] = sim.presets->deformables->add_surface_grid("cloth", { 0.5, 0.5 }, { n, n }, cm);
+    cloth.point_set.add_rotation(10.0, Eigen::Vector3d::UnitZ());
+    cloth.point_set.add_displacement({ 0.01, 0.005, 0.15 + gap });
+
+    auto [b2V, b2T, boxB] = sim.presets->rigidbodies->add_box("boxB", 0.2, 0.1);
+    boxB.rigidbody.add_rotation(25.0, Eigen::Vector3d::UnitZ());
+    boxB.rigidbody.add_translation({ -0.08, 0.06, 0.15 + 2.0 * gap + 0.05 });
+
+    auto [b3V, b3T, boxC] = sim.presets->rigidbodies->add_box("boxC", 0.5, 0.2);
+    boxC.rigidbody.add_rotation(3.0, Eigen::Vector3d(0.2, 0.3, 1.0).normalized());
+    boxC.rigidbody.add_translation({ 0.15 + 0.1 + gap + 0.004, 0.01, 0.03 });
+
+    auto vm = stark::Volume::Params::Soft_Rubber();
+    auto [sV, sT] = stark::generate_tet_grid({ 0.12, -0.1, 0.15 + 2.0 * gap + 0.04 }, { 0.08, 0.08, 0.08 }, { 2, 2, 2 });
+    auto soft = sim.presets->deformables->add_volume("soft", sV, sT, vm);
+
+    const double mu = a.d("mu", 0.5);
+    auto ct = sim.interactions->contact;
+    ct->set_friction(boxA.contact, cloth.contact, mu);
+    ct->set_friction(boxB.contact, cloth.contact, mu);
+    ct->set_friction(boxA.contact, boxC.contact, mu);
+    ct->set_friction(soft.contact, cloth.contact, mu);
+    ct->set_friction(cloth.contact, cloth.contact, mu);
+    sc.json = "{\"kind\":\"contactmix\"}";
+    return sc;
+}
+
 static Scene make_scene(const std::string& name, const Args& a)
 {
+    if (name == "contactmix") return scene_contactmix(a);
     if (name == "rbchain") return scene_rbchain(a);
     if (name == "tetblock") return scene_tetblock(a);
     if (name == "tetbeam") return scene_tetbeam(a);
@@ -435,12 +485,8 @@ int main(int argc, char** argv)
     }
     if (mode == "dump") {
         // Run `steps` time steps, then start the next one by hand, perturb v1 and snapshot
+        // steps = 0: snapshot at the initial configuration (needs a primed JIT cache, see `prime`)
         for (int s = 0; s < steps; s++) sc.sim->run_one_time_step();
-        if (steps == 0) {
-            // Force initialization (JIT) without taking a step: one step on a copy would alter state, so run the
-            // before-simulation path through a zero-gravity-free trick: simply take the snapshot after init callbacks
-            sc.sim->run_one_time_step();
-        }
         std::vector<double> u_conv(st.global_potential->get_total_n_dofs());
         st.global_potential->get_dofs(u_conv.data());
         st.callbacks->run_before_time_step();  // v1 <- 0; friction tables; rb caches

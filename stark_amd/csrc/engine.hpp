@@ -65,8 +65,8 @@ struct DevBuf
     }
 };
 
-constexpr int MAX_BIND = 24;
-constexpr int MAX_NB = 5;
+constexpr int MAX_BIND = 40;
+constexpr int MAX_NB = 8;
 
 // Kernel argument block of one potential (device pointers)
 struct PotArgs
@@ -208,7 +208,6 @@ int find_kind(const char* name);
 int kind_nb(int kind);
 int kind_nbind(int kind);
 void kind_strides(int kind, int* out);
-void kind_dof_bindings(int kind, int* out);
 const char* kind_name(int kind);
 int n_kinds();
 

@@ -38,7 +38,6 @@ struct KindInfo
     const char* name;
     int NB, NBIND, NIN;
     int strides[MAX_BIND];
-    int dofb[MAX_NB];
 };
 static std::vector<KindInfo> make_kinds()
 {
@@ -53,7 +52,6 @@ static std::vector<KindInfo> make_kinds()
         static_assert(En::Layout::NBIND <= MAX_BIND, "too many bindings"); \
         static_assert(En::NB <= MAX_NB, "too many DoF blocks");           \
         En::Layout::strides(k.strides);                                   \
-        for (int i = 0; i < En::NB; i++) k.dofb[i] = En::dof_binding[i];  \
         v.push_back(k);                                                   \
     }
     MISTARK_FOR_EACH_ENERGY(X)
@@ -76,7 +74,6 @@ int find_kind(const char* name)
 int kind_nb(int kind) { return kinds()[kind].NB; }
 int kind_nbind(int kind) { return kinds()[kind].NBIND; }
 void kind_strides(int kind, int* out) { std::memcpy(out, kinds()[kind].strides, sizeof(int) * kinds()[kind].NBIND); }
-void kind_dof_bindings(int kind, int* out) { std::memcpy(out, kinds()[kind].dofb, sizeof(int) * kinds()[kind].NB); }
 
 // ======================================================================================================================
 // Element evaluation
@@ -541,20 +538,23 @@ void prepare(Context& c)
             A.conn = P.conn.p;
             A.conn_stride = P.conn_stride;
             A.n_elem = P.n_elem;
-            int dofb[MAX_NB];
-            kind_dof_bindings(P.kind, dofb);
             for (size_t b = 0; b < P.bindings.size(); b++) {
                 const Array& arr = c.arrays[P.bindings[b].array];
                 A.arr[b] = arr.dev;
                 A.conn_col[b] = P.bindings[b].conn_col;
             }
-            for (int k = 0; k < P.NB; k++) {
-                const mistark_binding& bd = P.bindings[dofb[k]];
-                const Array& arr = c.arrays[bd.array];
-                if (arr.dof_set < 0) throw Error("potential '" + P.name + "': binding " + std::to_string(dofb[k]) + " must be a DoF array");
-                A.dof_col[k] = bd.conn_col;
-                A.dof_row_off[k] = (int)(c.dof_sets[arr.dof_set].offset / 3);
-            }
+            // local DoF blocks: DoF sets in registration order, then binding order (SecondOrderCompiledPotential.cpp:10-33)
+            int nblk = 0;
+            for (int set = 0; set < (int)c.dof_sets.size(); set++)
+                for (size_t b = 0; b < P.bindings.size(); b++) {
+                    const Array& arr = c.arrays[P.bindings[b].array];
+                    if (arr.dof_set != set) continue;
+                    if (nblk >= P.NB) throw Error("potential '" + P.name + "': more DoF bindings than the kernel's " + std::to_string(P.NB) + " blocks");
+                    A.dof_col[nblk] = P.bindings[b].conn_col;
+                    A.dof_row_off[nblk] = (int)(c.dof_sets[set].offset / 3);
+                    nblk++;
+                }
+            if (nblk != P.NB) throw Error("potential '" + P.name + "': expected " + std::to_string(P.NB) + " DoF bindings, got " + std::to_string(nblk));
         }
         c.n_elem_total = e_off;
         c.hess_total = h_off;
@@ -766,9 +766,9 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
 {
     if (!c.have_hessians) throw Error("project: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
     const int np = (int)c.pots.size();
-    if (np + 4 > 64) throw Error("project: too many potentials");
-    c.counters.ensure(64);
-    MS_CHECK(hipMemsetAsync(c.counters.p, 0, 64 * sizeof(int64_t), c.stream));
+    if (np + 4 > 128) throw Error("project: too many potentials");
+    c.counters.ensure(128);
+    MS_CHECK(hipMemsetAsync(c.counters.p, 0, 128 * sizeof(int64_t), c.stream));
     const uint8_t* act = nullptr;
     if (by_gradient) {
         hipLaunchKernelGGL(k_active_blocks, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.grad.p, c.nbr, threshold, c.active_blocks.p, c.counters.p);
@@ -785,7 +785,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         hipLaunchKernelGGL(k_project_select, dim3(grid_for(P.n_elem)), dim3(BLOCK), 0, c.stream, P.n_elem, P.args, P.NB, c.is_projected.p + P.e_off, act, c.proj_list.p + P.e_off,
                            c.counters.p, 4 + pi);
     }
-    int64_t h[64];
+    int64_t h[128];
     MS_CHECK(hipMemcpyAsync(h, c.counters.p, sizeof(h), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
     // 2) eigen-projection, one wavefront per selected element; deltas go straight into the assembled matrix if it is current
@@ -806,6 +806,9 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
             case 3: hipLaunchKernelGGL((k_project_eig<3>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
             case 4: hipLaunchKernelGGL((k_project_eig<4>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
             case 5: hipLaunchKernelGGL((k_project_eig<5>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 6: hipLaunchKernelGGL((k_project_eig<6>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 7: hipLaunchKernelGGL((k_project_eig<7>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 8: hipLaunchKernelGGL((k_project_eig<8>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
             default: throw Error("project: unsupported block count");
         }
     }

@@ -1,5 +1,6 @@
 // registry.hpp — list of the potentials the engine evaluates, keyed by the reference's registry names.
 #pragma once
+#include "contact_energies.hpp"
 #include "energies.hpp"
 
 #define MISTARK_FOR_EACH_ENERGY(X) \
@@ -23,4 +24,5 @@
     X(E_RBAngleLimits)             \
     X(E_RBDampedSpring)            \
     X(E_RBLinearVelocity)          \
-    X(E_RBAngularVelocity)
+    X(E_RBAngularVelocity)         \
+    MISTARK_FOR_EACH_CONTACT_ENERGY(X)

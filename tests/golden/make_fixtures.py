@@ -35,6 +35,10 @@ FIXTURES = {
     # rigid bodies: chain of boxes exercising the 2 inertia + 11 constraint potentials
     "rbchain": ("dump", "rbchain", "steps=2 amp=0.3"),
     "traj_rbchain": ("traj", "rbchain", "steps=3"),
+    # IPC contact + friction zoo (cloth over a fixed rigid box, rigid box + soft block over the cloth, rigid-rigid pair):
+    # at t = 0 (all barrier tables of the initial gaps) and after one step
+    "contactmix_t0": ("dump", "contactmix", "steps=0 amp=0.03"),
+    "contactmix_t1": ("dump", "contactmix", "steps=1 amp=0.003"),
     # Newton trajectories (iterates after every Newton iteration)
     "traj_tetbeam_eo_8x2x2": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=1 steps=3"),
     "traj_cloth_flat_8": ("traj", "cloth", "n=8 flat=1 eo=0 steps=3"),

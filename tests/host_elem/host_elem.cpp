@@ -28,13 +28,12 @@ static void eval(const double* in, int n_elem, double* E, double* g, double* H)
     }
 }
 
-extern "C" int host_elem_info(const char* name, int* nb, int* nin, int* nbind, int* strides, int* dof_binding)
+extern "C" int host_elem_info(const char* name, int* nb, int* nin, int* nbind, int* strides)
 {
 #define X(En)                                                            \
     if (std::strcmp(name, En::name) == 0) {                              \
         *nb = En::NB; *nin = En::Layout::NIN; *nbind = En::Layout::NBIND; \
         En::Layout::strides(strides);                                    \
-        for (int k = 0; k < En::NB; k++) dof_binding[k] = En::dof_binding[k]; \
         return 0;                                                        \
     }
     MISTARK_FOR_EACH_ENERGY(X)
