@@ -68,6 +68,12 @@ typedef struct mistark_binding
  * Returns the potential id (>= 0). Calling again with an existing name replaces connectivity and bindings. */
 int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride,
                       const mistark_binding* bindings, int32_t n_bindings);
+/* Marks a potential whose connectivity changes inside the Newton loop (the reference's contact tables are refilled in
+ * before_energy_evaluation, EnergyFrictionalContact.cpp:117-119). Its Hessian blocks go to a second, small block-CSR part
+ * (A = A_static + A_dynamic) so that a connectivity update only re-patterns that part, not the whole matrix. */
+int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic);
+/* LabelledConnectivity::clear() + push_back() (symx/src/compile/LabelledConnectivity.h): replaces the rows of a potential. */
+int mistark_potential_update_connectivity(mistark_ctx* ctx, int potential, const int32_t* conn, int32_t n_elem);
 /* Number of potentials known to the engine and their registry names (for the shim's "unknown name" error path). */
 int mistark_n_supported_potentials(void);
 const char* mistark_supported_potential(int i);

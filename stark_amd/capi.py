@@ -98,6 +98,8 @@ def lib():
     L.mistark_project.argtypes = [p, dbl, C.c_int, p, C.POINTER(i64), C.POINTER(i64)]
     L.mistark_project_by_gradient.argtypes = [p, dbl, C.c_int, dbl, C.POINTER(C.c_int), C.POINTER(i64)]
     L.mistark_assemble.argtypes = [p]
+    L.mistark_potential_set_dynamic.argtypes = [p, C.c_int, C.c_int]
+    L.mistark_potential_update_connectivity.argtypes = [p, C.c_int, p, C.c_int32]
     L.mistark_get_bsr.argtypes = [p, C.POINTER(i64), C.POINTER(i64), p, p, p]
     L.mistark_spmv.argtypes = [p, p, p]
     L.mistark_apply_preconditioner.argtypes = [p, p, p]

@@ -238,6 +238,33 @@ int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, i
     API_END(_ret)
 }
 
+int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
+    const int part = dynamic ? 1 : 0;
+    if (c.pots[potential].part != part) {
+        c.pots[potential].part = part;
+        c.layout_dirty = true;
+        c.part[0].dirty = c.part[1].dirty = true;
+    }
+    API_END(0)
+}
+int mistark_potential_update_connectivity(mistark_ctx* ctx, int potential, const int32_t* conn, int32_t n_elem)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
+    if (n_elem < 0) throw Error("bad connectivity shape");
+    Potential& P = c.pots[potential];
+    P.n_elem = n_elem;
+    P.conn_host.assign(conn, conn + (size_t)n_elem * P.conn_stride);
+    P.conn_dirty = true;   // -> only this potential's matrix part is re-patterned
+    c.layout_dirty = true;
+    API_END(0)
+}
+
 int64_t mistark_ndofs(mistark_ctx* ctx)
 {
     if (!ctx) return -1;
@@ -355,32 +382,59 @@ int mistark_get_bsr(mistark_ctx* ctx, int64_t* n_block_rows, int64_t* nnzb, int6
     API_BEGIN
     Context& c = ctx->c;
     prepare(c);
-    if (n_block_rows) *n_block_rows = c.nbr;
-    if (nnzb) *nnzb = c.nnzb;
-    if (row_ptr) MS_CHECK(hipMemcpyAsync(row_ptr, c.row_ptr.p, ((size_t)c.nbr + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
-    std::vector<uint32_t> cw;
-    std::vector<float> tv;
-    if (cols) {
-        cw.resize((size_t)c.ntiles * 64);
-        MS_CHECK(hipMemcpyAsync(cw.data(), c.colw.p, cw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-    }
-    if (vals) {
-        if (!c.have_matrix) throw Error("matrix not assembled");
-        tv.resize((size_t)c.ntiles * 576);
-        MS_CHECK(hipMemcpyAsync(tv.data(), c.vals.p, tv.size() * sizeof(float), hipMemcpyDeviceToHost, c.stream));
-    }
-    MS_CHECK(hipStreamSynchronize(c.stream));
-    if (cols)
-        for (int64_t s = 0; s < c.nnzb; s++) cols[s] = (int32_t)(cw[s] & 0x7fffffffu);
-    if (vals)
-        for (int64_t s = 0; s < c.nnzb; s++) {
-            const size_t base = (size_t)(s >> 6) * 576;
-            const size_t lane = (size_t)(s & 63);
-            for (int k = 0; k < 9; k++) {
-                const size_t idx = k < 4 ? base + lane * 4 + k : (k < 8 ? base + 256 + lane * 4 + (k - 4) : base + 512 + lane);
-                vals[(size_t)s * 9 + k] = tv[idx];
-            }
+    // the engine keeps A = A_static + A_dynamic (contacts) as two block-CSR parts; this parity accessor merges them on the host
+    struct Blk
+    {
+        uint64_t key;
+        float v[9];
+    };
+    std::vector<Blk> blks;
+    for (int part = 0; part < 2; part++) {
+        const BsrPart& m = c.part[part];
+        if (m.nnzb == 0) continue;
+        std::vector<uint32_t> cw((size_t)m.nnzb), rw((size_t)m.nnzb);
+        std::vector<float> tv;
+        MS_CHECK(hipMemcpyAsync(cw.data(), m.colw.p, cw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipMemcpyAsync(rw.data(), m.slot_row.p, rw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+        if (vals) {
+            if (!c.have_matrix) throw Error("matrix not assembled");
+            tv.resize((size_t)m.ntiles * 576);
+            MS_CHECK(hipMemcpyAsync(tv.data(), m.vals.p, tv.size() * sizeof(float), hipMemcpyDeviceToHost, c.stream));
         }
+        MS_CHECK(hipStreamSynchronize(c.stream));
+        for (int64_t s = 0; s < m.nnzb; s++) {
+            Blk b{};
+            b.key = (uint64_t)rw[s] * (uint64_t)c.nbr + (uint64_t)(cw[s] & 0x7fffffffu);
+            if (vals) {
+                const size_t base = (size_t)(s >> 6) * 576;
+                const size_t lane = (size_t)(s & 63);
+                for (int k = 0; k < 9; k++) {
+                    const size_t idx = k < 4 ? base + lane * 4 + k : (k < 8 ? base + 256 + lane * 4 + (k - 4) : base + 512 + lane);
+                    b.v[k] = tv[idx];
+                }
+            }
+            blks.push_back(b);
+        }
+    }
+    std::stable_sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) { return a.key < b.key; });
+    size_t n = 0;
+    for (size_t i = 0; i < blks.size(); i++) {
+        if (n > 0 && blks[n - 1].key == blks[i].key) {
+            for (int k = 0; k < 9; k++) blks[n - 1].v[k] += blks[i].v[k];
+        } else blks[n++] = blks[i];
+    }
+    blks.resize(n);
+    if (n_block_rows) *n_block_rows = c.nbr;
+    if (nnzb) *nnzb = (int64_t)n;
+    if (row_ptr) {
+        for (int64_t r = 0; r <= c.nbr; r++) row_ptr[r] = 0;
+        for (const Blk& b : blks) row_ptr[b.key / (uint64_t)c.nbr + 1]++;
+        for (int64_t r = 0; r < c.nbr; r++) row_ptr[r + 1] += row_ptr[r];
+    }
+    if (cols)
+        for (size_t i = 0; i < n; i++) cols[i] = (int32_t)(blks[i].key % (uint64_t)c.nbr);
+    if (vals)
+        for (size_t i = 0; i < n; i++) std::memcpy(vals + 9 * i, blks[i].v, sizeof(float) * 9);
     API_END(0)
 }
 int mistark_spmv(mistark_ctx* ctx, const double* x_host, double* y_host)
@@ -506,7 +560,8 @@ int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n,
     if (avg_ms) *avg_ms = c.spmv_n > 0 ? c.spmv_ms_sum / (double)c.spmv_n : 0.0;
     if (n) *n = c.spmv_n;
     // algorithmic bytes of one SpMV: nnzb*(9*4+4) + (nbr+1)*8 + 2*(3*nbr)*8
-    if (bytes_per_launch) *bytes_per_launch = (double)c.nnzb * 40.0 + ((double)c.nbr + 1.0) * 8.0 + 48.0 * (double)c.nbr;
+    if (bytes_per_launch)
+        *bytes_per_launch = (double)(c.part[0].nnzb + c.part[1].nnzb) * 40.0 + ((double)c.nbr + 1.0) * 8.0 + 48.0 * (double)c.nbr + 56.0 * (double)c.part[1].n_rows;
     if (reset) {
         c.spmv_ms_sum = 0.0;
         c.spmv_n = 0;

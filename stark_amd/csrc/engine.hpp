@@ -112,8 +112,29 @@ struct Potential
     PotArgs args{};
     size_t e_off = 0;   // first element in the element-energy pool
     size_t h_off = 0;   // first double in the element-Hessian pool
-    size_t k_off = 0;   // first key in the pattern key list
+    size_t k_off = 0;   // first 3x3 block in the element-Hessian pool (= h_off / 9)
+    size_t kp_off = 0;  // first key in the key list of its matrix part
+    int part = 0;       // 0: fixed connectivity, 1: connectivity changes inside the Newton loop (contacts)
     bool conn_dirty = true;
+};
+
+// One part of the split system matrix in tiled block-CSR form (see kernels.hip, "SpMV").
+struct BsrPart
+{
+    bool dirty = true;              // connectivity changed -> rebuild this part's pattern
+    bool have_matrix = false;
+    size_t n_keys = 0;
+    DevBuf<uint64_t> keys, keys_alt;
+    DevBuf<uint32_t> kidx, kidx_alt;
+    DevBuf<uint32_t> scan, slot_start;
+    const uint32_t* sorted_src = nullptr;  // element-block ids in sorted key order (one of kidx / kidx_alt)
+    int64_t nnzb = 0, ntiles = 0, n_rows = 0;
+    DevBuf<uint32_t> colw;          // bit31 = last block of its row, bits 0..30 = block column
+    DevBuf<uint32_t> slot_row;      // block row of each slot
+    DevBuf<int32_t> tile_first_row; // compact row of the first block of each tile (bit31: continues the previous tile's row)
+    DevBuf<int32_t> rowmap;         // compact row -> block row
+    DevBuf<int64_t> row_ptr;        // compact rows
+    DevBuf<float> vals;             // tiles of 64 blocks: float4 q0[64], float4 q1[64], float s[64]
 };
 
 struct PcgCtrl
@@ -137,7 +158,6 @@ struct Context
     std::vector<Array> arrays;
     std::vector<Potential> pots;
     bool layout_dirty = true;   // DoF sizes / arrays / potentials changed -> prepare()
-    bool pattern_dirty = true;  // connectivity changed -> rebuild sparsity pattern
 
     int64_t ndofs = 0, nbr = 0;
     DevBuf<double> u, grad, du, r, z, p, q, tmp_a, tmp_b;
@@ -146,24 +166,15 @@ struct Context
     DevBuf<uint8_t> is_projected, active_blocks;
     bool have_hessians = false;
 
-    // sparsity pattern
-    size_t n_keys = 0;
-    DevBuf<uint64_t> keys, keys_alt;
-    DevBuf<uint32_t> kidx, kidx_alt;
-    DevBuf<uint32_t> slot_of_src;  // per element block -> BSR slot
-    DevBuf<uint32_t> scan, slot_start;
-    const uint32_t* sorted_src = nullptr;  // source (element block) ids in sorted key order (one of kidx / kidx_alt)
-    size_t n_hess_blocks = 0;
+    // sparsity pattern / matrix: A = part[0] (fixed connectivity + all diagonal blocks) + part[1] (contacts)
+    BsrPart part[2];
+    DevBuf<uint32_t> slot_of_src;   // per element block (pool order) -> BSR slot inside the potential's part
+    DevBuf<int32_t> diag_slot[2];   // per block row: slot of the diagonal block in each part, -1 if absent
     int spmv_variant = 0;          // micro-benchmark ablation variant
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather
     bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path
     DevBuf<uint8_t> cub_tmp;
-    int64_t nnzb = 0, ntiles = 0;
-    DevBuf<uint32_t> colw;          // bit31 = last block of its row, bits 0..30 = block column
-    DevBuf<int32_t> tile_first_row, diag_slot, row_cnt;
-    DevBuf<int64_t> row_ptr;
-    DevBuf<float> vals;             // tiles of 64 blocks: float4 q0[64], float4 q1[64], float s[64]
     DevBuf<float> dinv;             // 9 floats per block row
     bool have_matrix = false;
     bool matrix_current = false;    // the assembled matrix reflects the current element Hessians

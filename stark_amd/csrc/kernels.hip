@@ -343,7 +343,7 @@ void vec_neg(Context& c, double* dst, const double* x, int64_t n) { vec_axpby(c,
 // ======================================================================================================================
 // prepare(): DoF layout, device arrays, kernel argument blocks, sparsity pattern
 // ======================================================================================================================
-__global__ __launch_bounds__(BLOCK) void k_keys(PotArgs a, int NB, uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t k_off)
+__global__ __launch_bounds__(BLOCK) void k_keys(PotArgs a, int NB, uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t pos_off, uint32_t blk_off)
 {
     const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
     const int nn = NB * NB;
@@ -354,16 +354,17 @@ __global__ __launch_bounds__(BLOCK) void k_keys(PotArgs a, int NB, uint64_t nbr,
     const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
     const uint64_t ra = a.dof_row_off[ba] + ce[a.dof_col[ba]];
     const uint64_t rb = a.dof_row_off[bb] + ce[a.dof_col[bb]];
-    const uint32_t src = k_off + (uint32_t)ab * (uint32_t)a.n_elem + (uint32_t)e;  // = index of the element block in the Hessian pool
-    keys[src] = ra * nbr + rb;
-    idx[src] = src;
+    const uint32_t off = (uint32_t)ab * (uint32_t)a.n_elem + (uint32_t)e;
+    keys[pos_off + off] = ra * nbr + rb;
+    idx[pos_off + off] = blk_off + off;  // index of the element block in the Hessian pool
 }
-__global__ __launch_bounds__(BLOCK) void k_diag_keys(uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t k_off)
+constexpr uint32_t NO_SRC = 0xFFFFFFFFu;
+__global__ __launch_bounds__(BLOCK) void k_diag_keys(uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t pos_off)
 {
     const uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= nbr) return;
-    keys[k_off + r] = r * nbr + r;
-    idx[k_off + r] = k_off + (uint32_t)r;
+    keys[pos_off + r] = r * nbr + r;
+    idx[pos_off + r] = NO_SRC;  // structural diagonal block, carries no data
 }
 __global__ __launch_bounds__(BLOCK) void k_heads(const uint64_t* __restrict__ keys, size_t n, uint32_t* __restrict__ head)
 {
@@ -373,13 +374,13 @@ __global__ __launch_bounds__(BLOCK) void k_heads(const uint64_t* __restrict__ ke
 }
 // scan = inclusive prefix of heads. slot = scan-1.
 __global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ scan, size_t n,
-                                                 uint64_t nbr, uint32_t* __restrict__ slot_of_src, uint32_t* __restrict__ colw, int32_t* __restrict__ row_cnt,
-                                                 int32_t* __restrict__ diag_slot, int32_t* __restrict__ tile_first_row, uint32_t* __restrict__ slot_start)
+                                                 uint64_t nbr, uint32_t* __restrict__ slot_of_src, uint32_t* __restrict__ colw, uint32_t* __restrict__ slot_row,
+                                                 int32_t* __restrict__ diag_slot, uint32_t* __restrict__ slot_start, uint32_t* __restrict__ row_head)
 {
     const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n) return;
     const uint32_t slot = scan[k] - 1;
-    slot_of_src[idx[k]] = slot;
+    if (idx[k] != NO_SRC) slot_of_src[idx[k]] = slot;
     const bool head = (k == 0 || keys[k] != keys[k - 1]);
     if (k == n - 1) slot_start[slot + 1] = (uint32_t)n;
     if (head) {
@@ -391,96 +392,117 @@ __global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ ke
         while (k2 < n && keys[k2] == key) k2++;
         const bool tail = (k2 >= n) || (uint32_t)(keys[k2] / nbr) != row;
         colw[slot] = col | (tail ? 0x80000000u : 0u);
-        atomicAdd(&row_cnt[row], 1);
+        slot_row[slot] = row;
+        row_head[slot] = (k == 0 || (uint32_t)(keys[k - 1] / nbr) != row) ? 1u : 0u;
         if (row == col) diag_slot[row] = (int32_t)slot;
-        if ((slot & 63u) == 0) {
-            // bit 31: the previous block (last of the previous tile) belongs to the same row
-            const bool cont = k > 0 && (uint32_t)(keys[k - 1] / nbr) == row;
-            tile_first_row[slot >> 6] = (int32_t)(row | (cont ? 0x80000000u : 0u));
-        }
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_rowptr_from_excl(const int32_t* __restrict__ excl, const int32_t* __restrict__ cnt, int64_t nbr, int64_t* __restrict__ row_ptr)
+// rscan = inclusive prefix of row_head over slots: compact row of a slot = rscan-1
+__global__ __launch_bounds__(BLOCK) void k_rows(const uint32_t* __restrict__ slot_row, const uint32_t* __restrict__ rscan, int64_t nnzb, int32_t* __restrict__ rowmap,
+                                                int64_t* __restrict__ row_ptr, int32_t* __restrict__ tile_first_row)
 {
-    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (r > nbr) return;
-    row_ptr[r] = r == nbr ? (int64_t)excl[nbr - 1] + cnt[nbr - 1] : (int64_t)excl[r];
+    const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= nnzb) return;
+    const uint32_t r1 = rscan[s];
+    const uint32_t r0 = s > 0 ? rscan[s - 1] : 0u;
+    const uint32_t crow = r1 - 1;
+    const bool head = r1 != r0;
+    if (head) {
+        rowmap[crow] = (int32_t)slot_row[s];
+        row_ptr[crow] = s;
+    }
+    if (s == nnzb - 1) row_ptr[r1] = nnzb;
+    // bit 31: the previous block (last of the previous tile) belongs to the same row
+    if ((s & 63) == 0) tile_first_row[s >> 6] = (int32_t)(crow | (head ? 0u : 0x80000000u));
 }
 
-static void build_pattern(Context& c)
+// Builds the sparsity pattern of one matrix part: part 0 = potentials with fixed connectivity (+ every diagonal block, so
+// each block row exists), part 1 = potentials whose connectivity changes inside the Newton loop (contacts). Part 1 only
+// contains the block rows it touches ("compact rows", rowmap -> global row).
+static void build_pattern(Context& c, int part)
 {
+    BsrPart& m = c.part[part];
     size_t nk = 0;
     for (auto& P : c.pots) {
-        P.k_off = nk;
+        if (P.part != part) continue;
+        P.kp_off = nk;
         nk += (size_t)P.n_elem * P.NB * P.NB;
     }
     const size_t diag_off = nk;
-    nk += (size_t)c.nbr;
-    if (nk >= (1ull << 32)) throw Error("pattern too large for 32-bit source indices");
-    c.n_keys = nk;
-    c.keys.ensure(nk);
-    c.keys_alt.ensure(nk);
-    c.kidx.ensure(nk);
-    c.kidx_alt.ensure(nk);
-    c.slot_of_src.ensure(nk);
-    c.scan.ensure(nk);
-    for (auto& P : c.pots) {
-        if (P.n_elem == 0) continue;
-        hipLaunchKernelGGL(k_keys, dim3(grid_for((int64_t)P.n_elem * P.NB * P.NB)), dim3(BLOCK), 0, c.stream, P.args, P.NB, (uint64_t)c.nbr, c.keys.p, c.kidx.p,
-                           (uint32_t)P.k_off);
+    if (part == 0) nk += (size_t)c.nbr;
+    m.n_keys = nk;
+    m.dirty = false;
+    m.have_matrix = false;
+    c.diag_slot[part].ensure((size_t)c.nbr);
+    MS_CHECK(hipMemsetAsync(c.diag_slot[part].p, 0xFF, (size_t)c.nbr * sizeof(int32_t), c.stream));
+    if (nk == 0) {
+        m.nnzb = m.ntiles = m.n_rows = 0;
+        return;
     }
-    hipLaunchKernelGGL(k_diag_keys, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, (uint64_t)c.nbr, c.keys.p, c.kidx.p, (uint32_t)diag_off);
+    if (nk >= (1ull << 31)) throw Error("pattern too large");
+    m.keys.ensure(nk);
+    m.keys_alt.ensure(nk);
+    m.kidx.ensure(nk);
+    m.kidx_alt.ensure(nk);
+    m.scan.ensure(nk);
+    for (auto& P : c.pots) {
+        if (P.part != part || P.n_elem == 0) continue;
+        hipLaunchKernelGGL(k_keys, dim3(grid_for((int64_t)P.n_elem * P.NB * P.NB)), dim3(BLOCK), 0, c.stream, P.args, P.NB, (uint64_t)c.nbr, m.keys.p, m.kidx.p,
+                           (uint32_t)P.kp_off, (uint32_t)P.k_off);
+    }
+    if (part == 0) hipLaunchKernelGGL(k_diag_keys, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, (uint64_t)c.nbr, m.keys.p, m.kidx.p, (uint32_t)diag_off);
     // sort (key, source) pairs
     int bits = 1;
     while ((1ull << bits) < (uint64_t)c.nbr * (uint64_t)c.nbr && bits < 64) bits++;
     size_t tmp_bytes = 0;
-    hipcub::DoubleBuffer<uint64_t> dk(c.keys.p, c.keys_alt.p);
-    hipcub::DoubleBuffer<uint32_t> dv(c.kidx.p, c.kidx_alt.p);
+    hipcub::DoubleBuffer<uint64_t> dk(m.keys.p, m.keys_alt.p);
+    hipcub::DoubleBuffer<uint32_t> dv(m.kidx.p, m.kidx_alt.p);
     MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, dk, dv, (int)nk, 0, bits, c.stream));
     c.cub_tmp.ensure(tmp_bytes);
     MS_CHECK(hipcub::DeviceRadixSort::SortPairs(c.cub_tmp.p, tmp_bytes, dk, dv, (int)nk, 0, bits, c.stream));
     const uint64_t* skeys = dk.Current();
     const uint32_t* sidx = dv.Current();
-    uint32_t* heads = (uint32_t*)(dv.Current() == c.kidx.p ? c.kidx_alt.p : c.kidx.p);  // the other value buffer is free now
+    uint32_t* heads = (uint32_t*)(dv.Current() == m.kidx.p ? m.kidx_alt.p : m.kidx.p);  // the other value buffer is free now
     hipLaunchKernelGGL(k_heads, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, nk, heads);
     size_t tmp2 = 0;
-    MS_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp2, heads, c.scan.p, (int)nk, c.stream));
+    MS_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp2, heads, m.scan.p, (int)nk, c.stream));
     c.cub_tmp.ensure(tmp2);
-    MS_CHECK(hipcub::DeviceScan::InclusiveSum(c.cub_tmp.p, tmp2, heads, c.scan.p, (int)nk, c.stream));
+    MS_CHECK(hipcub::DeviceScan::InclusiveSum(c.cub_tmp.p, tmp2, heads, m.scan.p, (int)nk, c.stream));
     uint32_t nnzb32 = 0;
-    MS_CHECK(hipMemcpyAsync(&nnzb32, c.scan.p + (nk - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipMemcpyAsync(&nnzb32, m.scan.p + (nk - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
-    c.nnzb = nnzb32;
-    c.ntiles = (c.nnzb + 63) / 64;
-    c.colw.ensure((size_t)c.ntiles * 64);
-    c.tile_first_row.ensure((size_t)c.ntiles);
-    c.diag_slot.ensure((size_t)c.nbr);
-    c.row_cnt.ensure((size_t)c.nbr + 1);
-    c.row_ptr.ensure((size_t)c.nbr + 1);
-    c.vals.ensure((size_t)c.ntiles * 576);
-    c.dinv.ensure((size_t)c.nbr * 9);
-    MS_CHECK(hipMemsetAsync(c.row_cnt.p, 0, ((size_t)c.nbr + 1) * sizeof(int32_t), c.stream));
-    MS_CHECK(hipMemsetAsync(c.colw.p, 0, (size_t)c.ntiles * 64 * sizeof(uint32_t), c.stream));
-    c.slot_start.ensure((size_t)c.nnzb + 1);
-    hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, c.scan.p, nk, (uint64_t)c.nbr, c.slot_of_src.p, c.colw.p, c.row_cnt.p,
-                       c.diag_slot.p, c.tile_first_row.p, c.slot_start.p);
-    c.sorted_src = sidx;
-    c.n_hess_blocks = diag_off;
-    // row_ptr = exclusive scan of the per-row block counts
-    int32_t* excl = (int32_t*)heads;  // reuse
+    m.nnzb = nnzb32;
+    m.ntiles = (m.nnzb + 63) / 64;
+    m.colw.ensure((size_t)m.ntiles * 64);
+    m.slot_row.ensure((size_t)m.nnzb);
+    m.tile_first_row.ensure((size_t)m.ntiles);
+    m.vals.ensure((size_t)m.ntiles * 576);
+    m.slot_start.ensure((size_t)m.nnzb + 1);
+    MS_CHECK(hipMemsetAsync(m.colw.p, 0, (size_t)m.ntiles * 64 * sizeof(uint32_t), c.stream));
+    uint32_t* row_head = heads;  // (heads is dead after the scan)
+    hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, (uint64_t)c.nbr, c.slot_of_src.p, m.colw.p, m.slot_row.p,
+                       c.diag_slot[part].p, m.slot_start.p, row_head);
+    m.sorted_src = sidx;
+    // compact rows
+    uint32_t* rscan = m.scan.p;  // (scan is dead after k_slots)
     size_t tmp3 = 0;
-    MS_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp3, c.row_cnt.p, excl, (int)c.nbr, c.stream));
+    MS_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp3, row_head, rscan, (int)m.nnzb, c.stream));
     c.cub_tmp.ensure(tmp3);
-    MS_CHECK(hipcub::DeviceScan::ExclusiveSum(c.cub_tmp.p, tmp3, c.row_cnt.p, excl, (int)c.nbr, c.stream));
-    hipLaunchKernelGGL(k_rowptr_from_excl, dim3(grid_for(c.nbr + 1)), dim3(BLOCK), 0, c.stream, excl, c.row_cnt.p, c.nbr, c.row_ptr.p);
+    MS_CHECK(hipcub::DeviceScan::InclusiveSum(c.cub_tmp.p, tmp3, row_head, rscan, (int)m.nnzb, c.stream));
+    uint32_t nrows32 = 0;
+    MS_CHECK(hipMemcpyAsync(&nrows32, rscan + (m.nnzb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
-    c.pattern_dirty = false;
-    c.have_matrix = false;
+    m.n_rows = nrows32;
+    m.rowmap.ensure((size_t)m.n_rows);
+    m.row_ptr.ensure((size_t)m.n_rows + 1);
+    hipLaunchKernelGGL(k_rows, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_row.p, rscan, m.nnzb, m.rowmap.p, m.row_ptr.p, m.tile_first_row.p);
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    if (part == 0 && m.n_rows != c.nbr) throw Error("internal: static part must contain every block row");
 }
 
 void prepare(Context& c)
 {
-    if (!c.layout_dirty && !c.pattern_dirty) return;
+    if (!c.layout_dirty && !c.part[0].dirty && !c.part[1].dirty) return;
     if (c.layout_dirty) {
         // DoF layout
         int64_t off = 0;
@@ -502,7 +524,7 @@ void prepare(Context& c)
         if (resized) {
             for (auto& s : c.dof_sets)
                 if (s.n > 0) MS_CHECK(hipMemcpyAsync(c.u.p + s.offset, s.host, s.n * sizeof(double), hipMemcpyHostToDevice, c.stream));
-            c.pattern_dirty = true;
+            c.part[0].dirty = c.part[1].dirty = true;
         }
         // arrays
         for (auto& a : c.arrays) {
@@ -520,10 +542,14 @@ void prepare(Context& c)
             }
         }
         // potentials
+        // pools: static potentials first, so their offsets do not move when only the contact tables change size
         size_t e_off = 0, h_off = 0;
+        for (int part = 0; part < 2; part++)
         for (auto& P : c.pots) {
+            if (P.part != part) continue;
             P.e_off = e_off;
             P.h_off = h_off;
+            P.k_off = h_off / 9;
             e_off += (size_t)P.n_elem;
             h_off += (size_t)P.n_elem * 9 * P.NB * P.NB;
             if (P.conn_dirty) {
@@ -531,7 +557,7 @@ void prepare(Context& c)
                 if (!P.conn_host.empty())
                     MS_CHECK(hipMemcpyAsync(P.conn.p, P.conn_host.data(), P.conn_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
                 P.conn_dirty = false;
-                c.pattern_dirty = true;
+                c.part[P.part].dirty = true;
             }
             PotArgs& A = P.args;
             std::memset(&A, 0, sizeof(A));
@@ -561,11 +587,14 @@ void prepare(Context& c)
         c.elemE.ensure(std::max<size_t>(e_off, 1));
         c.elemH.ensure(std::max<size_t>(h_off, 1));
         c.is_projected.ensure(std::max<size_t>(e_off, 1));
+        c.slot_of_src.ensure(std::max<size_t>(h_off / 9, 1));
+        c.dinv.ensure((size_t)c.nbr * 9);
         MS_CHECK(hipStreamSynchronize(c.stream));
         c.layout_dirty = false;
         c.have_hessians = false;
     }
-    if (c.pattern_dirty) build_pattern(c);
+    for (int part = 0; part < 2; part++)
+        if (c.part[part].dirty) build_pattern(c, part);
 }
 
 // ======================================================================================================================
@@ -789,7 +818,6 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     MS_CHECK(hipMemcpyAsync(h, c.counters.p, sizeof(h), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
     // 2) eigen-projection, one wavefront per selected element; deltas go straight into the assembled matrix if it is current
-    float* vals = c.matrix_current ? c.vals.p : nullptr;
     int64_t total = 0;
     for (int pi = 0; pi < np; pi++) {
         Potential& P = c.pots[pi];
@@ -799,6 +827,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         double* H = c.elemH.p + P.h_off;
         const uint32_t* list = c.proj_list.p + P.e_off;
         const uint32_t* sos = c.slot_of_src.p + P.k_off;
+        float* vals = c.matrix_current ? c.part[P.part].vals.p : nullptr;
         const dim3 g((nl + 3) / 4), b(BLOCK);
         switch (P.NB) {
             case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
@@ -836,7 +865,8 @@ __global__ __launch_bounds__(BLOCK) void k_assemble(const double* __restrict__ e
     const uint32_t slot = slot_of_src[blk];
     atomicAdd(&vals[tile_val_index(slot, comp)], (float)elemH[t]);
 }
-__global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __restrict__ vals, const int32_t* __restrict__ diag_slot, int64_t nbr, float* __restrict__ dinv)
+__global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __restrict__ vals, const int32_t* __restrict__ diag_slot, const float* __restrict__ vals_dyn,
+                                                              const int32_t* __restrict__ diag_slot_dyn, int64_t nbr, float* __restrict__ dinv)
 {
     // closed-form inverse of a SYMMETRIC 3x3 in float, reciprocal of the determinant through double
     // (BlockedSparseMatrix.h:1198-1214)
@@ -846,6 +876,13 @@ __global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __res
     float m[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) m[k] = vals[tile_val_index(s, k)];
+    if (vals_dyn) {
+        const int32_t sd = diag_slot_dyn[r];
+        if (sd >= 0) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) m[k] += vals_dyn[tile_val_index((uint32_t)sd, k)];
+        }
+    }
     const float tmp0 = m[4] * m[8];
     const float tmp1 = m[5] * m[5];
     const float tmp2 = m[2] * m[5];
@@ -868,7 +905,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __res
 // Gather assembly (default): one lane per (BSR block, component) sums the contributions of that block in the fixed order of
 // the sorted pattern keys: no atomics, deterministic, double accumulation rounded once to float; 9 consecutive lanes read the
 // 72 contiguous bytes of an element block.
-__global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restrict__ elemH, uint32_t n_hess_blocks, const uint32_t* __restrict__ slot_start,
+__global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restrict__ elemH, const uint32_t* __restrict__ slot_start,
                                                            const uint32_t* __restrict__ sorted_src, int64_t nnzb, float* __restrict__ vals)
 {
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -879,7 +916,7 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restr
     double acc = 0.0;
     for (uint32_t k = k0; k < k1; k++) {
         const uint32_t src = sorted_src[k];
-        if (src < n_hess_blocks) acc += elemH[(size_t)src * 9 + comp];  // (the always-present diagonal keys carry no data)
+        if (src != NO_SRC) acc += elemH[(size_t)src * 9 + comp];  // (the always-present diagonal keys carry no data)
     }
     vals[tile_val_index(slot, comp)] = (float)acc;
 }
@@ -887,13 +924,20 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restr
 void assemble(Context& c)
 {
     if (!c.have_hessians) throw Error("assemble: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
-    const int64_t nblk = (int64_t)(c.hess_total / 9);
-    if (c.atomic_assembly) {
-        MS_CHECK(hipMemsetAsync(c.vals.p, 0, (size_t)c.ntiles * 576 * sizeof(float), c.stream));
-        if (nblk > 0) hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, nblk, c.slot_of_src.p, c.vals.p);
-    } else {
-        hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(c.nnzb * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, (uint32_t)c.n_hess_blocks, c.slot_start.p, c.sorted_src,
-                           c.nnzb, c.vals.p);
+    for (int part = 0; part < 2; part++) {
+        BsrPart& m = c.part[part];
+        if (m.nnzb == 0) continue;
+        if (c.atomic_assembly) {
+            MS_CHECK(hipMemsetAsync(m.vals.p, 0, (size_t)m.ntiles * 576 * sizeof(float), c.stream));
+            for (auto& P : c.pots) {
+                const int64_t nblk = (int64_t)P.n_elem * P.NB * P.NB;
+                if (P.part != part || nblk == 0) continue;
+                hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p + P.h_off, nblk, c.slot_of_src.p + P.k_off, m.vals.p);
+            }
+        } else {
+            hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.nnzb, m.vals.p);
+        }
+        m.have_matrix = true;
     }
     c.have_matrix = true;
     c.matrix_current = true;
@@ -901,7 +945,9 @@ void assemble(Context& c)
 void build_preconditioner(Context& c)
 {
     if (!c.have_matrix) throw Error("preconditioner: matrix not assembled");
-    hipLaunchKernelGGL(k_block_diag_inverse, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.vals.p, c.diag_slot.p, c.nbr, c.dinv.p);
+    const BsrPart& d = c.part[1];
+    hipLaunchKernelGGL(k_block_diag_inverse, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.part[0].vals.p, c.diag_slot[0].p, d.nnzb ? d.vals.p : (const float*)nullptr,
+                       c.diag_slot[1].p, c.nbr, c.dinv.p);
 }
 
 // ======================================================================================================================
@@ -922,9 +968,11 @@ __device__ __forceinline__ double dpp_row_shr(double v)
 }
 template <int V>
 __global__ __launch_bounds__(BLOCK) void k_spmv_t(const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int32_t* __restrict__ tile_first_row, int64_t nnzb,
-                                                int64_t ntiles, const double* __restrict__ x, double* __restrict__ y, const double* __restrict__ pdot,
-                                                double* __restrict__ partials, const PcgCtrl* __restrict__ ctrl)
+                                                int64_t ntiles, const int32_t* __restrict__ rowmap, int accumulate, const double* __restrict__ x, double* __restrict__ y,
+                                                const double* __restrict__ pdot, double* __restrict__ partials, const PcgCtrl* __restrict__ ctrl)
 {
+    // rowmap != nullptr: the part stores only the block rows it touches (contacts), rowmap[compact row] = block row of y.
+    // accumulate: y += A x (second part of a split matrix), launched after the part that wrote y.
     if (ctrl && ctrl->done) return;
     __shared__ double sm[4];
     const int lane = threadIdx.x & 63;
@@ -1006,10 +1054,15 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_t(const float* __restrict__ vals
         const bool open_end = ((tails >> 63) & 1ull) == 0ull && (t * 64 + 63 < nnzb);
         if (open_end) { k0 = read_lane(y0, 63); k1 = read_lane(y1, 63); k2 = read_lane(y2, 63); }
         if (valid && tail && !ghost) {
-            const int row = tfr + __popcll(tails & ((1ull << lane) - 1ull));
+            int row = tfr + __popcll(tails & ((1ull << lane) - 1ull));
+            if (rowmap) row = rowmap[row];
             double* yr = y + 3 * (size_t)row;
             if (V == 4) {
                 acc += y0 + y1 + y2;
+            } else if (accumulate) {
+                yr[0] += y0;
+                yr[1] += y1;
+                yr[2] += y2;
             } else {
                 yr[0] = y0;
                 yr[1] = y1;
@@ -1027,11 +1080,25 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_t(const float* __restrict__ vals
     }
 }
 
-#define k_spmv k_spmv_t<0>
-static int spmv_grid(const Context& c)
+static int spmv_grid(const Context& c, int64_t ntiles, int max_grid)
 {
-    const int cap = c.spmv_grid_cap > 0 ? std::min(c.spmv_grid_cap, MAX_PARTIALS) : 1024;  // 16 waves/CU measured best (profiles/)
-    return (int)std::min<int64_t>(std::max<int64_t>((c.ntiles + 3) / 4, 1), cap);
+    const int cap = std::min(c.spmv_grid_cap > 0 ? c.spmv_grid_cap : 1024, max_grid);  // 16 waves/CU measured best (profiles/)
+    return (int)std::min<int64_t>(std::max<int64_t>((ntiles + 3) / 4, 1), cap);
+}
+// y = (A_static + A_dynamic) x; partial sums of pdot . y go to partials[0 .. return value)
+template <int V>
+static int launch_spmv(Context& c, const double* x, double* y, const double* pdot, double* partials, const PcgCtrl* ctrl)
+{
+    const BsrPart& m0 = c.part[0];
+    const BsrPart& m1 = c.part[1];
+    const int g0 = spmv_grid(c, m0.ntiles, MAX_PARTIALS / 2);
+    hipLaunchKernelGGL(k_spmv_t<V>, dim3(g0), dim3(BLOCK), 0, c.stream, m0.vals.p, m0.colw.p, m0.tile_first_row.p, m0.nnzb, m0.ntiles, (const int32_t*)nullptr, 0, x, y, pdot,
+                       partials, ctrl);
+    if (m1.nnzb == 0) return g0;
+    const int g1 = spmv_grid(c, m1.ntiles, MAX_PARTIALS / 2);
+    hipLaunchKernelGGL(k_spmv_t<V>, dim3(g1), dim3(BLOCK), 0, c.stream, m1.vals.p, m1.colw.p, m1.tile_first_row.p, m1.nnzb, m1.ntiles, (const int32_t*)m1.rowmap.p, 1, x, y,
+                       pdot, partials ? partials + g0 : nullptr, ctrl);
+    return g0 + g1;
 }
 // Micro-benchmark of the SpMV kernel on the assembled matrix: n back-to-back launches of q = A p (+ fused dot), HIP events
 // around the whole batch on the engine's stream. Returns the average launch duration in microseconds.
@@ -1041,20 +1108,18 @@ double spmv_bench(Context& c, int n)
     hipEvent_t e0, e1;
     MS_CHECK(hipEventCreate(&e0));
     MS_CHECK(hipEventCreate(&e1));
-    const int gs = spmv_grid(c);
     vec_fill(c, c.p.p, 1.0, c.ndofs);
-    for (int w = 0; w < 3; w++)
-        hipLaunchKernelGGL(k_spmv, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr);
+    for (int w = 0; w < 3; w++) launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr);
     MS_CHECK(hipEventRecord(e0, c.stream));
     for (int i = 0; i < n; i++) {
         switch (c.spmv_variant) {
-            case 1: hipLaunchKernelGGL(k_spmv_t<1>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
-            case 2: hipLaunchKernelGGL(k_spmv_t<2>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
-            case 4: hipLaunchKernelGGL(k_spmv_t<4>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
-            case 5: hipLaunchKernelGGL(k_spmv_t<5>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
-            case 6: hipLaunchKernelGGL(k_spmv_t<6>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
-            case 3: hipLaunchKernelGGL(k_spmv_t<3>, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr); break;
-            default: hipLaunchKernelGGL(k_spmv, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, c.partials.p, (const PcgCtrl*)nullptr);
+            case 1: launch_spmv<1>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
+            case 2: launch_spmv<2>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
+            case 3: launch_spmv<3>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
+            case 4: launch_spmv<4>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
+            case 5: launch_spmv<5>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
+            case 6: launch_spmv<6>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
+            default: launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr);
         }
     }
     MS_CHECK(hipEventRecord(e1, c.stream));
@@ -1069,8 +1134,7 @@ double spmv_bench(Context& c, int n)
 void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed)
 {
     (void)timed;
-    hipLaunchKernelGGL(k_spmv, dim3(spmv_grid(c)), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, x, y, pdot, partials,
-                       (const PcgCtrl*)nullptr);
+    launch_spmv<0>(c, x, y, pdot, partials, nullptr);
 }
 
 // ======================================================================================================================
@@ -1230,7 +1294,6 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     if (!c.have_matrix) throw Error("pcg: matrix not assembled");
     build_preconditioner(c);
     const int gv = grid_for(c.nbr, BLOCK, VEC_GRID);
-    const int gs = spmv_grid(c);
     double* part_pq = c.partials.p;
     double* part_rr = c.partials.p + MAX_PARTIALS;
     double* part_rz = c.partials.p + 2 * MAX_PARTIALS;
@@ -1259,7 +1322,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
                 }
                 MS_CHECK(hipEventRecord(c.ev[2 * sampled.size()], c.stream));
             }
-            hipLaunchKernelGGL(k_spmv, dim3(gs), dim3(BLOCK), 0, c.stream, c.vals.p, c.colw.p, c.tile_first_row.p, c.nnzb, c.ntiles, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p);
+            const int gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p);
             if (sample) {
                 MS_CHECK(hipEventRecord(c.ev[2 * sampled.size() + 1], c.stream));
                 sampled.push_back(k);

@@ -65,6 +65,14 @@ class Engine:
         self.potential_ids[name] = pid
         return pid
 
+    def set_dynamic(self, pid: int, dynamic: bool = True):
+        """Routes the potential's Hessian blocks to the dynamic (contact) part of the split matrix."""
+        self._ck(self.L.mistark_potential_set_dynamic(self.h, pid, int(dynamic)))
+
+    def update_connectivity(self, pid: int, conn: np.ndarray):
+        conn = np.ascontiguousarray(conn, dtype=np.int32)
+        self._ck(self.L.mistark_potential_update_connectivity(self.h, pid, conn.ctypes.data if conn.size else None, conn.shape[0]))
+
     def upload(self, array: int = -1):
         self._ck(self.L.mistark_upload(self.h, array))
 
