@@ -18,6 +18,8 @@
 //   symx::SecondOrderCompiledPotential / Assembly / ElementHessians           symx/src/solver/second_order/*.h
 //   bsm::BlockedSparseMatrix::{to_triplets,prepare_preconditioning}, bsm::solve_pcg   BlockedSparseMatrix/*.h
 #include <stark>
+#include "ipc_toolkit_geometry_functions.h"       // TriangleMeshCollisionDetection/src (narrow-phase classification)
+#include "models/interactions/friction_geometry.h"  // stark/src
 #include <Eigen/Sparse>
 #include <cstdio>
 #include <cstdlib>
@@ -69,9 +71,47 @@ struct Args
     std::string s(const std::string& k, const std::string& def) const { auto it = kv.find(k); return it == kv.end() ? def : it->second; }
 };
 
+// A collision mesh as handed to EnergyFrictionalContact::add_triangles (EnergyFrictionalContact.cpp:54-91), recorded so
+// that fixtures carry the detector's inputs next to the reference's contact tables
+struct ContactMeshRecord
+{
+    std::string kind;                          // "d" (deformable) or "rb"
+    int idx_in_ps = 0;                         // point set index / rigid body index
+    std::vector<int> verts;                    // per collision vertex: global index in the physical system's vertex array
+    std::vector<std::array<int, 3>> triangles; // local connectivity
+    std::vector<std::array<int, 2>> edges;     // find_edges_from_simplices(triangles, n_vertices)
+    double thickness = 0.0;
+};
 struct Scene
 {
     std::unique_ptr<stark::Simulation> sim;
+    std::vector<ContactMeshRecord> contact_meshes;
+    std::vector<std::array<double, 3>> friction_pairs;  // (mesh a, mesh b, mu)
+    int n_rb_collision_vertices = 0;
+    void record_deformable(const stark::PointSetHandler& ps, const std::vector<std::array<int, 3>>& tris, const std::vector<int>& map, double thickness)
+    {
+        ContactMeshRecord m;
+        m.kind = "d";
+        m.idx_in_ps = ps.get_idx();
+        for (int l : map) m.verts.push_back(ps.get_global_index(l));
+        m.triangles = tris;
+        m.edges = stark::find_edges_from_simplices(tris, (int)map.size());
+        m.thickness = thickness;
+        contact_meshes.push_back(m);
+    }
+    void record_rigid(const stark::RigidBodyHandler& rb, int n_vertices, const std::vector<std::array<int, 3>>& tris, double thickness)
+    {
+        ContactMeshRecord m;
+        m.kind = "rb";
+        m.idx_in_ps = rb.get_idx();
+        for (int l = 0; l < n_vertices; l++) m.verts.push_back(n_rb_collision_vertices + l);
+        n_rb_collision_vertices += n_vertices;
+        m.triangles = tris;
+        m.edges = stark::find_edges_from_simplices(tris, n_vertices);
+        m.thickness = thickness;
+        contact_meshes.push_back(m);
+    }
+    void record_friction(int a, int b, double mu) { friction_pairs.push_back({ (double)a, (double)b, mu }); }
     std::string json;  // scene description echoed into the manifest so the build can construct the identical scene
 };
 
@@ -238,23 +278,32 @@ static Scene scene_contactmix(const Args& a)
 
     auto [bV, bT, boxA] = sim.presets->rigidbodies->add_box("boxA", 1.0, 0.3);
     sim.rigidbodies->add_constraint_fix(boxA.rigidbody);
+    sc.record_rigid(boxA.rigidbody, (int)bV.size(), bT, th);
 
     auto cm = stark::Surface::Params::Cotton_Fabric();
     auto [cV, cT, cloth] = sim.presets->deformables->add_surface_grid("cloth", { 0.5, 0.5 }, { n, n }, cm);
+    sc.record_deformable(cloth.point_set, cT, cloth.point_set.all(), th);
     cloth.point_set.add_rotation(10.0, Eigen::Vector3d::UnitZ());
     cloth.point_set.add_displacement({ 0.01, 0.005, 0.15 + gap });
 
     auto [b2V, b2T, boxB] = sim.presets->rigidbodies->add_box("boxB", 0.2, 0.1);
+    sc.record_rigid(boxB.rigidbody, (int)b2V.size(), b2T, th);
     boxB.rigidbody.add_rotation(25.0, Eigen::Vector3d::UnitZ());
     boxB.rigidbody.add_translation({ -0.08, 0.06, 0.15 + 2.0 * gap + 0.05 });
 
     auto [b3V, b3T, boxC] = sim.presets->rigidbodies->add_box("boxC", 0.5, 0.2);
+    sc.record_rigid(boxC.rigidbody, (int)b3V.size(), b3T, th);
     boxC.rigidbody.add_rotation(3.0, Eigen::Vector3d(0.2, 0.3, 1.0).normalized());
     boxC.rigidbody.add_translation({ 0.15 + 0.1 + gap + 0.004, 0.01, 0.03 });
 
     auto vm = stark::Volume::Params::Soft_Rubber();
     auto [sV, sT] = stark::generate_tet_grid({ 0.12, -0.1, 0.15 + 2.0 * gap + 0.04 }, { 0.08, 0.08, 0.08 }, { 2, 2, 2 });
     auto soft = sim.presets->deformables->add_volume("soft", sV, sT, vm);
+    {
+        // the preset extracts the collision surface with find_surface (DeformablesPresets.cpp:66-72); same call, same result
+        auto [surf, map] = stark::find_surface(sV, sT);
+        sc.record_deformable(soft.point_set, surf, map, th);
+    }
 
     const double mu = a.d("mu", 0.5);
     auto ct = sim.interactions->contact;
@@ -263,12 +312,69 @@ static Scene scene_contactmix(const Args& a)
     ct->set_friction(boxA.contact, boxC.contact, mu);
     ct->set_friction(soft.contact, cloth.contact, mu);
     ct->set_friction(cloth.contact, cloth.contact, mu);
+    sc.record_friction(0, 1, mu);
+    sc.record_friction(2, 1, mu);
+    sc.record_friction(0, 3, mu);
+    sc.record_friction(4, 1, mu);
+    sc.record_friction(1, 1, mu);
     sc.json = "{\"kind\":\"contactmix\"}";
+    return sc;
+}
+
+// Vertex/edge contacts: box corners aimed at a corner and at an edge of a fixed box, a soft block corner aimed at another
+// corner -> the point-point and point-edge rows of the rb-rb and rb-deformable tables that flat contacts never produce
+static Scene scene_contactcorners(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "contactcorners");
+    settings.simulation.init_frictional_contact = true;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const double th = a.d("thickness", 0.01);
+    const double g = a.d("gap", 0.012);
+    auto gp = stark::EnergyFrictionalContact::GlobalParams();
+    gp.default_contact_thickness = th;
+    gp.min_contact_stiffness = a.d("kmin", 1e5);
+    sim.interactions->contact->set_global_params(gp);
+    const double h = 0.15, s3 = g / std::sqrt(3.0), s2 = g / std::sqrt(2.0);
+
+    auto [aV, aT, boxA] = sim.presets->rigidbodies->add_box("boxA", 1.0, 2.0 * h);
+    sim.rigidbodies->add_constraint_fix(boxA.rigidbody);
+    sc.record_rigid(boxA.rigidbody, (int)aV.size(), aT, th);
+
+    // corner of D on the diagonal of A's (+,+,+) corner
+    auto [dV, dT, boxD] = sim.presets->rigidbodies->add_box("boxD", 0.2, 0.1);
+    sc.record_rigid(boxD.rigidbody, (int)dV.size(), dT, th);
+    boxD.rigidbody.add_translation({ h + s3 + 0.05, h + s3 + 0.05, h + s3 + 0.05 });
+
+    // corner of E over the middle of A's edge (x = +h, z = +h)
+    auto [eV, eT, boxE] = sim.presets->rigidbodies->add_box("boxE", 0.2, 0.1);
+    sc.record_rigid(boxE.rigidbody, (int)eV.size(), eT, th);
+    boxE.rigidbody.add_translation({ h + s2 + 0.05, 0.013 + 0.05, h + s2 + 0.05 });
+
+    // corner of a soft block on the diagonal of A's (-,-,+) corner
+    auto vm = stark::Volume::Params::Soft_Rubber();
+    auto [sV, sT] = stark::generate_tet_grid({ -h - s3 - 0.04, -h - s3 - 0.04, h + s3 + 0.04 }, { 0.08, 0.08, 0.08 }, { 1, 1, 1 });
+    auto soft = sim.presets->deformables->add_volume("soft", sV, sT, vm);
+    {
+        auto [surf, map] = stark::find_surface(sV, sT);
+        sc.record_deformable(soft.point_set, surf, map, th);
+    }
+    const double mu = a.d("mu", 0.5);
+    auto ct = sim.interactions->contact;
+    ct->set_friction(boxA.contact, boxD.contact, mu);
+    ct->set_friction(boxA.contact, boxE.contact, mu);
+    ct->set_friction(boxA.contact, soft.contact, mu);
+    sc.record_friction(0, 1, mu);
+    sc.record_friction(0, 2, mu);
+    sc.record_friction(0, 3, mu);
+    sc.json = "{\"kind\":\"contactcorners\"}";
     return sc;
 }
 
 static Scene make_scene(const std::string& name, const Args& a)
 {
+    if (name == "contactcorners") return scene_contactcorners(a);
     if (name == "contactmix") return scene_contactmix(a);
     if (name == "rbchain") return scene_rbchain(a);
     if (name == "tetblock") return scene_tetblock(a);
@@ -443,6 +549,25 @@ static void dump_snapshot(Scene& sc, const std::string& dir, const Args& a)
         npy_f64(dir + "/prec_z.npy", z.data(), { (size_t)ndofs });
         st.context->n_threads = nt_save;
     }
+    // Collision meshes handed to the contact model (detector inputs; the tables above are the reference's detector outputs)
+    if (!sc.contact_meshes.empty()) {
+        man << "\"contact\":{\"stiffness\":" << sc.sim->interactions->contact->get_contact_stiffness() << ",\"meshes\":[";
+        for (size_t k = 0; k < sc.contact_meshes.size(); k++) {
+            const ContactMeshRecord& m = sc.contact_meshes[k];
+            const std::string P = dir + "/cm" + std::to_string(k);
+            std::vector<int32_t> v(m.verts.begin(), m.verts.end()), t, e;
+            for (auto& tri : m.triangles) t.insert(t.end(), tri.begin(), tri.end());
+            for (auto& ed : m.edges) e.insert(e.end(), ed.begin(), ed.end());
+            npy_i32(P + "_verts.npy", v.data(), { v.size() });
+            npy_i32(P + "_tris.npy", t.data(), { m.triangles.size(), (size_t)3 });
+            npy_i32(P + "_edges.npy", e.data(), { m.edges.size(), (size_t)2 });
+            man << (k ? "," : "") << "{\"kind\":" << jstr(m.kind) << ",\"idx_in_ps\":" << m.idx_in_ps << ",\"thickness\":" << m.thickness << "}";
+        }
+        man << "],\"friction\":[";
+        for (size_t k = 0; k < sc.friction_pairs.size(); k++)
+            man << (k ? "," : "") << "[" << (int)sc.friction_pairs[k][0] << "," << (int)sc.friction_pairs[k][1] << "," << sc.friction_pairs[k][2] << "]";
+        man << "]},\n";
+    }
     man << "\"end\":0\n}\n";
     std::ofstream(dir + "/manifest.json") << man.str();
 }
@@ -470,6 +595,88 @@ int main(int argc, char** argv)
         std::string s = argv[i];
         auto p = s.find('=');
         if (p != std::string::npos) a.kv[s.substr(0, p)] = s.substr(p + 1);
+    }
+    if (mode == "geom") {
+        // Known-answer vectors of the narrow-phase classification (ipc_toolkit_geometry_functions.cpp), the edge-triangle
+        // intersection test and the friction geometry (friction_geometry.cpp) on seeded pseudo-random primitives
+        const std::string dir = a.s("out", "/tmp/mistark_fixture");
+        fs::create_directories(dir);
+        const int n = a.i("n", 400);
+        uint64_t state = 0x9E3779B97F4A7C15ull;
+        auto rnd = [&]() {  // xorshift64*, uniform in [-1, 1)
+            state ^= state >> 12; state ^= state << 25; state ^= state >> 27;
+            return (double)((state * 0x2545F4914F6CDD1Dull) >> 11) / 9007199254740992.0 * 2.0 - 1.0;
+        };
+        auto V = [](const double* x) { return tmcd::Vec3d(x[0], x[1], x[2]); };
+        auto Ev = [](const double* x) { return Eigen::Vector3d(x[0], x[1], x[2]); };
+        std::vector<double> pt_in((size_t)n * 12), pt_d2(n), ee_in((size_t)n * 12), ee_d2(n), et_in((size_t)n * 15);
+        std::vector<int32_t> pt_type(n), ee_type(n), et_hit(n);
+        std::vector<double> fr_pt((size_t)n * 9), fr_pe((size_t)n * 8), fr_pp((size_t)n * 6), fr_ee((size_t)n * 8);
+        for (int i = 0; i < n; i++) {
+            // point - triangle: the point is placed over/around the triangle so that every region occurs
+            double* x = &pt_in[(size_t)i * 12];
+            for (int k = 3; k < 12; k++) x[k] = rnd();
+            {
+                const double a0 = 1.25 * rnd() + 0.25, b0 = 1.25 * rnd() + 0.25, h = 0.2 * rnd();
+                const tmcd::Vec3d t0 = V(x + 3), t1 = V(x + 6), t2 = V(x + 9);
+                const tmcd::Vec3d nrm = (t1 - t0).cross(t2 - t0);
+                const tmcd::Vec3d p = t0 + (t1 - t0) * a0 + (t2 - t0) * b0 + nrm * h;
+                for (int k = 0; k < 3; k++) x[k] = p[k];
+                tmcd::PointTriangleDistanceType ty;
+                pt_d2[i] = tmcd::point_triangle_sq_distance(ty, p, t0, t1, t2);
+                pt_type[i] = (int)ty;
+                const auto bary = stark::barycentric_point_triangle(Ev(x), Ev(x + 3), Ev(x + 6), Ev(x + 9));
+                const auto T = stark::projection_matrix_triangle(Ev(x + 3), Ev(x + 6), Ev(x + 9));
+                for (int k = 0; k < 3; k++) fr_pt[(size_t)i * 9 + k] = bary[k];
+                for (int k = 0; k < 6; k++) fr_pt[(size_t)i * 9 + 3 + k] = T[k];
+                const auto b2 = stark::barycentric_point_edge(Ev(x), Ev(x + 3), Ev(x + 6));
+                const auto T2 = stark::projection_matrix_point_edge(Ev(x), Ev(x + 3), Ev(x + 6));
+                for (int k = 0; k < 2; k++) fr_pe[(size_t)i * 8 + k] = b2[k];
+                for (int k = 0; k < 6; k++) fr_pe[(size_t)i * 8 + 2 + k] = T2[k];
+                const auto T3 = stark::projection_matrix_point_point(Ev(x), Ev(x + 3));
+                for (int k = 0; k < 6; k++) fr_pp[(size_t)i * 6 + k] = T3[k];
+            }
+            // edge - edge: every fourth pair nearly parallel
+            double* y = &ee_in[(size_t)i * 12];
+            for (int k = 0; k < 12; k++) y[k] = rnd();
+            if (i % 4 == 3)
+                for (int k = 0; k < 3; k++) y[9 + k] = y[6 + k] + (y[3 + k] - y[k]) * (0.5 + 0.4 * rnd()) + 1e-7 * rnd();
+            {
+                tmcd::EdgeEdgeDistanceType ty;
+                ee_d2[i] = tmcd::edge_edge_sq_distance(ty, V(y), V(y + 3), V(y + 6), V(y + 9), 1e-30);
+                ee_type[i] = (int)ty;
+                const auto b = stark::barycentric_edge_edge(Ev(y), Ev(y + 3), Ev(y + 6), Ev(y + 9));
+                const auto T = stark::projection_matrix_edge_edge(Ev(y), Ev(y + 3), Ev(y + 6), Ev(y + 9));
+                for (int k = 0; k < 2; k++) fr_ee[(size_t)i * 8 + k] = b[k];
+                for (int k = 0; k < 6; k++) fr_ee[(size_t)i * 8 + 2 + k] = T[k];
+            }
+            // edge - triangle intersection: the edge is aimed at a point around the triangle
+            double* w = &et_in[(size_t)i * 15];
+            for (int k = 6; k < 15; k++) w[k] = rnd();
+            {
+                const double a0 = 0.8 * rnd() + 0.3, b0 = 0.8 * rnd() + 0.3;
+                const tmcd::Vec3d t0 = V(w + 6), t1 = V(w + 9), t2 = V(w + 12);
+                const tmcd::Vec3d c = t0 + (t1 - t0) * a0 + (t2 - t0) * b0;
+                const tmcd::Vec3d dir(rnd(), rnd(), rnd());
+                const double s0 = 0.5 + rnd(), s1 = 0.5 + rnd();
+                const tmcd::Vec3d q0 = c - dir * s0, q1 = c + dir * s1;
+                for (int k = 0; k < 3; k++) { w[k] = q0[k]; w[3 + k] = q1[k]; }
+                et_hit[i] = tmcd::is_edge_intersecting_triangle(q0, q1, t0, t1, t2) ? 1 : 0;
+            }
+        }
+        npy_f64(dir + "/pt_in.npy", pt_in.data(), { (size_t)n, 12 });
+        npy_f64(dir + "/pt_d2.npy", pt_d2.data(), { (size_t)n });
+        npy_i32(dir + "/pt_type.npy", pt_type.data(), { (size_t)n });
+        npy_f64(dir + "/ee_in.npy", ee_in.data(), { (size_t)n, 12 });
+        npy_f64(dir + "/ee_d2.npy", ee_d2.data(), { (size_t)n });
+        npy_i32(dir + "/ee_type.npy", ee_type.data(), { (size_t)n });
+        npy_f64(dir + "/et_in.npy", et_in.data(), { (size_t)n, 15 });
+        npy_i32(dir + "/et_hit.npy", et_hit.data(), { (size_t)n });
+        npy_f64(dir + "/fr_pt.npy", fr_pt.data(), { (size_t)n, 9 });
+        npy_f64(dir + "/fr_pe.npy", fr_pe.data(), { (size_t)n, 8 });
+        npy_f64(dir + "/fr_pp.npy", fr_pp.data(), { (size_t)n, 6 });
+        npy_f64(dir + "/fr_ee.npy", fr_ee.data(), { (size_t)n, 8 });
+        return 0;
     }
     symx::suppress_compiler_output(true);
     Scene sc = make_scene(scene_name, a);

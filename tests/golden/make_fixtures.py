@@ -39,6 +39,10 @@ FIXTURES = {
     # at t = 0 (all barrier tables of the initial gaps) and after one step
     "contactmix_t0": ("dump", "contactmix", "steps=0 amp=0.03"),
     "contactmix_t1": ("dump", "contactmix", "steps=1 amp=0.003"),
+    # box / soft-block corners aimed at a corner and an edge of a fixed box: vertex-vertex and vertex-edge rows
+    "contactcorners_t0": ("dump", "contactcorners", "steps=0 amp=0.01"),
+    # known-answer vectors of the narrow-phase classification, edge-triangle intersection and friction geometry
+    "contact_geometry": ("geom", "none", "n=600"),
     # Newton trajectories (iterates after every Newton iteration)
     "traj_tetbeam_eo_8x2x2": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=1 steps=3"),
     "traj_cloth_flat_8": ("traj", "cloth", "n=8 flat=1 eo=0 steps=3"),
@@ -55,7 +59,8 @@ def pack(name):
     tmp = tempfile.mkdtemp(prefix="mistark_fx_")
     try:
         scene_args = [a for a in args if not a.startswith(("steps=", "amp="))]
-        run([HARNESS, "prime", scene] + scene_args)
+        if mode != "geom":
+            run([HARNESS, "prime", scene] + scene_args)
         run([HARNESS, mode, scene] + args + ["out=" + tmp])
         data = {}
         for fn in sorted(os.listdir(tmp)):
