@@ -21,6 +21,14 @@ class Binding(C.Structure):
     _fields_ = [("array", C.c_int32), ("stride", C.c_int32), ("conn_col", C.c_int32)]
 
 
+CONTACT_ROLES = ["v1", "x0", "X", "dt", "k", "thickness", "epsv", "rb_xloc", "rb_v1", "rb_w1", "rb_t0", "rb_q0"]
+
+
+class ContactArrays(C.Structure):
+    """include/mistark_contact.h: mistark_contact_arrays (engine array ids, -1 = absent)."""
+    _fields_ = [(r, C.c_int32) for r in CONTACT_ROLES]
+
+
 class PcgInfo(C.Structure):
     _fields_ = [("converged", C.c_int32), ("n_iterations", C.c_int32), ("found_indefiniteness", C.c_int32), ("reserved", C.c_int32), ("error", C.c_double)]
 
@@ -100,6 +108,18 @@ def lib():
     L.mistark_assemble.argtypes = [p]
     L.mistark_potential_set_dynamic.argtypes = [p, C.c_int, C.c_int]
     L.mistark_potential_update_connectivity.argtypes = [p, C.c_int, p, C.c_int32]
+    L.mistark_contact_init.argtypes = [p, C.POINTER(ContactArrays)]
+    L.mistark_contact_add_mesh.argtypes = [p, C.c_int, C.c_int, p, C.c_int32, p, C.c_int32, p, C.c_int32]
+    L.mistark_contact_set_friction.argtypes = [p, C.c_int, C.c_int, C.c_double]
+    L.mistark_contact_disable_collision.argtypes = [p, C.c_int, C.c_int]
+    L.mistark_contact_enable.argtypes = [p, C.c_int, C.c_int]
+    L.mistark_contact_update.argtypes = [p, C.c_double, C.POINTER(i64)]
+    L.mistark_contact_update_friction.argtypes = [p, C.POINTER(i64)]
+    L.mistark_contact_count_intersections.argtypes = [p, C.c_double, C.POINTER(i64)]
+    L.mistark_contact_get_table.argtypes = [p, C.c_char_p, p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.mistark_contact_get_friction_data.argtypes = [p, C.c_char_p, p, p, p, p, C.POINTER(C.c_int32)]
+    L.mistark_contact_get_vertices.argtypes = [p, p, C.POINTER(i64)]
+    L.mistark_contact_recipe.argtypes = [C.c_char_p, C.POINTER(C.c_int32), p, p, p]
     L.mistark_get_bsr.argtypes = [p, C.POINTER(i64), C.POINTER(i64), p, p, p]
     L.mistark_spmv.argtypes = [p, p, p]
     L.mistark_apply_preconditioner.argtypes = [p, p, p]

@@ -20,6 +20,47 @@ using namespace mistark;
     }                                  \
     return ret;
 
+namespace mistark {
+int register_potential(Context& c, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings)
+{
+    const int kind = find_kind(name);
+    if (kind < 0) throw Error(std::string("unknown potential '") + name + "' (no MI355X kernel registered under this name)");
+    if (n_bindings != kind_nbind(kind)) throw Error(std::string("potential '") + name + "': expected " + std::to_string(kind_nbind(kind)) + " bindings, got " + std::to_string(n_bindings));
+    int strides[MAX_BIND];
+    kind_strides(kind, strides);
+    for (int b = 0; b < n_bindings; b++) {
+        if (bindings[b].array < 0 || bindings[b].array >= (int)c.arrays.size()) throw Error(std::string("potential '") + name + "': bad array id in binding " + std::to_string(b));
+        if (bindings[b].stride != strides[b] || c.arrays[bindings[b].array].stride != strides[b])
+            throw Error(std::string("potential '") + name + "': binding " + std::to_string(b) + " must have stride " + std::to_string(strides[b]));
+        if (bindings[b].conn_col >= conn_stride) throw Error(std::string("potential '") + name + "': connectivity column out of range");
+    }
+    if (n_elem < 0 || conn_stride <= 0) throw Error("bad connectivity shape");
+    Potential* P = nullptr;
+    int id = -1;
+    for (size_t i = 0; i < c.pots.size(); i++)
+        if (c.pots[i].name == name) {
+            P = &c.pots[i];
+            id = (int)i;
+        }
+    if (!P) {
+        c.pots.emplace_back();
+        P = &c.pots.back();
+        id = (int)c.pots.size() - 1;
+    }
+    P->name = name;
+    P->kind = kind;
+    P->NB = kind_nb(kind);
+    P->n_elem = n_elem;
+    P->conn_stride = conn_stride;
+    if (conn) P->conn_host.assign(conn, conn + (size_t)n_elem * conn_stride);
+    else P->conn_host.clear();
+    P->bindings.assign(bindings, bindings + n_bindings);
+    P->conn_dirty = true;
+    c.layout_dirty = true;
+    return id;
+}
+}  // namespace mistark
+
 extern "C" {
 
 const char* mistark_version(void) { return "mistark 0.1 (gfx950, HIP)"; }
@@ -92,7 +133,7 @@ int mistark_array(mistark_ctx* ctx, const double* host, int64_t n_items, int str
     Context& c = ctx->c;
     if (stride <= 0) throw Error("bad stride");
     for (size_t i = 0; i < c.arrays.size(); i++) {
-        if (c.arrays[i].host == host && c.arrays[i].stride == stride) {
+        if (host != nullptr && c.arrays[i].host == host && c.arrays[i].stride == stride) {
             if (c.arrays[i].n_items != n_items) {
                 c.arrays[i].n_items = n_items;
                 c.arrays[i].need_upload = true;
@@ -135,7 +176,7 @@ static void upload_one(Context& c, Array& a)
         if (s.n > 0) MS_CHECK(hipMemcpyAsync(c.u.p + s.offset, s.host, s.n * sizeof(double), hipMemcpyHostToDevice, c.stream));
     } else {
         const size_t n = (size_t)a.n_items * a.stride;
-        if (n > 0) MS_CHECK(hipMemcpyAsync(a.dev, a.host, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+        if (n > 0 && a.host) MS_CHECK(hipMemcpyAsync(a.dev, a.host, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
     }
     a.need_upload = false;
 }
@@ -162,7 +203,7 @@ int mistark_upload(mistark_ctx* ctx, int array)
 static void download_one(Context& c, Array& a)
 {
     const size_t n = (size_t)a.n_items * a.stride;
-    if (n > 0) MS_CHECK(hipMemcpyAsync(const_cast<double*>(a.host), a.dev, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    if (n > 0 && a.host) MS_CHECK(hipMemcpyAsync(const_cast<double*>(a.host), a.dev, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
 }
 int mistark_download(mistark_ctx* ctx, int array)
 {
@@ -200,44 +241,9 @@ int mistark_array_fill(mistark_ctx* ctx, int dst, double value)
 int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings)
 {
     API_BEGIN
-    Context& c = ctx->c;
-    const int kind = find_kind(name);
-    if (kind < 0) throw Error(std::string("unknown potential '") + name + "' (no MI355X kernel registered under this name)");
-    if (n_bindings != kind_nbind(kind)) throw Error(std::string("potential '") + name + "': expected " + std::to_string(kind_nbind(kind)) + " bindings, got " + std::to_string(n_bindings));
-    int strides[MAX_BIND];
-    kind_strides(kind, strides);
-    for (int b = 0; b < n_bindings; b++) {
-        if (bindings[b].array < 0 || bindings[b].array >= (int)c.arrays.size()) throw Error(std::string("potential '") + name + "': bad array id in binding " + std::to_string(b));
-        if (bindings[b].stride != strides[b] || c.arrays[bindings[b].array].stride != strides[b])
-            throw Error(std::string("potential '") + name + "': binding " + std::to_string(b) + " must have stride " + std::to_string(strides[b]));
-        if (bindings[b].conn_col >= conn_stride) throw Error(std::string("potential '") + name + "': connectivity column out of range");
-    }
-    if (n_elem < 0 || conn_stride <= 0) throw Error("bad connectivity shape");
-    Potential* P = nullptr;
-    int id = -1;
-    for (size_t i = 0; i < c.pots.size(); i++)
-        if (c.pots[i].name == name) {
-            P = &c.pots[i];
-            id = (int)i;
-        }
-    if (!P) {
-        c.pots.emplace_back();
-        P = &c.pots.back();
-        id = (int)c.pots.size() - 1;
-    }
-    P->name = name;
-    P->kind = kind;
-    P->NB = kind_nb(kind);
-    P->n_elem = n_elem;
-    P->conn_stride = conn_stride;
-    P->conn_host.assign(conn, conn + (size_t)n_elem * conn_stride);
-    P->bindings.assign(bindings, bindings + n_bindings);
-    P->conn_dirty = true;
-    c.layout_dirty = true;
-    _ret = id;
+    _ret = register_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings);
     API_END(_ret)
 }
-
 int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)
 {
     API_BEGIN
@@ -381,7 +387,7 @@ int mistark_get_bsr(mistark_ctx* ctx, int64_t* n_block_rows, int64_t* nnzb, int6
 {
     API_BEGIN
     Context& c = ctx->c;
-    prepare(c);
+    ensure_pattern(c);
     // the engine keeps A = A_static + A_dynamic (contacts) as two block-CSR parts; this parity accessor merges them on the host
     struct Blk
     {

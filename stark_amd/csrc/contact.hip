@@ -1,0 +1,1039 @@
+// contact.hip — device contact detector: collision vertices, candidate search, closest-feature classification, routing into the
+// 21 barrier and 14 friction tables of stark::EnergyFrictionalContact, edge-triangle intersection count.
+//
+// Reference behaviour restated (see include/mistark_contact.h for the API mapping):
+//   vertices        EnergyFrictionalContact::_update_vertices                 EnergyFrictionalContact.cpp:219-250
+//   candidates      tmcd broad phase: enlarged float AABBs, orphan/blacklist   BroadPhasePTEEBase.cpp:162-270, AABBs.cpp:15-45
+//   narrow phase    tmcd::ProximityDetection::run                             ProximityDetection.cpp:75-190 (contact_geom.hpp)
+//   routing         _before_energy_evaluation__update_contacts                EnergyFrictionalContact.cpp:368-530
+//   friction        _before_time_step__update_friction_contacts               EnergyFrictionalContact.cpp:531-773
+//   intersections   tmcd::IntersectionDetection::run                          IntersectionDetection.cpp:50-95, BroadPhaseET.cpp:161-165
+//
+// Pipeline of one update (all on the engine's stream):
+//   k_contact_vertices -> k_contact_aabbs -> k_detect_pt / k_detect_ee (LDS-tiled all-pairs AABB rejection, narrow phase on the
+//   survivors, one 64-bit key per contact = table | source | closest feature | primitive a | primitive b) -> radix sort of the
+//   keys (deterministic row order, tables contiguous) -> k_table_bounds -> row counts to the host -> k_route writes every row
+//   (and the friction data) into the buffers the potentials' kernels read.
+// If the sorted key list equals the previous one the tables are left alone and the dynamic matrix pattern is kept.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <hipcub/hipcub.hpp>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mistark_contact.h"
+#include "contact_geom.hpp"
+#include "energies.hpp"
+#include "engine.hpp"
+
+namespace mistark {
+
+namespace {
+constexpr int CB = 256;  // workgroup size of the detector kernels
+constexpr int N_TABLES = 35;
+constexpr int N_CONTACT_TABLES = 21;
+enum Role { R_V1 = 0, R_X0, R_X, R_DT, R_K, R_THICK, R_EPSV, R_RB_XLOC, R_RB_V1, R_RB_W1, R_RB_T0, R_RB_Q0, R_T, R_MU, R_FN, R_BARY };
+const char* const TABLE_NAMES[N_TABLES] = {
+    "contact_d_d_pt_pp_cubic", "contact_d_d_pt_pe_cubic", "contact_d_d_pt_pt_cubic", "contact_d_d_ee_pp_cubic", "contact_d_d_ee_pe_cubic", "contact_d_d_ee_ee_cubic",
+    "contact_rb_rb_pt_pp_cubic", "contact_rb_rb_pt_pe_cubic", "contact_rb_rb_pt_pt_cubic", "contact_rb_rb_ee_pp_cubic", "contact_rb_rb_ee_pe_cubic", "contact_rb_rb_ee_ee_cubic",
+    "contact_rb_d_pt_pp_cubic", "contact_rb_d_pt_pe_cubic", "contact_rb_d_pt_pt_cubic", "contact_rb_d_pt_ep_cubic", "contact_rb_d_pt_tp_cubic",
+    "contact_rb_d_ee_pp_cubic", "contact_rb_d_ee_pe_cubic", "contact_rb_d_ee_ee_cubic", "contact_rb_d_ee_ep_cubic",
+    "friction_d_d_pp_C0", "friction_d_d_pe_C0", "friction_d_d_pt_C0", "friction_d_d_ee_C0",
+    "friction_rb_rb_pp_C0", "friction_rb_rb_pe_C0", "friction_rb_rb_pt_C0", "friction_rb_rb_ee_C0",
+    "friction_rb_d_pp_C0", "friction_rb_d_pe_C0", "friction_rb_d_pt_C0", "friction_rb_d_ee_C0", "friction_rb_d_ep_C0", "friction_rb_d_tp_C0"};
+
+struct Bind
+{
+    int role, stride, col;
+};
+// Binding recipe of table t: the reference's mws.make_* calls in order (EnergyFrictionalContact.cpp:829-1218 with the symbol
+// getters of :1358-1423). Systems: 0 = deformable, 1 = rigid body.
+std::vector<Bind> recipe(int t, int& conn_stride)
+{
+    std::vector<Bind> r;
+    auto d_x1 = [&](int c0, int n) {  // _get_d_x1
+        for (int i = 0; i < n; i++) r.push_back({R_V1, 3, c0 + i});
+        for (int i = 0; i < n; i++) r.push_back({R_X0, 3, c0 + i});
+        r.push_back({R_DT, 1, -1});
+    };
+    auto d_X = [&](int c0, int n) { for (int i = 0; i < n; i++) r.push_back({R_X, 3, c0 + i}); };
+    auto d_v1 = [&](int c0, int n) { for (int i = 0; i < n; i++) r.push_back({R_V1, 3, c0 + i}); };
+    auto rb = [&](int rbcol, int c0, int n) {  // _get_rb_x1 / _get_rb_v1
+        r.push_back({R_DT, 1, -1});
+        for (int i = 0; i < n; i++) r.push_back({R_RB_XLOC, 3, c0 + i});
+        r.push_back({R_RB_V1, 3, rbcol});
+        r.push_back({R_RB_W1, 3, rbcol});
+        r.push_back({R_RB_T0, 3, rbcol});
+        r.push_back({R_RB_Q0, 4, rbcol});
+    };
+    auto rb_X = [&](int c0, int n) { for (int i = 0; i < n; i++) r.push_back({R_RB_XLOC, 3, c0 + i}); };
+    if (t < N_CONTACT_TABLES) {
+        const int fam_sys = t < 6 ? 0 : (t < 12 ? 1 : 2);  // d_d, rb_rb, rb_d
+        const int sysA = fam_sys == 0 ? 0 : 1, sysB = fam_sys == 1 ? 1 : 0;
+        const int base = fam_sys == 0 ? 2 : (fam_sys == 1 ? 4 : 3);
+        const int rbA = 2, rbB = fam_sys == 1 ? 3 : 2;
+        const int k = fam_sys == 0 ? t : (fam_sys == 1 ? t - 6 : t - 12);
+        auto pos = [&](int sys, int rbcol, int c0, int n) { sys == 0 ? d_x1(c0, n) : rb(rbcol, c0, n); };
+        auto rest = [&](int sys, int c0, int n) { sys == 0 ? d_X(c0, n) : rb_X(c0, n); };
+        // point-triangle family (KA, KB) / edge-edge family (point on A, point on B)
+        int KA = 0, KB = 0, PA = -1, PB = -1;
+        if (fam_sys < 2) {
+            static const int ka[6] = {1, 1, 1, 0, 0, 0}, kb[6] = {1, 2, 3, 0, 0, 0}, pa[6] = {-1, -1, -1, 1, 1, 0}, pb[6] = {-1, -1, -1, 1, 0, 0};
+            KA = ka[k]; KB = kb[k]; PA = pa[k]; PB = pb[k];
+        } else {
+            static const int ka[9] = {1, 1, 1, 2, 3, 0, 0, 0, 0}, kb[9] = {1, 2, 3, 1, 1, 0, 0, 0, 0}, pa[9] = {-1, -1, -1, -1, -1, 1, 1, 0, 0}, pb[9] = {-1, -1, -1, -1, -1, 1, 0, 0, 1};
+            KA = ka[k]; KB = kb[k]; PA = pa[k]; PB = pb[k];
+        }
+        if (PA < 0) {
+            pos(sysA, rbA, base, KA);
+            pos(sysB, rbB, base + KA, KB);
+            conn_stride = base + KA + KB;
+            r.push_back({R_THICK, 1, 0});
+            r.push_back({R_THICK, 1, 1});
+            r.push_back({R_K, 1, -1});
+        } else {
+            int col = base;
+            for (int side = 0; side < 2; side++) {
+                const int sys = side == 0 ? sysA : sysB, rbcol = side == 0 ? rbA : rbB, has_p = side == 0 ? PA : PB;
+                pos(sys, rbcol, col, 2);
+                rest(sys, col, 2);
+                col += 2;
+                if (has_p) {
+                    pos(sys, rbcol, col, 1);
+                    col += 1;
+                }
+            }
+            conn_stride = col;
+            r.push_back({R_K, 1, -1});
+            r.push_back({R_THICK, 1, 0});
+            r.push_back({R_THICK, 1, 1});
+        }
+    } else {
+        const int f = t - N_CONTACT_TABLES;
+        const int fam_sys = f < 4 ? 0 : (f < 8 ? 1 : 2);
+        const int k = fam_sys == 0 ? f : (fam_sys == 1 ? f - 4 : f - 8);  // pp pe pt ee [ep tp]
+        static const int ka[6] = {1, 1, 1, 2, 2, 3}, kb[6] = {1, 2, 3, 2, 1, 1}, nb[6] = {0, 2, 3, 2, 2, 3};
+        const int base = fam_sys == 0 ? 1 : (fam_sys == 1 ? 3 : 2);
+        const int sysA = fam_sys == 0 ? 0 : 1, sysB = fam_sys == 1 ? 1 : 0;
+        sysA == 0 ? d_v1(base, ka[k]) : rb(1, base, ka[k]);
+        sysB == 0 ? d_v1(base + ka[k], kb[k]) : rb(2, base + ka[k], kb[k]);
+        conn_stride = base + ka[k] + kb[k];
+        if (nb[k]) r.push_back({R_BARY, nb[k], 0});
+        r.push_back({R_T, 6, 0});
+        r.push_back({R_MU, 1, 0});
+        r.push_back({R_FN, 1, 0});
+        r.push_back({R_EPSV, 1, -1});
+        r.push_back({R_DT, 1, -1});
+    }
+    return r;
+}
+int table_nbary(int t)
+{
+    if (t < N_CONTACT_TABLES) return 0;
+    const int f = t - N_CONTACT_TABLES;
+    const int k = f < 4 ? f : (f < 8 ? f - 4 : f - 8);
+    static const int nb[6] = {0, 2, 3, 2, 2, 3};
+    return nb[k];
+}
+
+// ---- device-side view of the collision meshes ----------------------------------------------------------------------------------------
+struct ContactDev
+{
+    const int32_t* cv_src;     // collision vertex -> index in the physical system's vertex array
+    const int32_t* cv_mesh;    // collision vertex -> mesh (group)
+    const int32_t* tri;        // 3 collision vertices per triangle
+    const int32_t* tri_mesh;
+    const int32_t* edge;       // 2 collision vertices per edge
+    const int32_t* edge_mesh;
+    const int32_t* mesh_kind;  // 0 deformable, 1 rigid body
+    const int32_t* mesh_idx;   // idx_in_ps
+    const uint8_t* disabled;   // n_mesh x n_mesh
+    const double* mu;          // n_mesh x n_mesh
+    const double* thick;       // per mesh
+    const double* X;           // 3 per collision vertex
+    const float* aabb;         // 6 per primitive: points | triangles | edges
+    int n_mesh, n_v, n_t, n_e;
+};
+struct TableDev
+{
+    int32_t* conn;
+    double *T, *mu, *fn, *bary;
+    int stride, nbary, start, pad;
+};
+
+// key = table[63:58] | source[57] (0 point-triangle, 1 edge-edge) | closest feature[56:53] | primitive a[51:26] | primitive b[25:0]
+constexpr int PRIM_BITS = 26;
+__host__ __device__ inline uint64_t pack_key(int table, int src, int type, int a, int b)
+{
+    return ((uint64_t)table << 58) | ((uint64_t)src << 57) | ((uint64_t)type << 53) | ((uint64_t)a << PRIM_BITS) | (uint64_t)b;
+}
+
+__device__ __forceinline__ D3 ldx(const double* X, int i) { return d3(X[3 * i], X[3 * i + 1], X[3 * i + 2]); }
+
+// table of a classified pair: family 0 pt_pp 1 pt_pe 2 pt_pt 3 ee_pp 4 ee_pe 5 ee_ee; ka / kb = system of the reference's A / B
+__device__ __forceinline__ int table_of(int fam, int ka, int kb, bool friction)
+{
+    if (!friction) {
+        if (ka == 0 && kb == 0) return fam;
+        if (ka == 1 && kb == 1) return 6 + fam;
+        if (ka == 1) {
+            const int m[6] = {12, 13, 14, 17, 18, 19};
+            return m[fam];
+        }
+        const int m[6] = {12, 15, 16, 17, 20, 19};  // deformable first: rigid side listed first, asymmetric families switch table
+        return m[fam];
+    }
+    const int k4m[6] = {0, 1, 2, 0, 1, 3};  // pp pe pt | pp pe ee
+    const int k4 = k4m[fam];
+    if (ka == 0 && kb == 0) return 21 + k4;
+    if (ka == 1 && kb == 1) return 25 + k4;
+    if (ka == 1) return 29 + k4;
+    const int m[4] = {29, 33, 34, 32};
+    return m[k4];
+}
+__device__ __forceinline__ int pt_family(int type) { return type <= P_T2 ? 0 : (type <= P_E2 ? 1 : 2); }
+__device__ __forceinline__ int ee_family(int type) { return type <= EA1_EB1 ? 3 : (type <= EA1_EB ? 4 : 5); }
+
+// ---- collision vertices ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(CB) void k_contact_vertices(ContactDev d, const double* __restrict__ x0, const double* __restrict__ v1, const double* __restrict__ xloc,
+                                                        const double* __restrict__ rb_v1, const double* __restrict__ rb_w1, const double* __restrict__ rb_t0,
+                                                        const double* __restrict__ rb_q0, double dt, double* __restrict__ X)
+{
+    const int i = blockIdx.x * CB + threadIdx.x;
+    if (i >= d.n_v) return;
+    const int m = d.cv_mesh[i], s = d.cv_src[i];
+    if (d.mesh_kind[m] == 0) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) X[3 * i + k] = x0[3 * s + k] + dt * v1[3 * s + k];
+    } else {
+        // integrate_loc_point: t1 = t0 + dt v1, R1 = R(normalize(q0 + dt/2 (0, w1) q0)) (rigidbody_transformations.cpp:30-43)
+        const int b = d.mesh_idx[m];
+        const V3<double> w(rb_w1[3 * b], rb_w1[3 * b + 1], rb_w1[3 * b + 2]);
+        const M3<double> R1 = rb_R1(rb_q0 + 4 * b, w, dt);
+        const V3<double> xl(xloc[3 * s], xloc[3 * s + 1], xloc[3 * s + 2]);
+        const V3<double> r = R1 * xl;
+        X[3 * i] = r.x + (rb_t0[3 * b] + dt * rb_v1[3 * b]);
+        X[3 * i + 1] = r.y + (rb_t0[3 * b + 1] + dt * rb_v1[3 * b + 1]);
+        X[3 * i + 2] = r.z + (rb_t0[3 * b + 2] + dt * rb_v1[3 * b + 2]);
+    }
+}
+// float AABBs rounded outwards and enlarged (AABBs.cpp:15-45); primitive order: points, triangles, edges
+__global__ __launch_bounds__(CB) void k_contact_aabbs(ContactDev d, float enl, float* __restrict__ aabb)
+{
+    const int i = blockIdx.x * CB + threadIdx.x;
+    const int n = d.n_v + d.n_t + d.n_e;
+    if (i >= n) return;
+    int v[3], nv;
+    if (i < d.n_v) {
+        v[0] = i;
+        nv = 1;
+    } else if (i < d.n_v + d.n_t) {
+        const int t = i - d.n_v;
+        v[0] = d.tri[3 * t]; v[1] = d.tri[3 * t + 1]; v[2] = d.tri[3 * t + 2];
+        nv = 3;
+    } else {
+        const int e = i - d.n_v - d.n_t;
+        v[0] = d.edge[2 * e]; v[1] = d.edge[2 * e + 1];
+        nv = 2;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        double lo = d.X[3 * v[0] + k], hi = lo;
+        for (int j = 1; j < nv; j++) {
+            const double x = d.X[3 * v[j] + k];
+            lo = x < lo ? x : lo;
+            hi = x > hi ? x : hi;
+        }
+        aabb[6 * (size_t)i + k] = __double2float_rd(lo) - enl;
+        aabb[6 * (size_t)i + 3 + k] = __double2float_ru(hi) + enl;
+    }
+}
+
+// ---- candidate search + narrow phase --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void push_key(uint64_t key, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+{
+    const int slot = atomicAdd(&counters[0], 1);
+    if (slot < key_cap) keys[slot] = key;
+}
+template <bool FRICTION>
+__device__ __noinline__ void narrow_pt(const ContactDev& d, int p, int t, double enl2, uint64_t* keys, int* counters, int key_cap)
+{
+    const int v0 = d.tri[3 * t], v1 = d.tri[3 * t + 1], v2 = d.tri[3 * t + 2];
+    if (p == v0 || p == v1 || p == v2) return;  // point of its own triangle (BroadPhasePTEEBase.cpp:193)
+    const int mp = d.cv_mesh[p], mt = d.tri_mesh[t];
+    if (d.disabled[mp * d.n_mesh + mt]) return;
+    int type;
+    const double d2 = point_triangle_sq_distance(type, ldx(d.X, p), ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, v2));
+    if (!(d2 < enl2)) return;                                           // ProximityDetection.cpp:105
+    if (::sqrt(d2) > d.thick[mp] + d.thick[mt]) return;                  // EnergyFrictionalContact.cpp:385
+    if (FRICTION && d.mu[mp * d.n_mesh + mt] == 0.0) return;            // :597
+    const int table = table_of(pt_family(type), d.mesh_kind[mp], d.mesh_kind[mt], FRICTION);
+    push_key(pack_key(table, 0, type, p, t), keys, counters, key_cap);
+}
+template <bool FRICTION>
+__device__ __noinline__ void narrow_ee(const ContactDev& d, int ea, int eb, double enl2, uint64_t* keys, int* counters, int key_cap)
+{
+    const int a0 = d.edge[2 * ea], a1 = d.edge[2 * ea + 1], b0 = d.edge[2 * eb], b1 = d.edge[2 * eb + 1];
+    if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) return;  // edges sharing a vertex (BroadPhasePTEEBase.cpp:246)
+    const int ma = d.edge_mesh[ea], mb = d.edge_mesh[eb];
+    if (d.disabled[ma * d.n_mesh + mb]) return;
+    const D3 xa0 = ldx(d.X, a0), xa1 = ldx(d.X, a1), xb0 = ldx(d.X, b0), xb1 = ldx(d.X, b1);
+    if (sq3(cross3(xa1 - xa0, xb1 - xb0)) <= 1e-30) return;  // (nearly) parallel edges never reach a table (ProximityDetection.cpp:152-155)
+    int type;
+    const double d2 = edge_edge_sq_distance(type, xa0, xa1, xb0, xb1);
+    if (!(d2 < enl2)) return;
+    if (::sqrt(d2) > d.thick[ma] + d.thick[mb]) return;
+    if (FRICTION && d.mu[ma * d.n_mesh + mb] == 0.0) return;
+    // roles: the reference's "first" is the edge-point; for EA_EB0 / EA_EB1 that is edge b (ProximityDetection.cpp:171-172)
+    const bool swapped = type == EA_EB0 || type == EA_EB1;
+    const int ka = d.mesh_kind[swapped ? mb : ma], kb = d.mesh_kind[swapped ? ma : mb];
+    const int table = table_of(ee_family(type), ka, kb, FRICTION);
+    push_key(pack_key(table, 1, type, ea, eb), keys, counters, key_cap);
+}
+__device__ __forceinline__ bool overlap6(const float* a, const float* lo, const float* hi, int j)
+{
+    return a[0] <= hi[j] && lo[j] <= a[3] && a[1] <= hi[CB + j] && lo[CB + j] <= a[4] && a[2] <= hi[2 * CB + j] && lo[2 * CB + j] <= a[5];
+}
+// All point x triangle pairs: blockIdx.x = tile of CB points (one per lane), blockIdx.y = chunk of triangles staged through LDS
+template <bool FRICTION>
+__global__ __launch_bounds__(CB) void k_detect_pt(ContactDev d, double enl2, int chunk, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+{
+    __shared__ float s_lo[3 * CB], s_hi[3 * CB];
+    const int p = blockIdx.x * CB + threadIdx.x;
+    const bool valid = p < d.n_v;
+    float a[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) a[k] = valid ? d.aabb[6 * (size_t)p + k] : 0.f;
+    const int t_begin = blockIdx.y * chunk;
+    const int t_end = min(d.n_t, t_begin + chunk);
+    for (int base = t_begin; base < t_end; base += CB) {
+        const int tj = base + threadIdx.x;
+        if (tj < t_end) {
+            const float* bb = d.aabb + 6 * (size_t)(d.n_v + tj);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                s_lo[k * CB + threadIdx.x] = bb[k];
+                s_hi[k * CB + threadIdx.x] = bb[3 + k];
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            const int cnt = min(CB, t_end - base);
+            for (int j = 0; j < cnt; j++)
+                if (overlap6(a, s_lo, s_hi, j)) narrow_pt<FRICTION>(d, p, base + j, enl2, keys, counters, key_cap);
+        }
+        __syncthreads();
+    }
+}
+// All edge pairs i < j (BroadPhasePTEEBase.cpp:239): row tile x column chunk, tiles entirely below the diagonal exit at once
+template <bool FRICTION>
+__global__ __launch_bounds__(CB) void k_detect_ee(ContactDev d, double enl2, int chunk, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+{
+    __shared__ float s_lo[3 * CB], s_hi[3 * CB];
+    const int row0 = blockIdx.x * CB;
+    const int e_begin = blockIdx.y * chunk;
+    const int e_end = min(d.n_e, e_begin + chunk);
+    if (e_end <= row0 + 1) return;  // every column index <= every row index
+    const int ea = row0 + threadIdx.x;
+    const bool valid = ea < d.n_e;
+    const size_t off = (size_t)(d.n_v + d.n_t);
+    float a[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) a[k] = valid ? d.aabb[6 * (off + ea) + k] : 0.f;
+    for (int base = e_begin; base < e_end; base += CB) {
+        if (base + CB <= row0 + 1) continue;
+        const int ej = base + threadIdx.x;
+        if (ej < e_end) {
+            const float* bb = d.aabb + 6 * (off + ej);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                s_lo[k * CB + threadIdx.x] = bb[k];
+                s_hi[k * CB + threadIdx.x] = bb[3 + k];
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            const int cnt = min(CB, e_end - base);
+            for (int j = max(0, ea + 1 - base); j < cnt; j++)
+                if (overlap6(a, s_lo, s_hi, j)) narrow_ee<FRICTION>(d, ea, base + j, enl2, keys, counters, key_cap);
+        }
+        __syncthreads();
+    }
+}
+// Edge x triangle intersections (AABBs without enlargement); counters[1] += hits
+__global__ __launch_bounds__(CB) void k_detect_et(ContactDev d, int chunk, int* __restrict__ counters)
+{
+    __shared__ float s_lo[3 * CB], s_hi[3 * CB];
+    const int e = blockIdx.x * CB + threadIdx.x;
+    const bool valid = e < d.n_e;
+    const size_t off = (size_t)(d.n_v + d.n_t);
+    float a[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) a[k] = valid ? d.aabb[6 * (off + e) + k] : 0.f;
+    const int t_begin = blockIdx.y * chunk;
+    const int t_end = min(d.n_t, t_begin + chunk);
+    int hits = 0;
+    for (int base = t_begin; base < t_end; base += CB) {
+        const int tj = base + threadIdx.x;
+        if (tj < t_end) {
+            const float* bb = d.aabb + 6 * (size_t)(d.n_v + tj);
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                s_lo[k * CB + threadIdx.x] = bb[k];
+                s_hi[k * CB + threadIdx.x] = bb[3 + k];
+            }
+        }
+        __syncthreads();
+        if (valid) {
+            const int cnt = min(CB, t_end - base);
+            for (int j = 0; j < cnt; j++) {
+                if (!overlap6(a, s_lo, s_hi, j)) continue;
+                const int t = base + j;
+                const int e0 = d.edge[2 * e], e1 = d.edge[2 * e + 1], v0 = d.tri[3 * t], v1 = d.tri[3 * t + 1], v2 = d.tri[3 * t + 2];
+                if (e0 == v0 || e0 == v1 || e0 == v2 || e1 == v0 || e1 == v1 || e1 == v2) continue;  // BroadPhaseET.cpp:161-165
+                if (d.disabled[d.edge_mesh[e] * d.n_mesh + d.tri_mesh[t]]) continue;
+                if (edge_intersects_triangle(ldx(d.X, e0), ldx(d.X, e1), ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, v2))) hits++;
+            }
+        }
+        __syncthreads();
+    }
+    if (hits) atomicAdd(&counters[1], hits);
+}
+
+// ---- sorted keys -> tables -----------------------------------------------------------------------------------------------------------
+// bounds[t] = first sorted key of table t (t = 0..N_TABLES), same[0] = 1 iff the list equals the previous one
+__global__ __launch_bounds__(CB) void k_table_bounds(const uint64_t* __restrict__ keys, int n, const uint64_t* __restrict__ prev, int n_prev, int* __restrict__ bounds,
+                                                    int* __restrict__ differs)
+{
+    const int i = blockIdx.x * CB + threadIdx.x;
+    if (i > n) return;
+    const int t_here = i < n ? (int)(keys[i] >> 58) : N_TABLES;
+    const int t_prev = i > 0 ? (int)(keys[i - 1] >> 58) : -1;
+    for (int t = t_prev + 1; t <= t_here; t++) bounds[t] = i;
+    if (i < n && (n != n_prev || keys[i] != prev[i])) differs[0] = 1;
+}
+struct Side
+{
+    int mesh, nv, has_edge;
+    int cv[3], ecv[2];
+};
+__device__ __forceinline__ void decode(const ContactDev& d, uint64_t key, int& fam, Side& A, Side& B)
+{
+    const int src = (int)((key >> 57) & 1), type = (int)((key >> 53) & 15);
+    const int a = (int)((key >> PRIM_BITS) & ((1u << PRIM_BITS) - 1)), b = (int)(key & ((1u << PRIM_BITS) - 1));
+    if (src == 0) {
+        fam = pt_family(type);
+        A.mesh = d.cv_mesh[a]; A.nv = 1; A.cv[0] = a; A.has_edge = 0;
+        B.mesh = d.tri_mesh[b]; B.has_edge = 0;
+        const int* t = d.tri + 3 * b;
+        if (fam == 0) {
+            B.nv = 1;
+            B.cv[0] = t[type];
+        } else if (fam == 1) {  // P_E0: (t0,t1), P_E1: (t1,t2), P_E2: (t2,t0) (ProximityDetection.cpp:117-119)
+            const int k = type - P_E0;
+            B.nv = 2;
+            B.cv[0] = t[k];
+            B.cv[1] = t[(k + 1) % 3];
+        } else {
+            B.nv = 3;
+            B.cv[0] = t[0]; B.cv[1] = t[1]; B.cv[2] = t[2];
+        }
+        return;
+    }
+    fam = ee_family(type);
+    const int ea[2] = {d.edge[2 * a], d.edge[2 * a + 1]}, eb[2] = {d.edge[2 * b], d.edge[2 * b + 1]};
+    const int ma = d.edge_mesh[a], mb = d.edge_mesh[b];
+    auto edge_side = [](Side& S, int mesh, const int* e) {
+        S.mesh = mesh; S.nv = 2; S.cv[0] = e[0]; S.cv[1] = e[1]; S.has_edge = 1; S.ecv[0] = e[0]; S.ecv[1] = e[1];
+    };
+    auto point_side = [](Side& S, int mesh, const int* e, int v) {
+        S.mesh = mesh; S.nv = 1; S.cv[0] = v; S.has_edge = 1; S.ecv[0] = e[0]; S.ecv[1] = e[1];
+    };
+    switch (type) {  // ProximityDetection.cpp:166-176
+        case EA0_EB0: point_side(A, ma, ea, ea[0]); point_side(B, mb, eb, eb[0]); break;
+        case EA0_EB1: point_side(A, ma, ea, ea[0]); point_side(B, mb, eb, eb[1]); break;
+        case EA1_EB0: point_side(A, ma, ea, ea[1]); point_side(B, mb, eb, eb[0]); break;
+        case EA1_EB1: point_side(A, ma, ea, ea[1]); point_side(B, mb, eb, eb[1]); break;
+        case EA_EB0: point_side(A, mb, eb, eb[0]); edge_side(B, ma, ea); break;
+        case EA_EB1: point_side(A, mb, eb, eb[1]); edge_side(B, ma, ea); break;
+        case EA0_EB: point_side(A, ma, ea, ea[0]); edge_side(B, mb, eb); break;
+        case EA1_EB: point_side(A, ma, ea, ea[1]); edge_side(B, mb, eb); break;
+        default: edge_side(A, ma, ea); edge_side(B, mb, eb); break;
+    }
+}
+// columns one side contributes to a BARRIER row: point-triangle families list the vertices, edge-edge families the edge then
+// the point (contact_and_friction_data.h)
+__device__ __forceinline__ int barrier_cols(const ContactDev& d, const Side& S, int fam, int* out)
+{
+    int n = 0;
+    if (fam >= 3) {
+        out[n++] = d.cv_src[S.ecv[0]];
+        out[n++] = d.cv_src[S.ecv[1]];
+        if (S.nv == 1) out[n++] = d.cv_src[S.cv[0]];
+    } else {
+        for (int i = 0; i < S.nv; i++) out[n++] = d.cv_src[S.cv[i]];
+    }
+    return n;
+}
+__global__ __launch_bounds__(CB) void k_route(ContactDev d, const uint64_t* __restrict__ keys, int n, const TableDev* __restrict__ tables, const double* __restrict__ kptr)
+{
+    const int i = blockIdx.x * CB + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    const int table = (int)(key >> 58);
+    const TableDev T = tables[table];
+    const int row = i - T.start;
+    int fam;
+    Side A, B;
+    decode(d, key, fam, A, B);
+    const int ka = d.mesh_kind[A.mesh], kb = d.mesh_kind[B.mesh];
+    const int ia = d.mesh_idx[A.mesh], ib = d.mesh_idx[B.mesh];
+    int32_t* out = T.conn + (size_t)row * T.stride;
+    int n_out = 0;
+    if (table < N_CONTACT_TABLES) {
+        int ca[3], cb[3];
+        const int na = barrier_cols(d, A, fam, ca), nb = barrier_cols(d, B, fam, cb);
+        if (ka == 0 && kb == 1) {  // deformable first: {B.group, A.group, B.idx_in_ps, B..., A...} (EnergyFrictionalContact.cpp:398-399 etc.)
+            out[n_out++] = B.mesh; out[n_out++] = A.mesh; out[n_out++] = ib;
+            for (int k = 0; k < nb; k++) out[n_out++] = cb[k];
+            for (int k = 0; k < na; k++) out[n_out++] = ca[k];
+        } else {
+            out[n_out++] = A.mesh; out[n_out++] = B.mesh;
+            if (ka == 1) out[n_out++] = ia;
+            if (ka == 1 && kb == 1) out[n_out++] = ib;
+            for (int k = 0; k < na; k++) out[n_out++] = ca[k];
+            for (int k = 0; k < nb; k++) out[n_out++] = cb[k];
+        }
+        return;
+    }
+    // friction row: running index, rigid body indices, vertices (:592-772)
+    out[n_out++] = row;
+    if (ka == 0 && kb == 1) {
+        out[n_out++] = ib;
+        for (int k = 0; k < B.nv; k++) out[n_out++] = d.cv_src[B.cv[k]];
+        for (int k = 0; k < A.nv; k++) out[n_out++] = d.cv_src[A.cv[k]];
+    } else {
+        if (ka == 1) out[n_out++] = ia;
+        if (ka == 1 && kb == 1) out[n_out++] = ib;
+        for (int k = 0; k < A.nv; k++) out[n_out++] = d.cv_src[A.cv[k]];
+        for (int k = 0; k < B.nv; k++) out[n_out++] = d.cv_src[B.cv[k]];
+    }
+    // contact data in the detected (A, B) order, whatever the row order (the lambdas of :548-587)
+    D3 xa[2], xb[3];
+    for (int k = 0; k < A.nv && k < 2; k++) xa[k] = ldx(d.X, A.cv[k]);
+    for (int k = 0; k < B.nv; k++) xb[k] = ldx(d.X, B.cv[k]);
+    double dist;
+    double* Tm = T.T + 6 * (size_t)row;
+    double* bary = T.bary ? T.bary + (size_t)T.nbary * row : nullptr;
+    if (fam == 0 || fam == 3) {
+        basis_point_point(xa[0], xb[0], Tm);
+        dist = ::sqrt(sq3(xb[0] - xa[0]));
+    } else if (fam == 1 || fam == 4) {
+        bary_point_edge(xa[0], xb[0], xb[1], bary);
+        basis_point_edge(xa[0], xb[0], xb[1], Tm);
+        dist = ::sqrt(point_line_sq(xa[0], xb[0], xb[1]));
+    } else if (fam == 2) {
+        bary_point_triangle(xa[0], xb[0], xb[1], xb[2], bary);
+        basis_triangle(xb[0], xb[1], xb[2], Tm);
+        const D3 nrm = cross3(xb[1] - xb[0], xb[2] - xb[0]);
+        const double h = dot3(xa[0] - xb[0], nrm);
+        dist = ::sqrt(h * h / sq3(nrm));
+    } else {
+        bary_edge_edge(xa[0], xa[1], xb[0], xb[1], bary);
+        basis_edge_edge(xa[0], xa[1], xb[0], xb[1], Tm);
+        const D3 nrm = cross3(xa[1] - xa[0], xb[1] - xb[0]);
+        const double h = dot3(xb[0] - xa[0], nrm);
+        dist = ::sqrt(h * h / sq3(nrm));
+    }
+    const double dhat = d.thick[A.mesh] + d.thick[B.mesh];
+    T.mu[row] = d.mu[A.mesh * d.n_mesh + B.mesh];
+    T.fn[row] = kptr[0] * (dhat - dist) * (dhat - dist);  // _barrier_force, cubic barrier (:1238-1242)
+}
+}  // namespace
+
+// ======================================================================================================================================
+struct ContactSystem
+{
+    mistark_contact_arrays arr{};
+    struct Mesh
+    {
+        int kind, idx_in_ps, v_off, n_v, t_off, n_t, e_off, n_e;
+    };
+    std::vector<Mesh> meshes;
+    std::vector<int32_t> h_cv_src, h_cv_mesh, h_tri, h_tri_mesh, h_edge, h_edge_mesh;
+    std::map<std::pair<int, int>, double> friction;
+    std::vector<std::pair<int, int>> disabled_pairs;
+    bool meshes_dirty = true;
+    bool pt_enabled = true, ee_enabled = true;
+
+    DevBuf<int32_t> cv_src, cv_mesh, tri, tri_mesh, edge, edge_mesh, mesh_kind, mesh_idx;
+    DevBuf<uint8_t> disabled;
+    DevBuf<double> mu, X;
+    DevBuf<float> aabb;
+    DevBuf<uint64_t> keys, keys_alt, prev;
+    int64_t n_prev = -1;  // keys of the barrier tables currently installed (-1: none)
+    DevBuf<int> counters;  // [0] candidates, [1] intersections, [2] differs, [8..8+N_TABLES] bounds
+    DevBuf<uint8_t> cub_tmp;
+    DevBuf<TableDev> tables_dev;
+    size_t key_cap = 0;
+
+    struct Table
+    {
+        int pot = -1, stride = 0, nbary = 0, n = 0;
+        int a_T = -1, a_mu = -1, a_fn = -1, a_bary = -1;
+        DevBuf<int32_t> conn;
+    };
+    Table tables[N_TABLES];
+    int n_v = 0, n_t = 0, n_e = 0;
+};
+void contact_destroy(ContactSystem* cs) { delete cs; }
+
+namespace {
+ContactSystem& CS(Context& c)
+{
+    if (!c.contact) throw Error("contact: call mistark_contact_init first");
+    return *c.contact;
+}
+int new_device_array(Context& c, int stride)
+{
+    c.arrays.emplace_back();
+    Array& a = c.arrays.back();
+    a.host = nullptr;  // device-only: filled by k_route
+    a.n_items = 0;
+    a.stride = stride;
+    a.need_upload = false;
+    c.layout_dirty = true;
+    return (int)c.arrays.size() - 1;
+}
+void contact_init(Context& c, const mistark_contact_arrays& arr)
+{
+    if (c.contact) throw Error("contact: already initialised");
+    auto* cs = new ContactSystem();
+    c.contact = cs;
+    cs->arr = arr;
+    const int32_t* ids = &arr.v1;
+    const bool has_d = arr.v1 >= 0 && arr.x0 >= 0 && arr.X >= 0;
+    const bool has_rb = arr.rb_xloc >= 0 && arr.rb_v1 >= 0 && arr.rb_w1 >= 0 && arr.rb_t0 >= 0 && arr.rb_q0 >= 0;
+    if (arr.dt < 0 || arr.k < 0 || arr.thickness < 0 || arr.epsv < 0) throw Error("contact: dt, k, thickness and epsv arrays are required");
+    for (int t = 0; t < N_TABLES; t++) {
+        ContactSystem::Table& T = cs->tables[t];
+        std::vector<Bind> rec = recipe(t, T.stride);
+        T.nbary = table_nbary(t);
+        bool usable = true;
+        for (const Bind& b : rec) {
+            if (b.role <= R_X && !has_d) usable = false;
+            if (b.role >= R_RB_XLOC && b.role <= R_RB_Q0 && !has_rb) usable = false;
+        }
+        if (!usable) continue;  // the scene has no such physical system: the table can never receive a row
+        if (t >= N_CONTACT_TABLES) {
+            T.a_T = new_device_array(c, 6);
+            T.a_mu = new_device_array(c, 1);
+            T.a_fn = new_device_array(c, 1);
+            if (T.nbary) T.a_bary = new_device_array(c, T.nbary);
+        }
+        std::vector<mistark_binding> bs;
+        for (const Bind& b : rec) {
+            int id;
+            switch (b.role) {
+                case R_T: id = T.a_T; break;
+                case R_MU: id = T.a_mu; break;
+                case R_FN: id = T.a_fn; break;
+                case R_BARY: id = T.a_bary; break;
+                default: id = ids[b.role];
+            }
+            bs.push_back(mistark_binding{id, b.stride, b.col});
+        }
+        T.pot = register_potential(c, TABLE_NAMES[t], nullptr, 0, T.stride, bs.data(), (int)bs.size());
+        c.pots[T.pot].part = 1;
+        T.conn.ensure(64 * (size_t)T.stride);
+        c.pots[T.pot].conn_ext = T.conn.p;
+        c.pots[T.pot].conn_dirty = false;
+    }
+    c.layout_dirty = true;
+    c.part[0].dirty = c.part[1].dirty = true;
+    cs->counters.ensure(64);
+    cs->tables_dev.ensure(N_TABLES);
+}
+int contact_add_mesh(Context& c, int kind, int idx_in_ps, const int32_t* vidx, int nv, const int32_t* tris, int nt, const int32_t* edges, int ne)
+{
+    ContactSystem& cs = CS(c);
+    if (kind != MISTARK_CONTACT_DEFORMABLE && kind != MISTARK_CONTACT_RIGIDBODY) throw Error("contact: bad mesh kind");
+    if (nv <= 0 || nt < 0 || ne < 0) throw Error("contact: bad mesh size");
+    ContactSystem::Mesh m{kind, idx_in_ps, cs.n_v, nv, cs.n_t, nt, cs.n_e, ne};
+    const int g = (int)cs.meshes.size();
+    for (int i = 0; i < nv; i++) {
+        cs.h_cv_src.push_back(vidx[i]);
+        cs.h_cv_mesh.push_back(g);
+    }
+    for (int i = 0; i < 3 * nt; i++) {
+        if (tris[i] < 0 || tris[i] >= nv) throw Error("contact: triangle vertex out of range");
+        cs.h_tri.push_back(cs.n_v + tris[i]);
+    }
+    for (int i = 0; i < nt; i++) cs.h_tri_mesh.push_back(g);
+    for (int i = 0; i < 2 * ne; i++) {
+        if (edges[i] < 0 || edges[i] >= nv) throw Error("contact: edge vertex out of range");
+        cs.h_edge.push_back(cs.n_v + edges[i]);
+    }
+    for (int i = 0; i < ne; i++) cs.h_edge_mesh.push_back(g);
+    cs.n_v += nv;
+    cs.n_t += nt;
+    cs.n_e += ne;
+    if (std::max(cs.n_v, std::max(cs.n_t, cs.n_e)) >= (1 << PRIM_BITS)) throw Error("contact: too many collision primitives");
+    cs.meshes.push_back(m);
+    if (kind == MISTARK_CONTACT_RIGIDBODY) cs.disabled_pairs.push_back({g, g});
+    cs.meshes_dirty = true;
+    cs.n_prev = -1;
+    return g;
+}
+template <class T>
+void upload(Context& c, DevBuf<T>& dst, const std::vector<T>& src)
+{
+    dst.ensure(std::max<size_t>(src.size(), 1));
+    if (!src.empty()) MS_CHECK(hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, c.stream));
+}
+void upload_meshes(Context& c, ContactSystem& cs)
+{
+    if (!cs.meshes_dirty) return;
+    const int nm = (int)cs.meshes.size();
+    std::vector<int32_t> kind(nm), idx(nm);
+    for (int g = 0; g < nm; g++) {
+        kind[g] = cs.meshes[g].kind;
+        idx[g] = cs.meshes[g].idx_in_ps;
+    }
+    std::vector<uint8_t> dis((size_t)nm * nm, 0);
+    for (auto& p : cs.disabled_pairs) dis[(size_t)p.first * nm + p.second] = dis[(size_t)p.second * nm + p.first] = 1;
+    std::vector<double> mu((size_t)nm * nm, 0.0);
+    for (auto& kv : cs.friction) mu[(size_t)kv.first.first * nm + kv.first.second] = mu[(size_t)kv.first.second * nm + kv.first.first] = kv.second;
+    upload(c, cs.cv_src, cs.h_cv_src);
+    upload(c, cs.cv_mesh, cs.h_cv_mesh);
+    upload(c, cs.tri, cs.h_tri);
+    upload(c, cs.tri_mesh, cs.h_tri_mesh);
+    upload(c, cs.edge, cs.h_edge);
+    upload(c, cs.edge_mesh, cs.h_edge_mesh);
+    upload(c, cs.mesh_kind, kind);
+    upload(c, cs.mesh_idx, idx);
+    upload(c, cs.disabled, dis);
+    upload(c, cs.mu, mu);
+    cs.X.ensure(3 * (size_t)cs.n_v);
+    cs.aabb.ensure(6 * (size_t)(cs.n_v + cs.n_t + cs.n_e));
+    MS_CHECK(hipStreamSynchronize(c.stream));  // (the staging vectors above are temporaries)
+    cs.meshes_dirty = false;
+}
+const double* arr_dev(Context& c, int id) { return id >= 0 ? c.arrays[id].dev : nullptr; }
+ContactDev dev_view(Context& c, ContactSystem& cs)
+{
+    ContactDev d{};
+    d.cv_src = cs.cv_src.p; d.cv_mesh = cs.cv_mesh.p; d.tri = cs.tri.p; d.tri_mesh = cs.tri_mesh.p; d.edge = cs.edge.p; d.edge_mesh = cs.edge_mesh.p;
+    d.mesh_kind = cs.mesh_kind.p; d.mesh_idx = cs.mesh_idx.p; d.disabled = cs.disabled.p; d.mu = cs.mu.p;
+    d.thick = arr_dev(c, cs.arr.thickness);
+    d.X = cs.X.p; d.aabb = cs.aabb.p;
+    d.n_mesh = (int)cs.meshes.size(); d.n_v = cs.n_v; d.n_t = cs.n_t; d.n_e = cs.n_e;
+    return d;
+}
+double max_thickness(Context& c, ContactSystem& cs)
+{
+    const Array& a = c.arrays[cs.arr.thickness];
+    if (a.n_items < (int64_t)cs.meshes.size() || !a.host) throw Error("contact: the thickness array must hold one value per collision mesh");
+    double m = 0.0;
+    for (size_t g = 0; g < cs.meshes.size(); g++) m = std::max(m, a.host[g]);
+    if (!(m > 0.0)) throw Error("contact: contact thickness must be positive");
+    return m;
+}
+int chunk_for(int n_rows, int n_cols)
+{
+    // enough workgroups to fill 256 CUs several times over without making the column chunks shorter than 2 LDS tiles
+    const int row_tiles = std::max(1, (n_rows + CB - 1) / CB);
+    const int want_chunks = std::max(1, 2048 / row_tiles);
+    int chunk = (n_cols + want_chunks - 1) / want_chunks;
+    chunk = std::max(2 * CB, ((chunk + CB - 1) / CB) * CB);
+    return chunk;
+}
+void update_vertices(Context& c, ContactSystem& cs, const ContactDev& d, double dt, float enl)
+{
+    hipLaunchKernelGGL(k_contact_vertices, dim3((cs.n_v + CB - 1) / CB), dim3(CB), 0, c.stream, d, arr_dev(c, cs.arr.x0), arr_dev(c, cs.arr.v1), arr_dev(c, cs.arr.rb_xloc),
+                       arr_dev(c, cs.arr.rb_v1), arr_dev(c, cs.arr.rb_w1), arr_dev(c, cs.arr.rb_t0), arr_dev(c, cs.arr.rb_q0), dt, cs.X.p);
+    const int np = cs.n_v + cs.n_t + cs.n_e;
+    hipLaunchKernelGGL(k_contact_aabbs, dim3((np + CB - 1) / CB), dim3(CB), 0, c.stream, d, enl, cs.aabb.p);
+}
+// Runs detection and installs the tables [t0, t1). Returns the number of rows.
+int64_t detect_and_route(Context& c, double dt, bool friction)
+{
+    ContactSystem& cs = CS(c);
+    if (cs.meshes.empty()) return 0;
+    prepare(c);
+    upload_meshes(c, cs);
+    const double enl = 2.0 * max_thickness(c, cs);
+    const float enl_f = nextafterf((float)enl, INFINITY) + 1.1920929e-07f;  // (float)enl + eps (AABBs.cpp:38), rounded up
+    ContactDev d = dev_view(c, cs);
+    update_vertices(c, cs, d, dt, enl_f);
+    if (cs.key_cap == 0) {
+        cs.key_cap = 1 << 18;
+        cs.keys.ensure(cs.key_cap);
+        cs.keys_alt.ensure(cs.key_cap);
+    }
+    int h[64];
+    int n = 0;
+    for (;;) {
+        MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
+        if (cs.pt_enabled && cs.n_t > 0) {
+            const int chunk = chunk_for(cs.n_v, cs.n_t);
+            const dim3 g((cs.n_v + CB - 1) / CB, (cs.n_t + chunk - 1) / chunk);
+            if (friction) hipLaunchKernelGGL(k_detect_pt<true>, g, dim3(CB), 0, c.stream, d, enl * enl, chunk, cs.keys.p, cs.counters.p, (int)cs.key_cap);
+            else hipLaunchKernelGGL(k_detect_pt<false>, g, dim3(CB), 0, c.stream, d, enl * enl, chunk, cs.keys.p, cs.counters.p, (int)cs.key_cap);
+        }
+        if (cs.ee_enabled && cs.n_e > 1) {
+            const int chunk = chunk_for(cs.n_e, cs.n_e);
+            const dim3 g((cs.n_e + CB - 1) / CB, (cs.n_e + chunk - 1) / chunk);
+            if (friction) hipLaunchKernelGGL(k_detect_ee<true>, g, dim3(CB), 0, c.stream, d, enl * enl, chunk, cs.keys.p, cs.counters.p, (int)cs.key_cap);
+            else hipLaunchKernelGGL(k_detect_ee<false>, g, dim3(CB), 0, c.stream, d, enl * enl, chunk, cs.keys.p, cs.counters.p, (int)cs.key_cap);
+        }
+        MS_CHECK(hipMemcpyAsync(h, cs.counters.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+        n = h[0];
+        if ((size_t)n <= cs.key_cap) break;
+        cs.key_cap = (size_t)n + n / 2;  // the list did not fit: grow and search again
+        cs.keys.ensure(cs.key_cap);
+        cs.keys_alt.ensure(cs.key_cap);
+        cs.n_prev = -1;
+    }
+    const int t0 = friction ? N_CONTACT_TABLES : 0, t1 = friction ? N_TABLES : N_CONTACT_TABLES;
+    const uint64_t* sorted = cs.keys.p;
+    if (n > 1) {
+        hipcub::DoubleBuffer<uint64_t> dk(cs.keys.p, cs.keys_alt.p);
+        size_t tmp = 0;
+        MS_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, dk, n, 0, 64, c.stream));
+        cs.cub_tmp.ensure(tmp);
+        MS_CHECK(hipcub::DeviceRadixSort::SortKeys(cs.cub_tmp.p, tmp, dk, n, 0, 64, c.stream));
+        sorted = dk.Current();
+    }
+    const bool compare = !friction && cs.n_prev >= 0;
+    if (compare) cs.prev.ensure(std::max<size_t>((size_t)cs.n_prev, 1));
+    hipLaunchKernelGGL(k_table_bounds, dim3((n + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, sorted, n, compare ? cs.prev.p : sorted, compare ? (int)cs.n_prev : -1,
+                       cs.counters.p + 8, cs.counters.p + 2);
+    MS_CHECK(hipMemcpyAsync(h, cs.counters.p, 64 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    const int* bounds = h + 8;
+    const bool unchanged = compare && n == cs.n_prev && h[2] == 0;
+    if (unchanged) return n;
+    // install the new row counts; buffers are (re)allocated before the routing kernel writes them
+    std::vector<TableDev> td(N_TABLES);
+    bool any = false;
+    for (int t = t0; t < t1; t++) {
+        ContactSystem::Table& T = cs.tables[t];
+        const int rows = bounds[t + 1] - bounds[t];
+        if (T.pot < 0) {
+            if (rows) throw Error(std::string("contact: rows for table '") + TABLE_NAMES[t] + "' but its physical system was not bound at mistark_contact_init");
+            continue;
+        }
+        Potential& P = c.pots[T.pot];
+        if (rows != P.n_elem) c.layout_dirty = true;
+        any = any || rows || P.n_elem;
+        T.n = rows;
+        P.n_elem = rows;
+        T.conn.ensure(std::max<size_t>((size_t)rows * T.stride, 1));
+        P.conn_ext = T.conn.p;
+        for (int id : {T.a_T, T.a_mu, T.a_fn, T.a_bary})
+            if (id >= 0 && c.arrays[id].n_items != rows) {
+                c.arrays[id].n_items = rows;
+                c.layout_dirty = true;
+            }
+    }
+    c.layout_dirty = true;  // (conn_ext may have moved: refresh the kernels' argument blocks)
+    if (any) c.part[1].dirty = true;
+    prepare(c);
+    for (int t = t0; t < t1; t++) {
+        ContactSystem::Table& T = cs.tables[t];
+        TableDev& o = td[t];
+        o.conn = T.conn.p;
+        o.stride = T.stride;
+        o.nbary = T.nbary;
+        o.start = bounds[t];
+        o.T = T.a_T >= 0 ? c.arrays[T.a_T].dev : nullptr;
+        o.mu = T.a_mu >= 0 ? c.arrays[T.a_mu].dev : nullptr;
+        o.fn = T.a_fn >= 0 ? c.arrays[T.a_fn].dev : nullptr;
+        o.bary = T.a_bary >= 0 ? c.arrays[T.a_bary].dev : nullptr;
+    }
+    if (n > 0) {
+        MS_CHECK(hipMemcpyAsync(cs.tables_dev.p, td.data(), N_TABLES * sizeof(TableDev), hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(k_route, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, sorted, n, (const TableDev*)cs.tables_dev.p, arr_dev(c, cs.arr.k));
+    }
+    if (!friction) {
+        cs.prev.ensure(std::max<size_t>((size_t)n, 1));
+        if (n > 0) MS_CHECK(hipMemcpyAsync(cs.prev.p, sorted, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c.stream));
+        cs.n_prev = n;
+    }
+    MS_CHECK(hipStreamSynchronize(c.stream));  // td is a temporary
+    return n;
+}
+int64_t count_intersections(Context& c, double dt)
+{
+    ContactSystem& cs = CS(c);
+    if (cs.meshes.empty() || cs.n_e == 0 || cs.n_t == 0) return 0;
+    prepare(c);
+    upload_meshes(c, cs);
+    ContactDev d = dev_view(c, cs);
+    update_vertices(c, cs, d, dt, 0.f);
+    MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 8 * sizeof(int), c.stream));
+    const int chunk = chunk_for(cs.n_e, cs.n_t);
+    hipLaunchKernelGGL(k_detect_et, dim3((cs.n_e + CB - 1) / CB, (cs.n_t + chunk - 1) / chunk), dim3(CB), 0, c.stream, d, chunk, cs.counters.p);
+    int h[2];
+    MS_CHECK(hipMemcpyAsync(h, cs.counters.p, sizeof(h), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    return h[1];
+}
+int find_table(const char* name)
+{
+    for (int t = 0; t < N_TABLES; t++)
+        if (std::strcmp(name, TABLE_NAMES[t]) == 0) return t;
+    return -1;
+}
+}  // namespace
+}  // namespace mistark
+
+using namespace mistark;
+
+#define CAPI_BEGIN       \
+    if (!ctx) return -1; \
+    try {
+#define CAPI_END(ret)                 \
+    }                                 \
+    catch (const std::exception& e)   \
+    {                                 \
+        ctx->c.last_error = e.what(); \
+        return -1;                    \
+    }                                 \
+    return ret;
+
+extern "C" {
+int mistark_contact_init(mistark_ctx* ctx, const mistark_contact_arrays* arrays)
+{
+    CAPI_BEGIN
+    if (!arrays) throw Error("contact: null arrays");
+    const int32_t* ids = &arrays->v1;
+    for (int i = 0; i < 12; i++)
+        if (ids[i] >= (int)ctx->c.arrays.size()) throw Error("contact: bad array id");
+    contact_init(ctx->c, *arrays);
+    CAPI_END(0)
+}
+int mistark_contact_add_mesh(mistark_ctx* ctx, int kind, int idx_in_ps, const int32_t* vertex_index, int32_t n_vertices, const int32_t* triangles, int32_t n_triangles,
+                             const int32_t* edges, int32_t n_edges)
+{
+    int g = -1;
+    CAPI_BEGIN
+    g = contact_add_mesh(ctx->c, kind, idx_in_ps, vertex_index, n_vertices, triangles, n_triangles, edges, n_edges);
+    CAPI_END(g)
+}
+int mistark_contact_set_friction(mistark_ctx* ctx, int a, int b, double mu)
+{
+    CAPI_BEGIN
+    ContactSystem& cs = CS(ctx->c);
+    const int nm = (int)cs.meshes.size();
+    if (a < 0 || b < 0 || a >= nm || b >= nm) throw Error("contact: bad group id");
+    cs.friction[{std::min(a, b), std::max(a, b)}] = mu;
+    cs.meshes_dirty = true;
+    CAPI_END(0)
+}
+int mistark_contact_disable_collision(mistark_ctx* ctx, int a, int b)
+{
+    CAPI_BEGIN
+    ContactSystem& cs = CS(ctx->c);
+    const int nm = (int)cs.meshes.size();
+    if (a < 0 || b < 0 || a >= nm || b >= nm) throw Error("contact: bad group id");
+    cs.disabled_pairs.push_back({std::min(a, b), std::max(a, b)});
+    cs.meshes_dirty = true;
+    cs.n_prev = -1;
+    CAPI_END(0)
+}
+int mistark_contact_enable(mistark_ctx* ctx, int point_triangle, int edge_edge)
+{
+    CAPI_BEGIN
+    ContactSystem& cs = CS(ctx->c);
+    cs.pt_enabled = point_triangle != 0;
+    cs.ee_enabled = edge_edge != 0;
+    cs.n_prev = -1;
+    CAPI_END(0)
+}
+int mistark_contact_update(mistark_ctx* ctx, double dt, int64_t* n_contacts)
+{
+    CAPI_BEGIN
+    const int64_t n = detect_and_route(ctx->c, dt, false);
+    if (n_contacts) *n_contacts = n;
+    CAPI_END(0)
+}
+int mistark_contact_update_friction(mistark_ctx* ctx, int64_t* n_contacts)
+{
+    CAPI_BEGIN
+    const int64_t n = detect_and_route(ctx->c, 0.0, true);
+    if (n_contacts) *n_contacts = n;
+    CAPI_END(0)
+}
+int mistark_contact_count_intersections(mistark_ctx* ctx, double dt, int64_t* n_found)
+{
+    CAPI_BEGIN
+    const int64_t n = count_intersections(ctx->c, dt);
+    if (n_found) *n_found = n;
+    CAPI_END(0)
+}
+int mistark_contact_get_table(mistark_ctx* ctx, const char* potential, int32_t* conn, int32_t* n_rows, int32_t* stride)
+{
+    CAPI_BEGIN
+    ContactSystem& cs = CS(ctx->c);
+    const int t = find_table(potential);
+    if (t < 0) throw Error(std::string("contact: unknown table '") + potential + "'");
+    ContactSystem::Table& T = cs.tables[t];
+    if (n_rows) *n_rows = T.n;
+    if (stride) *stride = T.stride;
+    if (conn && T.n > 0) {
+        MS_CHECK(hipMemcpyAsync(conn, T.conn.p, (size_t)T.n * T.stride * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->c.stream));
+        MS_CHECK(hipStreamSynchronize(ctx->c.stream));
+    }
+    CAPI_END(0)
+}
+int mistark_contact_get_friction_data(mistark_ctx* ctx, const char* potential, double* T_out, double* mu, double* fn, double* bary, int32_t* nbary)
+{
+    CAPI_BEGIN
+    Context& c = ctx->c;
+    ContactSystem& cs = CS(c);
+    const int t = find_table(potential);
+    if (t < N_CONTACT_TABLES) throw Error(std::string("contact: '") + potential + "' is not a friction table");
+    ContactSystem::Table& T = cs.tables[t];
+    if (nbary) *nbary = T.nbary;
+    auto get = [&](int id, double* out, int stride) {
+        if (out && id >= 0 && T.n > 0) MS_CHECK(hipMemcpyAsync(out, c.arrays[id].dev, (size_t)T.n * stride * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    };
+    get(T.a_T, T_out, 6);
+    get(T.a_mu, mu, 1);
+    get(T.a_fn, fn, 1);
+    get(T.a_bary, bary, T.nbary);
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    CAPI_END(0)
+}
+int mistark_contact_get_vertices(mistark_ctx* ctx, double* x, int64_t* n_vertices)
+{
+    CAPI_BEGIN
+    ContactSystem& cs = CS(ctx->c);
+    if (n_vertices) *n_vertices = cs.n_v;
+    if (x && cs.n_v > 0 && cs.X.p) {
+        MS_CHECK(hipMemcpyAsync(x, cs.X.p, 3 * (size_t)cs.n_v * sizeof(double), hipMemcpyDeviceToHost, ctx->c.stream));
+        MS_CHECK(hipStreamSynchronize(ctx->c.stream));
+    }
+    CAPI_END(0)
+}
+int mistark_contact_recipe(const char* potential, int32_t* conn_stride, int32_t* roles, int32_t* strides, int32_t* conn_cols)
+{
+    const int t = find_table(potential);
+    if (t < 0) return -1;
+    int stride = 0;
+    const std::vector<Bind> r = recipe(t, stride);
+    if (conn_stride) *conn_stride = stride;
+    for (size_t i = 0; i < r.size(); i++) {
+        if (roles) roles[i] = r[i].role;
+        if (strides) strides[i] = r[i].stride;
+        if (conn_cols) conn_cols[i] = r[i].col;
+    }
+    return (int)r.size();
+}
+}

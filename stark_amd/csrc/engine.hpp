@@ -116,6 +116,7 @@ struct Potential
     size_t kp_off = 0;  // first key in the key list of its matrix part
     int part = 0;       // 0: fixed connectivity, 1: connectivity changes inside the Newton loop (contacts)
     bool conn_dirty = true;
+    const int32_t* conn_ext = nullptr;  // connectivity written on the device by the contact detector (overrides conn)
 };
 
 // One part of the split system matrix in tiled block-CSR form (see kernels.hip, "SpMV").
@@ -127,6 +128,8 @@ struct BsrPart
     DevBuf<uint64_t> keys, keys_alt;
     DevBuf<uint32_t> kidx, kidx_alt;
     DevBuf<uint32_t> scan, slot_start;
+    DevBuf<uint32_t> slot_of_src;   // per element block of this part (pool order, from blk_base) -> BSR slot
+    size_t blk_base = 0;            // first element block of this part in the element-Hessian pool
     const uint32_t* sorted_src = nullptr;  // element-block ids in sorted key order (one of kidx / kidx_alt)
     int64_t nnzb = 0, ntiles = 0, n_rows = 0;
     DevBuf<uint32_t> colw;          // bit31 = last block of its row, bits 0..30 = block column
@@ -168,7 +171,6 @@ struct Context
 
     // sparsity pattern / matrix: A = part[0] (fixed connectivity + all diagonal blocks) + part[1] (contacts)
     BsrPart part[2];
-    DevBuf<uint32_t> slot_of_src;   // per element block (pool order) -> BSR slot inside the potential's part
     DevBuf<int32_t> diag_slot[2];   // per block row: slot of the diagonal block in each part, -1 if absent
     int spmv_variant = 0;          // micro-benchmark ablation variant
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
@@ -193,6 +195,8 @@ struct Context
     double spmv_ms_sum = 0.0;
     int64_t spmv_n = 0;
 
+    struct ContactSystem* contact = nullptr;  // device contact detector (contact.hip), created by mistark_contact_init
+
     int last_cg_iters = 0;          // iteration count of the previous solve (first-batch predictor)
     // statistics of the last evaluation
     int64_t n_projected_total = 0;
@@ -202,6 +206,9 @@ struct Context
 
 // host-side kernels launchers (kernels.hip)
 void prepare(Context& c);
+void ensure_pattern(Context& c);
+void contact_destroy(struct ContactSystem* cs);
+int register_potential(Context& c, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings);
 void eval(Context& c, int mode, double* E, double* grad_host);
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active,
              int64_t* n_projected_now, int64_t* n_changed_now);

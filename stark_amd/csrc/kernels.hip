@@ -374,13 +374,13 @@ __global__ __launch_bounds__(BLOCK) void k_heads(const uint64_t* __restrict__ ke
 }
 // scan = inclusive prefix of heads. slot = scan-1.
 __global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ scan, size_t n,
-                                                 uint64_t nbr, uint32_t* __restrict__ slot_of_src, uint32_t* __restrict__ colw, uint32_t* __restrict__ slot_row,
+                                                 uint64_t nbr, uint32_t* __restrict__ slot_of_src, uint32_t blk_base, uint32_t* __restrict__ colw, uint32_t* __restrict__ slot_row,
                                                  int32_t* __restrict__ diag_slot, uint32_t* __restrict__ slot_start, uint32_t* __restrict__ row_head)
 {
     const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n) return;
     const uint32_t slot = scan[k] - 1;
-    if (idx[k] != NO_SRC) slot_of_src[idx[k]] = slot;
+    if (idx[k] != NO_SRC) slot_of_src[idx[k] - blk_base] = slot;
     const bool head = (k == 0 || keys[k] != keys[k - 1]);
     if (k == n - 1) slot_start[slot + 1] = (uint32_t)n;
     if (head) {
@@ -431,6 +431,7 @@ static void build_pattern(Context& c, int part)
     const size_t diag_off = nk;
     if (part == 0) nk += (size_t)c.nbr;
     m.n_keys = nk;
+    m.slot_of_src.ensure(std::max<size_t>(nk, 1));
     m.dirty = false;
     m.have_matrix = false;
     c.diag_slot[part].ensure((size_t)c.nbr);
@@ -480,7 +481,7 @@ static void build_pattern(Context& c, int part)
     m.slot_start.ensure((size_t)m.nnzb + 1);
     MS_CHECK(hipMemsetAsync(m.colw.p, 0, (size_t)m.ntiles * 64 * sizeof(uint32_t), c.stream));
     uint32_t* row_head = heads;  // (heads is dead after the scan)
-    hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, (uint64_t)c.nbr, c.slot_of_src.p, m.colw.p, m.slot_row.p,
+    hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, (uint64_t)c.nbr, m.slot_of_src.p, (uint32_t)m.blk_base, m.colw.p, m.slot_row.p,
                        c.diag_slot[part].p, m.slot_start.p, row_head);
     m.sorted_src = sidx;
     // compact rows
@@ -502,7 +503,7 @@ static void build_pattern(Context& c, int part)
 
 void prepare(Context& c)
 {
-    if (!c.layout_dirty && !c.part[0].dirty && !c.part[1].dirty) return;
+    if (!c.layout_dirty) return;
     if (c.layout_dirty) {
         // DoF layout
         int64_t off = 0;
@@ -535,7 +536,7 @@ void prepare(Context& c)
                 const size_t na = (size_t)a.n_items * a.stride;
                 a.own.ensure(std::max<size_t>(na, 1));
                 a.dev = a.own.p;
-                if (a.need_upload && na > 0) {
+                if (a.need_upload && na > 0 && a.host) {
                     MS_CHECK(hipMemcpyAsync(a.dev, a.host, na * sizeof(double), hipMemcpyHostToDevice, c.stream));
                     a.need_upload = false;
                 }
@@ -544,7 +545,8 @@ void prepare(Context& c)
         // potentials
         // pools: static potentials first, so their offsets do not move when only the contact tables change size
         size_t e_off = 0, h_off = 0;
-        for (int part = 0; part < 2; part++)
+        for (int part = 0; part < 2; part++) {
+        c.part[part].blk_base = h_off / 9;
         for (auto& P : c.pots) {
             if (P.part != part) continue;
             P.e_off = e_off;
@@ -552,7 +554,7 @@ void prepare(Context& c)
             P.k_off = h_off / 9;
             e_off += (size_t)P.n_elem;
             h_off += (size_t)P.n_elem * 9 * P.NB * P.NB;
-            if (P.conn_dirty) {
+            if (P.conn_dirty && !P.conn_ext) {
                 P.conn.ensure(std::max<size_t>(P.conn_host.size(), 1));
                 if (!P.conn_host.empty())
                     MS_CHECK(hipMemcpyAsync(P.conn.p, P.conn_host.data(), P.conn_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
@@ -561,7 +563,7 @@ void prepare(Context& c)
             }
             PotArgs& A = P.args;
             std::memset(&A, 0, sizeof(A));
-            A.conn = P.conn.p;
+            A.conn = P.conn_ext ? P.conn_ext : P.conn.p;
             A.conn_stride = P.conn_stride;
             A.n_elem = P.n_elem;
             for (size_t b = 0; b < P.bindings.size(); b++) {
@@ -582,17 +584,23 @@ void prepare(Context& c)
                 }
             if (nblk != P.NB) throw Error("potential '" + P.name + "': expected " + std::to_string(P.NB) + " DoF bindings, got " + std::to_string(nblk));
         }
+        }
         c.n_elem_total = e_off;
         c.hess_total = h_off;
         c.elemE.ensure(std::max<size_t>(e_off, 1));
         c.elemH.ensure(std::max<size_t>(h_off, 1));
         c.is_projected.ensure(std::max<size_t>(e_off, 1));
-        c.slot_of_src.ensure(std::max<size_t>(h_off / 9, 1));
         c.dinv.ensure((size_t)c.nbr * 9);
         MS_CHECK(hipStreamSynchronize(c.stream));
         c.layout_dirty = false;
         c.have_hessians = false;
     }
+}
+// Sparsity patterns are built on first use (assembly / projection into an assembled matrix): evaluations that only need
+// energies (line search) never pay for a contact-set change.
+void ensure_pattern(Context& c)
+{
+    prepare(c);
     for (int part = 0; part < 2; part++)
         if (c.part[part].dirty) build_pattern(c, part);
 }
@@ -793,6 +801,7 @@ __global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restric
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active, int64_t* n_projected_now,
              int64_t* n_changed_now)
 {
+    ensure_pattern(c);
     if (!c.have_hessians) throw Error("project: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
     const int np = (int)c.pots.size();
     if (np + 4 > 128) throw Error("project: too many potentials");
@@ -826,7 +835,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         total += nl;
         double* H = c.elemH.p + P.h_off;
         const uint32_t* list = c.proj_list.p + P.e_off;
-        const uint32_t* sos = c.slot_of_src.p + P.k_off;
+        const uint32_t* sos = c.part[P.part].slot_of_src.p + (P.k_off - c.part[P.part].blk_base);
         float* vals = c.matrix_current ? c.part[P.part].vals.p : nullptr;
         const dim3 g((nl + 3) / 4), b(BLOCK);
         switch (P.NB) {
@@ -923,6 +932,7 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restr
 
 void assemble(Context& c)
 {
+    ensure_pattern(c);
     if (!c.have_hessians) throw Error("assemble: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
     for (int part = 0; part < 2; part++) {
         BsrPart& m = c.part[part];
@@ -932,7 +942,7 @@ void assemble(Context& c)
             for (auto& P : c.pots) {
                 const int64_t nblk = (int64_t)P.n_elem * P.NB * P.NB;
                 if (P.part != part || nblk == 0) continue;
-                hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p + P.h_off, nblk, c.slot_of_src.p + P.k_off, m.vals.p);
+                hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p + P.h_off, nblk, m.slot_of_src.p + (P.k_off - m.blk_base), m.vals.p);
             }
         } else {
             hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.nnzb, m.vals.p);
@@ -1350,6 +1360,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
 
 Context::~Context()
 {
+    contact_destroy(contact);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (h_scratch) (void)hipHostFree(h_scratch);
     if (stream) (void)hipStreamDestroy(stream);

@@ -73,6 +73,65 @@ class Engine:
         conn = np.ascontiguousarray(conn, dtype=np.int32)
         self._ck(self.L.mistark_potential_update_connectivity(self.h, pid, conn.ctypes.data if conn.size else None, conn.shape[0]))
 
+    # ---- device contact detector (include/mistark_contact.h) ----------------------------------------------------------------
+    def contact_init(self, **array_ids):
+        """array_ids: engine array ids by role (capi.CONTACT_ROLES); absent roles are -1."""
+        a = capi.ContactArrays(*[int(array_ids.get(r, -1)) for r in capi.CONTACT_ROLES])
+        self._ck(self.L.mistark_contact_init(self.h, C.byref(a)))
+
+    def contact_add_mesh(self, kind: str, idx_in_ps: int, verts, tris, edges) -> int:
+        v = np.ascontiguousarray(verts, dtype=np.int32)
+        t = np.ascontiguousarray(tris, dtype=np.int32).reshape(-1, 3)
+        e = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+        return self._ck(self.L.mistark_contact_add_mesh(self.h, 0 if kind == "d" else 1, idx_in_ps, v.ctypes.data, len(v), t.ctypes.data if t.size else None, len(t),
+                                                        e.ctypes.data if e.size else None, len(e)))
+
+    def contact_set_friction(self, a, b, mu):
+        self._ck(self.L.mistark_contact_set_friction(self.h, a, b, mu))
+
+    def contact_disable_collision(self, a, b):
+        self._ck(self.L.mistark_contact_disable_collision(self.h, a, b))
+
+    def contact_update(self, dt) -> int:
+        n = C.c_int64()
+        self._ck(self.L.mistark_contact_update(self.h, dt, C.byref(n)))
+        return n.value
+
+    def contact_update_friction(self) -> int:
+        n = C.c_int64()
+        self._ck(self.L.mistark_contact_update_friction(self.h, C.byref(n)))
+        return n.value
+
+    def contact_count_intersections(self, dt) -> int:
+        n = C.c_int64()
+        self._ck(self.L.mistark_contact_count_intersections(self.h, dt, C.byref(n)))
+        return n.value
+
+    def contact_table(self, name: str) -> np.ndarray:
+        n, st = C.c_int32(), C.c_int32()
+        self._ck(self.L.mistark_contact_get_table(self.h, name.encode(), None, C.byref(n), C.byref(st)))
+        out = np.zeros((n.value, st.value), dtype=np.int32)
+        if n.value:
+            self._ck(self.L.mistark_contact_get_table(self.h, name.encode(), out.ctypes.data, C.byref(n), C.byref(st)))
+        return out
+
+    def contact_friction_data(self, name: str, n_rows: int) -> dict:
+        nb = C.c_int32()
+        self._ck(self.L.mistark_contact_get_friction_data(self.h, name.encode(), None, None, None, None, C.byref(nb)))
+        T = np.zeros((n_rows, 6)); mu = np.zeros(n_rows); fn = np.zeros(n_rows); bary = np.zeros((n_rows, max(nb.value, 1)))
+        self._ck(self.L.mistark_contact_get_friction_data(self.h, name.encode(), T.ctypes.data, mu.ctypes.data, fn.ctypes.data, bary.ctypes.data if nb.value else None, C.byref(nb)))
+        out = dict(T=T, mu=mu, fn=fn)
+        if nb.value:
+            out["bary"] = bary
+        return out
+
+    def contact_vertices(self) -> np.ndarray:
+        n = C.c_int64()
+        self._ck(self.L.mistark_contact_get_vertices(self.h, None, C.byref(n)))
+        x = np.zeros((n.value, 3))
+        self._ck(self.L.mistark_contact_get_vertices(self.h, x.ctypes.data, C.byref(n)))
+        return x
+
     def upload(self, array: int = -1):
         self._ck(self.L.mistark_upload(self.h, array))
 

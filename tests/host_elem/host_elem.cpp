@@ -65,3 +65,34 @@ extern "C" int host_tet_closed_eval(int full, const double* in, int n_elem, doub
     }
     return 0;
 }
+
+// ---- narrow-phase geometry of the contact detector (stark_amd/csrc/contact_geom.hpp), batch wrappers ------------------------
+#include "../../stark_amd/csrc/contact_geom.hpp"
+static D3 ld(const double* x) { return d3(x[0], x[1], x[2]); }
+extern "C" void host_geom_point_triangle(const double* in, int n, int* type, double* d2)
+{
+    for (int i = 0; i < n; i++) d2[i] = point_triangle_sq_distance(type[i], ld(in + 12 * i), ld(in + 12 * i + 3), ld(in + 12 * i + 6), ld(in + 12 * i + 9));
+}
+extern "C" void host_geom_edge_edge(const double* in, int n, int* type, double* d2)
+{
+    for (int i = 0; i < n; i++) d2[i] = edge_edge_sq_distance(type[i], ld(in + 12 * i), ld(in + 12 * i + 3), ld(in + 12 * i + 6), ld(in + 12 * i + 9));
+}
+extern "C" void host_geom_edge_triangle(const double* in, int n, int* hit)
+{
+    for (int i = 0; i < n; i++) hit[i] = edge_intersects_triangle(ld(in + 15 * i), ld(in + 15 * i + 3), ld(in + 15 * i + 6), ld(in + 15 * i + 9), ld(in + 15 * i + 12)) ? 1 : 0;
+}
+// out: pt [bary3 | T6], pe [bary2 | T6], pp [T6] from the point-triangle inputs; ee [bary2 | T6] from the edge-edge inputs
+extern "C" void host_geom_friction(const double* pt_in, const double* ee_in, int n, double* pt, double* pe, double* pp, double* ee)
+{
+    for (int i = 0; i < n; i++) {
+        const D3 p = ld(pt_in + 12 * i), a = ld(pt_in + 12 * i + 3), b = ld(pt_in + 12 * i + 6), c = ld(pt_in + 12 * i + 9);
+        bary_point_triangle(p, a, b, c, pt + 9 * i);
+        basis_triangle(a, b, c, pt + 9 * i + 3);
+        bary_point_edge(p, a, b, pe + 8 * i);
+        basis_point_edge(p, a, b, pe + 8 * i + 2);
+        basis_point_point(p, a, pp + 6 * i);
+        const D3 A = ld(ee_in + 12 * i), B = ld(ee_in + 12 * i + 3), P = ld(ee_in + 12 * i + 6), Q = ld(ee_in + 12 * i + 9);
+        bary_edge_edge(A, B, P, Q, ee + 8 * i);
+        basis_edge_edge(A, B, P, Q, ee + 8 * i + 2);
+    }
+}

@@ -103,3 +103,32 @@ def test_closed_form_tet_matches_reference(host_lib, path):
         assert np.abs(gs - gref).max() <= 1e-11 * np.abs(gref).max() + 1e-13 * np.abs(Href).max()
         checked += 1
     assert checked > 0
+
+
+def test_contact_geometry_matches_reference_known_answers(host_lib):
+    """stark_amd/csrc/contact_geom.hpp (the detector's narrow phase, compiled for the host) against the reference's own
+    classification / distance / intersection / friction-geometry functions on the seeded vectors of contact_geometry.npz."""
+    z = np.load(os.path.join(GOLDEN, "contact_geometry.npz"))
+    n = len(z["pt_type"])
+    P = ctypes.c_void_p
+    pt_in = np.ascontiguousarray(z["pt_in"]); ee_in = np.ascontiguousarray(z["ee_in"]); et_in = np.ascontiguousarray(z["et_in"])
+    ty = np.zeros(n, dtype=np.int32); d2 = np.zeros(n)
+    host_lib.host_geom_point_triangle(P(pt_in.ctypes.data), n, P(ty.ctypes.data), P(d2.ctypes.data))
+    assert (ty == z["pt_type"]).all()
+    assert np.abs(d2 - z["pt_d2"]).max() <= 1e-13 * max(1.0, z["pt_d2"].max())
+    host_lib.host_geom_edge_edge(P(ee_in.ctypes.data), n, P(ty.ctypes.data), P(d2.ctypes.data))
+    cross2 = ((np.cross(ee_in[:, 3:6] - ee_in[:, 0:3], ee_in[:, 9:12] - ee_in[:, 6:9])) ** 2).sum(1)
+    ok = cross2 >= 1e-30
+    assert (ty[ok] == z["ee_type"][ok]).all()
+    assert np.abs(d2[ok] - z["ee_d2"][ok]).max() <= 1e-12 * max(1.0, z["ee_d2"].max())
+    hit = np.zeros(n, dtype=np.int32)
+    host_lib.host_geom_edge_triangle(P(et_in.ctypes.data), n, P(hit.ctypes.data))
+    assert (hit == z["et_hit"]).all()
+    pt = np.zeros((n, 9)); pe = np.zeros((n, 8)); pp = np.zeros((n, 6)); ee = np.zeros((n, 8))
+    host_lib.host_geom_friction(P(pt_in.ctypes.data), P(ee_in.ctypes.data), n, P(pt.ctypes.data), P(pe.ctypes.data), P(pp.ctypes.data), P(ee.ctypes.data))
+    assert np.abs(pt[:, :3] - z["fr_pt"][:, :3]).max() < 1e-10
+    assert np.abs(pt[:, 3:] - z["fr_pt"][:, 3:]).max() < 1e-12
+    assert np.abs(pe - z["fr_pe"]).max() < 1e-11
+    assert np.abs(pp - z["fr_pp"]).max() < 1e-12
+    assert np.abs(ee[:, :2] - z["fr_ee"][:, :2]).max() <= 1e-9 * np.abs(z["fr_ee"][:, :2]).max()
+    assert np.abs(ee[:, 2:] - z["fr_ee"][:, 2:]).max() < 1e-9

@@ -1,0 +1,142 @@
+"""GPU parity of the device contact detector (stark_amd/csrc/contact.hip) against the reference's own contact and friction
+tables recorded in the contact fixtures, and of the full evaluation through the module-registered potentials."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import contact as oc  # noqa: E402
+from oracle import evaluator as ev  # noqa: E402
+from contact_util import friction_order, sorted_rows, state_from_fixture  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+CONTACT_FIXTURES = ["contactmix_t0", "contactmix_t1", "contactcorners_t0"]
+
+
+def is_contact(name):
+    return name.startswith("contact_") or name.startswith("friction_")
+
+
+def build(name):
+    """Engine with the fixture's non-contact potentials registered from the fixture and the 35 contact/friction potentials
+    registered by the device contact module; collision meshes from the fixture's detector inputs."""
+    import copy
+
+    from gpu_util import engine_from_problem
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    base = copy.copy(prob)
+    base.potentials = [copy.copy(p) for p in prob.potentials]
+    for p in base.potentials:
+        if is_contact(p.name):
+            p.conn = p.conn[:0]   # (skipped by engine_from_problem)
+    eng = engine_from_problem(base, man)
+    st, roles = state_from_fixture(prob, man)
+    ids = {}
+    for role, aid in roles.items():
+        stride = {"rb_q0": 4}.get(role, 3 if role in ("v1", "x0", "X", "rb_xloc", "rb_v1", "rb_w1", "rb_t0") else 1)
+        key = (aid, stride)
+        if key not in eng.array_ids:
+            eng.array_ids[key] = eng.array(eng.host_arrays[aid].reshape(-1, stride), stride)
+        ids["thickness" if role == "thick" else role] = eng.array_ids[key]
+    eng.contact_init(**ids)
+    scene = oc.scene_from_fixture(man, z)
+    for m in scene.meshes:
+        eng.contact_add_mesh(m.kind, m.idx_in_ps, m.verts, m.tris, m.edges)
+    for (a, b), mu in scene.friction.items():
+        eng.contact_set_friction(a, b, mu)
+    return eng, prob, man, z, scene, st
+
+
+@pytest.mark.parametrize("name", CONTACT_FIXTURES)
+def test_device_tables_match_reference(name):
+    from stark_amd import capi
+
+    eng, prob, man, z, scene, st = build(name)
+    dt = float(np.asarray(st["dt"]).ravel()[0])
+    n_fr = eng.contact_update_friction()
+    n_ct = eng.contact_update(dt)
+    # collision vertices
+    X = np.concatenate(oc.mesh_vertices(scene, st, dt))
+    assert np.abs(eng.contact_vertices() - X).max() <= 1e-14 * max(1.0, np.abs(X).max())
+    assert eng.contact_count_intersections(dt) == 0
+    tot_c = tot_f = 0
+    for pi, p in enumerate(man["potentials"]):
+        if not is_contact(p["name"]):
+            continue
+        ref = prob.potentials[pi].conn
+        ours = eng.contact_table(p["name"])
+        assert ours.shape == ref.shape, (p["name"], ours.shape, ref.shape)
+        if p["name"].startswith("contact_"):
+            # bit-exact contact-pair indexing: the same rows in every barrier table (row order: ours is sorted by pair id)
+            assert (sorted_rows(ours) == sorted_rows(ref)).all(), p["name"]
+            tot_c += len(ref)
+            continue
+        tot_f += len(ref)
+        if len(ref) == 0:
+            continue
+        assert (ours[:, 0] == np.arange(len(ours))).all()
+        rec = oc.RECIPES[p["name"]][1]
+        ref_data = {}
+        for (role, stride, _), b in zip(rec, p["bindings"]):
+            if role in ("T", "mu", "fn", "bary"):
+                ref_data[role] = np.asarray(prob.arrays[b["array"]]).reshape(-1, stride)
+        data = eng.contact_friction_data(p["name"], len(ours))
+        data = {k: v.reshape(len(ours), -1) for k, v in data.items() if k in ref_data}
+        o1, o2 = friction_order(ours, data), friction_order(ref, ref_data)
+        assert (ours[o1, 1:] == ref[o2, 1:]).all(), p["name"]
+        for role, rd in ref_data.items():
+            scale = max(np.abs(rd).max(), 1e-300)
+            assert np.abs(data[role][ours[o1, 0]] - rd[ref[o2, 0]]).max() <= 1e-9 * scale, (p["name"], role)
+    assert tot_c == n_ct and tot_f == n_fr and tot_c > 0 and tot_f > 0
+
+    # the whole evaluation through the device-written tables: energy, gradient, assembled matrix, linear solve
+    E, grad = eng.eval(capi.EVAL_P_G_H)
+    scale = sum(abs(p.get("E", 0.0)) for p in man["potentials"])
+    assert abs(E - man["E"]) <= 1e-11 * max(1.0, scale)
+    assert np.abs(grad - z["grad"]).max() <= 1e-9 * np.abs(z["grad"]).max()
+    eng.assemble()
+    y = eng.spmv(np.sin(0.37 * np.arange(eng.ndofs)))
+    assert np.abs(y - z["spmv_y"]).max() <= 2e-6 * np.abs(z["spmv_y"]).max()
+    # a second detection at the same state leaves the tables (and the dynamic matrix pattern) alone
+    assert eng.contact_update(dt) == n_ct
+    E2, _ = eng.eval(capi.EVAL_P)
+    assert abs(E2 - E) <= 1e-13 * max(1.0, abs(E))
+    eng.close()
+
+
+def test_detects_intersections_and_moving_contacts():
+    """Moves the cloth of the contact zoo through the fixed box: contact sets change with the DoFs, the intersection test fires."""
+    from stark_amd import capi
+
+    eng, prob, man, z, scene, st = build("contactmix_t0")
+    dt = float(np.asarray(st["dt"]).ravel()[0])
+    eng.contact_update_friction()
+    n0 = eng.contact_update(dt)
+    u = eng.get_dofs()
+    # push every deformable node down by 5 cm within one step
+    soft = man["dof_sets"][0]
+    u2 = u.copy()
+    u2[soft["offset"] + 2:soft["offset"] + soft["size"]:3] -= 0.05 / dt
+    eng.set_dofs(u2)
+    n1 = eng.contact_update(dt)
+    st2 = dict(st)
+    st2["v1"] = u2[soft["offset"]:soft["offset"] + soft["size"]].reshape(-1, 3)
+    X = oc.mesh_vertices(scene, st2, dt)
+    prox = oc.detect(scene, X, 2.0 * oc.max_thickness(scene))
+    tables = oc.contact_tables(scene, prox)
+    assert n1 == sum(len(t) for t in tables.values()) and n1 != n0
+    for name, t in tables.items():
+        assert (sorted_rows(eng.contact_table(name)) == sorted_rows(t)).all(), name
+    assert oc.has_intersections(scene, X)
+    assert eng.contact_count_intersections(dt) > 0
+    # evaluation still works with the new tables (energies of penetrated pairs are just large)
+    E, g = eng.eval(capi.EVAL_P_G_H)
+    assert np.isfinite(E)
+    eng.assemble()
+    eng.close()

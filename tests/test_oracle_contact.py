@@ -12,6 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import contact as oc  # noqa: E402
 from oracle import evaluator as ev  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from contact_util import roles_from_manifest, sorted_rows, state_from_fixture  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 CONTACT_FIXTURES = ["contactmix_t0", "contactmix_t1", "contactcorners_t0"]
@@ -58,48 +60,11 @@ def load(name):
     return prob, man, z
 
 
-def roles_from_manifest(man):
-    """role -> array id, from every contact/friction potential that has elements, and the check that the recipes reproduce the
-    reference's binding lists (stride and connectivity column of every mws.make_* call) for ALL 35 potentials."""
-    roles = {}
-    seen = 0
-    for p in man["potentials"]:
-        if p["name"] not in oc.RECIPES:
-            continue
-        seen += 1
-        stride, rec = oc.RECIPES[p["name"]]
-        assert p["conn_stride"] == stride, p["name"]
-        assert [(b["stride"], b["conn"]) for b in p["bindings"]] == [(s, c) for _, s, c in rec], p["name"]
-        for (role, _, _), b in zip(rec, p["bindings"]):
-            if b["array"] >= 0 and role not in ("T", "mu", "fn", "bary"):
-                assert roles.setdefault(role, b["array"]) == b["array"], (p["name"], role)
-    assert seen == 35
-    return roles
-
-
 @pytest.mark.parametrize("name", CONTACT_FIXTURES)
 def test_recipes_match_reference_bindings(name):
     _, man, _ = load(name)
     roles = roles_from_manifest(man)
     assert {"v1", "x0", "dt", "k", "thick"} <= set(roles) or name == "contactcorners_t0"
-
-
-def state_from_fixture(prob, man):
-    roles = roles_from_manifest(man)
-    st = {r: np.asarray(prob.arrays[i]) for r, i in roles.items()}
-    for r in ("x0", "v1", "X", "rb_xloc", "rb_v1", "rb_w1", "rb_t0"):
-        if r in st:
-            st[r] = st[r].reshape(-1, 3)
-    if "rb_q0" in st:
-        st["rb_q0"] = st["rb_q0"].reshape(-1, 4)
-    return st, roles
-
-
-def sorted_rows(a):
-    a = np.asarray(a)
-    if a.shape[0] == 0:
-        return a
-    return a[np.lexsort(a.T[::-1])]
 
 
 @pytest.mark.parametrize("name", CONTACT_FIXTURES)
