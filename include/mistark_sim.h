@@ -22,6 +22,7 @@ typedef struct mistark_sim_settings
     int32_t device;
     int32_t mirror_state_to_host;
     int32_t enable_output;
+    int32_t init_frictional_contact; /* Settings::Simulation::init_frictional_contact */
     mistark_newton_settings newton;
 } mistark_sim_settings;
 void mistark_sim_default_settings(mistark_sim_settings* s);
@@ -59,6 +60,40 @@ int mistark_sim_add_surface_grid(mistark_sim* sim, const char* label, const doub
 int mistark_sim_add_surface(mistark_sim* sim, const char* label, const double* vertices, int64_t n_vertices, const int32_t* triangles, int64_t n_triangles, const mistark_surface_params* p);
 /* deformables->prescribed_positions->add_inside_aabb: returns the group index */
 int mistark_sim_prescribe_inside_aabb(mistark_sim* sim, int point_set, const double center[3], const double dim[3], double stiffness, double tolerance);
+
+/* PointSetHandler::add_displacement / add_rotation (also at rest pose), before the first step */
+int mistark_sim_point_set_add_displacement(mistark_sim* sim, int point_set, const double d[3]);
+int mistark_sim_point_set_add_rotation(mistark_sim* sim, int point_set, double angle_deg, const double axis[3], const double pivot[3]);
+
+/* ---- rigid bodies (stark::RigidBodies, RigidBodyPresets::add_box, RigidBodyHandler) ---------------------------------------- */
+int mistark_sim_add_rigid_box(mistark_sim* sim, const char* label, double mass, const double size[3]); /* returns the body index */
+int mistark_sim_rb_set_translation(mistark_sim* sim, int rb, const double t[3]);
+int mistark_sim_rb_add_translation(mistark_sim* sim, int rb, const double t[3]);
+int mistark_sim_rb_add_rotation(mistark_sim* sim, int rb, double angle_deg, const double axis[3], const double pivot[3]);
+int mistark_sim_rb_set_velocity(mistark_sim* sim, int rb, const double v[3], const double w[3]);
+int mistark_sim_rb_set_default_constraint_params(mistark_sim* sim, double stiffness, double tolerance_in_m, double tolerance_in_deg);
+/* RigidBodies::add_constraint_<type>(a, b, ...): type is the reference's suffix ("fix", "global_point", "global_direction",
+ * "point", "point_on_axis", "distance", "distance_limits", "direction", "angle_limit", "spring", "linear_velocity",
+ * "angular_velocity", "attachment", "point_with_angle_limit", "hinge", "hinge_with_angle_limit", "slider", "prismatic_slider",
+ * "spring_with_limits", "prismatic_press", "motor"); params = the remaining arguments flattened in the reference's order
+ * (points / directions as 3 doubles). b is ignored by the single-body types. */
+int mistark_sim_rb_add_constraint(mistark_sim* sim, const char* type, int a, int b, const double* params, int n_params);
+/* t1 [3], q1 [4: w x y z], v1 [3], w1 [3] (nullable outputs) */
+int mistark_sim_rb_get_state(mistark_sim* sim, int rb, double* t, double* q, double* v, double* w);
+
+/* ---- frictional contact (stark::EnergyFrictionalContact) -------------------------------------------------------------------- */
+typedef struct mistark_contact_global_params
+{
+    double default_contact_thickness, min_contact_stiffness, max_contact_stiffness, friction_stick_slide_threshold;
+    int32_t collisions_enabled, friction_enabled, triangle_point_enabled, edge_edge_enabled, intersection_test_enabled;
+} mistark_contact_global_params;
+void mistark_contact_default_global_params(mistark_contact_global_params* p);
+int mistark_sim_set_contact_global_params(mistark_sim* sim, const mistark_contact_global_params* p);
+/* contact group (EnergyFrictionalContact::Handler index) of a point set (kind 0) or rigid body (kind 1) added through a preset */
+int mistark_sim_contact_group(mistark_sim* sim, int kind, int idx);
+int mistark_sim_set_friction(mistark_sim* sim, int group_a, int group_b, double mu);
+int mistark_sim_disable_collision(mistark_sim* sim, int group_a, int group_b);
+int mistark_sim_get_contact_info(mistark_sim* sim, double* contact_stiffness, int64_t* n_contacts, int64_t* n_friction_contacts, int64_t* n_detections);
 
 /* Replace the Newton settings used by the following steps (stark::core::Settings::newton). */
 int mistark_sim_set_newton_settings(mistark_sim* sim, const mistark_newton_settings* s);

@@ -10,6 +10,8 @@
 #include <array>
 #include <cmath>
 #include <cstdint>
+#include <iterator>
+#include <map>
 #include <stdexcept>
 #include <vector>
 
@@ -131,6 +133,125 @@ inline void find_internal_angles(std::vector<std::array<int, 4>>& out, const std
         if (buf.size() == 2) out.push_back({e[0], e[1], buf[0], buf[1]});
         else if (buf.size() > 2) throw std::runtime_error("triangle mesh has edges with more than two incident triangles");
     }
+}
+
+// ---- small rotations (Eigen::Matrix3d / Quaterniond replacements; quaternions are (w, x, y, z)) ------------------------------------
+using Mat3 = std::array<double, 9>;  // row-major
+using Quat = std::array<double, 4>;
+inline Mat3 mat_identity() { return {1, 0, 0, 0, 1, 0, 0, 0, 1}; }
+inline Vec3 operator*(const Mat3& R, const Vec3& v)
+{
+    return {R[0] * v[0] + R[1] * v[1] + R[2] * v[2], R[3] * v[0] + R[4] * v[1] + R[5] * v[2], R[6] * v[0] + R[7] * v[1] + R[8] * v[2]};
+}
+inline Mat3 transpose(const Mat3& R) { return {R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8]}; }
+inline Mat3 matmul(const Mat3& A, const Mat3& B)
+{
+    Mat3 C{};
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) C[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+    return C;
+}
+inline Vec3 normalized(const Vec3& v) { return (1.0 / norm(v)) * v; }
+inline Quat quat_normalized(const Quat& q)
+{
+    const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    return {q[0] / n, q[1] / n, q[2] / n, q[3] / n};
+}
+inline Quat quat_mul(const Quat& a, const Quat& b)  // Hamilton product
+{
+    return {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+            a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+}
+inline Quat quat_angle_axis(double angle_rad, const Vec3& unit_axis)  // Eigen::Quaterniond(AngleAxis)
+{
+    const double s = std::sin(0.5 * angle_rad);
+    return {std::cos(0.5 * angle_rad), s * unit_axis[0], s * unit_axis[1], s * unit_axis[2]};
+}
+inline Mat3 quat_to_matrix(const Quat& q)  // Eigen::Quaterniond::toRotationMatrix
+{
+    const double w = q[0], x = q[1], y = q[2], z = q[3];
+    const double tx = 2.0 * x, ty = 2.0 * y, tz = 2.0 * z;
+    const double twx = tx * w, twy = ty * w, twz = tz * w, txx = tx * x, txy = ty * x, txz = tz * x, tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    return {1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1.0 - (txx + tyy)};
+}
+// q1 = normalize(q0 + dt/2 (0, w) * q0)   (stark/src/models/rigidbodies/rigidbody_transformations.cpp:30-37)
+inline Quat quat_time_integration(const Quat& q0, const Vec3& w, double dt)
+{
+    const Quat p = quat_mul({0.0, w[0], w[1], w[2]}, q0);
+    return quat_normalized({q0[0] + 0.5 * dt * p[0], q0[1] + 0.5 * dt * p[1], q0[2] + 0.5 * dt * p[2], q0[3] + 0.5 * dt * p[3]});
+}
+inline double deg2rad(double deg) { return 2.0 * M_PI * (deg / 360.0); }  // stark/src/utils/mesh_utils.cpp:28-31
+inline double rad2deg(double rad) { return 360.0 * rad / (2.0 * M_PI); }
+
+// ---- stark::find_surface (stark/src/utils/mesh_utils.cpp:280-327) ----------------------------------------------------------------
+// Faces that belong to one tet only, wound to point away from that tet, re-indexed to a compact vertex set. The reference walks an
+// unordered_map, so its triangle ORDER and compact numbering are unspecified; here faces are emitted in the order of their sorted
+// vertex triple and vertices are numbered by first appearance. Which faces, and the winding rule per face, are the reference's.
+inline void find_surface(std::vector<std::array<int, 3>>& out_triangles, std::vector<int>& out_tri_to_tet_node, const std::vector<Vec3>& vertices,
+                         const std::vector<std::array<int, 4>>& tets)
+{
+    // sorted face -> tet; a face of the surface occurs exactly once (sort + run-length instead of a hash map: 4 faces per tet)
+    struct Face
+    {
+        std::array<int, 3> f;
+        int tet;
+    };
+    std::vector<Face> all;
+    all.reserve(4 * tets.size());
+    for (int ti = 0; ti < (int)tets.size(); ti++) {
+        const auto& t = tets[ti];
+        const std::array<std::array<int, 3>, 4> faces = {{{t[0], t[1], t[2]}, {t[0], t[1], t[3]}, {t[0], t[2], t[3]}, {t[1], t[2], t[3]}}};
+        for (auto f : faces) {
+            std::sort(f.begin(), f.end());
+            all.push_back({f, ti});
+        }
+    }
+    std::sort(all.begin(), all.end(), [](const Face& a, const Face& b) { return a.f < b.f; });
+    std::vector<std::pair<std::array<int, 3>, int>> face_tet;
+    for (size_t i = 0; i < all.size();) {
+        size_t j = i + 1;
+        while (j < all.size() && all[j].f == all[i].f) j++;
+        if ((j - i) % 2 == 1) face_tet.push_back({all[i].f, all[i].tet});  // (insert / erase toggling of the reference)
+        i = j;
+    }
+    out_triangles.clear();
+    out_tri_to_tet_node.clear();
+    std::vector<int> old_to_new(vertices.size(), -1);
+    for (const auto& kv : face_tet) {
+        std::array<int, 3> f = kv.first;
+        const auto& t = tets[kv.second];
+        const Vec3 center = 0.25 * (vertices[t[0]] + vertices[t[1]] + vertices[t[2]] + vertices[t[3]]);
+        // is_outward_facing (mesh_utils.cpp:20-25): normal . (tet center - face center) < 0; the reference swaps in that case (:318-320)
+        const Vec3 nrm = cross(vertices[f[1]] - vertices[f[0]], vertices[f[2]] - vertices[f[0]]);
+        const Vec3 fc = (1.0 / 3.0) * (vertices[f[0]] + vertices[f[1]] + vertices[f[2]]);
+        if (dot(nrm, center - fc) < 0.0) std::swap(f[0], f[1]);
+        std::array<int, 3> nf;
+        for (int i = 0; i < 3; i++) {  // reduce_connectivity (mesh_utils.h:121-143)
+            if (old_to_new[f[i]] < 0) {
+                old_to_new[f[i]] = (int)out_tri_to_tet_node.size();
+                out_tri_to_tet_node.push_back(f[i]);
+            }
+            nf[i] = old_to_new[f[i]];
+        }
+        out_triangles.push_back(nf);
+    }
+}
+
+// ---- stark::make_box (stark/src/utils/mesh_generators.cpp:34-65): par_shapes' unit cube, centred and scaled -------------------------
+inline void make_box(std::vector<Vec3>& V, std::vector<std::array<int, 3>>& T, const Vec3& size)
+{
+    static const double c[8][3] = {{0, 0, 0}, {0, 1, 0}, {1, 1, 0}, {1, 0, 0}, {0, 0, 1}, {0, 1, 1}, {1, 1, 1}, {1, 0, 1}};
+    static const int t[12][3] = {{7, 6, 5}, {5, 4, 7}, {0, 1, 2}, {2, 3, 0}, {6, 7, 3}, {3, 2, 6}, {5, 6, 2}, {2, 1, 5}, {4, 5, 1}, {1, 0, 4}, {7, 4, 0}, {0, 3, 7}};
+    V.clear();
+    T.clear();
+    for (auto& p : c) V.push_back({(p[0] - 0.5) * size[0], (p[1] - 0.5) * size[1], (p[2] - 0.5) * size[2]});
+    for (auto& f : t) T.push_back({f[0], f[1], f[2]});
+}
+// stark/src/models/rigidbodies/inertia_tensors.cpp:31-47
+inline Mat3 inertia_tensor_box(double mass, const Vec3& size)
+{
+    const double l = size[0], w = size[1], h = size[2];
+    return {(1.0 / 12.0) * mass * (w * w + h * h), 0, 0, 0, (1.0 / 12.0) * mass * (l * l + h * h), 0, 0, 0, (1.0 / 12.0) * mass * (l * l + w * w)};
 }
 
 }  // namespace mistark

@@ -180,6 +180,27 @@ std::vector<int> PointSetHandler::all() const
 }
 Vec3 PointSetHandler::get_position(int i) const { return dyn->x1[get_global_index(i)]; }
 Vec3 PointSetHandler::get_rest_position(int i) const { return dyn->X[get_global_index(i)]; }
+PointSetHandler& PointSetHandler::add_displacement(const Vec3& d, bool also_at_rest_pose)
+{
+    for (int i = get_begin(); i < get_end(); i++) {
+        dyn->x1[i] = dyn->x1[i] + d;
+        dyn->x0[i] = dyn->x0[i] + d;
+        if (also_at_rest_pose) dyn->X[i] = dyn->X[i] + d;
+    }
+    dyn->mark_state_edited();
+    return *this;
+}
+PointSetHandler& PointSetHandler::add_rotation(double angle_deg, const Vec3& axis, const Vec3& pivot, bool also_at_rest_pose)
+{
+    const Mat3 R = quat_to_matrix(quat_angle_axis(deg2rad(angle_deg), normalized(axis)));
+    for (int i = get_begin(); i < get_end(); i++) {
+        dyn->x0[i] = R * (dyn->x0[i] - pivot) + pivot;  // rotate_deg(point, R, pivot)
+        dyn->x1[i] = dyn->x0[i];
+        if (also_at_rest_pose) dyn->X[i] = dyn->x0[i];
+    }
+    dyn->mark_state_edited();
+    return *this;
+}
 
 PointDynamics::PointDynamics(Stark& s) : stark(s)
 {
@@ -241,6 +262,10 @@ void PointDynamics::mirror_to_host()
     stark.check(mistark_download(stark.ctx, id_v0));
     stark.check(mistark_dofs_to_host_arrays(stark.ctx));
     x1 = x0;
+}
+void PointDynamics::mark_state_edited()
+{
+    if (stark.ctx) upload_state();
 }
 void PointDynamics::upload_state()
 {
@@ -754,12 +779,13 @@ Volume::Params Volume::Params::Soft_Rubber()
 }
 Surface::Handler DeformablesPresets::add_surface(const std::string& label, const std::vector<Vec3>& V, const std::vector<std::array<int, 3>>& T, const Surface::Params& p)
 {
-    // DeformablesPresets.cpp:31-44 (contact registration: next scope row)
+    // DeformablesPresets.cpp:31-44
     PointSetHandler ps = deformables->point_sets->add(V, label);
     auto inertia = deformables->lumped_inertia->add(ps, T, p.inertia);
     auto strain = deformables->triangle_strain->add(ps, T, p.strain);
     auto bending = deformables->discrete_shells->add(ps, T, p.bending);
-    return {ps, inertia, strain, bending};
+    ContactHandler contact = interactions->contact->add_triangles(ps, T, p.contact);
+    return {ps, inertia, strain, bending, contact};
 }
 Surface::VCH DeformablesPresets::add_surface_grid(const std::string& label, const std::array<double, 2>& dim, const std::array<int, 2>& sub, const Surface::Params& p)
 {
@@ -771,11 +797,18 @@ Surface::VCH DeformablesPresets::add_surface_grid(const std::string& label, cons
 }
 Volume::Handler DeformablesPresets::add_volume(const std::string& label, const std::vector<Vec3>& V, const std::vector<std::array<int, 4>>& T, const Volume::Params& p)
 {
-    // DeformablesPresets.cpp:65-79
+    // DeformablesPresets.cpp:65-79: the collision mesh is the surface of the tet mesh
     PointSetHandler ps = deformables->point_sets->add(V, label);
     auto inertia = deformables->lumped_inertia->add(ps, T, p.inertia);
     auto strain = deformables->tet_strain->add(ps, T, p.strain);
-    return {ps, inertia, strain};
+    ContactHandler contact;
+    if (interactions->contact->is_active()) {
+        std::vector<std::array<int, 3>> surface;
+        std::vector<int> tri_to_tet_map;
+        find_surface(surface, tri_to_tet_map, V, T);
+        contact = interactions->contact->add_triangles(ps, surface, tri_to_tet_map, p.contact);
+    }
+    return {ps, inertia, strain, contact};
 }
 Volume::VCH DeformablesPresets::add_volume_grid(const std::string& label, const Vec3& dim, const std::array<int, 3>& sub, const Volume::Params& p)
 {
@@ -785,13 +818,36 @@ Volume::VCH DeformablesPresets::add_volume_grid(const std::string& label, const 
     auto h = add_volume(label, V, T, p);
     return {V, T, h};
 }
+RigidBody::Handler RigidBodyPresets::add(const std::string& label, double mass, const Mat3& inertia_local, const std::vector<Vec3>& V, const std::vector<std::array<int, 3>>& T,
+                                         const EnergyFrictionalContact::Params& cp)
+{
+    // RigidBodyPresets.cpp:11-26
+    (void)label;
+    RigidBodyHandler body = rigidbodies->add(mass, inertia_local);
+    ContactHandler contact;
+    if (interactions->contact->is_active()) contact = interactions->contact->add_triangles(body, V, T, cp);
+    return {body, contact};
+}
+RigidBody::VCH RigidBodyPresets::add_box(const std::string& label, double mass, const Vec3& size, const EnergyFrictionalContact::Params& cp)
+{
+    std::vector<Vec3> V;
+    std::vector<std::array<int, 3>> T;
+    make_box(V, T, size);
+    auto h = add(label, mass, inertia_tensor_box(mass, size), V, T, cp);
+    return {V, T, h};
+}
 Simulation::Simulation(const Settings& settings) : stark(settings)
 {
-    // Simulation.cpp:84-100
+    // Simulation.cpp:84-100: deformables, rigid bodies, interactions (= registration order of DoF sets and potentials)
     auto pd = std::make_shared<PointDynamics>(stark);
+    auto rbd = std::make_shared<RigidBodyDynamics>(stark);
     deformables = std::make_shared<Deformables>(stark, pd);
+    rigidbodies = std::make_shared<RigidBodies>(stark, rbd);
+    interactions = std::make_shared<Interactions>();
+    interactions->contact = std::make_shared<EnergyFrictionalContact>(stark, pd, rbd);
     presets = std::make_shared<Presets>();
-    presets->deformables = std::make_shared<DeformablesPresets>(deformables);
+    presets->deformables = std::make_shared<DeformablesPresets>(deformables, interactions);
+    presets->rigidbodies = std::make_shared<RigidBodyPresets>(rigidbodies, interactions);
 }
 
 }  // namespace mistark

@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "../../../include/mistark.h"
+#include "../../../include/mistark_contact.h"
 #include "mesh.hpp"
 
 namespace mistark {
@@ -157,6 +158,9 @@ public:
     std::vector<int> all() const;
     Vec3 get_position(int local_index) const;
     Vec3 get_rest_position(int local_index) const;
+    // PointSetHandler.cpp:104-129 (before the first step: edits the host arrays the registration starts from)
+    PointSetHandler& add_displacement(const Vec3& displacement, bool also_at_rest_pose = true);
+    PointSetHandler& add_rotation(double angle_deg, const Vec3& axis, const Vec3& pivot = {0.0, 0.0, 0.0}, bool also_at_rest_pose = true);
 };
 
 class PointDynamics : public Registrable
@@ -178,6 +182,7 @@ public:
     Vec3 get_x1(int global_index, double dt) const { return x0[global_index] + dt * v1[global_index]; }
     void mirror_to_host();   // device -> host for x0, v0, v1 (x1 recomputed)
     void upload_state();     // host -> device after the user edited positions / velocities / forces
+    void mark_state_edited();  // host arrays were edited before/between steps: re-register (uploads them)
     void register_dofs(mistark_ctx* ctx) override;
 
 private:
@@ -334,6 +339,234 @@ private:
     std::vector<std::array<double, 4>> bergou_K;                                 // flat
 };
 
+// ---- rigid bodies ---------------------------------------------------------------------------------------------------------------------
+// stark::RigidBodyDynamics (stark/src/models/rigidbodies/RigidBodyDynamics.*): the state of the (few) bodies is kept on the host and
+// pushed to the device before every step; the solved v1 / w1 are the only values read back.
+class RigidBodyDynamics : public Registrable
+{
+public:
+    std::vector<Vec3> t0, t1, v0, v1, w0, w1, a, aa, force, torque;
+    std::vector<Quat> q0, q1, q0_;
+    std::vector<Mat3> R0, R1;
+    std::vector<std::string> labels;
+    int id_v1 = -1, id_w1 = -1, id_v0 = -1, id_w0 = -1, id_a = -1, id_aa = -1, id_force = -1, id_torque = -1, id_t0 = -1, id_q0_ = -1;
+
+    explicit RigidBodyDynamics(Stark& stark);
+    int add(const std::string& label = "");
+    int get_n_bodies() const { return (int)t0.size(); }
+    Vec3 get_x1(int rb, const Vec3& x_loc, double dt) const;  // integrate_loc_point
+    Vec3 get_d1(int rb, const Vec3& d_loc, double dt) const;  // integrate_loc_direction
+    Vec3 get_position_at(int rb, const Vec3& x_loc) const { return R1[rb] * x_loc + t1[rb]; }
+    Vec3 get_direction(int rb, const Vec3& d_loc) const { return R1[rb] * d_loc; }
+    void fetch_velocities();  // device -> host for v1, w1
+    void register_dofs(mistark_ctx* ctx) override;
+
+private:
+    Stark& stark;
+    void _before_time_step();
+    void _on_time_step_accepted();
+};
+using spRigidBodyDynamics = std::shared_ptr<RigidBodyDynamics>;
+
+// stark::EnergyRigidBodyInertia (stark/src/models/rigidbodies/EnergyRigidBodyInertia.*)
+class EnergyRigidBodyInertia : public Registrable
+{
+public:
+    std::vector<double> mass, linear_damping, angular_damping, is_quasistatic;
+    std::vector<Mat3> J_loc, J0_glob;
+    EnergyRigidBodyInertia(Stark& stark, spRigidBodyDynamics rb);
+    void add(int rb_idx, double mass, const Mat3& inertia_loc);
+    void register_potentials(mistark_ctx* ctx) override;
+
+private:
+    Stark& stark;
+    spRigidBodyDynamics rb;
+    std::vector<std::array<int32_t, 1>> conn;
+    int id_J0 = -1;
+    void _before_time_step();
+};
+
+// stark::RigidBodyHandler (stark/src/models/rigidbodies/RigidBodyHandler.*), the part scenes use
+class RigidBodyHandler
+{
+    RigidBodyDynamics* rb = nullptr;
+    EnergyRigidBodyInertia* inertia = nullptr;
+    int idx = -1;
+
+public:
+    RigidBodyHandler() = default;
+    RigidBodyHandler(RigidBodyDynamics* rb, EnergyRigidBodyInertia* inertia, int idx) : rb(rb), inertia(inertia), idx(idx) {}
+    int get_idx() const { return idx; }
+    bool is_valid() const { return rb != nullptr; }
+    Vec3 get_translation() const { return rb->t1[idx]; }
+    Quat get_quaternion() const { return rb->q1[idx]; }
+    Vec3 get_velocity() const { return rb->v1[idx]; }
+    Vec3 get_angular_velocity() const { return rb->w1[idx]; }
+    RigidBodyHandler& set_translation(const Vec3& t);
+    RigidBodyHandler& add_translation(const Vec3& t);
+    RigidBodyHandler& set_rotation(const Quat& q);
+    RigidBodyHandler& set_rotation(double angle_deg, const Vec3& axis);
+    RigidBodyHandler& add_rotation(const Quat& q);
+    RigidBodyHandler& add_rotation(double angle_deg, const Vec3& axis, const Vec3& pivot = {0.0, 0.0, 0.0});
+    RigidBodyHandler& set_velocity(const Vec3& v);
+    RigidBodyHandler& set_angular_velocity(const Vec3& w);
+    RigidBodyHandler& set_force_at_centroid(const Vec3& f);
+    RigidBodyHandler& set_torque(const Vec3& t);
+    RigidBodyHandler& set_linear_damping(double d);
+    RigidBodyHandler& set_angular_damping(double d);
+    Vec3 transform_global_to_local_point(const Vec3& x) const { return transpose(rb->R1[idx]) * (x - rb->t1[idx]); }
+    Vec3 transform_global_to_local_direction(const Vec3& d) const { return transpose(rb->R1[idx]) * d; }
+    Vec3 transform_local_to_global_point(const Vec3& x) const { return rb->R1[idx] * x + rb->t1[idx]; }
+};
+
+// stark::EnergyRigidBodyConstraints + the RigidBodyConstraints containers (EnergyRigidBodyConstraints.*, RigidBodyConstraints.h).
+// One table per constraint kind: connectivity rows {idx, a[, b]} and per-constraint parameter columns, bound in the reference's order.
+class EnergyRigidBodyConstraints : public Registrable
+{
+public:
+    enum Kind { GlobalPoints = 0, GlobalDirections, Points, PointOnAxes, Distances, DistanceLimits, Directions, AngleLimits, DampedSprings, LinearVelocity, AngularVelocity, N_KINDS };
+    struct Table
+    {
+        std::vector<std::array<int32_t, 3>> conn;      // idx, a, b (b unused for the global kinds)
+        std::vector<Vec3> v0, v1, v2;                   // up to three vector columns (meaning per kind)
+        std::vector<double> s0, s1, s2;                 // up to three scalar columns
+        std::vector<double> stiffness, tolerance, is_active;
+        bool values_dirty = false;
+    };
+    Table tables[N_KINDS];
+    double stiffness_hard_multiplier = 2.0, stiffness_soft_multiplier = 1.05, soft_constraint_capacity_hardening_point = 0.5;
+
+    EnergyRigidBodyConstraints(Stark& stark, spRigidBodyDynamics rb);
+    int add(Kind kind, int a, int b, const Vec3* vecs, int n_vecs, const double* scalars, int n_scalars, double stiffness, double tolerance);
+    void register_potentials(mistark_ctx* ctx) override;
+
+private:
+    Stark& stark;
+    spRigidBodyDynamics rb;
+    int id_stiffness[N_KINDS];
+    bool _is_converged_state_valid();
+    void _on_time_step_accepted();
+    bool _adjust_constraints_stiffness(double cap, double multiplier, bool are_positions_set);
+    void _upload_stiffness();
+};
+
+// stark::RigidBodies (stark/src/models/rigidbodies/RigidBodies.*)
+class RigidBodies
+{
+    double default_stiffness = 1e6, default_tolerance_in_m = 0.001, default_tolerance_in_deg = 1.0;
+    spRigidBodyDynamics rb;
+
+public:
+    std::shared_ptr<EnergyRigidBodyInertia> inertia;
+    std::shared_ptr<EnergyRigidBodyConstraints> constraints;
+    RigidBodies(Stark& stark, spRigidBodyDynamics rb);
+    void set_default_constraint_stiffness(double k) { default_stiffness = k; }
+    void set_default_constraint_distance_tolerance(double t) { default_tolerance_in_m = t; }
+    void set_default_constraint_angle_tolerance(double t) { default_tolerance_in_deg = t; }
+    RigidBodyHandler add(double mass, const Mat3& inertia_local);
+    RigidBodyHandler handler(int idx) { return RigidBodyHandler(rb.get(), inertia.get(), idx); }
+    // each returns the index of the (last) base constraint it created
+    int add_constraint_global_point(const RigidBodyHandler& body, const Vec3& p_glob);
+    int add_constraint_global_direction(const RigidBodyHandler& body, const Vec3& d_glob);
+    int add_constraint_point(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob);
+    int add_constraint_point_on_axis(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob, const Vec3& d_glob);
+    int add_constraint_distance(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& a_glob, const Vec3& b_glob);
+    int add_constraint_distance_limits(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& a_glob, const Vec3& b_glob, double min_distance, double max_distance);
+    int add_constraint_direction(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& d_glob);
+    int add_constraint_angle_limit(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& d_glob, double admissible_angle_deg);
+    int add_constraint_spring(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& a_glob, const Vec3& b_glob, double stiffness, double damping = 0.0);
+    int add_constraint_linear_velocity(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& d_glob, double target_v, double max_force, double delay = 0.01);
+    int add_constraint_angular_velocity(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& d_glob, double target_w, double max_abs_torque, double delay = 0.01);
+    void add_constraint_fix(const RigidBodyHandler& body);
+    void add_constraint_attachment(const RigidBodyHandler& a, const RigidBodyHandler& b);
+    void add_constraint_point_with_angle_limit(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob, const Vec3& d_glob, double admissible_angle_deg);
+    void add_constraint_hinge(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob, const Vec3& d_glob);
+    void add_constraint_hinge_with_angle_limit(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob, const Vec3& d_glob, double admissible_angle_deg);
+    void add_constraint_slider(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob, const Vec3& d_glob);
+    void add_constraint_prismatic_slider(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob, const Vec3& d_glob);
+    void add_constraint_spring_with_limits(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& a_glob, const Vec3& b_glob, double stiffness, double min_length, double max_length, double damping = 0.0);
+    void add_constraint_prismatic_press(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob, const Vec3& d_glob, double target_v, double max_force, double delay = 0.01);
+    void add_constraint_motor(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob, const Vec3& d_glob, double target_w, double max_torque, double delay = 0.01);
+};
+
+// ---- stark::EnergyFrictionalContact (stark/src/models/interactions/EnergyFrictionalContact.*) ---------------------------------------
+// Host half of the contact model: parameters, collision mesh registration, stiffness adaptation and the callbacks; detection,
+// classification and the 35 potentials' tables are the device contact module's (include/mistark_contact.h).
+class EnergyFrictionalContact : public Registrable
+{
+public:
+    struct GlobalParams
+    {
+        double default_contact_thickness = -1.0;
+        double min_contact_stiffness = 1e6, max_contact_stiffness = 1e20, friction_stick_slide_threshold = 0.1;
+        bool collisions_enabled = true, friction_enabled = true, triangle_point_enabled = true, edge_edge_enabled = true, intersection_test_enabled = true;
+    };
+    struct Params
+    {
+        double contact_thickness = 0.0;
+    };
+    struct Handler
+    {
+        EnergyFrictionalContact* model = nullptr;
+        int idx = -1;
+        int get_idx() const { return idx; }
+        bool is_valid() const { return model != nullptr; }
+        void set_contact_thickness(double t) { model->set_contact_thickness(*this, t); }
+        void set_friction(const Handler& other, double mu) { model->set_friction(*this, other, mu); }
+        void disable_collision(const Handler& other) { model->disable_collision(*this, other); }
+    };
+    EnergyFrictionalContact(Stark& stark, spPointDynamics dyn, spRigidBodyDynamics rb);
+    GlobalParams get_global_params() const { return global_params; }
+    void set_global_params(const GlobalParams& p);
+    double get_contact_stiffness() const { return contact_stiffness; }
+    Handler add_triangles(const PointSetHandler& set, const std::vector<std::array<int, 3>>& triangles, const Params& params);
+    Handler add_triangles(const PointSetHandler& set, const std::vector<std::array<int, 3>>& triangles, const std::vector<int>& point_set_map, const Params& params);
+    Handler add_edges(const PointSetHandler& set, const std::vector<std::array<int, 2>>& edges, const Params& params);
+    Handler add_triangles(const RigidBodyHandler& rb, const std::vector<Vec3>& vertices, const std::vector<std::array<int, 3>>& triangles, const Params& params);
+    void set_contact_thickness(const Handler& obj, double t);
+    void set_friction(const Handler& a, const Handler& b, double mu);
+    void disable_collision(const Handler& a, const Handler& b);
+    bool is_empty() const { return meshes.empty(); }
+    bool is_active() const { return is_initialized; }
+    int64_t last_n_contacts = 0, last_n_friction_contacts = 0, n_detections = 0;
+    void register_potentials(mistark_ctx* ctx) override;
+
+private:
+    struct Mesh
+    {
+        int kind, idx_in_ps;
+        std::vector<int32_t> verts;  // index in the physical system's vertex array
+        std::vector<std::array<int, 3>> triangles;
+        std::vector<std::array<int, 2>> edges;
+    };
+    Stark& stark;
+    spPointDynamics dyn;
+    spRigidBodyDynamics rb;
+    bool is_initialized = false;
+    GlobalParams global_params;
+    double contact_stiffness = 1e6;
+    std::vector<double> contact_thicknesses;
+    std::vector<Vec3> rigidbody_local_vertices;
+    std::vector<Mesh> meshes;
+    std::vector<std::array<double, 3>> friction_pairs;  // a, b, mu
+    std::vector<std::array<int, 2>> disabled_pairs;
+    int id_k = -1;
+    double k_uploaded = -1.0;
+    double _init_contact_thickness(double t) const;
+    void _sync_stiffness();
+    void _before_time_step();
+    void _before_energy_evaluation();
+    bool _is_intermediate_state_valid(bool is_initial_check);
+    void _on_intermediate_state_invalid();
+    void _on_time_step_accepted();
+    bool _should_continue_execution();
+};
+using ContactHandler = EnergyFrictionalContact::Handler;
+struct Interactions
+{
+    std::shared_ptr<EnergyFrictionalContact> contact;
+};
+
 // ---- stark::Deformables + presets + Simulation ---------------------------------------------------------------------------
 struct Deformables
 {
@@ -352,6 +585,7 @@ struct Params
     EnergyLumpedInertia::Params inertia;
     EnergyTriangleStrain::Params strain;
     EnergyDiscreteShells::Params bending;
+    EnergyFrictionalContact::Params contact;
     static Params Cotton_Fabric();  // stark/src/models/presets/deformables_preset_types.cpp:44-58
 };
 struct Handler
@@ -360,6 +594,7 @@ struct Handler
     EnergyLumpedInertia::Handler inertia;
     EnergyTriangleStrain::Handler strain;
     EnergyDiscreteShells::Handler bending;
+    ContactHandler contact;
 };
 struct VCH
 {
@@ -373,6 +608,7 @@ struct Params
 {
     EnergyLumpedInertia::Params inertia;
     EnergyTetStrain::Params strain;
+    EnergyFrictionalContact::Params contact;
     static Params Soft_Rubber();  // stark/src/models/presets/deformables_preset_types.cpp:70-80
 };
 struct Handler
@@ -380,6 +616,7 @@ struct Handler
     PointSetHandler point_set;
     EnergyLumpedInertia::Handler inertia;
     EnergyTetStrain::Handler strain;
+    ContactHandler contact;
 };
 struct VCH
 {
@@ -389,20 +626,48 @@ struct VCH
 };
 }  // namespace Volume
 
+namespace RigidBody {
+struct Handler
+{
+    RigidBodyHandler rigidbody;
+    ContactHandler contact;
+};
+struct VCH
+{
+    std::vector<Vec3> vertices;
+    std::vector<std::array<int, 3>> triangles;
+    Handler handler;
+};
+}  // namespace RigidBody
+
 class DeformablesPresets
 {
     std::shared_ptr<Deformables> deformables;
+    std::shared_ptr<Interactions> interactions;
 
 public:
-    explicit DeformablesPresets(std::shared_ptr<Deformables> d) : deformables(d) {}
+    DeformablesPresets(std::shared_ptr<Deformables> d, std::shared_ptr<Interactions> i) : deformables(d), interactions(i) {}
     Surface::Handler add_surface(const std::string& label, const std::vector<Vec3>& vertices, const std::vector<std::array<int, 3>>& triangles, const Surface::Params& params);
     Surface::VCH add_surface_grid(const std::string& label, const std::array<double, 2>& dim, const std::array<int, 2>& subdivisions, const Surface::Params& params);
     Volume::Handler add_volume(const std::string& label, const std::vector<Vec3>& vertices, const std::vector<std::array<int, 4>>& tets, const Volume::Params& params);
     Volume::VCH add_volume_grid(const std::string& label, const Vec3& dim, const std::array<int, 3>& subdivisions, const Volume::Params& params);
 };
+// stark::RigidBodyPresets (stark/src/models/presets/RigidBodyPresets.cpp)
+class RigidBodyPresets
+{
+    std::shared_ptr<RigidBodies> rigidbodies;
+    std::shared_ptr<Interactions> interactions;
+
+public:
+    RigidBodyPresets(std::shared_ptr<RigidBodies> r, std::shared_ptr<Interactions> i) : rigidbodies(r), interactions(i) {}
+    RigidBody::Handler add(const std::string& label, double mass, const Mat3& inertia_local, const std::vector<Vec3>& vertices, const std::vector<std::array<int, 3>>& triangles,
+                           const EnergyFrictionalContact::Params& contact = {});
+    RigidBody::VCH add_box(const std::string& label, double mass, const Vec3& size, const EnergyFrictionalContact::Params& contact = {});
+};
 struct Presets
 {
     std::shared_ptr<DeformablesPresets> deformables;
+    std::shared_ptr<RigidBodyPresets> rigidbodies;
 };
 
 class Simulation
@@ -411,6 +676,8 @@ class Simulation
 
 public:
     std::shared_ptr<Deformables> deformables;
+    std::shared_ptr<RigidBodies> rigidbodies;
+    std::shared_ptr<Interactions> interactions;
     std::shared_ptr<Presets> presets;
     explicit Simulation(const Settings& settings);
     Stark& get_stark() { return stark; }

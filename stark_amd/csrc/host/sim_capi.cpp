@@ -10,6 +10,9 @@ struct mistark_sim
 {
     std::unique_ptr<Simulation> sim;
     std::vector<PointSetHandler> sets;
+    std::vector<int> set_group;  // contact group of each point set (-1: none)
+    std::vector<RigidBodyHandler> bodies;
+    std::vector<int> body_group;
     std::string last_error;
 };
 
@@ -78,6 +81,7 @@ void mistark_sim_default_settings(mistark_sim_settings* s)
     s->device = 0;
     s->mirror_state_to_host = 1;
     s->enable_output = 0;
+    s->init_frictional_contact = 0;  // (the reference defaults to true; scenes of this facade opt in)
     s->newton = d.newton;
 }
 void mistark_volume_params_soft_rubber(mistark_volume_params* p)
@@ -132,6 +136,7 @@ int mistark_sim_create(const mistark_sim_settings* in, mistark_sim** out)
     st.execution.device = d.device;
     st.execution.mirror_state_to_host = d.mirror_state_to_host != 0;
     st.output.enable_output = d.enable_output != 0;
+    st.simulation.init_frictional_contact = d.init_frictional_contact != 0;
     st.newton = d.newton;
     auto* s = new mistark_sim();
     try {
@@ -154,6 +159,7 @@ int mistark_sim_add_volume_grid(mistark_sim* s, const char* label, const double 
     generate_tet_grid(V, T, {center[0], center[1], center[2]}, {dim[0], dim[1], dim[2]}, {sub[0], sub[1], sub[2]});
     auto h = s->sim->presets->deformables->add_volume(label ? label : "", V, T, to_cpp(*p));
     s->sets.push_back(h.point_set);
+    s->set_group.push_back(h.contact.get_idx());
     _ret = (int)s->sets.size() - 1;
     SIM_END
 }
@@ -166,6 +172,7 @@ int mistark_sim_add_volume(mistark_sim* s, const char* label, const double* v, i
     for (int64_t i = 0; i < nt; i++) T[i] = {t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]};
     auto h = s->sim->presets->deformables->add_volume(label ? label : "", V, T, to_cpp(*p));
     s->sets.push_back(h.point_set);
+    s->set_group.push_back(h.contact.get_idx());
     _ret = (int)s->sets.size() - 1;
     SIM_END
 }
@@ -174,6 +181,7 @@ int mistark_sim_add_surface_grid(mistark_sim* s, const char* label, const double
     SIM_BEGIN
     auto vch = s->sim->presets->deformables->add_surface_grid(label ? label : "", {dim[0], dim[1]}, {sub[0], sub[1]}, to_cpp(*p));
     s->sets.push_back(vch.handler.point_set);
+    s->set_group.push_back(vch.handler.contact.get_idx());
     _ret = (int)s->sets.size() - 1;
     SIM_END
 }
@@ -186,6 +194,7 @@ int mistark_sim_add_surface(mistark_sim* s, const char* label, const double* v, 
     for (int64_t i = 0; i < nt; i++) T[i] = {t[3 * i], t[3 * i + 1], t[3 * i + 2]};
     auto h = s->sim->presets->deformables->add_surface(label ? label : "", V, T, to_cpp(*p));
     s->sets.push_back(h.point_set);
+    s->set_group.push_back(h.contact.get_idx());
     _ret = (int)s->sets.size() - 1;
     SIM_END
 }
@@ -198,6 +207,179 @@ int mistark_sim_prescribe_inside_aabb(mistark_sim* s, int ps, const double c[3],
     p.tolerance = tolerance > 0.0 ? tolerance : std::numeric_limits<double>::max();
     auto h = s->sim->deformables->prescribed_positions->add_inside_aabb(s->sets[ps], {c[0], c[1], c[2]}, {d[0], d[1], d[2]}, p);
     _ret = h.get_idx();
+    SIM_END
+}
+static Vec3 v3(const double* p) { return {p[0], p[1], p[2]}; }
+static PointSetHandler& the_set(mistark_sim* s, int ps)
+{
+    if (ps < 0 || ps >= (int)s->sets.size()) throw std::runtime_error("bad point set");
+    return s->sets[ps];
+}
+static RigidBodyHandler& the_body(mistark_sim* s, int rb)
+{
+    if (rb < 0 || rb >= (int)s->bodies.size()) throw std::runtime_error("bad rigid body");
+    return s->bodies[rb];
+}
+int mistark_sim_point_set_add_displacement(mistark_sim* s, int ps, const double d[3])
+{
+    SIM_BEGIN
+    the_set(s, ps).add_displacement(v3(d));
+    SIM_END
+}
+int mistark_sim_point_set_add_rotation(mistark_sim* s, int ps, double angle_deg, const double axis[3], const double pivot[3])
+{
+    SIM_BEGIN
+    the_set(s, ps).add_rotation(angle_deg, v3(axis), pivot ? v3(pivot) : Vec3{0.0, 0.0, 0.0});
+    SIM_END
+}
+int mistark_sim_add_rigid_box(mistark_sim* s, const char* label, double mass, const double size[3])
+{
+    SIM_BEGIN
+    auto vch = s->sim->presets->rigidbodies->add_box(label ? label : "", mass, v3(size));
+    s->bodies.push_back(vch.handler.rigidbody);
+    s->body_group.push_back(vch.handler.contact.get_idx());
+    _ret = (int)s->bodies.size() - 1;
+    SIM_END
+}
+int mistark_sim_rb_set_translation(mistark_sim* s, int rb, const double t[3])
+{
+    SIM_BEGIN
+    the_body(s, rb).set_translation(v3(t));
+    SIM_END
+}
+int mistark_sim_rb_add_translation(mistark_sim* s, int rb, const double t[3])
+{
+    SIM_BEGIN
+    the_body(s, rb).add_translation(v3(t));
+    SIM_END
+}
+int mistark_sim_rb_add_rotation(mistark_sim* s, int rb, double angle_deg, const double axis[3], const double pivot[3])
+{
+    SIM_BEGIN
+    the_body(s, rb).add_rotation(angle_deg, v3(axis), pivot ? v3(pivot) : Vec3{0.0, 0.0, 0.0});
+    SIM_END
+}
+int mistark_sim_rb_set_velocity(mistark_sim* s, int rb, const double v[3], const double w[3])
+{
+    SIM_BEGIN
+    if (v) the_body(s, rb).set_velocity(v3(v));
+    if (w) the_body(s, rb).set_angular_velocity(v3(w));
+    SIM_END
+}
+int mistark_sim_rb_set_default_constraint_params(mistark_sim* s, double stiffness, double tol_m, double tol_deg)
+{
+    SIM_BEGIN
+    auto& R = *s->sim->rigidbodies;
+    if (stiffness > 0.0) R.set_default_constraint_stiffness(stiffness);
+    if (tol_m > 0.0) R.set_default_constraint_distance_tolerance(tol_m);
+    if (tol_deg > 0.0) R.set_default_constraint_angle_tolerance(tol_deg);
+    SIM_END
+}
+int mistark_sim_rb_add_constraint(mistark_sim* s, const char* type, int ia, int ib, const double* p, int n)
+{
+    SIM_BEGIN
+    auto& R = *s->sim->rigidbodies;
+    const std::string t = type ? type : "";
+    RigidBodyHandler& a = the_body(s, ia);
+    auto need = [&](int k) {
+        if (n != k) throw std::runtime_error("constraint '" + t + "' expects " + std::to_string(k) + " parameters");
+    };
+    const bool single = t == "fix" || t == "global_point" || t == "global_direction";
+    RigidBodyHandler& b = single ? a : the_body(s, ib);
+    if (t == "fix") { need(0); R.add_constraint_fix(a); }
+    else if (t == "global_point") { need(3); R.add_constraint_global_point(a, v3(p)); }
+    else if (t == "global_direction") { need(3); R.add_constraint_global_direction(a, v3(p)); }
+    else if (t == "point") { need(3); R.add_constraint_point(a, b, v3(p)); }
+    else if (t == "point_on_axis") { need(6); R.add_constraint_point_on_axis(a, b, v3(p), v3(p + 3)); }
+    else if (t == "distance") { need(6); R.add_constraint_distance(a, b, v3(p), v3(p + 3)); }
+    else if (t == "distance_limits") { need(8); R.add_constraint_distance_limits(a, b, v3(p), v3(p + 3), p[6], p[7]); }
+    else if (t == "direction") { need(3); R.add_constraint_direction(a, b, v3(p)); }
+    else if (t == "angle_limit") { need(4); R.add_constraint_angle_limit(a, b, v3(p), p[3]); }
+    else if (t == "spring") { need(8); R.add_constraint_spring(a, b, v3(p), v3(p + 3), p[6], p[7]); }
+    else if (t == "linear_velocity") { need(6); R.add_constraint_linear_velocity(a, b, v3(p), p[3], p[4], p[5]); }
+    else if (t == "angular_velocity") { need(6); R.add_constraint_angular_velocity(a, b, v3(p), p[3], p[4], p[5]); }
+    else if (t == "attachment") { need(0); R.add_constraint_attachment(a, b); }
+    else if (t == "point_with_angle_limit") { need(7); R.add_constraint_point_with_angle_limit(a, b, v3(p), v3(p + 3), p[6]); }
+    else if (t == "hinge") { need(6); R.add_constraint_hinge(a, b, v3(p), v3(p + 3)); }
+    else if (t == "hinge_with_angle_limit") { need(7); R.add_constraint_hinge_with_angle_limit(a, b, v3(p), v3(p + 3), p[6]); }
+    else if (t == "slider") { need(6); R.add_constraint_slider(a, b, v3(p), v3(p + 3)); }
+    else if (t == "prismatic_slider") { need(6); R.add_constraint_prismatic_slider(a, b, v3(p), v3(p + 3)); }
+    else if (t == "spring_with_limits") { need(10); R.add_constraint_spring_with_limits(a, b, v3(p), v3(p + 3), p[6], p[7], p[8], p[9]); }
+    else if (t == "prismatic_press") { need(9); R.add_constraint_prismatic_press(a, b, v3(p), v3(p + 3), p[6], p[7], p[8]); }
+    else if (t == "motor") { need(9); R.add_constraint_motor(a, b, v3(p), v3(p + 3), p[6], p[7], p[8]); }
+    else throw std::runtime_error("unknown rigid body constraint type '" + t + "'");
+    SIM_END
+}
+int mistark_sim_rb_get_state(mistark_sim* s, int rb, double* t, double* q, double* v, double* w)
+{
+    SIM_BEGIN
+    RigidBodyHandler& h = the_body(s, rb);
+    if (t) { const Vec3 x = h.get_translation(); std::memcpy(t, x.data(), sizeof(x)); }
+    if (q) { const Quat x = h.get_quaternion(); std::memcpy(q, x.data(), sizeof(x)); }
+    if (v) { const Vec3 x = h.get_velocity(); std::memcpy(v, x.data(), sizeof(x)); }
+    if (w) { const Vec3 x = h.get_angular_velocity(); std::memcpy(w, x.data(), sizeof(x)); }
+    SIM_END
+}
+void mistark_contact_default_global_params(mistark_contact_global_params* p)
+{
+    if (!p) return;
+    const EnergyFrictionalContact::GlobalParams d;
+    p->default_contact_thickness = d.default_contact_thickness;
+    p->min_contact_stiffness = d.min_contact_stiffness;
+    p->max_contact_stiffness = d.max_contact_stiffness;
+    p->friction_stick_slide_threshold = d.friction_stick_slide_threshold;
+    p->collisions_enabled = d.collisions_enabled;
+    p->friction_enabled = d.friction_enabled;
+    p->triangle_point_enabled = d.triangle_point_enabled;
+    p->edge_edge_enabled = d.edge_edge_enabled;
+    p->intersection_test_enabled = d.intersection_test_enabled;
+}
+int mistark_sim_set_contact_global_params(mistark_sim* s, const mistark_contact_global_params* p)
+{
+    SIM_BEGIN
+    EnergyFrictionalContact::GlobalParams g;
+    g.default_contact_thickness = p->default_contact_thickness;
+    g.min_contact_stiffness = p->min_contact_stiffness;
+    g.max_contact_stiffness = p->max_contact_stiffness;
+    g.friction_stick_slide_threshold = p->friction_stick_slide_threshold;
+    g.collisions_enabled = p->collisions_enabled != 0;
+    g.friction_enabled = p->friction_enabled != 0;
+    g.triangle_point_enabled = p->triangle_point_enabled != 0;
+    g.edge_edge_enabled = p->edge_edge_enabled != 0;
+    g.intersection_test_enabled = p->intersection_test_enabled != 0;
+    s->sim->interactions->contact->set_global_params(g);
+    SIM_END
+}
+int mistark_sim_contact_group(mistark_sim* s, int kind, int idx)
+{
+    SIM_BEGIN
+    const std::vector<int>& g = kind == 0 ? s->set_group : s->body_group;
+    if (idx < 0 || idx >= (int)g.size()) throw std::runtime_error("bad object index");
+    _ret = g[idx];
+    if (_ret < 0) throw std::runtime_error("the object has no collision mesh (frictional contact not initialised)");
+    SIM_END
+}
+static ContactHandler group_handler(mistark_sim* s, int g) { return ContactHandler{s->sim->interactions->contact.get(), g}; }
+int mistark_sim_set_friction(mistark_sim* s, int a, int b, double mu)
+{
+    SIM_BEGIN
+    s->sim->interactions->contact->set_friction(group_handler(s, a), group_handler(s, b), mu);
+    SIM_END
+}
+int mistark_sim_disable_collision(mistark_sim* s, int a, int b)
+{
+    SIM_BEGIN
+    s->sim->interactions->contact->disable_collision(group_handler(s, a), group_handler(s, b));
+    SIM_END
+}
+int mistark_sim_get_contact_info(mistark_sim* s, double* k, int64_t* n_contacts, int64_t* n_friction, int64_t* n_detections)
+{
+    SIM_BEGIN
+    auto& c = *s->sim->interactions->contact;
+    if (k) *k = c.get_contact_stiffness();
+    if (n_contacts) *n_contacts = c.last_n_contacts;
+    if (n_friction) *n_friction = c.last_n_friction_contacts;
+    if (n_detections) *n_detections = c.n_detections;
     SIM_END
 }
 int mistark_sim_set_newton_settings(mistark_sim* s, const mistark_newton_settings* ns)

@@ -11,7 +11,7 @@ from . import capi
 class SimSettings(C.Structure):
     _fields_ = [("gravity", C.c_double * 3), ("max_time_step_size", C.c_double), ("use_adaptive_time_step", C.c_int32),
                 ("time_step_size_success_multiplier", C.c_double), ("time_step_size_lower_bound", C.c_double), ("device", C.c_int32),
-                ("mirror_state_to_host", C.c_int32), ("enable_output", C.c_int32), ("newton", capi.NewtonSettings)]
+                ("mirror_state_to_host", C.c_int32), ("enable_output", C.c_int32), ("init_frictional_contact", C.c_int32), ("newton", capi.NewtonSettings)]
 
 
 class VolumeParams(C.Structure):
@@ -25,6 +25,12 @@ class SurfaceParams(C.Structure):
                 ("thickness", C.c_double), ("youngs_modulus", C.c_double), ("poissons_ratio", C.c_double), ("strain_damping", C.c_double),
                 ("strain_limit", C.c_double), ("strain_limit_stiffness", C.c_double), ("inflation", C.c_double), ("bending_stiffness", C.c_double),
                 ("bending_damping", C.c_double), ("flat_rest_angle", C.c_int32)]
+
+
+class ContactGlobalParams(C.Structure):
+    _fields_ = [("default_contact_thickness", C.c_double), ("min_contact_stiffness", C.c_double), ("max_contact_stiffness", C.c_double),
+                ("friction_stick_slide_threshold", C.c_double), ("collisions_enabled", C.c_int32), ("friction_enabled", C.c_int32),
+                ("triangle_point_enabled", C.c_int32), ("edge_edge_enabled", C.c_int32), ("intersection_test_enabled", C.c_int32)]
 
 
 class SimInfo(C.Structure):
@@ -67,6 +73,24 @@ def _lib():
         L.mistark_sim_get_info.argtypes = [p, C.POINTER(SimInfo)]
         L.mistark_sim_get_points.argtypes = [p, C.c_int, p]
         L.mistark_sim_set_points.argtypes = [p, C.c_int, p]
+        D = C.POINTER(C.c_double)
+        L.mistark_sim_point_set_add_displacement.argtypes = [p, C.c_int, D]
+        L.mistark_sim_point_set_add_rotation.argtypes = [p, C.c_int, C.c_double, D, D]
+        L.mistark_sim_add_rigid_box.argtypes = [p, C.c_char_p, C.c_double, D]
+        L.mistark_sim_rb_set_translation.argtypes = [p, C.c_int, D]
+        L.mistark_sim_rb_add_translation.argtypes = [p, C.c_int, D]
+        L.mistark_sim_rb_add_rotation.argtypes = [p, C.c_int, C.c_double, D, D]
+        L.mistark_sim_rb_set_velocity.argtypes = [p, C.c_int, D, D]
+        L.mistark_sim_rb_set_default_constraint_params.argtypes = [p, C.c_double, C.c_double, C.c_double]
+        L.mistark_sim_rb_add_constraint.argtypes = [p, C.c_char_p, C.c_int, C.c_int, D, C.c_int]
+        L.mistark_sim_rb_get_state.argtypes = [p, C.c_int, p, p, p, p]
+        L.mistark_contact_default_global_params.argtypes = [C.POINTER(ContactGlobalParams)]
+        L.mistark_contact_default_global_params.restype = None
+        L.mistark_sim_set_contact_global_params.argtypes = [p, C.POINTER(ContactGlobalParams)]
+        L.mistark_sim_contact_group.argtypes = [p, C.c_int, C.c_int]
+        L.mistark_sim_set_friction.argtypes = [p, C.c_int, C.c_int, C.c_double]
+        L.mistark_sim_disable_collision.argtypes = [p, C.c_int, C.c_int]
+        L.mistark_sim_get_contact_info.argtypes = [p, D, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _bound = True
     return L
 
@@ -86,6 +110,12 @@ def soft_rubber() -> VolumeParams:
 def cotton_fabric() -> SurfaceParams:
     p = SurfaceParams()
     _lib().mistark_surface_params_cotton_fabric(C.byref(p))
+    return p
+
+
+def contact_global_params() -> ContactGlobalParams:
+    p = ContactGlobalParams()
+    _lib().mistark_contact_default_global_params(C.byref(p))
     return p
 
 
@@ -133,6 +163,68 @@ class Simulation:
 
     def add_surface_grid(self, label, dim, subdivisions, params: SurfaceParams) -> int:
         return self._ck(self.L.mistark_sim_add_surface_grid(self.h, label.encode(), _d3(dim), _i3(subdivisions), C.byref(params)))
+
+    def add_volume(self, label, vertices, tets, params: VolumeParams) -> int:
+        v = np.ascontiguousarray(vertices, dtype=np.float64)
+        t = np.ascontiguousarray(tets, dtype=np.int32)
+        return self._ck(self.L.mistark_sim_add_volume(self.h, label.encode(), v.ctypes.data, len(v), t.ctypes.data, len(t), C.byref(params)))
+
+    def add_surface(self, label, vertices, triangles, params: SurfaceParams) -> int:
+        v = np.ascontiguousarray(vertices, dtype=np.float64)
+        t = np.ascontiguousarray(triangles, dtype=np.int32)
+        return self._ck(self.L.mistark_sim_add_surface(self.h, label.encode(), v.ctypes.data, len(v), t.ctypes.data, len(t), C.byref(params)))
+
+    def point_set_add_displacement(self, ps, d):
+        self._ck(self.L.mistark_sim_point_set_add_displacement(self.h, ps, _d3(d)))
+
+    def point_set_add_rotation(self, ps, angle_deg, axis, pivot=(0.0, 0.0, 0.0)):
+        self._ck(self.L.mistark_sim_point_set_add_rotation(self.h, ps, angle_deg, _d3(axis), _d3(pivot)))
+
+    # ---- rigid bodies ---------------------------------------------------------------------------------------------------
+    def add_rigid_box(self, label, mass, size) -> int:
+        size = (size, size, size) if np.isscalar(size) else size
+        return self._ck(self.L.mistark_sim_add_rigid_box(self.h, label.encode(), mass, _d3(size)))
+
+    def rb_set_translation(self, rb, t):
+        self._ck(self.L.mistark_sim_rb_set_translation(self.h, rb, _d3(t)))
+
+    def rb_add_translation(self, rb, t):
+        self._ck(self.L.mistark_sim_rb_add_translation(self.h, rb, _d3(t)))
+
+    def rb_add_rotation(self, rb, angle_deg, axis, pivot=(0.0, 0.0, 0.0)):
+        self._ck(self.L.mistark_sim_rb_add_rotation(self.h, rb, angle_deg, _d3(axis), _d3(pivot)))
+
+    def rb_set_default_constraint_params(self, stiffness=0.0, tolerance_in_m=0.0, tolerance_in_deg=0.0):
+        self._ck(self.L.mistark_sim_rb_set_default_constraint_params(self.h, stiffness, tolerance_in_m, tolerance_in_deg))
+
+    def rb_add_constraint(self, kind, a, b=-1, *params):
+        flat = []
+        for x in params:
+            flat.extend([float(x)] if np.isscalar(x) else [float(v) for v in x])
+        self._ck(self.L.mistark_sim_rb_add_constraint(self.h, kind.encode(), a, b, _d3(flat) if flat else None, len(flat)))
+
+    def rb_state(self, rb):
+        t, q, v, w = np.zeros(3), np.zeros(4), np.zeros(3), np.zeros(3)
+        self._ck(self.L.mistark_sim_rb_get_state(self.h, rb, t.ctypes.data, q.ctypes.data, v.ctypes.data, w.ctypes.data))
+        return t, q, v, w
+
+    # ---- frictional contact ----------------------------------------------------------------------------------------------
+    def set_contact_global_params(self, p: ContactGlobalParams):
+        self._ck(self.L.mistark_sim_set_contact_global_params(self.h, C.byref(p)))
+
+    def contact_group(self, kind, idx) -> int:
+        return self._ck(self.L.mistark_sim_contact_group(self.h, 0 if kind == "d" else 1, idx))
+
+    def set_friction(self, group_a, group_b, mu):
+        self._ck(self.L.mistark_sim_set_friction(self.h, group_a, group_b, mu))
+
+    def disable_collision(self, group_a, group_b):
+        self._ck(self.L.mistark_sim_disable_collision(self.h, group_a, group_b))
+
+    def contact_info(self):
+        k, n, nf, nd = C.c_double(), C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.L.mistark_sim_get_contact_info(self.h, C.byref(k), C.byref(n), C.byref(nf), C.byref(nd)))
+        return dict(contact_stiffness=k.value, n_contacts=n.value, n_friction_contacts=nf.value, n_detections=nd.value)
 
     def prescribe_inside_aabb(self, point_set, center, dim, stiffness, tolerance=0.0) -> int:
         return self._ck(self.L.mistark_sim_prescribe_inside_aabb(self.h, point_set, _d3(center), _d3(dim), stiffness, tolerance))

@@ -67,3 +67,69 @@ def test_cloth_scene_trajectory():
     x = sim.points("x0")
     assert np.abs(x - z["x_end"]).max() <= 1e-6 * np.abs(z["x_end"]).max()
     sim.close()
+
+
+def test_rigid_body_chain_trajectory():
+    """The rbchain scene of oracle/ref_harness.cpp (9 boxes, all 13 rigid-body potentials) through the host layer's
+    RigidBodies API: same Newton iteration counts and the same converged velocities as the reference, step by step."""
+    from stark_amd import sim as S
+
+    z, traj, man = _load("traj_rbchain")
+    st = S.default_settings()
+    st.init_frictional_contact = 0
+    sim = S.Simulation(st)
+    sim.rb_set_default_constraint_params(stiffness=1e4)
+    axis = np.array([1.0, 0.5, -0.3])
+    axis /= np.linalg.norm(axis)
+
+    def box(x, y, zz):
+        b = sim.add_rigid_box("box", 1.0 + 0.1 * x, (0.1, 0.12, 0.08))
+        sim.rb_set_translation(b, (x, y, zz))
+        sim.rb_add_rotation(b, 20.0 * x + 5.0, axis)
+        return b
+
+    def unit(v):
+        v = np.asarray(v, dtype=float)
+        return v / np.linalg.norm(v)
+
+    b0 = box(0.0, 0.0, 0.0)
+    sim.rb_add_constraint("fix", b0)
+    b1 = box(0.15, 0.0, 0.0)
+    sim.rb_add_constraint("point", b0, b1, (0.07, 0.02, 0.01))
+    b2 = box(0.30, 0.02, 0.0)
+    sim.rb_add_constraint("point_on_axis", b1, b2, (0.22, 0.0, 0.01), unit((1.0, 0.2, 0.0)))
+    b3 = box(0.45, 0.0, 0.03)
+    sim.rb_add_constraint("distance", b2, b3, (0.33, 0.0, 0.0), (0.42, 0.01, 0.02))
+    b4 = box(0.60, 0.0, 0.0)
+    sim.rb_add_constraint("distance_limits", b3, b4, (0.48, 0.0, 0.0), (0.57, 0.0, 0.0), 0.08995, 0.09005)
+    sim.rb_add_constraint("direction", b3, b4, unit((0.0, 1.0, 0.2)))
+    b5 = box(0.75, 0.0, 0.0)
+    sim.rb_add_constraint("point", b4, b5, (0.67, 0.0, 0.0))
+    sim.rb_add_constraint("angle_limit", b4, b5, (1.0, 0.0, 0.0), 0.5)
+    b6 = box(0.90, 0.0, 0.0)
+    sim.rb_add_constraint("spring", b5, b6, (0.78, 0.0, 0.0), (0.87, 0.01, 0.0), 200.0, 3.0)
+    b7 = box(1.05, 0.0, 0.0)
+    sim.rb_add_constraint("point_on_axis", b6, b7, (0.97, 0.0, 0.0), (1.0, 0.0, 0.0))
+    sim.rb_add_constraint("linear_velocity", b6, b7, (1.0, 0.0, 0.0), 0.3, 5.0, 0.05)
+    b8 = box(1.20, 0.0, 0.0)
+    sim.rb_add_constraint("hinge", b7, b8, (1.12, 0.0, 0.0), (0.0, 1.0, 0.0))
+    sim.rb_add_constraint("angular_velocity", b7, b8, (0.0, 1.0, 0.0), 1.0, 2.0, 0.1)
+
+    iterates, iter_step = z["iterates"], np.array(traj["iter_step"])
+    nb = 9
+    its = []
+    for step in range(len(traj["steps"])):
+        assert sim.run_one_step()
+        i = sim.info()
+        # the reference's first call ends with "invalid converged state" (the fix anchor sags beyond its 1 mm tolerance, the
+        # constraint stiffness is doubled and the step is redone): the recorded time after each call tells which calls advanced
+        assert abs(i.current_time - traj["steps"][step]["time"]) < 1e-12, (step, i.last_newton_result)
+        its.append(i.last_stats.newton_iterations)
+        ref = iterates[np.nonzero(iter_step == step)[0][-1]]   # last evaluation point of the step = converged DoFs
+        v_ref, w_ref = ref[:3 * nb].reshape(nb, 3), ref[3 * nb:].reshape(nb, 3)
+        v = np.array([sim.rb_state(b)[2] for b in range(nb)])
+        w = np.array([sim.rb_state(b)[3] for b in range(nb)])
+        assert np.abs(v - v_ref).max() <= 2e-5 * max(np.abs(v_ref).max(), 1e-3), step
+        assert np.abs(w - w_ref).max() <= 2e-5 * max(np.abs(w_ref).max(), 1e-3), step
+    assert its == traj["newton_iterations"]
+    sim.close()
