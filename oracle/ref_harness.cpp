@@ -27,6 +27,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <optional>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -372,8 +373,88 @@ static Scene scene_contactcorners(const Args& a)
     return sc;
 }
 
+// Hello-world of the reference's README (cfg 1) without the spin script: Cotton_Fabric cloth over a fixed rigid box
+static Scene scene_clothbox(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "clothbox");
+    settings.simulation.init_frictional_contact = true;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const int n = a.i("n", 32);
+    const double th = a.d("thickness", 0.0025), gap = a.d("gap", 0.04), mu = a.d("mu", 0.5), size = a.d("size", 0.4), bs = a.d("box", 0.08);
+    auto gp = stark::EnergyFrictionalContact::GlobalParams();
+    gp.default_contact_thickness = th;
+    gp.min_contact_stiffness = a.d("kmin", gp.min_contact_stiffness);
+    sim.interactions->contact->set_global_params(gp);
+    auto [cV, cT, cloth] = sim.presets->deformables->add_surface_grid("cloth", { size, size }, { n, n }, stark::Surface::Params::Cotton_Fabric());
+    sc.record_deformable(cloth.point_set, cT, cloth.point_set.all(), th);
+    auto [bV, bT, box] = sim.presets->rigidbodies->add_box("box", 1.0, bs);
+    sc.record_rigid(box.rigidbody, (int)bV.size(), bT, th);
+    box.rigidbody.add_translation({ 0.0, 0.0, -0.5 * bs - gap });
+    sim.rigidbodies->add_constraint_fix(box.rigidbody);
+    if (mu > 0.0) {
+        sim.interactions->contact->set_friction(cloth.contact, box.contact, mu);
+        sc.record_friction(0, 1, mu);
+    }
+    std::ostringstream js;
+    js << "{\"kind\":\"clothbox\",\"n\":" << n << ",\"thickness\":" << th << ",\"gap\":" << gap << ",\"mu\":" << mu << ",\"size\":" << size << ",\"box\":" << bs
+       << ",\"kmin\":" << gp.min_contact_stiffness << "}";
+    sc.json = js.str();
+    return sc;
+}
+
+// cfg 4: Soft_Rubber tet block dropped on a fixed rigid box, IPC contact + friction
+static Scene scene_blockbox(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "blockbox");
+    settings.simulation.init_frictional_contact = true;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const int nx = a.i("nx", 44), ny = a.i("ny", 44), nz = a.i("nz", 43);
+    const double L = a.d("L", 1.0), gap = a.d("gap", 0.05), th = a.d("thickness", 1e-3), mu = a.d("mu", 0.5), bx = a.d("bx", 3.0), bz = a.d("bz", 0.1);
+    auto gp = stark::EnergyFrictionalContact::GlobalParams();
+    gp.default_contact_thickness = th;
+    gp.min_contact_stiffness = a.d("kmin", 1e8);
+    sim.interactions->contact->set_global_params(gp);
+    // Registration order matters for friction: with the deformable registered FIRST, edge-edge friction rows take the
+    // reference's "deformable -> rigid" branch (EnergyFrictionalContact.cpp:763-766), whose barycentric pair is stored in (A, B) =
+    // (deformable, rigid) order but consumed as (rigid, deformable) (:1200-1207 with :1348-1356); the result then depends on the
+    // orientation of the collision edges, i.e. on find_surface's unordered_map iteration order. boxfirst=1 avoids that branch.
+    const bool boxfirst = a.i("boxfirst", 1) != 0;
+    auto vm = stark::Volume::Params::Soft_Rubber();
+    auto [sV, sT] = stark::generate_tet_grid({ 0.0, 0.0, 0.5 * bz + gap + 0.5 * L }, { L, L, L }, { nx, ny, nz });
+    std::optional<stark::Volume::Handler> soft_;
+    std::optional<stark::RigidBody::Handler> box_;
+    auto add_block = [&]() {
+        soft_.emplace(sim.presets->deformables->add_volume("block", sV, sT, vm));
+        auto [surf, map] = stark::find_surface(sV, sT);
+        sc.record_deformable(soft_->point_set, surf, map, th);
+    };
+    auto add_the_box = [&]() {
+        auto [bV, bT, bh] = sim.presets->rigidbodies->add_box("box", 1.0, { bx, bx, bz });
+        box_.emplace(bh);
+        sc.record_rigid(box_->rigidbody, (int)bV.size(), bT, th);
+        sim.rigidbodies->add_constraint_fix(box_->rigidbody);
+    };
+    if (boxfirst) { add_the_box(); add_block(); }
+    else { add_block(); add_the_box(); }
+    if (mu > 0.0) {
+        sim.interactions->contact->set_friction(soft_->contact, box_->contact, mu);
+        sc.record_friction(0, 1, mu);
+    }
+    std::ostringstream js;
+    js << "{\"kind\":\"blockbox\",\"nx\":" << nx << ",\"ny\":" << ny << ",\"nz\":" << nz << ",\"L\":" << L << ",\"gap\":" << gap << ",\"thickness\":" << th
+       << ",\"mu\":" << mu << ",\"bx\":" << bx << ",\"bz\":" << bz << ",\"kmin\":" << gp.min_contact_stiffness << ",\"boxfirst\":" << (boxfirst ? 1 : 0) << "}";
+    sc.json = js.str();
+    return sc;
+}
+
 static Scene make_scene(const std::string& name, const Args& a)
 {
+    if (name == "clothbox") return scene_clothbox(a);
+    if (name == "blockbox") return scene_blockbox(a);
     if (name == "contactcorners") return scene_contactcorners(a);
     if (name == "contactmix") return scene_contactmix(a);
     if (name == "rbchain") return scene_rbchain(a);

@@ -647,7 +647,7 @@ void contact_init(Context& c, const mistark_contact_arrays& arr)
             bs.push_back(mistark_binding{id, b.stride, b.col});
         }
         T.pot = register_potential(c, TABLE_NAMES[t], nullptr, 0, T.stride, bs.data(), (int)bs.size());
-        c.pots[T.pot].part = 1;
+        c.pots[T.pot].part = getenv("MISTARK_NO_SPLIT") ? 0 : 1;  // (debug switch: everything in the static part)
         T.conn.ensure(64 * (size_t)T.stride);
         c.pots[T.pot].conn_ext = T.conn.p;
         c.pots[T.pot].conn_dirty = false;
@@ -820,7 +820,6 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     if (unchanged) return n;
     // install the new row counts; buffers are (re)allocated before the routing kernel writes them
     std::vector<TableDev> td(N_TABLES);
-    bool any = false;
     for (int t = t0; t < t1; t++) {
         ContactSystem::Table& T = cs.tables[t];
         const int rows = bounds[t + 1] - bounds[t];
@@ -830,7 +829,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
         }
         Potential& P = c.pots[T.pot];
         if (rows != P.n_elem) c.layout_dirty = true;
-        any = any || rows || P.n_elem;
+        if (rows || P.n_elem) c.part[P.part].dirty = true;
         T.n = rows;
         P.n_elem = rows;
         T.conn.ensure(std::max<size_t>((size_t)rows * T.stride, 1));
@@ -842,7 +841,6 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
             }
     }
     c.layout_dirty = true;  // (conn_ext may have moved: refresh the kernels' argument blocks)
-    if (any) c.part[1].dirty = true;
     prepare(c);
     for (int t = t0; t < t1; t++) {
         ContactSystem::Table& T = cs.tables[t];

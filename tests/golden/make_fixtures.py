@@ -46,6 +46,11 @@ FIXTURES = {
     # Newton trajectories (iterates after every Newton iteration)
     "traj_tetbeam_eo_8x2x2": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=1 steps=3"),
     "traj_cloth_flat_8": ("traj", "cloth", "n=8 flat=1 eo=0 steps=3"),
+    # contact scenes (cfg 1 / cfg 4 at fixture size): cloth resting on a fixed rigid box, soft block pressed on a fixed rigid box
+    "traj_clothbox_8": ("traj", "clothbox", "n=8 gap=0.004 steps=4"),
+    "traj_blockbox_3": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=1"),
+    # block registered first, no friction (with friction this order makes the reference's result depend on an unordered_map walk)
+    "traj_blockbox_3_nofriction": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=0 mu=0"),
 }
 
 
