@@ -1,10 +1,13 @@
 #!/usr/bin/env python3
 """bench.py — Newton-steps/s and ms/linear-solve of the MI355X engine on BASELINE.json's headline workload.
 
-A "step" is ONE NEWTON ITERATION of the hot path (evaluate E/grad/element Hessians -> [project] -> assemble -> block-Jacobi
-PCG -> line search), the reference's `newton_iterations` counter (NewtonsMethod.cpp:243,249). The workload is the 1M-tet
-Neo-Hookean block of configs[3] (generate_tet_grid {44,44,43}, Soft_Rubber, full EnergyTetStrain), bottom face clamped,
-gravity; the IPC contact of that config is not part of this round's path and is named as missing in config.workload.
+A "step" is ONE NEWTON ITERATION of the hot path (contact detection -> evaluate E/grad/element Hessians -> [project] ->
+assemble -> block-Jacobi PCG -> intersection check -> line search), the reference's `newton_iterations` counter
+(NewtonsMethod.cpp:243,249). The workload is configs[3]: a 1M-tet Soft_Rubber (stable Neo-Hookean, full EnergyTetStrain)
+block generate_tet_grid{44,44,43} resting on a fixed rigid box {3,3,0.1} with IPC frictional contact (thickness 1e-3,
+mu 0.5, min contact stiffness 1e8), gravity, dt = 1/30. The block starts 1.5 mm above the box (inside the 2 mm barrier range)
+instead of SURVEY.md's 5 cm so that the barrier is active from the first Newton step of the timed region.
+`--scene clamped` runs the contact-free variant (bottom face clamped) used by earlier profiles.
 Synthetic data only. Inputs are resident in HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W         (N>1: launched by torch.distributed.run, one rank per GPU)
@@ -20,15 +23,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def build_scene(S, nx, ny, nz, device, eo=False):
+GAP, THICKNESS, MU, KMIN, BOX = 0.0015, 1e-3, 0.5, 1e8, (3.0, 3.0, 0.1)
+
+
+def build_scene(S, nx, ny, nz, device, scene="contact", eo=False):
     st = S.default_settings()
     st.device = device
     st.mirror_state_to_host = 0      # state stays in HBM between steps
+    st.init_frictional_contact = 1 if scene == "contact" else 0
     sim = S.Simulation(st)
     p = S.soft_rubber()
     p.elasticity_only = 1 if eo else 0
-    ps = sim.add_volume_grid("block", (0.0, 0.0, 0.6), (1.0, 1.0, 1.0), (nx, ny, nz), p)
-    sim.prescribe_inside_aabb(ps, (0.0, 0.0, 0.1), (2.0, 2.0, 2e-3), 1e7)
+    if scene != "contact":
+        ps = sim.add_volume_grid("block", (0.0, 0.0, 0.6), (1.0, 1.0, 1.0), (nx, ny, nz), p)
+        sim.prescribe_inside_aabb(ps, (0.0, 0.0, 0.1), (2.0, 2.0, 2e-3), 1e7)
+        return sim
+    gp = S.contact_global_params()
+    gp.default_contact_thickness = THICKNESS
+    gp.min_contact_stiffness = KMIN
+    sim.set_contact_global_params(gp)
+    # (box registered first: see oracle/ref_harness.cpp scene_blockbox on why the order matters for the reference's friction)
+    rb = sim.add_rigid_box("box", 1.0, BOX)
+    sim.rb_add_constraint("fix", rb)
+    ps = sim.add_volume_grid("block", (0.0, 0.0, 0.5 * BOX[2] + GAP + 0.5), (1.0, 1.0, 1.0), (nx, ny, nz), p)
+    sim.set_friction(sim.contact_group("d", ps), sim.contact_group("rb", rb), MU)
     return sim
 
 
@@ -55,7 +73,7 @@ def run_newton_steps(sim, S, capi, n_steps):
     return i.total_newton_iterations - n0, i.total_linear_solves - ls0, i.total_cg_iterations - cg0, i.total_linear_solve_time - tl0
 
 
-def cpu_baseline(nx, ny, nz):
+def cpu_baseline(nx, ny, nz, scene="contact"):
     """The UNMODIFIED reference (oracle/_ref/ref_harness, built by oracle/Makefile) timed on this host's cores."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     cores = os.cpu_count() or 1
@@ -63,9 +81,13 @@ def cpu_baseline(nx, ny, nz):
     if not os.path.exists(harness):
         return {"value": None, "unit": "Newton-steps/s", "cores": threads, "kind": "reference", "sample": "unavailable: oracle/_ref/ref_harness not built"}
     args = ["nx=%d" % nx, "ny=%d" % ny, "nz=%d" % nz, "threads=%d" % threads, "codegen=/tmp/mistark_bench_codegen", "outdir=/tmp/mistark_bench_out"]
+    name = "tetblock"
+    if scene == "contact":
+        name = "blockbox"
+        args += ["L=1", "gap=%g" % GAP, "thickness=%g" % THICKNESS, "mu=%g" % MU, "kmin=%g" % KMIN, "bx=%g" % BOX[0], "bz=%g" % BOX[2], "boxfirst=1"]
     try:
-        subprocess.run([harness, "prime", "tetblock", "nx=2", "ny=2", "nz=2"] + args[3:], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-        out = subprocess.run([harness, "time", "tetblock"] + args + ["steps=2", "warmup=1"], check=True, capture_output=True, timeout=900).stdout.decode()
+        subprocess.run([harness, "prime", name, "nx=2", "ny=2", "nz=2"] + args[3:], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        out = subprocess.run([harness, "time", name] + args + ["steps=2", "warmup=1"], check=True, capture_output=True, timeout=1500).stdout.decode()
         line = [l for l in out.splitlines() if l.startswith("{")][-1]
         r = json.loads(line)
         return {"value": r["newton_steps_per_s"], "unit": "Newton-steps/s", "cores": threads, "kind": "reference",
@@ -81,6 +103,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--grid", type=str, default="44,44,43", help="hexahedra per dimension (12 tets each)")
+    ap.add_argument("--scene", type=str, default="contact", choices=["contact", "clamped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
     nx, ny, nz = [int(v) for v in a.grid.split(",")]
@@ -101,7 +124,7 @@ def main():
     from stark_amd import capi
     from stark_amd import sim as S
 
-    sim = build_scene(S, nx, ny, nz, local_rank)
+    sim = build_scene(S, nx, ny, nz, local_rank, a.scene)
 
     def barrier():
         if dist is not None:
@@ -145,9 +168,11 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "tet block generate_tet_grid{%d,%d,%d} = %d tets / %d DoF, Soft_Rubber stable Neo-Hookean (full EnergyTetStrain) + lumped inertia, "
-                            "bottom face clamped, gravity, dt=1/30; IPC contact of configs[3] NOT included yet" % (nx, ny, nz, n_tets, info.ndofs),
-                "step": "one Newton iteration (eval P+g+H, assembly, block-Jacobi PCG, line search)",
+                "workload": ("configs[3]: tet block generate_tet_grid{%d,%d,%d} = %d tets / %d DoF, Soft_Rubber stable Neo-Hookean (full EnergyTetStrain) + lumped "
+                             "inertia on a fixed rigid box {3,3,0.1}, IPC barrier + lagged friction (thickness 1e-3, mu 0.5, kmin 1e8), device proximity/intersection "
+                             "detection every evaluation, gravity, dt=1/30, initial gap 1.5 mm" % (nx, ny, nz, n_tets, info.ndofs)) if a.scene == "contact" else
+                            ("tet block generate_tet_grid{%d,%d,%d} = %d tets / %d DoF, Soft_Rubber, bottom face clamped, gravity, dt=1/30, NO contact" % (nx, ny, nz, n_tets, info.ndofs)),
+                "step": "one Newton iteration (contact detection, eval P+g+H, assembly, block-Jacobi PCG, intersection check, line search)",
                 "parallelism": "single GPU" if world == 1 else "replicas x%d (no sharding yet)" % world,
                 "projection": "Progressive",
             },
@@ -155,6 +180,7 @@ def main():
             "cg_iterations_per_solve": n_cg / max(n_ls, 1),
             "linear_solves": n_ls,
             "host_timers_s": {k: round(v, 6) for k, v in stage.items()},
+            "contact": sim.contact_info() if a.scene == "contact" else None,
             "roofline": {
                 "kernel": "k_spmv (3x3-block CSR, float values, double vectors)",
                 "bound": "hbm",
@@ -169,7 +195,7 @@ def main():
             },
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nx, ny, nz)
+            out["cpu_baseline"] = cpu_baseline(nx, ny, nz, a.scene)
         else:
             out["cpu_baseline"] = {"value": None, "unit": "Newton-steps/s", "cores": 0, "kind": "reference", "sample": "skipped (N>1 or --no-cpu-baseline)"}
         print(json.dumps(out))

@@ -53,6 +53,8 @@ int mistark_contact_add_mesh(mistark_ctx* ctx, int kind, int idx_in_ps, const in
 int mistark_contact_set_friction(mistark_ctx* ctx, int group_a, int group_b, double mu);
 int mistark_contact_disable_collision(mistark_ctx* ctx, int group_a, int group_b);
 int mistark_contact_enable(mistark_ctx* ctx, int point_triangle, int edge_edge);
+/* Candidate search: 0 (default) = sweep and prune over sorted boxes, 1 = LDS-tiled all-pairs (ablation / cross-check). Same pair set. */
+int mistark_contact_set_broad_phase(mistark_ctx* ctx, int brute_force);
 
 /* Barrier tables for the positions x0 + dt v1 (v1 = the engine's current DoFs). n_contacts: total rows (nullable). */
 int mistark_contact_update(mistark_ctx* ctx, double dt, int64_t* n_contacts);

@@ -113,6 +113,7 @@ def lib():
     L.mistark_contact_set_friction.argtypes = [p, C.c_int, C.c_int, C.c_double]
     L.mistark_contact_disable_collision.argtypes = [p, C.c_int, C.c_int]
     L.mistark_contact_enable.argtypes = [p, C.c_int, C.c_int]
+    L.mistark_contact_set_broad_phase.argtypes = [p, C.c_int]
     L.mistark_contact_update.argtypes = [p, C.c_double, C.POINTER(i64)]
     L.mistark_contact_update_friction.argtypes = [p, C.POINTER(i64)]
     L.mistark_contact_count_intersections.argtypes = [p, C.c_double, C.POINTER(i64)]

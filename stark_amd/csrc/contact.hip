@@ -403,6 +403,96 @@ __global__ __launch_bounds__(CB) void k_detect_et(ContactDev d, int chunk, int* 
     if (hits) atomicAdd(&counters[1], hits);
 }
 
+// ---- sweep and prune along one axis ----------------------------------------------------------------------------------------------
+// All primitives are sorted by (class, lo[axis]) once per update; a pair of overlapping boxes is then found exactly once: by the box
+// with the smaller lo, inside the contiguous run of boxes whose lo lies in [its lo, its hi]. One WAVEFRONT walks one source box's run
+// (64 candidates per step, coalesced over the sorted copy of the boxes), so a box that spans the whole scene (a face of a large rigid
+// body) costs a long run for one wave, not a stalled lane. Same pair set as the all-pairs kernels above (kept as fallback/ablation).
+__device__ __forceinline__ uint32_t float_key(float f)
+{
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving
+}
+__global__ __launch_bounds__(CB) void k_bp_keys(ContactDev d, int axis, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+{
+    const int i = blockIdx.x * CB + threadIdx.x;
+    const int n = d.n_v + d.n_t + d.n_e;
+    if (i >= n) return;
+    const uint64_t cls = i < d.n_v ? 0 : (i < d.n_v + d.n_t ? 1 : 2);
+    keys[i] = (cls << 32) | float_key(d.aabb[6 * (size_t)i + axis]);
+    idx[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(CB) void k_bp_gather(ContactDev d, int axis, const uint32_t* __restrict__ sidx, float* __restrict__ s_aabb, float* __restrict__ s_lo)
+{
+    const int j = blockIdx.x * CB + threadIdx.x;
+    const int n = d.n_v + d.n_t + d.n_e;
+    if (j >= n) return;
+    const float* b = d.aabb + 6 * (size_t)sidx[j];
+#pragma unroll
+    for (int k = 0; k < 6; k++) s_aabb[6 * (size_t)j + k] = b[k];
+    s_lo[j] = b[axis];
+}
+__device__ __forceinline__ int lower_bound_f(const float* a, int lo, int hi, float v)  // first index with a[i] >= v
+{
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] < v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ int upper_bound_f(const float* a, int lo, int hi, float v)  // first index with a[i] > v
+{
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (a[mid] <= v) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+// MODE 0: point -> triangles, 1: triangle -> points, 2: edge -> later edges, 3: edge -> triangles (intersection), 4: triangle -> edges
+template <int MODE, bool FRICTION>
+__global__ __launch_bounds__(CB) void k_sweep(ContactDev d, int axis, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const float* __restrict__ s_lo,
+                                              double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+{
+    const int lane = threadIdx.x & 63;
+    const int w = blockIdx.x * (CB / 64) + (threadIdx.x >> 6);
+    const int p0 = 0, t0 = d.n_v, e0 = d.n_v + d.n_t, n = d.n_v + d.n_t + d.n_e;  // class segments of the sorted order
+    const int src_begin = (MODE == 0) ? p0 : ((MODE == 1 || MODE == 4) ? t0 : e0);
+    const int src_count = (MODE == 0) ? d.n_v : ((MODE == 1 || MODE == 4) ? d.n_t : d.n_e);
+    if (w >= src_count) return;
+    const int sp = src_begin + w;
+    const float* sb = s_aabb + 6 * (size_t)sp;
+    const float lo = sb[axis], hi = sb[3 + axis];
+    const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+    const float lo1 = sb[a1], hi1 = sb[3 + a1], lo2 = sb[a2], hi2 = sb[3 + a2];
+    const int tgt_begin = (MODE == 0 || MODE == 3) ? t0 : (MODE == 1 ? p0 : e0);
+    const int tgt_end = (MODE == 0 || MODE == 3) ? e0 : (MODE == 1 ? t0 : n);
+    int j0, j1;
+    if (MODE == 0 || MODE == 3) j0 = lower_bound_f(s_lo, tgt_begin, tgt_end, lo);   // target lo in [lo, hi]
+    else if (MODE == 2) j0 = sp + 1;                                                   // later edges only
+    else j0 = upper_bound_f(s_lo, tgt_begin, tgt_end, lo);                             // target lo in (lo, hi]: the other direction took lo == lo
+    j1 = upper_bound_f(s_lo, tgt_begin, tgt_end, hi);
+    const int src = (int)sidx[sp] - src_begin;  // index inside its class
+    int hits = 0;
+    for (int j = j0 + lane; j < j1; j += 64) {
+        const float* tb = s_aabb + 6 * (size_t)j;
+        if (!(lo1 <= tb[3 + a1] && tb[a1] <= hi1 && lo2 <= tb[3 + a2] && tb[a2] <= hi2)) continue;
+        const int tgt = (int)sidx[j] - tgt_begin;
+        if (MODE == 0) narrow_pt<FRICTION>(d, src, tgt, enl2, keys, counters, key_cap);
+        else if (MODE == 1) narrow_pt<FRICTION>(d, tgt, src, enl2, keys, counters, key_cap);
+        else if (MODE == 2) narrow_ee<FRICTION>(d, src < tgt ? src : tgt, src < tgt ? tgt : src, enl2, keys, counters, key_cap);
+        else {
+            const int e = MODE == 3 ? src : tgt, t = MODE == 3 ? tgt : src;
+            const int v0 = d.edge[2 * e], v1 = d.edge[2 * e + 1], u0 = d.tri[3 * t], u1 = d.tri[3 * t + 1], u2 = d.tri[3 * t + 2];
+            if (v0 == u0 || v0 == u1 || v0 == u2 || v1 == u0 || v1 == u1 || v1 == u2) continue;  // BroadPhaseET.cpp:161-165
+            if (d.disabled[d.edge_mesh[e] * d.n_mesh + d.tri_mesh[t]]) continue;
+            if (edge_intersects_triangle(ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, u0), ldx(d.X, u1), ldx(d.X, u2))) hits++;
+        }
+    }
+    if ((MODE == 3 || MODE == 4) && hits) atomicAdd(&counters[1], hits);
+}
+
 // ---- sorted keys -> tables -----------------------------------------------------------------------------------------------------------
 // bounds[t] = first sorted key of table t (t = 0..N_TABLES), same[0] = 1 iff the list equals the previous one
 __global__ __launch_bounds__(CB) void k_table_bounds(const uint64_t* __restrict__ keys, int n, const uint64_t* __restrict__ prev, int n_prev, int* __restrict__ bounds,
@@ -574,6 +664,14 @@ struct ContactSystem
     DevBuf<double> mu, X;
     DevBuf<float> aabb;
     DevBuf<uint64_t> keys, keys_alt, prev;
+    // sweep and prune
+    DevBuf<uint64_t> bp_keys, bp_keys_alt;
+    DevBuf<uint32_t> bp_idx, bp_idx_alt;
+    DevBuf<float> s_aabb, s_lo;
+    const uint32_t* s_idx = nullptr;
+    int axis = -1;
+    int64_t n_updates = 0;
+    bool brute_force = false;  // ablation / fallback: LDS-tiled all-pairs kernels
     int64_t n_prev = -1;  // keys of the barrier tables currently installed (-1: none)
     DevBuf<int> counters;  // [0] candidates, [1] intersections, [2] differs, [8..8+N_TABLES] bounds
     DevBuf<uint8_t> cub_tmp;
@@ -758,6 +856,48 @@ void update_vertices(Context& c, ContactSystem& cs, const ContactDev& d, double 
     const int np = cs.n_v + cs.n_t + cs.n_e;
     hipLaunchKernelGGL(k_contact_aabbs, dim3((np + CB - 1) / CB), dim3(CB), 0, c.stream, d, enl, cs.aabb.p);
 }
+void choose_axis(Context& c, ContactSystem& cs)
+{
+    // the axis with the largest extent of the collision vertices; re-evaluated now and then (a stale choice only costs speed)
+    if (cs.axis >= 0 && (cs.n_updates % 256) != 0) return;
+    std::vector<double> X(3 * (size_t)cs.n_v);
+    MS_CHECK(hipMemcpyAsync(X.data(), cs.X.p, X.size() * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < cs.n_v; i++)
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::min(lo[k], X[3 * (size_t)i + k]);
+            hi[k] = std::max(hi[k], X[3 * (size_t)i + k]);
+        }
+    int ax = 0;
+    for (int k = 1; k < 3; k++)
+        if (hi[k] - lo[k] > hi[ax] - lo[ax]) ax = k;
+    cs.axis = ax;
+}
+void sort_boxes(Context& c, ContactSystem& cs, const ContactDev& d)
+{
+    choose_axis(c, cs);
+    cs.n_updates++;
+    const int n = cs.n_v + cs.n_t + cs.n_e;
+    cs.bp_keys.ensure(n); cs.bp_keys_alt.ensure(n); cs.bp_idx.ensure(n); cs.bp_idx_alt.ensure(n);
+    cs.s_aabb.ensure(6 * (size_t)n); cs.s_lo.ensure(n);
+    hipLaunchKernelGGL(k_bp_keys, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.axis, cs.bp_keys.p, cs.bp_idx.p);
+    hipcub::DoubleBuffer<uint64_t> dk(cs.bp_keys.p, cs.bp_keys_alt.p);
+    hipcub::DoubleBuffer<uint32_t> dv(cs.bp_idx.p, cs.bp_idx_alt.p);
+    size_t tmp = 0;
+    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, n, 0, 34, c.stream));
+    cs.cub_tmp.ensure(tmp);
+    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(cs.cub_tmp.p, tmp, dk, dv, n, 0, 34, c.stream));
+    cs.s_idx = dv.Current();
+    hipLaunchKernelGGL(k_bp_gather, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.axis, cs.s_idx, cs.s_aabb.p, cs.s_lo.p);
+}
+template <int MODE, bool FR>
+void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, int n_src, double enl2)
+{
+    if (n_src <= 0) return;
+    hipLaunchKernelGGL((k_sweep<MODE, FR>), dim3((n_src + CB / 64 - 1) / (CB / 64)), dim3(CB), 0, c.stream, d, cs.axis, cs.s_idx, (const float*)cs.s_aabb.p, (const float*)cs.s_lo.p, enl2,
+                       cs.keys.p, cs.counters.p, (int)cs.key_cap);
+}
 // Runs detection and installs the tables [t0, t1). Returns the number of rows.
 int64_t detect_and_route(Context& c, double dt, bool friction)
 {
@@ -776,8 +916,19 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     }
     int h[64];
     int n = 0;
+    if (!cs.brute_force) sort_boxes(c, cs, d);
     for (;;) {
         MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
+        if (!cs.brute_force) {
+            if (cs.pt_enabled && cs.n_t > 0) {
+                if (friction) { launch_sweep<0, true>(c, cs, d, cs.n_v, enl * enl); launch_sweep<1, true>(c, cs, d, cs.n_t, enl * enl); }
+                else { launch_sweep<0, false>(c, cs, d, cs.n_v, enl * enl); launch_sweep<1, false>(c, cs, d, cs.n_t, enl * enl); }
+            }
+            if (cs.ee_enabled && cs.n_e > 1) {
+                if (friction) launch_sweep<2, true>(c, cs, d, cs.n_e, enl * enl);
+                else launch_sweep<2, false>(c, cs, d, cs.n_e, enl * enl);
+            }
+        } else {
         if (cs.pt_enabled && cs.n_t > 0) {
             const int chunk = chunk_for(cs.n_v, cs.n_t);
             const dim3 g((cs.n_v + CB - 1) / CB, (cs.n_t + chunk - 1) / chunk);
@@ -789,6 +940,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
             const dim3 g((cs.n_e + CB - 1) / CB, (cs.n_e + chunk - 1) / chunk);
             if (friction) hipLaunchKernelGGL(k_detect_ee<true>, g, dim3(CB), 0, c.stream, d, enl * enl, chunk, cs.keys.p, cs.counters.p, (int)cs.key_cap);
             else hipLaunchKernelGGL(k_detect_ee<false>, g, dim3(CB), 0, c.stream, d, enl * enl, chunk, cs.keys.p, cs.counters.p, (int)cs.key_cap);
+        }
         }
         MS_CHECK(hipMemcpyAsync(h, cs.counters.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
         MS_CHECK(hipStreamSynchronize(c.stream));
@@ -875,8 +1027,19 @@ int64_t count_intersections(Context& c, double dt)
     ContactDev d = dev_view(c, cs);
     update_vertices(c, cs, d, dt, 0.f);
     MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 8 * sizeof(int), c.stream));
-    const int chunk = chunk_for(cs.n_e, cs.n_t);
-    hipLaunchKernelGGL(k_detect_et, dim3((cs.n_e + CB - 1) / CB, (cs.n_t + chunk - 1) / chunk), dim3(CB), 0, c.stream, d, chunk, cs.counters.p);
+    if (!cs.brute_force) {
+        if (cs.key_cap == 0) {
+            cs.key_cap = 1 << 18;
+            cs.keys.ensure(cs.key_cap);
+            cs.keys_alt.ensure(cs.key_cap);
+        }
+        sort_boxes(c, cs, d);
+        launch_sweep<3, false>(c, cs, d, cs.n_e, 0.0);
+        launch_sweep<4, false>(c, cs, d, cs.n_t, 0.0);
+    } else {
+        const int chunk = chunk_for(cs.n_e, cs.n_t);
+        hipLaunchKernelGGL(k_detect_et, dim3((cs.n_e + CB - 1) / CB, (cs.n_t + chunk - 1) / chunk), dim3(CB), 0, c.stream, d, chunk, cs.counters.p);
+    }
     int h[2];
     MS_CHECK(hipMemcpyAsync(h, cs.counters.p, sizeof(h), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
@@ -942,6 +1105,14 @@ int mistark_contact_disable_collision(mistark_ctx* ctx, int a, int b)
     if (a < 0 || b < 0 || a >= nm || b >= nm) throw Error("contact: bad group id");
     cs.disabled_pairs.push_back({std::min(a, b), std::max(a, b)});
     cs.meshes_dirty = true;
+    cs.n_prev = -1;
+    CAPI_END(0)
+}
+int mistark_contact_set_broad_phase(mistark_ctx* ctx, int brute_force)
+{
+    CAPI_BEGIN
+    ContactSystem& cs = CS(ctx->c);
+    cs.brute_force = brute_force != 0;
     cs.n_prev = -1;
     CAPI_END(0)
 }

@@ -138,6 +138,13 @@ struct BsrPart
     DevBuf<int32_t> rowmap;         // compact row -> block row
     DevBuf<int64_t> row_ptr;        // compact rows
     DevBuf<float> vals;             // tiles of 64 blocks: float4 q0[64], float4 q1[64], float s[64]
+    DevBuf<uint32_t> long_slots;    // blocks with > LONG_SLOT contributions (summed by k_assemble_long)
+    int n_long = 0;
+    // contact part only: rows cut into chunks for k_spmv_chunks
+    int64_t n_chunks = 0;
+    DevBuf<uint32_t> row_chunk0;    // per compact row (+1): first chunk
+    DevBuf<int32_t> chunk_row;      // per chunk: compact row
+    DevBuf<double> chunk_partial;   // 3 per chunk (long rows only)
 };
 
 struct PcgCtrl

@@ -387,11 +387,7 @@ __global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ ke
         slot_start[slot] = (uint32_t)k;
         const uint64_t key = keys[k];
         const uint32_t row = (uint32_t)(key / nbr), col = (uint32_t)(key % nbr);
-        // last block of its row <=> the next distinct key belongs to another row
-        size_t k2 = k + 1;
-        while (k2 < n && keys[k2] == key) k2++;
-        const bool tail = (k2 >= n) || (uint32_t)(keys[k2] / nbr) != row;
-        colw[slot] = col | (tail ? 0x80000000u : 0u);
+        colw[slot] = col;  // (bit 31 = last block of its row is set by k_rows)
         slot_row[slot] = row;
         row_head[slot] = (k == 0 || (uint32_t)(keys[k - 1] / nbr) != row) ? 1u : 0u;
         if (row == col) diag_slot[row] = (int32_t)slot;
@@ -399,7 +395,7 @@ __global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ ke
 }
 // rscan = inclusive prefix of row_head over slots: compact row of a slot = rscan-1
 __global__ __launch_bounds__(BLOCK) void k_rows(const uint32_t* __restrict__ slot_row, const uint32_t* __restrict__ rscan, int64_t nnzb, int32_t* __restrict__ rowmap,
-                                                int64_t* __restrict__ row_ptr, int32_t* __restrict__ tile_first_row)
+                                                int64_t* __restrict__ row_ptr, int32_t* __restrict__ tile_first_row, uint32_t* __restrict__ colw)
 {
     const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (s >= nnzb) return;
@@ -412,10 +408,31 @@ __global__ __launch_bounds__(BLOCK) void k_rows(const uint32_t* __restrict__ slo
         row_ptr[crow] = s;
     }
     if (s == nnzb - 1) row_ptr[r1] = nnzb;
+    if (s == nnzb - 1 || slot_row[s + 1] != slot_row[s]) colw[s] |= 0x80000000u;  // last block of its row
     // bit 31: the previous block (last of the previous tile) belongs to the same row
     if ((s & 63) == 0) tile_first_row[s >> 6] = (int32_t)(crow | (head ? 0u : 0x80000000u));
 }
 
+constexpr int CHUNK_BLOCKS = 256;
+__global__ __launch_bounds__(BLOCK) void k_chunk_count(const int64_t* __restrict__ row_ptr, int64_t n_rows, uint32_t* __restrict__ cnt)
+{
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r > n_rows) return;
+    cnt[r] = r < n_rows ? (uint32_t)((row_ptr[r + 1] - row_ptr[r] + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS) : 0u;
+}
+__global__ __launch_bounds__(BLOCK) void k_chunk_fill(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ row_chunk0, int64_t n_rows, int32_t* __restrict__ chunk_row)
+{
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n_rows) return;
+    for (uint32_t k = row_chunk0[r]; k < row_chunk0[r + 1]; k++) chunk_row[k] = (int32_t)r;
+}
+constexpr uint32_t LONG_SLOT = 48;  // BSR blocks with more contributions than this are summed by a whole wavefront (k_assemble_long)
+__global__ __launch_bounds__(BLOCK) void k_long_slots(const uint32_t* __restrict__ slot_start, int64_t nnzb, uint32_t* __restrict__ list, int* __restrict__ count)
+{
+    const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (s >= nnzb) return;
+    if (slot_start[s + 1] - slot_start[s] > LONG_SLOT) list[atomicAdd(count, 1)] = (uint32_t)s;
+}
 // Builds the sparsity pattern of one matrix part: part 0 = potentials with fixed connectivity (+ every diagonal block, so
 // each block row exists), part 1 = potentials whose connectivity changes inside the Newton loop (contacts). Part 1 only
 // contains the block rows it touches ("compact rows", rowmap -> global row).
@@ -484,6 +501,13 @@ static void build_pattern(Context& c, int part)
     hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, (uint64_t)c.nbr, m.slot_of_src.p, (uint32_t)m.blk_base, m.colw.p, m.slot_row.p,
                        c.diag_slot[part].p, m.slot_start.p, row_head);
     m.sorted_src = sidx;
+    // blocks with very many contributions
+    m.long_slots.ensure((size_t)m.nnzb);
+    c.counters.ensure(128);
+    MS_CHECK(hipMemsetAsync(c.counters.p, 0, sizeof(int64_t), c.stream));
+    hipLaunchKernelGGL(k_long_slots, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_start.p, m.nnzb, m.long_slots.p, (int*)c.counters.p);
+    int n_long_h = 0;
+    MS_CHECK(hipMemcpyAsync(&n_long_h, c.counters.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     // compact rows
     uint32_t* rscan = m.scan.p;  // (scan is dead after k_slots)
     size_t tmp3 = 0;
@@ -494,11 +518,30 @@ static void build_pattern(Context& c, int part)
     MS_CHECK(hipMemcpyAsync(&nrows32, rscan + (m.nnzb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
     m.n_rows = nrows32;
+    m.n_long = n_long_h;  // (copied before the synchronisation above)
     m.rowmap.ensure((size_t)m.n_rows);
     m.row_ptr.ensure((size_t)m.n_rows + 1);
-    hipLaunchKernelGGL(k_rows, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_row.p, rscan, m.nnzb, m.rowmap.p, m.row_ptr.p, m.tile_first_row.p);
+    hipLaunchKernelGGL(k_rows, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_row.p, rscan, m.nnzb, m.rowmap.p, m.row_ptr.p, m.tile_first_row.p, m.colw.p);
     MS_CHECK(hipStreamSynchronize(c.stream));
     if (part == 0 && m.n_rows != c.nbr) throw Error("internal: static part must contain every block row");
+    if (part == 1) {
+        // row chunks of <= CHUNK_BLOCKS blocks for the chunked SpMV of the contact part (a rigid body in contact owns block rows
+        // with thousands of blocks; see k_spmv_chunks)
+        m.row_chunk0.ensure((size_t)m.n_rows + 1);
+        uint32_t* cnt = (uint32_t*)row_head;  // reuse
+        hipLaunchKernelGGL(k_chunk_count, dim3(grid_for(m.n_rows + 1)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, m.n_rows, cnt);
+        size_t tmp5 = 0;
+        MS_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp5, cnt, m.row_chunk0.p, (int)m.n_rows + 1, c.stream));
+        c.cub_tmp.ensure(tmp5);
+        MS_CHECK(hipcub::DeviceScan::ExclusiveSum(c.cub_tmp.p, tmp5, cnt, m.row_chunk0.p, (int)m.n_rows + 1, c.stream));
+        uint32_t nch = 0;
+        MS_CHECK(hipMemcpyAsync(&nch, m.row_chunk0.p + m.n_rows, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+        m.n_chunks = nch;
+        m.chunk_row.ensure(std::max<size_t>(nch, 1));
+        m.chunk_partial.ensure(3 * std::max<size_t>(nch, 1));
+        hipLaunchKernelGGL(k_chunk_fill, dim3(grid_for(m.n_rows)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, m.row_chunk0.p, m.n_rows, m.chunk_row.p);
+    }
 }
 
 void prepare(Context& c)
@@ -914,6 +957,30 @@ __global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __res
 // Gather assembly (default): one lane per (BSR block, component) sums the contributions of that block in the fixed order of
 // the sorted pattern keys: no atomics, deterministic, double accumulation rounded once to float; 9 consecutive lanes read the
 // 72 contiguous bytes of an element block.
+// one wavefront per long block (e.g. the diagonal block of a rigid body touched by thousands of contacts): lanes take
+// contributions k0 + lane, k0 + lane + 64, ... and the nine sums are reduced across the wave; the order is fixed by the sorted keys
+__global__ __launch_bounds__(BLOCK) void k_assemble_long(const double* __restrict__ elemH, const uint32_t* __restrict__ slot_start, const uint32_t* __restrict__ sorted_src,
+                                                        const uint32_t* __restrict__ list, int n_long, float* __restrict__ vals)
+{
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_long) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t slot = list[w];
+    const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = k0 + lane; k < k1; k += 64) {
+        const uint32_t src = sorted_src[k];
+        if (src == NO_SRC) continue;
+        const double* h = elemH + (size_t)src * 9;
+#pragma unroll
+        for (int c = 0; c < 9; c++) acc[c] += h[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const double v = wave_sum(acc[c]);
+        if (lane == 0) vals[tile_val_index(slot, c)] = (float)v;
+    }
+}
 __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restrict__ elemH, const uint32_t* __restrict__ slot_start,
                                                            const uint32_t* __restrict__ sorted_src, int64_t nnzb, float* __restrict__ vals)
 {
@@ -922,6 +989,7 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restr
     const uint32_t slot = (uint32_t)(t / 9);
     const int comp = (int)(t - (int64_t)slot * 9);
     const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1];
+    if (k1 - k0 > LONG_SLOT) return;  // k_assemble_long
     double acc = 0.0;
     for (uint32_t k = k0; k < k1; k++) {
         const uint32_t src = sorted_src[k];
@@ -946,6 +1014,8 @@ void assemble(Context& c)
             }
         } else {
             hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.nnzb, m.vals.p);
+            if (m.n_long > 0)
+                hipLaunchKernelGGL(k_assemble_long, dim3((m.n_long + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.long_slots.p, m.n_long, m.vals.p);
         }
         m.have_matrix = true;
     }
@@ -1095,6 +1165,80 @@ static int spmv_grid(const Context& c, int64_t ntiles, int max_grid)
     const int cap = std::min(c.spmv_grid_cap > 0 ? c.spmv_grid_cap : 1024, max_grid);  // 16 waves/CU measured best (profiles/)
     return (int)std::min<int64_t>(std::max<int64_t>((ntiles + 3) / 4, 1), cap);
 }
+// SpMV of the contact part: y += A_dyn x. Its block rows are short (a contact touches a handful of nodes) except the rows of rigid
+// bodies in contact, which hold one block per touching node (thousands): rows are cut into chunks of <= CHUNK_BLOCKS blocks, one
+// wavefront reduces one chunk; single-chunk rows are added to y at once, the chunks of a long row go to a scratch array that
+// k_spmv_chunks_fix sums in order (deterministic, no atomics). p . (A_dyn x) is linear in the chunks and summed right here.
+__global__ __launch_bounds__(BLOCK) void k_spmv_chunks(const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int64_t* __restrict__ row_ptr,
+                                                      const uint32_t* __restrict__ row_chunk0, const int32_t* __restrict__ chunk_row, int64_t n_chunks,
+                                                      const int32_t* __restrict__ rowmap, const double* __restrict__ x, double* __restrict__ y,
+                                                      const double* __restrict__ pdot, double* __restrict__ chunk_partial, double* __restrict__ partials,
+                                                      const PcgCtrl* __restrict__ ctrl)
+{
+    if (ctrl && ctrl->done) return;
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63;
+    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    double dot = 0.0;
+    for (int64_t ch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ch < n_chunks; ch += n_waves) {
+        const int r = chunk_row[ch];
+        const uint32_t c0 = row_chunk0[r], c1 = row_chunk0[r + 1];
+        const int64_t s0 = row_ptr[r] + (int64_t)(ch - c0) * CHUNK_BLOCKS;
+        const int64_t s1 = min(row_ptr[r + 1], s0 + (int64_t)CHUNK_BLOCKS);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int64_t s = s0 + lane; s < s1; s += 64) {
+            const size_t col = (size_t)(colw[s] & 0x7fffffffu);
+            const float* tv = vals + (size_t)(s >> 6) * 576;
+            const int l = (int)(s & 63);
+            const float4 qa = reinterpret_cast<const float4*>(tv)[l];
+            const float4 qb = reinterpret_cast<const float4*>(tv)[64 + l];
+            const float cc = tv[512 + l];
+            const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
+            a0 += (double)qa.x * x0 + (double)qa.y * x1 + (double)qa.z * x2;
+            a1 += (double)qa.w * x0 + (double)qb.x * x1 + (double)qb.y * x2;
+            a2 += (double)qb.z * x0 + (double)qb.w * x1 + (double)cc * x2;
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        a2 = wave_sum(a2);
+        if (lane == 0) {
+            const size_t rg = (size_t)rowmap[r];
+            if (c1 - c0 == 1) {
+                y[3 * rg] += a0;
+                y[3 * rg + 1] += a1;
+                y[3 * rg + 2] += a2;
+            } else {
+                chunk_partial[3 * ch] = a0;
+                chunk_partial[3 * ch + 1] = a1;
+                chunk_partial[3 * ch + 2] = a2;
+            }
+            if (pdot) dot += pdot[3 * rg] * a0 + pdot[3 * rg + 1] * a1 + pdot[3 * rg + 2] * a2;
+        }
+    }
+    if (partials) {
+        dot = block_sum(dot, sm);
+        if (threadIdx.x == 0) partials[blockIdx.x] = dot;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_spmv_chunks_fix(const uint32_t* __restrict__ row_chunk0, int64_t n_rows, const int32_t* __restrict__ rowmap,
+                                                          const double* __restrict__ chunk_partial, double* __restrict__ y, const PcgCtrl* __restrict__ ctrl)
+{
+    if (ctrl && ctrl->done) return;
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= n_rows) return;
+    const uint32_t c0 = row_chunk0[r], c1 = row_chunk0[r + 1];
+    if (c1 - c0 <= 1) return;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (uint32_t k = c0; k < c1; k++) {
+        a0 += chunk_partial[3 * (size_t)k];
+        a1 += chunk_partial[3 * (size_t)k + 1];
+        a2 += chunk_partial[3 * (size_t)k + 2];
+    }
+    const size_t rg = (size_t)rowmap[r];
+    y[3 * rg] += a0;
+    y[3 * rg + 1] += a1;
+    y[3 * rg + 2] += a2;
+}
 // y = (A_static + A_dynamic) x; partial sums of pdot . y go to partials[0 .. return value)
 template <int V>
 static int launch_spmv(Context& c, const double* x, double* y, const double* pdot, double* partials, const PcgCtrl* ctrl)
@@ -1105,9 +1249,11 @@ static int launch_spmv(Context& c, const double* x, double* y, const double* pdo
     hipLaunchKernelGGL(k_spmv_t<V>, dim3(g0), dim3(BLOCK), 0, c.stream, m0.vals.p, m0.colw.p, m0.tile_first_row.p, m0.nnzb, m0.ntiles, (const int32_t*)nullptr, 0, x, y, pdot,
                        partials, ctrl);
     if (m1.nnzb == 0) return g0;
-    const int g1 = spmv_grid(c, m1.ntiles, MAX_PARTIALS / 2);
-    hipLaunchKernelGGL(k_spmv_t<V>, dim3(g1), dim3(BLOCK), 0, c.stream, m1.vals.p, m1.colw.p, m1.tile_first_row.p, m1.nnzb, m1.ntiles, (const int32_t*)m1.rowmap.p, 1, x, y,
-                       pdot, partials ? partials + g0 : nullptr, ctrl);
+    const int g1 = (int)std::min<int64_t>(std::max<int64_t>((m1.n_chunks + 3) / 4, 1), MAX_PARTIALS / 2);
+    hipLaunchKernelGGL(k_spmv_chunks, dim3(g1), dim3(BLOCK), 0, c.stream, m1.vals.p, m1.colw.p, m1.row_ptr.p, m1.row_chunk0.p, m1.chunk_row.p, m1.n_chunks,
+                       (const int32_t*)m1.rowmap.p, x, y, pdot, m1.chunk_partial.p, partials ? partials + g0 : nullptr, ctrl);
+    hipLaunchKernelGGL(k_spmv_chunks_fix, dim3(grid_for(m1.n_rows)), dim3(BLOCK), 0, c.stream, m1.row_chunk0.p, m1.n_rows, (const int32_t*)m1.rowmap.p, m1.chunk_partial.p, y,
+                       ctrl);
     return g0 + g1;
 }
 // Micro-benchmark of the SpMV kernel on the assembled matrix: n back-to-back launches of q = A p (+ fused dot), HIP events

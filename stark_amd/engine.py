@@ -92,6 +92,9 @@ class Engine:
     def contact_disable_collision(self, a, b):
         self._ck(self.L.mistark_contact_disable_collision(self.h, a, b))
 
+    def contact_set_broad_phase(self, brute_force: bool):
+        self._ck(self.L.mistark_contact_set_broad_phase(self.h, int(brute_force)))
+
     def contact_update(self, dt) -> int:
         n = C.c_int64()
         self._ck(self.L.mistark_contact_update(self.h, dt, C.byref(n)))

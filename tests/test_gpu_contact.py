@@ -53,11 +53,13 @@ def build(name):
     return eng, prob, man, z, scene, st
 
 
+@pytest.mark.parametrize("broad_phase", ["sweep_and_prune", "all_pairs"])
 @pytest.mark.parametrize("name", CONTACT_FIXTURES)
-def test_device_tables_match_reference(name):
+def test_device_tables_match_reference(name, broad_phase):
     from stark_amd import capi
 
     eng, prob, man, z, scene, st = build(name)
+    eng.contact_set_broad_phase(broad_phase == "all_pairs")
     dt = float(np.asarray(st["dt"]).ravel()[0])
     n_fr = eng.contact_update_friction()
     n_ct = eng.contact_update(dt)
