@@ -231,6 +231,21 @@ int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n,
 /* Micro-benchmark: n back-to-back SpMV launches on the currently assembled matrix, average duration in microseconds. */
 int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us);
 
+/* ---- multi-GPU: elements of every potential sharded by contiguous ranges over `world` ranks (one engine context per GPU) ------------
+ * Energy, gradient and the assembled matrix are summed over the ranks (RCCL all-reduce on the engine's stream); the linear solve,
+ * line search and contact detection are replicated, so every rank holds the full state and runs the same host code.
+ * Call right after mistark_create, before the first evaluation. */
+int mistark_shard_range(int64_t n_elements, int rank, int world, int64_t* begin, int64_t* end); /* the contiguous range of a rank */
+int mistark_dist_unique_id(char out[128]);  /* rank 0: ncclGetUniqueId, to be broadcast by the launcher (e.g. torch.distributed) */
+int mistark_dist_init_rccl(mistark_ctx* ctx, int rank, int world, const char unique_id[128]);
+/* one-rank RCCL round trip (f64 + f32 all-reduce of `inout`) through the entry points the N-rank path uses */
+int mistark_dist_rccl_selftest(mistark_ctx* ctx, double* inout, int64_t n);
+/* the same sharded path with several contexts inside one process (one host thread per context), used by the single-GPU tests */
+typedef struct mistark_local_group mistark_local_group;
+mistark_local_group* mistark_local_group_create(int world);
+void mistark_local_group_destroy(mistark_local_group* group);
+int mistark_dist_init_local(mistark_ctx* ctx, mistark_local_group* group, int rank);
+
 #ifdef __cplusplus
 }
 #endif

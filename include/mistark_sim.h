@@ -95,6 +95,10 @@ int mistark_sim_set_friction(mistark_sim* sim, int group_a, int group_b, double 
 int mistark_sim_disable_collision(mistark_sim* sim, int group_a, int group_b);
 int mistark_sim_get_contact_info(mistark_sim* sim, double* contact_stiffness, int64_t* n_contacts, int64_t* n_friction_contacts, int64_t* n_detections);
 
+/* multi-GPU sharding (mistark.h): every rank builds the same scene, then one of these before the first step */
+int mistark_sim_set_dist_rccl(mistark_sim* sim, int rank, int world, const char unique_id[128]);
+int mistark_sim_set_dist_local(mistark_sim* sim, mistark_local_group* group, int rank, int world);
+
 /* Replace the Newton settings used by the following steps (stark::core::Settings::newton). */
 int mistark_sim_set_newton_settings(mistark_sim* sim, const mistark_newton_settings* s);
 /* Stark::run_one_step: 1 = continue, 0 = stop */

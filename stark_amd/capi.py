@@ -121,6 +121,15 @@ def lib():
     L.mistark_contact_get_friction_data.argtypes = [p, C.c_char_p, p, p, p, p, C.POINTER(C.c_int32)]
     L.mistark_contact_get_vertices.argtypes = [p, p, C.POINTER(i64)]
     L.mistark_contact_recipe.argtypes = [C.c_char_p, C.POINTER(C.c_int32), p, p, p]
+    L.mistark_shard_range.argtypes = [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
+    L.mistark_dist_unique_id.argtypes = [p]
+    L.mistark_dist_init_rccl.argtypes = [p, C.c_int, C.c_int, p]
+    L.mistark_dist_rccl_selftest.argtypes = [p, p, i64]
+    L.mistark_local_group_create.argtypes = [C.c_int]
+    L.mistark_local_group_create.restype = p
+    L.mistark_local_group_destroy.argtypes = [p]
+    L.mistark_local_group_destroy.restype = None
+    L.mistark_dist_init_local.argtypes = [p, p, C.c_int]
     L.mistark_get_bsr.argtypes = [p, C.POINTER(i64), C.POINTER(i64), p, p, p]
     L.mistark_spmv.argtypes = [p, p, p]
     L.mistark_apply_preconditioner.argtypes = [p, p, p]

@@ -2,6 +2,7 @@
 #include <algorithm>
 #include <cstring>
 
+#include "dist.hpp"
 #include "engine.hpp"
 
 using namespace mistark;
@@ -536,6 +537,87 @@ int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settin
     const int r = newton_solve(ctx->c, s, callbacks, st);
     if (stats) *stats = st;
     return r;
+    API_END(0)
+}
+
+// ---- multi-GPU -------------------------------------------------------------------------------------------------------------------
+struct mistark_local_group
+{
+    std::shared_ptr<LocalGroup> g;
+};
+int mistark_shard_range(int64_t n, int rank, int world, int64_t* begin, int64_t* end)
+{
+    if (world < 1 || rank < 0 || rank >= world || n < 0) return -1;
+    long long b, e;
+    shard_range(n, rank, world, b, e);
+    if (begin) *begin = b;
+    if (end) *end = e;
+    return 0;
+}
+int mistark_dist_unique_id(char out[128])
+{
+    try {
+        rccl_unique_id(out);
+    } catch (const std::exception&) {
+        return -1;
+    }
+    return 0;
+}
+static void set_dist(Context& c, int rank, int world, std::unique_ptr<Collective> coll)
+{
+    if (world < 1 || rank < 0 || rank >= world) throw Error("bad rank / world size");
+    c.rank = rank;
+    c.world = world;
+    c.coll = std::move(coll);
+    c.layout_dirty = true;
+    c.part[0].dirty = c.part[1].dirty = true;
+}
+int mistark_dist_init_rccl(mistark_ctx* ctx, int rank, int world, const char unique_id[128])
+{
+    API_BEGIN
+    MS_CHECK(hipSetDevice(ctx->c.device));
+    set_dist(ctx->c, rank, world, world > 1 ? make_rccl_collective(rank, world, unique_id) : nullptr);
+    API_END(0)
+}
+int mistark_dist_rccl_selftest(mistark_ctx* ctx, double* inout, int64_t n)
+{
+    // one-rank communicator through the same dlopen'ed entry points the N-rank path uses: sums `inout` with itself only
+    API_BEGIN
+    Context& c = ctx->c;
+    MS_CHECK(hipSetDevice(c.device));
+    char id[128];
+    rccl_unique_id(id);
+    std::unique_ptr<Collective> coll = make_rccl_collective(0, 1, id);
+    DevBuf<double> d;
+    DevBuf<float> f;
+    d.ensure((size_t)n);
+    f.ensure((size_t)n);
+    std::vector<float> hf((size_t)n);
+    for (int64_t i = 0; i < n; i++) hf[i] = (float)inout[i];
+    MS_CHECK(hipMemcpyAsync(d.p, inout, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    MS_CHECK(hipMemcpyAsync(f.p, hf.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, c.stream));
+    coll->allreduce_f64(d.p, (size_t)n, c.stream);
+    coll->allreduce_f32(f.p, (size_t)n, c.stream);
+    MS_CHECK(hipMemcpyAsync(inout, d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipMemcpyAsync(hf.data(), f.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    for (int64_t i = 0; i < n; i++)
+        if (hf[i] != (float)inout[i]) throw Error("RCCL self test: float and double results differ");
+    API_END(0)
+}
+mistark_local_group* mistark_local_group_create(int world)
+{
+    if (world < 1) return nullptr;
+    auto* g = new mistark_local_group();
+    g->g = std::make_shared<LocalGroup>(world);
+    return g;
+}
+void mistark_local_group_destroy(mistark_local_group* g) { delete g; }
+int mistark_dist_init_local(mistark_ctx* ctx, mistark_local_group* group, int rank)
+{
+    API_BEGIN
+    if (!group) throw Error("null group");
+    set_dist(ctx->c, rank, group->g->world, group->g->world > 1 ? make_local_collective(group->g, rank) : nullptr);
     API_END(0)
 }
 

@@ -8,6 +8,8 @@
 #include <string>
 #include <vector>
 
+#include <memory>
+
 #include "../../include/mistark.h"
 
 namespace mistark {
@@ -76,6 +78,7 @@ struct PotArgs
     const int32_t* conn;
     int conn_stride;
     int n_elem;
+    int e_begin, e_count;     // this rank's contiguous element range (multi-GPU sharding; the whole table on one GPU)
     int dof_col[MAX_NB];      // connectivity column providing the node of local DoF block k
     int dof_row_off[MAX_NB];  // first block row of the DoF set of local DoF block k
 };
@@ -147,6 +150,11 @@ struct BsrPart
     DevBuf<double> chunk_partial;   // 3 per chunk (long rows only)
 };
 
+struct SrcRange  // element blocks [k_off, k_off + nn*n_elem) of one potential, of which elements [e_begin, e_begin+e_count) are local
+{
+    uint32_t k_off, n_elem, nn, e_begin, e_count;
+};
+
 struct PcgCtrl
 {
     int done;
@@ -202,6 +210,12 @@ struct Context
     double spmv_ms_sum = 0.0;
     int64_t spmv_n = 0;
 
+    // multi-GPU: elements of every potential are sharded by contiguous ranges; E, gradient and the assembled matrix
+    // are summed over the ranks; everything else is replicated
+    int rank = 0, world = 1;
+    std::unique_ptr<struct Collective> coll;
+    DevBuf<double> dist_scalar;
+    DevBuf<SrcRange> src_ranges;
     struct ContactSystem* contact = nullptr;  // device contact detector (contact.hip), created by mistark_contact_init
 
     int last_cg_iters = 0;          // iteration count of the previous solve (first-batch predictor)

@@ -37,6 +37,12 @@ void Stark::ensure_registered()
     }
     const int rc = mistark_create(settings.execution.device, &ctx);
     if (rc != 0) throw std::runtime_error("mistark_create failed (" + std::to_string(rc) + "): no MI355X visible; the hot path has no CPU fallback");
+    if (settings.execution.world > 1) {
+        const auto& ex = settings.execution;
+        if (ex.local_group) check(mistark_dist_init_local(ctx, ex.local_group, ex.rank));
+        else if (ex.rccl_unique_id.size() == 128) check(mistark_dist_init_rccl(ctx, ex.rank, ex.world, ex.rccl_unique_id.data()));
+        else throw std::runtime_error("multi-GPU run without a communicator id");
+    }
     for (auto* m : models) m->register_dofs(ctx);
     dt_array_id = mistark_array(ctx, &dt, 1, 1);
     check(dt_array_id);

@@ -51,6 +51,10 @@ struct Settings
         double end_simulation_time = std::numeric_limits<double>::max();
         int device = 0;                   // MI355X ordinal (replaces n_threads)
         bool mirror_state_to_host = true; // refresh PointDynamics host arrays after every accepted step
+        // multi-GPU sharding (include/mistark.h "multi-GPU"): one Simulation per GPU, all built identically
+        int rank = 0, world = 1;
+        std::string rccl_unique_id;        // 128 bytes from mistark_dist_unique_id (rank 0), shared by the launcher
+        mistark_local_group* local_group = nullptr;  // in-process group instead of RCCL (tests)
     } execution;
     Settings() { mistark_newton_default_settings(&newton); }
 };

@@ -382,6 +382,27 @@ int mistark_sim_get_contact_info(mistark_sim* s, double* k, int64_t* n_contacts,
     if (n_detections) *n_detections = c.n_detections;
     SIM_END
 }
+int mistark_sim_set_dist_rccl(mistark_sim* s, int rank, int world, const char unique_id[128])
+{
+    SIM_BEGIN
+    auto& ex = s->sim->get_stark().settings.execution;
+    ex.rank = rank;
+    ex.world = world;
+    ex.rccl_unique_id.assign(unique_id, unique_id + 128);
+    ex.local_group = nullptr;
+    s->sim->get_stark().mark_registration_dirty();
+    SIM_END
+}
+int mistark_sim_set_dist_local(mistark_sim* s, mistark_local_group* group, int rank, int world)
+{
+    SIM_BEGIN
+    auto& ex = s->sim->get_stark().settings.execution;
+    ex.rank = rank;
+    ex.world = world;
+    ex.local_group = group;
+    s->sim->get_stark().mark_registration_dirty();
+    SIM_END
+}
 int mistark_sim_set_newton_settings(mistark_sim* s, const mistark_newton_settings* ns)
 {
     SIM_BEGIN

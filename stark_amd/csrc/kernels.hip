@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstring>
 
+#include "dist.hpp"
 #include "engine.hpp"
 #include "registry.hpp"
 #include "tet_closed.hpp"
@@ -95,8 +96,9 @@ __device__ __forceinline__ void gather_inputs(const PotArgs& a, int e, double* i
 template <class En>
 __global__ __launch_bounds__(BLOCK) void k_eval_p(PotArgs a, double* __restrict__ elemE)
 {
-    const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= a.n_elem) return;
+    const int le = blockIdx.x * BLOCK + threadIdx.x;
+    if (le >= a.e_count) return;
+    const int e = a.e_begin + le;
     double in[En::Layout::NIN];
     gather_inputs<En>(a, e, in);
     if (!element_active<En>(in)) {  // conditional potential, element switched off (SecondOrderCompiledPotential.cpp:185-197)
@@ -115,9 +117,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
 {
     constexpr int NB = En::NB, n = 3 * NB, NP = n * (n + 1) / 2;
     const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= (long long)a.n_elem * NP) return;
-    const int e = (int)(t / NP);
-    int rem = (int)(t - (long long)e * NP);
+    if (t >= (long long)a.e_count * NP) return;
+    const int le = (int)(t / NP);
+    const int e = a.e_begin + le;
+    int rem = (int)(t - (long long)le * NP);
     const bool first = rem == 0;
     int i = 0;
     while (rem >= n - i) {
@@ -147,8 +150,9 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
 template <class En, bool FULL, bool STORE_H>
 __global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
 {
-    const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= a.n_elem) return;
+    const int le = blockIdx.x * BLOCK + threadIdx.x;
+    if (le >= a.e_count) return;
+    const int e = a.e_begin + le;
     double in[En::Layout::NIN];
     gather_inputs<En>(a, e, in);
     double E, g[12];
@@ -166,26 +170,26 @@ __global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __
 template <class En, bool FULL>
 static void launch_tet_closed(Context& c, Potential& P, int mode)
 {
-    if (P.n_elem == 0) return;
+    if (P.args.e_count == 0) return;
     double* E = c.elemE.p + P.e_off;
     if (mode == MISTARK_EVAL_P_G)
-        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, false>), dim3(grid_for(P.n_elem)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
+        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, false>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
     else
-        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, true>), dim3(grid_for(P.n_elem)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
+        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, true>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
 }
 
 template <class En>
 static void launch_eval(Context& c, Potential& P, int mode)
 {
-    if (P.n_elem == 0) return;
+    if (P.args.e_count == 0) return;
     constexpr int n = 3 * En::NB, NP = n * (n + 1) / 2;
     double* E = c.elemE.p + P.e_off;
     if (mode == MISTARK_EVAL_P) {
-        hipLaunchKernelGGL((k_eval_p<En>), dim3(grid_for(P.n_elem)), dim3(BLOCK), 0, c.stream, P.args, E);
+        hipLaunchKernelGGL((k_eval_p<En>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E);
     } else if (mode == MISTARK_EVAL_P_G) {
-        hipLaunchKernelGGL((k_eval_pgh<En, false>), dim3(grid_for((int64_t)P.n_elem * NP)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
+        hipLaunchKernelGGL((k_eval_pgh<En, false>), dim3(grid_for((int64_t)P.args.e_count * NP)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
     } else {
-        hipLaunchKernelGGL((k_eval_pgh<En, true>), dim3(grid_for((int64_t)P.n_elem * NP)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
+        hipLaunchKernelGGL((k_eval_pgh<En, true>), dim3(grid_for((int64_t)P.args.e_count * NP)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
     }
 }
 
@@ -413,6 +417,22 @@ __global__ __launch_bounds__(BLOCK) void k_rows(const uint32_t* __restrict__ slo
     if ((s & 63) == 0) tile_first_row[s >> 6] = (int32_t)(crow | (head ? 0u : 0x80000000u));
 }
 
+// multi-GPU: element blocks of other ranks are removed from the gather lists (NO_SRC) once per pattern
+__global__ __launch_bounds__(BLOCK) void k_filter_sources(uint32_t* __restrict__ src, size_t n, const SrcRange* __restrict__ rg, int n_rg)
+{
+    const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t b = src[k];
+    if (b == NO_SRC) return;
+    for (int i = 0; i < n_rg; i++) {
+        const uint32_t span = rg[i].n_elem * rg[i].nn;
+        if (b >= rg[i].k_off && b < rg[i].k_off + span) {
+            const uint32_t e = (b - rg[i].k_off) % rg[i].n_elem;
+            if (e < rg[i].e_begin || e >= rg[i].e_begin + rg[i].e_count) src[k] = NO_SRC;
+            return;
+        }
+    }
+}
 constexpr int CHUNK_BLOCKS = 256;
 __global__ __launch_bounds__(BLOCK) void k_chunk_count(const int64_t* __restrict__ row_ptr, int64_t n_rows, uint32_t* __restrict__ cnt)
 {
@@ -501,6 +521,16 @@ static void build_pattern(Context& c, int part)
     hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, (uint64_t)c.nbr, m.slot_of_src.p, (uint32_t)m.blk_base, m.colw.p, m.slot_row.p,
                        c.diag_slot[part].p, m.slot_start.p, row_head);
     m.sorted_src = sidx;
+    if (c.world > 1) {
+        // keep only this rank's element blocks in the gather lists (the sum over ranks restores the rest)
+        std::vector<SrcRange> rg;
+        for (auto& P : c.pots)
+            if (P.part == part && P.n_elem > 0) rg.push_back({(uint32_t)P.k_off, (uint32_t)P.n_elem, (uint32_t)(P.NB * P.NB), (uint32_t)P.args.e_begin, (uint32_t)P.args.e_count});
+        c.src_ranges.ensure(std::max<size_t>(rg.size(), 1));
+        if (!rg.empty()) MS_CHECK(hipMemcpyAsync(c.src_ranges.p, rg.data(), rg.size() * sizeof(SrcRange), hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(k_filter_sources, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, (uint32_t*)sidx, nk, (const SrcRange*)c.src_ranges.p, (int)rg.size());
+        MS_CHECK(hipStreamSynchronize(c.stream));  // rg is a temporary
+    }
     // blocks with very many contributions
     m.long_slots.ensure((size_t)m.nnzb);
     c.counters.ensure(128);
@@ -560,7 +590,7 @@ void prepare(Context& c)
         c.nbr = off / 3;
         if (c.ndofs == 0) throw Error("no degrees of freedom");
         const size_t n = (size_t)c.ndofs;
-        c.u.ensure(n); c.grad.ensure(n); c.du.ensure(n); c.r.ensure(n); c.z.ensure(n); c.p.ensure(n); c.q.ensure(n); c.tmp_a.ensure(n); c.tmp_b.ensure(n);
+        c.u.ensure(n); c.grad.ensure(n + 8); c.du.ensure(n); c.r.ensure(n); c.z.ensure(n); c.p.ensure(n); c.q.ensure(n); c.tmp_a.ensure(n); c.tmp_b.ensure(n);
         c.partials.ensure(4 * MAX_PARTIALS);
         c.ctrl.ensure(1);
         c.counters.ensure(8);
@@ -609,6 +639,12 @@ void prepare(Context& c)
             A.conn = P.conn_ext ? P.conn_ext : P.conn.p;
             A.conn_stride = P.conn_stride;
             A.n_elem = P.n_elem;
+            {
+                long long b, e;
+                shard_range(P.n_elem, c.rank, c.world, b, e);
+                A.e_begin = (int)b;
+                A.e_count = (int)(e - b);
+            }
             for (size_t b = 0; b < P.bindings.size(); b++) {
                 const Array& arr = c.arrays[P.bindings[b].array];
                 A.arr[b] = arr.dev;
@@ -633,6 +669,7 @@ void prepare(Context& c)
         c.elemE.ensure(std::max<size_t>(e_off, 1));
         c.elemH.ensure(std::max<size_t>(h_off, 1));
         c.is_projected.ensure(std::max<size_t>(e_off, 1));
+        if (c.world > 1) MS_CHECK(hipMemsetAsync(c.elemE.p, 0, std::max<size_t>(e_off, 1) * sizeof(double), c.stream));  // other ranks' elements count 0
         c.dinv.ensure((size_t)c.nbr * 9);
         MS_CHECK(hipStreamSynchronize(c.stream));
         c.layout_dirty = false;
@@ -662,7 +699,15 @@ void eval(Context& c, int mode, double* E, double* grad_host)
         c.matrix_current = false;
         c.n_projected_total = 0;
     }
-    const double e = c.n_elem_total ? reduce_sum(c, c.elemE.p, (int64_t)c.n_elem_total) : 0.0;
+    double e = c.n_elem_total ? reduce_sum(c, c.elemE.p, (int64_t)c.n_elem_total) : 0.0;
+    if (c.world > 1) {
+        // one collective for the energy and the gradient: E rides behind the last DoF
+        MS_CHECK(hipMemcpyAsync(c.grad.p + c.ndofs, &e, sizeof(double), hipMemcpyHostToDevice, c.stream));
+        if (mode == MISTARK_EVAL_P) c.coll->allreduce_f64(c.grad.p + c.ndofs, 1, c.stream);
+        else c.coll->allreduce_f64(c.grad.p, (size_t)c.ndofs + 1, c.stream);
+        MS_CHECK(hipMemcpyAsync(&e, c.grad.p + c.ndofs, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+    }
     if (E) *E = e;
     if (grad_host && mode != MISTARK_EVAL_P) {
         MS_CHECK(hipMemcpyAsync(grad_host, c.grad.p, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
@@ -691,8 +736,10 @@ __device__ __forceinline__ size_t tile_val_index(uint32_t slot, int comp)
 __global__ __launch_bounds__(BLOCK) void k_project_select(int n_elem, PotArgs a, int NB, uint8_t* __restrict__ is_projected, const uint8_t* __restrict__ active_blocks,
                                                           uint32_t* __restrict__ list, int64_t* __restrict__ counters, int list_counter)
 {
-    const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= n_elem) return;
+    const int le = blockIdx.x * BLOCK + threadIdx.x;
+    if (le >= a.e_count) return;
+    const int e = a.e_begin + le;
+    (void)n_elem;
     if (is_projected[e]) return;
     if (active_blocks) {
         bool touch = false;
@@ -862,8 +909,8 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     c.proj_list.ensure(std::max<size_t>(c.n_elem_total, 1));
     for (int pi = 0; pi < np; pi++) {
         Potential& P = c.pots[pi];
-        if (P.n_elem == 0) continue;
-        hipLaunchKernelGGL(k_project_select, dim3(grid_for(P.n_elem)), dim3(BLOCK), 0, c.stream, P.n_elem, P.args, P.NB, c.is_projected.p + P.e_off, act, c.proj_list.p + P.e_off,
+        if (P.args.e_count == 0) continue;
+        hipLaunchKernelGGL(k_project_select, dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.n_elem, P.args, P.NB, c.is_projected.p + P.e_off, act, c.proj_list.p + P.e_off,
                            c.counters.p, 4 + pi);
     }
     int64_t h[128];
@@ -879,7 +926,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         double* H = c.elemH.p + P.h_off;
         const uint32_t* list = c.proj_list.p + P.e_off;
         const uint32_t* sos = c.part[P.part].slot_of_src.p + (P.k_off - c.part[P.part].blk_base);
-        float* vals = c.matrix_current ? c.part[P.part].vals.p : nullptr;
+        float* vals = (c.matrix_current && c.world == 1) ? c.part[P.part].vals.p : nullptr;  // sharded: the matrix is re-assembled (summed over ranks)
         const dim3 g((nl + 3) / 4), b(BLOCK);
         switch (P.NB) {
             case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
@@ -894,6 +941,16 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         }
     }
     c.n_projected_total += total;
+    if (c.world > 1) {
+        // every rank must take the same decision: has ANY rank changed element Hessians?
+        double flag = total > 0 ? 1.0 : 0.0;
+        c.dist_scalar.ensure(8);
+        MS_CHECK(hipMemcpyAsync(c.dist_scalar.p, &flag, sizeof(double), hipMemcpyHostToDevice, c.stream));
+        c.coll->allreduce_f64(c.dist_scalar.p, 1, c.stream);
+        MS_CHECK(hipMemcpyAsync(&flag, c.dist_scalar.p, sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+        if (flag > 0.0) c.matrix_current = false;
+    }
     if (n_projected_now) *n_projected_now = total;
     if (n_changed_now) {
         int64_t h2[2];
@@ -1005,7 +1062,7 @@ void assemble(Context& c)
     for (int part = 0; part < 2; part++) {
         BsrPart& m = c.part[part];
         if (m.nnzb == 0) continue;
-        if (c.atomic_assembly) {
+        if (c.atomic_assembly && c.world == 1) {
             MS_CHECK(hipMemsetAsync(m.vals.p, 0, (size_t)m.ntiles * 576 * sizeof(float), c.stream));
             for (auto& P : c.pots) {
                 const int64_t nblk = (int64_t)P.n_elem * P.NB * P.NB;
@@ -1017,6 +1074,7 @@ void assemble(Context& c)
             if (m.n_long > 0)
                 hipLaunchKernelGGL(k_assemble_long, dim3((m.n_long + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.long_slots.p, m.n_long, m.vals.p);
         }
+        if (c.world > 1) c.coll->allreduce_f32(m.vals.p, (size_t)m.ntiles * 576, c.stream);
         m.have_matrix = true;
     }
     c.have_matrix = true;

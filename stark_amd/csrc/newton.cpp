@@ -121,7 +121,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                     default: throw Error("unknown projection mode");
                 }
             }
-            if (reassemble) {
+            if (reassemble || !c.matrix_current) {  // (sharded runs cannot patch the summed matrix in place)
                 Timer t(st.t_assembly);
                 assemble(c);
                 assembled = true;

@@ -73,6 +73,14 @@ class Engine:
         conn = np.ascontiguousarray(conn, dtype=np.int32)
         self._ck(self.L.mistark_potential_update_connectivity(self.h, pid, conn.ctypes.data if conn.size else None, conn.shape[0]))
 
+    # ---- multi-GPU sharding ------------------------------------------------------------------------------------------------
+    def dist_init_local(self, group, rank: int):
+        self._ck(self.L.mistark_dist_init_local(self.h, group, rank))
+
+    def dist_init_rccl(self, rank: int, world: int, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        self._ck(self.L.mistark_dist_init_rccl(self.h, rank, world, buf))
+
     # ---- device contact detector (include/mistark_contact.h) ----------------------------------------------------------------
     def contact_init(self, **array_ids):
         """array_ids: engine array ids by role (capi.CONTACT_ROLES); absent roles are -1."""

@@ -90,6 +90,8 @@ def _lib():
         L.mistark_sim_contact_group.argtypes = [p, C.c_int, C.c_int]
         L.mistark_sim_set_friction.argtypes = [p, C.c_int, C.c_int, C.c_double]
         L.mistark_sim_disable_collision.argtypes = [p, C.c_int, C.c_int]
+        L.mistark_sim_set_dist_rccl.argtypes = [p, C.c_int, C.c_int, p]
+        L.mistark_sim_set_dist_local.argtypes = [p, p, C.c_int, C.c_int]
         L.mistark_sim_get_contact_info.argtypes = [p, D, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _bound = True
     return L
@@ -207,6 +209,14 @@ class Simulation:
         t, q, v, w = np.zeros(3), np.zeros(4), np.zeros(3), np.zeros(3)
         self._ck(self.L.mistark_sim_rb_get_state(self.h, rb, t.ctypes.data, q.ctypes.data, v.ctypes.data, w.ctypes.data))
         return t, q, v, w
+
+    # ---- multi-GPU sharding ------------------------------------------------------------------------------------------------
+    def set_dist_rccl(self, rank, world, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        self._ck(self.L.mistark_sim_set_dist_rccl(self.h, rank, world, buf))
+
+    def set_dist_local(self, group, rank, world):
+        self._ck(self.L.mistark_sim_set_dist_local(self.h, group, rank, world))
 
     # ---- frictional contact ----------------------------------------------------------------------------------------------
     def set_contact_global_params(self, p: ContactGlobalParams):

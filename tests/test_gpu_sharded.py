@@ -1,0 +1,150 @@
+"""GPU: the multi-GPU path (elements sharded by contiguous ranges, E / gradient / matrix summed over the ranks, replicated solve)
+run with several engine contexts in ONE process on one MI355X (in-process collective, one host thread per rank): every rank must
+reproduce the single-rank results. The RCCL transport differs only in how the sum is carried (tests/test_dist_cpu.py covers the
+partition arithmetic with gloo on CPU)."""
+import json
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from oracle import evaluator as ev  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def run_ranks(world, fn):
+    """fn(rank) in one thread per rank; returns the list of results (re-raises the first exception)."""
+    out, err = [None] * world, [None] * world
+
+    def work(r):
+        try:
+            out[r] = fn(r)
+        except BaseException as e:  # noqa: BLE001
+            err[r] = e
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", ["tetbeam_full_4x1x1", "cloth_shells_6", "contactmix_t1", "rbchain"])
+def test_sharded_stages_equal_single_rank(name, world):
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    x = np.sin(0.37 * np.arange(man["ndofs"]))
+
+    def stages(eng):
+        E, g = eng.eval(capi.EVAL_P_G_H)
+        Ep, _ = eng.eval(capi.EVAL_P)
+        eng.eval(capi.EVAL_P_G_H)
+        eng.assemble()
+        y = eng.spmv(x)
+        eng.project(1e-10)                       # every element Hessian to PSD, matrix re-assembled below
+        eng.assemble()
+        y2 = eng.spmv(x)
+        du, info = eng.pcg(1e-8, 1e-6, 5000)
+        return dict(E=E, Ep=Ep, g=g, y=y, y2=y2, du=du, its=info.n_iterations, conv=info.converged)
+
+    single = engine_from_problem(prob, man)
+    ref = stages(single)
+    single.close()
+    L = capi.lib()
+    group = L.mistark_local_group_create(world)
+
+    def rank_fn(r):
+        eng = engine_from_problem(prob, man)
+        eng.dist_init_local(group, r)
+        res = stages(eng)
+        eng.close()
+        return res
+
+    res = run_ranks(world, rank_fn)
+    L.mistark_local_group_destroy(group)
+    gs = max(np.abs(ref["g"]).max(), 1e-300)
+    for r in res:
+        assert abs(r["E"] - ref["E"]) <= 1e-12 * max(1.0, abs(ref["E"])) and abs(r["Ep"] - ref["Ep"]) <= 1e-12 * max(1.0, abs(ref["Ep"]))
+        assert np.abs(r["g"] - ref["g"]).max() <= 1e-12 * gs
+        # the matrix is a float sum of per-rank float partial sums instead of one rounding: last-bit differences
+        assert np.abs(r["y"] - ref["y"]).max() <= 2e-6 * np.abs(ref["y"]).max()
+        assert np.abs(r["y2"] - ref["y2"]).max() <= 2e-6 * np.abs(ref["y2"]).max()
+        assert r["conv"] == ref["conv"] and abs(r["its"] - ref["its"]) <= 2
+        assert np.abs(r["du"] - ref["du"]).max() <= 1e-4 * max(np.abs(ref["du"]).max(), 1e-300)
+    # the replicated parts rely on every rank holding the SAME bits
+    for r in res[1:]:
+        assert r["E"] == res[0]["E"] and (r["g"] == res[0]["g"]).all() and (r["y"] == res[0]["y"]).all() and (r["du"] == res[0]["du"]).all()
+
+
+def test_sharded_contact_scene_trajectory():
+    """The block-on-box contact scene (device detection, friction, rigid body) stepped by two ranks: same Newton iteration counts
+    and end state as the reference trajectory, identical on both ranks."""
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    z = np.load(os.path.join(GOLDEN, "traj_blockbox_3.npz"))
+    traj = json.loads(bytes(z["traj_json"]).decode())
+    sc = traj["scene"]
+    world = 2
+    L = capi.lib()
+    group = L.mistark_local_group_create(world)
+
+    def rank_fn(r):
+        st = S.default_settings()
+        st.init_frictional_contact = 1
+        sim = S.Simulation(st)
+        gp = S.contact_global_params()
+        gp.default_contact_thickness = sc["thickness"]
+        gp.min_contact_stiffness = sc["kmin"]
+        sim.set_contact_global_params(gp)
+        rb = sim.add_rigid_box("box", 1.0, (sc["bx"], sc["bx"], sc["bz"]))
+        sim.rb_add_constraint("fix", rb)
+        Lb = sc["L"]
+        ps = sim.add_volume_grid("block", (0.0, 0.0, 0.5 * sc["bz"] + sc["gap"] + 0.5 * Lb), (Lb, Lb, Lb), (sc["nx"], sc["ny"], sc["nz"]), S.soft_rubber())
+        sim.set_friction(sim.contact_group("d", ps), sim.contact_group("rb", rb), sc["mu"])
+        sim.set_dist_local(group, r, world)
+        its = []
+        for _ in traj["steps"]:
+            assert sim.run_one_step()
+            its.append(sim.info().last_stats.newton_iterations)
+        x = sim.points("x0")
+        sim.close()
+        return its, x
+
+    res = run_ranks(world, rank_fn)
+    L.mistark_local_group_destroy(group)
+    for its, x in res:
+        assert its == traj["newton_iterations"]
+        assert np.abs(x - z["x_end"]).max() <= 1e-4 * np.abs(z["x_end"]).max()
+    assert (res[0][1] == res[1][1]).all()
+
+
+def test_rccl_transport_single_rank_roundtrip():
+    """The RCCL entry points (dlopen'ed librccl: unique id, communicator, f64 / f32 sum all-reduce on the engine's stream) on the one GPU
+    of the test box: a one-rank communicator must return its input."""
+    import ctypes as C
+
+    import stark_amd
+
+    eng = stark_amd.Engine(0)
+    x = np.linspace(-3.0, 5.0, 1000)
+    y = x.copy()
+    assert eng.L.mistark_dist_rccl_selftest(eng.h, y.ctypes.data, len(y)) == 0, eng.L.mistark_last_error(eng.h)
+    assert (x == y).all()
+    buf = C.create_string_buffer(128)
+    assert eng.L.mistark_dist_unique_id(buf) == 0 and any(b != 0 for b in buf.raw)
+    eng.close()
