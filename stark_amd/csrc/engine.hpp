@@ -148,6 +148,8 @@ struct BsrPart
     DevBuf<uint32_t> row_chunk0;    // per compact row (+1): first chunk
     DevBuf<int32_t> chunk_row;      // per chunk: compact row
     DevBuf<double> chunk_partial;   // 3 per chunk (long rows only)
+    DevBuf<double> yd;              // 3 per compact row: A_dyn x of single-chunk rows
+    DevBuf<int32_t> crow_of_row;    // block row -> compact row of this part, -1 if absent
 };
 
 struct SrcRange  // element blocks [k_off, k_off + nn*n_elem) of one potential, of which elements [e_begin, e_begin+e_count) are local

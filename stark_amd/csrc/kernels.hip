@@ -434,6 +434,11 @@ __global__ __launch_bounds__(BLOCK) void k_filter_sources(uint32_t* __restrict__
     }
 }
 constexpr int CHUNK_BLOCKS = 256;
+__global__ __launch_bounds__(BLOCK) void k_crow_of_row(const int32_t* __restrict__ rowmap, int64_t n_rows, int32_t* __restrict__ crow_of_row)
+{
+    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r < n_rows) crow_of_row[rowmap[r]] = (int32_t)r;
+}
 __global__ __launch_bounds__(BLOCK) void k_chunk_count(const int64_t* __restrict__ row_ptr, int64_t n_rows, uint32_t* __restrict__ cnt)
 {
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -569,6 +574,10 @@ static void build_pattern(Context& c, int part)
         MS_CHECK(hipStreamSynchronize(c.stream));
         m.n_chunks = nch;
         m.chunk_row.ensure(std::max<size_t>(nch, 1));
+        m.yd.ensure(3 * std::max<size_t>((size_t)m.n_rows, 1));
+        m.crow_of_row.ensure((size_t)c.nbr);
+        MS_CHECK(hipMemsetAsync(m.crow_of_row.p, 0xFF, (size_t)c.nbr * sizeof(int32_t), c.stream));
+        hipLaunchKernelGGL(k_crow_of_row, dim3(grid_for(m.n_rows)), dim3(BLOCK), 0, c.stream, m.rowmap.p, m.n_rows, m.crow_of_row.p);
         m.chunk_partial.ensure(3 * std::max<size_t>(nch, 1));
         hipLaunchKernelGGL(k_chunk_fill, dim3(grid_for(m.n_rows)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, m.row_chunk0.p, m.n_rows, m.chunk_row.p);
     }
@@ -1105,7 +1114,7 @@ __device__ __forceinline__ double dpp_row_shr(double v)
     return __hiloint2double(hi, lo);
 }
 template <int V>
-__global__ __launch_bounds__(BLOCK) void k_spmv_t(const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int32_t* __restrict__ tile_first_row, int64_t nnzb,
+__device__ __forceinline__ void spmv_static(const int bid, const int nblk, const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int32_t* __restrict__ tile_first_row, int64_t nnzb,
                                                 int64_t ntiles, const int32_t* __restrict__ rowmap, int accumulate, const double* __restrict__ x, double* __restrict__ y,
                                                 const double* __restrict__ pdot, double* __restrict__ partials, const PcgCtrl* __restrict__ ctrl)
 {
@@ -1120,9 +1129,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_t(const float* __restrict__ vals
     // straddles two tiles of the range is carried in registers; for the first row of the range, which usually began in the
     // previous wavefront's last tile, that tile is re-read as a "ghost" (only its trailing open segment is used) and the
     // previous wavefront drops its open tail. Every row is written exactly once: no atomics, no zero-fill, deterministic.
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t n_waves = (int64_t)nblk * 4;
     const int64_t tpw = (ntiles + n_waves - 1) / n_waves;
-    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t gw = (int64_t)bid * 4 + wave;
     const int64_t t_begin = gw * tpw, t_end = (t_begin + tpw < ntiles) ? t_begin + tpw : ntiles;
     int64_t t_lead = t_begin;
     if (t_begin < t_end) {
@@ -1214,7 +1223,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_t(const float* __restrict__ vals
     }
     if (partials) {
         acc = block_sum(acc, sm);
-        if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+        if (threadIdx.x == 0) partials[bid] = acc;
     }
 }
 
@@ -1227,26 +1236,34 @@ static int spmv_grid(const Context& c, int64_t ntiles, int max_grid)
 // bodies in contact, which hold one block per touching node (thousands): rows are cut into chunks of <= CHUNK_BLOCKS blocks, one
 // wavefront reduces one chunk; single-chunk rows are added to y at once, the chunks of a long row go to a scratch array that
 // k_spmv_chunks_fix sums in order (deterministic, no atomics). p . (A_dyn x) is linear in the chunks and summed right here.
-__global__ __launch_bounds__(BLOCK) void k_spmv_chunks(const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int64_t* __restrict__ row_ptr,
-                                                      const uint32_t* __restrict__ row_chunk0, const int32_t* __restrict__ chunk_row, int64_t n_chunks,
-                                                      const int32_t* __restrict__ rowmap, const double* __restrict__ x, double* __restrict__ y,
-                                                      const double* __restrict__ pdot, double* __restrict__ chunk_partial, double* __restrict__ partials,
-                                                      const PcgCtrl* __restrict__ ctrl)
+struct DynPart  // the contact part as the fused SpMV kernel sees it
 {
-    if (ctrl && ctrl->done) return;
+    const float* vals;
+    const uint32_t* colw;
+    const int64_t* row_ptr;
+    const uint32_t* row_chunk0;
+    const int32_t* chunk_row;
+    const int32_t* rowmap;
+    double* yd;             // 3 per compact row (rows with a single chunk)
+    double* chunk_partial;  // 3 per chunk (rows with several chunks)
+    int64_t n_chunks;
+};
+__device__ __forceinline__ void spmv_chunks(const int bid, const int nblk, const DynPart& d, const double* __restrict__ x, const double* __restrict__ pdot,
+                                            double* __restrict__ partials)
+{
     __shared__ double sm[4];
     const int lane = threadIdx.x & 63;
-    const int64_t n_waves = (int64_t)gridDim.x * 4;
+    const int64_t n_waves = (int64_t)nblk * 4;
     double dot = 0.0;
-    for (int64_t ch = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); ch < n_chunks; ch += n_waves) {
-        const int r = chunk_row[ch];
-        const uint32_t c0 = row_chunk0[r], c1 = row_chunk0[r + 1];
-        const int64_t s0 = row_ptr[r] + (int64_t)(ch - c0) * CHUNK_BLOCKS;
-        const int64_t s1 = min(row_ptr[r + 1], s0 + (int64_t)CHUNK_BLOCKS);
+    for (int64_t ch = (int64_t)bid * 4 + (threadIdx.x >> 6); ch < d.n_chunks; ch += n_waves) {
+        const int r = d.chunk_row[ch];
+        const uint32_t c0 = d.row_chunk0[r], c1 = d.row_chunk0[r + 1];
+        const int64_t s0 = d.row_ptr[r] + (int64_t)(ch - c0) * CHUNK_BLOCKS;
+        const int64_t s1 = min(d.row_ptr[r + 1], s0 + (int64_t)CHUNK_BLOCKS);
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
         for (int64_t s = s0 + lane; s < s1; s += 64) {
-            const size_t col = (size_t)(colw[s] & 0x7fffffffu);
-            const float* tv = vals + (size_t)(s >> 6) * 576;
+            const size_t col = (size_t)(d.colw[s] & 0x7fffffffu);
+            const float* tv = d.vals + (size_t)(s >> 6) * 576;
             const int l = (int)(s & 63);
             const float4 qa = reinterpret_cast<const float4*>(tv)[l];
             const float4 qb = reinterpret_cast<const float4*>(tv)[64 + l];
@@ -1260,58 +1277,79 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_chunks(const float* __restrict__
         a1 = wave_sum(a1);
         a2 = wave_sum(a2);
         if (lane == 0) {
-            const size_t rg = (size_t)rowmap[r];
-            if (c1 - c0 == 1) {
-                y[3 * rg] += a0;
-                y[3 * rg + 1] += a1;
-                y[3 * rg + 2] += a2;
-            } else {
-                chunk_partial[3 * ch] = a0;
-                chunk_partial[3 * ch + 1] = a1;
-                chunk_partial[3 * ch + 2] = a2;
+            double* out = (c1 - c0 == 1) ? d.yd + 3 * (size_t)r : d.chunk_partial + 3 * (size_t)ch;
+            out[0] = a0;
+            out[1] = a1;
+            out[2] = a2;
+            if (pdot) {
+                const size_t rg = (size_t)d.rowmap[r];
+                dot += pdot[3 * rg] * a0 + pdot[3 * rg + 1] * a1 + pdot[3 * rg + 2] * a2;
             }
-            if (pdot) dot += pdot[3 * rg] * a0 + pdot[3 * rg + 1] * a1 + pdot[3 * rg + 2] * a2;
         }
     }
     if (partials) {
         dot = block_sum(dot, sm);
-        if (threadIdx.x == 0) partials[blockIdx.x] = dot;
+        if (threadIdx.x == 0) partials[bid] = dot;
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_spmv_chunks_fix(const uint32_t* __restrict__ row_chunk0, int64_t n_rows, const int32_t* __restrict__ rowmap,
-                                                          const double* __restrict__ chunk_partial, double* __restrict__ y, const PcgCtrl* __restrict__ ctrl)
+// contribution of the contact part to block row `row` (written by spmv_chunks)
+__device__ __forceinline__ void dyn_row(const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0, const double* __restrict__ yd,
+                                        const double* __restrict__ chunk_partial, int64_t row, double& q0, double& q1, double& q2)
+{
+    const int32_t cr = crow_of_row[row];
+    if (cr < 0) return;
+    const uint32_t c0 = row_chunk0[cr], c1 = row_chunk0[cr + 1];
+    if (c1 - c0 == 1) {
+        q0 += yd[3 * (size_t)cr];
+        q1 += yd[3 * (size_t)cr + 1];
+        q2 += yd[3 * (size_t)cr + 2];
+    } else {
+        for (uint32_t k = c0; k < c1; k++) {  // fixed order: deterministic
+            q0 += chunk_partial[3 * (size_t)k];
+            q1 += chunk_partial[3 * (size_t)k + 1];
+            q2 += chunk_partial[3 * (size_t)k + 2];
+        }
+    }
+}
+// One launch for y = A_static x (rows written once, see spmv_static) and the contact part's row sums (yd / chunk_partial);
+// the consumer adds them (k_pcg_step inside the solver, k_spmv_combine elsewhere). Workgroups [0, g0) take the static tiles.
+template <int V>
+__global__ __launch_bounds__(BLOCK) void k_spmv_fused(int g0, const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int32_t* __restrict__ tile_first_row,
+                                                     int64_t nnzb, int64_t ntiles, DynPart d, const double* __restrict__ x, double* __restrict__ y,
+                                                     const double* __restrict__ pdot, double* __restrict__ partials, const PcgCtrl* __restrict__ ctrl)
 {
     if (ctrl && ctrl->done) return;
-    const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= n_rows) return;
-    const uint32_t c0 = row_chunk0[r], c1 = row_chunk0[r + 1];
-    if (c1 - c0 <= 1) return;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    for (uint32_t k = c0; k < c1; k++) {
-        a0 += chunk_partial[3 * (size_t)k];
-        a1 += chunk_partial[3 * (size_t)k + 1];
-        a2 += chunk_partial[3 * (size_t)k + 2];
-    }
-    const size_t rg = (size_t)rowmap[r];
-    y[3 * rg] += a0;
-    y[3 * rg + 1] += a1;
-    y[3 * rg + 2] += a2;
+    if ((int)blockIdx.x < g0) spmv_static<V>((int)blockIdx.x, g0, vals, colw, tile_first_row, nnzb, ntiles, nullptr, 0, x, y, pdot, partials, nullptr);
+    else spmv_chunks((int)blockIdx.x - g0, (int)gridDim.x - g0, d, x, pdot, partials ? partials + g0 : nullptr);
+}
+__global__ __launch_bounds__(BLOCK) void k_spmv_combine(int64_t nbr, const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0,
+                                                       const double* __restrict__ yd, const double* __restrict__ chunk_partial, double* __restrict__ y)
+{
+    const int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (row >= nbr) return;
+    double q0 = 0.0, q1 = 0.0, q2 = 0.0;
+    dyn_row(crow_of_row, row_chunk0, yd, chunk_partial, row, q0, q1, q2);
+    y[3 * row] += q0;
+    y[3 * row + 1] += q1;
+    y[3 * row + 2] += q2;
 }
 // y = (A_static + A_dynamic) x; partial sums of pdot . y go to partials[0 .. return value)
 template <int V>
-static int launch_spmv(Context& c, const double* x, double* y, const double* pdot, double* partials, const PcgCtrl* ctrl)
+static int launch_spmv(Context& c, const double* x, double* y, const double* pdot, double* partials, const PcgCtrl* ctrl, bool combine = true)
 {
     const BsrPart& m0 = c.part[0];
-    const BsrPart& m1 = c.part[1];
+    BsrPart& m1 = c.part[1];
     const int g0 = spmv_grid(c, m0.ntiles, MAX_PARTIALS / 2);
-    hipLaunchKernelGGL(k_spmv_t<V>, dim3(g0), dim3(BLOCK), 0, c.stream, m0.vals.p, m0.colw.p, m0.tile_first_row.p, m0.nnzb, m0.ntiles, (const int32_t*)nullptr, 0, x, y, pdot,
-                       partials, ctrl);
-    if (m1.nnzb == 0) return g0;
-    const int g1 = (int)std::min<int64_t>(std::max<int64_t>((m1.n_chunks + 3) / 4, 1), MAX_PARTIALS / 2);
-    hipLaunchKernelGGL(k_spmv_chunks, dim3(g1), dim3(BLOCK), 0, c.stream, m1.vals.p, m1.colw.p, m1.row_ptr.p, m1.row_chunk0.p, m1.chunk_row.p, m1.n_chunks,
-                       (const int32_t*)m1.rowmap.p, x, y, pdot, m1.chunk_partial.p, partials ? partials + g0 : nullptr, ctrl);
-    hipLaunchKernelGGL(k_spmv_chunks_fix, dim3(grid_for(m1.n_rows)), dim3(BLOCK), 0, c.stream, m1.row_chunk0.p, m1.n_rows, (const int32_t*)m1.rowmap.p, m1.chunk_partial.p, y,
-                       ctrl);
+    DynPart d{};
+    int g1 = 0;
+    if (m1.nnzb > 0) {
+        g1 = (int)std::min<int64_t>(std::max<int64_t>((m1.n_chunks + 3) / 4, 1), MAX_PARTIALS / 2);
+        d = DynPart{m1.vals.p, m1.colw.p, m1.row_ptr.p, m1.row_chunk0.p, m1.chunk_row.p, m1.rowmap.p, m1.yd.p, m1.chunk_partial.p, m1.n_chunks};
+    }
+    hipLaunchKernelGGL(k_spmv_fused<V>, dim3(g0 + g1), dim3(BLOCK), 0, c.stream, g0, m0.vals.p, m0.colw.p, m0.tile_first_row.p, m0.nnzb, m0.ntiles, d, x, y, pdot, partials, ctrl);
+    if (g1 > 0 && combine)
+        hipLaunchKernelGGL(k_spmv_combine, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.nbr, (const int32_t*)m1.crow_of_row.p, (const uint32_t*)m1.row_chunk0.p,
+                           (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, y);
     return g0 + g1;
 }
 // Micro-benchmark of the SpMV kernel on the assembled matrix: n back-to-back launches of q = A p (+ fused dot), HIP events
@@ -1410,7 +1448,9 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_init2(const double* __restrict__ 
 }
 __global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, const double* __restrict__ part_pq, int n_pq, const float* __restrict__ dinv, int64_t nbr,
                                                     const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ x, double* __restrict__ r,
-                                                    double* __restrict__ z, double* __restrict__ part_rr, double* __restrict__ part_rz, PcgCtrl* __restrict__ ctrl)
+                                                    double* __restrict__ z, double* __restrict__ part_rr, double* __restrict__ part_rz, PcgCtrl* __restrict__ ctrl,
+                                                    const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0, const double* __restrict__ yd,
+                                                    const double* __restrict__ chunk_partial)
 {
     if (ctrl->done) return;
     __shared__ double sm[4];
@@ -1437,7 +1477,9 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, co
     double rr = 0.0, rzn = 0.0;
     for (int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x; row < nbr; row += (int64_t)gridDim.x * BLOCK) {
         const size_t i = 3 * (size_t)row;
-        const double r0 = r[i] - alpha * q[i], r1 = r[i + 1] - alpha * q[i + 1], r2 = r[i + 2] - alpha * q[i + 2];
+        double q0 = q[i], q1 = q[i + 1], q2 = q[i + 2];
+        if (crow_of_row) dyn_row(crow_of_row, row_chunk0, yd, chunk_partial, row, q0, q1, q2);  // + contact part (k_spmv_fused)
+        const double r0 = r[i] - alpha * q0, r1 = r[i + 1] - alpha * q1, r2 = r[i + 2] - alpha * q2;
         x[i] += alpha * p[i];
         x[i + 1] += alpha * p[i + 1];
         x[i + 2] += alpha * p[i + 2];
@@ -1508,6 +1550,8 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     if (!c.have_matrix) throw Error("pcg: matrix not assembled");
     build_preconditioner(c);
     const int gv = grid_for(c.nbr, BLOCK, VEC_GRID);
+    BsrPart& m1 = c.part[1];
+    const bool dyn = m1.nnzb > 0;
     double* part_pq = c.partials.p;
     double* part_rr = c.partials.p + MAX_PARTIALS;
     double* part_rz = c.partials.p + 2 * MAX_PARTIALS;
@@ -1536,13 +1580,14 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
                 }
                 MS_CHECK(hipEventRecord(c.ev[2 * sampled.size()], c.stream));
             }
-            const int gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p);
+            const int gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false);
             if (sample) {
                 MS_CHECK(hipEventRecord(c.ev[2 * sampled.size() + 1], c.stream));
                 sampled.push_back(k);
             }
             hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, c.p.p, c.q.p, c.du.p, c.r.p, c.z.p, part_rr,
-                               part_rz, c.ctrl.p);
+                               part_rz, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : nullptr, (const uint32_t*)m1.row_chunk0.p, (const double*)m1.yd.p,
+                               (const double*)m1.chunk_partial.p);
             hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p);
         }
         MS_CHECK(hipMemcpyAsync(h, c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost, c.stream));
