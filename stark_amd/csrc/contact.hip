@@ -403,34 +403,69 @@ __global__ __launch_bounds__(CB) void k_detect_et(ContactDev d, int chunk, int* 
     if (hits) atomicAdd(&counters[1], hits);
 }
 
-// ---- sweep and prune along one axis ----------------------------------------------------------------------------------------------
-// All primitives are sorted by (class, lo[axis]) once per update; a pair of overlapping boxes is then found exactly once: by the box
-// with the smaller lo, inside the contiguous run of boxes whose lo lies in [its lo, its hi]. One WAVEFRONT walks one source box's run
-// (64 candidates per step, coalesced over the sorted copy of the boxes), so a box that spans the whole scene (a face of a large rigid
-// body) costs a long run for one wave, not a stalled lane. Same pair set as the all-pairs kernels above (kept as fallback/ablation).
+// ---- banded sweep and prune -----------------------------------------------------------------------------------------------------------
+// Boxes are binned into NBANDS slices along a second axis (a box spanning several slices gets one entry per slice) and every
+// (class, band) segment is sorted by lo[sweep axis]. A pair of overlapping boxes is reported exactly once: in the band
+// max(first band of a, first band of b) — the first band both live in — and there by the box with the smaller lo, inside the
+// contiguous run of boxes whose lo lies in [its lo, its hi]. One WAVEFRONT walks one entry's run, 64 candidates per step over a
+// sorted copy of the boxes (coalesced), so a box that spans the whole scene (a face of a large rigid body) costs long runs for a few
+// waves, not a stalled lane. Same pair set as the all-pairs kernels above (kept as cross-check / ablation).
+constexpr int NBANDS = 64;
+struct Bands
+{
+    int axis, band_axis;
+    float band_lo, band_scale;
+};
 __device__ __forceinline__ uint32_t float_key(float f)
 {
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // order-preserving
 }
-__global__ __launch_bounds__(CB) void k_bp_keys(ContactDev d, int axis, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+__device__ __forceinline__ int band_of(const Bands& B, float v)
+{
+    const float t = (v - B.band_lo) * B.band_scale;
+    return t <= 0.f ? 0 : (t >= (float)(NBANDS - 1) ? NBANDS - 1 : (int)t);  // monotone in v, clamped
+}
+__global__ __launch_bounds__(CB) void k_bp_count(ContactDev d, Bands B, uint32_t* __restrict__ cnt)
+{
+    const int i = blockIdx.x * CB + threadIdx.x;
+    const int n = d.n_v + d.n_t + d.n_e;
+    if (i > n) return;
+    cnt[i] = i < n ? (uint32_t)(band_of(B, d.aabb[6 * (size_t)i + 3 + B.band_axis]) - band_of(B, d.aabb[6 * (size_t)i + B.band_axis]) + 1) : 0u;
+}
+__global__ __launch_bounds__(CB) void k_bp_fill(ContactDev d, Bands B, const uint32_t* __restrict__ off, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, int cap,
+                                               int* __restrict__ counters)
 {
     const int i = blockIdx.x * CB + threadIdx.x;
     const int n = d.n_v + d.n_t + d.n_e;
     if (i >= n) return;
+    if (i == 0) counters[3] = (int)off[n];  // number of entries (host checks it against the capacity)
     const uint64_t cls = i < d.n_v ? 0 : (i < d.n_v + d.n_t ? 1 : 2);
-    keys[i] = (cls << 32) | float_key(d.aabb[6 * (size_t)i + axis]);
-    idx[i] = (uint32_t)i;
+    const float* b = d.aabb + 6 * (size_t)i;
+    const int b0 = band_of(B, b[B.band_axis]), b1 = band_of(B, b[3 + B.band_axis]);
+    const uint32_t fk = float_key(b[B.axis]);
+    for (int k = b0; k <= b1; k++) {
+        const uint32_t e = off[i] + (uint32_t)(k - b0);
+        if (e < (uint32_t)cap) {
+            keys[e] = (cls << 38) | ((uint64_t)k << 32) | fk;
+            idx[e] = (uint32_t)i;
+        }
+    }
 }
-__global__ __launch_bounds__(CB) void k_bp_gather(ContactDev d, int axis, const uint32_t* __restrict__ sidx, float* __restrict__ s_aabb, float* __restrict__ s_lo)
+// sorted entries -> sorted copy of the boxes + segment starts seg[cls * NBANDS + band] (seg[3 * NBANDS] = number of entries)
+__global__ __launch_bounds__(CB) void k_bp_gather(ContactDev d, Bands B, const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ sidx, int cap,
+                                                 float* __restrict__ s_aabb, float* __restrict__ s_lo, int* __restrict__ seg)
 {
     const int j = blockIdx.x * CB + threadIdx.x;
-    const int n = d.n_v + d.n_t + d.n_e;
-    if (j >= n) return;
+    if (j > cap) return;
+    const int here = j < cap ? (int)min((uint64_t)(3 * NBANDS), skeys[j] >> 32) : 3 * NBANDS;  // padding keys sort last
+    const int prev = j > 0 ? (int)min((uint64_t)(3 * NBANDS), skeys[j - 1] >> 32) : -1;
+    for (int t = prev + 1; t <= here; t++) seg[t] = j;
+    if (j >= cap || here >= 3 * NBANDS) return;
     const float* b = d.aabb + 6 * (size_t)sidx[j];
 #pragma unroll
     for (int k = 0; k < 6; k++) s_aabb[6 * (size_t)j + k] = b[k];
-    s_lo[j] = b[axis];
+    s_lo[j] = b[B.axis];
 }
 __device__ __forceinline__ int lower_bound_f(const float* a, int lo, int hi, float v)  // first index with a[i] >= v
 {
@@ -450,47 +485,60 @@ __device__ __forceinline__ int upper_bound_f(const float* a, int lo, int hi, flo
     }
     return lo;
 }
-// MODE 0: point -> triangles, 1: triangle -> points, 2: edge -> later edges, 3: edge -> triangles (intersection), 4: triangle -> edges
-template <int MODE, bool FRICTION>
-__global__ __launch_bounds__(CB) void k_sweep(ContactDev d, int axis, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const float* __restrict__ s_lo,
-                                              double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+// One wavefront per sorted entry. PROXIMITY: point entries look for triangles (lo in [lo, hi]), triangle entries for points
+// (lo in (lo, hi]), edge entries for later edges. INTERSECTION (!PROXIMITY): edge entries look for triangles, triangle entries for edges.
+template <bool PROXIMITY, bool FRICTION>
+__global__ __launch_bounds__(CB) void k_sweep(ContactDev d, Bands B, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const float* __restrict__ s_lo,
+                                              const int* __restrict__ seg, int pt_on, int ee_on, double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
 {
     const int lane = threadIdx.x & 63;
-    const int w = blockIdx.x * (CB / 64) + (threadIdx.x >> 6);
-    const int p0 = 0, t0 = d.n_v, e0 = d.n_v + d.n_t, n = d.n_v + d.n_t + d.n_e;  // class segments of the sorted order
-    const int src_begin = (MODE == 0) ? p0 : ((MODE == 1 || MODE == 4) ? t0 : e0);
-    const int src_count = (MODE == 0) ? d.n_v : ((MODE == 1 || MODE == 4) ? d.n_t : d.n_e);
-    if (w >= src_count) return;
-    const int sp = src_begin + w;
+    const int sp = blockIdx.x * (CB / 64) + (threadIdx.x >> 6);
+    if (sp >= seg[3 * NBANDS]) return;
+    const int gi = (int)sidx[sp];  // primitive (points | triangles | edges numbering)
+    const int cls = gi < d.n_v ? 0 : (gi < d.n_v + d.n_t ? 1 : 2);
+    int tc;  // class of the targets
+    if (PROXIMITY) {
+        if (cls == 2 ? !ee_on : !pt_on) return;
+        tc = cls == 0 ? 1 : (cls == 1 ? 0 : 2);
+    } else {
+        if (cls == 0) return;
+        tc = cls == 2 ? 1 : 2;
+    }
     const float* sb = s_aabb + 6 * (size_t)sp;
-    const float lo = sb[axis], hi = sb[3 + axis];
-    const int a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
-    const float lo1 = sb[a1], hi1 = sb[3 + a1], lo2 = sb[a2], hi2 = sb[3 + a2];
-    const int tgt_begin = (MODE == 0 || MODE == 3) ? t0 : (MODE == 1 ? p0 : e0);
-    const int tgt_end = (MODE == 0 || MODE == 3) ? e0 : (MODE == 1 ? t0 : n);
-    int j0, j1;
-    if (MODE == 0 || MODE == 3) j0 = lower_bound_f(s_lo, tgt_begin, tgt_end, lo);   // target lo in [lo, hi]
-    else if (MODE == 2) j0 = sp + 1;                                                   // later edges only
-    else j0 = upper_bound_f(s_lo, tgt_begin, tgt_end, lo);                             // target lo in (lo, hi]: the other direction took lo == lo
-    j1 = upper_bound_f(s_lo, tgt_begin, tgt_end, hi);
-    const int src = (int)sidx[sp] - src_begin;  // index inside its class
+    const int ax = B.axis, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+    const float lo = sb[ax], hi = sb[3 + ax], lo1 = sb[a1], hi1 = sb[3 + a1], lo2 = sb[a2], hi2 = sb[3 + a2];
+    // which band is this entry? the entries of a box are consecutive bands starting at its first one; recover it from the segment
+    const int b_first = band_of(B, sb[B.band_axis]);
+    int band = b_first;
+    while (band < NBANDS - 1 && sp >= seg[cls * NBANDS + band + 1]) band++;
+    const int t_begin = seg[tc * NBANDS + band], t_end = seg[tc * NBANDS + band + 1];
+    int j0;
+    if (cls == 2 && tc == 2) j0 = sp + 1;                                   // later edges of the same segment
+    else if (cls == 0 || (!PROXIMITY && cls == 2)) j0 = lower_bound_f(s_lo, t_begin, t_end, lo);  // target lo in [lo, hi]
+    else j0 = upper_bound_f(s_lo, t_begin, t_end, lo);                        // target lo in (lo, hi]: the other direction took ties
+    const int j1 = upper_bound_f(s_lo, t_begin, t_end, hi);
+    const int class_start[3] = {0, d.n_v, d.n_v + d.n_t};
+    const int src = gi - class_start[cls];
     int hits = 0;
     for (int j = j0 + lane; j < j1; j += 64) {
         const float* tb = s_aabb + 6 * (size_t)j;
         if (!(lo1 <= tb[3 + a1] && tb[a1] <= hi1 && lo2 <= tb[3 + a2] && tb[a2] <= hi2)) continue;
-        const int tgt = (int)sidx[j] - tgt_begin;
-        if (MODE == 0) narrow_pt<FRICTION>(d, src, tgt, enl2, keys, counters, key_cap);
-        else if (MODE == 1) narrow_pt<FRICTION>(d, tgt, src, enl2, keys, counters, key_cap);
-        else if (MODE == 2) narrow_ee<FRICTION>(d, src < tgt ? src : tgt, src < tgt ? tgt : src, enl2, keys, counters, key_cap);
-        else {
-            const int e = MODE == 3 ? src : tgt, t = MODE == 3 ? tgt : src;
+        const int tb_first = band_of(B, tb[B.band_axis]);
+        if (band != (b_first > tb_first ? b_first : tb_first)) continue;      // the pair is reported in its first common band only
+        const int tgt = (int)sidx[j] - class_start[tc];
+        if (PROXIMITY) {
+            if (cls == 0) narrow_pt<FRICTION>(d, src, tgt, enl2, keys, counters, key_cap);
+            else if (cls == 1) narrow_pt<FRICTION>(d, tgt, src, enl2, keys, counters, key_cap);
+            else narrow_ee<FRICTION>(d, src < tgt ? src : tgt, src < tgt ? tgt : src, enl2, keys, counters, key_cap);
+        } else {
+            const int e = cls == 2 ? src : tgt, t = cls == 2 ? tgt : src;
             const int v0 = d.edge[2 * e], v1 = d.edge[2 * e + 1], u0 = d.tri[3 * t], u1 = d.tri[3 * t + 1], u2 = d.tri[3 * t + 2];
             if (v0 == u0 || v0 == u1 || v0 == u2 || v1 == u0 || v1 == u1 || v1 == u2) continue;  // BroadPhaseET.cpp:161-165
             if (d.disabled[d.edge_mesh[e] * d.n_mesh + d.tri_mesh[t]]) continue;
             if (edge_intersects_triangle(ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, u0), ldx(d.X, u1), ldx(d.X, u2))) hits++;
         }
     }
-    if ((MODE == 3 || MODE == 4) && hits) atomicAdd(&counters[1], hits);
+    if (!PROXIMITY && hits) atomicAdd(&counters[1], hits);
 }
 
 // ---- sorted keys -> tables -----------------------------------------------------------------------------------------------------------
@@ -668,8 +716,11 @@ struct ContactSystem
     DevBuf<uint64_t> bp_keys, bp_keys_alt;
     DevBuf<uint32_t> bp_idx, bp_idx_alt;
     DevBuf<float> s_aabb, s_lo;
+    DevBuf<uint32_t> bp_cnt, bp_off;
+    DevBuf<int> seg;
     const uint32_t* s_idx = nullptr;
-    int axis = -1;
+    Bands bands{-1, -1, 0.f, 1.f};
+    int bp_cap = 0;
     int64_t n_updates = 0;
     bool brute_force = false;  // ablation / fallback: LDS-tiled all-pairs kernels
     int64_t n_prev = -1;  // keys of the barrier tables currently installed (-1: none)
@@ -856,10 +907,11 @@ void update_vertices(Context& c, ContactSystem& cs, const ContactDev& d, double 
     const int np = cs.n_v + cs.n_t + cs.n_e;
     hipLaunchKernelGGL(k_contact_aabbs, dim3((np + CB - 1) / CB), dim3(CB), 0, c.stream, d, enl, cs.aabb.p);
 }
-void choose_axis(Context& c, ContactSystem& cs)
+void choose_axes(Context& c, ContactSystem& cs)
 {
-    // the axis with the largest extent of the collision vertices; re-evaluated now and then (a stale choice only costs speed)
-    if (cs.axis >= 0 && (cs.n_updates % 256) != 0) return;
+    // sweep axis = largest extent of the collision vertices, band axis = second largest; re-evaluated now and then (a stale choice
+    // only costs speed: band indices are clamped, monotone functions of the coordinate)
+    if (cs.bands.axis >= 0 && (cs.n_updates % 256) != 0) return;
     std::vector<double> X(3 * (size_t)cs.n_v);
     MS_CHECK(hipMemcpyAsync(X.data(), cs.X.p, X.size() * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
@@ -869,34 +921,45 @@ void choose_axis(Context& c, ContactSystem& cs)
             lo[k] = std::min(lo[k], X[3 * (size_t)i + k]);
             hi[k] = std::max(hi[k], X[3 * (size_t)i + k]);
         }
-    int ax = 0;
-    for (int k = 1; k < 3; k++)
-        if (hi[k] - lo[k] > hi[ax] - lo[ax]) ax = k;
-    cs.axis = ax;
+    int order[3] = {0, 1, 2};
+    std::sort(order, order + 3, [&](int a, int b) { return hi[a] - lo[a] > hi[b] - lo[b]; });
+    cs.bands.axis = order[0];
+    cs.bands.band_axis = order[1];
+    const double ext = std::max(hi[order[1]] - lo[order[1]], 1e-12);
+    cs.bands.band_lo = (float)lo[order[1]];
+    cs.bands.band_scale = (float)(NBANDS / ext);
 }
+// false: the entry list did not fit (capacity grown, caller repeats)
 void sort_boxes(Context& c, ContactSystem& cs, const ContactDev& d)
 {
-    choose_axis(c, cs);
+    choose_axes(c, cs);
     cs.n_updates++;
     const int n = cs.n_v + cs.n_t + cs.n_e;
-    cs.bp_keys.ensure(n); cs.bp_keys_alt.ensure(n); cs.bp_idx.ensure(n); cs.bp_idx_alt.ensure(n);
-    cs.s_aabb.ensure(6 * (size_t)n); cs.s_lo.ensure(n);
-    hipLaunchKernelGGL(k_bp_keys, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.axis, cs.bp_keys.p, cs.bp_idx.p);
+    if (cs.bp_cap < n + n / 2 + 4096) cs.bp_cap = n + n / 2 + 4096;
+    const int cap = cs.bp_cap;
+    cs.bp_cnt.ensure((size_t)n + 1); cs.bp_off.ensure((size_t)n + 1);
+    cs.bp_keys.ensure(cap); cs.bp_keys_alt.ensure(cap); cs.bp_idx.ensure(cap); cs.bp_idx_alt.ensure(cap);
+    cs.s_aabb.ensure(6 * (size_t)cap); cs.s_lo.ensure(cap); cs.seg.ensure(3 * NBANDS + 2);
+    hipLaunchKernelGGL(k_bp_count, dim3((n + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, cs.bp_cnt.p);
+    size_t tmp = 0;
+    MS_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cs.bp_cnt.p, cs.bp_off.p, n + 1, c.stream));
+    cs.cub_tmp.ensure(tmp);
+    MS_CHECK(hipcub::DeviceScan::ExclusiveSum(cs.cub_tmp.p, tmp, cs.bp_cnt.p, cs.bp_off.p, n + 1, c.stream));
+    MS_CHECK(hipMemsetAsync(cs.bp_keys.p, 0xFF, (size_t)cap * sizeof(uint64_t), c.stream));  // padding entries sort last
+    hipLaunchKernelGGL(k_bp_fill, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, (const uint32_t*)cs.bp_off.p, cs.bp_keys.p, cs.bp_idx.p, cap, cs.counters.p + 32);
     hipcub::DoubleBuffer<uint64_t> dk(cs.bp_keys.p, cs.bp_keys_alt.p);
     hipcub::DoubleBuffer<uint32_t> dv(cs.bp_idx.p, cs.bp_idx_alt.p);
-    size_t tmp = 0;
-    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, n, 0, 34, c.stream));
+    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, cap, 0, 40, c.stream));
     cs.cub_tmp.ensure(tmp);
-    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(cs.cub_tmp.p, tmp, dk, dv, n, 0, 34, c.stream));
+    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(cs.cub_tmp.p, tmp, dk, dv, cap, 0, 40, c.stream));
     cs.s_idx = dv.Current();
-    hipLaunchKernelGGL(k_bp_gather, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.axis, cs.s_idx, cs.s_aabb.p, cs.s_lo.p);
+    hipLaunchKernelGGL(k_bp_gather, dim3((cap + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, (const uint64_t*)dk.Current(), cs.s_idx, cap, cs.s_aabb.p, cs.s_lo.p, cs.seg.p);
 }
-template <int MODE, bool FR>
-void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, int n_src, double enl2)
+template <bool PROX, bool FR>
+void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, double enl2)
 {
-    if (n_src <= 0) return;
-    hipLaunchKernelGGL((k_sweep<MODE, FR>), dim3((n_src + CB / 64 - 1) / (CB / 64)), dim3(CB), 0, c.stream, d, cs.axis, cs.s_idx, (const float*)cs.s_aabb.p, (const float*)cs.s_lo.p, enl2,
-                       cs.keys.p, cs.counters.p, (int)cs.key_cap);
+    hipLaunchKernelGGL((k_sweep<PROX, FR>), dim3((cs.bp_cap + CB / 64 - 1) / (CB / 64)), dim3(CB), 0, c.stream, d, cs.bands, cs.s_idx, (const float*)cs.s_aabb.p, (const float*)cs.s_lo.p,
+                       (const int*)cs.seg.p, (int)(cs.pt_enabled && cs.n_t > 0), (int)(cs.ee_enabled && cs.n_e > 1), enl2, cs.keys.p, cs.counters.p, (int)cs.key_cap);
 }
 // Runs detection and installs the tables [t0, t1). Returns the number of rows.
 int64_t detect_and_route(Context& c, double dt, bool friction)
@@ -916,18 +979,12 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     }
     int h[64];
     int n = 0;
-    if (!cs.brute_force) sort_boxes(c, cs, d);
     for (;;) {
         MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
         if (!cs.brute_force) {
-            if (cs.pt_enabled && cs.n_t > 0) {
-                if (friction) { launch_sweep<0, true>(c, cs, d, cs.n_v, enl * enl); launch_sweep<1, true>(c, cs, d, cs.n_t, enl * enl); }
-                else { launch_sweep<0, false>(c, cs, d, cs.n_v, enl * enl); launch_sweep<1, false>(c, cs, d, cs.n_t, enl * enl); }
-            }
-            if (cs.ee_enabled && cs.n_e > 1) {
-                if (friction) launch_sweep<2, true>(c, cs, d, cs.n_e, enl * enl);
-                else launch_sweep<2, false>(c, cs, d, cs.n_e, enl * enl);
-            }
+            sort_boxes(c, cs, d);
+            if (friction) launch_sweep<true, true>(c, cs, d, enl * enl);
+            else launch_sweep<true, false>(c, cs, d, enl * enl);
         } else {
         if (cs.pt_enabled && cs.n_t > 0) {
             const int chunk = chunk_for(cs.n_v, cs.n_t);
@@ -942,9 +999,13 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
             else hipLaunchKernelGGL(k_detect_ee<false>, g, dim3(CB), 0, c.stream, d, enl * enl, chunk, cs.keys.p, cs.counters.p, (int)cs.key_cap);
         }
         }
-        MS_CHECK(hipMemcpyAsync(h, cs.counters.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipMemcpyAsync(h, cs.counters.p, 40 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
         MS_CHECK(hipStreamSynchronize(c.stream));
         n = h[0];
+        if (!cs.brute_force && h[35] > cs.bp_cap) {  // (counters[32 + 3]) the banded box list did not fit: grow and search again
+            cs.bp_cap = h[35] + h[35] / 4;
+            continue;
+        }
         if ((size_t)n <= cs.key_cap) break;
         cs.key_cap = (size_t)n + n / 2;  // the list did not fit: grow and search again
         cs.keys.ensure(cs.key_cap);
@@ -1033,9 +1094,19 @@ int64_t count_intersections(Context& c, double dt)
             cs.keys.ensure(cs.key_cap);
             cs.keys_alt.ensure(cs.key_cap);
         }
-        sort_boxes(c, cs, d);
-        launch_sweep<3, false>(c, cs, d, cs.n_e, 0.0);
-        launch_sweep<4, false>(c, cs, d, cs.n_t, 0.0);
+        for (;;) {
+            sort_boxes(c, cs, d);
+            launch_sweep<false, false>(c, cs, d, 0.0);
+            int hb[40];
+            MS_CHECK(hipMemcpyAsync(hb, cs.counters.p, sizeof(hb), hipMemcpyDeviceToHost, c.stream));
+            MS_CHECK(hipStreamSynchronize(c.stream));
+            if (hb[35] > cs.bp_cap) {
+                cs.bp_cap = hb[35] + hb[35] / 4;
+                MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 8 * sizeof(int), c.stream));
+                continue;
+            }
+            return hb[1];
+        }
     } else {
         const int chunk = chunk_for(cs.n_e, cs.n_t);
         hipLaunchKernelGGL(k_detect_et, dim3((cs.n_e + CB - 1) / CB, (cs.n_t + chunk - 1) / chunk), dim3(CB), 0, c.stream, d, chunk, cs.counters.p);
