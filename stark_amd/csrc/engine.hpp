@@ -209,6 +209,7 @@ struct Context
     // SpMV timing
     bool time_spmv = false;
     std::vector<hipEvent_t> ev;
+    std::vector<hipEvent_t> pcg_ev;  // batch completion events of the PCG driver
     double spmv_ms_sum = 0.0;
     int64_t spmv_n = 0;
 

@@ -1533,18 +1533,6 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
 
 // SpMV timing inside the solver: every SPMV_SAMPLE-th launch is bracketed by a pair of pooled HIP events on the engine's stream
 constexpr int SPMV_SAMPLE = 8;
-static void drain_spmv_events(Context& c, const std::vector<int>& iters, int last_real_iter)
-{
-    for (size_t i = 0; i < iters.size(); i++) {
-        if (iters[i] > last_real_iter) continue;  // early-exit launch after convergence
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c.ev[2 * i], c.ev[2 * i + 1]) == hipSuccess) {
-            c.spmv_ms_sum += ms;
-            c.spmv_n++;
-        }
-    }
-}
-
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
 {
     if (!c.have_matrix) throw Error("pcg: matrix not assembled");
@@ -1558,44 +1546,72 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     double* part_bb = c.partials.p + 3 * MAX_PARTIALS;
     hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(BLOCK), 0, c.stream, rhs_dev, c.dinv.p, c.nbr, c.du.p, c.r.p, c.z.p, c.p.p, part_bb, part_rz);
     hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, part_bb, part_rz, gv, abs_tol, c.ctrl.p);
-    PcgCtrl* h = reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048);  // pinned
-    h->done = 0;
+    // Iterations are launched in batches of PCG_BATCH; after each batch the control block is copied to a pinned slot and an
+    // event recorded. The host launches batch b+1 BEFORE it waits for batch b's event, so the GPU never idles on the host's
+    // convergence check, and at most one batch of device-side no-op launches (ctrl->done) is wasted after convergence.
+    constexpr int PCG_BATCH = 8;
+    PcgCtrl* hs[2] = {reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048), reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048 + 64)};  // pinned
+    while (c.pcg_ev.size() < 2) {
+        hipEvent_t e;
+        MS_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c.pcg_ev.push_back(e);
+    }
+    std::vector<int> sampled[2];
     int k = 1;
-    // first batch: the iteration count of the previous solve (Newton systems change slowly), then small top-ups;
-    // launches after convergence are device-side no-ops (ctrl->done)
-    int batch = c.last_cg_iters > 0 ? std::max(8, ((c.last_cg_iters + 7) / 8) * 8) : 16;
-    bool finished = false;
-    std::vector<int> sampled;
-    while (!finished) {
-        const int k_end = std::min(max_iter, k + batch - 1);
-        sampled.clear();
+    auto launch_batch = [&](int slot) {
+        const int k_end = std::min(max_iter, k + PCG_BATCH - 1);
+        sampled[slot].clear();
         for (; k <= k_end; k++) {
             const bool sample = c.time_spmv && (k % SPMV_SAMPLE) == 0;
+            const size_t e0 = (size_t)slot * 2 * PCG_BATCH + 2 * sampled[slot].size();
             if (sample) {
-                const size_t need = 2 * (sampled.size() + 1);
-                while (c.ev.size() < need) {
+                while (c.ev.size() < (size_t)4 * PCG_BATCH) {
                     hipEvent_t e;
                     MS_CHECK(hipEventCreate(&e));
                     c.ev.push_back(e);
                 }
-                MS_CHECK(hipEventRecord(c.ev[2 * sampled.size()], c.stream));
+                MS_CHECK(hipEventRecord(c.ev[e0], c.stream));
             }
             const int gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false);
             if (sample) {
-                MS_CHECK(hipEventRecord(c.ev[2 * sampled.size() + 1], c.stream));
-                sampled.push_back(k);
+                MS_CHECK(hipEventRecord(c.ev[e0 + 1], c.stream));
+                sampled[slot].push_back(k);
             }
             hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, c.p.p, c.q.p, c.du.p, c.r.p, c.z.p, part_rr,
                                part_rz, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : nullptr, (const uint32_t*)m1.row_chunk0.p, (const double*)m1.yd.p,
                                (const double*)m1.chunk_partial.p);
             hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p);
         }
-        MS_CHECK(hipMemcpyAsync(h, c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost, c.stream));
-        MS_CHECK(hipStreamSynchronize(c.stream));
-        if (c.time_spmv) drain_spmv_events(c, sampled, h->done ? h->n_iter : k_end);
-        if (h->done || k > max_iter) finished = true;
-        batch = 8;
+        MS_CHECK(hipMemcpyAsync(hs[slot], c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipEventRecord(c.pcg_ev[slot], c.stream));
+        return k_end;
+    };
+    auto drain = [&](int slot, int last_real_iter) {
+        for (size_t i = 0; i < sampled[slot].size(); i++) {
+            if (sampled[slot][i] > last_real_iter) continue;  // early-exit launch after convergence
+            float ms = 0.f;
+            const size_t e0 = (size_t)slot * 2 * PCG_BATCH + 2 * i;
+            if (hipEventElapsedTime(&ms, c.ev[e0], c.ev[e0 + 1]) == hipSuccess) {
+                c.spmv_ms_sum += ms;
+                c.spmv_n++;
+            }
+        }
+    };
+    PcgCtrl* h = nullptr;
+    int slot = 0;
+    int k_end_cur = launch_batch(0);
+    for (;;) {
+        const bool more = k <= max_iter;
+        int k_end_next = 0;
+        if (more) k_end_next = launch_batch(slot ^ 1);  // keep the GPU fed while the host looks at the previous batch
+        MS_CHECK(hipEventSynchronize(c.pcg_ev[slot]));
+        h = hs[slot];
+        if (c.time_spmv) drain(slot, h->done ? h->n_iter : k_end_cur);
+        if (h->done || !more) break;
+        slot ^= 1;
+        k_end_cur = k_end_next;
     }
+    // (a look-ahead batch launched after convergence consists of device-side no-ops; later work queues behind it on the same stream)
     const int n_it = h->done ? h->n_iter : max_iter;
     c.last_cg_iters = n_it;
     if (info) {
@@ -1611,6 +1627,7 @@ Context::~Context()
 {
     contact_destroy(contact);
     for (auto e : ev) (void)hipEventDestroy(e);
+    for (auto e : pcg_ev) (void)hipEventDestroy(e);
     if (h_scratch) (void)hipHostFree(h_scratch);
     if (stream) (void)hipStreamDestroy(stream);
 }
