@@ -146,7 +146,11 @@ def lib():
 
 
 def exported_symbols():
-    """Every entry point include/mistark.h declares (used by the CPU-side load test)."""
+    """Every entry point include/*.h declares (used by the CPU-side load test)."""
     import re
-    hdr = open(os.path.join(os.path.dirname(_HERE), "include", "mistark.h")).read()
-    return sorted(set(re.findall(r"\b(mistark_[a-z0-9_]+)\s*\(", hdr)))
+    out = set()
+    for h in ("mistark.h", "mistark_contact.h", "mistark_sim.h"):
+        hdr = open(os.path.join(os.path.dirname(_HERE), "include", h)).read()
+        out |= set(re.findall(r"\b(mistark_[a-z0-9_]+)\s*\(", hdr))
+        out -= set(re.findall(r"struct\s+(mistark_[a-z0-9_]+)", hdr))  # (type names mentioned in comments)
+    return sorted(out)
