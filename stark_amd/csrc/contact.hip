@@ -176,23 +176,19 @@ __device__ __forceinline__ D3 ldx(const double* X, int i) { return d3(X[3 * i], 
 // table of a classified pair: family 0 pt_pp 1 pt_pe 2 pt_pt 3 ee_pp 4 ee_pe 5 ee_ee; ka / kb = system of the reference's A / B
 __device__ __forceinline__ int table_of(int fam, int ka, int kb, bool friction)
 {
+    // (written with selects instead of lookup arrays: run-time indexed local arrays live in scratch memory)
     if (!friction) {
         if (ka == 0 && kb == 0) return fam;
         if (ka == 1 && kb == 1) return 6 + fam;
-        if (ka == 1) {
-            const int m[6] = {12, 13, 14, 17, 18, 19};
-            return m[fam];
-        }
-        const int m[6] = {12, 15, 16, 17, 20, 19};  // deformable first: rigid side listed first, asymmetric families switch table
-        return m[fam];
+        if (ka == 1) return fam < 3 ? 12 + fam : 14 + fam;  // pt_pp pt_pe pt_pt | ee_pp ee_pe ee_ee -> 12 13 14 | 17 18 19
+        // deformable first: the rigid side is listed first and the asymmetric families switch table: 12 15 16 | 17 20 19
+        return fam == 0 ? 12 : (fam == 1 ? 15 : (fam == 2 ? 16 : (fam == 3 ? 17 : (fam == 4 ? 20 : 19))));
     }
-    const int k4m[6] = {0, 1, 2, 0, 1, 3};  // pp pe pt | pp pe ee
-    const int k4 = k4m[fam];
+    const int k4 = fam < 3 ? fam : (fam == 5 ? 3 : fam - 3);  // pp pe pt | pp pe ee
     if (ka == 0 && kb == 0) return 21 + k4;
     if (ka == 1 && kb == 1) return 25 + k4;
     if (ka == 1) return 29 + k4;
-    const int m[4] = {29, 33, 34, 32};
-    return m[k4];
+    return k4 == 0 ? 29 : (k4 == 1 ? 33 : (k4 == 2 ? 34 : 32));  // pp -> pp, pe -> ep, pt -> tp, ee -> ee
 }
 __device__ __forceinline__ int pt_family(int type) { return type <= P_T2 ? 0 : (type <= P_E2 ? 1 : 2); }
 __device__ __forceinline__ int ee_family(int type) { return type <= EA1_EB1 ? 3 : (type <= EA1_EB ? 4 : 5); }
@@ -259,7 +255,7 @@ __device__ __forceinline__ void push_key(uint64_t key, uint64_t* __restrict__ ke
     if (slot < key_cap) keys[slot] = key;
 }
 template <bool FRICTION>
-__device__ __noinline__ void narrow_pt(const ContactDev& d, int p, int t, double enl2, uint64_t* keys, int* counters, int key_cap)
+__device__ __forceinline__ void narrow_pt(const ContactDev& d, int p, int t, double enl2, uint64_t* keys, int* counters, int key_cap)
 {
     const int v0 = d.tri[3 * t], v1 = d.tri[3 * t + 1], v2 = d.tri[3 * t + 2];
     if (p == v0 || p == v1 || p == v2) return;  // point of its own triangle (BroadPhasePTEEBase.cpp:193)
@@ -274,7 +270,7 @@ __device__ __noinline__ void narrow_pt(const ContactDev& d, int p, int t, double
     push_key(pack_key(table, 0, type, p, t), keys, counters, key_cap);
 }
 template <bool FRICTION>
-__device__ __noinline__ void narrow_ee(const ContactDev& d, int ea, int eb, double enl2, uint64_t* keys, int* counters, int key_cap)
+__device__ __forceinline__ void narrow_ee(const ContactDev& d, int ea, int eb, double enl2, uint64_t* keys, int* counters, int key_cap)
 {
     const int a0 = d.edge[2 * ea], a1 = d.edge[2 * ea + 1], b0 = d.edge[2 * eb], b1 = d.edge[2 * eb + 1];
     if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) return;  // edges sharing a vertex (BroadPhasePTEEBase.cpp:246)
@@ -517,15 +513,17 @@ __global__ __launch_bounds__(CB) void k_sweep(ContactDev d, Bands B, const uint3
     else if (cls == 0 || (!PROXIMITY && cls == 2)) j0 = lower_bound_f(s_lo, t_begin, t_end, lo);  // target lo in [lo, hi]
     else j0 = upper_bound_f(s_lo, t_begin, t_end, lo);                        // target lo in (lo, hi]: the other direction took ties
     const int j1 = upper_bound_f(s_lo, t_begin, t_end, hi);
-    const int class_start[3] = {0, d.n_v, d.n_v + d.n_t};
-    const int src = gi - class_start[cls];
+    // (no local arrays indexed at run time: they would live in scratch memory)
+    const int src_start = cls == 0 ? 0 : (cls == 1 ? d.n_v : d.n_v + d.n_t);
+    const int tgt_start = tc == 0 ? 0 : (tc == 1 ? d.n_v : d.n_v + d.n_t);
+    const int src = gi - src_start;
     int hits = 0;
     for (int j = j0 + lane; j < j1; j += 64) {
         const float* tb = s_aabb + 6 * (size_t)j;
         if (!(lo1 <= tb[3 + a1] && tb[a1] <= hi1 && lo2 <= tb[3 + a2] && tb[a2] <= hi2)) continue;
         const int tb_first = band_of(B, tb[B.band_axis]);
         if (band != (b_first > tb_first ? b_first : tb_first)) continue;      // the pair is reported in its first common band only
-        const int tgt = (int)sidx[j] - class_start[tc];
+        const int tgt = (int)sidx[j] - tgt_start;
         if (PROXIMITY) {
             if (cls == 0) narrow_pt<FRICTION>(d, src, tgt, enl2, keys, counters, key_cap);
             else if (cls == 1) narrow_pt<FRICTION>(d, tgt, src, enl2, keys, counters, key_cap);
