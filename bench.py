@@ -92,7 +92,8 @@ def cpu_baseline(nx, ny, nz, scene="contact"):
         r = json.loads(line)
         return {"value": r["newton_steps_per_s"], "unit": "Newton-steps/s", "cores": threads, "kind": "reference",
                 "sample": "same scene, %d Newton iterations over 2 time steps after 1 warm-up step (pattern build + JIT excluded)" % r["newton_iterations"],
-                "ms_per_linear_solve": r["ms_per_linear_solve"], "wall_s": r["wall_s"]}
+                "ms_per_linear_solve": r["ms_per_linear_solve"], "wall_s": r["wall_s"], "newton_iterations": r["newton_iterations"],
+                "linear_solves": r.get("linear_solves")}
     except Exception as e:  # noqa: BLE001
         return {"value": None, "unit": "Newton-steps/s", "cores": threads, "kind": "reference", "sample": "failed: %r" % (e,)}
 

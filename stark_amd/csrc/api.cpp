@@ -73,6 +73,8 @@ int mistark_create(int device, mistark_ctx** out)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return -2;  // no GPU: the product path fails loudly, there is no CPU fallback
     if (device < 0 || device >= n) return -3;
+    // the Newton loop synchronises with the device a few dozen times per iteration (scalars only): spin instead of sleeping
+    (void)hipSetDeviceFlags(hipDeviceScheduleSpin);
     if (hipSetDevice(device) != hipSuccess) return -4;
     mistark_ctx* ctx = new mistark_ctx();
     ctx->c.device = device;
