@@ -205,7 +205,10 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
-                "traffic": None,
+                # HBM-side bytes per real SpMV launch from rocprofv3 PMC passes of this command (profiles/r01_v6_pmc_*.txt):
+                # 2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KB -> bytes.
+                # Only valid for the default workload; other sizes report null.
+                "traffic": (2 * 65124.8 + 5393.0) * 1024.0 if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "avg_launch_ms": spmv_ms,
                 "launches_timed": spmv_n,

@@ -52,3 +52,31 @@ if solves:
     print("linear solves: %d, span %.1f ms, busy %.1f ms, idle %.1f ms; gaps > 5 us: %d (sum %.1f ms), top gaps us: %s" % (
         len(solves), span / 1e6, busy / 1e6, (span - busy) / 1e6, sum(1 for g in allg if g > 5000), sum(g for g in allg if g > 5000) / 1e6,
         [round(g / 1e3, 1) for g in allg[:8]]))
+
+# ---- all idle time attributed to the kernel that precedes it (where does the GPU wait for the host?)
+idle = collections.Counter()
+idle_n = collections.Counter()
+for i, (name, s, e) in enumerate(rows[:-1]):
+    short = name.split("(")[0].replace("void ", "").replace("mistark::", "")[:48]
+    g = rows[i + 1][1] - e
+    if g > 0:
+        idle[short] += g
+        idle_n[short] += 1
+print("idle time by preceding kernel (total ms, count, avg us):")
+for k, v in idle.most_common(16):
+    print("  %-50s %9.2f %7d %9.1f" % (k, v / 1e6, idle_n[k], v / 1e3 / idle_n[k]))
+
+# ---- idle gaps > 20 us by (previous kernel -> next kernel): which host round trips cost the most
+pair = collections.Counter()
+pair_n = collections.Counter()
+def sh(n):
+    return n.split("(")[0].replace("void ", "").replace("mistark::", "").replace("(anonymous namespace)::", "")[:34]
+for i, (name, s, e) in enumerate(rows[:-1]):
+    g = rows[i + 1][1] - e
+    if g > 20000:
+        k = sh(name) + " -> " + sh(rows[i + 1][0])
+        pair[k] += g
+        pair_n[k] += 1
+print("idle gaps > 20 us by (previous -> next) kernel (total ms, count, avg us):")
+for k, v in pair.most_common(22):
+    print("  %-74s %8.2f %6d %8.1f" % (k, v / 1e6, pair_n[k], v / 1e3 / pair_n[k]))

