@@ -138,7 +138,9 @@ def edge_intersects_triangle(q1, q2, a, b, c):
 
 # ---- friction geometry (friction_geometry.cpp) ---------------------------------------------------------------------------------
 def _normalized(v):
-    return v / np.sqrt(_sq(v))[..., None]
+    """Eigen's normalized(): zero vectors are returned unchanged."""
+    n = np.sqrt(_sq(v))[..., None]
+    return np.where(n > 0, v / np.where(n > 0, n, 1.0), v)
 
 
 def barycentric_point_triangle(p, a, b, c):

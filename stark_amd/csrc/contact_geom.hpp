@@ -25,7 +25,13 @@ MS_HD D3 operator*(double s, const D3& a) { return D3{s * a.x, s * a.y, s * a.z}
 MS_HD double dot3(const D3& a, const D3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 MS_HD D3 cross3(const D3& a, const D3& b) { return D3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 MS_HD double sq3(const D3& a) { return dot3(a, a); }
-MS_HD D3 unit3(const D3& a) { return (1.0 / ::sqrt(sq3(a))) * a; }
+// Eigen's normalized(): a zero vector is returned unchanged (friction_geometry.cpp relies on it: a point exactly below its partner
+// gives e x n = 0 in projection_matrix_point_point, i.e. a zero tangent basis and no friction for that contact, not a NaN)
+MS_HD D3 unit3(const D3& a)
+{
+    const double n2 = sq3(a);
+    return n2 > 0.0 ? (1.0 / ::sqrt(n2)) * a : a;
+}
 
 // closest features (ipc_toolkit_geometry_functions.h:12-40)
 enum PtType : int { P_T0 = 0, P_T1, P_T2, P_E0, P_E1, P_E2, P_T };

@@ -1148,6 +1148,20 @@ __device__ __forceinline__ void spmv_static(const int bid, const int nblk, const
         }
     }
     double k0 = 0.0, k1 = 0.0, k2 = 0.0;  // carry into the first segment of the next tile (wave-uniform)
+    // Software pipeline of depth one: the column words and values of tile t+1 are requested before the x gather of tile t, so a
+    // wave has one dependent load (x[col]) per tile on its critical path instead of two (colw -> x). Tiles are padded, so the
+    // loads of a partially filled last tile are in bounds.
+    uint32_t w_cur = 0;
+    float4 a_cur = make_float4(0.f, 0.f, 0.f, 0.f), b_cur = a_cur;
+    float c_cur = 0.f;
+    auto load_tile = [&](int64_t t, uint32_t& w, float4& a, float4& b, float& cc) {
+        w = colw[t * 64 + lane];
+        const float4* q = reinterpret_cast<const float4*>(vals + (size_t)t * 576);
+        a = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[lane];
+        b = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[64 + lane];
+        cc = (V == 3) ? 1.f : vals[(size_t)t * 576 + 512 + lane];
+    };
+    if (t_lead < t_end) load_tile(t_lead, w_cur, a_cur, b_cur, c_cur);
     for (int64_t t = t_lead; t < t_end; t++) {
         const bool ghost = t < t_begin;
         const int64_t s = t * 64 + lane;
@@ -1157,14 +1171,13 @@ __device__ __forceinline__ void spmv_static(const int bid, const int nblk, const
         const int32_t tfr_w = tile_first_row[t];   // bit 31: the tile starts inside a row begun in the previous tile
         const int tfr = tfr_w & 0x7fffffff;
         const bool tile_cont = tfr_w < 0;
+        const uint32_t w = w_cur;
+        const float4 a = a_cur, b = b_cur;
+        const float cc = c_cur;
+        if (t + 1 < t_end) load_tile(t + 1, w_cur, a_cur, b_cur, c_cur);
         if (valid) {
-            const uint32_t w = colw[s];
             tail = (w >> 31) != 0;
             const size_t col = (V == 2) ? (size_t)(s % 170000) : (size_t)(w & 0x7fffffffu);
-            const float4* q = reinterpret_cast<const float4*>(vals + (size_t)t * 576);
-            const float4 a = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[lane];
-            const float4 b = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[64 + lane];
-            const float cc = (V == 3) ? 1.f : vals[(size_t)t * 576 + 512 + lane];
             const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
             y0 = (double)a.x * x0 + (double)a.y * x1 + (double)a.z * x2;
             y1 = (double)a.w * x0 + (double)b.x * x1 + (double)b.y * x2;

@@ -66,6 +66,12 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
         }
         const double residual = reduce_max_abs(c, c.grad.p, ndofs);  // default residual: ||grad||_inf (solver_utils.h:28)
         if (it == 0) res_0 = residual;
+        if (!(residual == residual)) {
+            // NaN gradient: the reference would spin forever here (every comparison below is false and the projection threshold
+            // becomes NaN too); report the failure instead so that the time step is halved / the run stops
+            result = MISTARK_LINEAR_SYSTEM_SOLVE_FAILURE;
+            break;
+        }
         if (residual < s.bailout_residual) {
             result = MISTARK_SUCCESSFUL;
             break;

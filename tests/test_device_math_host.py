@@ -132,3 +132,21 @@ def test_contact_geometry_matches_reference_known_answers(host_lib):
     assert np.abs(pp - z["fr_pp"]).max() < 1e-12
     assert np.abs(ee[:, :2] - z["fr_ee"][:, :2]).max() <= 1e-9 * np.abs(z["fr_ee"][:, :2]).max()
     assert np.abs(ee[:, 2:] - z["fr_ee"][:, 2:]).max() < 1e-9
+
+
+def test_tangent_basis_of_vertically_aligned_points_is_zero_not_nan(host_lib):
+    """projection_matrix_point_point with p exactly below a: e x n = 0; Eigen's normalized() leaves the zero vector alone, so the
+    reference stores a zero tangent basis (no friction for that contact). The device geometry must not produce NaNs there (it once
+    did, which made a whole Newton solve spin on NaN residuals)."""
+    P = ctypes.c_void_p
+    pt_in = np.zeros((1, 12))
+    pt_in[0, 0:3] = [0.1, 0.2, 0.3]        # p
+    pt_in[0, 3:6] = [0.1, 0.2, 0.5]        # a straight above p  ->  n = (0, 0, -1)
+    pt_in[0, 6:9] = [1.0, 0.0, 0.0]
+    pt_in[0, 9:12] = [0.0, 1.0, 0.0]
+    ee_in = np.ascontiguousarray(np.arange(12, dtype=np.float64).reshape(1, 12) * 0.37 % 1.0)
+    pt = np.zeros((1, 9)); pe = np.zeros((1, 8)); pp = np.ones((1, 6)); ee = np.zeros((1, 8))
+    host_lib.host_geom_friction(P(pt_in.ctypes.data), P(ee_in.ctypes.data), 1, P(pt.ctypes.data), P(pe.ctypes.data), P(pp.ctypes.data), P(ee.ctypes.data))
+    assert np.isfinite(pp).all() and np.abs(pp).max() == 0.0
+    from oracle import contact as oc
+    assert np.abs(oc.projection_matrix_point_point(pt_in[:, 0:3], pt_in[:, 3:6])).max() == 0.0
