@@ -61,6 +61,35 @@ int mistark_sim_add_surface(mistark_sim* sim, const char* label, const double* v
 /* deformables->prescribed_positions->add_inside_aabb: returns the group index */
 int mistark_sim_prescribe_inside_aabb(mistark_sim* sim, int point_set, const double center[3], const double dim[3], double stiffness, double tolerance);
 
+/* deformables->prescribed_positions->add(set, points, params): returns the group index */
+int mistark_sim_prescribe_points(mistark_sim* sim, int point_set, const int32_t* points, int64_t n, double stiffness, double tolerance);
+
+/* ---- rods (stark::Line presets, DeformablesPresets.cpp:11-29; EnergySegmentStrain::Params) ---------------------------------- */
+typedef struct mistark_line_params
+{
+    double density, inertia_damping;
+    int32_t quasistatic;
+    int32_t elasticity_only;
+    double scale, section_radius, youngs_modulus, strain_damping, strain_limit, strain_limit_stiffness;
+} mistark_line_params;
+void mistark_line_params_elastic_rubberband(mistark_line_params* p);
+/* presets->deformables->add_line / add_line_as_segments: return the point-set index */
+int mistark_sim_add_line(mistark_sim* sim, const char* label, const double* vertices, int64_t n_vertices, const int32_t* segments, int64_t n_segments, const mistark_line_params* p);
+int mistark_sim_add_line_as_segments(mistark_sim* sim, const char* label, const double begin[3], const double end[3], int32_t n_segments, const mistark_line_params* p);
+
+/* ---- attachments (stark::EnergyAttachments::add overloads, EnergyAttachments.cpp:138-333); point / edge / triangle indices are
+ * local to their point set, bary are 2 or 3 doubles per attachment; tolerance <= 0 means none. Return the handler index. ---- */
+int mistark_sim_attach_point_point(mistark_sim* sim, int set_0, int set_1, const int32_t* points_0, const int32_t* points_1, int64_t n, double stiffness, double tolerance);
+int mistark_sim_attach_point_edge(mistark_sim* sim, int set_0, int set_1, const int32_t* points, const int32_t* edges, const double* bary, int64_t n, double stiffness, double tolerance);
+int mistark_sim_attach_point_triangle(mistark_sim* sim, int set_0, int set_1, const int32_t* points, const int32_t* triangles, const double* bary, int64_t n, double stiffness,
+                                      double tolerance);
+int mistark_sim_attach_edge_edge(mistark_sim* sim, int set_0, int set_1, const int32_t* edges_0, const int32_t* edges_1, const double* bary_0, const double* bary_1, int64_t n,
+                                 double stiffness, double tolerance);
+/* rb_points_loc == NULL: the points' current positions in the body frame (EnergyAttachments.cpp:322-333) */
+int mistark_sim_attach_rigid_body(mistark_sim* sim, int rb, int point_set, const double* rb_points_loc, const int32_t* points, int64_t n, double stiffness, double tolerance);
+/* EnergyAttachments::get_params(handler).stiffness (doubled by the tolerance check) */
+int mistark_sim_attachment_stiffness(mistark_sim* sim, int handler, double* stiffness);
+
 /* PointSetHandler::add_displacement / add_rotation (also at rest pose), before the first step */
 int mistark_sim_point_set_add_displacement(mistark_sim* sim, int point_set, const double d[3]);
 int mistark_sim_point_set_add_rotation(mistark_sim* sim, int point_set, double angle_deg, const double axis[3], const double pivot[3]);

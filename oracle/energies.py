@@ -596,11 +596,86 @@ _CONTACT = {
     "friction_rb_d_ep_C0": _friction("rb", 2, "d", 1, 4), "friction_rb_d_tp_C0": _friction("rb", 3, "d", 1, 5),
 }
 
+# ----------------------------------------------------------------------------------------------------------------------
+# Rods. stark/src/models/deformables/line/EnergySegmentStrain.cpp:11-55 (complete), :57-88 (elasticity only)
+# bindings: v1[2]*, x0[2], X[2], scale, section_radius, youngs_modulus, [strain_damping, strain_limit, strain_limit_stiffness,] dt
+def _segment_strain(b, full):
+    v1, x0, X = b[0:2], b[2:4], b[4:6]
+    (scale_,), (radius,), (youngs,) = b[6:9]
+    if full:
+        (damping,), (strain_limit,), (sl_k,), (dt,) = b[9:13]
+    else:
+        (dt,) = b[9]
+    x1 = [_x1(x0[i], v1[i], dt) for i in range(2)]
+    Xs = [scale(scale_, X[i]) for i in range(2)]
+    section_area = np.pi * radius ** 2
+    l_rest = norm(sub(Xs[0], Xs[1]))
+    l = norm(sub(x1[0], x1[1]))
+    e = (l - l_rest) / l_rest
+    volume = section_area * l_rest
+    E = volume * youngs * e.powN(2) / 2.0
+    if full:
+        over = e - strain_limit
+        E = E + where(over.v > 0.0, volume * sl_k * over.powN(3) / 3.0, 0.0)
+        l0 = norm(sub(x0[1], x0[0]))
+        e0 = (l0 - l_rest) / l_rest
+        E = E + dt * damping * ((e - e0) / dt).powN(2) / 2.0
+    return E
+
+
+def EnergySegmentStrain(b):
+    return _segment_strain(b, True)
+
+
+def EnergySegmentStrain_Elasticity_Only(b):
+    return _segment_strain(b, False)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Attachments. stark/src/models/interactions/EnergyAttachments.cpp:17-35, 37-60, 62-85, 87-111, 113-135
+def EnergyAttachments_d_d_p_p(b):
+    v1a, v1b, x0a, x0b, (k,), (dt,) = b
+    return 0.5 * k * sqnorm(sub(_x1(x0b, v1b, dt), _x1(x0a, v1a, dt)))
+
+
+def _comb(w, pts):
+    out = scale(w[0], pts[0])
+    for wi, pi in zip(w[1:], pts[1:]):
+        out = add(out, scale(wi, pi))
+    return out
+
+
+def EnergyAttachments_d_d_p_e(b):
+    v1, x0, bary, (k,), (dt,) = b[0:3], b[3:6], b[6], b[7], b[8]
+    x1 = [_x1(x0[i], v1[i], dt) for i in range(3)]
+    return 0.5 * k * sqnorm(sub(_comb(bary, x1[1:3]), x1[0]))
+
+
+def EnergyAttachments_d_d_p_t(b):
+    v1, x0, bary, (k,), (dt,) = b[0:4], b[4:8], b[8], b[9], b[10]
+    x1 = [_x1(x0[i], v1[i], dt) for i in range(4)]
+    return 0.5 * k * sqnorm(sub(_comb(bary, x1[1:4]), x1[0]))
+
+
+def EnergyAttachments_d_d_e_e(b):
+    v1, x0, bary_0, bary_1, (k,), (dt,) = b[0:4], b[4:8], b[8], b[9], b[10], b[11]
+    x1 = [_x1(x0[i], v1[i], dt) for i in range(4)]
+    return 0.5 * k * sqnorm(sub(_comb(bary_1, x1[2:4]), _comb(bary_0, x1[0:2])))
+
+
+def EnergyAttachments_rb_d(b):
+    (k,), (dt,), v1_d, x0_d, x_loc, v1, w1, t0, q0 = b
+    x1_rb = _rb_x1(v1, w1, t0, q0, x_loc, dt)
+    return 0.5 * k * sqnorm(sub(_x1(x0_d, v1_d, dt), x1_rb))
+
+
 REGISTRY = {f.__name__: f for f in [
     EnergyLumpedInertia, EnergyPrescribedPositions, EnergyTetStrain, EnergyTetStrain_Elasticity_Only,
     EnergyTriangleStrain, EnergyTriangleStrain_Elasticity_Only, EnergyDiscreteShells, EnergyBendingFlat,
     EnergyRigidBodyInertia_Linear, EnergyRigidBodyInertia_Angular, rb_constraint_global_points, rb_constraint_global_directions,
     rb_constraint_points, rb_constraint_point_on_axis, rb_constraint_distances, rb_constraint_distance_limits, rb_constraint_directions,
     rb_constraint_angle_limits, rb_constraint_damped_spring, rb_constraint_linear_velocity, rb_constraint_angular_velocity,
+    EnergySegmentStrain, EnergySegmentStrain_Elasticity_Only, EnergyAttachments_d_d_p_p, EnergyAttachments_d_d_p_e, EnergyAttachments_d_d_p_t,
+    EnergyAttachments_d_d_e_e, EnergyAttachments_rb_d,
 ]}
 REGISTRY.update(_CONTACT)

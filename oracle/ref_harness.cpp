@@ -451,8 +451,81 @@ static Scene scene_blockbox(const Args& a)
     return sc;
 }
 
+// Rods + attachments: a cloth hanging from two rods (complete / elasticity-only segment strain) by a
+// point-point and a point-edge attachment, a free rod riding on the cloth (point-triangle and edge-edge attachments) and a free
+// rigid box hanging from the cloth's far edge (rigid-deformable attachments). No contact.
+static Scene scene_attachzoo(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "attachzoo");
+    settings.simulation.init_frictional_contact = false;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const int n = a.i("n", 6);
+    const double d = a.d("size", 0.4), hd = 0.5 * d, h = d / n;
+    const double k = a.d("k", 1e4), tol = a.d("tol", std::numeric_limits<double>::max());
+    auto [cV, cT, cloth] = sim.presets->deformables->add_surface_grid("cloth", { d, d }, { n, n }, stark::Surface::Params::Cotton_Fabric());
+    auto find = [&](double x, double y) {
+        int best = 0;
+        for (int i = 0; i < (int)cV.size(); i++)
+            if ((cV[i] - Eigen::Vector3d(x, y, 0.0)).norm() < (cV[best] - Eigen::Vector3d(x, y, 0.0)).norm()) best = i;
+        return best;
+    };
+    auto bc = stark::EnergyPrescribedPositions::Params().set_stiffness(1e6);
+    auto att = stark::EnergyAttachments::Params().set_stiffness(k).set_tolerance(tol);
+
+    // rod A: complete model, hangs the corner (-hd, -hd) by a point-point attachment
+    auto lpA = stark::Line::Params::Elastic_Rubberband();
+    lpA.strain.strain_limit = a.d("rod_strain_limit", 0.01);
+    lpA.strain.damping = a.d("rod_damping", 1e-3);
+    auto [aV, aS, rodA] = sim.presets->deformables->add_line_as_segments("rodA", { -hd, -hd, 0.3 }, { -hd, -hd, 0.0 }, 5, lpA);
+    sim.deformables->prescribed_positions->add(rodA.point_set, { 0 }, bc);
+    sim.interactions->attachments->add(rodA.point_set, cloth.point_set, std::vector<int>{ 5 }, std::vector<int>{ find(-hd, -hd) }, att);
+
+    // rod B: elasticity only, ends on the boundary edge next to the corner (hd, -hd): point-edge attachment
+    auto lpB = stark::Line::Params::Elastic_Rubberband();
+    lpB.strain.elasticity_only = true;
+    const int e0 = find(hd, -hd), e1 = find(hd - h, -hd);
+    const Eigen::Vector3d endB = 0.3 * cV[e0] + 0.7 * cV[e1];
+    auto [bV, bS, rodB] = sim.presets->deformables->add_line_as_segments("rodB", endB + Eigen::Vector3d(0.0, 0.0, 0.3), endB, 4, lpB);
+    sim.deformables->prescribed_positions->add(rodB.point_set, { 0 }, bc);
+    sim.interactions->attachments->add(rodB.point_set, cloth.point_set, std::vector<int>{ 4 }, std::vector<std::array<int, 2>>{ { e0, e1 } }, std::vector<std::array<double, 2>>{ { 0.3, 0.7 } }, att);
+
+    // rod C: free, lies on the cloth; one end sits in a triangle, one segment is tied to a cloth edge
+    const std::array<int, 3> tri = cT[cT.size() / 2];
+    const Eigen::Vector3d pC = 0.2 * cV[tri[0]] + 0.3 * cV[tri[1]] + 0.5 * cV[tri[2]];
+    auto lpC = stark::Line::Params::Elastic_Rubberband();
+    auto [rV, rS, rodC] = sim.presets->deformables->add_line_as_segments("rodC", pC, pC + Eigen::Vector3d(3.0 * h, 0.7 * h, 0.0), 3, lpC);
+    sim.interactions->attachments->add(rodC.point_set, cloth.point_set, std::vector<int>{ 0 }, std::vector<std::array<int, 3>>{ tri }, std::vector<std::array<double, 3>>{ { 0.2, 0.3, 0.5 } }, att);
+    {
+        const Eigen::Vector3d mid = 0.5 * (rV[2] + rV[3]);
+        const int q0 = find(mid.x(), mid.y());
+        const int q1 = find(cV[q0].x() + h, cV[q0].y());
+        sim.interactions->attachments->add(rodC.point_set, cloth.point_set, std::vector<std::array<int, 2>>{ { 2, 3 } }, std::vector<std::array<int, 2>>{ { q0, q1 } }, std::vector<std::array<double, 2>>{ { 0.5, 0.5 } },
+                                           std::vector<std::array<double, 2>>{ { 0.4, 0.6 } }, att);
+    }
+
+    // free rigid box hanging from the cloth's y = +hd edge
+    const double bs = a.d("box", 0.15);
+    auto [xV, xT, box] = sim.presets->rigidbodies->add_box("box", a.d("box_mass", 0.3), bs);
+    box.rigidbody.add_rotation(10.0, Eigen::Vector3d::UnitX());
+    box.rigidbody.add_translation({ 0.0, hd + 0.5 * bs, 0.0 });
+    std::vector<int> edge_points;
+    for (int i = 0; i < (int)cV.size(); i++)
+        if (std::abs(cV[i].y() - hd) < 1e-9 && std::abs(cV[i].x()) < 0.5 * bs + 1e-9) edge_points.push_back(i);
+    sim.interactions->attachments->add(box.rigidbody, cloth.point_set, edge_points, att);
+
+    std::ostringstream js;
+    js.precision(17);
+    js << "{\"kind\":\"attachzoo\",\"n\":" << n << ",\"size\":" << d << ",\"k\":" << k << ",\"tol\":" << (tol > 1e300 ? -1.0 : tol) << ",\"box\":" << bs
+       << ",\"box_mass\":" << a.d("box_mass", 0.3) << ",\"rod_strain_limit\":" << lpA.strain.strain_limit << ",\"rod_damping\":" << lpA.strain.damping << "}";
+    sc.json = js.str();
+    return sc;
+}
+
 static Scene make_scene(const std::string& name, const Args& a)
 {
+    if (name == "attachzoo") return scene_attachzoo(a);
     if (name == "clothbox") return scene_clothbox(a);
     if (name == "blockbox") return scene_blockbox(a);
     if (name == "contactcorners") return scene_contactcorners(a);

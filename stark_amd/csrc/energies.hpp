@@ -646,6 +646,127 @@ struct E_RBAngularVelocity
     }
 };
 
+// ======================================================================================================================
+// Rods: stark/src/models/deformables/line/EnergySegmentStrain.cpp:11-55 (complete) and :57-88 (elasticity only)
+// bindings: v1[2]*, x0[2], X[2], scale, section_radius, youngs_modulus, [strain_damping, strain_limit, strain_limit_stiffness,] dt
+template <bool FULL>
+struct E_SegmentStrainT
+{
+    using Layout = std::conditional_t<FULL, Strides<3, 3, 3, 3, 3, 3, 1, 1, 1, 1, 1, 1, 1>, Strides<3, 3, 3, 3, 3, 3, 1, 1, 1, 1>>;
+    static constexpr int NB = 2;
+    static constexpr int dof_binding[NB] = {0, 1};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double scale = L.s(18), radius = L.s(19), youngs_modulus = L.s(20);
+        const double damping = FULL ? L.s(21) : 0.0, strain_limit = FULL ? L.s(22) : 0.0, sl_k = FULL ? L.s(23) : 0.0;
+        const double dt = L.s(FULL ? 24 : 21);
+        const V3<double> x00 = L.v(6), x01 = L.v(9);
+        const V3<T> x10 = x00 + dt * L.dof(0, 0), x11 = x01 + dt * L.dof(3, 1);
+        const double l_rest = norm(scale * L.v(12) - scale * L.v(15));
+        const T l = norm(x10 - x11);
+        const T e = (l - l_rest) * (1.0 / l_rest);
+        const double volume = M_PI * radius * radius * l_rest;
+        T E = (0.5 * volume * youngs_modulus) * pow2(e);
+        if constexpr (FULL) {
+            const T over = e - strain_limit;
+            if (val(over) > 0.0) E = E + (volume * sl_k / 3.0) * pow3(over);
+            const double e0 = (norm(x01 - x00) - l_rest) / l_rest;
+            E = E + (0.5 * dt * damping) * pow2((e - e0) * (1.0 / dt));
+        }
+        return E;
+    }
+};
+struct E_SegmentStrain : E_SegmentStrainT<true>
+{
+    static constexpr const char* name = "EnergySegmentStrain";
+};
+struct E_SegmentStrainEO : E_SegmentStrainT<false>
+{
+    static constexpr const char* name = "EnergySegmentStrain_Elasticity_Only";
+};
+
+// ======================================================================================================================
+// Attachments (penalty springs between material points): stark/src/models/interactions/EnergyAttachments.cpp
+// E = k/2 |q - p|^2 with p, q barycentric combinations of end-of-step positions.
+// :17-35   d_d_p_p   bindings: v1[a,b]*, x0[a,b], k[group], dt
+struct E_AttachPP
+{
+    static constexpr const char* name = "EnergyAttachments_d_d_p_p";
+    using Layout = Strides<3, 3, 3, 3, 1, 1>;
+    static constexpr int NB = 2;
+    static constexpr int dof_binding[NB] = {0, 1};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double k = L.s(12), dt = L.s(13);
+        const V3<T> a = L.v(6) + dt * L.dof(0, 0), b = L.v(9) + dt * L.dof(3, 1);
+        return 0.5 * k * sqnorm(b - a);
+    }
+};
+// :37-60   d_d_p_e   bindings: v1[p,e0,e1]*, x0[p,e0,e1], bary[idx] (2), k[group], dt
+struct E_AttachPE
+{
+    static constexpr const char* name = "EnergyAttachments_d_d_p_e";
+    using Layout = Strides<3, 3, 3, 3, 3, 3, 2, 1, 1>;
+    static constexpr int NB = 3;
+    static constexpr int dof_binding[NB] = {0, 1, 2};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double b0 = L.s(18), b1 = L.s(19), k = L.s(20), dt = L.s(21);
+        const V3<T> p = L.v(9) + dt * L.dof(0, 0), e0 = L.v(12) + dt * L.dof(3, 1), e1 = L.v(15) + dt * L.dof(6, 2);
+        return 0.5 * k * sqnorm((b0 * e0 + b1 * e1) - p);
+    }
+};
+// :62-85   d_d_p_t   bindings: v1[p,t0,t1,t2]*, x0[p,t0,t1,t2], bary[idx] (3), k[group], dt
+struct E_AttachPT
+{
+    static constexpr const char* name = "EnergyAttachments_d_d_p_t";
+    using Layout = Strides<3, 3, 3, 3, 3, 3, 3, 3, 3, 1, 1>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {0, 1, 2, 3};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double b0 = L.s(24), b1 = L.s(25), b2 = L.s(26), k = L.s(27), dt = L.s(28);
+        const V3<T> p = L.v(12) + dt * L.dof(0, 0), t0 = L.v(15) + dt * L.dof(3, 1), t1 = L.v(18) + dt * L.dof(6, 2), t2 = L.v(21) + dt * L.dof(9, 3);
+        return 0.5 * k * sqnorm((b0 * t0 + b1 * t1 + b2 * t2) - p);
+    }
+};
+// :87-111  d_d_e_e   bindings: v1[ea0,ea1,eb0,eb1]*, x0[...], bary_0[idx] (2), bary_1[idx] (2), k[group], dt
+struct E_AttachEE
+{
+    static constexpr const char* name = "EnergyAttachments_d_d_e_e";
+    using Layout = Strides<3, 3, 3, 3, 3, 3, 3, 3, 2, 2, 1, 1>;
+    static constexpr int NB = 4;
+    static constexpr int dof_binding[NB] = {0, 1, 2, 3};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double a0 = L.s(24), a1 = L.s(25), b0 = L.s(26), b1 = L.s(27), k = L.s(28), dt = L.s(29);
+        const V3<T> ea0 = L.v(12) + dt * L.dof(0, 0), ea1 = L.v(15) + dt * L.dof(3, 1), eb0 = L.v(18) + dt * L.dof(6, 2), eb1 = L.v(21) + dt * L.dof(9, 3);
+        return 0.5 * k * sqnorm((b0 * eb0 + b1 * eb1) - (a0 * ea0 + a1 * ea1));
+    }
+};
+// :113-135 rb_d      bindings: k[group], dt, v1_d[p]*, x0_d[p], x_loc[idx], body {v1*, w1*, t0, q0_}[rb]
+// local DoF order (DoF sets in registration order): soft.v1 of the point, rigid.v1, rigid.w1
+struct E_AttachRBD
+{
+    static constexpr const char* name = "EnergyAttachments_rb_d";
+    using Layout = Strides<1, 1, 3, 3, 3, 3, 3, 3, 4>;
+    static constexpr int NB = 3;
+    static constexpr int dof_binding[NB] = {2, 5, 6};
+    template <class T>
+    MS_HD static T energy(const Loader<T>& L)
+    {
+        const double k = L.s(0), dt = L.s(1);
+        const V3<T> x1_d = L.v(5) + dt * L.dof(2, 0);
+        const V3<T> x1_rb = rb_point(L, 11, 1, 2, L.v(8), dt);
+        return 0.5 * k * sqnorm(x1_d - x1_rb);
+    }
+};
+
 // element condition: potentials without one are always active
 template <class En, class = void>
 struct HasCond : std::false_type {};

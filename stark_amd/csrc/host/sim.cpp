@@ -1,5 +1,6 @@
 // host/sim.cpp — see sim.hpp. Reference citations are given per function.
 #include "sim.hpp"
+#include "bind.hpp"
 
 #include <chrono>
 #include <cstdio>
@@ -283,27 +284,6 @@ void PointDynamics::upload_state()
 // ======================================================================================================================
 // helpers
 // ======================================================================================================================
-namespace {
-struct BindList
-{
-    std::vector<mistark_binding> b;
-    mistark_ctx* ctx;
-    Stark& stark;
-    BindList(mistark_ctx* c, Stark& s) : ctx(c), stark(s) {}
-    void add(const double* host, int64_t n_items, int stride, int col)
-    {
-        const int id = mistark_array(ctx, host, n_items, stride);
-        stark.check(id);
-        b.push_back({id, stride, col});
-    }
-    void add_id(int id, int stride, int col) { b.push_back({id, stride, col}); }
-    template <std::size_t N>
-    void potential(const char* name, const std::vector<std::array<int32_t, N>>& conn)
-    {
-        stark.check(mistark_potential(ctx, name, conn.empty() ? nullptr : conn[0].data(), (int32_t)conn.size(), (int32_t)N, b.data(), (int32_t)b.size()));
-    }
-};
-}  // namespace
 
 // ======================================================================================================================
 // EnergyLumpedInertia  (stark/src/models/deformables/point/EnergyLumpedInertia.cpp)
@@ -352,6 +332,18 @@ EnergyLumpedInertia::Handler EnergyLumpedInertia::add(const PointSetHandler& set
             nz.push_back(vol[i]);
         }
     return add(set, points, nz, params);
+}
+EnergyLumpedInertia::Handler EnergyLumpedInertia::add(const PointSetHandler& set, const std::vector<std::array<int, 2>>& segments, const Params& params)
+{
+    // EnergyLumpedInertia.cpp:95-115: half of each segment's rest length to either end point
+    std::vector<double> vol(set.size(), 0.0);
+    for (const auto& e : segments) {
+        const auto g = set.get_global_indices(e);
+        const double l = 0.5 * norm(dyn->X[g[0]] - dyn->X[g[1]]);
+        vol[e[0]] += l;
+        vol[e[1]] += l;
+    }
+    return add(set, vol, params);
 }
 EnergyLumpedInertia::Handler EnergyLumpedInertia::add(const PointSetHandler& set, const std::vector<std::array<int, 3>>& tris, const Params& params)
 {
@@ -749,6 +741,7 @@ Deformables::Deformables(Stark& stark, spPointDynamics dyn) : point_sets(dyn)
     // construction order = potential registration order of the reference (stark/src/models/deformables/Deformables.cpp)
     lumped_inertia = std::make_shared<EnergyLumpedInertia>(stark, dyn);
     prescribed_positions = std::make_shared<EnergyPrescribedPositions>(stark, dyn);
+    segment_strain = std::make_shared<EnergySegmentStrain>(stark, dyn);
     triangle_strain = std::make_shared<EnergyTriangleStrain>(stark, dyn);
     discrete_shells = std::make_shared<EnergyDiscreteShells>(stark, dyn);
     tet_strain = std::make_shared<EnergyTetStrain>(stark, dyn);
@@ -850,6 +843,7 @@ Simulation::Simulation(const Settings& settings) : stark(settings)
     deformables = std::make_shared<Deformables>(stark, pd);
     rigidbodies = std::make_shared<RigidBodies>(stark, rbd);
     interactions = std::make_shared<Interactions>();
+    interactions->attachments = std::make_shared<EnergyAttachments>(stark, pd, rbd);  // Interactions.cpp:8-9: attachments, then contact
     interactions->contact = std::make_shared<EnergyFrictionalContact>(stark, pd, rbd);
     presets = std::make_shared<Presets>();
     presets->deformables = std::make_shared<DeformablesPresets>(deformables, interactions);

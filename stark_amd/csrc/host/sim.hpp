@@ -222,6 +222,7 @@ public:
     EnergyLumpedInertia(Stark& stark, spPointDynamics dyn);
     Handler add(const PointSetHandler& set, const std::vector<int>& points, const std::vector<double>& lumped_volume, const Params& params);
     Handler add(const PointSetHandler& set, const std::vector<double>& lumped_volume, const Params& params);
+    Handler add(const PointSetHandler& set, const std::vector<std::array<int, 2>>& segments, const Params& params);
     Handler add(const PointSetHandler& set, const std::vector<std::array<int, 3>>& triangles, const Params& params);
     Handler add(const PointSetHandler& set, const std::vector<std::array<int, 4>>& tets, const Params& params);
     Params get_params(const Handler& h) const;
@@ -266,6 +267,31 @@ private:
     bool targets_dirty = false, stiffness_dirty = false;
     bool _is_converged_state_valid();
     void _before_energy_evaluation();
+};
+
+// stark::EnergySegmentStrain (stark/src/models/deformables/line/EnergySegmentStrain.*): rods
+class EnergySegmentStrain : public Registrable
+{
+public:
+    struct Params
+    {
+        bool elasticity_only = false;
+        double scale = 1.0, section_radius = 5e-3, youngs_modulus = 1e3, damping = 0.0;
+        double strain_limit = std::numeric_limits<double>::max(), strain_limit_stiffness = 1e3;
+    };
+    MISTARK_HANDLER(EnergySegmentStrain, Params)
+    EnergySegmentStrain(Stark& stark, spPointDynamics dyn);
+    Handler add(const PointSetHandler& set, const std::vector<std::array<int, 2>>& segments, const Params& params);
+    Params get_params(const Handler& h) const;
+    void set_params(const Handler& h, const Params& p);
+    void register_potentials(mistark_ctx* ctx) override;
+
+private:
+    Stark& stark;
+    spPointDynamics dyn;
+    std::vector<std::array<int32_t, 4>> conn_elasticity_only, conn_complete;  // idx, group, i, j
+    std::vector<char> elasticity_only;
+    std::vector<double> scale, section_radius, youngs_modulus, strain_damping, strain_limit, strain_limit_stiffness;
 };
 
 class EnergyTetStrain : public Registrable
@@ -566,8 +592,54 @@ private:
     bool _should_continue_execution();
 };
 using ContactHandler = EnergyFrictionalContact::Handler;
+
+// ---- stark::EnergyAttachments (stark/src/models/interactions/EnergyAttachments.*) ------------------------------------------------------
+// Penalty springs gluing material points: deformable point to point / edge / triangle, edge to edge, and rigid body to deformable point.
+class EnergyAttachments : public Registrable
+{
+public:
+    struct Params
+    {
+        double stiffness = 1e3;
+        double tolerance = std::numeric_limits<double>::max();
+    };
+    MISTARK_HANDLER(EnergyAttachments, Params)
+    EnergyAttachments(Stark& stark, spPointDynamics dyn, spRigidBodyDynamics rb);
+    Handler add(const PointSetHandler& set_0, const PointSetHandler& set_1, const std::vector<int>& points_0, const std::vector<int>& points_1, const Params& params);
+    Handler add(const PointSetHandler& set_0, const PointSetHandler& set_1, const std::vector<int>& points, const std::vector<std::array<int, 2>>& edges,
+                const std::vector<std::array<double, 2>>& bary, const Params& params);
+    Handler add(const PointSetHandler& set_0, const PointSetHandler& set_1, const std::vector<int>& points, const std::vector<std::array<int, 3>>& triangles,
+                const std::vector<std::array<double, 3>>& bary, const Params& params);
+    Handler add(const PointSetHandler& set_0, const PointSetHandler& set_1, const std::vector<std::array<int, 2>>& edges_0, const std::vector<std::array<int, 2>>& edges_1,
+                const std::vector<std::array<double, 2>>& bary_0, const std::vector<std::array<double, 2>>& bary_1, const Params& params);
+    Handler add(const RigidBodyHandler& rb, const PointSetHandler& set, const std::vector<Vec3>& rb_points_loc, const std::vector<int>& set_points, const Params& params);
+    Handler add(const RigidBodyHandler& rb, const PointSetHandler& set, const std::vector<int>& points, const Params& params);
+    Params get_params(const Handler& h) const;
+    void set_params(const Handler& h, const Params& p);
+    void register_potentials(mistark_ctx* ctx) override;
+
+private:
+    enum Type { PointPoint = 0, PointEdge, PointTriangle, EdgeEdge, RigidDeformable, N_TYPES };
+    Stark& stark;
+    spPointDynamics dyn;
+    spRigidBodyDynamics rb;
+    std::vector<std::array<int32_t, 3>> conn_p_p;  // group, a, b
+    std::vector<std::array<int32_t, 5>> conn_p_e;  // idx, group, p, e0, e1
+    std::vector<std::array<int32_t, 6>> conn_p_t;  // idx, group, p, t0, t1, t2
+    std::vector<std::array<int32_t, 6>> conn_e_e;  // idx, group, ea0, ea1, eb0, eb1
+    std::vector<std::array<int32_t, 4>> conn_rb_d; // idx, group, rb, p
+    std::vector<std::array<double, 2>> bary_p_e, bary_e_e_0, bary_e_e_1;
+    std::vector<std::array<double, 3>> bary_p_t;
+    std::vector<Vec3> rb_points_loc;
+    std::vector<double> stiffness[N_TYPES], tolerance[N_TYPES];  // per group
+    int id_stiffness[N_TYPES] = {-1, -1, -1, -1, -1};
+    std::vector<std::pair<int, int>> handlers_map;  // handler -> (type, group)
+    Handler new_handler(int type, const Params& params, int& group);
+    bool _is_converged_state_valid();
+};
 struct Interactions
 {
+    std::shared_ptr<EnergyAttachments> attachments;
     std::shared_ptr<EnergyFrictionalContact> contact;
 };
 
@@ -577,12 +649,35 @@ struct Deformables
     spPointDynamics point_sets;
     std::shared_ptr<EnergyLumpedInertia> lumped_inertia;
     std::shared_ptr<EnergyPrescribedPositions> prescribed_positions;
+    std::shared_ptr<EnergySegmentStrain> segment_strain;
     std::shared_ptr<EnergyTriangleStrain> triangle_strain;
     std::shared_ptr<EnergyDiscreteShells> discrete_shells;
     std::shared_ptr<EnergyTetStrain> tet_strain;
     Deformables(Stark& stark, spPointDynamics dyn);
 };
 
+namespace Line {
+struct Params
+{
+    EnergyLumpedInertia::Params inertia;
+    EnergySegmentStrain::Params strain;
+    EnergyFrictionalContact::Params contact;
+    static Params Elastic_Rubberband();  // stark/src/models/presets/deformables_preset_types.cpp:17-37
+};
+struct Handler
+{
+    PointSetHandler point_set;
+    EnergyLumpedInertia::Handler inertia;
+    EnergySegmentStrain::Handler strain;
+    ContactHandler contact;
+};
+struct VCH
+{
+    std::vector<Vec3> vertices;
+    std::vector<std::array<int, 2>> segments;
+    Handler handler;
+};
+}  // namespace Line
 namespace Surface {
 struct Params
 {
@@ -651,6 +746,8 @@ class DeformablesPresets
 
 public:
     DeformablesPresets(std::shared_ptr<Deformables> d, std::shared_ptr<Interactions> i) : deformables(d), interactions(i) {}
+    Line::Handler add_line(const std::string& label, const std::vector<Vec3>& vertices, const std::vector<std::array<int, 2>>& segments, const Line::Params& params);
+    Line::VCH add_line_as_segments(const std::string& label, const Vec3& begin, const Vec3& end, int n_segments, const Line::Params& params);
     Surface::Handler add_surface(const std::string& label, const std::vector<Vec3>& vertices, const std::vector<std::array<int, 3>>& triangles, const Surface::Params& params);
     Surface::VCH add_surface_grid(const std::string& label, const std::array<double, 2>& dim, const std::array<int, 2>& subdivisions, const Surface::Params& params);
     Volume::Handler add_volume(const std::string& label, const std::vector<Vec3>& vertices, const std::vector<std::array<int, 4>>& tets, const Volume::Params& params);

@@ -10,6 +10,7 @@ struct mistark_sim
 {
     std::unique_ptr<Simulation> sim;
     std::vector<PointSetHandler> sets;
+    std::vector<EnergyAttachments::Handler> attachments;
     std::vector<int> set_group;  // contact group of each point set (-1: none)
     std::vector<RigidBodyHandler> bodies;
     std::vector<int> body_group;
@@ -65,6 +66,15 @@ static Surface::Params to_cpp(const mistark_surface_params& p)
     q.bending.damping = p.bending_damping;
     q.bending.flat_rest_angle = p.flat_rest_angle != 0;
     return q;
+}
+
+template <std::size_t N, class T>
+static std::vector<std::array<T, N>> rows(const T* p, int64_t n)
+{
+    std::vector<std::array<T, N>> out((size_t)n);
+    for (int64_t i = 0; i < n; i++)
+        for (std::size_t k = 0; k < N; k++) out[i][k] = p[N * i + k];
+    return out;
 }
 
 extern "C" {
@@ -219,6 +229,117 @@ static RigidBodyHandler& the_body(mistark_sim* s, int rb)
 {
     if (rb < 0 || rb >= (int)s->bodies.size()) throw std::runtime_error("bad rigid body");
     return s->bodies[rb];
+}
+int mistark_sim_prescribe_points(mistark_sim* s, int ps, const int32_t* points, int64_t n, double stiffness, double tolerance)
+{
+    SIM_BEGIN
+    EnergyPrescribedPositions::Params p;
+    p.stiffness = stiffness;
+    p.tolerance = tolerance > 0.0 ? tolerance : std::numeric_limits<double>::max();
+    _ret = s->sim->deformables->prescribed_positions->add(the_set(s, ps), std::vector<int>(points, points + n), p).get_idx();
+    SIM_END
+}
+// ---- rods ----------------------------------------------------------------------------------------------------------------
+void mistark_line_params_elastic_rubberband(mistark_line_params* o)
+{
+    const Line::Params p = Line::Params::Elastic_Rubberband();
+    *o = mistark_line_params{p.inertia.density, p.inertia.damping, p.inertia.quasistatic ? 1 : 0, p.strain.elasticity_only ? 1 : 0, p.strain.scale, p.strain.section_radius,
+                             p.strain.youngs_modulus, p.strain.damping, p.strain.strain_limit, p.strain.strain_limit_stiffness};
+}
+static Line::Params to_cpp(const mistark_line_params& c)
+{
+    Line::Params p;
+    p.inertia.density = c.density;
+    p.inertia.damping = c.inertia_damping;
+    p.inertia.quasistatic = c.quasistatic != 0;
+    p.strain.elasticity_only = c.elasticity_only != 0;
+    p.strain.scale = c.scale;
+    p.strain.section_radius = c.section_radius;
+    p.strain.youngs_modulus = c.youngs_modulus;
+    p.strain.damping = c.strain_damping;
+    p.strain.strain_limit = c.strain_limit;
+    p.strain.strain_limit_stiffness = c.strain_limit_stiffness;
+    return p;
+}
+int mistark_sim_add_line(mistark_sim* s, const char* label, const double* v, int64_t nv, const int32_t* seg, int64_t ns, const mistark_line_params* p)
+{
+    SIM_BEGIN
+    std::vector<Vec3> V((size_t)nv);
+    std::vector<std::array<int, 2>> S((size_t)ns);
+    for (int64_t i = 0; i < nv; i++) V[i] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+    for (int64_t i = 0; i < ns; i++) S[i] = {seg[2 * i], seg[2 * i + 1]};
+    auto h = s->sim->presets->deformables->add_line(label ? label : "", V, S, to_cpp(*p));
+    s->sets.push_back(h.point_set);
+    s->set_group.push_back(h.contact.get_idx());
+    _ret = (int)s->sets.size() - 1;
+    SIM_END
+}
+int mistark_sim_add_line_as_segments(mistark_sim* s, const char* label, const double begin[3], const double end[3], int32_t n_segments, const mistark_line_params* p)
+{
+    SIM_BEGIN
+    auto vch = s->sim->presets->deformables->add_line_as_segments(label ? label : "", v3(begin), v3(end), n_segments, to_cpp(*p));
+    s->sets.push_back(vch.handler.point_set);
+    s->set_group.push_back(vch.handler.contact.get_idx());
+    _ret = (int)s->sets.size() - 1;
+    SIM_END
+}
+// ---- attachments ---------------------------------------------------------------------------------------------------------
+static EnergyAttachments::Params attachment_params(double stiffness, double tolerance)
+{
+    return EnergyAttachments::Params{stiffness, tolerance > 0.0 ? tolerance : std::numeric_limits<double>::max()};
+}
+static int keep(mistark_sim* s, const EnergyAttachments::Handler& h)
+{
+    s->attachments.push_back(h);
+    return (int)s->attachments.size() - 1;
+}
+int mistark_sim_attach_point_point(mistark_sim* s, int s0, int s1, const int32_t* p0, const int32_t* p1, int64_t n, double k, double tol)
+{
+    SIM_BEGIN
+    _ret = keep(s, s->sim->interactions->attachments->add(the_set(s, s0), the_set(s, s1), std::vector<int>(p0, p0 + n), std::vector<int>(p1, p1 + n), attachment_params(k, tol)));
+    SIM_END
+}
+int mistark_sim_attach_point_edge(mistark_sim* s, int s0, int s1, const int32_t* pts, const int32_t* edges, const double* bary, int64_t n, double k, double tol)
+{
+    SIM_BEGIN
+    _ret = keep(s, s->sim->interactions->attachments->add(the_set(s, s0), the_set(s, s1), std::vector<int>(pts, pts + n), rows<2, int>(edges, n), rows<2, double>(bary, n),
+                                                          attachment_params(k, tol)));
+    SIM_END
+}
+int mistark_sim_attach_point_triangle(mistark_sim* s, int s0, int s1, const int32_t* pts, const int32_t* tris, const double* bary, int64_t n, double k, double tol)
+{
+    SIM_BEGIN
+    _ret = keep(s, s->sim->interactions->attachments->add(the_set(s, s0), the_set(s, s1), std::vector<int>(pts, pts + n), rows<3, int>(tris, n), rows<3, double>(bary, n),
+                                                          attachment_params(k, tol)));
+    SIM_END
+}
+int mistark_sim_attach_edge_edge(mistark_sim* s, int s0, int s1, const int32_t* e0, const int32_t* e1, const double* b0, const double* b1, int64_t n, double k, double tol)
+{
+    SIM_BEGIN
+    _ret = keep(s, s->sim->interactions->attachments->add(the_set(s, s0), the_set(s, s1), rows<2, int>(e0, n), rows<2, int>(e1, n), rows<2, double>(b0, n), rows<2, double>(b1, n),
+                                                          attachment_params(k, tol)));
+    SIM_END
+}
+int mistark_sim_attach_rigid_body(mistark_sim* s, int rb, int ps, const double* loc, const int32_t* pts, int64_t n, double k, double tol)
+{
+    SIM_BEGIN
+    const std::vector<int> points(pts, pts + n);
+    auto att = s->sim->interactions->attachments;
+    if (loc) {
+        std::vector<Vec3> L((size_t)n);
+        for (int64_t i = 0; i < n; i++) L[i] = v3(loc + 3 * i);
+        _ret = keep(s, att->add(the_body(s, rb), the_set(s, ps), L, points, attachment_params(k, tol)));
+    } else {
+        _ret = keep(s, att->add(the_body(s, rb), the_set(s, ps), points, attachment_params(k, tol)));
+    }
+    SIM_END
+}
+int mistark_sim_attachment_stiffness(mistark_sim* s, int handler, double* stiffness)
+{
+    SIM_BEGIN
+    if (handler < 0 || handler >= (int)s->attachments.size()) throw std::runtime_error("bad attachment handler");
+    *stiffness = s->attachments[handler].get_params().stiffness;
+    SIM_END
 }
 int mistark_sim_point_set_add_displacement(mistark_sim* s, int ps, const double d[3])
 {

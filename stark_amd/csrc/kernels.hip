@@ -1136,7 +1136,11 @@ __device__ __forceinline__ void spmv_static(const int bid, const int nblk, const
     // previous wavefront drops its open tail. Every row is written exactly once: no atomics, no zero-fill, deterministic.
     const int64_t n_waves = (int64_t)nblk * 4;
     const int64_t tpw = (ntiles + n_waves - 1) / n_waves;
-    const int64_t gw = (int64_t)bid * 4 + wave;
+    // XCD-aware placement: consecutive workgroup ids land on different XCDs (round robin over the 8 dies, each with its own L2).
+    // Give every XCD one contiguous eighth of the tiles, so that the x entries its rows gather (a band around the diagonal) are
+    // shared through that die's L2 instead of being fetched by all eight.
+    const int pbid = (V != 5 && (nblk & 7) == 0) ? (bid & 7) * (nblk >> 3) + (bid >> 3) : bid;
+    const int64_t gw = (int64_t)pbid * 4 + wave;
     const int64_t t_begin = gw * tpw, t_end = (t_begin + tpw < ntiles) ? t_begin + tpw : ntiles;
     int64_t t_lead = t_begin;
     if (t_begin < t_end) {

@@ -25,4 +25,11 @@
     X(E_RBDampedSpring)            \
     X(E_RBLinearVelocity)          \
     X(E_RBAngularVelocity)         \
+    X(E_SegmentStrain)             \
+    X(E_SegmentStrainEO)           \
+    X(E_AttachPP)                  \
+    X(E_AttachPE)                  \
+    X(E_AttachPT)                  \
+    X(E_AttachEE)                  \
+    X(E_AttachRBD)                 \
     MISTARK_FOR_EACH_CONTACT_ENERGY(X)

@@ -27,6 +27,12 @@ class SurfaceParams(C.Structure):
                 ("bending_damping", C.c_double), ("flat_rest_angle", C.c_int32)]
 
 
+class LineParams(C.Structure):
+    _fields_ = [("density", C.c_double), ("inertia_damping", C.c_double), ("quasistatic", C.c_int32), ("elasticity_only", C.c_int32), ("scale", C.c_double),
+                ("section_radius", C.c_double), ("youngs_modulus", C.c_double), ("strain_damping", C.c_double), ("strain_limit", C.c_double),
+                ("strain_limit_stiffness", C.c_double)]
+
+
 class ContactGlobalParams(C.Structure):
     _fields_ = [("default_contact_thickness", C.c_double), ("min_contact_stiffness", C.c_double), ("max_contact_stiffness", C.c_double),
                 ("friction_stick_slide_threshold", C.c_double), ("collisions_enabled", C.c_int32), ("friction_enabled", C.c_int32),
@@ -65,6 +71,17 @@ def _lib():
         L.mistark_sim_add_surface_grid.argtypes = [p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(SurfaceParams)]
         L.mistark_sim_add_surface.argtypes = [p, C.c_char_p, p, C.c_int64, p, C.c_int64, C.POINTER(SurfaceParams)]
         L.mistark_sim_prescribe_inside_aabb.argtypes = [p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double]
+        L.mistark_sim_prescribe_points.argtypes = [p, C.c_int, p, C.c_int64, C.c_double, C.c_double]
+        L.mistark_line_params_elastic_rubberband.argtypes = [C.POINTER(LineParams)]
+        L.mistark_line_params_elastic_rubberband.restype = None
+        L.mistark_sim_add_line.argtypes = [p, C.c_char_p, p, C.c_int64, p, C.c_int64, C.POINTER(LineParams)]
+        L.mistark_sim_add_line_as_segments.argtypes = [p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32, C.POINTER(LineParams)]
+        L.mistark_sim_attach_point_point.argtypes = [p, C.c_int, C.c_int, p, p, C.c_int64, C.c_double, C.c_double]
+        L.mistark_sim_attach_point_edge.argtypes = [p, C.c_int, C.c_int, p, p, p, C.c_int64, C.c_double, C.c_double]
+        L.mistark_sim_attach_point_triangle.argtypes = [p, C.c_int, C.c_int, p, p, p, C.c_int64, C.c_double, C.c_double]
+        L.mistark_sim_attach_edge_edge.argtypes = [p, C.c_int, C.c_int, p, p, p, p, C.c_int64, C.c_double, C.c_double]
+        L.mistark_sim_attach_rigid_body.argtypes = [p, C.c_int, C.c_int, p, p, C.c_int64, C.c_double, C.c_double]
+        L.mistark_sim_attachment_stiffness.argtypes = [p, C.c_int, C.POINTER(C.c_double)]
         L.mistark_sim_run_one_step.argtypes = [p]
         L.mistark_sim_set_newton_settings.argtypes = [p, C.POINTER(capi.NewtonSettings)]
         L.mistark_sim_prepare.argtypes = [p]
@@ -112,6 +129,12 @@ def soft_rubber() -> VolumeParams:
 def cotton_fabric() -> SurfaceParams:
     p = SurfaceParams()
     _lib().mistark_surface_params_cotton_fabric(C.byref(p))
+    return p
+
+
+def elastic_rubberband() -> LineParams:
+    p = LineParams()
+    _lib().mistark_line_params_elastic_rubberband(C.byref(p))
     return p
 
 
@@ -175,6 +198,48 @@ class Simulation:
         v = np.ascontiguousarray(vertices, dtype=np.float64)
         t = np.ascontiguousarray(triangles, dtype=np.int32)
         return self._ck(self.L.mistark_sim_add_surface(self.h, label.encode(), v.ctypes.data, len(v), t.ctypes.data, len(t), C.byref(params)))
+
+    def add_line(self, label, vertices, segments, params: LineParams) -> int:
+        v = np.ascontiguousarray(vertices, dtype=np.float64)
+        t = np.ascontiguousarray(segments, dtype=np.int32)
+        return self._ck(self.L.mistark_sim_add_line(self.h, label.encode(), v.ctypes.data, len(v), t.ctypes.data, len(t), C.byref(params)))
+
+    def add_line_as_segments(self, label, begin, end, n_segments, params: LineParams) -> int:
+        return self._ck(self.L.mistark_sim_add_line_as_segments(self.h, label.encode(), _d3(begin), _d3(end), int(n_segments), C.byref(params)))
+
+    def prescribe_points(self, point_set, points, stiffness, tolerance=0.0) -> int:
+        pts = np.ascontiguousarray(points, dtype=np.int32)
+        return self._ck(self.L.mistark_sim_prescribe_points(self.h, point_set, pts.ctypes.data, len(pts), stiffness, tolerance))
+
+    # EnergyAttachments::add overloads; indices are local to their point set, tolerance <= 0 = none; return the handler index
+    def attach_point_point(self, set_0, set_1, points_0, points_1, stiffness, tolerance=0.0) -> int:
+        a, b = np.ascontiguousarray(points_0, dtype=np.int32), np.ascontiguousarray(points_1, dtype=np.int32)
+        return self._ck(self.L.mistark_sim_attach_point_point(self.h, set_0, set_1, a.ctypes.data, b.ctypes.data, len(a), stiffness, tolerance))
+
+    def attach_point_edge(self, set_0, set_1, points, edges, bary, stiffness, tolerance=0.0) -> int:
+        a, e = np.ascontiguousarray(points, dtype=np.int32), np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+        w = np.ascontiguousarray(bary, dtype=np.float64).reshape(-1, 2)
+        return self._ck(self.L.mistark_sim_attach_point_edge(self.h, set_0, set_1, a.ctypes.data, e.ctypes.data, w.ctypes.data, len(a), stiffness, tolerance))
+
+    def attach_point_triangle(self, set_0, set_1, points, triangles, bary, stiffness, tolerance=0.0) -> int:
+        a, t = np.ascontiguousarray(points, dtype=np.int32), np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        w = np.ascontiguousarray(bary, dtype=np.float64).reshape(-1, 3)
+        return self._ck(self.L.mistark_sim_attach_point_triangle(self.h, set_0, set_1, a.ctypes.data, t.ctypes.data, w.ctypes.data, len(a), stiffness, tolerance))
+
+    def attach_edge_edge(self, set_0, set_1, edges_0, edges_1, bary_0, bary_1, stiffness, tolerance=0.0) -> int:
+        e0, e1 = np.ascontiguousarray(edges_0, dtype=np.int32).reshape(-1, 2), np.ascontiguousarray(edges_1, dtype=np.int32).reshape(-1, 2)
+        w0, w1 = np.ascontiguousarray(bary_0, dtype=np.float64).reshape(-1, 2), np.ascontiguousarray(bary_1, dtype=np.float64).reshape(-1, 2)
+        return self._ck(self.L.mistark_sim_attach_edge_edge(self.h, set_0, set_1, e0.ctypes.data, e1.ctypes.data, w0.ctypes.data, w1.ctypes.data, len(e0), stiffness, tolerance))
+
+    def attach_rigid_body(self, rb, point_set, points, stiffness, tolerance=0.0, rb_points_loc=None) -> int:
+        a = np.ascontiguousarray(points, dtype=np.int32)
+        loc = None if rb_points_loc is None else np.ascontiguousarray(rb_points_loc, dtype=np.float64).reshape(-1, 3)
+        return self._ck(self.L.mistark_sim_attach_rigid_body(self.h, rb, point_set, None if loc is None else loc.ctypes.data, a.ctypes.data, len(a), stiffness, tolerance))
+
+    def attachment_stiffness(self, handler) -> float:
+        k = C.c_double()
+        self._ck(self.L.mistark_sim_attachment_stiffness(self.h, handler, C.byref(k)))
+        return k.value
 
     def point_set_add_displacement(self, ps, d):
         self._ck(self.L.mistark_sim_point_set_add_displacement(self.h, ps, _d3(d)))

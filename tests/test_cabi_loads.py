@@ -30,7 +30,7 @@ def test_host_only_entry_points_work_without_gpu():
         covered = e.value
     assert covered == 998976
     assert L.mistark_shard_range(10, 3, 2, C.byref(b), C.byref(e)) < 0
-    assert L.mistark_n_supported_potentials() == 56
+    assert L.mistark_n_supported_potentials() == 63
     stride = C.c_int32()
     assert L.mistark_contact_recipe(b"contact_rb_d_pt_tp_cubic", C.byref(stride), None, None, None) == 14 and stride.value == 7
 

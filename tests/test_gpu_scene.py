@@ -220,3 +220,121 @@ def test_block_on_box_contact_trajectory(name):
         _run_and_compare(sim, z, traj, tol=1e-3, its_slack=2)
     assert sim.contact_info()["n_contacts"] > 0
     sim.close()
+
+
+def _attachzoo(S, sc):
+    """The attachzoo scene of oracle/ref_harness.cpp through the host layer: cloth hanging from two rods (point-point and point-edge
+    attachments), a free rod riding on it (point-triangle, edge-edge) and a free rigid box hanging from its far edge (rigid-deformable)."""
+    st = S.default_settings()
+    st.init_frictional_contact = 0
+    sim = S.Simulation(st)
+    n, d = sc["n"], sc["size"]
+    hd, h = 0.5 * d, d / sc["n"]
+    k, tol = sc["k"], sc["tol"]
+    cloth = sim.add_surface_grid("cloth", (d, d), (n, n), S.cotton_fabric())
+    cV = sim.points("X").copy()
+    nc = len(cV)
+
+    def find(x, y):
+        return int(np.argmin(np.linalg.norm(cV - np.array([x, y, 0.0]), axis=1)))
+
+    lpA = S.elastic_rubberband()
+    lpA.strain_limit = sc["rod_strain_limit"]
+    lpA.strain_damping = sc["rod_damping"]
+    rodA = sim.add_line_as_segments("rodA", (-hd, -hd, 0.3), (-hd, -hd, 0.0), 5, lpA)
+    sim.prescribe_points(rodA, [0], 1e6)
+    hA = sim.attach_point_point(rodA, cloth, [5], [find(-hd, -hd)], k, tol)
+
+    lpB = S.elastic_rubberband()
+    lpB.elasticity_only = 1
+    e0, e1 = find(hd, -hd), find(hd - h, -hd)
+    endB = 0.3 * cV[e0] + 0.7 * cV[e1]
+    rodB = sim.add_line_as_segments("rodB", endB + np.array([0.0, 0.0, 0.3]), endB, 4, lpB)
+    sim.prescribe_points(rodB, [0], 1e6)
+    sim.attach_point_edge(rodB, cloth, [4], [[e0, e1]], [[0.3, 0.7]], k, tol)
+    return sim, cloth, cV, nc, find, h, hd, k, tol, hA
+
+
+def _attachzoo_full(S, sc, triangles):
+    sim, cloth, cV, nc, find, h, hd, k, tol, hA = _attachzoo(S, sc)
+    tri = triangles[len(triangles) // 2]
+    pC = 0.2 * cV[tri[0]] + 0.3 * cV[tri[1]] + 0.5 * cV[tri[2]]
+    rodC = sim.add_line_as_segments("rodC", pC, pC + np.array([3.0 * h, 0.7 * h, 0.0]), 3, S.elastic_rubberband())
+    sim.attach_point_triangle(rodC, cloth, [0], [tri], [[0.2, 0.3, 0.5]], k, tol)
+    rV = sim.points("X")[-4:]
+    mid = 0.5 * (rV[2] + rV[3])
+    q0 = find(mid[0], mid[1])
+    q1 = find(cV[q0][0] + h, cV[q0][1])
+    sim.attach_edge_edge(rodC, cloth, [[2, 3]], [[q0, q1]], [[0.5, 0.5]], [[0.4, 0.6]], k, tol)
+    bs = sc["box"]
+    box = sim.add_rigid_box("box", sc["box_mass"], (bs, bs, bs))
+    sim.rb_add_rotation(box, 10.0, (1.0, 0.0, 0.0))
+    sim.rb_add_translation(box, (0.0, hd + 0.5 * bs, 0.0))
+    edge_points = [i for i in range(nc) if abs(cV[i][1] - hd) < 1e-9 and abs(cV[i][0]) < 0.5 * bs + 1e-9]
+    sim.attach_rigid_body(box, cloth, edge_points, k, tol)
+    return sim, box, hA
+
+
+def _cloth_triangles(man, z):
+    """The cloth's triangle list (local = global indices: the cloth is the first point set) read off the reference's connectivity."""
+    names = [q["name"] for q in man["potentials"]]
+    return z["p%d_conn" % names.index("EnergyTriangleStrain")][:, 2:5]
+
+
+def test_rods_and_attachments_trajectory():
+    """§8(f) rank 1: EnergySegmentStrain (+ elasticity only) and the five EnergyAttachments potentials through the host layer's
+    Line presets and EnergyAttachments::add overloads reproduce the reference's trajectory."""
+    from stark_amd import sim as S
+
+    z, traj, man = _load("traj_attachzoo")
+    sc = traj["scene"]
+    sim, box, _ = _attachzoo_full(S, sc, _cloth_triangles(man, z))
+    # same registration as the reference: rest positions of every point set in order
+    names = [q["name"] for q in man["potentials"]]
+    pi = names.index("EnergySegmentStrain")
+    Xref = z["a%d" % man["potentials"][pi]["bindings"][4]["array"]]
+    X = sim.points("X")
+    assert X.shape == Xref.shape and np.abs(X - Xref).max() <= 1e-15
+    its, cg = [], 0
+    for step in range(len(traj["steps"])):
+        assert sim.run_one_step()
+        i = sim.info()
+        assert i.last_newton_result == 0
+        assert abs(i.current_time - traj["steps"][step]["time"]) < 1e-12
+        its.append(i.last_stats.newton_iterations)
+        cg += i.last_stats.cg_iterations
+    assert its == traj["newton_iterations"]
+    assert abs(cg - sum(traj["cg_iterations"])) <= 0.02 * sum(traj["cg_iterations"])
+    x = sim.points("x0")
+    # tolerance: the free rod and the hanging box are soft modes (a thin cloth carries them), so the Newton residual tolerance leaves
+    # ~1e-5 of slack in their positions per step; measured difference after 4 steps: 3e-5 relative
+    assert np.abs(x - z["x_end"]).max() <= 1e-4 * np.abs(z["x_end"]).max()
+    # the rigid box hanging from the cloth: converged velocities of the last step
+    ref = z["iterates"][-1]
+    nd = 3 * X.shape[0]
+    t, q, v, w = sim.rb_state(box)
+    assert np.abs(v - ref[nd:nd + 3]).max() <= 1e-3 * max(np.abs(ref[nd:nd + 3]).max(), 1e-3)
+    assert np.abs(w - ref[nd + 3:nd + 6]).max() <= 1e-3 * max(np.abs(ref[nd + 3:nd + 6]).max(), 1e-3)
+    sim.close()
+
+
+def test_attachment_tolerance_hardens_stiffness():
+    """EnergyAttachments::_is_converged_state_valid (EnergyAttachments.cpp:418-520): a spring stretched beyond its tolerance doubles
+    its group's stiffness and the step is redone until it holds."""
+    from stark_amd import sim as S
+
+    z, traj, man = _load("traj_attachzoo")
+    sc = dict(traj["scene"])
+    sc["k"], sc["tol"] = 20.0, 1e-4   # far too soft for the weights hanging from them
+    sim, box, hA = _attachzoo_full(S, sc, _cloth_triangles(man, z))
+    handlers = range(hA, hA + 5)   # point-point, point-edge, point-triangle, edge-edge, rigid-deformable: one group each
+    assert all(sim.attachment_stiffness(h) == 20.0 for h in handlers)
+    for _ in range(40):   # calls that end in an invalid converged state do not advance time
+        assert sim.run_one_step()
+        if sim.info().current_time_step >= 1:
+            break
+    assert sim.info().current_time_step >= 1
+    ks = np.array([sim.attachment_stiffness(h) for h in handlers])
+    assert ks.max() > 20.0 and np.all(np.log2(ks / 20.0) == np.round(np.log2(ks / 20.0)))
+    assert sim.info().failed_steps >= 1
+    sim.close()
