@@ -100,6 +100,17 @@ struct Scene
         m.thickness = thickness;
         contact_meshes.push_back(m);
     }
+    // edge-only collision mesh (EnergyFrictionalContact::add_edges, EnergyFrictionalContact.cpp:66-77): the segments as given
+    void record_deformable_edges(const stark::PointSetHandler& ps, const std::vector<std::array<int, 2>>& segments, double thickness)
+    {
+        ContactMeshRecord m;
+        m.kind = "d";
+        m.idx_in_ps = ps.get_idx();
+        for (int l : ps.all()) m.verts.push_back(ps.get_global_index(l));
+        m.edges = segments;
+        m.thickness = thickness;
+        contact_meshes.push_back(m);
+    }
     void record_rigid(const stark::RigidBodyHandler& rb, int n_vertices, const std::vector<std::array<int, 3>>& tris, double thickness)
     {
         ContactMeshRecord m;
@@ -373,6 +384,50 @@ static Scene scene_contactcorners(const Args& a)
     return sc;
 }
 
+// Rods in contact (edge-only collision meshes, Line presets): a rod lying diagonally over a fixed rigid box, a second rod crossing
+// over the first, and a cloth patch over both
+static Scene scene_contactrods(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "contactrods");
+    settings.simulation.init_frictional_contact = true;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const double th = a.d("thickness", 0.01), g = a.d("gap", 0.012), h = 0.15;
+    auto gp = stark::EnergyFrictionalContact::GlobalParams();
+    gp.default_contact_thickness = th;
+    gp.min_contact_stiffness = a.d("kmin", 1e5);
+    sim.interactions->contact->set_global_params(gp);
+
+    auto [aV, aT, boxA] = sim.presets->rigidbodies->add_box("boxA", 1.0, 2.0 * h);
+    sim.rigidbodies->add_constraint_fix(boxA.rigidbody);
+    sc.record_rigid(boxA.rigidbody, (int)aV.size(), aT, th);
+
+    auto lp = stark::Line::Params::Elastic_Rubberband();
+    auto [r1V, r1S, rod1] = sim.presets->deformables->add_line_as_segments("rod1", { -0.2, -0.12, h + g }, { 0.2, 0.1, h + g }, 7, lp);
+    sc.record_deformable_edges(rod1.point_set, r1S, th);
+    auto [r2V, r2S, rod2] = sim.presets->deformables->add_line_as_segments("rod2", { -0.1, 0.17, h + 2.0 * g }, { 0.13, -0.18, h + 2.0 * g + 0.004 }, 5, lp);
+    sc.record_deformable_edges(rod2.point_set, r2S, th);
+
+    auto [cV, cT, cloth] = sim.presets->deformables->add_surface_grid("cloth", { 0.2, 0.2 }, { 4, 4 }, stark::Surface::Params::Cotton_Fabric());
+    sc.record_deformable(cloth.point_set, cT, cloth.point_set.all(), th);
+    cloth.point_set.add_rotation(7.0, Eigen::Vector3d::UnitZ());
+    cloth.point_set.add_displacement({ 0.01, 0.0, h + 3.0 * g + 0.002 });
+
+    const double mu = a.d("mu", 0.5);
+    auto ct = sim.interactions->contact;
+    ct->set_friction(boxA.contact, rod1.contact, mu);
+    ct->set_friction(rod1.contact, rod2.contact, mu);
+    ct->set_friction(rod2.contact, cloth.contact, mu);
+    ct->set_friction(rod1.contact, cloth.contact, mu);
+    sc.record_friction(0, 1, mu);
+    sc.record_friction(1, 2, mu);
+    sc.record_friction(2, 3, mu);
+    sc.record_friction(1, 3, mu);
+    sc.json = "{\"kind\":\"contactrods\"}";
+    return sc;
+}
+
 // Hello-world of the reference's README (cfg 1) without the spin script: Cotton_Fabric cloth over a fixed rigid box
 static Scene scene_clothbox(const Args& a)
 {
@@ -528,6 +583,7 @@ static Scene make_scene(const std::string& name, const Args& a)
     if (name == "attachzoo") return scene_attachzoo(a);
     if (name == "clothbox") return scene_clothbox(a);
     if (name == "blockbox") return scene_blockbox(a);
+    if (name == "contactrods") return scene_contactrods(a);
     if (name == "contactcorners") return scene_contactcorners(a);
     if (name == "contactmix") return scene_contactmix(a);
     if (name == "rbchain") return scene_rbchain(a);

@@ -41,6 +41,9 @@ FIXTURES = {
     "contactmix_t1": ("dump", "contactmix", "steps=1 amp=0.003"),
     # box / soft-block corners aimed at a corner and an edge of a fixed box: vertex-vertex and vertex-edge rows
     "contactcorners_t0": ("dump", "contactcorners", "steps=0 amp=0.01"),
+    # rods (edge-only collision meshes) on a rigid box, across each other and under a cloth
+    "contactrods_t0": ("dump", "contactrods", "steps=0 amp=0.03"),
+    "contactrods_t1": ("dump", "contactrods", "steps=1 amp=0.003"),
     # known-answer vectors of the narrow-phase classification, edge-triangle intersection and friction geometry
     "contact_geometry": ("geom", "none", "n=600"),
     # rods + attachments (§8(f) rank 1): both segment-strain potentials and the five attachment potentials

@@ -15,7 +15,7 @@ from contact_util import friction_order, sorted_rows, state_from_fixture  # noqa
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CONTACT_FIXTURES = ["contactmix_t0", "contactmix_t1", "contactcorners_t0"]
+CONTACT_FIXTURES = ["contactmix_t0", "contactmix_t1", "contactcorners_t0", "contactrods_t0", "contactrods_t1"]
 
 
 def is_contact(name):

@@ -16,7 +16,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from contact_util import roles_from_manifest, sorted_rows, state_from_fixture  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-CONTACT_FIXTURES = ["contactmix_t0", "contactmix_t1", "contactcorners_t0"]
+CONTACT_FIXTURES = ["contactmix_t0", "contactmix_t1", "contactcorners_t0", "contactrods_t0", "contactrods_t1"]
 
 
 def test_narrow_phase_known_answers():
