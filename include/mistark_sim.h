@@ -107,6 +107,25 @@ int mistark_sim_rb_set_default_constraint_params(mistark_sim* sim, double stiffn
  * "spring_with_limits", "prismatic_press", "motor"); params = the remaining arguments flattened in the reference's order
  * (points / directions as 3 doubles). b is ignored by the single-body types. */
 int mistark_sim_rb_add_constraint(mistark_sim* sim, const char* type, int a, int b, const double* params, int n_params);
+/* RigidBodies::add(mass, inertia_local) without a collision mesh (RigidBodies.cpp:14-20); inertia row-major 3x3. Returns the body index. */
+int mistark_sim_rb_add(mistark_sim* sim, double mass, const double inertia_local[9]);
+/* stark::inertia_tensor_box (stark/src/utils/mesh_utils.h) */
+void mistark_inertia_tensor_box(double mass, const double size[3], double out[9]);
+/* RigidBodyHandler::add_force_at_centroid / add_torque (RigidBodyHandler.cpp:109-127), global coordinates */
+int mistark_sim_rb_add_force_at_centroid(mistark_sim* sim, int rb, const double f[3]);
+int mistark_sim_rb_add_torque(mistark_sim* sim, int rb, const double t[3]);
+/* number of base constraints of a kind so far ("global_point", "global_direction", "point", "point_on_axis", "distance",
+ * "distance_limits", "direction", "angle_limit", "spring", "linear_velocity", "angular_velocity"): the index the next one will get.
+ * mistark_sim_rb_add_constraint returns the index of the (last) base constraint it created. */
+int mistark_sim_rb_constraint_count(mistark_sim* sim, const char* base_type);
+/* The constraint handlers' measurements (rigidbody_constraints_ui.h): out = {violation, force or torque} of base constraint `idx`:
+ * get_violation_in_m_and_force / get_violation_in_deg_and_torque / get_signed_violation_in_m_and_force /
+ * get_signed_spring_displacement_in_m_and_force (which = 0) / get_signed_damper_velocity_and_force (which = 1) /
+ * get_signed_velocity_violation_and_force / get_signed_angular_velocity_violation_in_deg_per_s_and_torque; tolerance = the handler's
+ * get_tolerance_in_m / get_tolerance_in_deg (nullable). */
+int mistark_sim_rb_constraint_measure(mistark_sim* sim, const char* base_type, int idx, int which, double out[2], double* tolerance);
+/* Simulation::run(duration) (Simulation.cpp:62-71): steps until the simulated time advanced by `duration`; returns 1 if the last step succeeded */
+int mistark_sim_run(mistark_sim* sim, double duration);
 /* t1 [3], q1 [4: w x y z], v1 [3], w1 [3] (nullable outputs) */
 int mistark_sim_rb_get_state(mistark_sim* sim, int rb, double* t, double* q, double* v, double* w);
 

@@ -236,6 +236,23 @@ RigidBodyHandler& RigidBodyHandler::set_torque(const Vec3& t)
     rb->torque[idx] = t;
     return *this;
 }
+// RigidBodyHandler.cpp:98-127
+RigidBodyHandler& RigidBodyHandler::add_force_at_centroid(const Vec3& f)
+{
+    rb->force[idx] = rb->force[idx] + f;
+    return *this;
+}
+RigidBodyHandler& RigidBodyHandler::add_force_at(const Vec3& f, const Vec3& p)
+{
+    rb->force[idx] = rb->force[idx] + f;
+    rb->torque[idx] = rb->torque[idx] + cross(p - rb->t1[idx], f);
+    return *this;
+}
+RigidBodyHandler& RigidBodyHandler::add_torque(const Vec3& t)
+{
+    rb->torque[idx] = rb->torque[idx] + t;
+    return *this;
+}
 RigidBodyHandler& RigidBodyHandler::set_linear_damping(double d)
 {
     inertia->linear_damping[idx] = d;
@@ -399,6 +416,89 @@ bool EnergyRigidBodyConstraints::_adjust_constraints_stiffness(double cap, doubl
         if (changed && id_stiffness[kind] >= 0) stark.check(mistark_upload(stark.ctx, id_stiffness[kind]));
     }
     return is_valid;
+}
+
+std::array<double, 2> EnergyRigidBodyConstraints::measure(Kind kind, int idx, int which) const
+{
+    const Table& T = tables[kind];
+    if (idx < 0 || idx >= (int)T.conn.size()) throw std::runtime_error("EnergyRigidBodyConstraints::measure(): bad constraint index");
+    const int a = T.conn[idx][1], b = T.conn[idx][2];
+    auto X = [&](int body, const Vec3& loc) { return rb->get_position_at(body, loc); };
+    auto D = [&](int body, const Vec3& loc) { return rb->get_direction(body, loc); };
+    auto V = [&](int body, const Vec3& loc) { return rb->v1[body] + cross(rb->w1[body], rb->get_position_at(body, loc) - rb->t1[body]); };
+    const double k = T.stiffness[idx];
+    const double EPS = 100.0 * std::numeric_limits<double>::epsilon();  // RigidBodyConstraints.h:52
+    auto c1_controller = [](const Vec3& da1, const Vec3& va1, const Vec3& vb1, double target, double max_force, double delay) -> std::array<double, 2> {
+        // RigidBodyConstraints.h:70-85
+        const double dv = dot(da1, vb1 - va1) - target;
+        if (dv < -delay) return {dv, -max_force};
+        if (dv < delay) return {dv, -(max_force / delay) * dv};
+        return {dv, max_force};
+    };
+    switch (kind) {
+        case GlobalPoints: {  // :114-119
+            const double C = norm(X(a, T.v0[idx]) - T.v1[idx]);
+            return {C, k * C};
+        }
+        case GlobalDirections: {  // :154-164
+            const Vec3 u = D(a, T.v0[idx]) - T.v1[idx];
+            const double C = norm(u);
+            const Vec3 force = (-k * C / (C + EPS)) * u;
+            return {rad2deg(std::asin(C)), norm(cross(T.v1[idx], force))};
+        }
+        case Points: {  // :195-200
+            const double C = norm(X(b, T.v1[idx]) - X(a, T.v0[idx]));
+            return {C, k * C};
+        }
+        case PointOnAxes: {  // :232-236
+            const Vec3 a1 = X(a, T.v0[idx]), da1 = D(a, T.v1[idx]), b1 = X(b, T.v2[idx]);
+            const double C = std::sqrt(sq_distance_point_line(b1, a1, a1 + da1));
+            return {C, k * C};
+        }
+        case Distances: {  // :269-275 (signed)
+            const double C = norm(X(b, T.v1[idx]) - X(a, T.v0[idx])) - T.s0[idx];
+            return {C, -k * C};
+        }
+        case DistanceLimits: {  // :312-327 (signed)
+            const double d = norm(X(b, T.v1[idx]) - X(a, T.v0[idx]));
+            if (d < T.s0[idx]) return {d - T.s0[idx], -k * (d - T.s0[idx])};
+            if (d > T.s1[idx]) return {d - T.s1[idx], -k * (d - T.s1[idx])};
+            return {0.0, 0.0};
+        }
+        case Directions: {  // :361-371
+            const Vec3 da = D(a, T.v0[idx]), u = D(b, T.v1[idx]) - da;
+            const double C = norm(u);
+            const Vec3 force = (k * C / (C + EPS)) * u;
+            return {rad2deg(std::asin(C)), norm(cross(da, force))};
+        }
+        case AngleLimits: {  // :414-427
+            const Vec3 da = D(a, T.v0[idx]), u = D(b, T.v1[idx]) - da;
+            const double d = norm(u);
+            if (d > T.s0[idx]) {
+                const double C = d - T.s0[idx];
+                const Vec3 force = (k * C * C / (d + EPS)) * u;
+                return {rad2deg(std::acos((2.0 - C * C) / 2.0)), norm(cross(da, force))};
+            }
+            return {0.0, 0.0};
+        }
+        case DampedSprings: {  // :467-481
+            const Vec3 a1 = X(a, T.v0[idx]), b1 = X(b, T.v1[idx]);
+            if (which == 0) {
+                const double C = norm(b1 - a1) - T.s0[idx];
+                return {C, -k * C};
+            }
+            const double dv = dot(V(b, T.v1[idx]) - V(a, T.v0[idx]), normalized(b1 - a1));
+            return {dv, -T.s1[idx] * dv};
+        }
+        case LinearVelocity:  // :511-514
+            return c1_controller(D(a, T.v0[idx]), rb->v1[a], rb->v1[b], T.s0[idx], T.s1[idx], T.s2[idx]);
+        case AngularVelocity: {  // :544-548
+            const auto r = c1_controller(D(a, T.v0[idx]), rb->w1[a], rb->w1[b], T.s0[idx], T.s1[idx], T.s2[idx]);
+            return {rad2deg(r[0]), r[1]};
+        }
+        default: break;
+    }
+    throw std::runtime_error("EnergyRigidBodyConstraints::measure(): bad kind");
 }
 
 // ======================================================================================================================

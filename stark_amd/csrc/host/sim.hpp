@@ -441,7 +441,11 @@ public:
     RigidBodyHandler& set_velocity(const Vec3& v);
     RigidBodyHandler& set_angular_velocity(const Vec3& w);
     RigidBodyHandler& set_force_at_centroid(const Vec3& f);
+    RigidBodyHandler& add_force_at_centroid(const Vec3& f);
+    RigidBodyHandler& add_force_at(const Vec3& f, const Vec3& application_point_glob);
     RigidBodyHandler& set_torque(const Vec3& t);
+    RigidBodyHandler& add_torque(const Vec3& t);
+    Vec3 get_velocity_at(const Vec3& x_loc) const { return rb->v1[idx] + cross(rb->w1[idx], rb->get_position_at(idx, x_loc) - rb->t1[idx]); }
     RigidBodyHandler& set_linear_damping(double d);
     RigidBodyHandler& set_angular_damping(double d);
     Vec3 transform_global_to_local_point(const Vec3& x) const { return transpose(rb->R1[idx]) * (x - rb->t1[idx]); }
@@ -468,6 +472,9 @@ public:
 
     EnergyRigidBodyConstraints(Stark& stark, spRigidBodyDynamics rb);
     int add(Kind kind, int a, int b, const Vec3* vecs, int n_vecs, const double* scalars, int n_scalars, double stiffness, double tolerance);
+    // The handlers' measurements (rigidbody_constraints_ui.h:75-330 with the static functions of RigidBodyConstraints.h): {violation, force or
+    // torque} of constraint `idx` of `kind` at the current state; which = 1 selects the damper of a damped spring.
+    std::array<double, 2> measure(Kind kind, int idx, int which = 0) const;
     void register_potentials(mistark_ctx* ctx) override;
 
 private:

@@ -408,17 +408,17 @@ int mistark_sim_rb_add_constraint(mistark_sim* s, const char* type, int ia, int 
     const bool single = t == "fix" || t == "global_point" || t == "global_direction";
     RigidBodyHandler& b = single ? a : the_body(s, ib);
     if (t == "fix") { need(0); R.add_constraint_fix(a); }
-    else if (t == "global_point") { need(3); R.add_constraint_global_point(a, v3(p)); }
-    else if (t == "global_direction") { need(3); R.add_constraint_global_direction(a, v3(p)); }
-    else if (t == "point") { need(3); R.add_constraint_point(a, b, v3(p)); }
-    else if (t == "point_on_axis") { need(6); R.add_constraint_point_on_axis(a, b, v3(p), v3(p + 3)); }
-    else if (t == "distance") { need(6); R.add_constraint_distance(a, b, v3(p), v3(p + 3)); }
-    else if (t == "distance_limits") { need(8); R.add_constraint_distance_limits(a, b, v3(p), v3(p + 3), p[6], p[7]); }
-    else if (t == "direction") { need(3); R.add_constraint_direction(a, b, v3(p)); }
-    else if (t == "angle_limit") { need(4); R.add_constraint_angle_limit(a, b, v3(p), p[3]); }
-    else if (t == "spring") { need(8); R.add_constraint_spring(a, b, v3(p), v3(p + 3), p[6], p[7]); }
-    else if (t == "linear_velocity") { need(6); R.add_constraint_linear_velocity(a, b, v3(p), p[3], p[4], p[5]); }
-    else if (t == "angular_velocity") { need(6); R.add_constraint_angular_velocity(a, b, v3(p), p[3], p[4], p[5]); }
+    else if (t == "global_point") { need(3); _ret = R.add_constraint_global_point(a, v3(p)); }
+    else if (t == "global_direction") { need(3); _ret = R.add_constraint_global_direction(a, v3(p)); }
+    else if (t == "point") { need(3); _ret = R.add_constraint_point(a, b, v3(p)); }
+    else if (t == "point_on_axis") { need(6); _ret = R.add_constraint_point_on_axis(a, b, v3(p), v3(p + 3)); }
+    else if (t == "distance") { need(6); _ret = R.add_constraint_distance(a, b, v3(p), v3(p + 3)); }
+    else if (t == "distance_limits") { need(8); _ret = R.add_constraint_distance_limits(a, b, v3(p), v3(p + 3), p[6], p[7]); }
+    else if (t == "direction") { need(3); _ret = R.add_constraint_direction(a, b, v3(p)); }
+    else if (t == "angle_limit") { need(4); _ret = R.add_constraint_angle_limit(a, b, v3(p), p[3]); }
+    else if (t == "spring") { need(8); _ret = R.add_constraint_spring(a, b, v3(p), v3(p + 3), p[6], p[7]); }
+    else if (t == "linear_velocity") { need(6); _ret = R.add_constraint_linear_velocity(a, b, v3(p), p[3], p[4], p[5]); }
+    else if (t == "angular_velocity") { need(6); _ret = R.add_constraint_angular_velocity(a, b, v3(p), p[3], p[4], p[5]); }
     else if (t == "attachment") { need(0); R.add_constraint_attachment(a, b); }
     else if (t == "point_with_angle_limit") { need(7); R.add_constraint_point_with_angle_limit(a, b, v3(p), v3(p + 3), p[6]); }
     else if (t == "hinge") { need(6); R.add_constraint_hinge(a, b, v3(p), v3(p + 3)); }
@@ -429,6 +429,69 @@ int mistark_sim_rb_add_constraint(mistark_sim* s, const char* type, int ia, int 
     else if (t == "prismatic_press") { need(9); R.add_constraint_prismatic_press(a, b, v3(p), v3(p + 3), p[6], p[7], p[8]); }
     else if (t == "motor") { need(9); R.add_constraint_motor(a, b, v3(p), v3(p + 3), p[6], p[7], p[8]); }
     else throw std::runtime_error("unknown rigid body constraint type '" + t + "'");
+    SIM_END
+}
+static EnergyRigidBodyConstraints::Kind base_kind(const std::string& t)
+{
+    using K = EnergyRigidBodyConstraints;
+    static const std::pair<const char*, K::Kind> names[] = {{"global_point", K::GlobalPoints}, {"global_direction", K::GlobalDirections}, {"point", K::Points},
+                                                            {"point_on_axis", K::PointOnAxes}, {"distance", K::Distances}, {"distance_limits", K::DistanceLimits},
+                                                            {"direction", K::Directions}, {"angle_limit", K::AngleLimits}, {"spring", K::DampedSprings},
+                                                            {"linear_velocity", K::LinearVelocity}, {"angular_velocity", K::AngularVelocity}};
+    for (const auto& n : names)
+        if (t == n.first) return n.second;
+    throw std::runtime_error("unknown base rigid body constraint type '" + t + "'");
+}
+int mistark_sim_rb_add(mistark_sim* s, double mass, const double J[9])
+{
+    SIM_BEGIN
+    Mat3 inertia;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) inertia[3 * i + j] = J[3 * i + j];
+    s->bodies.push_back(s->sim->rigidbodies->add(mass, inertia));
+    s->body_group.push_back(-1);
+    _ret = (int)s->bodies.size() - 1;
+    SIM_END
+}
+void mistark_inertia_tensor_box(double mass, const double size[3], double out[9])
+{
+    const Mat3 J = inertia_tensor_box(mass, {size[0], size[1], size[2]});
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) out[3 * i + j] = J[3 * i + j];
+}
+int mistark_sim_rb_add_force_at_centroid(mistark_sim* s, int rb, const double f[3])
+{
+    SIM_BEGIN
+    the_body(s, rb).add_force_at_centroid(v3(f));
+    SIM_END
+}
+int mistark_sim_rb_add_torque(mistark_sim* s, int rb, const double t[3])
+{
+    SIM_BEGIN
+    the_body(s, rb).add_torque(v3(t));
+    SIM_END
+}
+int mistark_sim_rb_constraint_count(mistark_sim* s, const char* type)
+{
+    SIM_BEGIN
+    _ret = (int)s->sim->rigidbodies->constraints->tables[base_kind(type ? type : "")].conn.size();
+    SIM_END
+}
+int mistark_sim_rb_constraint_measure(mistark_sim* s, const char* type, int idx, int which, double out[2], double* tolerance)
+{
+    SIM_BEGIN
+    auto& C = *s->sim->rigidbodies->constraints;
+    const auto kind = base_kind(type ? type : "");
+    const auto r = C.measure(kind, idx, which);
+    out[0] = r[0];
+    out[1] = r[1];
+    if (tolerance) *tolerance = C.tables[kind].tolerance.at((size_t)idx);
+    SIM_END
+}
+int mistark_sim_run(mistark_sim* s, double duration)
+{
+    SIM_BEGIN
+    _ret = s->sim->get_stark().run(duration) ? 1 : 0;
     SIM_END
 }
 int mistark_sim_rb_get_state(mistark_sim* s, int rb, double* t, double* q, double* v, double* w)

@@ -1374,6 +1374,19 @@ static int launch_spmv(Context& c, const double* x, double* y, const double* pdo
                            (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, y);
     return g0 + g1;
 }
+// reference point for the micro-benchmark (variant 9): a plain grid-stride float4 read of the matrix values, i.e. what streaming the
+// matrix costs at best on this box (measured 16.2 us for the 1M-tet block = 6.3 TB/s)
+__global__ __launch_bounds__(BLOCK) void k_stream_ref(const float4* __restrict__ v, size_t n4, double* __restrict__ partials)
+{
+    __shared__ double sm[4];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * BLOCK) {
+        const float4 a = v[i];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    const double t = block_sum((double)(s.x + s.y + s.z + s.w), sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
 // Micro-benchmark of the SpMV kernel on the assembled matrix: n back-to-back launches of q = A p (+ fused dot), HIP events
 // around the whole batch on the engine's stream. Returns the average launch duration in microseconds.
 double spmv_bench(Context& c, int n)
@@ -1388,6 +1401,7 @@ double spmv_bench(Context& c, int n)
     for (int i = 0; i < n; i++) {
         switch (c.spmv_variant) {
             case 1: launch_spmv<1>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
+            case 9: hipLaunchKernelGGL(k_stream_ref, dim3(2048), dim3(BLOCK), 0, c.stream, (const float4*)c.part[0].vals.p, (size_t)c.part[0].ntiles * 144, c.partials.p); break;
             case 2: launch_spmv<2>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
             case 3: launch_spmv<3>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
             case 4: launch_spmv<4>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;

@@ -101,6 +101,14 @@ def _lib():
         L.mistark_sim_rb_set_default_constraint_params.argtypes = [p, C.c_double, C.c_double, C.c_double]
         L.mistark_sim_rb_add_constraint.argtypes = [p, C.c_char_p, C.c_int, C.c_int, D, C.c_int]
         L.mistark_sim_rb_get_state.argtypes = [p, C.c_int, p, p, p, p]
+        L.mistark_sim_rb_add.argtypes = [p, C.c_double, D]
+        L.mistark_inertia_tensor_box.argtypes = [C.c_double, D, D]
+        L.mistark_inertia_tensor_box.restype = None
+        L.mistark_sim_rb_add_force_at_centroid.argtypes = [p, C.c_int, D]
+        L.mistark_sim_rb_add_torque.argtypes = [p, C.c_int, D]
+        L.mistark_sim_rb_constraint_count.argtypes = [p, C.c_char_p]
+        L.mistark_sim_rb_constraint_measure.argtypes = [p, C.c_char_p, C.c_int, C.c_int, D, D]
+        L.mistark_sim_run.argtypes = [p, C.c_double]
         L.mistark_contact_default_global_params.argtypes = [C.POINTER(ContactGlobalParams)]
         L.mistark_contact_default_global_params.restype = None
         L.mistark_sim_set_contact_global_params.argtypes = [p, C.POINTER(ContactGlobalParams)]
@@ -136,6 +144,12 @@ def elastic_rubberband() -> LineParams:
     p = LineParams()
     _lib().mistark_line_params_elastic_rubberband(C.byref(p))
     return p
+
+
+def inertia_tensor_box(mass, size) -> np.ndarray:
+    out = (C.c_double * 9)()
+    _lib().mistark_inertia_tensor_box(float(mass), _d3(size), out)
+    return np.array(out[:]).reshape(3, 3)
 
 
 def contact_global_params() -> ContactGlobalParams:
@@ -252,6 +266,29 @@ class Simulation:
         size = (size, size, size) if np.isscalar(size) else size
         return self._ck(self.L.mistark_sim_add_rigid_box(self.h, label.encode(), mass, _d3(size)))
 
+    def rb_add(self, mass, inertia_local) -> int:
+        """RigidBodies::add(mass, inertia) without a collision mesh."""
+        return self._ck(self.L.mistark_sim_rb_add(self.h, float(mass), _d3(np.asarray(inertia_local, dtype=float).reshape(9))))
+
+    def rb_add_force_at_centroid(self, rb, f):
+        self._ck(self.L.mistark_sim_rb_add_force_at_centroid(self.h, rb, _d3(f)))
+
+    def rb_add_torque(self, rb, t):
+        self._ck(self.L.mistark_sim_rb_add_torque(self.h, rb, _d3(t)))
+
+    def rb_constraint_count(self, base_type) -> int:
+        return self._ck(self.L.mistark_sim_rb_constraint_count(self.h, base_type.encode()))
+
+    def rb_constraint_measure(self, base_type, idx, which=0):
+        """(violation, force or torque, tolerance) of a base constraint, as the reference's constraint handlers report them."""
+        out = (C.c_double * 2)()
+        tol = C.c_double()
+        self._ck(self.L.mistark_sim_rb_constraint_measure(self.h, base_type.encode(), idx, which, out, C.byref(tol)))
+        return out[0], out[1], tol.value
+
+    def run(self, duration) -> bool:
+        return self._ck(self.L.mistark_sim_run(self.h, float(duration))) == 1
+
     def rb_set_translation(self, rb, t):
         self._ck(self.L.mistark_sim_rb_set_translation(self.h, rb, _d3(t)))
 
@@ -268,7 +305,7 @@ class Simulation:
         flat = []
         for x in params:
             flat.extend([float(x)] if np.isscalar(x) else [float(v) for v in x])
-        self._ck(self.L.mistark_sim_rb_add_constraint(self.h, kind.encode(), a, b, _d3(flat) if flat else None, len(flat)))
+        return self._ck(self.L.mistark_sim_rb_add_constraint(self.h, kind.encode(), a, b, _d3(flat) if flat else None, len(flat)))
 
     def rb_state(self, rb):
         t, q, v, w = np.zeros(3), np.zeros(4), np.zeros(3), np.zeros(3)
