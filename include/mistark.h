@@ -149,6 +149,12 @@ enum
 enum { MISTARK_PROJ_NEWTON = 0, MISTARK_PROJ_PROJECTED_NEWTON = 1, MISTARK_PROJ_ON_DEMAND = 2, MISTARK_PROJ_PROGRESSIVE = 3 };
 
 /* symx::NewtonSettings (solver_utils.h:173-259) with STARK's overrides as defaults (stark/src/core/Settings.cpp:43-50) */
+/* symx::LinearSolver. DirectLLT (NewtonsMethod.cpp:395-418) is a dense Cholesky for small systems (<= 3072 unknowns); larger ones are an error. */
+enum
+{
+    MISTARK_SOLVER_BDPCG = 0,
+    MISTARK_SOLVER_DIRECT_LLT = 1
+};
 typedef struct mistark_newton_settings
 {
     int32_t max_iterations;
@@ -173,6 +179,7 @@ typedef struct mistark_newton_settings
     double cg_rel_tolerance;
     int32_t cg_stop_on_indefiniteness;
     double bailout_residual;
+    int32_t linear_solver; /* symx::LinearSolver (solver_utils.h): MISTARK_SOLVER_BDPCG (default) or MISTARK_SOLVER_DIRECT_LLT */
 } mistark_newton_settings;
 void mistark_newton_default_settings(mistark_newton_settings* s);
 

@@ -140,6 +140,7 @@ static stark::Settings base_settings(const Args& a, const std::string& name)
     settings.execution.n_threads = a.i("threads", 1);
     settings.simulation.max_time_step_size = a.d("dt", 1.0 / 30.0);
     settings.simulation.use_adaptive_time_step = a.i("adaptive", 1) != 0;
+    if (a.s("solver", "pcg") == "llt") settings.newton.linear_solver = symx::LinearSolver::DirectLLT;  // NewtonsMethod.cpp:395-418
     const std::string proj = a.s("projection", "Progressive");
     if (proj == "Progressive") settings.newton.projection_mode = symx::ProjectionToPD::Progressive;
     else if (proj == "ProjectedNewton") settings.newton.projection_mode = symx::ProjectionToPD::ProjectedNewton;

@@ -40,7 +40,7 @@ class NewtonSettings(C.Structure):
         ("line_search_armijo_beta", C.c_double), ("max_backtracking_armijo_iterations", C.c_int32), ("max_backtracking_invalid_state_iterations", C.c_int32),
         ("projection_mode", C.c_int32), ("projection_eps", C.c_double), ("project_to_pd_use_mirroring", C.c_int32), ("project_on_demand_countdown", C.c_int32),
         ("ppn_tightening_factor", C.c_double), ("ppn_release_factor", C.c_double), ("cg_max_iterations", C.c_int32), ("cg_abs_tolerance", C.c_double),
-        ("cg_rel_tolerance", C.c_double), ("cg_stop_on_indefiniteness", C.c_int32), ("bailout_residual", C.c_double),
+        ("cg_rel_tolerance", C.c_double), ("cg_stop_on_indefiniteness", C.c_int32), ("bailout_residual", C.c_double), ("linear_solver", C.c_int32),
     ]
 
 

@@ -527,6 +527,7 @@ void mistark_newton_default_settings(mistark_newton_settings* s)
     s->cg_rel_tolerance = 1e-4;
     s->cg_stop_on_indefiniteness = 1;
     s->bailout_residual = 1e-10;
+    s->linear_solver = MISTARK_SOLVER_BDPCG;
 }
 
 int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settings, const mistark_newton_callbacks* callbacks, mistark_newton_stats* stats)

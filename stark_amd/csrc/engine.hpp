@@ -195,6 +195,7 @@ struct Context
     bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path
     DevBuf<uint8_t> cub_tmp;
     DevBuf<float> dinv;             // 9 floats per block row
+    DevBuf<double> dense;           // DirectLLT: the matrix as a dense column-major array (small systems only)
     bool have_matrix = false;
     bool matrix_current = false;    // the assembled matrix reflects the current element Hessians
     DevBuf<uint32_t> proj_list;     // element ids selected for projection (per potential, at e_off)
@@ -246,6 +247,7 @@ void build_preconditioner(Context& c);
 double spmv_bench(Context& c, int n);
 void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed);
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info);
+bool direct_llt(Context& c, const double* rhs_dev, double* x_dev);  // direct.hip
 double reduce_max_abs(Context& c, const double* v, int64_t n);
 double reduce_dot(Context& c, const double* a, const double* b, int64_t n);
 void vec_axpby(Context& c, double* dst, double a, const double* x, double b, const double* y, int64_t n);

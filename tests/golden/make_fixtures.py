@@ -52,6 +52,8 @@ FIXTURES = {
     # Newton trajectories (iterates after every Newton iteration)
     "traj_tetbeam_eo_8x2x2": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=1 steps=3"),
     "traj_cloth_flat_8": ("traj", "cloth", "n=8 flat=1 eo=0 steps=3"),
+    # the same beam with the reference's DirectLLT linear solver (exact Newton steps)
+    "traj_tetbeam_llt_6x2x2": ("traj", "tetbeam", "nx=6 ny=2 nz=2 eo=1 steps=3 solver=llt"),
     # contact scenes (cfg 1 / cfg 4 at fixture size): cloth resting on a fixed rigid box, soft block pressed on a fixed rigid box
     "traj_clothbox_8": ("traj", "clothbox", "n=8 gap=0.004 steps=4"),
     "traj_blockbox_3": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=1"),

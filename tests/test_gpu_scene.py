@@ -46,6 +46,47 @@ def test_tetbeam_scene_trajectory():
     sim.close()
 
 
+def test_tetbeam_direct_llt_trajectory():
+    """symx::LinearSolver::DirectLLT (NewtonsMethod.cpp:395-418; a dense device Cholesky here): the reference's trajectory of the beam with
+    exact Newton steps: same iteration counts (one per step). Positions to 5e-7: the Hessian is stored in float on both sides but summed
+    in a different order (float rounding of A), and a single Newton step per time step does not correct that."""
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    z, traj, man = _load("traj_tetbeam_llt_6x2x2")
+    sc = traj["scene"]
+    st = S.default_settings()
+    st.newton.linear_solver = 1  # MISTARK_SOLVER_DIRECT_LLT
+    sim = S.Simulation(st)
+    p = S.soft_rubber()
+    p.elasticity_only = sc["eo"]
+    ps = sim.add_volume_grid("beam", (0, 0, 0), (sc["lx"], sc["ly"], sc["lz"]), (sc["nx"], sc["ny"], sc["nz"]), p)
+    sim.prescribe_inside_aabb(ps, (-0.5 * sc["lx"], 0, 0), (2e-3, 2 * sc["ly"], 2 * sc["lz"]), 1e7)
+    its = []
+    for _ in traj["steps"]:
+        assert sim.run_one_step()
+        i = sim.info()
+        assert i.last_newton_result == 0
+        assert i.last_stats.cg_iterations == 0
+        its.append(i.last_stats.newton_iterations)
+    assert its == traj["newton_iterations"]
+    x = sim.points("x0")
+    assert np.abs(x - z["x_end"]).max() <= 5e-7 * np.abs(z["x_end"]).max()
+    sim.close()
+
+
+def test_direct_llt_refuses_large_systems():
+    from stark_amd import sim as S
+
+    st = S.default_settings()
+    st.newton.linear_solver = 1
+    sim = S.Simulation(st)
+    sim.add_volume_grid("beam", (0, 0, 0), (4, 1, 1), (24, 6, 6), S.soft_rubber())   # > 3072 unknowns
+    with pytest.raises(S.SimError, match="DirectLLT"):
+        sim.run_one_step()
+    sim.close()
+
+
 def test_cloth_scene_trajectory():
     from stark_amd import sim as S
 

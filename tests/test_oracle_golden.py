@@ -74,7 +74,7 @@ def test_oracle_matches_reference_stages(path):
 
 
 # (rigid-body trajectories need the rigid-body state update and constraint hardening of the host layer: tests/test_gpu_scene.py)
-TRAJ = [p for p in DUMPS if os.path.basename(p).startswith("traj_") and "rb" not in os.path.basename(p) and "box" not in os.path.basename(p) and "attach" not in os.path.basename(p)]  # (rigid-body and contact trajectories: scene tests)
+TRAJ = [p for p in DUMPS if os.path.basename(p).startswith("traj_") and "rb" not in os.path.basename(p) and "box" not in os.path.basename(p) and "attach" not in os.path.basename(p) and "llt" not in os.path.basename(p)]  # (rigid-body and contact trajectories: scene tests)
 
 
 @pytest.mark.parametrize("path", TRAJ, ids=[os.path.basename(p)[:-4] for p in TRAJ])
