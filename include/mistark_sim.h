@@ -61,6 +61,14 @@ int mistark_sim_add_surface(mistark_sim* sim, const char* label, const double* v
 /* deformables->prescribed_positions->add_inside_aabb: returns the group index */
 int mistark_sim_prescribe_inside_aabb(mistark_sim* sim, int point_set, const double center[3], const double dim[3], double stiffness, double tolerance);
 
+/* stark::generate_triangle_grid (stark/src/utils/mesh_generators.cpp:100-166): (n0+1)(n1+1) vertices (3 doubles, z = 0) and 2 n0 n1 triangles.
+ * Pass NULL outputs to query the counts. */
+int mistark_generate_triangle_grid(const double center[2], const double dim[2], const int32_t subdivisions[2], double* vertices, int64_t* n_vertices, int32_t* triangles,
+                                   int64_t* n_triangles);
+/* stark::find_edges_from_simplices for triangles (stark/src/utils/mesh_utils.cpp): unique edges in the reference's order. edges may be NULL (count only). */
+int mistark_find_edges_from_triangles(const int32_t* triangles, int64_t n_triangles, int64_t n_vertices, int32_t* edges, int64_t* n_edges);
+/* deformables->prescribed_positions->add_outside_aabb (EnergyPrescribedPositions.cpp:66-78) */
+int mistark_sim_prescribe_outside_aabb(mistark_sim* sim, int point_set, const double center[3], const double dim[3], double stiffness, double tolerance);
 /* deformables->prescribed_positions->add(set, points, params): returns the group index */
 int mistark_sim_prescribe_points(mistark_sim* sim, int point_set, const int32_t* points, int64_t n, double stiffness, double tolerance);
 

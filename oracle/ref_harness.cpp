@@ -507,6 +507,26 @@ static Scene scene_blockbox(const Args& a)
     return sc;
 }
 
+// examples/main.cpp hanging_net: an n x n net of Elastic_Rubberband segments (the edges of a triangle grid) fixed along its perimeter
+static Scene scene_hangingnet(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "hangingnet");
+    settings.simulation.init_frictional_contact = false;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const int n = a.i("n", 20);
+    const double d = a.d("size", 1.0);
+    auto [V, T] = stark::generate_triangle_grid({ 0.0, 0.0 }, { d, d }, { n, n });
+    auto E = stark::find_edges_from_simplices(T, (int)V.size());
+    auto H = sim.presets->deformables->add_line("segments", V, E, stark::Line::Params::Elastic_Rubberband());
+    sim.deformables->prescribed_positions->add_outside_aabb(H.point_set, { 0.0, 0.0, 0.0 }, { d - 0.001, d - 0.001, d - 0.001 }, stark::EnergyPrescribedPositions::Params());
+    std::ostringstream js;
+    js << "{\"kind\":\"hangingnet\",\"n\":" << n << ",\"size\":" << d << "}";
+    sc.json = js.str();
+    return sc;
+}
+
 // Rods + attachments: a cloth hanging from two rods (complete / elasticity-only segment strain) by a
 // point-point and a point-edge attachment, a free rod riding on the cloth (point-triangle and edge-edge attachments) and a free
 // rigid box hanging from the cloth's far edge (rigid-deformable attachments). No contact.
@@ -581,6 +601,7 @@ static Scene scene_attachzoo(const Args& a)
 
 static Scene make_scene(const std::string& name, const Args& a)
 {
+    if (name == "hangingnet") return scene_hangingnet(a);
     if (name == "attachzoo") return scene_attachzoo(a);
     if (name == "clothbox") return scene_clothbox(a);
     if (name == "blockbox") return scene_blockbox(a);

@@ -448,6 +448,18 @@ EnergyPrescribedPositions::Handler EnergyPrescribedPositions::add_inside_aabb(co
     }
     return add(set, pts, params);
 }
+EnergyPrescribedPositions::Handler EnergyPrescribedPositions::add_outside_aabb(const PointSetHandler& set, const Vec3& c, const Vec3& dim, const Params& params)
+{
+    // EnergyPrescribedPositions.cpp:66-78
+    std::vector<int> pts;
+    for (int i = 0; i < set.size(); i++) {
+        const Vec3 p = set.get_position(i);
+        bool in = true;
+        for (int k = 0; k < 3; k++) in = in && (p[k] >= c[k] - 0.5 * dim[k]) && (p[k] <= c[k] + 0.5 * dim[k]);
+        if (!in) pts.push_back(i);
+    }
+    return add(set, pts, params);
+}
 EnergyPrescribedPositions::Params EnergyPrescribedPositions::get_params(const Handler& h) const { return Params{stiffness[h.idx], tolerance[h.idx]}; }
 void EnergyPrescribedPositions::set_params(const Handler& h, const Params& p)
 {

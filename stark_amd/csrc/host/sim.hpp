@@ -250,6 +250,7 @@ public:
     EnergyPrescribedPositions(Stark& stark, spPointDynamics dyn);
     Handler add(const PointSetHandler& set, const std::vector<int>& points, const Params& params);
     Handler add_inside_aabb(const PointSetHandler& set, const Vec3& aabb_center, const Vec3& aabb_dim, const Params& params);
+    Handler add_outside_aabb(const PointSetHandler& set, const Vec3& aabb_center, const Vec3& aabb_dim, const Params& params);
     Params get_params(const Handler& h) const;
     void set_params(const Handler& h, const Params& p);
     void set_transformation(const Handler& h, const Vec3& t, const std::array<double, 9>& R);

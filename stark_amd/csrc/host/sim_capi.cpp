@@ -219,6 +219,51 @@ int mistark_sim_prescribe_inside_aabb(mistark_sim* s, int ps, const double c[3],
     _ret = h.get_idx();
     SIM_END
 }
+int mistark_generate_triangle_grid(const double center[2], const double dim[2], const int32_t sub[2], double* vertices, int64_t* n_vertices, int32_t* triangles, int64_t* n_triangles)
+{
+    try {
+        std::vector<Vec3> V;
+        std::vector<std::array<int, 3>> T;
+        generate_triangle_grid(V, T, {center[0], center[1]}, {dim[0], dim[1]}, {sub[0], sub[1]});
+        if (n_vertices) *n_vertices = (int64_t)V.size();
+        if (n_triangles) *n_triangles = (int64_t)T.size();
+        if (vertices) std::memcpy(vertices, V.data(), V.size() * sizeof(Vec3));
+        if (triangles)
+            for (size_t i = 0; i < T.size(); i++)
+                for (int k = 0; k < 3; k++) triangles[3 * i + k] = T[i][k];
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+int mistark_find_edges_from_triangles(const int32_t* triangles, int64_t nt, int64_t nv, int32_t* edges, int64_t* n_edges)
+{
+    try {
+        std::vector<std::array<int, 3>> T((size_t)nt);
+        for (int64_t i = 0; i < nt; i++) T[i] = {triangles[3 * i], triangles[3 * i + 1], triangles[3 * i + 2]};
+        std::vector<std::array<int, 2>> E;
+        find_edges_from_simplices(E, T, (int)nv);
+        if (n_edges) *n_edges = (int64_t)E.size();
+        if (edges)
+            for (size_t i = 0; i < E.size(); i++) {
+                edges[2 * i] = E[i][0];
+                edges[2 * i + 1] = E[i][1];
+            }
+        return 0;
+    } catch (...) {
+        return -1;
+    }
+}
+int mistark_sim_prescribe_outside_aabb(mistark_sim* s, int ps, const double c[3], const double d[3], double stiffness, double tolerance)
+{
+    SIM_BEGIN
+    if (ps < 0 || ps >= (int)s->sets.size()) throw std::runtime_error("bad point set");
+    EnergyPrescribedPositions::Params p;
+    p.stiffness = stiffness;
+    p.tolerance = tolerance > 0.0 ? tolerance : std::numeric_limits<double>::max();
+    _ret = s->sim->deformables->prescribed_positions->add_outside_aabb(s->sets[ps], {c[0], c[1], c[2]}, {d[0], d[1], d[2]}, p).get_idx();
+    SIM_END
+}
 static Vec3 v3(const double* p) { return {p[0], p[1], p[2]}; }
 static PointSetHandler& the_set(mistark_sim* s, int ps)
 {

@@ -71,6 +71,7 @@ def _lib():
         L.mistark_sim_add_surface_grid.argtypes = [p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(SurfaceParams)]
         L.mistark_sim_add_surface.argtypes = [p, C.c_char_p, p, C.c_int64, p, C.c_int64, C.POINTER(SurfaceParams)]
         L.mistark_sim_prescribe_inside_aabb.argtypes = [p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double]
+        L.mistark_sim_prescribe_outside_aabb.argtypes = [p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_double]
         L.mistark_sim_prescribe_points.argtypes = [p, C.c_int, p, C.c_int64, C.c_double, C.c_double]
         L.mistark_line_params_elastic_rubberband.argtypes = [C.POINTER(LineParams)]
         L.mistark_line_params_elastic_rubberband.restype = None
@@ -150,6 +151,29 @@ def inertia_tensor_box(mass, size) -> np.ndarray:
     out = (C.c_double * 9)()
     _lib().mistark_inertia_tensor_box(float(mass), _d3(size), out)
     return np.array(out[:]).reshape(3, 3)
+
+
+def generate_triangle_grid(center, dim, subdivisions):
+    """stark::generate_triangle_grid: (vertices [n, 3], triangles [m, 3])."""
+    L = _lib()
+    L.mistark_generate_triangle_grid.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64)]
+    nv, nt = C.c_int64(), C.c_int64()
+    assert L.mistark_generate_triangle_grid(_d3(center), _d3(dim), _i3(subdivisions), None, C.byref(nv), None, C.byref(nt)) == 0
+    V, T = np.zeros((nv.value, 3)), np.zeros((nt.value, 3), dtype=np.int32)
+    assert L.mistark_generate_triangle_grid(_d3(center), _d3(dim), _i3(subdivisions), V.ctypes.data, C.byref(nv), T.ctypes.data, C.byref(nt)) == 0
+    return V, T
+
+
+def find_edges_from_triangles(triangles, n_vertices):
+    """stark::find_edges_from_simplices for triangles: unique edges [k, 2] in the reference's order."""
+    L = _lib()
+    L.mistark_find_edges_from_triangles.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.POINTER(C.c_int64)]
+    T = np.ascontiguousarray(triangles, dtype=np.int32)
+    ne = C.c_int64()
+    assert L.mistark_find_edges_from_triangles(T.ctypes.data, len(T), n_vertices, None, C.byref(ne)) == 0
+    E = np.zeros((ne.value, 2), dtype=np.int32)
+    assert L.mistark_find_edges_from_triangles(T.ctypes.data, len(T), n_vertices, E.ctypes.data, C.byref(ne)) == 0
+    return E
 
 
 def contact_global_params() -> ContactGlobalParams:
@@ -340,6 +364,9 @@ class Simulation:
 
     def prescribe_inside_aabb(self, point_set, center, dim, stiffness, tolerance=0.0) -> int:
         return self._ck(self.L.mistark_sim_prescribe_inside_aabb(self.h, point_set, _d3(center), _d3(dim), stiffness, tolerance))
+
+    def prescribe_outside_aabb(self, point_set, center, dim, stiffness, tolerance=0.0) -> int:
+        return self._ck(self.L.mistark_sim_prescribe_outside_aabb(self.h, point_set, _d3(center), _d3(dim), stiffness, tolerance))
 
     def set_newton_settings(self, s: capi.NewtonSettings):
         self._ck(self.L.mistark_sim_set_newton_settings(self.h, C.byref(s)))

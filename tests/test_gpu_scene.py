@@ -379,3 +379,36 @@ def test_attachment_tolerance_hardens_stiffness():
     assert ks.max() > 20.0 and np.all(np.log2(ks / 20.0) == np.round(np.log2(ks / 20.0)))
     assert sim.info().failed_steps >= 1
     sim.close()
+
+
+def test_hanging_net_example_trajectory():
+    """The reference's example scene hanging_net (examples/main.cpp:12-39): a net of Elastic_Rubberband segments along the edges of a
+    triangle grid, perimeter prescribed, hanging under gravity; same mesh utilities, same trajectory."""
+    from stark_amd import sim as S
+
+    z, traj, man = _load("traj_hangingnet_12")
+    sc = traj["scene"]
+    n, d = sc["n"], sc["size"]
+    st = S.default_settings()
+    st.init_frictional_contact = 0
+    sim = S.Simulation(st)
+    V, T = S.generate_triangle_grid((0.0, 0.0), (d, d), (n, n))
+    E = S.find_edges_from_triangles(T, len(V))
+    net = sim.add_line("segments", V, E, S.elastic_rubberband())
+    sim.prescribe_outside_aabb(net, (0.0, 0.0, 0.0), (d - 0.001, d - 0.001, d - 0.001), 1e3)
+    # the segments in the reference's order (find_edges_from_simplices)
+    names = [q["name"] for q in man["potentials"]]
+    conn = z["p%d_conn" % names.index("EnergySegmentStrain")]
+    assert np.array_equal(conn[:, 2:4], E)
+    its, cg = [], 0
+    for _ in traj["steps"]:
+        assert sim.run_one_step()
+        i = sim.info()
+        assert i.last_newton_result == 0
+        its.append(i.last_stats.newton_iterations)
+        cg += i.last_stats.cg_iterations
+    assert its == traj["newton_iterations"]
+    assert abs(cg - sum(traj["cg_iterations"])) <= 2
+    x = sim.points("x0")
+    assert np.abs(x - z["x_end"]).max() <= 1e-6 * np.abs(z["x_end"]).max()
+    sim.close()
