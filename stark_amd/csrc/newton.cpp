@@ -95,6 +95,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
             if (s.projection_mode == MISTARK_PROJ_PROGRESSIVE && !assembled) {
                 Timer t(st.t_assembly);
                 assemble(c);
+                MS_CHECK(hipStreamSynchronize(c.stream));  // stage timers measure GPU work, not launch time (the next stage synchronises anyway)
                 assembled = true;
             }
             bool reassemble = !assembled;  // projections performed after assembly update the matrix in place (update_global)
@@ -130,6 +131,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
             if (reassemble || !c.matrix_current) {  // (sharded runs cannot patch the summed matrix in place)
                 Timer t(st.t_assembly);
                 assemble(c);
+                MS_CHECK(hipStreamSynchronize(c.stream));  // stage timers measure GPU work, not launch time (the next stage synchronises anyway)
                 assembled = true;
             }
 
