@@ -1061,10 +1061,18 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restr
     const int comp = (int)(t - (int64_t)slot * 9);
     const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1];
     if (k1 - k0 > LONG_SLOT) return;  // k_assemble_long
+    // the contributions of a block are summed in list order (deterministic); their loads are issued eight at a time, the source ids
+    // first, so a thread has eight element-Hessian reads in flight instead of one dependent pair after the other
     double acc = 0.0;
-    for (uint32_t k = k0; k < k1; k++) {
-        const uint32_t src = sorted_src[k];
-        if (src != NO_SRC) acc += elemH[(size_t)src * 9 + comp];  // (the always-present diagonal keys carry no data)
+    for (uint32_t kb = k0; kb < k1; kb += 8) {
+        uint32_t src[8];
+        double h[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) src[u] = kb + u < k1 ? sorted_src[kb + u] : NO_SRC;
+#pragma unroll
+        for (int u = 0; u < 8; u++) h[u] = src[u] != NO_SRC ? elemH[(size_t)src[u] * 9 + comp] : 0.0;  // (the structural diagonal keys carry no data)
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += h[u];
     }
     vals[tile_val_index(slot, comp)] = (float)acc;
 }
