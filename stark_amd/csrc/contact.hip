@@ -478,23 +478,33 @@ __global__ __launch_bounds__(CB) void k_bp_gather(ContactDev d, Bands B, const u
     for (int k = 0; k < 6; k++) s_aabb[6 * (size_t)j + k] = b[k];
     s_lo[j] = b[B.axis];
 }
-__device__ __forceinline__ int lower_bound_f(const float* a, int lo, int hi, float v)  // first index with a[i] >= v
+// Binary search of the sorted lower bounds by a whole wavefront: every step probes 64 evenly spaced positions at once, so a range of n entries is
+// narrowed in log64(n) dependent loads instead of log2(n) (a sweep entry spent most of its time in these chains). STRICT: count the
+// entries < v (lower bound), otherwise the entries <= v (upper bound). All lanes return the same index.
+template <bool STRICT>
+__device__ __forceinline__ int wave_bound_f(const float* __restrict__ a, int lo, int hi, float v)
 {
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (a[mid] < v) lo = mid + 1;
-        else hi = mid;
+    const int lane = threadIdx.x & 63;
+    while (hi - lo > 64) {
+        const int step = (hi - lo + 63) >> 6;
+        const int pos = lo + lane * step;
+        bool below = false;
+        if (pos < hi) {
+            const float x = a[pos];
+            below = STRICT ? (x < v) : (x <= v);
+        }
+        const int c = __popcll(__ballot(below));  // the predicate is monotone along the sorted array: lanes 0 .. c-1
+        if (c == 0) return lo;
+        const int new_hi = lo + c * step < hi ? lo + c * step : hi;
+        lo = lo + (c - 1) * step + 1;
+        hi = new_hi;
     }
-    return lo;
-}
-__device__ __forceinline__ int upper_bound_f(const float* a, int lo, int hi, float v)  // first index with a[i] > v
-{
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (a[mid] <= v) lo = mid + 1;
-        else hi = mid;
+    bool below = false;
+    if (lo + lane < hi) {
+        const float x = a[lo + lane];
+        below = STRICT ? (x < v) : (x <= v);
     }
-    return lo;
+    return lo + __popcll(__ballot(below));
 }
 // One wavefront per sorted entry. PROXIMITY: point entries look for triangles (lo in [lo, hi]), triangle entries for points
 // (lo in (lo, hi]), edge entries for later edges. INTERSECTION (!PROXIMITY): edge entries look for triangles, triangle entries for edges.
@@ -525,9 +535,9 @@ __global__ __launch_bounds__(CB) void k_sweep(ContactDev d, Bands B, const uint3
     const int t_begin = seg[tc * NBANDS + band], t_end = seg[tc * NBANDS + band + 1];
     int j0;
     if (cls == 2 && tc == 2) j0 = sp + 1;                                   // later edges of the same segment
-    else if (cls == 0 || (!PROXIMITY && cls == 2)) j0 = lower_bound_f(s_lo, t_begin, t_end, lo);  // target lo in [lo, hi]
-    else j0 = upper_bound_f(s_lo, t_begin, t_end, lo);                        // target lo in (lo, hi]: the other direction took ties
-    const int j1 = upper_bound_f(s_lo, t_begin, t_end, hi);
+    else if (cls == 0 || (!PROXIMITY && cls == 2)) j0 = wave_bound_f<true>(s_lo, t_begin, t_end, lo);  // target lo in [lo, hi]
+    else j0 = wave_bound_f<false>(s_lo, t_begin, t_end, lo);                       // target lo in (lo, hi]: the other direction took ties
+    const int j1 = wave_bound_f<false>(s_lo, j0 > t_begin ? j0 : t_begin, t_end, hi);
     // (no local arrays indexed at run time: they would live in scratch memory)
     const int src_start = cls == 0 ? 0 : (cls == 1 ? d.n_v : d.n_v + d.n_t);
     const int tgt_start = tc == 0 ? 0 : (tc == 1 ? d.n_v : d.n_v + d.n_t);
