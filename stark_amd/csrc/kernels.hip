@@ -146,17 +146,57 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
     if (first) elemE[e] = r.v;
 }
 
-// Closed-form tet kernels (tet_closed.hpp): one lane per tet, 12 gradient atomics, 16 coalescing-friendly block stores
+// Closed-form tet kernels (tet_closed.hpp): one lane per tet, 12 gradient atomics. The 16 Hessian blocks of a tet belong to 16 pools
+// (H[pair][element][9]); a lane storing its own 72 bytes would make every store instruction touch 64 separate segments, so each block
+// goes through LDS: the wavefront's 64 blocks of one pair are 4608 contiguous bytes and leave as nine fully coalesced stores (and nine
+// more for the transposed pair).
+struct TetBlockStagedSink
+{
+    double* stage;    // [9][64] of this wavefront
+    double* Hwave;    // pool position of the wavefront's first element (pair 0)
+    size_t hstride;   // doubles between pair pools
+    int lane, n_valid;
+    __device__ __forceinline__ void put(int a, int b, const double* blk)
+    {
+#pragma unroll
+        for (int c = 0; c < 9; c++) stage[c * 64 + lane] = blk[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double* Hab = Hwave + (size_t)(a * 4 + b) * hstride;
+        double* Hba = Hwave + (size_t)(b * 4 + a) * hstride;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const int idx = k * 64 + lane, el = idx / 9, c = idx - 9 * el;
+            if (el < n_valid) {
+                Hab[idx] = stage[c * 64 + el];
+                if (a != b) Hba[idx] = stage[((c % 3) * 3 + c / 3) * 64 + el];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
 template <class En, bool FULL, bool STORE_H>
 __global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
 {
+    __shared__ double stage[STORE_H ? (BLOCK / 64) * 9 * 64 : 1];
     const int le = blockIdx.x * BLOCK + threadIdx.x;
-    if (le >= a.e_count) return;
-    const int e = a.e_begin + le;
+    const bool valid = le < a.e_count;
+    const int e = a.e_begin + (valid ? le : a.e_count - 1);  // (lanes past the end repeat the last element and store nothing)
     double in[En::Layout::NIN];
     gather_inputs<En>(a, e, in);
     double E, g[12];
-    tet_closed_eval<FULL>(in, E, g, STORE_H ? elemH + (size_t)e * 9 : nullptr, (size_t)a.n_elem * 9, STORE_H);
+    if (STORE_H) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        const int le_wave = le - lane;
+        TetBlockStagedSink sink{stage + wave * 9 * 64, elemH + (size_t)(a.e_begin + le_wave) * 9, (size_t)a.n_elem * 9, lane, min(64, a.e_count - le_wave)};
+        tet_closed_eval_to<FULL>(in, E, g, sink, true);
+    } else {
+        tet_closed_eval<FULL>(in, E, g, nullptr, 0, false);
+    }
+    if (!valid) return;
     elemE[e] = E;
     const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
 #pragma unroll

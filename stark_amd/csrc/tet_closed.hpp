@@ -23,8 +23,8 @@ namespace mistark {
 // in[]: gathered inputs in the binding order of the reference (same layout as E_TetStrain / E_TetStrainEO in energies.hpp):
 //   v1[4] (0..11), x0[4] (12..23), X[4] (24..35), then EO: scale, e, nu, dt | FULL: scale, e, nu, strain_limit, strain_limit_stiffness, damping, dt
 // out: E (energy), g[12] (dE/dv), 3x3 blocks (a,b) row-major at H + (4a+b)*hstride (only if want_h)
-template <bool FULL>
-MS_HD void tet_closed_eval(const double* in, double& E_out, double* g, double* H, size_t hstride, bool want_h)
+template <bool FULL, class Sink>
+MS_HD void tet_closed_eval_to(const double* in, double& E_out, double* g, Sink& sink, bool want_h)
 {
     const double scale = in[36], e = in[37], nu = in[38];
     const double strain_limit = FULL ? in[39] : 0.0, sl_k = FULL ? in[40] : 0.0, damping = FULL ? in[41] : 0.0;
@@ -207,15 +207,33 @@ MS_HD void tet_closed_eval(const double* in, double& E_out, double* g, double* H
             M[2][1] -= q[0];
             M[2][0] += q[1];
             M[0][2] -= q[1];
-            double* Hab = H + (size_t)(a * 4 + b) * hstride;
-            double* Hba = H + (size_t)(b * 4 + a) * hstride;
+            double blk[9];
             for (int i = 0; i < 3; i++)
-                for (int k = 0; k < 3; k++) {
-                    const double v = sh * M[i][k];
-                    Hab[3 * i + k] = v;
-                    Hba[3 * k + i] = v;
-                }
+                for (int k = 0; k < 3; k++) blk[3 * i + k] = sh * M[i][k];
+            sink.put(a, b, blk);  // block (a, b), a <= b; the sink also places the transposed block (b, a)
         }
+}
+// blocks straight to memory: (a, b) row-major at H + (4a+b)*hstride
+struct TetBlockMemSink
+{
+    double* H;
+    size_t hstride;
+    MS_HD void put(int a, int b, const double* blk)
+    {
+        double* Hab = H + (size_t)(a * 4 + b) * hstride;
+        double* Hba = H + (size_t)(b * 4 + a) * hstride;
+        for (int i = 0; i < 3; i++)
+            for (int k = 0; k < 3; k++) {
+                Hab[3 * i + k] = blk[3 * i + k];
+                Hba[3 * k + i] = blk[3 * i + k];
+            }
+    }
+};
+template <bool FULL>
+MS_HD void tet_closed_eval(const double* in, double& E_out, double* g, double* H, size_t hstride, bool want_h)
+{
+    TetBlockMemSink sink{H, hstride};
+    tet_closed_eval_to<FULL>(in, E_out, g, sink, want_h);
 }
 
 }  // namespace mistark
