@@ -87,11 +87,11 @@ def cpu_baseline(nx, ny, nz, scene="contact"):
         args += ["L=1", "gap=%g" % GAP, "thickness=%g" % THICKNESS, "mu=%g" % MU, "kmin=%g" % KMIN, "bx=%g" % BOX[0], "bz=%g" % BOX[2], "boxfirst=1"]
     try:
         subprocess.run([harness, "prime", name, "nx=2", "ny=2", "nz=2"] + args[3:], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-        out = subprocess.run([harness, "time", name] + args + ["steps=2", "warmup=1"], check=True, capture_output=True, timeout=1500).stdout.decode()
+        out = subprocess.run([harness, "time", name] + args + ["steps=4", "warmup=1"], check=True, capture_output=True, timeout=1500).stdout.decode()
         line = [l for l in out.splitlines() if l.startswith("{")][-1]
         r = json.loads(line)
         return {"value": r["newton_steps_per_s"], "unit": "Newton-steps/s", "cores": threads, "kind": "reference",
-                "sample": "same scene, %d Newton iterations over 2 time steps after 1 warm-up step (pattern build + JIT excluded)" % r["newton_iterations"],
+                "sample": "same scene, %d Newton iterations over 4 time steps after 1 warm-up step (pattern build + JIT excluded)" % r["newton_iterations"],
                 "ms_per_linear_solve": r["ms_per_linear_solve"], "wall_s": r["wall_s"], "newton_iterations": r["newton_iterations"],
                 "linear_solves": r.get("linear_solves")}
     except Exception as e:  # noqa: BLE001
@@ -205,10 +205,10 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
-                # HBM-side bytes per real SpMV launch from rocprofv3 PMC passes of this command (profiles/r01_v6_pmc_*.txt):
+                # HBM-side bytes per real SpMV launch from rocprofv3 PMC passes of this command (profiles/r01_v7_pmc_*.txt):
                 # 2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KB -> bytes.
                 # Only valid for the default workload; other sizes report null.
-                "traffic": (2 * 65124.8 + 5393.0) * 1024.0 if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
+                "traffic": (2 * 61690.2 + 5215.0) * 1024.0 if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "avg_launch_ms": spmv_ms,
                 "launches_timed": spmv_n,
