@@ -824,7 +824,7 @@ void contact_init(Context& c, const mistark_contact_arrays& arr)
             bs.push_back(mistark_binding{id, b.stride, b.col});
         }
         T.pot = register_potential(c, TABLE_NAMES[t], nullptr, 0, T.stride, bs.data(), (int)bs.size());
-        c.pots[T.pot].part = getenv("MISTARK_NO_SPLIT") ? 0 : 1;  // (debug switch: everything in the static part)
+        c.pots[T.pot].part = 1;  // contact tables change inside the Newton loop: dynamic matrix part
         T.conn.ensure(64 * (size_t)T.stride);
         c.pots[T.pot].conn_ext = T.conn.p;
         c.pots[T.pot].conn_dirty = false;

@@ -406,7 +406,6 @@ bool EnergyRigidBodyConstraints::_adjust_constraints_stiffness(double cap, doubl
                 }
                 default: break;
             }
-            if (getenv("MISTARK_DEBUG_RB")) std::printf("rb constraint kind %d idx %d: C = %.6g tol %.6g k %.3g (positions_set %d)\n", kind, idx, C, T.tolerance[idx], T.stiffness[idx], (int)are_positions_set);
             if (C > T.tolerance[idx]) {
                 is_valid = false;
                 T.stiffness[idx] *= multiplier;
