@@ -68,6 +68,19 @@ typedef struct mistark_binding
  * Returns the potential id (>= 0). Calling again with an existing name replaces connectivity and bindings. */
 int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride,
                       const mistark_binding* bindings, int32_t n_bindings);
+
+/* A potential WITHOUT a hand-written kernel (user-defined energies, README.md:109-126 of the reference): the energy is handed over as
+ * SymX's own straight-line op sequence and interpreted on the device (slow path; see csrc/custom.hip). The reference-side shim builds
+ * it with `symx::Sequence seq({potential.get_expression()})` (symx/src/compile/Sequence.h:24-41) and copies `seq.ops`:
+ *   ops       n_ops rows {type, dst, a, b, cond} with symx::ExprType codes (symx/src/symbol/Expr.h:12-43) and the value numbering of
+ *             symx/src/compile/Compilation.cpp:381-469: values < n_inputs are the gathered inputs (the bindings flattened in order),
+ *             a Symbol op binds output 0 (the energy), Branch ops are the if (value > 0) / else / endif markers
+ *   constants one double per op (used by ConstantFloat ops)
+ *   cond_*    optional second sequence: the element is active iff its value is > 0 (Potential::get_condition, conditional potentials)
+ * Bindings on DoF arrays define the local DoF blocks exactly as for mistark_potential. Limits: 96 inputs, 256 live temporaries. */
+int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings,
+                             const int32_t* ops, const double* constants, int32_t n_ops, int32_t n_inputs, const int32_t* cond_ops, const double* cond_constants,
+                             int32_t n_cond_ops);
 /* Marks a potential whose connectivity changes inside the Newton loop (the reference's contact tables are refilled in
  * before_energy_evaluation, EnergyFrictionalContact.cpp:117-119). Its Hessian blocks go to a second, small block-CSR part
  * (A = A_static + A_dynamic) so that a connectivity update only re-patterns that part, not the whole matrix. */

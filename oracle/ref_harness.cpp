@@ -687,6 +687,22 @@ static void dump_snapshot(Scene& sc, const std::string& dir, const Args& a)
         man << "]";
 
         if (n_elem > 0) {
+            // the energy (and condition) as SymX's own straight-line op sequence (symx/src/compile/Sequence.h:24-41; semantics of an op:
+            // Compilation.cpp:381-469): rows {type, dst, a, b, cond} + one constant per op. What a generic evaluator consumes.
+            auto dump_ops = [&](const symx::Scalar& expr, const std::string& tag) {
+                symx::Sequence seq({ expr });
+                std::vector<int32_t> rows;
+                std::vector<double> consts;
+                for (const auto& op : seq.ops) {
+                    rows.insert(rows.end(), { (int32_t)op.type, op.dst, op.a, op.b, op.cond });
+                    consts.push_back(op.constant);
+                }
+                npy_i32(P + "_" + tag + ".npy", rows.data(), { seq.ops.size(), (size_t)5 });
+                npy_f64(P + "_" + tag + "c.npy", consts.data(), { seq.ops.size() });
+                return seq.get_n_inputs();
+            };
+            man << ",\"n_inputs\":" << dump_ops(pot.get_expression(), "ops");
+            if (pot.has_conditional()) dump_ops(pot.get_condition(), "cops");
             symx::DeferredParallelTasks tasks;
             symx::SecondOrderCompiledPotential cp(pot, dof_maps, st.context->compilation_directory, tasks);
             tasks.run(8);

@@ -60,6 +60,52 @@ int register_potential(Context& c, const char* name, const int32_t* conn, int32_
     c.layout_dirty = true;
     return id;
 }
+int register_custom_potential(Context& c, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings,
+                              const int32_t* ops, const double* consts, int32_t n_ops, int32_t n_inputs, const int32_t* cond_ops, const double* cond_consts, int32_t n_cond_ops)
+{
+    if (!name || !*name) throw Error("custom potential: empty name");
+    if (n_bindings <= 0 || n_bindings > MAX_BIND) throw Error(std::string("custom potential '") + name + "': between 1 and " + std::to_string(MAX_BIND) + " bindings");
+    if (n_elem < 0 || conn_stride <= 0) throw Error("bad connectivity shape");
+    std::vector<int32_t> strides((size_t)n_bindings);
+    int nb = 0;
+    for (int b = 0; b < n_bindings; b++) {
+        if (bindings[b].array < 0 || bindings[b].array >= (int)c.arrays.size()) throw Error(std::string("custom potential '") + name + "': bad array id in binding " + std::to_string(b));
+        const Array& arr = c.arrays[bindings[b].array];
+        if (bindings[b].stride != arr.stride) throw Error(std::string("custom potential '") + name + "': binding " + std::to_string(b) + " stride differs from its array's");
+        if (bindings[b].conn_col >= conn_stride) throw Error(std::string("custom potential '") + name + "': connectivity column out of range");
+        if (arr.dof_set >= 0) {
+            if (arr.stride != 3 || bindings[b].conn_col < 0) throw Error(std::string("custom potential '") + name + "': DoF bindings are 3-vectors fetched through a connectivity column");
+            nb++;
+        }
+        strides[b] = bindings[b].stride;
+    }
+    if (nb == 0 || nb > MAX_NB) throw Error(std::string("custom potential '") + name + "': between 1 and " + std::to_string(MAX_NB) + " DoF bindings");
+    auto prog = make_custom_program(name, strides.data(), n_bindings, ops, consts, n_ops, n_inputs, cond_ops, cond_consts, n_cond_ops);
+    Potential* P = nullptr;
+    int id = -1;
+    for (size_t i = 0; i < c.pots.size(); i++)
+        if (c.pots[i].name == name) {
+            P = &c.pots[i];
+            id = (int)i;
+        }
+    if (!P) {
+        c.pots.emplace_back();
+        P = &c.pots.back();
+        id = (int)c.pots.size() - 1;
+    }
+    P->name = name;
+    P->kind = KIND_CUSTOM;
+    P->prog = prog;
+    P->NB = nb;
+    P->n_elem = n_elem;
+    P->conn_stride = conn_stride;
+    if (conn) P->conn_host.assign(conn, conn + (size_t)n_elem * conn_stride);
+    else P->conn_host.clear();
+    P->bindings.assign(bindings, bindings + n_bindings);
+    P->conn_dirty = true;
+    c.layout_dirty = true;
+    return id;
+}
 }  // namespace mistark
 
 extern "C" {
@@ -245,6 +291,13 @@ int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, i
 {
     API_BEGIN
     _ret = register_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings);
+    API_END(_ret)
+}
+int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings,
+                             const int32_t* ops, const double* constants, int32_t n_ops, int32_t n_inputs, const int32_t* cond_ops, const double* cond_constants, int32_t n_cond_ops)
+{
+    API_BEGIN
+    _ret = register_custom_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings, ops, constants, n_ops, n_inputs, cond_ops, cond_constants, n_cond_ops);
     API_END(_ret)
 }
 int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)

@@ -102,10 +102,13 @@ struct Array
     bool need_upload = true;
 };
 
+struct CustomProgram;  // custom.hip: an energy given as SymX's op sequence, interpreted on the device
+constexpr int KIND_CUSTOM = -2;
 struct Potential
 {
     std::string name;
-    int kind = -1;
+    int kind = -1;              // index into the registry of compiled kernels, or KIND_CUSTOM
+    std::shared_ptr<CustomProgram> prog;
     int NB = 0;
     int n_elem = 0;
     int conn_stride = 0;
@@ -248,6 +251,10 @@ double spmv_bench(Context& c, int n);
 void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed);
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info);
 bool direct_llt(Context& c, const double* rhs_dev, double* x_dev);  // direct.hip
+// custom.hip
+std::shared_ptr<CustomProgram> make_custom_program(const std::string& name, const int32_t* strides, int n_bindings, const int32_t* ops, const double* consts, int n_ops, int n_inputs,
+                                                   const int32_t* cond_ops, const double* cond_consts, int n_cond_ops);
+void launch_eval_custom(Context& c, Potential& P, int mode);
 double reduce_max_abs(Context& c, const double* v, int64_t n);
 double reduce_dot(Context& c, const double* a, const double* b, int64_t n);
 void vec_axpby(Context& c, double* dst, double a, const double* x, double b, const double* y, int64_t n);

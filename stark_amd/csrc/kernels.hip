@@ -235,6 +235,10 @@ static void launch_eval(Context& c, Potential& P, int mode)
 
 static void launch_eval_kind(Context& c, Potential& P, int mode)
 {
+    if (P.kind == KIND_CUSTOM) {  // no compiled kernel under this name: the caller supplied the expression (custom.hip)
+        launch_eval_custom(c, P, mode);
+        return;
+    }
     if (mode != MISTARK_EVAL_P && !c.force_generic) {
         if (P.name == E_TetStrain::name) { launch_tet_closed<E_TetStrain, true>(c, P, mode); return; }
         if (P.name == E_TetStrainEO::name) { launch_tet_closed<E_TetStrainEO, false>(c, P, mode); return; }

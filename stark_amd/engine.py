@@ -65,6 +65,26 @@ class Engine:
         self.potential_ids[name] = pid
         return pid
 
+    def potential_custom(self, name: str, conn: np.ndarray, bindings, ops, constants, n_inputs: int, cond_ops=None, cond_constants=None) -> int:
+        """A potential given as SymX's op sequence (rows {type, dst, a, b, cond} + one constant per op), interpreted on the device."""
+        conn = np.ascontiguousarray(conn, dtype=np.int32)
+        b = (capi.Binding * len(bindings))(*[capi.Binding(a, s, c) for a, s, c in bindings])
+        ops = np.ascontiguousarray(ops, dtype=np.int32).reshape(-1, 5)
+        cst = np.ascontiguousarray(constants, dtype=np.float64)
+        nco = 0
+        cops = ccst = None
+        if cond_ops is not None and len(cond_ops):
+            cops = np.ascontiguousarray(cond_ops, dtype=np.int32).reshape(-1, 5)
+            ccst = np.ascontiguousarray(cond_constants, dtype=np.float64)
+            nco = len(cops)
+        self.L.mistark_potential_custom.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(capi.Binding), C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        pid = self._ck(self.L.mistark_potential_custom(self.h, name.encode(), conn.ctypes.data if conn.size else None, conn.shape[0], conn.shape[1], b, len(bindings),
+                                                       ops.ctypes.data, cst.ctypes.data, len(ops), int(n_inputs), cops.ctypes.data if nco else None,
+                                                       ccst.ctypes.data if nco else None, nco))
+        self.potential_ids[name] = pid
+        return pid
+
     def set_dynamic(self, pid: int, dynamic: bool = True):
         """Routes the potential's Hessian blocks to the dynamic (contact) part of the split matrix."""
         self._ck(self.L.mistark_potential_set_dynamic(self.h, pid, int(dynamic)))

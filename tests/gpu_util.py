@@ -4,7 +4,9 @@ import numpy as np
 import stark_amd
 
 
-def engine_from_problem(prob, man=None):
+def engine_from_problem(prob, man=None, custom_ops=None):
+    """custom_ops: the fixture's npz; every potential is then registered through mistark_potential_custom with the reference's own op
+    sequence (interpreted on the device) instead of its compiled kernel."""
     eng = stark_amd.Engine(0)
     host = [np.ascontiguousarray(a, dtype=np.float64) for a in prob.arrays]
     # DoF sets in registration order; empty sets are registered with size 0
@@ -24,7 +26,13 @@ def engine_from_problem(prob, man=None):
             if key not in ids:
                 ids[key] = eng.array(host[b.array].reshape(-1, b.stride), b.stride)
             bs.append((ids[key], b.stride, b.conn))
-        pot_ids[pi] = eng.potential(pot.name, pot.conn, bs)
+        if custom_ops is not None:
+            z = custom_ops
+            has_c = ("p%d_cops" % pi) in z
+            pot_ids[pi] = eng.potential_custom(pot.name, pot.conn, bs, z["p%d_ops" % pi], z["p%d_opsc" % pi], sum(s for _, s, _ in bs),
+                                               z["p%d_cops" % pi] if has_c else None, z["p%d_copsc" % pi] if has_c else None)
+        else:
+            pot_ids[pi] = eng.potential(pot.name, pot.conn, bs)
     eng.host_arrays = host
     eng.array_ids = ids
     eng.pot_ids = pot_ids

@@ -26,14 +26,15 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-@pytest.mark.parametrize("variant", ["default", "generic_atomic", "split_matrix", "split_matrix_atomic"])
+@pytest.mark.parametrize("variant", ["default", "generic_atomic", "split_matrix", "split_matrix_atomic", "custom_ops"])
 @pytest.mark.parametrize("path", DUMPS, ids=[os.path.basename(p)[:-4] for p in DUMPS])
 def test_stages_match_reference(path, variant):
     from gpu_util import engine_from_problem
     from stark_amd import capi
 
     prob, man, z = ev.load_fixture(path)
-    eng = engine_from_problem(prob, man)
+    # custom_ops: no compiled kernel is used; every potential runs the reference's symx::Sequence through the device interpreter
+    eng = engine_from_problem(prob, man, custom_ops=z if variant == "custom_ops" else None)
     assert eng.ndofs == man["ndofs"]
     if variant == "generic_atomic":  # generic hyper-dual kernels for every potential + atomic scatter assembly
         eng.set_option("force_generic", 1)

@@ -97,3 +97,26 @@ def test_oracle_newton_trajectory(path):
         assert np.abs(a - b).max() <= 1e-6 * max(1.0, np.abs(b).max())
     iv1, ix0, iv0 = ev.point_state_arrays(prob)
     assert np.abs(prob.arrays[ix0] - z["x_end"]).max() <= 1e-6 * np.abs(z["x_end"]).max()
+
+
+@pytest.mark.parametrize("path", DUMPS, ids=[os.path.basename(p)[:-4] for p in DUMPS])
+def test_symx_op_sequences_reproduce_reference_elements(path):
+    """The op sequences the fixtures carry (the reference's own symx::Sequence of every potential's energy) evaluated by the oracle's
+    interpreter give the reference's element Hessians: pins both the fixtures' sequences and the interpreter used as oracle for
+    stark_amd/csrc/custom.hip."""
+    from oracle import symx_ops
+
+    prob, man, z = ev.load_fixture(path)
+    n_checked = 0
+    for pi, ref in enumerate(man["potentials"]):
+        if ref["n_elem"] == 0 or ("p%d_ops" % pi) not in z:
+            continue
+        pot = prob.potentials[pi]
+        cops = z["p%d_cops" % pi] if ("p%d_cops" % pi) in z else None
+        o = symx_ops.evaluate(prob, pot, z["p%d_ops" % pi], z["p%d_opsc" % pi], cops, z["p%d_copsc" % pi] if cops is not None else None)
+        assert len(o.E) == ref["n_hessians"], ref["name"]
+        assert abs(o.E.sum() - ref["E"]) <= 1e-11 * max(1.0, np.abs(o.E).sum()), ref["name"]
+        assert (z["p%d_hrows" % pi] == o.block_rows).all()
+        assert _rel(o.H, z["p%d_hvals" % pi]) < ELEMENT_TOL.get(ref["name"], 1e-11), ref["name"]
+        n_checked += 1
+    assert n_checked > 0
