@@ -962,7 +962,8 @@ int main(int argc, char** argv)
         const std::string dir = a.s("out", "/tmp/mistark_traj");
         fs::create_directories(dir);
         st.callbacks->run_before_time_step();  // fills the per-step caches (rigid-body q0_, J0_glob; v1 = 0) the potentials read
-        dump_snapshot(sc, dir, a);  // evaluator inputs + stage outputs at the initial state (t = 0, v1 = 0)
+        const bool slim = a.i("slim", 0) != 0;  // larger scenes: only the step log and the final state (no evaluator inputs, no iterates)
+        if (!slim) dump_snapshot(sc, dir, a);  // evaluator inputs + stage outputs at the initial state (t = 0, v1 = 0)
         std::vector<std::vector<double>> iterates;
         std::vector<int> iter_step;
         int cur_step = 0;
@@ -970,6 +971,7 @@ int main(int argc, char** argv)
             std::vector<double> u(st.global_potential->get_total_n_dofs());
             st.global_potential->get_dofs(u.data());
             if (!iterates.empty() && iter_step.back() == cur_step && iterates.back() == u) return;
+            if (slim) iterates.clear();  // (keep the last one for the duplicate test only)
             iterates.push_back(u);
             iter_step.push_back(cur_step);
         });
@@ -994,7 +996,7 @@ int main(int argc, char** argv)
         const size_t nd = st.global_potential->get_total_n_dofs();
         std::vector<double> flat(iterates.size() * nd);
         for (size_t i = 0; i < iterates.size(); i++) std::memcpy(&flat[i * nd], iterates[i].data(), nd * sizeof(double));
-        npy_f64(dir + "/iterates.npy", flat.data(), { iterates.size(), nd });
+        if (!slim) npy_f64(dir + "/iterates.npy", flat.data(), { iterates.size(), nd });
         auto& ps = *sc.sim->deformables->point_sets;
         if (ps.size() > 0) {
             npy_f64(dir + "/x_end.npy", ps.x0.data[0].data(), { (size_t)ps.size(), 3 });

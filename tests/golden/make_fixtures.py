@@ -56,6 +56,10 @@ FIXTURES = {
     "traj_cloth_flat_8": ("traj", "cloth", "n=8 flat=1 eo=0 steps=3"),
     # the same beam with the reference's DirectLLT linear solver (exact Newton steps)
     "traj_tetbeam_llt_6x2x2": ("traj", "tetbeam", "nx=6 ny=2 nz=2 eo=1 steps=3 solver=llt"),
+    # configs[1] at FULL size (105 k tets, Soft_Rubber with damping + strain limiting, clamped end, no contact) and a mid-size configs[3]
+    # (12 k-tet block on a fixed box, contact + friction): step log and final state only
+    "traj_cfg1_tetbeam_52x13x13": ("traj", "tetbeam", "nx=52 ny=13 nz=13 eo=0 steps=3 slim=1 threads=8"),
+    "traj_cfg3_blockbox_10": ("traj", "blockbox", "nx=10 ny=10 nz=10 L=0.5 gap=0.002 thickness=0.002 bx=1.5 kmin=1e6 steps=4 boxfirst=1 slim=1 threads=8"),
     # contact scenes (cfg 1 / cfg 4 at fixture size): cloth resting on a fixed rigid box, soft block pressed on a fixed rigid box
     "traj_clothbox_8": ("traj", "clothbox", "n=8 gap=0.004 steps=4"),
     "traj_blockbox_3": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=1"),

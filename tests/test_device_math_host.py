@@ -15,7 +15,7 @@ from oracle import evaluator as ev
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-DUMPS = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "geometry" not in os.path.basename(p))
+DUMPS = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "geometry" not in os.path.basename(p) and "_cfg" not in os.path.basename(p))  # (traj_cfg*: step log + final state only, scene tests)
 ELEMENT_TOL = {"EnergyDiscreteShells": 1e-8}  # see tests/test_oracle_golden.py
 
 

@@ -12,7 +12,8 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def _load(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
-    return z, json.loads(bytes(z["traj_json"]).decode()), json.loads(bytes(z["manifest_json"]).decode())
+    man = json.loads(bytes(z["manifest_json"]).decode()) if "manifest_json" in z else None  # (traj_cfg*: step log + final state only)
+    return z, json.loads(bytes(z["traj_json"]).decode()), man
 
 
 def test_tetbeam_scene_trajectory():
@@ -226,10 +227,10 @@ def test_cloth_on_box_contact_trajectory():
     sim.close()
 
 
-@pytest.mark.parametrize("name", ["traj_blockbox_3", "traj_blockbox_3_nofriction"])
+@pytest.mark.parametrize("name", ["traj_blockbox_3", "traj_blockbox_3_nofriction", "traj_cfg3_blockbox_10"])
 def test_block_on_box_contact_trajectory(name):
-    """cfg 4 at fixture size: Soft_Rubber tet block landing on a fixed rigid box (collision surface from find_surface), with
-    friction (box registered first) and without (block first)."""
+    """configs[3] at fixture size (and at 12 k tets): Soft_Rubber tet block landing on a fixed rigid box (collision surface from
+    find_surface), with friction (box registered first) and without (block first)."""
     from stark_amd import sim as S
 
     z, traj, man = _load(name)
@@ -411,4 +412,32 @@ def test_hanging_net_example_trajectory():
     assert abs(cg - sum(traj["cg_iterations"])) <= 2
     x = sim.points("x0")
     assert np.abs(x - z["x_end"]).max() <= 1e-6 * np.abs(z["x_end"]).max()
+    sim.close()
+
+
+def test_cfg1_full_size_beam_trajectory():
+    """configs[1] at its full size: generate_tet_grid{52,13,13} = 105 456 tets, Soft_Rubber with damping and strain limiting, clamped
+    end, 3 time steps of the unmodified reference (8 threads): same Newton iteration counts, CG total within 2 %, end state 1e-6."""
+    from stark_amd import sim as S
+
+    z, traj, _ = _load("traj_cfg1_tetbeam_52x13x13")
+    sc = traj["scene"]
+    sim = S.Simulation()
+    p = S.soft_rubber()
+    p.elasticity_only = sc["eo"]
+    ps = sim.add_volume_grid("beam", (0, 0, 0), (sc["lx"], sc["ly"], sc["lz"]), (sc["nx"], sc["ny"], sc["nz"]), p)
+    sim.prescribe_inside_aabb(ps, (-0.5 * sc["lx"], 0, 0), (2e-3, 2 * sc["ly"], 2 * sc["lz"]), 1e7)
+    cg = 0
+    its = []
+    for step in range(len(traj["steps"])):
+        assert sim.run_one_step()
+        i = sim.info()
+        assert i.last_newton_result == 0 and abs(i.current_time - traj["steps"][step]["time"]) < 1e-12
+        its.append(i.last_stats.newton_iterations)
+        cg += i.last_stats.cg_iterations
+    assert its == traj["newton_iterations"]
+    assert abs(cg - sum(traj["cg_iterations"])) <= 0.02 * sum(traj["cg_iterations"]) + 2
+    assert sim.points("x0").shape == z["x_end"].shape
+    assert np.abs(sim.points("x0") - z["x_end"]).max() <= 1e-6 * np.abs(z["x_end"]).max()
+    assert np.abs(sim.points("v0") - z["v_end"]).max() <= 1e-5 * max(np.abs(z["v_end"]).max(), 1.0)
     sim.close()

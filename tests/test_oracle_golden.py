@@ -15,7 +15,7 @@ import scipy.sparse as sp
 from oracle import evaluator as ev
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-DUMPS = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "geometry" not in os.path.basename(p))
+DUMPS = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "geometry" not in os.path.basename(p) and "_cfg" not in os.path.basename(p))  # (traj_cfg*: step log + final state only, scene tests)
 
 
 # EnergyDiscreteShells evaluates acos((1-1e-12) n0.n1) on (nearly) flat hinges: d acos/dx = -1/sqrt(1-x^2) with
