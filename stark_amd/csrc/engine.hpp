@@ -210,6 +210,8 @@ struct Context
     double* h_scratch = nullptr;    // pinned host scratch
     void* h_pin = nullptr;          // pinned staging area of fetch()
     size_t h_pin_bytes = 0;
+    uint8_t* pub = nullptr;         // coherent pinned page small read-backs are published into (kernels.hip: publish)
+    uint32_t pub_seq = 0;
     size_t h_scratch_n = 0;
 
     // SpMV timing

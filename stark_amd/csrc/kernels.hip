@@ -341,9 +341,49 @@ static double* host_scratch(Context& c, size_t n)
     }
     return c.h_scratch;
 }
+// Small device -> host read-backs (scalars, partial sums, counters: a few dozen per Newton iteration). Instead of a copy command plus a
+// stream synchronisation, a one-workgroup kernel writes the words into coherent pinned host memory and then a sequence number; the
+// host spins on that number. Saves the copy-engine hop and the completion-signal round trip of every read-back.
+constexpr size_t PUBLISH_MAX_BYTES = 8192;
+__global__ __launch_bounds__(256) void k_publish(const uint32_t* __restrict__ src, int n_words, uint32_t* __restrict__ dst_host, uint32_t* __restrict__ flag_host, uint32_t seq)
+{
+    for (int i = threadIdx.x; i < n_words; i += 256) dst_host[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_store_n(flag_host, seq, __ATOMIC_RELEASE);
+        __threadfence_system();
+    }
+}
+static bool publish(Context& c, void* dst_host, const void* src_dev, size_t bytes)
+{
+    if (bytes > PUBLISH_MAX_BYTES || (bytes & 3) || (reinterpret_cast<uintptr_t>(src_dev) & 3)) return false;
+    if (!c.pub) {
+        MS_CHECK(hipHostMalloc((void**)&c.pub, PUBLISH_MAX_BYTES + 64, hipHostMallocCoherent | hipHostMallocMapped));
+        std::memset(c.pub, 0, PUBLISH_MAX_BYTES + 64);
+    }
+    uint32_t* flag = reinterpret_cast<uint32_t*>(c.pub + PUBLISH_MAX_BYTES);
+    const uint32_t seq = ++c.pub_seq;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c.stream, (const uint32_t*)src_dev, (int)(bytes / 4), (uint32_t*)c.pub, flag, seq);
+    // spin; fall back to a real synchronisation now and then so that a failed launch surfaces as an error instead of a hang
+    for (uint64_t spins = 0;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 0xFFFFF) == 0xFFFFF) {
+            MS_CHECK(hipStreamQuery(c.stream) == hipErrorNotReady ? hipSuccess : hipStreamSynchronize(c.stream));
+            if (hipStreamQuery(c.stream) == hipSuccess && __atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                MS_CHECK(hipStreamSynchronize(c.stream));
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) throw Error("read-back kernel finished without publishing its data");
+                break;
+            }
+        }
+    }
+    std::memcpy(dst_host, c.pub, bytes);
+    return true;
+}
 void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes)
 {
     if (bytes == 0) return;
+    if (publish(c, dst_host, src_dev, bytes)) return;
     if (c.h_pin_bytes < bytes) {
         if (c.h_pin) (void)hipHostFree(c.h_pin);
         c.h_pin_bytes = std::max<size_t>(bytes, 1 << 16);
@@ -355,6 +395,7 @@ void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes)
 }
 static void fetch_partials(Context& c, int n, double* out_host, const double* part_dev)
 {
+    if (publish(c, out_host, part_dev, (size_t)n * sizeof(double))) return;
     MS_CHECK(hipMemcpyAsync(out_host, part_dev, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
 }
@@ -1718,6 +1759,7 @@ Context::~Context()
     for (auto e : pcg_ev) (void)hipEventDestroy(e);
     if (h_scratch) (void)hipHostFree(h_scratch);
     if (h_pin) (void)hipHostFree(h_pin);
+    if (pub) (void)hipHostFree(pub);
     if (stream) (void)hipStreamDestroy(stream);
 }
 
