@@ -199,16 +199,16 @@ def main():
             "host_timers_s": {k: round(v, 6) for k, v in stage.items()},
             "contact": sim.contact_info() if a.scene == "contact" else None,
             "roofline": {
-                "kernel": "k_spmv (3x3-block CSR, float values, double vectors)",
+                "kernel": "k_spmv_fused (3x3-block CSR in row-aligned chunks, float values, double vectors)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
-                # HBM-side bytes per real SpMV launch from rocprofv3 PMC passes of this command (profiles/r01_v7_pmc_*.txt):
+                # HBM-side bytes per real SpMV launch from rocprofv3 PMC passes of this command (profiles/r01_v8_pmc_*.txt):
                 # 2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KB -> bytes.
                 # Only valid for the default workload; other sizes report null.
-                "traffic": (2 * 61690.2 + 5215.0) * 1024.0 if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
+                "traffic": (2 * 56787.4 + 5809.1) * 1024.0 if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "avg_launch_ms": spmv_ms,
                 "launches_timed": spmv_n,

@@ -463,13 +463,19 @@ int mistark_get_bsr(mistark_ctx* ctx, int64_t* n_block_rows, int64_t* nnzb, int6
             tv.resize((size_t)m.ntiles * 576);
             MS_CHECK(hipMemcpyAsync(tv.data(), m.vals.p, tv.size() * sizeof(float), hipMemcpyDeviceToHost, c.stream));
         }
+        std::vector<uint32_t> store;  // static part: position of CSR slot s in the chunk-aligned storage
+        if (part == 0 && m.n_chunks_static > 0) {
+            store.resize((size_t)m.nnzb);
+            MS_CHECK(hipMemcpyAsync(store.data(), m.store_slot.p, store.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+        }
         MS_CHECK(hipStreamSynchronize(c.stream));
         for (int64_t s = 0; s < m.nnzb; s++) {
             Blk b{};
             b.key = (uint64_t)rw[s] * (uint64_t)c.nbr + (uint64_t)(cw[s] & 0x7fffffffu);
             if (vals) {
-                const size_t base = (size_t)(s >> 6) * 576;
-                const size_t lane = (size_t)(s & 63);
+                const size_t pos = store.empty() ? (size_t)s : (size_t)store[s];
+                const size_t base = (pos >> 6) * 576;
+                const size_t lane = pos & 63;
                 for (int k = 0; k < 9; k++) {
                     const size_t idx = k < 4 ? base + lane * 4 + k : (k < 8 ? base + 256 + lane * 4 + (k - 4) : base + 512 + lane);
                     b.v[k] = tv[idx];

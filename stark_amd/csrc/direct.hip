@@ -15,15 +15,16 @@ constexpr int DT = 1024;
 
 namespace {
 // dense (column-major, full storage) += the 3x3 blocks of one matrix part
-__global__ __launch_bounds__(256) void k_dense_add(const float* __restrict__ vals, const uint32_t* __restrict__ colw, const uint32_t* __restrict__ slot_row, int64_t nnzb, int n,
-                                                   double* __restrict__ A)
+__global__ __launch_bounds__(256) void k_dense_add(const float* __restrict__ vals, const uint32_t* __restrict__ colw, const uint32_t* __restrict__ slot_row,
+                                                   const uint32_t* __restrict__ store_slot, int64_t nnzb, int n, double* __restrict__ A)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= nnzb * 9) return;
     const int64_t s = t / 9;
     const int comp = (int)(t - s * 9);
-    const size_t base = (size_t)(s >> 6) * 576;
-    const size_t lane = (size_t)(s & 63);
+    const size_t pos = store_slot ? (size_t)store_slot[s] : (size_t)s;  // (static part: chunk-aligned storage)
+    const size_t base = (pos >> 6) * 576;
+    const size_t lane = pos & 63;
     const size_t idx = comp < 4 ? base + lane * 4 + comp : (comp < 8 ? base + 256 + lane * 4 + (comp - 4) : base + 512 + lane);
     const int row = 3 * (int)slot_row[s] + comp / 3, col = 3 * (int)(colw[s] & 0x7fffffffu) + comp % 3;
     A[(size_t)col * n + row] += (double)vals[idx];  // (row, col) pairs are unique within a part
@@ -102,7 +103,7 @@ bool direct_llt(Context& c, const double* rhs_dev, double* x_dev)
     for (int part = 0; part < 2; part++) {
         const BsrPart& m = c.part[part];
         if (m.nnzb == 0) continue;
-        hipLaunchKernelGGL(k_dense_add, dim3((unsigned)((m.nnzb * 9 + 255) / 256)), dim3(256), 0, c.stream, m.vals.p, m.colw.p, m.slot_row.p, m.nnzb, n, c.dense.p);
+        hipLaunchKernelGGL(k_dense_add, dim3((unsigned)((m.nnzb * 9 + 255) / 256)), dim3(256), 0, c.stream, m.vals.p, m.colw.p, m.slot_row.p, (part == 0 && m.n_chunks_static > 0) ? (const uint32_t*)m.store_slot.p : (const uint32_t*)nullptr, m.nnzb, n, c.dense.p);
     }
     int* status = reinterpret_cast<int*>(c.counters.p + 7);
     hipLaunchKernelGGL(k_cholesky_solve, dim3(1), dim3(DT), 0, c.stream, c.dense.p, n, rhs_dev, x_dev, status);

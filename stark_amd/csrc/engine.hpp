@@ -153,6 +153,14 @@ struct BsrPart
     DevBuf<double> chunk_partial;   // 3 per chunk (long rows only)
     DevBuf<double> yd;              // 3 per compact row: A_dyn x of single-chunk rows
     DevBuf<int32_t> crow_of_row;    // block row -> compact row of this part, -1 if absent
+    // static part only: CSR order cut into row-aligned chunks (kernels.hip: build_aligned). `vals` / `scol` hold ntiles tiles in that
+    // storage order and store_slot maps a CSR slot to its position there.
+    int64_t n_chunks_static = 0;
+    DevBuf<uint32_t> store_slot;    // per CSR slot: position (tile * 64 + lane) of the block in vals / scol
+    DevBuf<uint32_t> scol;          // per stored position: block column, bit 31 = last block of its row (padding: 0)
+    DevBuf<uint64_t> row_pos;       // per block row: position of its first block
+    DevBuf<uint32_t> long_rows;     // rows longer than a chunk (stored after the chunks, one wavefront each)
+    int n_long_rows = 0;
 };
 
 struct SrcRange  // element blocks [k_off, k_off + nn*n_elem) of one potential, of which elements [e_begin, e_begin+e_count) are local

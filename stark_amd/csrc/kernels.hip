@@ -531,6 +531,7 @@ __global__ __launch_bounds__(BLOCK) void k_filter_sources(uint32_t* __restrict__
     }
 }
 constexpr int CHUNK_BLOCKS = 256;
+constexpr int DYN_SHORT_ROW = 32;  // contact rows of a node hold a handful of blocks; only the rows of rigid bodies in contact are long
 __global__ __launch_bounds__(BLOCK) void k_crow_of_row(const int32_t* __restrict__ rowmap, int64_t n_rows, int32_t* __restrict__ crow_of_row)
 {
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -540,7 +541,8 @@ __global__ __launch_bounds__(BLOCK) void k_chunk_count(const int64_t* __restrict
 {
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r > n_rows) return;
-    cnt[r] = r < n_rows ? (uint32_t)((row_ptr[r + 1] - row_ptr[r] + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS) : 0u;
+    const int64_t len = r < n_rows ? row_ptr[r + 1] - row_ptr[r] : 0;
+    cnt[r] = len > DYN_SHORT_ROW ? (uint32_t)((len + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS) : 0u;  // short rows are summed by one lane each (spmv_chunks)
 }
 __global__ __launch_bounds__(BLOCK) void k_chunk_fill(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ row_chunk0, int64_t n_rows, int32_t* __restrict__ chunk_row)
 {
@@ -555,6 +557,102 @@ __global__ __launch_bounds__(BLOCK) void k_long_slots(const uint32_t* __restrict
     if (s >= nnzb) return;
     if (slot_start[s + 1] - slot_start[s] > LONG_SLOT) list[atomicAdd(count, 1)] = (uint32_t)s;
 }
+// ---- storage of the static part: CSR order cut into row-aligned chunks -----------------------------------------------------------------
+// The blocks stay in CSR order (the lanes of a tile gather neighbouring columns of the same row: few cache lines), but padding blocks
+// are inserted so that every chunk of SPMV_CHUNK_TILES tiles holds complete rows only. A wavefront of the SpMV owns one chunk: nothing
+// is carried in or out, no tile is read by two wavefronts, and no wavefront starts with a search for its first row (that control
+// structure cost the earlier kernel 6 of 28.6 us). Rows longer than a chunk are stored after the chunks and reduced one wavefront per
+// row. The layout is computed once per pattern on the host (one pass over the row lengths).
+constexpr int SPMV_CHUNK_TILES = 8;
+__global__ __launch_bounds__(BLOCK) void k_store_fill(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ colw, const uint64_t* __restrict__ row_pos, int64_t nbr,
+                                                      uint32_t* __restrict__ store_slot, uint32_t* __restrict__ scol)
+{
+    const int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (row >= nbr) return;
+    const int64_t s0 = row_ptr[row], s1 = row_ptr[row + 1];
+    const uint64_t p0 = row_pos[row];
+    for (int64_t s = s0; s < s1; s++) {
+        const uint32_t pos = (uint32_t)(p0 + (uint64_t)(s - s0));
+        store_slot[s] = pos;
+        scol[pos] = (colw[s] & 0x7fffffffu) | (s == s1 - 1 ? 0x80000000u : 0u);  // bit 31: last block of its row
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_remap_slots(uint32_t* __restrict__ slots, size_t n, const uint32_t* __restrict__ store_slot)
+{
+    const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t s = slots[k];
+    if (s != 0xFFFFFFFFu) slots[k] = store_slot[s];
+}
+static void build_aligned(Context& c, BsrPart& m)
+{
+    const int64_t nbr = c.nbr;
+    std::vector<int64_t> rp((size_t)nbr + 1);
+    MS_CHECK(hipMemcpyAsync(rp.data(), m.row_ptr.p, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    const uint64_t chunk = (uint64_t)SPMV_CHUNK_TILES * 64;
+    std::vector<uint64_t> row_pos((size_t)nbr);
+    std::vector<uint32_t> long_rows;  // rows that do not fit a chunk
+    uint64_t cur = 0;
+    for (int64_t r = 0; r < nbr; r++) {
+        const uint64_t len = (uint64_t)(rp[r + 1] - rp[r]);
+        if (len > chunk) {
+            long_rows.push_back((uint32_t)r);
+            cur = (cur + 63) / 64 * 64;  // the rows of a tile must be consecutive (row = first row + row ends before the lane): restart on a tile
+            continue;
+        }
+        if (len > 0 && cur / chunk != (cur + len - 1) / chunk) cur = (cur / chunk + 1) * chunk;  // the row would straddle: pad to the next chunk
+        row_pos[r] = cur;
+        cur += len;
+    }
+    const uint64_t n_chunk_tiles = (cur + chunk - 1) / chunk * SPMV_CHUNK_TILES;
+    uint64_t pos = n_chunk_tiles * 64;
+    std::vector<uint64_t> long_pos;
+    for (uint32_t r : long_rows) {  // long rows after the chunks, each starting on a tile
+        row_pos[r] = pos;
+        long_pos.push_back(pos);
+        pos += ((uint64_t)(rp[r + 1] - rp[r]) + 63) / 64 * 64;
+    }
+    if (pos >= (1ull << 31)) throw Error("static matrix part too large");
+    m.n_chunks_static = (int64_t)(n_chunk_tiles / SPMV_CHUNK_TILES);
+    m.ntiles = (int64_t)(pos / 64);
+    // first row of every chunk tile (bit 31: the tile starts inside a row begun in the previous tile of the same chunk)
+    std::vector<int32_t> tfr((size_t)n_chunk_tiles, 0);
+    {
+        int64_t r = 0;
+        auto is_long = [&](int64_t q) { return (uint64_t)(rp[q + 1] - rp[q]) > chunk; };
+        int64_t last_row = 0;
+        for (uint64_t t = 0; t < n_chunk_tiles; t++) {
+            const uint64_t p = t * 64;
+            // advance to the last non-long, non-empty row starting at or before p
+            while (r < nbr && (is_long(r) || rp[r + 1] == rp[r] || row_pos[r] + (uint64_t)(rp[r + 1] - rp[r]) <= p)) {
+                if (!is_long(r) && rp[r + 1] > rp[r]) last_row = r;
+                r++;
+            }
+            if (r < nbr && row_pos[r] <= p) tfr[t] = (int32_t)((uint32_t)r | (row_pos[r] < p ? 0x80000000u : 0u));
+            else tfr[t] = (int32_t)(uint32_t)(r < nbr ? r : last_row);  // tile starts in padding or exactly at row r
+        }
+    }
+    m.tile_first_row.ensure(std::max<size_t>(tfr.size(), 1));
+    m.row_pos.ensure((size_t)nbr);
+    m.long_rows.ensure(std::max<size_t>(long_rows.size(), 1));
+    m.n_long_rows = (int)long_rows.size();
+    MS_CHECK(hipMemcpyAsync(m.tile_first_row.p, tfr.data(), tfr.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+    MS_CHECK(hipMemcpyAsync(m.row_pos.p, row_pos.data(), row_pos.size() * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
+    if (!long_rows.empty()) MS_CHECK(hipMemcpyAsync(m.long_rows.p, long_rows.data(), long_rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+    m.store_slot.ensure((size_t)m.nnzb);
+    m.scol.ensure(std::max<size_t>((size_t)m.ntiles * 64, 1));
+    m.vals.ensure(std::max<size_t>((size_t)m.ntiles * 576, 1));
+    MS_CHECK(hipMemsetAsync(m.vals.p, 0, (size_t)m.ntiles * 576 * sizeof(float), c.stream));  // padding stays zero: assembly writes real blocks only
+    MS_CHECK(hipMemsetAsync(m.scol.p, 0, (size_t)m.ntiles * 64 * sizeof(uint32_t), c.stream));  // padding: column 0, not a row end
+    hipLaunchKernelGGL(k_store_fill, dim3(grid_for(nbr)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, m.colw.p, m.row_pos.p, nbr, m.store_slot.p, m.scol.p);
+    // everything that addresses vals by slot: element-block destinations and the diagonal blocks
+    const size_t n_src = m.n_keys - (size_t)nbr;  // (the structural diagonal keys at the end have no source block)
+    if (n_src > 0) hipLaunchKernelGGL(k_remap_slots, dim3(grid_for(n_src)), dim3(BLOCK), 0, c.stream, m.slot_of_src.p, n_src, m.store_slot.p);
+    hipLaunchKernelGGL(k_remap_slots, dim3(grid_for(nbr)), dim3(BLOCK), 0, c.stream, (uint32_t*)c.diag_slot[0].p, (size_t)nbr, m.store_slot.p);
+    MS_CHECK(hipStreamSynchronize(c.stream));  // (host vectors above are temporaries)
+}
+
 // Builds the sparsity pattern of one matrix part: part 0 = potentials with fixed connectivity (+ every diagonal block, so
 // each block row exists), part 1 = potentials whose connectivity changes inside the Newton loop (contacts). Part 1 only
 // contains the block rows it touches ("compact rows", rowmap -> global row).
@@ -654,6 +752,7 @@ static void build_pattern(Context& c, int part)
     hipLaunchKernelGGL(k_rows, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_row.p, rscan, m.nnzb, m.rowmap.p, m.row_ptr.p, m.tile_first_row.p, m.colw.p);
     MS_CHECK(hipStreamSynchronize(c.stream));
     if (part == 0 && m.n_rows != c.nbr) throw Error("internal: static part must contain every block row");
+    if (part == 0) build_aligned(c, m);
     if (part == 1) {
         // row chunks of <= CHUNK_BLOCKS blocks for the chunked SpMV of the contact part (a rigid body in contact owns block rows
         // with thousands of blocks; see k_spmv_chunks)
@@ -1116,7 +1215,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __res
 // one wavefront per long block (e.g. the diagonal block of a rigid body touched by thousands of contacts): lanes take
 // contributions k0 + lane, k0 + lane + 64, ... and the nine sums are reduced across the wave; the order is fixed by the sorted keys
 __global__ __launch_bounds__(BLOCK) void k_assemble_long(const double* __restrict__ elemH, const uint32_t* __restrict__ slot_start, const uint32_t* __restrict__ sorted_src,
-                                                        const uint32_t* __restrict__ list, int n_long, float* __restrict__ vals)
+                                                        const uint32_t* __restrict__ list, int n_long, const uint32_t* __restrict__ store_slot, float* __restrict__ vals)
 {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_long) return;
@@ -1134,11 +1233,11 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_long(const double* __restric
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         const double v = wave_sum(acc[c]);
-        if (lane == 0) vals[tile_val_index(slot, c)] = (float)v;
+        if (lane == 0) vals[tile_val_index(store_slot ? store_slot[slot] : slot, c)] = (float)v;
     }
 }
 __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restrict__ elemH, const uint32_t* __restrict__ slot_start,
-                                                           const uint32_t* __restrict__ sorted_src, int64_t nnzb, float* __restrict__ vals)
+                                                           const uint32_t* __restrict__ sorted_src, int64_t nnzb, const uint32_t* __restrict__ store_slot, float* __restrict__ vals)
 {
     const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= nnzb * 9) return;
@@ -1159,7 +1258,7 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restr
 #pragma unroll
         for (int u = 0; u < 8; u++) acc += h[u];
     }
-    vals[tile_val_index(slot, comp)] = (float)acc;
+    vals[tile_val_index(store_slot ? store_slot[slot] : slot, comp)] = (float)acc;
 }
 
 void assemble(Context& c)
@@ -1177,9 +1276,10 @@ void assemble(Context& c)
                 hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p + P.h_off, nblk, m.slot_of_src.p + (P.k_off - m.blk_base), m.vals.p);
             }
         } else {
-            hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.nnzb, m.vals.p);
+            const uint32_t* store = part == 0 ? m.store_slot.p : nullptr;
+            hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.nnzb, store, m.vals.p);
             if (m.n_long > 0)
-                hipLaunchKernelGGL(k_assemble_long, dim3((m.n_long + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.long_slots.p, m.n_long, m.vals.p);
+                hipLaunchKernelGGL(k_assemble_long, dim3((m.n_long + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.long_slots.p, m.n_long, store, m.vals.p);
         }
         if (c.world > 1) c.coll->allreduce_f32(m.vals.p, (size_t)m.ntiles * 576, c.stream);
         m.have_matrix = true;
@@ -1211,128 +1311,128 @@ __device__ __forceinline__ double dpp_row_shr(double v)
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+// y = A_static x (build_aligned). One wavefront per chunk of SPMV_CHUNK_TILES tiles; a chunk holds complete rows, so the wavefront
+// neither reads a neighbour's tile nor hands a partial row on. Per tile: the column words and values (prefetched one tile ahead), the
+// x gather, the nine float -> double conversions and FMAs of the reference (BlockedSparseMatrix.h:986-1138), then a segmented inclusive
+// scan over the 64 lanes (DPP row shifts + three scalar carries, no LDS) whose row-end lanes write y; a row that continues into the next
+// tile of the chunk is carried in registers. Every row is written exactly once: no atomics, no zero fill, deterministic.
 template <int V>
-__device__ __forceinline__ void spmv_static(const int bid, const int nblk, const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int32_t* __restrict__ tile_first_row, int64_t nnzb,
-                                                int64_t ntiles, const int32_t* __restrict__ rowmap, int accumulate, const double* __restrict__ x, double* __restrict__ y,
-                                                const double* __restrict__ pdot, double* __restrict__ partials, const PcgCtrl* __restrict__ ctrl)
+__device__ __forceinline__ void spmv_chunked_static(const int bid, const int nblk, const float* __restrict__ vals, const uint32_t* __restrict__ scol,
+                                                    const int32_t* __restrict__ tile_first_row, int64_t n_chunks, const double* __restrict__ x, double* __restrict__ y,
+                                                    const double* __restrict__ pdot, double* __restrict__ partials)
 {
-    // rowmap != nullptr: the part stores only the block rows it touches (contacts), rowmap[compact row] = block row of y.
-    // accumulate: y += A x (second part of a split matrix), launched after the part that wrote y.
-    if (ctrl && ctrl->done) return;
     __shared__ double sm[4];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     double acc = 0.0;
-    // Each wavefront owns a contiguous range of tiles and every block row whose LAST block lies in that range. A row that
-    // straddles two tiles of the range is carried in registers; for the first row of the range, which usually began in the
-    // previous wavefront's last tile, that tile is re-read as a "ghost" (only its trailing open segment is used) and the
-    // previous wavefront drops its open tail. Every row is written exactly once: no atomics, no zero-fill, deterministic.
+    // XCD-aware placement: consecutive workgroup ids land on different XCDs (round robin over the 8 dies, each with its own L2); give
+    // every XCD one contiguous eighth of the chunks so that the x entries its rows gather are shared through that die's L2
+    const int pbid = ((nblk & 7) == 0) ? (bid & 7) * (nblk >> 3) + (bid >> 3) : bid;
     const int64_t n_waves = (int64_t)nblk * 4;
-    const int64_t tpw = (ntiles + n_waves - 1) / n_waves;
-    // XCD-aware placement: consecutive workgroup ids land on different XCDs (round robin over the 8 dies, each with its own L2).
-    // Give every XCD one contiguous eighth of the tiles, so that the x entries its rows gather (a band around the diagonal) are
-    // shared through that die's L2 instead of being fetched by all eight.
-    const int pbid = (V != 5 && (nblk & 7) == 0) ? (bid & 7) * (nblk >> 3) + (bid >> 3) : bid;
-    const int64_t gw = (int64_t)pbid * 4 + wave;
-    const int64_t t_begin = gw * tpw, t_end = (t_begin + tpw < ntiles) ? t_begin + tpw : ntiles;
-    int64_t t_lead = t_begin;
-    if (t_begin < t_end) {
-        // walk back while the row continues from the previous tile; stop at the first tile that contains a row end
-        while (t_lead > 0 && tile_first_row[t_lead] < 0) {
-            t_lead--;
-            const uint32_t w = colw[t_lead * 64 + lane];
-            if (__ballot((w >> 31) != 0) != 0ull) break;
-        }
-    }
-    double k0 = 0.0, k1 = 0.0, k2 = 0.0;  // carry into the first segment of the next tile (wave-uniform)
-    // Software pipeline of depth one: the column words and values of tile t+1 are requested before the x gather of tile t, so a
-    // wave has one dependent load (x[col]) per tile on its critical path instead of two (colw -> x). Tiles are padded, so the
-    // loads of a partially filled last tile are in bounds.
-    uint32_t w_cur = 0;
-    float4 a_cur = make_float4(0.f, 0.f, 0.f, 0.f), b_cur = a_cur;
-    float c_cur = 0.f;
-    auto load_tile = [&](int64_t t, uint32_t& w, float4& a, float4& b, float& cc) {
-        w = colw[t * 64 + lane];
-        const float4* q = reinterpret_cast<const float4*>(vals + (size_t)t * 576);
-        a = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[lane];
-        b = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[64 + lane];
-        cc = (V == 3) ? 1.f : vals[(size_t)t * 576 + 512 + lane];
-    };
-    if (t_lead < t_end) load_tile(t_lead, w_cur, a_cur, b_cur, c_cur);
-    for (int64_t t = t_lead; t < t_end; t++) {
-        const bool ghost = t < t_begin;
-        const int64_t s = t * 64 + lane;
-        const bool valid = s < nnzb;
-        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
-        bool tail = false;
-        const int32_t tfr_w = tile_first_row[t];   // bit 31: the tile starts inside a row begun in the previous tile
-        const int tfr = tfr_w & 0x7fffffff;
-        const bool tile_cont = tfr_w < 0;
-        const uint32_t w = w_cur;
-        const float4 a = a_cur, b = b_cur;
-        const float cc = c_cur;
-        if (t + 1 < t_end) load_tile(t + 1, w_cur, a_cur, b_cur, c_cur);
-        if (valid) {
-            tail = (w >> 31) != 0;
-            const size_t col = (V == 2) ? (size_t)(s % 170000) : (size_t)(w & 0x7fffffffu);
-            const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
-            y0 = (double)a.x * x0 + (double)a.y * x1 + (double)a.z * x2;
-            y1 = (double)a.w * x0 + (double)b.x * x1 + (double)b.y * x2;
-            y2 = (double)b.z * x0 + (double)b.w * x1 + (double)cc * x2;
-        }
-        if (V >= 1 && V <= 3) {  // ablation: loads + block products only
-            acc += y0 + y1 + y2;
-            continue;
-        }
-        const bool seg_end = !valid || tail || lane == 63;
-        const unsigned long long ends = __ballot(seg_end);
-        const unsigned long long tails = __ballot(valid && tail);
-        const unsigned long long heads = (ends << 1) | 1ull;
-        const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-        const int start = 63 - __clzll(heads & le);
-        // segmented inclusive scan without LDS traffic: DPP row shifts inside each 16-lane row, then three scalar carries
-        {
-            const int l16 = lane & 15;
-#define MS_SEG_STEP(D, CTRL)                                                     \
-            {                                                                        \
-                const double u0 = dpp_row_shr<CTRL>(y0), u1 = dpp_row_shr<CTRL>(y1), u2 = dpp_row_shr<CTRL>(y2); \
-                if (l16 >= D && lane - D >= start) { y0 += u0; y1 += u1; y2 += u2; } \
+    for (int64_t ch = (int64_t)pbid * 4 + wave; ch < n_chunks; ch += n_waves) {
+        const int64_t t_begin = ch * SPMV_CHUNK_TILES;
+        double k0 = 0.0, k1 = 0.0, k2 = 0.0;  // carry into the first segment of the next tile (wave-uniform)
+        for (int u = 0; u < SPMV_CHUNK_TILES; u++) {
+            const int64_t t = t_begin + u;
+            const uint32_t w = scol[t * 64 + lane];
+            const float4* q = reinterpret_cast<const float4*>(vals + (size_t)t * 576);
+            const float4 a = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[lane], b = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[64 + lane];
+            const float cc = (V == 3) ? 1.f : vals[(size_t)t * 576 + 512 + lane];
+            const size_t c3 = 3 * (size_t)(w & 0x7fffffffu);
+            const double x0 = x[c3], x1 = x[c3 + 1], x2 = x[c3 + 2];
+            double y0 = (double)a.x * x0 + (double)a.y * x1 + (double)a.z * x2;
+            double y1 = (double)a.w * x0 + (double)b.x * x1 + (double)b.y * x2;
+            double y2 = (double)b.z * x0 + (double)b.w * x1 + (double)cc * x2;
+            if (V == 1 || V == 3) {  // ablation: loads + block products only
+                acc += y0 + y1 + y2;
+                continue;
             }
-            MS_SEG_STEP(1, 0x111)
-            MS_SEG_STEP(2, 0x112)
-            MS_SEG_STEP(4, 0x114)
-            MS_SEG_STEP(8, 0x118)
+            const bool tail = (w >> 31) != 0;
+            const int32_t tfr_w = tile_first_row[t];  // bit 31: the tile starts inside a row begun in the previous tile
+            const int tfr = tfr_w & 0x7fffffff;
+            const bool tile_cont = tfr_w < 0;
+            const unsigned long long tails = __ballot(tail);
+            const unsigned long long heads = (tails << 1) | 1ull;
+            const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+            const int start = 63 - __clzll(heads & le);
+            // segmented inclusive scan without LDS traffic: DPP row shifts inside each 16-lane row, then three scalar carries
+            {
+                const int l16 = lane & 15;
+#define MS_SEG_STEP(D, CTRL)                                                     \
+                {                                                                    \
+                    const double u0 = dpp_row_shr<CTRL>(y0), u1 = dpp_row_shr<CTRL>(y1), u2 = dpp_row_shr<CTRL>(y2); \
+                    if (l16 >= D && lane - D >= start) { y0 += u0; y1 += u1; y2 += u2; } \
+                }
+                MS_SEG_STEP(1, 0x111)
+                MS_SEG_STEP(2, 0x112)
+                MS_SEG_STEP(4, 0x114)
+                MS_SEG_STEP(8, 0x118)
 #undef MS_SEG_STEP
 #pragma unroll
-            for (int r = 1; r < 4; r++) {
-                const double c0 = read_lane(y0, 16 * r - 1), c1 = read_lane(y1, 16 * r - 1), c2 = read_lane(y2, 16 * r - 1);
-                if ((lane >> 4) == r && start < 16 * r) { y0 += c0; y1 += c1; y2 += c2; }
+                for (int r = 1; r < 4; r++) {
+                    const double c0 = read_lane(y0, 16 * r - 1), c1 = read_lane(y1, 16 * r - 1), c2 = read_lane(y2, 16 * r - 1);
+                    if ((lane >> 4) == r && start < 16 * r) { y0 += c0; y1 += c1; y2 += c2; }
+                }
             }
-        }
-        // first segment: take over the carry of the previous tile processed by this wavefront
-        if (tile_cont && t > t_lead && start == 0) { y0 += k0; y1 += k1; y2 += k2; }
-        // last segment open (the row ends in a later tile): hand it on in registers; at the end of the range the next
-        // wavefront recomputes it from its ghost tile
-        const bool open_end = ((tails >> 63) & 1ull) == 0ull && (t * 64 + 63 < nnzb);
-        if (open_end) { k0 = read_lane(y0, 63); k1 = read_lane(y1, 63); k2 = read_lane(y2, 63); }
-        if (valid && tail && !ghost) {
-            int row = tfr + __popcll(tails & ((1ull << lane) - 1ull));
-            if (rowmap) row = rowmap[row];
-            double* yr = y + 3 * (size_t)row;
-            if (V == 4) {
-                acc += y0 + y1 + y2;
-            } else if (accumulate) {
-                yr[0] += y0;
-                yr[1] += y1;
-                yr[2] += y2;
-            } else {
+            // first segment: take over the carry of the previous tile of this chunk
+            if (tile_cont && start == 0) { y0 += k0; y1 += k1; y2 += k2; }
+            // last segment open (the row ends in the next tile of the chunk; never at the end of a chunk): hand it on in registers
+            if (((tails >> 63) & 1ull) == 0ull) { k0 = read_lane(y0, 63); k1 = read_lane(y1, 63); k2 = read_lane(y2, 63); }
+            if (tail) {
+                const int row = tfr + __popcll(tails & ((1ull << lane) - 1ull));
+                double* yr = y + 3 * (size_t)row;
                 yr[0] = y0;
                 yr[1] = y1;
                 yr[2] = y2;
+                if (pdot) {
+                    const double* pr = pdot + 3 * (size_t)row;
+                    acc += pr[0] * y0 + pr[1] * y1 + pr[2] * y2;
+                }
             }
-            if (pdot && V != 6 && V != 4) {
-                const double* pr = pdot + 3 * (size_t)row;
-                acc += pr[0] * y0 + pr[1] * y1 + pr[2] * y2;
+        }
+    }
+    if (partials) {
+        acc = block_sum(acc, sm);
+        if (threadIdx.x == 0) partials[bid] = acc;
+    }
+}
+// Rows longer than a chunk (a rigid body attached to very many points): stored after the chunks, one wavefront per row.
+__device__ __forceinline__ void spmv_long_rows(const int bid, const int nblk, const float* __restrict__ vals, const uint32_t* __restrict__ scol, const uint32_t* __restrict__ list,
+                                               int n_list, const int64_t* __restrict__ row_ptr, const uint64_t* __restrict__ row_pos, const double* __restrict__ x,
+                                               double* __restrict__ y, const double* __restrict__ pdot, double* __restrict__ partials)
+{
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int k = bid * 4 + (threadIdx.x >> 6); k < n_list; k += nblk * 4) {
+        const int64_t r = list[k];
+        const int64_t len = row_ptr[r + 1] - row_ptr[r];
+        const size_t base = (size_t)row_pos[r];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int64_t s = lane; s < len; s += 64) {
+            const size_t pos = base + (size_t)s;
+            const size_t col = scol[pos] & 0x7fffffffu;
+            const float* tv = vals + (pos >> 6) * 576;
+            const int l = (int)(pos & 63);
+            const float4 qa = reinterpret_cast<const float4*>(tv)[l];
+            const float4 qb = reinterpret_cast<const float4*>(tv)[64 + l];
+            const float cc = tv[512 + l];
+            const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
+            a0 += (double)qa.x * x0 + (double)qa.y * x1 + (double)qa.z * x2;
+            a1 += (double)qa.w * x0 + (double)qb.x * x1 + (double)qb.y * x2;
+            a2 += (double)qb.z * x0 + (double)qb.w * x1 + (double)cc * x2;
+        }
+        a0 = wave_sum(a0);
+        a1 = wave_sum(a1);
+        a2 = wave_sum(a2);
+        if (lane == 0) {
+            double* yr = y + 3 * (size_t)r;
+            yr[0] = a0;
+            yr[1] = a1;
+            yr[2] = a2;
+            if (pdot) {
+                const double* pr = pdot + 3 * (size_t)r;
+                acc += pr[0] * a0 + pr[1] * a1 + pr[2] * a2;
             }
         }
     }
@@ -1342,10 +1442,11 @@ __device__ __forceinline__ void spmv_static(const int bid, const int nblk, const
     }
 }
 
-static int spmv_grid(const Context& c, int64_t ntiles, int max_grid)
+static int spmv_grid(const Context& c, int64_t n_chunks, int max_grid)
 {
-    const int cap = std::min(c.spmv_grid_cap > 0 ? c.spmv_grid_cap : 1024, max_grid);  // 16 waves/CU measured best (profiles/)
-    return (int)std::min<int64_t>(std::max<int64_t>((ntiles + 3) / 4, 1), cap);
+    // one wavefront per chunk when they fit the grid cap; a multiple of 8 workgroups keeps the XCD placement of spmv_chunked_static
+    const int cap = std::min(c.spmv_grid_cap > 0 ? c.spmv_grid_cap : 2048, max_grid);
+    return (int)std::max<int64_t>(std::min<int64_t>(((n_chunks + 3) / 4 + 7) / 8 * 8, cap / 8 * 8), 8);
 }
 // SpMV of the contact part: y += A_dyn x. Its block rows are short (a contact touches a handful of nodes) except the rows of rigid
 // bodies in contact, which hold one block per touching node (thousands): rows are cut into chunks of <= CHUNK_BLOCKS blocks, one
@@ -1362,43 +1463,85 @@ struct DynPart  // the contact part as the fused SpMV kernel sees it
     double* yd;             // 3 per compact row (rows with a single chunk)
     double* chunk_partial;  // 3 per chunk (rows with several chunks)
     int64_t n_chunks;
+    int64_t n_rows;
 };
 __device__ __forceinline__ void spmv_chunks(const int bid, const int nblk, const DynPart& d, const double* __restrict__ x, const double* __restrict__ pdot,
                                             double* __restrict__ partials)
 {
+    // These few workgroups run beside thousands of static-part wavefronts that saturate the memory system, where every dependent load
+    // costs 1.5-2 us: their chains must be short or they become the critical path of the whole launch (measured: +4.5 us with one lane
+    // per row and the chunk loop behind it). Workgroups [0, g_chunks) reduce the chunks of long rows, one per wavefront; the others take
+    // the short rows, four lanes per row.
     __shared__ double sm[4];
     const int lane = threadIdx.x & 63;
-    const int64_t n_waves = (int64_t)nblk * 4;
+    const int g_chunks = (int)min((d.n_chunks + 3) / 4, (int64_t)nblk / 2);
     double dot = 0.0;
-    for (int64_t ch = (int64_t)bid * 4 + (threadIdx.x >> 6); ch < d.n_chunks; ch += n_waves) {
-        const int r = d.chunk_row[ch];
-        const uint32_t c0 = d.row_chunk0[r], c1 = d.row_chunk0[r + 1];
-        const int64_t s0 = d.row_ptr[r] + (int64_t)(ch - c0) * CHUNK_BLOCKS;
-        const int64_t s1 = min(d.row_ptr[r + 1], s0 + (int64_t)CHUNK_BLOCKS);
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (int64_t s = s0 + lane; s < s1; s += 64) {
-            const size_t col = (size_t)(d.colw[s] & 0x7fffffffu);
-            const float* tv = d.vals + (size_t)(s >> 6) * 576;
-            const int l = (int)(s & 63);
-            const float4 qa = reinterpret_cast<const float4*>(tv)[l];
-            const float4 qb = reinterpret_cast<const float4*>(tv)[64 + l];
-            const float cc = tv[512 + l];
-            const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
-            a0 += (double)qa.x * x0 + (double)qa.y * x1 + (double)qa.z * x2;
-            a1 += (double)qa.w * x0 + (double)qb.x * x1 + (double)qb.y * x2;
-            a2 += (double)qb.z * x0 + (double)qb.w * x1 + (double)cc * x2;
+    if (bid < g_chunks) {
+        for (int64_t ch = (int64_t)bid * 4 + (threadIdx.x >> 6); ch < d.n_chunks; ch += (int64_t)g_chunks * 4) {
+            const int r = d.chunk_row[ch];
+            const uint32_t c0 = d.row_chunk0[r], c1 = d.row_chunk0[r + 1];
+            const int64_t s0 = d.row_ptr[r] + (int64_t)(ch - c0) * CHUNK_BLOCKS;
+            const int64_t s1 = min(d.row_ptr[r + 1], s0 + (int64_t)CHUNK_BLOCKS);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int64_t s = s0 + lane; s < s1; s += 64) {
+                const size_t col = (size_t)(d.colw[s] & 0x7fffffffu);
+                const float* tv = d.vals + (size_t)(s >> 6) * 576;
+                const int l = (int)(s & 63);
+                const float4 qa = reinterpret_cast<const float4*>(tv)[l];
+                const float4 qb = reinterpret_cast<const float4*>(tv)[64 + l];
+                const float cc = tv[512 + l];
+                const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
+                a0 += (double)qa.x * x0 + (double)qa.y * x1 + (double)qa.z * x2;
+                a1 += (double)qa.w * x0 + (double)qb.x * x1 + (double)qb.y * x2;
+                a2 += (double)qb.z * x0 + (double)qb.w * x1 + (double)cc * x2;
+            }
+            a0 = wave_sum(a0);
+            a1 = wave_sum(a1);
+            a2 = wave_sum(a2);
+            if (lane == 0) {
+                double* out = (c1 - c0 == 1) ? d.yd + 3 * (size_t)r : d.chunk_partial + 3 * (size_t)ch;
+                out[0] = a0;
+                out[1] = a1;
+                out[2] = a2;
+                if (pdot) {
+                    const size_t rg = (size_t)d.rowmap[r];
+                    dot += pdot[3 * rg] * a0 + pdot[3 * rg + 1] * a1 + pdot[3 * rg + 2] * a2;
+                }
+            }
         }
-        a0 = wave_sum(a0);
-        a1 = wave_sum(a1);
-        a2 = wave_sum(a2);
-        if (lane == 0) {
-            double* out = (c1 - c0 == 1) ? d.yd + 3 * (size_t)r : d.chunk_partial + 3 * (size_t)ch;
-            out[0] = a0;
-            out[1] = a1;
-            out[2] = a2;
-            if (pdot) {
-                const size_t rg = (size_t)d.rowmap[r];
-                dot += pdot[3 * rg] * a0 + pdot[3 * rg + 1] * a1 + pdot[3 * rg + 2] * a2;
+    } else {
+        const int g_short = nblk - g_chunks;
+        const int q = threadIdx.x & 3;
+        for (int64_t r = (int64_t)(bid - g_chunks) * (BLOCK / 4) + (threadIdx.x >> 2); r < d.n_rows; r += (int64_t)g_short * (BLOCK / 4)) {
+            const int64_t s0 = d.row_ptr[r], s1 = d.row_ptr[r + 1];
+            const bool is_short = s1 - s0 <= DYN_SHORT_ROW;  // (the same for the four lanes of a row)
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            if (is_short) {
+                for (int64_t s = s0 + q; s < s1; s += 4) {
+                    const size_t col = (size_t)(d.colw[s] & 0x7fffffffu);
+                    const float* tv = d.vals + (size_t)(s >> 6) * 576;
+                    const int l = (int)(s & 63);
+                    const float4 qa = reinterpret_cast<const float4*>(tv)[l];
+                    const float4 qb = reinterpret_cast<const float4*>(tv)[64 + l];
+                    const float cc = tv[512 + l];
+                    const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
+                    a0 += (double)qa.x * x0 + (double)qa.y * x1 + (double)qa.z * x2;
+                    a1 += (double)qa.w * x0 + (double)qb.x * x1 + (double)qb.y * x2;
+                    a2 += (double)qb.z * x0 + (double)qb.w * x1 + (double)cc * x2;
+                }
+            }
+            // the four partial sums of a row, in a fixed order (all lanes of the wavefront take part in the shuffles)
+            a0 += __shfl_xor(a0, 1, 64); a1 += __shfl_xor(a1, 1, 64); a2 += __shfl_xor(a2, 1, 64);
+            a0 += __shfl_xor(a0, 2, 64); a1 += __shfl_xor(a1, 2, 64); a2 += __shfl_xor(a2, 2, 64);
+            if (is_short && q == 0) {
+                double* out = d.yd + 3 * (size_t)r;
+                out[0] = a0;
+                out[1] = a1;
+                out[2] = a2;
+                if (pdot) {
+                    const size_t rg = (size_t)d.rowmap[r];
+                    dot += pdot[3 * rg] * a0 + pdot[3 * rg + 1] * a1 + pdot[3 * rg + 2] * a2;
+                }
             }
         }
     }
@@ -1414,7 +1557,7 @@ __device__ __forceinline__ void dyn_row(const int32_t* __restrict__ crow_of_row,
     const int32_t cr = crow_of_row[row];
     if (cr < 0) return;
     const uint32_t c0 = row_chunk0[cr], c1 = row_chunk0[cr + 1];
-    if (c1 - c0 == 1) {
+    if (c1 - c0 <= 1) {  // short rows (no chunk) and single-chunk rows: the row sum itself
         q0 += yd[3 * (size_t)cr];
         q1 += yd[3 * (size_t)cr + 1];
         q2 += yd[3 * (size_t)cr + 2];
@@ -1426,16 +1569,31 @@ __device__ __forceinline__ void dyn_row(const int32_t* __restrict__ crow_of_row,
         }
     }
 }
-// One launch for y = A_static x (rows written once, see spmv_static) and the contact part's row sums (yd / chunk_partial);
-// the consumer adds them (k_pcg_step inside the solver, k_spmv_combine elsewhere). Workgroups [0, g0) take the static tiles.
+struct StaticPart  // the static part as the fused SpMV kernel sees it
+{
+    const float* vals;
+    const uint32_t* scol;
+    const int32_t* tile_first_row;
+    const uint32_t* long_rows;
+    const int64_t* row_ptr;
+    const uint64_t* row_pos;
+    int64_t n_chunks;
+    int n_long_rows;
+};
+// One launch for y = A_static x (rows written once, see spmv_chunked_static) and the contact part's row sums (yd / chunk_partial); the
+// consumer adds them (k_pcg_step inside the solver, k_spmv_combine elsewhere). The few workgroups of the contact part and of over-long
+// rows come FIRST in the grid: dispatched last they would start when the static part drains and add their whole duration to the kernel
+// (measured: 27.7 us with them at the end, 21.7 us for the static part alone). Workgroups [0, g1): chunks of the contact part,
+// [g1, g1 + gr): over-long static rows, the rest: chunks of the static part. partials keep the order static | long | contact.
 template <int V>
-__global__ __launch_bounds__(BLOCK) void k_spmv_fused(int g0, const float* __restrict__ vals, const uint32_t* __restrict__ colw, const int32_t* __restrict__ tile_first_row,
-                                                     int64_t nnzb, int64_t ntiles, DynPart d, const double* __restrict__ x, double* __restrict__ y,
+__global__ __launch_bounds__(BLOCK) void k_spmv_fused(int g0, int gr, int g1, StaticPart m, DynPart d, const double* __restrict__ x, double* __restrict__ y,
                                                      const double* __restrict__ pdot, double* __restrict__ partials, const PcgCtrl* __restrict__ ctrl)
 {
     if (ctrl && ctrl->done) return;
-    if ((int)blockIdx.x < g0) spmv_static<V>((int)blockIdx.x, g0, vals, colw, tile_first_row, nnzb, ntiles, nullptr, 0, x, y, pdot, partials, nullptr);
-    else spmv_chunks((int)blockIdx.x - g0, (int)gridDim.x - g0, d, x, pdot, partials ? partials + g0 : nullptr);
+    const int b = (int)blockIdx.x;
+    if (b < g1) spmv_chunks(b, g1, d, x, pdot, partials ? partials + g0 + gr : nullptr);
+    else if (b < g1 + gr) spmv_long_rows(b - g1, gr, m.vals, m.scol, m.long_rows, m.n_long_rows, m.row_ptr, m.row_pos, x, y, pdot, partials ? partials + g0 : nullptr);
+    else spmv_chunked_static<V>(b - g1 - gr, g0, m.vals, m.scol, m.tile_first_row, m.n_chunks, x, y, pdot, partials);
 }
 __global__ __launch_bounds__(BLOCK) void k_spmv_combine(int64_t nbr, const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0,
                                                        const double* __restrict__ yd, const double* __restrict__ chunk_partial, double* __restrict__ y)
@@ -1454,18 +1612,21 @@ static int launch_spmv(Context& c, const double* x, double* y, const double* pdo
 {
     const BsrPart& m0 = c.part[0];
     BsrPart& m1 = c.part[1];
-    const int g0 = spmv_grid(c, m0.ntiles, MAX_PARTIALS / 2);
+    const int g0 = spmv_grid(c, m0.n_chunks_static, MAX_PARTIALS / 2);
+    const int gr = std::min(((m0.n_long_rows + 3) / 4 + 7) / 8 * 8, MAX_PARTIALS / 4);
+    const StaticPart sp{m0.vals.p, m0.scol.p, m0.tile_first_row.p, m0.long_rows.p, m0.row_ptr.p, m0.row_pos.p, m0.n_chunks_static, m0.n_long_rows};
     DynPart d{};
     int g1 = 0;
     if (m1.nnzb > 0) {
-        g1 = (int)std::min<int64_t>(std::max<int64_t>((m1.n_chunks + 3) / 4, 1), MAX_PARTIALS / 2);
-        d = DynPart{m1.vals.p, m1.colw.p, m1.row_ptr.p, m1.row_chunk0.p, m1.chunk_row.p, m1.rowmap.p, m1.yd.p, m1.chunk_partial.p, m1.n_chunks};
+        // workgroups for the chunks of long rows (one per wavefront) + for the short rows (four lanes each); a multiple of 8 keeps the XCD placement of the static part
+        g1 = (int)std::min<int64_t>(((m1.n_chunks + 3) / 4 + (m1.n_rows + BLOCK / 4 - 1) / (BLOCK / 4) + 7) / 8 * 8, MAX_PARTIALS / 4);
+        d = DynPart{m1.vals.p, m1.colw.p, m1.row_ptr.p, m1.row_chunk0.p, m1.chunk_row.p, m1.rowmap.p, m1.yd.p, m1.chunk_partial.p, m1.n_chunks, m1.n_rows};
     }
-    hipLaunchKernelGGL(k_spmv_fused<V>, dim3(g0 + g1), dim3(BLOCK), 0, c.stream, g0, m0.vals.p, m0.colw.p, m0.tile_first_row.p, m0.nnzb, m0.ntiles, d, x, y, pdot, partials, ctrl);
+    hipLaunchKernelGGL(k_spmv_fused<V>, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, x, y, pdot, partials, ctrl);
     if (g1 > 0 && combine)
         hipLaunchKernelGGL(k_spmv_combine, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.nbr, (const int32_t*)m1.crow_of_row.p, (const uint32_t*)m1.row_chunk0.p,
                            (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, y);
-    return g0 + g1;
+    return g0 + gr + g1;
 }
 // reference point for the micro-benchmark (variant 9): a plain grid-stride float4 read of the matrix values, i.e. what streaming the
 // matrix costs at best on this box (measured 16.2 us for the 1M-tet block = 6.3 TB/s)
@@ -1480,6 +1641,29 @@ __global__ __launch_bounds__(BLOCK) void k_stream_ref(const float4* __restrict__
     const double t = block_sum((double)(s.x + s.y + s.z + s.w), sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
+// variant 11: what a block product needs (column word, values, x gather, nine FMAs) in the simplest possible loop, no row reduction:
+// the floor for any kernel on this storage
+__global__ __launch_bounds__(BLOCK) void k_spmv_products_only(const float* __restrict__ vals, const uint32_t* __restrict__ colw, int64_t ntiles, const double* __restrict__ x,
+                                                             double* __restrict__ partials)
+{
+    __shared__ double sm[4];
+    const int lane = threadIdx.x & 63;
+    const int64_t n_waves = (int64_t)gridDim.x * 4, gw = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t tpw = (ntiles + n_waves - 1) / n_waves, t0 = gw * tpw, t1 = t0 + tpw < ntiles ? t0 + tpw : ntiles;
+    double acc = 0.0;
+    for (int64_t t = t0; t < t1; t++) {
+        const uint32_t w = colw[t * 64 + lane];
+        const float4* q = reinterpret_cast<const float4*>(vals + (size_t)t * 576);
+        const float4 a = q[lane], b = q[64 + lane];
+        const float cc = vals[(size_t)t * 576 + 512 + lane];
+        const size_t c3 = 3 * (size_t)(w & 0x7fffffffu);
+        const double x0 = x[c3], x1 = x[c3 + 1], x2 = x[c3 + 2];
+        acc += ((double)a.x * x0 + (double)a.y * x1 + (double)a.z * x2) + ((double)a.w * x0 + (double)b.x * x1 + (double)b.y * x2) +
+               ((double)b.z * x0 + (double)b.w * x1 + (double)cc * x2);
+    }
+    acc = block_sum(acc, sm);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
 // Micro-benchmark of the SpMV kernel on the assembled matrix: n back-to-back launches of q = A p (+ fused dot), HIP events
 // around the whole batch on the engine's stream. Returns the average launch duration in microseconds.
 double spmv_bench(Context& c, int n)
@@ -1493,14 +1677,11 @@ double spmv_bench(Context& c, int n)
     MS_CHECK(hipEventRecord(e0, c.stream));
     for (int i = 0; i < n; i++) {
         switch (c.spmv_variant) {
-            case 1: launch_spmv<1>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
+            case 1: launch_spmv<1>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr, false); break;
+            case 11: hipLaunchKernelGGL(k_spmv_products_only, dim3(c.spmv_grid_cap > 0 ? c.spmv_grid_cap : 1024), dim3(BLOCK), 0, c.stream, (const float*)c.part[0].vals.p, (const uint32_t*)c.part[0].scol.p, c.part[0].ntiles, (const double*)c.p.p, c.partials.p); break;
             case 9: hipLaunchKernelGGL(k_stream_ref, dim3(2048), dim3(BLOCK), 0, c.stream, (const float4*)c.part[0].vals.p, (size_t)c.part[0].ntiles * 144, c.partials.p); break;
-            case 2: launch_spmv<2>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
-            case 3: launch_spmv<3>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
-            case 4: launch_spmv<4>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
-            case 5: launch_spmv<5>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
-            case 6: launch_spmv<6>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr); break;
-            default: launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr);
+            case 3: launch_spmv<3>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr, false); break;
+            default: launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr, false);  // as inside the solver: k_pcg_step adds the contact rows
         }
     }
     MS_CHECK(hipEventRecord(e1, c.stream));

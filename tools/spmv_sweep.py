@@ -1,4 +1,8 @@
-"""Developer tool: SpMV micro-benchmark sweep on the 1M-tet block matrix (run on the GPU box)."""
+"""Developer tool: SpMV micro-benchmark sweep on the 1M-tet block matrix (run on the GPU box).
+
+Variants (mistark_set_option "spmv_variant"): 0 = the solver's launch (static chunks + contact part, contact rows left to the consumer),
+1 = the same without the row reduction (loads + block products), 3 = without the matrix value loads, 9 = plain float4 stream of the value
+buffer (floor of the memory system for this matrix), 11 = loads + gather + products in the simplest possible loop."""
 import ctypes as C
 import sys
 
@@ -12,7 +16,7 @@ sim.run_one_step()
 L = capi.lib()
 h = sim.engine_handle()
 _, _, nbytes = sim.spmv_timing()
-for variant in [0, 1, 3, 9]:
+for variant in [0, 1, 3, 9, 11]:
   for cap in [int(a) for a in sys.argv[1:]] or [512, 1024, 2048, 4096]:
     L.mistark_set_option(h, b"spmv_grid_cap", cap)
     L.mistark_set_option(h, b"spmv_variant", variant)
