@@ -1859,7 +1859,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     // Iterations are launched in batches of PCG_BATCH; after each batch the control block is copied to a pinned slot and an
     // event recorded. The host launches batch b+1 BEFORE it waits for batch b's event, so the GPU never idles on the host's
     // convergence check, and at most one batch of device-side no-op launches (ctrl->done) is wasted after convergence.
-    constexpr int PCG_BATCH = 8;
+    constexpr int PCG_BATCH = 4;
     PcgCtrl* hs[2] = {reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048), reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048 + 64)};  // pinned
     while (c.pcg_ev.size() < 2) {
         hipEvent_t e;
