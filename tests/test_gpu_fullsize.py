@@ -84,3 +84,47 @@ def test_full_size_properties():
     st = sim.info().last_stats
     assert st.newton_iterations >= 1
     sim.close()
+
+
+def _bsr_matvec(row_ptr, cols, vals, x):
+    """y = A x from the exported block CSR (float blocks, double accumulate), row after row."""
+    import scipy.sparse as sp
+
+    A = sp.bsr_matrix((vals.astype(np.float64), cols, row_ptr), shape=(3 * (len(row_ptr) - 1),) * 2)
+    return A @ x
+
+
+@pytest.mark.parametrize("n_cloth", [24, 40])
+def test_spmv_rows_longer_than_a_chunk(n_cloth):
+    """The static matrix part is stored in row-aligned chunks of 8 tiles (512 blocks); a rigid body attached to every point of a
+    cloth owns two block rows with one block per point (625 / 1681 here): at 24 x 24 they still fit a chunk of their own, at 40 x 40 they
+    take the over-long-row path. The device product must equal the product with the exported matrix either way."""
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    st = S.default_settings()
+    st.init_frictional_contact = 0
+    sim = S.Simulation(st)
+    cloth = sim.add_surface_grid("cloth", (1.0, 1.0), (n_cloth, n_cloth), S.cotton_fabric())
+    box = sim.add_rigid_box("box", 1.0, (0.2, 0.2, 0.2))
+    sim.rb_add_translation(box, (0.0, 0.0, 0.3))
+    npts = (n_cloth + 1) ** 2
+    sim.attach_rigid_body(box, cloth, list(range(npts)), 1e3)
+    sim.prescribe_inside_aabb(cloth, (0.5, 0.5, 0.0), (0.001, 0.001, 0.001), 1e6)
+    assert sim.run_one_step()
+    eng = _Eng(sim)
+    eng.eval(capi.EVAL_P_G_H)
+    eng.assemble()
+    row_ptr, cols, vals = eng.get_bsr()
+    lens = np.diff(row_ptr)
+    assert lens.max() >= npts     # the body's rows
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal(eng.ndofs)
+    y = eng.spmv(x)
+    y_ref = _bsr_matvec(row_ptr, cols, vals, x)
+    assert np.abs(y - y_ref).max() <= 1e-12 * np.abs(y_ref).max()
+    # and the solver built on it still converges to the right answer
+    du, pinfo = eng.pcg(1e-10, 1e-8, 20000, rhs=x)
+    assert pinfo.converged
+    assert np.linalg.norm(x - _bsr_matvec(row_ptr, cols, vals, du)) <= 1e-6 * np.linalg.norm(x)
+    sim.close()
