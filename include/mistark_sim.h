@@ -24,6 +24,12 @@ typedef struct mistark_sim_settings
     int32_t enable_output;
     int32_t init_frictional_contact; /* Settings::Simulation::init_frictional_contact */
     mistark_newton_settings newton;
+    /* Settings::Output (stark/src/core/Settings.h:12-24): VTK frames <output_directory>/<simulation_name>_<label>_<frame>.vtk of every
+     * labelled object at `fps` (< 0: every accepted step); off by default */
+    int32_t enable_frame_writes;
+    int32_t fps;
+    char output_directory[256];
+    char simulation_name[64];
 } mistark_sim_settings;
 void mistark_sim_default_settings(mistark_sim_settings* s);
 

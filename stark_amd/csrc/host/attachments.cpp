@@ -292,6 +292,7 @@ Line::Handler DeformablesPresets::add_line(const std::string& label, const std::
     auto inertia = deformables->lumped_inertia->add(ps, segments, p.inertia);
     auto strain = deformables->segment_strain->add(ps, segments, p.strain);
     ContactHandler contact = interactions->contact->add_edges(ps, segments, p.contact);
+    if (!label.empty() && interactions->output) interactions->output->add_segment_mesh(label, ps, segments);
     return {ps, inertia, strain, contact};
 }
 Line::VCH DeformablesPresets::add_line_as_segments(const std::string& label, const Vec3& begin, const Vec3& end, int n_segments, const Line::Params& p)

@@ -63,6 +63,7 @@ void Stark::_initialize()
     bool valid = true;
     for (auto& f : callbacks->newton->is_initial_state_valid) valid = valid && f();
     if (!valid) throw std::runtime_error("Initial state is not valid");
+    _write_frame();  // Stark.cpp:303
 }
 
 namespace {
@@ -139,6 +140,7 @@ bool Stark::run_one_step()
         for (auto& f : callbacks->after_time_step) f();
         current_time += dt;
         current_time_step++;
+        _write_frame();  // Stark.cpp:201
         const double dt_taken = dt;
         dt = std::min(settings.simulation.max_time_step_size, dt * settings.simulation.time_step_size_success_multiplier);
         if (settings.output.enable_output) {
@@ -157,6 +159,32 @@ bool Stark::run_one_step()
     dt /= 2.0;
     if (dt < settings.simulation.time_step_size_lower_bound) return false;
     return true;
+}
+std::string Stark::get_frame_path(const std::string& name) const
+{
+    return settings.output.output_directory + "/" + settings.output.simulation_name + "_" + name + "_" + std::to_string(current_frame);
+}
+void Stark::_write_frame()
+{
+    // Stark.cpp:314-338
+    if (!settings.output.enable_frame_writes) return;
+    auto write_frame_impl = [&]() {
+        if (settings.output.fps != 0)
+            for (auto& f : callbacks->write_frame) f();
+        if (settings.output.enable_output) std::printf("[Frame: %d] Time: %.3f s\n", current_frame, current_time);
+        current_frame++;
+    };
+    if (settings.output.fps < 0) {
+        write_frame_impl();
+    } else if (current_frame == 0) {
+        write_frame_impl();
+        next_frame_time += 1.0 / (double)settings.output.fps;
+    } else {
+        while (current_time > next_frame_time + 100.0 * std::numeric_limits<double>::epsilon()) {
+            write_frame_impl();
+            next_frame_time += 1.0 / (double)settings.output.fps;
+        }
+    }
 }
 bool Stark::run(double duration, std::function<void()> callback)
 {
@@ -796,6 +824,7 @@ Surface::Handler DeformablesPresets::add_surface(const std::string& label, const
     auto strain = deformables->triangle_strain->add(ps, T, p.strain);
     auto bending = deformables->discrete_shells->add(ps, T, p.bending);
     ContactHandler contact = interactions->contact->add_triangles(ps, T, p.contact);
+    if (!label.empty() && interactions->output) interactions->output->add_triangle_mesh(label, ps, T);
     return {ps, inertia, strain, bending, contact};
 }
 Surface::VCH DeformablesPresets::add_surface_grid(const std::string& label, const std::array<double, 2>& dim, const std::array<int, 2>& sub, const Surface::Params& p)
@@ -819,6 +848,7 @@ Volume::Handler DeformablesPresets::add_volume(const std::string& label, const s
         find_surface(surface, tri_to_tet_map, V, T);
         contact = interactions->contact->add_triangles(ps, surface, tri_to_tet_map, p.contact);
     }
+    if (!label.empty() && interactions->output) interactions->output->add_tet_mesh(label, ps, T);
     return {ps, inertia, strain, contact};
 }
 Volume::VCH DeformablesPresets::add_volume_grid(const std::string& label, const Vec3& dim, const std::array<int, 3>& sub, const Volume::Params& p)
@@ -833,10 +863,10 @@ RigidBody::Handler RigidBodyPresets::add(const std::string& label, double mass, 
                                          const EnergyFrictionalContact::Params& cp)
 {
     // RigidBodyPresets.cpp:11-26
-    (void)label;
     RigidBodyHandler body = rigidbodies->add(mass, inertia_local);
     ContactHandler contact;
     if (interactions->contact->is_active()) contact = interactions->contact->add_triangles(body, V, T, cp);
+    if (!label.empty() && interactions->output) interactions->output->add_triangle_mesh(label, body, V, T);
     return {body, contact};
 }
 RigidBody::VCH RigidBodyPresets::add_box(const std::string& label, double mass, const Vec3& size, const EnergyFrictionalContact::Params& cp)
@@ -857,6 +887,7 @@ Simulation::Simulation(const Settings& settings) : stark(settings)
     interactions = std::make_shared<Interactions>();
     interactions->attachments = std::make_shared<EnergyAttachments>(stark, pd, rbd);  // Interactions.cpp:8-9: attachments, then contact
     interactions->contact = std::make_shared<EnergyFrictionalContact>(stark, pd, rbd);
+    interactions->output = std::make_shared<MeshOutput>(stark, pd, rbd);
     presets = std::make_shared<Presets>();
     presets->deformables = std::make_shared<DeformablesPresets>(deformables, interactions);
     presets->rigidbodies = std::make_shared<RigidBodyPresets>(rigidbodies, interactions);

@@ -33,7 +33,10 @@ struct Settings
     struct Output
     {
         std::string simulation_name = "";
-        bool enable_output = false;  // console line per step (Stark.cpp:182-189)
+        std::string output_directory = "";
+        bool enable_output = false;        // console line per step (Stark.cpp:182-189)
+        bool enable_frame_writes = false;  // VTK frames through the write_frame callbacks (Stark.cpp:314-338); needs output_directory
+        int fps = 30;                      // < 0: a frame after every accepted time step
     } output;
     struct Simulation
     {
@@ -80,6 +83,8 @@ struct Callbacks
     std::shared_ptr<SolverCallbacks> newton = std::make_shared<SolverCallbacks>();
     std::vector<std::function<void()>> before_simulation, before_time_step, after_time_step, on_time_step_accepted;
     std::vector<std::function<bool()>> should_continue_execution;
+    std::vector<std::function<void()>> write_frame;
+    void add_write_frame(std::function<void()> f) { write_frame.push_back(f); }
     void add_before_simulation(std::function<void()> f) { before_simulation.push_back(f); }
     void add_before_time_step(std::function<void()> f) { before_time_step.push_back(f); }
     void add_after_time_step(std::function<void()> f) { after_time_step.push_back(f); }
@@ -105,6 +110,9 @@ public:
     std::shared_ptr<Callbacks> callbacks = std::make_shared<Callbacks>();
     double current_time = 0.0;
     int current_time_step = 0;
+    int current_frame = 0;
+    double next_frame_time = 0.0;
+    std::string get_frame_path(const std::string& name) const;  // Stark.cpp:245-248
     double dt = -1.0;        // bound by address into the potentials, like mws.make_scalar(stark.dt)
     Vec3 gravity = {0.0, 0.0, -9.81};
     mistark_newton_stats last_stats{};
@@ -134,6 +142,7 @@ private:
     int dt_array_id = -1, gravity_array_id = -1;
     double dt_uploaded = -1.0;
     void _initialize();
+    void _write_frame();
 };
 
 // ---- stark::PointSetHandler / PointDynamics ------------------------------------------------------------------------------
@@ -645,10 +654,44 @@ private:
     Handler new_handler(int type, const Params& params, int& group);
     bool _is_converged_state_valid();
 };
+class MeshOutput;
 struct Interactions
 {
+    std::shared_ptr<MeshOutput> output;  // (the reference keeps one output object per subsystem; one serves both here)
     std::shared_ptr<EnergyAttachments> attachments;
     std::shared_ptr<EnergyFrictionalContact> contact;
+};
+
+// ---- frame output (stark/src/models/deformables/DeformablesMeshOutput.*, rigidbodies/RigidBodiesMeshOutput.*) ------
+// Legacy binary VTK files, one per output label and frame, written from the host mirror of the state (positions leave the device once
+// per frame, not per step). Meshes with the same label are merged into one file.
+void write_VTK(const std::string& path, const std::vector<Vec3>& vertices, const int* conn, size_t n_cells, int nodes_per_cell);
+class MeshOutput
+{
+public:
+    MeshOutput(Stark& stark, spPointDynamics dyn, spRigidBodyDynamics rb);
+    void add_point_set(const std::string& label, const PointSetHandler& set);
+    void add_segment_mesh(const std::string& label, const PointSetHandler& set, const std::vector<std::array<int, 2>>& conn);
+    void add_triangle_mesh(const std::string& label, const PointSetHandler& set, const std::vector<std::array<int, 3>>& conn);
+    void add_tet_mesh(const std::string& label, const PointSetHandler& set, const std::vector<std::array<int, 4>>& conn);
+    void add_triangle_mesh(const std::string& label, const RigidBodyHandler& rb, const std::vector<Vec3>& local_vertices, const std::vector<std::array<int, 3>>& conn);
+    int frames_written = 0;
+
+private:
+    struct Mesh
+    {
+        std::string label;
+        int nodes_per_cell = 0;
+        int point_set = -1, rigid_body = -1;
+        std::vector<Vec3> local_vertices;  // rigid bodies
+        std::vector<int> conn;
+    };
+    Stark& stark;
+    spPointDynamics dyn;
+    spRigidBodyDynamics rb;
+    std::vector<Mesh> meshes;
+    void add(const std::string& label, int nodes_per_cell, int point_set, int rigid_body, const std::vector<Vec3>& loc, const int* conn, size_t n);
+    void _write_frame();
 };
 
 // ---- stark::Deformables + presets + Simulation ---------------------------------------------------------------------------

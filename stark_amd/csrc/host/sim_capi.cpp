@@ -93,6 +93,10 @@ void mistark_sim_default_settings(mistark_sim_settings* s)
     s->enable_output = 0;
     s->init_frictional_contact = 0;  // (the reference defaults to true; scenes of this facade opt in)
     s->newton = d.newton;
+    s->enable_frame_writes = 0;
+    s->fps = d.output.fps;
+    std::memset(s->output_directory, 0, sizeof(s->output_directory));
+    std::memset(s->simulation_name, 0, sizeof(s->simulation_name));
 }
 void mistark_volume_params_soft_rubber(mistark_volume_params* p)
 {
@@ -148,6 +152,10 @@ int mistark_sim_create(const mistark_sim_settings* in, mistark_sim** out)
     st.output.enable_output = d.enable_output != 0;
     st.simulation.init_frictional_contact = d.init_frictional_contact != 0;
     st.newton = d.newton;
+    st.output.enable_frame_writes = d.enable_frame_writes != 0;
+    st.output.fps = d.fps;
+    st.output.output_directory = std::string(d.output_directory, strnlen(d.output_directory, sizeof(d.output_directory)));
+    st.output.simulation_name = std::string(d.simulation_name, strnlen(d.simulation_name, sizeof(d.simulation_name)));
     auto* s = new mistark_sim();
     try {
         s->sim = std::make_unique<Simulation>(st);

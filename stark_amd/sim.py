@@ -11,7 +11,8 @@ from . import capi
 class SimSettings(C.Structure):
     _fields_ = [("gravity", C.c_double * 3), ("max_time_step_size", C.c_double), ("use_adaptive_time_step", C.c_int32),
                 ("time_step_size_success_multiplier", C.c_double), ("time_step_size_lower_bound", C.c_double), ("device", C.c_int32),
-                ("mirror_state_to_host", C.c_int32), ("enable_output", C.c_int32), ("init_frictional_contact", C.c_int32), ("newton", capi.NewtonSettings)]
+                ("mirror_state_to_host", C.c_int32), ("enable_output", C.c_int32), ("init_frictional_contact", C.c_int32), ("newton", capi.NewtonSettings),
+                ("enable_frame_writes", C.c_int32), ("fps", C.c_int32), ("output_directory", C.c_char * 256), ("simulation_name", C.c_char * 64)]
 
 
 class VolumeParams(C.Structure):

@@ -441,3 +441,47 @@ def test_cfg1_full_size_beam_trajectory():
     assert np.abs(sim.points("x0") - z["x_end"]).max() <= 1e-6 * np.abs(z["x_end"]).max()
     assert np.abs(sim.points("v0") - z["v_end"]).max() <= 1e-5 * max(np.abs(z["v_end"]).max(), 1.0)
     sim.close()
+
+
+def test_frame_output_vtk(tmp_path):
+    """Frame output of the host layer (Stark.cpp:314-338 with DeformablesMeshOutput / RigidBodiesMeshOutput): one legacy binary VTK file per
+    label and frame, points as float, frame 0 at initialisation and then at `fps`; the last file holds the state the simulation reports."""
+    from stark_amd import sim as S
+
+    st = S.default_settings()
+    st.init_frictional_contact = 0
+    st.enable_frame_writes = 1
+    st.fps = 30
+    st.output_directory = str(tmp_path).encode()
+    st.simulation_name = b"hang"
+    sim = S.Simulation(st)
+    cloth = sim.add_surface_grid("cloth", (0.4, 0.4), (6, 6), S.cotton_fabric())
+    sim.prescribe_inside_aabb(cloth, (0.2, 0.2, 0.0), (0.001, 0.001, 0.001), 1e6)
+    box = sim.add_rigid_box("box", 1.0, (0.1, 0.1, 0.1))
+    sim.rb_add_translation(box, (0.0, 0.0, 0.5))
+    for _ in range(3):
+        assert sim.run_one_step()
+    files = sorted(os.listdir(tmp_path))
+    # frame 0 at initialisation; then a frame once the time has PASSED the next multiple of 1/fps (Stark.cpp:333): steps 2 and 3 here
+    assert files == ["hang_box_%d.vtk" % k for k in range(3)] + ["hang_cloth_%d.vtk" % k for k in range(3)]
+
+    def read(path):
+        raw = open(path, "rb").read()
+        head, rest = raw.split(b"POINTS ", 1)
+        assert head.startswith(b"# vtk DataFile Version") and b"BINARY" in head and b"UNSTRUCTURED_GRID" in head
+        n = int(rest.split(b" ", 1)[0])
+        data = rest.split(b"\n", 1)[1]
+        pts = np.frombuffer(data[:12 * n], dtype=">f4").reshape(n, 3)
+        cells = data[12 * n:].split(b"CELLS ", 1)[1]
+        m, size = [int(v) for v in cells.split(b"\n", 1)[0].split()]
+        conn = np.frombuffer(cells.split(b"\n", 1)[1][:4 * size], dtype=">i4").reshape(m, size // m)
+        return pts, conn
+
+    pts, conn = read(os.path.join(tmp_path, "hang_cloth_2.vtk"))
+    assert pts.shape == (49, 3) and conn.shape == (72, 4) and (conn[:, 0] == 3).all() and conn[:, 1:].max() == 48
+    assert np.abs(pts - sim.points("x0").astype(np.float32)).max() <= 1e-6
+    bp, bc = read(os.path.join(tmp_path, "hang_box_2.vtk"))
+    assert bp.shape[0] == 8 or bp.shape[0] == 24
+    t = sim.rb_state(box)[0]
+    assert np.abs(bp.mean(axis=0) - t).max() <= 1e-5      # the box fell with its centre
+    sim.close()
