@@ -196,7 +196,7 @@ def main():
                              "detection every evaluation, gravity, dt=1/30, initial gap 1.5 mm" % (nx, ny, nz, n_tets, info.ndofs)) if a.scene == "contact" else
                             ("tet block generate_tet_grid{%d,%d,%d} = %d tets / %d DoF, Soft_Rubber, bottom face clamped, gravity, dt=1/30, NO contact" % (nx, ny, nz, n_tets, info.ndofs)),
                 "step": "one Newton iteration (contact detection, eval P+g+H, assembly, block-Jacobi PCG, intersection check, line search)",
-                "parallelism": "single GPU" if world == 1 else "elements sharded by contiguous ranges over %d GPUs; RCCL all-reduce of energy+gradient and of the assembled matrix; replicated PCG, line search and contact detection" % world,
+                "parallelism": "single GPU" if world == 1 else "elements sharded by contiguous ranges over %d GPUs; RCCL all-reduce of energy+gradient, of the assembled matrix and of the projection deltas; replicated PCG, line search and contact detection" % world,
                 "projection": "Progressive",
             },
             "ms_per_linear_solve": 1000.0 * t_ls / max(n_ls, 1),

@@ -234,6 +234,9 @@ struct Context
     int rank = 0, world = 1;
     std::unique_ptr<struct Collective> coll;
     DevBuf<double> dist_scalar;
+    // sharded projection: delta records of this rank, the common exchange buffer and its sort scratch (kernels.hip: exchange_projection_deltas)
+    DevBuf<uint32_t> proj_rec_pos, proj_keys, proj_keys_alt, proj_idx, proj_idx_alt;
+    DevBuf<float> proj_rec_val, proj_x;
     DevBuf<SrcRange> src_ranges;
     struct ContactSystem* contact = nullptr;  // device contact detector (contact.hip), created by mistark_contact_init
 

@@ -953,9 +953,17 @@ __global__ __launch_bounds__(BLOCK) void k_project_select(int n_elem, PotArgs a,
     list[idx] = (uint32_t)e;
 }
 
+struct ProjRecords  // sharded projection: where k_project_eig records its matrix deltas (pos == nullptr: not recording)
+{
+    uint32_t* pos;
+    float* val;
+    unsigned long long* count;
+    unsigned long long cap;
+    uint32_t part_bit;  // 0x80000000 for potentials of the dynamic matrix part
+};
 template <int NB>
 __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elemH, int n_elem, const uint32_t* __restrict__ list, int n_list, double eps, int mirroring,
-                                                       const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters)
+                                                       const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters, ProjRecords rec)
 {
     constexpr int n = 3 * NB, nn = n * n, m = (n + 1) & ~1;  // m: even number of players of the round-robin schedule
     __shared__ double sA[4][nn], sV[4][nn], sC[4][m], sS[4][m], sL[4][m];
@@ -1067,6 +1075,13 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elem
     const bool changed = __ballot(bad) != 0ull;
     if (lane == 0 && changed) atomicAdd((unsigned long long*)&counters[1], 1ull);
     if (!changed) return;  // untouched, like the reference (project_to_PD.cpp:25-29)
+    // sharded runs: the deltas are not added here but recorded (position in the tile storage, value), exchanged between the ranks and
+    // applied by all of them in the same order (project(): exchange_projection_deltas)
+    unsigned long long rec_base = 0;
+    if (rec.pos) {
+        if (lane == 0) rec_base = atomicAdd(rec.count, (unsigned long long)nn);
+        rec_base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(rec_base >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)rec_base);
+    }
     for (int t = lane; t < nn; t += 64) {
         const int i = t / n, j = t - i * n;
         double acc = 0.0;
@@ -1074,7 +1089,15 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elem
         const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
         const size_t blk = (size_t)(ba * NB + bb) * n_elem + e;
         double* dst = elemH + blk * 9 + ii * 3 + jj;
-        if (vals) atomicAdd(&vals[tile_val_index(slot_of_src[blk], ii * 3 + jj)], (float)(acc - *dst));
+        if (rec.pos) {
+            const unsigned long long k = rec_base + (unsigned long long)t;
+            if (k < rec.cap) {
+                rec.pos[k] = rec.part_bit | (uint32_t)tile_val_index(slot_of_src[blk], ii * 3 + jj);
+                rec.val[k] = (float)(acc - *dst);
+            }
+        } else if (vals) {
+            atomicAdd(&vals[tile_val_index(slot_of_src[blk], ii * 3 + jj)], (float)(acc - *dst));
+        }
         *dst = acc;
     }
 }
@@ -1089,6 +1112,93 @@ __global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restric
     if (!act) atomicAdd((unsigned long long*)&counters[2], 1ull);
 }
 
+// ---- sharded projection: the matrix is replicated, the projected elements are not ---------------------------------------------------
+// Each rank holds the deltas (projected - original) of ITS elements as records (position in the tile storage, float). The ranks learn
+// each other's record counts with one small all-reduce, place their records in a common zero-filled buffer at their offset, all-reduce
+// it (sum with zeros = exchange; only the all-reduce primitive is needed), sort by position (stable: equal positions keep the rank-major
+// list order, which is the same on every rank) and add the runs to the matrix: every rank applies the same numbers in the same order,
+// so the replicated solver keeps taking identical branches. When a round touches too many elements (PPN activating the whole mesh at
+// first contact) the ranks fall back to re-assembling and all-reducing the matrix.
+constexpr unsigned long long PROJ_REC_CAP = 8ull << 20;      // records per rank and round (64 MB)
+constexpr unsigned long long PROJ_REC_TOTAL_CAP = 24ull << 20;
+__global__ __launch_bounds__(BLOCK) void k_pack_records(const uint32_t* __restrict__ pos, const float* __restrict__ val, unsigned long long n, unsigned long long offset,
+                                                        float* __restrict__ x)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    float* o = x + 3 * (offset + i);
+    o[0] = (float)(pos[i] >> 16);     // (exact in float; bit patterns themselves would not survive a floating-point sum)
+    o[1] = (float)(pos[i] & 0xffffu);
+    o[2] = val[i];
+}
+__global__ __launch_bounds__(BLOCK) void k_unpack_keys(const float* __restrict__ x, unsigned long long n, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    keys[i] = ((uint32_t)x[3 * i] << 16) | (uint32_t)x[3 * i + 1];
+    idx[i] = (uint32_t)i;
+}
+__global__ __launch_bounds__(BLOCK) void k_apply_records(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx, const float* __restrict__ x, unsigned long long n,
+                                                         float* __restrict__ vals0, float* __restrict__ vals1)
+{
+    const unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t key = keys[i];
+    if (i > 0 && keys[i - 1] == key) return;  // not the head of its run
+    float* dst = (key & 0x80000000u) ? vals1 + (key & 0x7fffffffu) : vals0 + key;
+    float v = *dst;
+    for (unsigned long long k = i; k < n && keys[k] == key; k++) v += x[3 * (size_t)idx[k] + 2];  // the order of the common list
+    *dst = v;
+}
+static void exchange_projection_deltas(Context& c, bool recorded, int64_t n_projected_local)
+{
+    // counts (and "a rank overflowed its record buffer") of all ranks
+    c.dist_scalar.ensure((size_t)c.world + 2);
+    std::vector<double> h((size_t)c.world + 2, 0.0);
+    unsigned long long n_local = 0;
+    if (recorded) {
+        int64_t cnt = 0;
+        fetch(c, &cnt, c.counters.p + 3, sizeof(int64_t));
+        n_local = (unsigned long long)cnt;
+    }
+    h[(size_t)c.rank] = (double)n_local;
+    h[(size_t)c.world] = (recorded && n_local > PROJ_REC_CAP) ? 1.0 : 0.0;
+    h[(size_t)c.world + 1] = n_projected_local > 0 ? 1.0 : 0.0;
+    MS_CHECK(hipMemcpyAsync(c.dist_scalar.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    c.coll->allreduce_f64(c.dist_scalar.p, h.size(), c.stream);
+    fetch(c, h.data(), c.dist_scalar.p, h.size() * sizeof(double));
+    const bool any_projected = h[(size_t)c.world + 1] > 0.0;
+    if (!any_projected) return;
+    if (!recorded) {  // projection before the first assembly of this iteration: the assembly that follows sums the projected Hessians
+        c.matrix_current = false;
+        return;
+    }
+    unsigned long long total = 0, offset = 0;
+    for (int r = 0; r < c.world; r++) {
+        if (r == c.rank) offset = total;
+        total += (unsigned long long)h[(size_t)r];
+    }
+    if (h[(size_t)c.world] > 0.0 || total > PROJ_REC_TOTAL_CAP) {  // too many for the exchange: re-assemble (and all-reduce) instead
+        c.matrix_current = false;
+        return;
+    }
+    if (total == 0) return;  // elements were selected, none changed
+    c.proj_x.ensure(3 * (size_t)total);
+    MS_CHECK(hipMemsetAsync(c.proj_x.p, 0, 3 * (size_t)total * sizeof(float), c.stream));
+    if (n_local > 0)
+        hipLaunchKernelGGL(k_pack_records, dim3(grid_for((int64_t)n_local)), dim3(BLOCK), 0, c.stream, (const uint32_t*)c.proj_rec_pos.p, (const float*)c.proj_rec_val.p, n_local, offset,
+                           c.proj_x.p);
+    c.coll->allreduce_f32(c.proj_x.p, 3 * (size_t)total, c.stream);
+    c.proj_keys.ensure((size_t)total); c.proj_keys_alt.ensure((size_t)total); c.proj_idx.ensure((size_t)total); c.proj_idx_alt.ensure((size_t)total);
+    hipLaunchKernelGGL(k_unpack_keys, dim3(grid_for((int64_t)total)), dim3(BLOCK), 0, c.stream, (const float*)c.proj_x.p, total, c.proj_keys.p, c.proj_idx.p);
+    hipcub::DoubleBuffer<uint32_t> dk(c.proj_keys.p, c.proj_keys_alt.p), dv(c.proj_idx.p, c.proj_idx_alt.p);
+    size_t tmp = 0;
+    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, (int)total, 0, 32, c.stream));
+    c.cub_tmp.ensure(tmp);
+    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(c.cub_tmp.p, tmp, dk, dv, (int)total, 0, 32, c.stream));
+    hipLaunchKernelGGL(k_apply_records, dim3(grid_for((int64_t)total)), dim3(BLOCK), 0, c.stream, (const uint32_t*)dk.Current(), (const uint32_t*)dv.Current(), (const float*)c.proj_x.p, total,
+                       c.part[0].vals.p, c.part[1].vals.p);
+}
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active, int64_t* n_projected_now,
              int64_t* n_changed_now)
 {
@@ -1116,7 +1226,13 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     }
     int64_t h[128];
     fetch(c, h, c.counters.p, sizeof(h));
-    // 2) eigen-projection, one wavefront per selected element; deltas go straight into the assembled matrix if it is current
+    // 2) eigen-projection, one wavefront per selected element; deltas go straight into the assembled matrix if it is current.
+    //    Sharded: every rank projects its own elements and records the deltas; they are exchanged and applied below.
+    const bool record = c.world > 1 && c.matrix_current;
+    if (record) {
+        c.proj_rec_pos.ensure(PROJ_REC_CAP);
+        c.proj_rec_val.ensure(PROJ_REC_CAP);
+    }
     int64_t total = 0;
     for (int pi = 0; pi < np; pi++) {
         Potential& P = c.pots[pi];
@@ -1126,30 +1242,24 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         double* H = c.elemH.p + P.h_off;
         const uint32_t* list = c.proj_list.p + P.e_off;
         const uint32_t* sos = c.part[P.part].slot_of_src.p + (P.k_off - c.part[P.part].blk_base);
-        float* vals = (c.matrix_current && c.world == 1) ? c.part[P.part].vals.p : nullptr;  // sharded: the matrix is re-assembled (summed over ranks)
+        float* vals = (c.matrix_current && c.world == 1) ? c.part[P.part].vals.p : nullptr;
+        ProjRecords rec{};
+        if (record) rec = ProjRecords{c.proj_rec_pos.p, c.proj_rec_val.p, (unsigned long long*)(c.counters.p + 3), PROJ_REC_CAP, P.part == 1 ? 0x80000000u : 0u};
         const dim3 g((nl + 3) / 4), b(BLOCK);
         switch (P.NB) {
-            case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
-            case 2: hipLaunchKernelGGL((k_project_eig<2>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
-            case 3: hipLaunchKernelGGL((k_project_eig<3>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
-            case 4: hipLaunchKernelGGL((k_project_eig<4>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
-            case 5: hipLaunchKernelGGL((k_project_eig<5>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
-            case 6: hipLaunchKernelGGL((k_project_eig<6>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
-            case 7: hipLaunchKernelGGL((k_project_eig<7>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
-            case 8: hipLaunchKernelGGL((k_project_eig<8>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 2: hipLaunchKernelGGL((k_project_eig<2>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 3: hipLaunchKernelGGL((k_project_eig<3>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 4: hipLaunchKernelGGL((k_project_eig<4>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 5: hipLaunchKernelGGL((k_project_eig<5>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 6: hipLaunchKernelGGL((k_project_eig<6>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 7: hipLaunchKernelGGL((k_project_eig<7>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 8: hipLaunchKernelGGL((k_project_eig<8>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
             default: throw Error("project: unsupported block count");
         }
     }
     c.n_projected_total += total;
-    if (c.world > 1) {
-        // every rank must take the same decision: has ANY rank changed element Hessians?
-        double flag = total > 0 ? 1.0 : 0.0;
-        c.dist_scalar.ensure(8);
-        MS_CHECK(hipMemcpyAsync(c.dist_scalar.p, &flag, sizeof(double), hipMemcpyHostToDevice, c.stream));
-        c.coll->allreduce_f64(c.dist_scalar.p, 1, c.stream);
-        fetch(c, &flag, c.dist_scalar.p, sizeof(double));
-        if (flag > 0.0) c.matrix_current = false;
-    }
+    if (c.world > 1) exchange_projection_deltas(c, record, total);
     if (n_projected_now) *n_projected_now = total;
     if (n_changed_now) {
         int64_t h2[2];

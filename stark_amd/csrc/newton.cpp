@@ -128,7 +128,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                     default: throw Error("unknown projection mode");
                 }
             }
-            if (reassemble || !c.matrix_current) {  // (sharded runs cannot patch the summed matrix in place)
+            if (reassemble || !c.matrix_current) {  // (sharded runs: a projection round too large for the delta exchange asks for this)
                 Timer t(st.t_assembly);
                 assemble(c);
                 MS_CHECK(hipStreamSynchronize(c.stream));  // stage timers measure GPU work, not launch time (the next stage synchronises anyway)

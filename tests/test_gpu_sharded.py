@@ -55,11 +55,12 @@ def test_sharded_stages_equal_single_rank(name, world):
         eng.eval(capi.EVAL_P_G_H)
         eng.assemble()
         y = eng.spmv(x)
-        eng.project(1e-10)                       # every element Hessian to PSD, matrix re-assembled below
-        eng.assemble()
+        eng.project(1e-10)                       # every element Hessian to PSD; the assembled matrix is patched in place
+        yp = eng.spmv(x)                         # (sharded: the ranks exchange their deltas and all apply the same list)
+        eng.assemble()                           # ... and must equal the matrix assembled from the projected Hessians
         y2 = eng.spmv(x)
         du, info = eng.pcg(1e-8, 1e-6, 5000)
-        return dict(E=E, Ep=Ep, g=g, y=y, y2=y2, du=du, its=info.n_iterations, conv=info.converged)
+        return dict(E=E, Ep=Ep, g=g, y=y, yp=yp, y2=y2, du=du, its=info.n_iterations, conv=info.converged)
 
     single = engine_from_problem(prob, man)
     ref = stages(single)
@@ -83,11 +84,13 @@ def test_sharded_stages_equal_single_rank(name, world):
         # the matrix is a float sum of per-rank float partial sums instead of one rounding: last-bit differences
         assert np.abs(r["y"] - ref["y"]).max() <= 2e-6 * np.abs(ref["y"]).max()
         assert np.abs(r["y2"] - ref["y2"]).max() <= 2e-6 * np.abs(ref["y2"]).max()
+        assert np.abs(r["yp"] - ref["yp"]).max() <= 2e-6 * np.abs(ref["yp"]).max()
+        assert np.abs(r["yp"] - r["y2"]).max() <= 2e-6 * np.abs(r["y2"]).max()
         assert r["conv"] == ref["conv"] and abs(r["its"] - ref["its"]) <= 2
         assert np.abs(r["du"] - ref["du"]).max() <= 1e-4 * max(np.abs(ref["du"]).max(), 1e-300)
     # the replicated parts rely on every rank holding the SAME bits
     for r in res[1:]:
-        assert r["E"] == res[0]["E"] and (r["g"] == res[0]["g"]).all() and (r["y"] == res[0]["y"]).all() and (r["du"] == res[0]["du"]).all()
+        assert r["E"] == res[0]["E"] and (r["g"] == res[0]["g"]).all() and (r["y"] == res[0]["y"]).all() and (r["yp"] == res[0]["yp"]).all() and (r["du"] == res[0]["du"]).all()
 
 
 def test_sharded_contact_scene_trajectory():
