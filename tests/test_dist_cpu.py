@@ -65,6 +65,43 @@ def _rank_main(rank, world, port, name, result_dir):
     dense = torch.tensor(A_loc.toarray())
     dist.all_reduce(dense)
     assert np.abs(dense.numpy() - A_full.toarray()).max() <= 4e-7 * np.abs(A_full).max()
+    # projection round (stark_amd/csrc/kernels.hip: exchange_projection_deltas): every rank projects ITS elements, the deltas travel as
+    # (position, value) records in a common zero-filled float buffer (all-reduce = exchange), every rank sorts them by position (stable)
+    # and adds them to its copy of the summed matrix: the result must equal the matrix assembled from all projected Hessians
+    n = prob.ndofs
+    recs = []
+    for o in outs:
+        Hp, changed = ev.project_to_pd(o.H)
+        d = (Hp - o.H).astype(np.float32)
+        nb = o.block_rows.shape[1]
+        for e in np.nonzero(changed)[0]:
+            for a in range(nb):
+                for b in range(nb):
+                    for i in range(3):
+                        for j in range(3):
+                            recs.append(((3 * o.block_rows[e, a] + i) * n + 3 * o.block_rows[e, b] + j, d[e, 3 * a + i, 3 * b + j]))
+    cnt = torch.zeros(world, dtype=torch.float64)
+    cnt[rank] = len(recs)
+    dist.all_reduce(cnt)
+    counts = [int(c) for c in cnt]
+    total, offset = sum(counts), sum(counts[:rank])
+    buf = torch.zeros(3 * max(total, 1), dtype=torch.float32)
+    for k, (pos, v) in enumerate(recs):
+        buf[3 * (offset + k)] = float(pos >> 16)      # positions as two exact floats, like the engine
+        buf[3 * (offset + k) + 1] = float(pos & 0xffff)
+        buf[3 * (offset + k) + 2] = float(v)
+    dist.all_reduce(buf)
+    b3 = buf.numpy().reshape(-1, 3)[:total]
+    pos = (b3[:, 0].astype(np.int64) << 16) | b3[:, 1].astype(np.int64)
+    patched = dense.numpy().astype(np.float32).reshape(-1).copy()
+    for k in np.argsort(pos, kind="stable"):
+        patched[pos[k]] += b3[k, 2]
+    full_proj = []
+    for o in full_outs:
+        Hp, _ = ev.project_to_pd(o.H)
+        full_proj.append(ev.ElementOutput(o.name, o.E, o.g, Hp, o.block_rows, o.active))
+    A_proj = to_csr(ev.assemble(full_proj, prob.ndofs)).toarray()
+    assert np.abs(patched.reshape(n, n) - A_proj).max() <= 4e-6 * np.abs(A_proj).max()
     count = torch.tensor([float(covered)])
     dist.all_reduce(count)
     assert int(count.item()) == sum(p.conn.shape[0] for p in prob.potentials)
