@@ -690,6 +690,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     if (n == "force_generic") ctx->c.force_generic = value != 0;
     else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;
     else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;
+    else if (n == "proj_rec_cap") ctx->c.proj_rec_cap = value;
     else if (n == "spmv_variant") ctx->c.spmv_variant = value;
     else throw Error("unknown option '" + n + "'");
     API_END(0)

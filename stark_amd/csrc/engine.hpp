@@ -201,6 +201,7 @@ struct Context
     BsrPart part[2];
     DevBuf<int32_t> diag_slot[2];   // per block row: slot of the diagonal block in each part, -1 if absent
     int spmv_variant = 0;          // micro-benchmark ablation variant
+    long long proj_rec_cap = 0;    // tuning / tests: records per rank of the sharded projection exchange (0 = default)
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather
     bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path

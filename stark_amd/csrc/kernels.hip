@@ -1162,7 +1162,7 @@ static void exchange_projection_deltas(Context& c, bool recorded, int64_t n_proj
         n_local = (unsigned long long)cnt;
     }
     h[(size_t)c.rank] = (double)n_local;
-    h[(size_t)c.world] = (recorded && n_local > PROJ_REC_CAP) ? 1.0 : 0.0;
+    h[(size_t)c.world] = (recorded && n_local > (c.proj_rec_cap > 0 ? (unsigned long long)c.proj_rec_cap : PROJ_REC_CAP)) ? 1.0 : 0.0;
     h[(size_t)c.world + 1] = n_projected_local > 0 ? 1.0 : 0.0;
     MS_CHECK(hipMemcpyAsync(c.dist_scalar.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c.stream));
     c.coll->allreduce_f64(c.dist_scalar.p, h.size(), c.stream);
@@ -1229,6 +1229,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     // 2) eigen-projection, one wavefront per selected element; deltas go straight into the assembled matrix if it is current.
     //    Sharded: every rank projects its own elements and records the deltas; they are exchanged and applied below.
     const bool record = c.world > 1 && c.matrix_current;
+    const unsigned long long rec_cap = c.proj_rec_cap > 0 ? (unsigned long long)c.proj_rec_cap : PROJ_REC_CAP;
     if (record) {
         c.proj_rec_pos.ensure(PROJ_REC_CAP);
         c.proj_rec_val.ensure(PROJ_REC_CAP);
@@ -1244,7 +1245,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         const uint32_t* sos = c.part[P.part].slot_of_src.p + (P.k_off - c.part[P.part].blk_base);
         float* vals = (c.matrix_current && c.world == 1) ? c.part[P.part].vals.p : nullptr;
         ProjRecords rec{};
-        if (record) rec = ProjRecords{c.proj_rec_pos.p, c.proj_rec_val.p, (unsigned long long*)(c.counters.p + 3), PROJ_REC_CAP, P.part == 1 ? 0x80000000u : 0u};
+        if (record) rec = ProjRecords{c.proj_rec_pos.p, c.proj_rec_val.p, (unsigned long long*)(c.counters.p + 3), rec_cap, P.part == 1 ? 0x80000000u : 0u};
         const dim3 g((nl + 3) / 4), b(BLOCK);
         switch (P.NB) {
             case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;

@@ -40,9 +40,11 @@ def run_ranks(world, fn):
     return out
 
 
+@pytest.mark.parametrize("rec_cap", [0, 64], ids=["exchange", "fallback"])
 @pytest.mark.parametrize("world", [2, 3])
 @pytest.mark.parametrize("name", ["tetbeam_full_4x1x1", "cloth_shells_6", "contactmix_t1", "rbchain"])
-def test_sharded_stages_equal_single_rank(name, world):
+def test_sharded_stages_equal_single_rank(name, world, rec_cap):
+    """rec_cap = 64: the projection round does not fit the delta exchange, the ranks must agree to re-assemble instead."""
     from gpu_util import engine_from_problem
     from stark_amd import capi
 
@@ -71,6 +73,8 @@ def test_sharded_stages_equal_single_rank(name, world):
     def rank_fn(r):
         eng = engine_from_problem(prob, man)
         eng.dist_init_local(group, r)
+        if rec_cap:
+            eng.set_option("proj_rec_cap", rec_cap)
         res = stages(eng)
         eng.close()
         return res
@@ -84,8 +88,9 @@ def test_sharded_stages_equal_single_rank(name, world):
         # the matrix is a float sum of per-rank float partial sums instead of one rounding: last-bit differences
         assert np.abs(r["y"] - ref["y"]).max() <= 2e-6 * np.abs(ref["y"]).max()
         assert np.abs(r["y2"] - ref["y2"]).max() <= 2e-6 * np.abs(ref["y2"]).max()
-        assert np.abs(r["yp"] - ref["yp"]).max() <= 2e-6 * np.abs(ref["yp"]).max()
-        assert np.abs(r["yp"] - r["y2"]).max() <= 2e-6 * np.abs(r["y2"]).max()
+        if not rec_cap:   # (fallback: the matrix is only current again after the re-assembly)
+            assert np.abs(r["yp"] - ref["yp"]).max() <= 2e-6 * np.abs(ref["yp"]).max()
+            assert np.abs(r["yp"] - r["y2"]).max() <= 2e-6 * np.abs(r["y2"]).max()
         assert r["conv"] == ref["conv"] and abs(r["its"] - ref["its"]) <= 2
         assert np.abs(r["du"] - ref["du"]).max() <= 1e-4 * max(np.abs(ref["du"]).max(), 1e-300)
     # the replicated parts rely on every rank holding the SAME bits
