@@ -1,11 +1,12 @@
 // kernels.hip — hand-written HIP kernels (gfx950 / CDNA4, wave64) of the per-Newton-step hot path and their launchers.
 //
 //   element evaluation   : lane-per-(i,j) hyper-dual evaluation of the energy expressions (energies.hpp)
-//   pattern build        : (block row, block col) keys -> radix sort -> unique -> 64-block tiles
-//   assembly             : element 3x3 blocks -> float BSR tiles (float atomics), block-Jacobi inverse
-//   SpMV                 : one wavefront per 64-block tile, coalesced 16-B loads, in-wave segmented reduction
-//   PCG                  : 3 fused kernels per iteration, device-resident convergence control
-//   PSD projection       : per-element cyclic Jacobi eigen-decomposition
+//   pattern build        : (block row, block col) keys -> radix sort -> unique -> 64-block tiles; the static part re-laid in
+//                          row-aligned chunks of 8 tiles (build_aligned)
+//   assembly             : element 3x3 blocks -> float BSR tiles (deterministic gather; float atomics as an option), block-Jacobi inverse
+//   SpMV                 : one wavefront per chunk of complete rows, coalesced 16-B loads, in-wave segmented reduction
+//   PCG                  : 3 kernels per iteration, device-resident convergence control, look-ahead batches
+//   PSD projection       : per-element cyclic Jacobi eigen-decomposition; sharded runs exchange the matrix deltas
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -1408,10 +1409,11 @@ void build_preconditioner(Context& c)
 
 // ======================================================================================================================
 // SpMV  y = A x  (+ optional fused dot  pdot . y  -> per-block partials)
-// One wavefront per tile of 64 consecutive 3x3 blocks (CSR order). Values are laid out per tile as
+// Tiles of 64 consecutive 3x3 blocks (CSR order). Values are laid out per tile as
 // float4 q0[64] | float4 q1[64] | float s[64] so that every load instruction of a wave is a fully coalesced
 // 1 KiB (dwordx4) or 256 B (dword) request: 36 B per block, no padding. Column word: bit 31 marks the last block of a row.
-// Rows are reduced inside the wave by a DPP segmented scan; rows that straddle tiles are carried in registers (see kernel).
+// Rows are reduced inside the wave by a DPP segmented scan; rows that straddle tiles of a chunk are carried in registers
+// (spmv_chunked_static). The static part's tiles are grouped in row-aligned chunks (build_aligned), one wavefront each.
 // ======================================================================================================================
 template <int CTRL>
 __device__ __forceinline__ double dpp_row_shr(double v)
@@ -1559,10 +1561,11 @@ static int spmv_grid(const Context& c, int64_t n_chunks, int max_grid)
     const int cap = std::min(c.spmv_grid_cap > 0 ? c.spmv_grid_cap : 2048, max_grid);
     return (int)std::max<int64_t>(std::min<int64_t>(((n_chunks + 3) / 4 + 7) / 8 * 8, cap / 8 * 8), 8);
 }
-// SpMV of the contact part: y += A_dyn x. Its block rows are short (a contact touches a handful of nodes) except the rows of rigid
-// bodies in contact, which hold one block per touching node (thousands): rows are cut into chunks of <= CHUNK_BLOCKS blocks, one
-// wavefront reduces one chunk; single-chunk rows are added to y at once, the chunks of a long row go to a scratch array that
-// k_spmv_chunks_fix sums in order (deterministic, no atomics). p . (A_dyn x) is linear in the chunks and summed right here.
+// SpMV of the contact part: row sums of A_dyn x. Its block rows are short (a contact touches a handful of nodes: four lanes per row)
+// except the rows of rigid bodies in contact, which hold one block per touching node (thousands): those are cut into chunks of
+// <= CHUNK_BLOCKS blocks, one wavefront per chunk. Row sums go to `yd` (one per compact row), the chunks of a multi-chunk row to
+// `chunk_partial`; the consumer (dyn_row) adds them to y in a fixed order (deterministic, no atomics). p . (A_dyn x) is linear in
+// the rows and chunks and summed right here.
 struct DynPart  // the contact part as the fused SpMV kernel sees it
 {
     const float* vals;
