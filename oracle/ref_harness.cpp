@@ -204,6 +204,27 @@ static Scene scene_cloth(const Args& a)
     return sc;
 }
 
+// pystark/pystark/test_sim.py:4-31 (the reference's Python smoke test): s x s Cotton_Fabric cloth, n x n, two corners prescribed with the
+// default EnergyPrescribedPositions::Params, no contact, run for 1 s
+static Scene scene_pycloth(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "pycloth");
+    settings.simulation.init_frictional_contact = false;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const int n = a.i("n", 32);
+    const double s = a.d("size", 0.5);
+    auto [V, T, H] = sim.presets->deformables->add_surface_grid("cloth", { s, s }, { n, n }, stark::Surface::Params::Cotton_Fabric());
+    const Eigen::Vector3d dim = 0.001 * Eigen::Vector3d::Ones();
+    sim.deformables->prescribed_positions->add_inside_aabb(H.point_set, { 0.5 * s, 0.5 * s, 0.0 }, dim, stark::EnergyPrescribedPositions::Params());
+    sim.deformables->prescribed_positions->add_inside_aabb(H.point_set, { 0.5 * s, -0.5 * s, 0.0 }, dim, stark::EnergyPrescribedPositions::Params());
+    std::ostringstream js;
+    js << "{\"kind\":\"pycloth\",\"n\":" << n << ",\"size\":" << s << "}";
+    sc.json = js.str();
+    return sc;
+}
+
 // cfg-4 style block WITHOUT contact: generate_tet_grid(center (0,0,0.6), {lx,ly,lz}, {nx,ny,nz}), Soft_Rubber (full potential),
 // bottom face (z = 0.6 - lz/2) prescribed, gravity compresses the block
 static Scene scene_tetblock(const Args& a)
@@ -611,6 +632,7 @@ static Scene make_scene(const std::string& name, const Args& a)
     if (name == "rbchain") return scene_rbchain(a);
     if (name == "tetblock") return scene_tetblock(a);
     if (name == "tetbeam") return scene_tetbeam(a);
+    if (name == "pycloth") return scene_pycloth(a);
     if (name == "cloth") return scene_cloth(a);
     std::cerr << "unknown scene " << name << std::endl;
     exit(2);
