@@ -204,6 +204,29 @@ static Scene scene_cloth(const Args& a)
     return sc;
 }
 
+// examples/main.cpp hanging_deformable_box (:76-107): n^3 Soft_Rubber box (E = 1e4, damping + strain limiting on), two top corners prescribed
+static Scene scene_hangingbox(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "hangingbox");
+    settings.simulation.init_frictional_contact = false;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const int n = a.i("n", 10);
+    const double d = a.d("size", 0.5), hd = 0.5 * d;
+    auto material = stark::Volume::Params::Soft_Rubber();
+    material.strain.youngs_modulus = 1e4;
+    material.strain.elasticity_only = false;
+    auto [V, T, H] = sim.presets->deformables->add_volume_grid("box", { d, d, d }, { n, n, n }, material);
+    auto bc = stark::EnergyPrescribedPositions::Params().set_stiffness(1e7);
+    sim.deformables->prescribed_positions->add_inside_aabb(H.point_set, { hd, hd, hd }, { 0.001, 0.001, 0.001 }, bc);
+    sim.deformables->prescribed_positions->add_inside_aabb(H.point_set, { -hd, hd, hd }, { 0.001, 0.001, 0.001 }, bc);
+    std::ostringstream js;
+    js << "{\"kind\":\"hangingbox\",\"n\":" << n << ",\"size\":" << d << "}";
+    sc.json = js.str();
+    return sc;
+}
+
 // pystark/pystark/test_sim.py:4-31 (the reference's Python smoke test): s x s Cotton_Fabric cloth, n x n, two corners prescribed with the
 // default EnergyPrescribedPositions::Params, no contact, run for 1 s
 static Scene scene_pycloth(const Args& a)
@@ -632,6 +655,7 @@ static Scene make_scene(const std::string& name, const Args& a)
     if (name == "rbchain") return scene_rbchain(a);
     if (name == "tetblock") return scene_tetblock(a);
     if (name == "tetbeam") return scene_tetbeam(a);
+    if (name == "hangingbox") return scene_hangingbox(a);
     if (name == "pycloth") return scene_pycloth(a);
     if (name == "cloth") return scene_cloth(a);
     std::cerr << "unknown scene " << name << std::endl;

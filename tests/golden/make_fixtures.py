@@ -61,6 +61,8 @@ FIXTURES = {
     "traj_cfg1_tetbeam_52x13x13": ("traj", "tetbeam", "nx=52 ny=13 nz=13 eo=0 steps=3 slim=1 threads=8"),
     # the reference's Python smoke test (pystark/pystark/test_sim.py): hanging 32 x 32 cloth, 1 s = 30 steps
     "traj_cfg_pystark_hanging_cloth": ("traj", "pycloth", "n=32 steps=30 slim=1 threads=8"),
+    # the reference's example hanging_deformable_box (examples/main.cpp:76-107): 12 k tets, 6 steps
+    "traj_cfg_example_hanging_box": ("traj", "hangingbox", "n=10 steps=6 slim=1 threads=8"),
     "traj_cfg3_blockbox_10": ("traj", "blockbox", "nx=10 ny=10 nz=10 L=0.5 gap=0.002 thickness=0.002 bx=1.5 kmin=1e6 steps=4 boxfirst=1 slim=1 threads=8"),
     # contact scenes (cfg 1 / cfg 4 at fixture size): cloth resting on a fixed rigid box, soft block pressed on a fixed rigid box
     "traj_clothbox_8": ("traj", "clothbox", "n=8 gap=0.004 steps=4"),

@@ -514,3 +514,30 @@ def test_pystark_hanging_cloth_smoke_scene():
     assert sum(abs(a - b) for a, b in zip(its, ref)) <= 3, (its, ref)
     assert np.abs(sim.points("x0") - z["x_end"]).max() <= 1e-3 * s
     sim.close()
+
+
+def test_example_hanging_deformable_box():
+    """The reference's example hanging_deformable_box (examples/main.cpp:76-107): 10^3 hexahedra = 12 000 Soft_Rubber tets (E = 1e4, damping
+    and strain limiting active) hanging from two corners; 6 time steps of the unmodified reference."""
+    from stark_amd import sim as S
+
+    z, traj, _ = _load("traj_cfg_example_hanging_box")
+    sc = traj["scene"]
+    sim = S.Simulation()
+    p = S.soft_rubber()
+    p.youngs_modulus = 1e4
+    p.elasticity_only = 0
+    d, n = sc["size"], sc["n"]
+    hd = 0.5 * d
+    box = sim.add_volume_grid("box", (0, 0, 0), (d, d, d), (n, n, n), p)
+    sim.prescribe_inside_aabb(box, (hd, hd, hd), (0.001, 0.001, 0.001), 1e7)
+    sim.prescribe_inside_aabb(box, (-hd, hd, hd), (0.001, 0.001, 0.001), 1e7)
+    its = []
+    for step in range(len(traj["steps"])):
+        assert sim.run_one_step()
+        i = sim.info()
+        assert i.last_newton_result == 0 and abs(i.current_time - traj["steps"][step]["time"]) < 1e-9
+        its.append(i.last_stats.newton_iterations)
+    assert its == traj["newton_iterations"]
+    assert np.abs(sim.points("x0") - z["x_end"]).max() <= 1e-5 * d
+    sim.close()
