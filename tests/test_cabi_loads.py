@@ -46,3 +46,14 @@ def test_no_silent_cpu_fallback():
     L = capi.lib()
     h = C.c_void_p()
     assert L.mistark_create(0, C.byref(h)) != 0
+
+
+def test_headers_are_plain_c():
+    """The drop-in boundary is a C ABI: every header under include/ must compile as C99 on its own (plain pointers and sizes only)."""
+    import glob
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for h in sorted(glob.glob(os.path.join(root, "include", "*.h"))):
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", "-I" + os.path.join(root, "include"), h], capture_output=True)
+        assert r.returncode == 0, (h, r.stderr.decode())
