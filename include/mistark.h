@@ -241,7 +241,9 @@ int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settin
 /* ---- options --------------------------------------------------------------------------------------------------------- */
 /* Engine switches (all default 0): "force_generic" = evaluate every potential through the generic hyper-dual kernels (the
  * closed-form tet kernels are then cross-checked against them); "atomic_assembly" = scatter assembly with float atomics
- * instead of the deterministic gather. Returns 0, or < 0 for an unknown name. */
+ * instead of the deterministic gather. Returns 0, or < 0 for an unknown name. The environment variable
+ * MISTARK_OPTIONS="name=value,name=value" applies the same switches inside mistark_create (for a process that cannot be
+ * edited: a test suite, a profiler run); a bad entry makes mistark_create fail with -6. */
 int mistark_set_option(mistark_ctx* ctx, const char* name, int value);
 
 /* ---- timers ------------------------------------------------------------------------------------------------------- */

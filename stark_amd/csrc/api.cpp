@@ -1,6 +1,9 @@
 // api.cpp — extern "C" entry points of libmistark.so (see include/mistark.h for the contract and reference citations).
 #include <algorithm>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
 
 #include "dist.hpp"
 #include "engine.hpp"
@@ -129,6 +132,23 @@ int mistark_create(int device, mistark_ctx** out)
         return -5;
     }
     *out = ctx;
+    // MISTARK_OPTIONS="name=value,name=value": the mistark_set_option switches for a process that cannot be edited (a test suite, a profiler run)
+    if (const char* env = std::getenv("MISTARK_OPTIONS")) {
+        std::string all(env);
+        size_t at = 0;
+        while (at < all.size()) {
+            const size_t end = std::min(all.find(',', at), all.size());
+            const std::string item = all.substr(at, end - at);
+            const size_t eq = item.find('=');
+            if (eq == std::string::npos || mistark_set_option(ctx, item.substr(0, eq).c_str(), std::atoi(item.c_str() + eq + 1)) != 0) {
+                std::fprintf(stderr, "mistark: bad entry '%s' in MISTARK_OPTIONS\n", item.c_str());
+                mistark_destroy(ctx);
+                *out = nullptr;
+                return -6;
+            }
+            at = end + 1;
+        }
+    }
     return 0;
 }
 void mistark_destroy(mistark_ctx* ctx)
