@@ -378,6 +378,77 @@ static Scene scene_contactmix(const Args& a)
     return sc;
 }
 
+// configs[4] of BASELINE.json ("mixed scene: soft body + shell + hinged rigid bodies, full coupling"): a Soft_Rubber tet block resting
+// over a fixed floor box, a Cotton_Fabric cloth over the block, a chain of boxes joined by add_constraint_hinge (first link fixed)
+// over the cloth. Rigid bodies are registered first (see scene_blockbox about the registration order and friction).
+static Scene scene_mixed(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "mixed");
+    settings.simulation.init_frictional_contact = true;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const int nx = a.i("nx", 26), ny = a.i("ny", 26), nz = a.i("nz", 25), nc = a.i("nc", 128), nrb = a.i("nrb", 16);
+    const double L = a.d("L", 1.0), gap = a.d("gap", 0.0015), th = a.d("thickness", 1e-3), mu = a.d("mu", 0.5), bx = a.d("bx", 3.0), bz = a.d("bz", 0.1);
+    const double link = a.d("link", 0.05), cloth_size = a.d("cloth", 1.2);
+    auto gp = stark::EnergyFrictionalContact::GlobalParams();
+    gp.default_contact_thickness = th;
+    gp.min_contact_stiffness = a.d("kmin", 1e8);
+    sim.interactions->contact->set_global_params(gp);
+    auto ct = sim.interactions->contact;
+
+    auto [fV, fT, floor] = sim.presets->rigidbodies->add_box("floor", 1.0, { bx, bx, bz });
+    sc.record_rigid(floor.rigidbody, (int)fV.size(), fT, th);
+    sim.rigidbodies->add_constraint_fix(floor.rigidbody);
+
+    const double z_block = 0.5 * bz + gap + 0.5 * L;
+    const double z_cloth = 0.5 * bz + gap + L + gap;
+    const double z_chain = z_cloth + gap + 0.5 * link;
+    const double pitch = 1.5 * link;  // link length = link, spacing between links = link / 2
+    std::vector<stark::RigidBodyHandler> links;
+    std::vector<stark::EnergyFrictionalContact::Handler> link_contacts;
+    for (int i = 0; i < nrb; i++) {
+        auto [V, T, h] = sim.presets->rigidbodies->add_box("link", 0.2, { link, link, link });
+        h.rigidbody.set_translation({ (i - 0.5 * (nrb - 1)) * pitch, 0.0, z_chain });
+        sc.record_rigid(h.rigidbody, (int)V.size(), T, th);
+        links.push_back(h.rigidbody);
+        link_contacts.push_back(h.contact);
+    }
+    sim.rigidbodies->add_constraint_fix(links[0]);
+    for (int i = 0; i + 1 < nrb; i++) {
+        const Eigen::Vector3d mid((i + 0.5 - 0.5 * (nrb - 1)) * pitch, 0.0, z_chain);
+        sim.rigidbodies->add_constraint_hinge(links[i], links[i + 1], mid, Eigen::Vector3d::UnitY());
+        ct->disable_collision(link_contacts[i], link_contacts[i + 1]);
+    }
+
+    auto vm = stark::Volume::Params::Soft_Rubber();
+    auto [sV, sT] = stark::generate_tet_grid({ 0.0, 0.0, z_block }, { L, L, L }, { nx, ny, nz });
+    auto soft = sim.presets->deformables->add_volume("block", sV, sT, vm);
+    {
+        auto [surf, map] = stark::find_surface(sV, sT);
+        sc.record_deformable(soft.point_set, surf, map, th);
+    }
+    auto cm = stark::Surface::Params::Cotton_Fabric();
+    auto [cV, cT, cloth] = sim.presets->deformables->add_surface_grid("cloth", { cloth_size * L, cloth_size * L }, { nc, nc }, cm);
+    sc.record_deformable(cloth.point_set, cT, cloth.point_set.all(), th);
+    cloth.point_set.add_displacement({ 0.0, 0.0, z_cloth });
+
+    if (mu > 0.0) {
+        ct->set_friction(floor.contact, soft.contact, mu);
+        ct->set_friction(soft.contact, cloth.contact, mu);
+        for (int i = 0; i < nrb; i++) ct->set_friction(link_contacts[i], cloth.contact, mu);
+        sc.record_friction(0, nrb + 1, mu);
+        sc.record_friction(nrb + 1, nrb + 2, mu);
+        for (int i = 0; i < nrb; i++) sc.record_friction(1 + i, nrb + 2, mu);
+    }
+    std::ostringstream js;
+    js << "{\"kind\":\"mixed\",\"nx\":" << nx << ",\"ny\":" << ny << ",\"nz\":" << nz << ",\"nc\":" << nc << ",\"nrb\":" << nrb << ",\"L\":" << L << ",\"gap\":" << gap
+       << ",\"thickness\":" << th << ",\"mu\":" << mu << ",\"bx\":" << bx << ",\"bz\":" << bz << ",\"link\":" << link << ",\"cloth\":" << cloth_size
+       << ",\"kmin\":" << gp.min_contact_stiffness << "}";
+    sc.json = js.str();
+    return sc;
+}
+
 // Vertex/edge contacts: box corners aimed at a corner and at an edge of a fixed box, a soft block corner aimed at another
 // corner -> the point-point and point-edge rows of the rb-rb and rb-deformable tables that flat contacts never produce
 static Scene scene_contactcorners(const Args& a)
@@ -649,6 +720,7 @@ static Scene make_scene(const std::string& name, const Args& a)
     if (name == "attachzoo") return scene_attachzoo(a);
     if (name == "clothbox") return scene_clothbox(a);
     if (name == "blockbox") return scene_blockbox(a);
+    if (name == "mixed") return scene_mixed(a);
     if (name == "contactrods") return scene_contactrods(a);
     if (name == "contactcorners") return scene_contactcorners(a);
     if (name == "contactmix") return scene_contactmix(a);

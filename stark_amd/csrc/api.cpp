@@ -712,6 +712,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;
     else if (n == "proj_rec_cap") ctx->c.proj_rec_cap = value;
     else if (n == "spmv_variant") ctx->c.spmv_variant = value;
+    else if (n == "proj_variant") ctx->c.proj_variant = value;
     else throw Error("unknown option '" + n + "'");
     API_END(0)
 }

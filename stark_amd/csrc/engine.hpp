@@ -1,5 +1,6 @@
 // engine.hpp — internal declarations of the MI355X engine (not part of the C ABI; see include/mistark.h).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -64,6 +65,13 @@ struct DevBuf
         size_t want = n + n / 8 + 64;
         MS_CHECK(hipMalloc((void**)&p, want * sizeof(T)));
         cap = want;
+        // MISTARK_POISON=1: fill fresh allocations with a NaN pattern, so that a read of memory nobody wrote shows up in the tests
+        // instead of depending on what the allocator hands out (fresh processes get zero pages, long-lived ones do not)
+        static const bool poison = std::getenv("MISTARK_POISON") != nullptr;
+        if (poison) {
+            MS_CHECK(hipMemset(p, 0xFF, want * sizeof(T)));
+            MS_CHECK(hipDeviceSynchronize());  // (the memset runs on the null stream, the engine's stream does not wait for that one)
+        }
     }
 };
 
@@ -201,6 +209,7 @@ struct Context
     BsrPart part[2];
     DevBuf<int32_t> diag_slot[2];   // per block row: slot of the diagonal block in each part, -1 if absent
     int spmv_variant = 0;          // micro-benchmark ablation variant
+    int proj_variant = 0;          // 0 = PSD projection with the matrix in registers (k_project_eig_cols), 1 = in LDS (k_project_eig)
     long long proj_rec_cap = 0;    // tuning / tests: records per rank of the sharded projection exchange (0 = default)
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather

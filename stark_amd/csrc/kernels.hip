@@ -1103,6 +1103,154 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elem
     }
 }
 
+// ---- the same projection with the matrix in REGISTERS ---------------------------------------------------------------------------------
+// k_project_eig keeps A and V in LDS and is bound by the LDS pipe (≈ 45 64-lane, 8-byte LDS operations per rotation round and element:
+// 30 ns per 12 x 12 element on the whole chip). Here one group of m = even(n) lanes owns an element, lane c holds COLUMN c of A and of V
+// in registers, 64 / m elements share a wavefront. One round:
+//   every lane fetches its partner's two columns with ds_bpermute (no bank storage involved), both lanes of a pair compute the same
+//   rotation from the same three numbers and update their columns (A J, V J); the row rotations J^T need, in every column, the entry of
+//   the partner ROW: the updated columns go through LDS once (row-major, conflict-free) and come back as y[partner(i)].
+// ≈ 1/4 of the LDS bytes per element and round. Same cyclic-by-round Jacobi, same pair schedule, same threshold and clamping as
+// k_project_eig; an element's result does not depend on which other elements share its wavefront (a converged group applies identity
+// rotations).
+template <int n>
+__device__ __forceinline__ double pick(const double (&x)[n], int idx)
+{
+    double r = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; i++) r = i == idx ? x[i] : r;
+    return r;
+}
+// partner of player i in round r of the round-robin schedule of m players (k_project_eig: pairs (m-1, r), ((r+k) % (m-1), (r-k) % (m-1)))
+__device__ __forceinline__ int rr_partner(int m, int r, int i) { return i == m - 1 ? r : (i == r ? m - 1 : (2 * r - i + 2 * (m - 1)) % (m - 1)); }
+template <int NB>
+__global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__ elemH, int n_elem, const uint32_t* __restrict__ list, int n_list, double eps, int mirroring,
+                                                            const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters, ProjRecords rec)
+{
+    constexpr int n = 3 * NB, nn = n * n, m = (n + 1) & ~1, W = m, EPW = 64 / W;
+    __shared__ double sM[4][EPW + 1][m * W];  // [row][column] of the element of a group: row exchange; eigenvectors for the rebuild (+1: idle tail lanes)
+    __shared__ double2 sCS[4][EPW + 1][m];    // (c, s) of the current round by player
+    __shared__ double sL[4][EPW + 1][m];      // clamped eigenvalues
+    __shared__ double sR[4][64 + W];          // group sums
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g = lane / W, c = lane - g * W;
+    const int w = blockIdx.x * 4 + wave;
+    if (w * EPW >= n_list) return;  // (whole wavefront)
+    const int li = w * EPW + g;
+    const bool elem_ok = g < EPW && li < n_list;
+    const bool valid = elem_ok && c < n;  // this lane holds a column
+    const int e = elem_ok ? (int)list[li] : 0;
+    const size_t hs = (size_t)n_elem * 9;
+    const int bb = c / 3, jj = c - 3 * bb;
+    double* M = sM[wave][g];
+    double a[n], v[n];
+#pragma unroll
+    for (int i = 0; i < n; i++) {
+        const int ba = i / 3, ii = i - 3 * ba;
+        a[i] = valid ? elemH[(size_t)(ba * NB + bb) * hs + (size_t)e * 9 + ii * 3 + jj] : 0.0;
+        v[i] = i == c ? 1.0 : 0.0;
+    }
+    auto group_sum = [&](double x) {
+        sR[wave][lane] = x;
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; k++) sum += sR[wave][g * W + k];
+        return sum;
+    };
+    double fro = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; i++) fro += a[i] * a[i];
+    fro = group_sum(fro);
+    bool active = elem_ok;
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; i++) off += i == c ? 0.0 : a[i] * a[i];
+        off = group_sum(off);
+        if (off <= 1e-30 * fro) active = false;
+        if (__ballot(active) == 0ull) break;
+#pragma unroll 1
+        for (int r = 0; r < m - 1; r++) {
+            const int partner = rr_partner(m, r, c);
+            const int src = (g * W + partner) & 63;
+            const bool is_lo = c < partner;
+            // the three numbers of my pair's rotation: A[lo][lo], A[hi][hi], A[hi][lo] (the entry the lower lane holds)
+            const double d_own = pick<n>(a, c), x_own = pick<n>(a, partner);
+            const double d_oth = __shfl(d_own, src, 64), x_oth = __shfl(x_own, src, 64);
+            double cs = 1.0, sg = 0.0;  // my column <- cs * mine + sg * partner's
+            if (active && c < n && partner < n) {
+                const double app = is_lo ? d_own : d_oth, aqq = is_lo ? d_oth : d_own, apq = is_lo ? x_own : x_oth;
+                if (fabs(apq) > 1e-300) {
+                    const double theta = (aqq - app) / (2.0 * apq);
+                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    cs = 1.0 / sqrt(t * t + 1.0);
+                    const double sn = t * cs;
+                    sg = is_lo ? -sn : sn;  // new[lo] = cs old[lo] - sn old[hi];  new[hi] = sn old[lo] + cs old[hi]
+                }
+            }
+            sCS[wave][g][c] = make_double2(cs, sg);
+            // columns: A <- A J, V <- V J; the updated column of A goes to LDS row by row
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                a[i] = cs * a[i] + sg * __shfl(a[i], src, 64);
+                v[i] = cs * v[i] + sg * __shfl(v[i], src, 64);
+                M[i * W + c] = a[i];
+            }
+            // rows: A <- J^T A
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                const int pi = rr_partner(m, r, i);  // (uniform)
+                const double2 rot = sCS[wave][g][i];
+                const double y = pi < n ? M[pi * W + c] : 0.0;
+                a[i] = rot.x * a[i] + rot.y * y;
+            }
+        }
+    }
+    // eigenvalues = diag(A)
+    double l = pick<n>(a, c);
+    bool bad = false;
+    if (valid && l < eps) {
+        bad = true;
+        l = mirroring ? -l : eps;
+    }
+    const unsigned long long bad_mask = __ballot(bad);
+    const bool changed = elem_ok && ((bad_mask >> (g * W)) & ((1ull << W) - 1ull)) != 0ull;
+    if (changed && c == 0) atomicAdd((unsigned long long*)&counters[1], 1ull);
+    if (__ballot(changed) == 0ull) return;  // untouched, like the reference (project_to_PD.cpp:25-29)
+#pragma unroll
+    for (int i = 0; i < n; i++) M[i * W + c] = v[i];
+    sL[wave][g][c] = l;
+    unsigned long long rec_base = 0;
+    if (rec.pos) {
+        if (changed && c == 0) rec_base = atomicAdd(rec.count, (unsigned long long)nn);
+        const int first = (g * W) & 63;
+        rec_base = ((unsigned long long)(unsigned int)__shfl((int)(rec_base >> 32), first, 64) << 32) | (unsigned int)__shfl((int)rec_base, first, 64);
+    }
+    if (!(changed && valid)) return;
+    double wc[n];  // row c of V
+#pragma unroll
+    for (int k = 0; k < n; k++) wc[k] = M[c * W + k];
+#pragma unroll 1
+    for (int i = 0; i < n; i++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int k = 0; k < n; k++) acc = fma(M[i * W + k] * wc[k], sL[wave][g][k], acc);  // (V_ik V_ck) l_k: symmetric in (i, c) to the bit
+        const int ba = i / 3, ii = i - 3 * ba;
+        const size_t blk = (size_t)(ba * NB + bb) * n_elem + e;
+        double* dst = elemH + blk * 9 + ii * 3 + jj;
+        if (rec.pos) {
+            const unsigned long long k = rec_base + (unsigned long long)(i * n + c);
+            if (k < rec.cap) {
+                rec.pos[k] = rec.part_bit | (uint32_t)tile_val_index(slot_of_src[blk], ii * 3 + jj);
+                rec.val[k] = (float)(acc - *dst);
+            }
+        } else if (vals) {
+            atomicAdd(&vals[tile_val_index(slot_of_src[blk], ii * 3 + jj)], (float)(acc - *dst));
+        }
+        *dst = acc;
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restrict__ grad, int64_t nbr, double thr, uint8_t* __restrict__ active, int64_t* __restrict__ counters)
 {
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
@@ -1248,6 +1396,18 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         ProjRecords rec{};
         if (record) rec = ProjRecords{c.proj_rec_pos.p, c.proj_rec_val.p, (unsigned long long*)(c.counters.p + 3), rec_cap, P.part == 1 ? 0x80000000u : 0u};
         const dim3 g((nl + 3) / 4), b(BLOCK);
+        if (c.proj_variant == 0 && P.NB <= 6) {  // register-resident Jacobi, several elements per wavefront
+            auto grid = [&](int epw) { return dim3(((nl + epw - 1) / epw + 3) / 4); };
+            switch (P.NB) {
+                case 1: hipLaunchKernelGGL((k_project_eig_cols<1>), grid(16), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 2: hipLaunchKernelGGL((k_project_eig_cols<2>), grid(10), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 3: hipLaunchKernelGGL((k_project_eig_cols<3>), grid(6), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 4: hipLaunchKernelGGL((k_project_eig_cols<4>), grid(5), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 5: hipLaunchKernelGGL((k_project_eig_cols<5>), grid(4), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                default: hipLaunchKernelGGL((k_project_eig_cols<6>), grid(3), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            }
+            continue;
+        }
         switch (P.NB) {
             case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
             case 2: hipLaunchKernelGGL((k_project_eig<2>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;

@@ -64,6 +64,9 @@ FIXTURES = {
     # the reference's example hanging_deformable_box (examples/main.cpp:76-107): 12 k tets, 6 steps
     "traj_cfg_example_hanging_box": ("traj", "hangingbox", "n=10 steps=6 slim=1 threads=8"),
     "traj_cfg3_blockbox_10": ("traj", "blockbox", "nx=10 ny=10 nz=10 L=0.5 gap=0.002 thickness=0.002 bx=1.5 kmin=1e6 steps=4 boxfirst=1 slim=1 threads=8"),
+    # configs[4] at fixture size: tet block on a fixed floor + cloth over it + chain of 4 hinged boxes over the cloth, contact + friction
+    # between the layers (step log and final state)
+    "traj_cfg4_mixed_small": ("traj", "mixed", "nx=4 ny=4 nz=4 nc=10 nrb=4 L=0.4 gap=0.003 thickness=0.002 bx=1.2 kmin=1e6 link=0.04 steps=5 slim=1 threads=8"),
     # contact scenes (cfg 1 / cfg 4 at fixture size): cloth resting on a fixed rigid box, soft block pressed on a fixed rigid box
     "traj_clothbox_8": ("traj", "clothbox", "n=8 gap=0.004 steps=4"),
     "traj_blockbox_3": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=1"),

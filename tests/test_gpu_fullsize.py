@@ -128,3 +128,77 @@ def test_spmv_rows_longer_than_a_chunk(n_cloth):
     assert pinfo.converged
     assert np.linalg.norm(x - _bsr_matvec(row_ptr, cols, vals, du)) <= 1e-6 * np.linalg.norm(x)
     sim.close()
+
+
+def _step_and_check(sim, n_steps, expect_ndofs):
+    """A few whole time steps at full size: every step accepted, contact active, no edge-triangle intersection in the accepted
+    state, finite state; returns Newton iterations and wall time (reported by -s / tools, not asserted)."""
+    import time
+
+    t0 = time.perf_counter()
+    for _ in range(n_steps):
+        assert sim.run_one_step()
+    wall = time.perf_counter() - t0
+    info = sim.info()
+    assert info.ndofs == expect_ndofs
+    ci = sim.contact_info()
+    assert ci["n_contacts"] > 0
+    eng = _Eng(sim)
+    eng.contact_update(info.dt)
+    assert eng.contact_count_intersections(info.dt) == 0
+    x = sim.points("x0")
+    assert np.isfinite(x).all()
+    return info.total_newton_iterations, wall, ci
+
+
+def test_full_size_cloth_on_floor():
+    """BASELINE configs[2]: 256 x 256 Cotton_Fabric cloth (discrete-shell bending off: the preset's flat bending) dropped on a fixed
+    floor box with IPC contact + friction: 198 153 DoF."""
+    from stark_amd import sim as S
+
+    st = S.default_settings()
+    st.mirror_state_to_host = 0
+    st.init_frictional_contact = 1
+    sim = S.Simulation(st)
+    gp = S.contact_global_params()
+    gp.default_contact_thickness = 1e-3
+    sim.set_contact_global_params(gp)
+    floor = sim.add_rigid_box("floor", 1.0, (2.0, 2.0, 0.1))
+    sim.rb_add_constraint("fix", floor)
+    cloth = sim.add_surface_grid("cloth", (1.0, 1.0), (256, 256), S.cotton_fabric())
+    sim.point_set_add_displacement(cloth, (0.0, 0.0, 0.05 + 0.0015))
+    sim.set_friction(sim.contact_group("rb", floor), sim.contact_group("d", cloth), 0.5)
+    its, wall, ci = _step_and_check(sim, 8, 3 * 257 * 257 + 6)
+    x = sim.points("x0")
+    assert x[:, 2].min() > 0.05                      # nothing went through the floor's top face
+    assert ci["n_friction_contacts"] > 0
+    print("configs[2]: %d Newton iterations in %.3f s (8 steps) = %.1f Newton-steps/s" % (its, wall, its / wall))
+    sim.close()
+
+
+def test_full_size_mixed_scene():
+    """BASELINE configs[4]: 202 800-tet Soft_Rubber block on a fixed floor + 128 x 128 cloth over it + a chain of 16 boxes joined by
+    hinges (first link fixed) over the cloth; contact and friction between the layers (oracle/ref_harness.cpp scene_mixed)."""
+    from stark_amd import sim as S
+    from test_gpu_scene import _build_mixed
+
+    st = S.default_settings()
+    st.mirror_state_to_host = 0
+    st.init_frictional_contact = 1
+    sim = S.Simulation(st)
+    gp = S.contact_global_params()
+    gp.default_contact_thickness = 1e-3
+    gp.min_contact_stiffness = 1e8
+    sim.set_contact_global_params(gp)
+    sc = dict(nx=26, ny=26, nz=25, nc=128, nrb=16, L=1.0, gap=0.0015, bx=3.0, bz=0.1, link=0.05, cloth=1.2, mu=0.5)
+    floor, links, block, cloth = _build_mixed(S, sim, sc)
+    n_nodes = 27 * 27 * 26 + 26 * 26 * 25 + 129 * 129
+    its, wall, ci = _step_and_check(sim, 3, 3 * n_nodes + 6 * 17)
+    # the fixed first link stayed where it was, the hinges hold the chain together (1 mm default tolerance of the constraints)
+    t0 = np.array(sim.rb_state(links[0])[0])
+    assert np.abs(t0 - np.array([-0.5 * 15 * 0.075, 0.0, 0.05 + 0.0015 + 1.0 + 0.0015 + 0.0015 + 0.025])).max() < 2e-3
+    for a, b in zip(links[:-1], links[1:]):
+        d = np.linalg.norm(np.array(sim.rb_state(a)[0]) - np.array(sim.rb_state(b)[0]))
+        assert abs(d - 0.075) < 5e-3
+    print("configs[4]: %d Newton iterations in %.3f s (3 steps) = %.1f Newton-steps/s" % (its, wall, its / wall))
+    sim.close()
