@@ -209,7 +209,7 @@ struct Context
     BsrPart part[2];
     DevBuf<int32_t> diag_slot[2];   // per block row: slot of the diagonal block in each part, -1 if absent
     int spmv_variant = 0;          // micro-benchmark ablation variant
-    int proj_variant = 0;          // 0 = PSD projection with the matrix in registers (k_project_eig_cols), 1 = in LDS (k_project_eig)
+    int proj_variant = 0;          // PSD projection, bits: 1 = matrix in LDS (k_project_eig) instead of registers, 2 = no batching of short lists, 4 = IEEE div/sqrt
     long long proj_rec_cap = 0;    // tuning / tests: records per rank of the sharded projection exchange (0 = default)
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather

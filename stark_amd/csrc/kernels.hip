@@ -1124,17 +1124,22 @@ __device__ __forceinline__ double pick(const double (&x)[n], int idx)
 // partner of player i in round r of the round-robin schedule of m players (k_project_eig: pairs (m-1, r), ((r+k) % (m-1), (r-k) % (m-1)))
 __device__ __forceinline__ int rr_partner(int m, int r, int i) { return i == m - 1 ? r : (i == r ? m - 1 : (2 * r - i + 2 * (m - 1)) % (m - 1)); }
 template <int NB>
-__global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__ elemH, int n_elem, const uint32_t* __restrict__ list, int n_list, double eps, int mirroring,
-                                                            const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters, ProjRecords rec)
+struct ProjWaveShared  // LDS of ONE wavefront (waves of a block may work on different potentials, even different NB)
+{
+    static constexpr int n = 3 * NB, m = (n + 1) & ~1, W = m, EPW = 64 / W;
+    double M[EPW + 1][m * W];   // [row][column] of the element of a group: row exchange; eigenvectors for the rebuild (+1: idle tail lanes)
+    double2 CS[EPW + 1][m];     // (c, s) of the current round by player
+    double L[EPW + 1][m];       // clamped eigenvalues
+    double R[64 + W];           // group sums
+};
+// w = index of this wavefront within the list (EPW elements each)
+template <int NB>
+__device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, double* __restrict__ elemH, int n_elem, const uint32_t* __restrict__ list, int n_list, double eps,
+                                                  int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters, const ProjRecords& rec)
 {
     constexpr int n = 3 * NB, nn = n * n, m = (n + 1) & ~1, W = m, EPW = 64 / W;
-    __shared__ double sM[4][EPW + 1][m * W];  // [row][column] of the element of a group: row exchange; eigenvectors for the rebuild (+1: idle tail lanes)
-    __shared__ double2 sCS[4][EPW + 1][m];    // (c, s) of the current round by player
-    __shared__ double sL[4][EPW + 1][m];      // clamped eigenvalues
-    __shared__ double sR[4][64 + W];          // group sums
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
     const int g = lane / W, c = lane - g * W;
-    const int w = blockIdx.x * 4 + wave;
     if (w * EPW >= n_list) return;  // (whole wavefront)
     const int li = w * EPW + g;
     const bool elem_ok = g < EPW && li < n_list;
@@ -1142,7 +1147,7 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__
     const int e = elem_ok ? (int)list[li] : 0;
     const size_t hs = (size_t)n_elem * 9;
     const int bb = c / 3, jj = c - 3 * bb;
-    double* M = sM[wave][g];
+    double* M = S.M[g];
     double a[n], v[n];
 #pragma unroll
     for (int i = 0; i < n; i++) {
@@ -1151,10 +1156,10 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__
         v[i] = i == c ? 1.0 : 0.0;
     }
     auto group_sum = [&](double x) {
-        sR[wave][lane] = x;
+        S.R[lane] = x;
         double sum = 0.0;
 #pragma unroll
-        for (int k = 0; k < W; k++) sum += sR[wave][g * W + k];
+        for (int k = 0; k < W; k++) sum += S.R[g * W + k];
         return sum;
     };
     double fro = 0.0;
@@ -1162,6 +1167,21 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__
     for (int i = 0; i < n; i++) fro += a[i] * a[i];
     fro = group_sum(fro);
     bool active = elem_ok;
+    // 1 / sqrt(x) to double precision from the hardware estimate and two Newton steps (a rotation only has to be orthogonal to rounding,
+    // c^2 + s^2 = 1; its angle may be a few ulps off the ideal one: that costs nothing, the sweeps iterate anyway)
+    auto rsqrt_nr = [](double x) {
+        double y = __builtin_amdgcn_rsq(x);
+        y = y * (1.5 - 0.5 * x * y * y);
+        return y * (1.5 - 0.5 * x * y * y);
+    };
+    auto rcp_nr = [](double x) {
+        const double y = __builtin_amdgcn_rcp(x);
+        return fma(y, fma(-x, y, 1.0), y);
+    };
+    auto shfl64 = [](double x, int addr) {  // addr = 4 * source lane
+        const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x)), hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
+        return __hiloint2double(hi, lo);
+    };
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0.0;
 #pragma unroll
@@ -1169,38 +1189,57 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__
         off = group_sum(off);
         if (off <= 1e-30 * fro) active = false;
         if (__ballot(active) == 0ull) break;
+        int pr[n];  // (2 r - i) mod (m - 1) of the rows, advanced by 2 per round (uniform values: scalar registers)
+#pragma unroll
+        for (int i = 0; i < n; i++) pr[i] = (2 * (m - 1) - i) % (m - 1);
 #pragma unroll 1
         for (int r = 0; r < m - 1; r++) {
             const int partner = rr_partner(m, r, c);
-            const int src = (g * W + partner) & 63;
+            const int src = ((g * W + partner) & 63) << 2;
             const bool is_lo = c < partner;
             // the three numbers of my pair's rotation: A[lo][lo], A[hi][hi], A[hi][lo] (the entry the lower lane holds)
             const double d_own = pick<n>(a, c), x_own = pick<n>(a, partner);
-            const double d_oth = __shfl(d_own, src, 64), x_oth = __shfl(x_own, src, 64);
+            const double d_oth = shfl64(d_own, src), x_oth = shfl64(x_own, src);
             double cs = 1.0, sg = 0.0;  // my column <- cs * mine + sg * partner's
             if (active && c < n && partner < n) {
                 const double app = is_lo ? d_own : d_oth, aqq = is_lo ? d_oth : d_own, apq = is_lo ? x_own : x_oth;
                 if (fabs(apq) > 1e-300) {
-                    const double theta = (aqq - app) / (2.0 * apq);
-                    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                    cs = 1.0 / sqrt(t * t + 1.0);
+                    // tan of the rotation angle from the hardware reciprocal / reciprocal-square-root estimates + one Newton step each
+                    // (the IEEE division and square root sequences, with their scaling and fix-up code, were the longest dependent chain
+                    // of a round; a rotation only has to be orthogonal to rounding, which cs below takes care of)
+                    if (mirroring & 2) {
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        cs = 1.0 / sqrt(t * t + 1.0);
+                        const double sn = t * cs;
+                        sg = is_lo ? -sn : sn;
+                    } else {
+                    const double theta = (aqq - app) * rcp_nr(2.0 * apq);
+                    const double s2 = fma(theta, theta, 1.0);
+                    double y = __builtin_amdgcn_rsq(s2);
+                    y = y * (1.5 - 0.5 * s2 * y * y);
+                    const double root = s2 < 1e300 ? s2 * y : fabs(theta);
+                    const double t = copysign(rcp_nr(fabs(theta) + root), theta);
+                    cs = rsqrt_nr(t * t + 1.0);
                     const double sn = t * cs;
                     sg = is_lo ? -sn : sn;  // new[lo] = cs old[lo] - sn old[hi];  new[hi] = sn old[lo] + cs old[hi]
+                    }
                 }
             }
-            sCS[wave][g][c] = make_double2(cs, sg);
+            S.CS[g][c] = make_double2(cs, sg);
             // columns: A <- A J, V <- V J; the updated column of A goes to LDS row by row
 #pragma unroll
             for (int i = 0; i < n; i++) {
-                a[i] = cs * a[i] + sg * __shfl(a[i], src, 64);
-                v[i] = cs * v[i] + sg * __shfl(v[i], src, 64);
+                a[i] = cs * a[i] + sg * shfl64(a[i], src);
+                v[i] = cs * v[i] + sg * shfl64(v[i], src);
                 M[i * W + c] = a[i];
             }
             // rows: A <- J^T A
 #pragma unroll
             for (int i = 0; i < n; i++) {
-                const int pi = rr_partner(m, r, i);  // (uniform)
-                const double2 rot = sCS[wave][g][i];
+                const int pi = i == m - 1 ? r : (pr[i] == i ? m - 1 : pr[i]);  // = rr_partner(m, r, i)
+                pr[i] = pr[i] + 2 >= m - 1 ? pr[i] + 2 - (m - 1) : pr[i] + 2;
+                const double2 rot = S.CS[g][i];
                 const double y = pi < n ? M[pi * W + c] : 0.0;
                 a[i] = rot.x * a[i] + rot.y * y;
             }
@@ -1211,7 +1250,7 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__
     bool bad = false;
     if (valid && l < eps) {
         bad = true;
-        l = mirroring ? -l : eps;
+        l = (mirroring & 1) ? -l : eps;
     }
     const unsigned long long bad_mask = __ballot(bad);
     const bool changed = elem_ok && ((bad_mask >> (g * W)) & ((1ull << W) - 1ull)) != 0ull;
@@ -1219,7 +1258,7 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__
     if (__ballot(changed) == 0ull) return;  // untouched, like the reference (project_to_PD.cpp:25-29)
 #pragma unroll
     for (int i = 0; i < n; i++) M[i * W + c] = v[i];
-    sL[wave][g][c] = l;
+    S.L[g][c] = l;
     unsigned long long rec_base = 0;
     if (rec.pos) {
         if (changed && c == 0) rec_base = atomicAdd(rec.count, (unsigned long long)nn);
@@ -1234,7 +1273,7 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__
     for (int i = 0; i < n; i++) {
         double acc = 0.0;
 #pragma unroll
-        for (int k = 0; k < n; k++) acc = fma(M[i * W + k] * wc[k], sL[wave][g][k], acc);  // (V_ik V_ck) l_k: symmetric in (i, c) to the bit
+        for (int k = 0; k < n; k++) acc = fma(M[i * W + k] * wc[k], S.L[g][k], acc);  // (V_ik V_ck) l_k: symmetric in (i, c) to the bit
         const int ba = i / 3, ii = i - 3 * ba;
         const size_t blk = (size_t)(ba * NB + bb) * n_elem + e;
         double* dst = elemH + blk * 9 + ii * 3 + jj;
@@ -1248,6 +1287,62 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__
             atomicAdd(&vals[tile_val_index(slot_of_src[blk], ii * 3 + jj)], (float)(acc - *dst));
         }
         *dst = acc;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__ elemH, int n_elem, const uint32_t* __restrict__ list, int n_list, double eps, int mirroring,
+                                                            const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters, ProjRecords rec)
+{
+    __shared__ ProjWaveShared<NB> S[4];
+    const int wave = threadIdx.x >> 6;
+    project_cols_body<NB>(S[wave], blockIdx.x * 4 + wave, elemH, n_elem, list, n_list, eps, mirroring, slot_of_src, vals, counters, rec);
+}
+// The short lists of one projection round (contact kinds with a few dozen rows, the rigid-body potentials, ...) in ONE launch: a lone
+// wavefront needs 100-300 us for its elements whatever their number (≈ 90 dependent rotation rounds), a dozen such launches in a row is
+// where the time of a round went. Every wavefront looks up the potential it works for.
+struct ProjDesc
+{
+    double* H;
+    const uint32_t* list;
+    const uint32_t* sos;
+    float* vals;
+    int n_elem, nl, NB, first_wave;
+    uint32_t part_bit;
+};
+constexpr int PROJ_BATCH = 40;
+struct ProjBatch
+{
+    ProjDesc d[PROJ_BATCH];
+    int n;
+};
+union ProjWaveSharedAny
+{
+    ProjWaveShared<1> s1;
+    ProjWaveShared<2> s2;
+    ProjWaveShared<3> s3;
+    ProjWaveShared<4> s4;
+    ProjWaveShared<5> s5;
+    ProjWaveShared<6> s6;
+    __device__ ProjWaveSharedAny() {}
+};
+__global__ __launch_bounds__(BLOCK) void k_project_eig_multi(ProjBatch B, double eps, int mirroring, int64_t* __restrict__ counters, ProjRecords rec)
+{
+    __shared__ ProjWaveSharedAny S[4];
+    const int wave = threadIdx.x >> 6;
+    const int gw = blockIdx.x * 4 + wave;
+    int k = 0;
+    while (k + 1 < B.n && gw >= B.d[k + 1].first_wave) k++;
+    const ProjDesc& D = B.d[k];
+    rec.part_bit = D.part_bit;
+    const int w = gw - D.first_wave;
+    switch (D.NB) {
+        case 1: project_cols_body<1>(S[wave].s1, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        case 2: project_cols_body<2>(S[wave].s2, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        case 3: project_cols_body<3>(S[wave].s3, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        case 4: project_cols_body<4>(S[wave].s4, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        case 5: project_cols_body<5>(S[wave].s5, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        default: project_cols_body<6>(S[wave].s6, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
     }
 }
 
@@ -1384,11 +1479,24 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         c.proj_rec_val.ensure(PROJ_REC_CAP);
     }
     int64_t total = 0;
+    if (c.proj_variant & 4) mirroring |= 2;
+    constexpr int SHORT_LIST = 4096;  // lists up to this length share one launch (k_project_eig_multi)
+    ProjBatch batch;
+    batch.n = 0;
+    int batch_waves = 0;
+    ProjRecords batch_rec{};
+    auto flush = [&]() {
+        if (batch.n == 0) return;
+        hipLaunchKernelGGL(k_project_eig_multi, dim3((batch_waves + 3) / 4), dim3(BLOCK), 0, c.stream, batch, eps, mirroring, c.counters.p, batch_rec);
+        batch.n = 0;
+        batch_waves = 0;
+    };
     for (int pi = 0; pi < np; pi++) {
         Potential& P = c.pots[pi];
         const int nl = (int)h[4 + pi];
         if (nl == 0) continue;
         total += nl;
+        hipStream_t stream = c.stream;
         double* H = c.elemH.p + P.h_off;
         const uint32_t* list = c.proj_list.p + P.e_off;
         const uint32_t* sos = c.part[P.part].slot_of_src.p + (P.k_off - c.part[P.part].blk_base);
@@ -1396,30 +1504,39 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         ProjRecords rec{};
         if (record) rec = ProjRecords{c.proj_rec_pos.p, c.proj_rec_val.p, (unsigned long long*)(c.counters.p + 3), rec_cap, P.part == 1 ? 0x80000000u : 0u};
         const dim3 g((nl + 3) / 4), b(BLOCK);
-        if (c.proj_variant == 0 && P.NB <= 6) {  // register-resident Jacobi, several elements per wavefront
-            auto grid = [&](int epw) { return dim3(((nl + epw - 1) / epw + 3) / 4); };
+        if (!(c.proj_variant & 1) && P.NB <= 6) {  // register-resident Jacobi, several elements per wavefront
+            const int epw = 64 / ((3 * P.NB + 1) & ~1);
+            if (nl <= SHORT_LIST && !(c.proj_variant & 2)) {
+                if (batch.n == PROJ_BATCH) flush();
+                batch.d[batch.n++] = ProjDesc{H, list, sos, vals, P.n_elem, nl, P.NB, batch_waves, rec.part_bit};
+                batch_waves += (nl + epw - 1) / epw;
+                batch_rec = rec;
+                continue;
+            }
+            const dim3 grid(((nl + epw - 1) / epw + 3) / 4);
             switch (P.NB) {
-                case 1: hipLaunchKernelGGL((k_project_eig_cols<1>), grid(16), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 2: hipLaunchKernelGGL((k_project_eig_cols<2>), grid(10), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 3: hipLaunchKernelGGL((k_project_eig_cols<3>), grid(6), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 4: hipLaunchKernelGGL((k_project_eig_cols<4>), grid(5), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 5: hipLaunchKernelGGL((k_project_eig_cols<5>), grid(4), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                default: hipLaunchKernelGGL((k_project_eig_cols<6>), grid(3), b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 1: hipLaunchKernelGGL((k_project_eig_cols<1>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 2: hipLaunchKernelGGL((k_project_eig_cols<2>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 3: hipLaunchKernelGGL((k_project_eig_cols<3>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 4: hipLaunchKernelGGL((k_project_eig_cols<4>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 5: hipLaunchKernelGGL((k_project_eig_cols<5>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                default: hipLaunchKernelGGL((k_project_eig_cols<6>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
             }
             continue;
         }
         switch (P.NB) {
-            case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 2: hipLaunchKernelGGL((k_project_eig<2>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 3: hipLaunchKernelGGL((k_project_eig<3>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 4: hipLaunchKernelGGL((k_project_eig<4>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 5: hipLaunchKernelGGL((k_project_eig<5>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 6: hipLaunchKernelGGL((k_project_eig<6>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 7: hipLaunchKernelGGL((k_project_eig<7>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 8: hipLaunchKernelGGL((k_project_eig<8>), g, b, 0, c.stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 2: hipLaunchKernelGGL((k_project_eig<2>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 3: hipLaunchKernelGGL((k_project_eig<3>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 4: hipLaunchKernelGGL((k_project_eig<4>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 5: hipLaunchKernelGGL((k_project_eig<5>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 6: hipLaunchKernelGGL((k_project_eig<6>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 7: hipLaunchKernelGGL((k_project_eig<7>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 8: hipLaunchKernelGGL((k_project_eig<8>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
             default: throw Error("project: unsupported block count");
         }
     }
+    flush();
     c.n_projected_total += total;
     if (c.world > 1) exchange_projection_deltas(c, record, total);
     if (n_projected_now) *n_projected_now = total;
