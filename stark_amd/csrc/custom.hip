@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) void k_eval_custom(PotArgs a, ProgDev p, doubl
     }
     if (MODE >= 1 && i == j && on) {
         const int ba = i / 3, ii = i - 3 * ba;
-        const int row = a.dof_row_off[ba] + a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];
-        atomicAdd(&grad[3 * (size_t)row + ii], r.a);
+        const int node = a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];
+        if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);  // (k_eval_pgh)
+        else atomicAdd(&grad[3 * (size_t)(a.dof_row_off[ba] + node) + ii], r.a);
     }
     if (first) elemE[e] = r.v;
 }

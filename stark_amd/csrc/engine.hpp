@@ -89,7 +89,15 @@ struct PotArgs
     int e_begin, e_count;     // this rank's contiguous element range (multi-GPU sharding; the whole table on one GPU)
     int dof_col[MAX_NB];      // connectivity column providing the node of local DoF block k
     int dof_row_off[MAX_NB];  // first block row of the DoF set of local DoF block k
+    // Gradient rows of SMALL DoF sets (a handful of rigid bodies touched by tens of thousands of contacts) are not accumulated in place:
+    // 68 k atomics on the same six addresses serialise (1.6 ms per contact kind on configs[2]). Their contributions go to one of
+    // HOT_WAYS copies chosen by the workgroup index and are folded into the gradient after the last potential (k_fold_hot).
+    int hot_base[MAX_NB];     // index of the set's first row among the hot rows, -1: accumulate in place
+    double* grad_hot;         // [HOT_WAYS][n_hot][3]
+    int n_hot;
 };
+constexpr int HOT_WAYS = 64;
+constexpr int64_t HOT_SET_ROWS = 1024;  // DoF sets up to this many block rows take the hot path
 
 struct DofSet
 {
@@ -154,6 +162,8 @@ struct BsrPart
     DevBuf<float> vals;             // tiles of 64 blocks: float4 q0[64], float4 q1[64], float s[64]
     DevBuf<uint32_t> long_slots;    // blocks with > LONG_SLOT contributions (summed by k_assemble_long)
     int n_long = 0;
+    DevBuf<uint32_t> vlong_slots;   // blocks with > VERY_LONG_SLOT contributions (k_assemble_vlong_part / _fold)
+    int n_vlong = 0;
     // contact part only: rows cut into chunks for k_spmv_chunks
     int64_t n_chunks = 0;
     DevBuf<uint32_t> row_chunk0;    // per compact row (+1): first chunk
@@ -209,6 +219,10 @@ struct Context
     BsrPart part[2];
     DevBuf<int32_t> diag_slot[2];   // per block row: slot of the diagonal block in each part, -1 if absent
     int spmv_variant = 0;          // micro-benchmark ablation variant
+    DevBuf<double> vlong_part;
+    DevBuf<double> grad_hot;
+    DevBuf<int32_t> hot_rows;      // global block row of every hot row
+    int n_hot = 0;
     int proj_variant = 0;          // PSD projection, bits: 1 = matrix in LDS (k_project_eig) instead of registers, 2 = no batching of short lists, 4 = IEEE div/sqrt
     long long proj_rec_cap = 0;    // tuning / tests: records per rank of the sharded projection exchange (0 = default)
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)

@@ -141,10 +141,21 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
         elemH[((size_t)(bb * NB + ba) * a.n_elem + e) * 9 + jj * 3 + ii] = r.ab;
     }
     if (i == j && on) {
-        const int row = a.dof_row_off[ba] + a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];
-        atomicAdd(&grad[3 * (size_t)row + ii], r.a);
+        const int node = a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];
+        if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);
+        else atomicAdd(&grad[3 * (size_t)(a.dof_row_off[ba] + node) + ii], r.a);
     }
     if (first) elemE[e] = r.v;
+}
+// hot rows: the HOT_WAYS partial sums in fixed order, added to what the in-place accumulating kernels (closed-form tets) left there
+__global__ __launch_bounds__(BLOCK) void k_fold_hot(const double* __restrict__ grad_hot, const int32_t* __restrict__ hot_rows, int n_hot, double* __restrict__ grad)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= 3 * n_hot) return;
+    double acc = 0.0;
+    for (int w = 0; w < HOT_WAYS; w++) acc += grad_hot[(size_t)w * 3 * n_hot + t];
+    const int r = t / 3;
+    grad[3 * (size_t)hot_rows[r] + (t - 3 * r)] += acc;
 }
 
 // Closed-form tet kernels (tet_closed.hpp): one lane per tet, 12 gradient atomics. The 16 Hessian blocks of a tet belong to 16 pools
@@ -552,11 +563,16 @@ __global__ __launch_bounds__(BLOCK) void k_chunk_fill(const int64_t* __restrict_
     for (uint32_t k = row_chunk0[r]; k < row_chunk0[r + 1]; k++) chunk_row[k] = (int32_t)r;
 }
 constexpr uint32_t LONG_SLOT = 48;  // BSR blocks with more contributions than this are summed by a whole wavefront (k_assemble_long)
-__global__ __launch_bounds__(BLOCK) void k_long_slots(const uint32_t* __restrict__ slot_start, int64_t nnzb, uint32_t* __restrict__ list, int* __restrict__ count)
+constexpr uint32_t VERY_LONG_SLOT = 4096;  // ... and beyond this by VLONG_SPLIT wavefronts and a second pass (the blocks of a rigid body under 10^4..10^5 contacts)
+constexpr int VLONG_SPLIT = 64;
+__global__ __launch_bounds__(BLOCK) void k_long_slots(const uint32_t* __restrict__ slot_start, int64_t nnzb, uint32_t* __restrict__ list, uint32_t* __restrict__ vlist,
+                                                     int* __restrict__ count)
 {
     const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (s >= nnzb) return;
-    if (slot_start[s + 1] - slot_start[s] > LONG_SLOT) list[atomicAdd(count, 1)] = (uint32_t)s;
+    const uint32_t len = slot_start[s + 1] - slot_start[s];
+    if (len > VERY_LONG_SLOT) vlist[atomicAdd(count + 1, 1)] = (uint32_t)s;
+    else if (len > LONG_SLOT) list[atomicAdd(count, 1)] = (uint32_t)s;
 }
 // ---- storage of the static part: CSR order cut into row-aligned chunks -----------------------------------------------------------------
 // The blocks stay in CSR order (the lanes of a tile gather neighbouring columns of the same row: few cache lines), but padding blocks
@@ -735,8 +751,9 @@ static void build_pattern(Context& c, int part)
     m.long_slots.ensure((size_t)m.nnzb);
     c.counters.ensure(128);
     MS_CHECK(hipMemsetAsync(c.counters.p, 0, sizeof(int64_t), c.stream));
-    hipLaunchKernelGGL(k_long_slots, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_start.p, m.nnzb, m.long_slots.p, (int*)c.counters.p);
-    int n_long_h = 0;
+    m.vlong_slots.ensure((size_t)nk / VERY_LONG_SLOT + 64);  // (a pattern of nk contributions holds at most nk / VERY_LONG_SLOT of them)
+    hipLaunchKernelGGL(k_long_slots, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_start.p, m.nnzb, m.long_slots.p, m.vlong_slots.p, (int*)c.counters.p);
+    int n_long_h[2] = {0, 0};
     // compact rows
     uint32_t* rscan = m.scan.p;  // (scan is dead after k_slots)
     size_t tmp3 = 0;
@@ -745,9 +762,10 @@ static void build_pattern(Context& c, int part)
     MS_CHECK(hipcub::DeviceScan::InclusiveSum(c.cub_tmp.p, tmp3, row_head, rscan, (int)m.nnzb, c.stream));
     uint32_t nrows32 = 0;
     fetch(c, &nrows32, rscan + (m.nnzb - 1), sizeof(uint32_t));
-    fetch(c, &n_long_h, c.counters.p, sizeof(int));
+    fetch(c, n_long_h, c.counters.p, 2 * sizeof(int));
     m.n_rows = nrows32;
-    m.n_long = n_long_h;
+    m.n_long = n_long_h[0];
+    m.n_vlong = n_long_h[1];
     m.rowmap.ensure((size_t)m.n_rows);
     m.row_ptr.ensure((size_t)m.n_rows + 1);
     hipLaunchKernelGGL(k_rows, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_row.p, rscan, m.nnzb, m.rowmap.p, m.row_ptr.p, m.tile_first_row.p, m.colw.p);
@@ -803,6 +821,24 @@ void prepare(Context& c)
                 if (s.n > 0) MS_CHECK(hipMemcpyAsync(c.u.p + s.offset, s.host, s.n * sizeof(double), hipMemcpyHostToDevice, c.stream));
             c.part[0].dirty = c.part[1].dirty = true;
         }
+        // hot rows (PotArgs::hot_base): the rows of the small DoF sets
+        std::vector<int> hot_base_of_set(c.dof_sets.size(), -1);
+        {
+            std::vector<int32_t> hot_rows;
+            for (size_t k = 0; k < c.dof_sets.size(); k++) {
+                const int64_t rows = c.dof_sets[k].n / 3;
+                if (rows == 0 || rows > HOT_SET_ROWS) continue;
+                hot_base_of_set[k] = (int)hot_rows.size();
+                for (int64_t r = 0; r < rows; r++) hot_rows.push_back((int32_t)(c.dof_sets[k].offset / 3 + r));
+            }
+            c.n_hot = (int)hot_rows.size();
+            c.hot_rows.ensure(std::max<size_t>(hot_rows.size(), 1));
+            c.grad_hot.ensure(std::max<size_t>((size_t)HOT_WAYS * 3 * hot_rows.size(), 1));
+            if (!hot_rows.empty()) {
+                MS_CHECK(hipMemcpyAsync(c.hot_rows.p, hot_rows.data(), hot_rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+                MS_CHECK(hipStreamSynchronize(c.stream));  // (hot_rows is a local)
+            }
+        }
         // arrays
         for (auto& a : c.arrays) {
             if (a.dof_set >= 0) {
@@ -853,6 +889,9 @@ void prepare(Context& c)
                 A.arr[b] = arr.dev;
                 A.conn_col[b] = P.bindings[b].conn_col;
             }
+            A.grad_hot = c.grad_hot.p;
+            A.n_hot = c.n_hot;
+            for (int k = 0; k < MAX_NB; k++) A.hot_base[k] = -1;
             // local DoF blocks: DoF sets in registration order, then binding order (SecondOrderCompiledPotential.cpp:10-33)
             int nblk = 0;
             for (int set = 0; set < (int)c.dof_sets.size(); set++)
@@ -862,6 +901,7 @@ void prepare(Context& c)
                     if (nblk >= P.NB) throw Error("potential '" + P.name + "': more DoF bindings than the kernel's " + std::to_string(P.NB) + " blocks");
                     A.dof_col[nblk] = P.bindings[b].conn_col;
                     A.dof_row_off[nblk] = (int)(c.dof_sets[set].offset / 3);
+                    A.hot_base[nblk] = hot_base_of_set[set];
                     nblk++;
                 }
             if (nblk != P.NB) throw Error("potential '" + P.name + "': expected " + std::to_string(P.NB) + " DoF bindings, got " + std::to_string(nblk));
@@ -894,8 +934,13 @@ void ensure_pattern(Context& c)
 void eval(Context& c, int mode, double* E, double* grad_host)
 {
     prepare(c);
-    if (mode != MISTARK_EVAL_P) MS_CHECK(hipMemsetAsync(c.grad.p, 0, (size_t)c.ndofs * sizeof(double), c.stream));
+    if (mode != MISTARK_EVAL_P) {
+        MS_CHECK(hipMemsetAsync(c.grad.p, 0, (size_t)c.ndofs * sizeof(double), c.stream));
+        if (c.n_hot > 0) MS_CHECK(hipMemsetAsync(c.grad_hot.p, 0, (size_t)HOT_WAYS * 3 * c.n_hot * sizeof(double), c.stream));
+    }
     for (auto& P : c.pots) launch_eval_kind(c, P, mode);
+    if (mode != MISTARK_EVAL_P && c.n_hot > 0)
+        hipLaunchKernelGGL(k_fold_hot, dim3(grid_for(3 * (int64_t)c.n_hot)), dim3(BLOCK), 0, c.stream, (const double*)c.grad_hot.p, (const int32_t*)c.hot_rows.p, c.n_hot, c.grad.p);
     if (mode == MISTARK_EVAL_P_G_H) {
         MS_CHECK(hipMemsetAsync(c.is_projected.p, 0, c.n_elem_total, c.stream));
         c.have_hessians = true;
@@ -1625,6 +1670,48 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_long(const double* __restric
         if (lane == 0) vals[tile_val_index(store_slot ? store_slot[slot] : slot, c)] = (float)v;
     }
 }
+// very long blocks: VLONG_SPLIT wavefronts per block sum contiguous ranges of its contribution list, a second pass adds the partial sums in
+// range order (deterministic like the one-wavefront version, 64 times the parallelism: 2.2 ms -> tens of us for the four diagonal blocks
+// of a floor under 136 k contact and friction rows)
+__global__ __launch_bounds__(BLOCK) void k_assemble_vlong_part(const double* __restrict__ elemH, const uint32_t* __restrict__ slot_start, const uint32_t* __restrict__ sorted_src,
+                                                              const uint32_t* __restrict__ list, int n_vlong, double* __restrict__ part)
+{
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n_vlong * VLONG_SPLIT) return;
+    const int lane = threadIdx.x & 63;
+    const int b = w / VLONG_SPLIT, j = w - b * VLONG_SPLIT;
+    const uint32_t slot = list[b];
+    const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1];
+    const uint32_t chunk = (k1 - k0 + VLONG_SPLIT - 1) / VLONG_SPLIT;
+    const uint32_t c0 = k0 + (uint32_t)j * chunk, c1 = min(k1, c0 + chunk);
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t k = c0 + lane; k < c1; k += 64) {
+        const uint32_t src = sorted_src[k];
+        if (src == NO_SRC) continue;
+        const double* h = elemH + (size_t)src * 9;
+#pragma unroll
+        for (int c = 0; c < 9; c++) acc[c] += h[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const double v = wave_sum(acc[c]);
+        if (lane == 0) part[(size_t)w * 9 + c] = v;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_assemble_vlong_fold(const double* __restrict__ part, const uint32_t* __restrict__ list, int n_vlong, const uint32_t* __restrict__ store_slot,
+                                                              float* __restrict__ vals)
+{
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n_vlong) return;
+    const int lane = threadIdx.x & 63;
+    static_assert(VLONG_SPLIT == 64, "one lane per partial sum");
+    const uint32_t slot = list[b];
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const double v = wave_sum(part[((size_t)b * VLONG_SPLIT + lane) * 9 + c]);
+        if (lane == 0) vals[tile_val_index(store_slot ? store_slot[slot] : slot, c)] = (float)v;
+    }
+}
 __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restrict__ elemH, const uint32_t* __restrict__ slot_start,
                                                            const uint32_t* __restrict__ sorted_src, int64_t nnzb, const uint32_t* __restrict__ store_slot, float* __restrict__ vals)
 {
@@ -1669,6 +1756,12 @@ void assemble(Context& c)
             hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.nnzb, store, m.vals.p);
             if (m.n_long > 0)
                 hipLaunchKernelGGL(k_assemble_long, dim3((m.n_long + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.long_slots.p, m.n_long, store, m.vals.p);
+            if (m.n_vlong > 0) {
+                c.vlong_part.ensure((size_t)m.n_vlong * VLONG_SPLIT * 9);
+                hipLaunchKernelGGL(k_assemble_vlong_part, dim3((m.n_vlong * VLONG_SPLIT + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.vlong_slots.p,
+                                   m.n_vlong, c.vlong_part.p);
+                hipLaunchKernelGGL(k_assemble_vlong_fold, dim3((m.n_vlong + 3) / 4), dim3(BLOCK), 0, c.stream, (const double*)c.vlong_part.p, m.vlong_slots.p, m.n_vlong, store, m.vals.p);
+            }
         }
         if (c.world > 1) c.coll->allreduce_f32(m.vals.p, (size_t)m.ntiles * 576, c.stream);
         m.have_matrix = true;
