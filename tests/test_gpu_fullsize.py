@@ -172,6 +172,26 @@ def test_full_size_cloth_on_floor():
     x = sim.points("x0")
     assert x[:, 2].min() > 0.05                      # nothing went through the floor's top face
     assert ci["n_friction_contacts"] > 0
+    # the floor's diagonal blocks collect > 10^5 contributions each: summed by 64 wavefronts + an ordered fold (k_assemble_vlong_*);
+    # the scatter assembly with float atomics is an independent path to the same matrix
+    from stark_amd import capi
+    eng = _Eng(sim)
+    eng.contact_update(sim.info().dt)
+    eng.eval(capi.EVAL_P_G_H)
+    eng.assemble()
+    row_ptr, cols, vals = eng.get_bsr()
+    eng.set_option("atomic_assembly", 1)
+    eng.eval(capi.EVAL_P_G_H)
+    eng.assemble()
+    row_ptr2, cols2, vals2 = eng.get_bsr()
+    eng.set_option("atomic_assembly", 0)
+    assert (row_ptr == row_ptr2).all() and (cols == cols2).all()
+    n_rb_blocks = int(row_ptr[-1] - row_ptr[-3])     # the two block rows of the floor (v, w): dense against every touched node
+    assert n_rb_blocks > 2 * 60000
+    scale = np.abs(vals).max()
+    assert np.abs(vals - vals2).max() <= 2e-4 * scale  # float atomics in arbitrary order over 1.4e5 terms vs double sums rounded once
+    rb = slice(int(row_ptr[-3]), int(row_ptr[-1]))
+    assert np.abs(vals[rb]).max() > 0
     print("configs[2]: %d Newton iterations in %.3f s (8 steps) = %.1f Newton-steps/s" % (its, wall, its / wall))
     sim.close()
 
