@@ -481,85 +481,156 @@ __global__ __launch_bounds__(CB) void k_bp_gather(ContactDev d, Bands B, const u
 // Binary search of the sorted lower bounds by a whole wavefront: every step probes 64 evenly spaced positions at once, so a range of n entries is
 // narrowed in log64(n) dependent loads instead of log2(n) (a sweep entry spent most of its time in these chains). STRICT: count the
 // entries < v (lower bound), otherwise the entries <= v (upper bound). All lanes return the same index.
-template <bool STRICT>
+template <bool STRICT, int SUB = 64>
 __device__ __forceinline__ int wave_bound_f(const float* __restrict__ a, int lo, int hi, float v)
 {
-    const int lane = threadIdx.x & 63;
-    while (hi - lo > 64) {
-        const int step = (hi - lo + 63) >> 6;
-        const int pos = lo + lane * step;
+    // SUB lanes (a power of two) cooperate; the other groups of the wavefront run their own searches in the same instructions
+    const int lane = threadIdx.x & 63, sl = lane & (SUB - 1), gb = lane & ~(SUB - 1);
+    const unsigned long long gmask = SUB == 64 ? ~0ull : ((1ull << SUB) - 1ull);
+    while (hi - lo > SUB) {
+        const int step = (hi - lo + SUB - 1) / SUB;
+        const int pos = lo + sl * step;
         bool below = false;
         if (pos < hi) {
             const float x = a[pos];
             below = STRICT ? (x < v) : (x <= v);
         }
-        const int c = __popcll(__ballot(below));  // the predicate is monotone along the sorted array: lanes 0 .. c-1
+        const int c = __popcll((__ballot(below) >> gb) & gmask);  // the predicate is monotone along the sorted array: lanes 0 .. c-1
         if (c == 0) return lo;
         const int new_hi = lo + c * step < hi ? lo + c * step : hi;
         lo = lo + (c - 1) * step + 1;
         hi = new_hi;
     }
     bool below = false;
-    if (lo + lane < hi) {
-        const float x = a[lo + lane];
+    if (lo + sl < hi) {
+        const float x = a[lo + sl];
         below = STRICT ? (x < v) : (x <= v);
     }
-    return lo + __popcll(__ballot(below));
+    return lo + __popcll((__ballot(below) >> gb) & gmask);
 }
-// One wavefront per sorted entry. PROXIMITY: point entries look for triangles (lo in [lo, hi]), triangle entries for points
+// SWEEP_SUB lanes per sorted entry (most ranges hold a few dozen candidates: a whole wavefront per entry was launch-bound, 0.4 M
+// wavefronts for a 256 x 256 cloth). PROXIMITY: point entries look for triangles (lo in [lo, hi]), triangle entries for points
 // (lo in (lo, hi]), edge entries for later edges. INTERSECTION (!PROXIMITY): edge entries look for triangles, triangle entries for edges.
-template <bool PROXIMITY, bool FRICTION>
-__global__ __launch_bounds__(CB) void k_sweep(ContactDev d, Bands B, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const float* __restrict__ s_lo,
-                                              const int* __restrict__ seg, int pt_on, int ee_on, double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+// A wavefront scans at most SWEEP_SPLIT candidates itself: the rest of a long range (a floor triangle under a 256 x 256 cloth has 66 k
+// points in its interval) becomes tasks of SWEEP_SPLIT candidates that k_sweep_tasks spreads over the chip; one wavefront walking such a
+// range alone was 0.9 ms of a 1 ms detection.
+constexpr int SWEEP_SUB = 16;
+constexpr int SWEEP_SPLIT = 512;
+constexpr int SWEEP_TASK_CAP = 1 << 16;
+constexpr int SWEEP_TASK_WAVES = 4096;
+struct SweepEntry
 {
-    const int lane = threadIdx.x & 63;
-    const int sp = blockIdx.x * (CB / 64) + (threadIdx.x >> 6);
-    if (sp >= seg[3 * NBANDS]) return;
+    int cls, tc, band, b_first, src, tgt_start, a1, a2;
+    float lo, hi, lo1, hi1, lo2, hi2;
+};
+template <bool PROXIMITY>
+__device__ __forceinline__ bool sweep_entry(const ContactDev& d, const Bands& B, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const int* __restrict__ seg, int sp,
+                                            int pt_on, int ee_on, SweepEntry& E)
+{
     const int gi = (int)sidx[sp];  // primitive (points | triangles | edges numbering)
-    const int cls = gi < d.n_v ? 0 : (gi < d.n_v + d.n_t ? 1 : 2);
-    int tc;  // class of the targets
+    E.cls = gi < d.n_v ? 0 : (gi < d.n_v + d.n_t ? 1 : 2);
     if (PROXIMITY) {
-        if (cls == 2 ? !ee_on : !pt_on) return;
-        tc = cls == 0 ? 1 : (cls == 1 ? 0 : 2);
+        if (E.cls == 2 ? !ee_on : !pt_on) return false;
+        E.tc = E.cls == 0 ? 1 : (E.cls == 1 ? 0 : 2);
     } else {
-        if (cls == 0) return;
-        tc = cls == 2 ? 1 : 2;
+        if (E.cls == 0) return false;
+        E.tc = E.cls == 2 ? 1 : 2;
     }
     const float* sb = s_aabb + 6 * (size_t)sp;
-    const int ax = B.axis, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
-    const float lo = sb[ax], hi = sb[3 + ax], lo1 = sb[a1], hi1 = sb[3 + a1], lo2 = sb[a2], hi2 = sb[3 + a2];
+    const int ax = B.axis;
+    E.a1 = (ax + 1) % 3;
+    E.a2 = (ax + 2) % 3;
+    E.lo = sb[ax]; E.hi = sb[3 + ax]; E.lo1 = sb[E.a1]; E.hi1 = sb[3 + E.a1]; E.lo2 = sb[E.a2]; E.hi2 = sb[3 + E.a2];
     // which band is this entry? the entries of a box are consecutive bands starting at its first one; recover it from the segment
-    const int b_first = band_of(B, sb[B.band_axis]);
-    int band = b_first;
-    while (band < NBANDS - 1 && sp >= seg[cls * NBANDS + band + 1]) band++;
-    const int t_begin = seg[tc * NBANDS + band], t_end = seg[tc * NBANDS + band + 1];
-    int j0;
-    if (cls == 2 && tc == 2) j0 = sp + 1;                                   // later edges of the same segment
-    else if (cls == 0 || (!PROXIMITY && cls == 2)) j0 = wave_bound_f<true>(s_lo, t_begin, t_end, lo);  // target lo in [lo, hi]
-    else j0 = wave_bound_f<false>(s_lo, t_begin, t_end, lo);                       // target lo in (lo, hi]: the other direction took ties
-    const int j1 = wave_bound_f<false>(s_lo, j0 > t_begin ? j0 : t_begin, t_end, hi);
-    // (no local arrays indexed at run time: they would live in scratch memory)
-    const int src_start = cls == 0 ? 0 : (cls == 1 ? d.n_v : d.n_v + d.n_t);
-    const int tgt_start = tc == 0 ? 0 : (tc == 1 ? d.n_v : d.n_v + d.n_t);
-    const int src = gi - src_start;
+    E.b_first = band_of(B, sb[B.band_axis]);
+    E.band = E.b_first;
+    while (E.band < NBANDS - 1 && sp >= seg[E.cls * NBANDS + E.band + 1]) E.band++;
+    const int src_start = E.cls == 0 ? 0 : (E.cls == 1 ? d.n_v : d.n_v + d.n_t);
+    E.tgt_start = E.tc == 0 ? 0 : (E.tc == 1 ? d.n_v : d.n_v + d.n_t);
+    E.src = gi - src_start;
+    return true;
+}
+// candidates [j0, j1) of one entry, 64 at a time; returns this lane's intersection count (!PROXIMITY)
+template <bool PROXIMITY, bool FRICTION, int SUB>
+__device__ __forceinline__ int sweep_scan(const ContactDev& d, const Bands& B, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const SweepEntry& E, int j0, int j1,
+                                          double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+{
+    const int sl = threadIdx.x & (SUB - 1);
     int hits = 0;
-    for (int j = j0 + lane; j < j1; j += 64) {
+    // (no local arrays indexed at run time: they would live in scratch memory)
+    for (int j = j0 + sl; j < j1; j += SUB) {
         const float* tb = s_aabb + 6 * (size_t)j;
-        if (!(lo1 <= tb[3 + a1] && tb[a1] <= hi1 && lo2 <= tb[3 + a2] && tb[a2] <= hi2)) continue;
+        if (!(E.lo1 <= tb[3 + E.a1] && tb[E.a1] <= E.hi1 && E.lo2 <= tb[3 + E.a2] && tb[E.a2] <= E.hi2)) continue;
         const int tb_first = band_of(B, tb[B.band_axis]);
-        if (band != (b_first > tb_first ? b_first : tb_first)) continue;      // the pair is reported in its first common band only
-        const int tgt = (int)sidx[j] - tgt_start;
+        if (E.band != (E.b_first > tb_first ? E.b_first : tb_first)) continue;      // the pair is reported in its first common band only
+        const int tgt = (int)sidx[j] - E.tgt_start, src = E.src;
         if (PROXIMITY) {
-            if (cls == 0) narrow_pt<FRICTION>(d, src, tgt, enl2, keys, counters, key_cap);
-            else if (cls == 1) narrow_pt<FRICTION>(d, tgt, src, enl2, keys, counters, key_cap);
+            if (E.cls == 0) narrow_pt<FRICTION>(d, src, tgt, enl2, keys, counters, key_cap);
+            else if (E.cls == 1) narrow_pt<FRICTION>(d, tgt, src, enl2, keys, counters, key_cap);
             else narrow_ee<FRICTION>(d, src < tgt ? src : tgt, src < tgt ? tgt : src, enl2, keys, counters, key_cap);
         } else {
-            const int e = cls == 2 ? src : tgt, t = cls == 2 ? tgt : src;
+            const int e = E.cls == 2 ? src : tgt, t = E.cls == 2 ? tgt : src;
             const int v0 = d.edge[2 * e], v1 = d.edge[2 * e + 1], u0 = d.tri[3 * t], u1 = d.tri[3 * t + 1], u2 = d.tri[3 * t + 2];
             if (v0 == u0 || v0 == u1 || v0 == u2 || v1 == u0 || v1 == u1 || v1 == u2) continue;  // BroadPhaseET.cpp:161-165
             if (d.disabled[d.edge_mesh[e] * d.n_mesh + d.tri_mesh[t]]) continue;
             if (edge_intersects_triangle(ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, u0), ldx(d.X, u1), ldx(d.X, u2))) hits++;
         }
+    }
+    return hits;
+}
+template <bool PROXIMITY, bool FRICTION>
+__global__ __launch_bounds__(CB) void k_sweep(ContactDev d, Bands B, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const float* __restrict__ s_lo,
+                                              const int* __restrict__ seg, int pt_on, int ee_on, double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap,
+                                              int* __restrict__ task_count, int* __restrict__ tasks)
+{
+    constexpr int SUB = SWEEP_SUB;
+    const int lane = threadIdx.x & 63, sl = lane & (SUB - 1), gb = lane & ~(SUB - 1);
+    const int sp = blockIdx.x * (CB / SUB) + threadIdx.x / SUB;
+    if (sp >= seg[3 * NBANDS]) return;
+    SweepEntry E;
+    if (!sweep_entry<PROXIMITY>(d, B, sidx, s_aabb, seg, sp, pt_on, ee_on, E)) return;
+    const int t_begin = seg[E.tc * NBANDS + E.band], t_end = seg[E.tc * NBANDS + E.band + 1];
+    int j0;
+    if (E.cls == 2 && E.tc == 2) j0 = sp + 1;                                   // later edges of the same segment
+    else if (E.cls == 0 || (!PROXIMITY && E.cls == 2)) j0 = wave_bound_f<true, SUB>(s_lo, t_begin, t_end, E.lo);  // target lo in [lo, hi]
+    else j0 = wave_bound_f<false, SUB>(s_lo, t_begin, t_end, E.lo);                       // target lo in (lo, hi]: the other direction took ties
+    const int j1 = wave_bound_f<false, SUB>(s_lo, j0 > t_begin ? j0 : t_begin, t_end, E.hi);
+    int j_own = j1;
+    if (j1 - j0 > SWEEP_SPLIT) {  // long range: hand the rest out in tasks (those that fit the list; the remainder stays here)
+        const int first = j0 + SWEEP_SPLIT;
+        const int n_task = (j1 - first + SWEEP_SPLIT - 1) / SWEEP_SPLIT;
+        int base = 0;
+        if (sl == 0) base = atomicAdd(task_count, n_task);
+        base = __shfl(base, gb, 64);
+        const int n_fit = base >= SWEEP_TASK_CAP ? 0 : (n_task < SWEEP_TASK_CAP - base ? n_task : SWEEP_TASK_CAP - base);
+        for (int t = sl; t < n_fit; t += SUB) {
+            int* T = tasks + 3 * (size_t)(base + t);
+            T[0] = sp;
+            T[1] = first + t * SWEEP_SPLIT;
+            T[2] = first + (t + 1) * SWEEP_SPLIT < j1 ? first + (t + 1) * SWEEP_SPLIT : j1;
+        }
+        j_own = first;
+        if (n_fit < n_task) {  // (list full)
+            const int hits2 = sweep_scan<PROXIMITY, FRICTION, SUB>(d, B, sidx, s_aabb, E, first + n_fit * SWEEP_SPLIT, j1, enl2, keys, counters, key_cap);
+            if (!PROXIMITY && hits2) atomicAdd(&counters[1], hits2);
+        }
+    }
+    const int hits = sweep_scan<PROXIMITY, FRICTION, SUB>(d, B, sidx, s_aabb, E, j0, j_own, enl2, keys, counters, key_cap);
+    if (!PROXIMITY && hits) atomicAdd(&counters[1], hits);
+}
+template <bool PROXIMITY, bool FRICTION>
+__global__ __launch_bounds__(CB) void k_sweep_tasks(ContactDev d, Bands B, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const int* __restrict__ seg, int pt_on,
+                                                    int ee_on, double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap,
+                                                    const int* __restrict__ task_count, const int* __restrict__ tasks)
+{
+    const int w = blockIdx.x * (CB / 64) + (threadIdx.x >> 6);
+    const int n = task_count[0] < SWEEP_TASK_CAP ? task_count[0] : SWEEP_TASK_CAP;
+    int hits = 0;
+    for (int t = w; t < n; t += SWEEP_TASK_WAVES) {
+        const int* T = tasks + 3 * (size_t)t;
+        SweepEntry E;
+        if (!sweep_entry<PROXIMITY>(d, B, sidx, s_aabb, seg, T[0], pt_on, ee_on, E)) continue;
+        hits += sweep_scan<PROXIMITY, FRICTION, 64>(d, B, sidx, s_aabb, E, T[1], T[2], enl2, keys, counters, key_cap);
     }
     if (!PROXIMITY && hits) atomicAdd(&counters[1], hits);
 }
@@ -748,6 +819,7 @@ struct ContactSystem
     bool brute_force = false;  // ablation / fallback: LDS-tiled all-pairs kernels
     int64_t n_prev = -1;  // keys of the barrier tables currently installed (-1: none)
     DevBuf<int> counters;  // [0] candidates, [1] intersections, [2] differs, [8..8+N_TABLES] bounds
+    DevBuf<int> sweep_tasks;  // (entry, first candidate, end) of the split-off parts of long sweep ranges + their count
     DevBuf<uint8_t> cub_tmp;
     DevBuf<TableDev> tables_dev;
     size_t key_cap = 0;
@@ -986,8 +1058,14 @@ void sort_boxes(Context& c, ContactSystem& cs, const ContactDev& d)
 template <bool PROX, bool FR>
 void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, double enl2)
 {
-    hipLaunchKernelGGL((k_sweep<PROX, FR>), dim3((cs.bp_cap + CB / 64 - 1) / (CB / 64)), dim3(CB), 0, c.stream, d, cs.bands, cs.s_idx, (const float*)cs.s_aabb.p, (const float*)cs.s_lo.p,
-                       (const int*)cs.seg.p, (int)(cs.pt_enabled && cs.n_t > 0), (int)(cs.ee_enabled && cs.n_e > 1), enl2, cs.keys.p, cs.counters.p, (int)cs.key_cap);
+    cs.sweep_tasks.ensure(3 * (size_t)SWEEP_TASK_CAP + 4);
+    int* task_count = cs.sweep_tasks.p + 3 * (size_t)SWEEP_TASK_CAP;
+    MS_CHECK(hipMemsetAsync(task_count, 0, sizeof(int), c.stream));
+    const int pt_on = (int)(cs.pt_enabled && cs.n_t > 0), ee_on = (int)(cs.ee_enabled && cs.n_e > 1);
+    hipLaunchKernelGGL((k_sweep<PROX, FR>), dim3((cs.bp_cap + CB / SWEEP_SUB - 1) / (CB / SWEEP_SUB)), dim3(CB), 0, c.stream, d, cs.bands, cs.s_idx, (const float*)cs.s_aabb.p, (const float*)cs.s_lo.p,
+                       (const int*)cs.seg.p, pt_on, ee_on, enl2, cs.keys.p, cs.counters.p, (int)cs.key_cap, task_count, cs.sweep_tasks.p);
+    hipLaunchKernelGGL((k_sweep_tasks<PROX, FR>), dim3(SWEEP_TASK_WAVES / (CB / 64)), dim3(CB), 0, c.stream, d, cs.bands, cs.s_idx, (const float*)cs.s_aabb.p, (const int*)cs.seg.p, pt_on,
+                       ee_on, enl2, cs.keys.p, cs.counters.p, (int)cs.key_cap, (const int*)task_count, (const int*)cs.sweep_tasks.p);
 }
 // Runs detection and installs the tables [t0, t1). Returns the number of rows.
 int64_t detect_and_route(Context& c, double dt, bool friction)
