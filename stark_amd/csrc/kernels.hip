@@ -1114,7 +1114,7 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elem
         double l = A[lane * n + lane];
         if (l < eps) {
             bad = true;
-            l = mirroring ? -l : eps;
+            l = (mirroring & 1) ? -l : eps;  // (bit 1: k_project_eig_cols' IEEE switch)
         }
         sL[wave][lane] = l;
     }

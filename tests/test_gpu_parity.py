@@ -127,6 +127,38 @@ def test_stages_match_reference(path, variant):
     eng.close()
 
 
+@pytest.mark.parametrize("proj_variant", [1, 2, 4, 7])
+@pytest.mark.parametrize("name", ["tetbeam_eo_4x1x1_big", "contactmix_t1", "rbchain", "cloth_shells_6"])
+def test_projection_variants_agree(name, proj_variant):
+    """The PSD projection has a register-resident kernel (default), the earlier LDS kernel (bit 1), per-potential launches instead of
+    the batched one (bit 2) and IEEE division/square root for the rotation angles (bit 4): every combination gives the reference's
+    projected Hessians and the same "changed" count, and agrees with the default path to 1e-12."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    path = os.path.join(GOLDEN, name + ".npz")
+    prob, man, z = ev.load_fixture(path)
+    out = []
+    for variant in (0, proj_variant):
+        eng = engine_from_problem(prob, man)
+        eng.set_option("proj_variant", variant)
+        eng.eval(capi.EVAL_P_G_H)
+        eng.assemble()                              # the deltas also go into the assembled matrix
+        n_proj, n_changed = eng.project(1e-10, False, None)
+        H = {pi: eng.element_hessians(pid, man["potentials"][pi]["n_elem"])[0] for pi, pid in eng.pot_ids.items()}
+        out.append((n_proj, n_changed, H, eng.get_bsr()[2]))
+        eng.close()
+    (np0, nc0, H0, v0), (np1, nc1, H1, v1) = out
+    assert np0 == np1 == man["n_hessians"] and nc0 == nc1
+    for pi in H0:
+        Hp = z["p%d_hvals_proj" % pi]
+        den = np.maximum(np.sqrt((Hp ** 2).sum(axis=(1, 2))), 1e-300)
+        assert (np.sqrt(((H0[pi] - H1[pi]) ** 2).sum(axis=(1, 2))) <= 1e-12 * den).all()
+        tol = max(1e-9, 10 * ELEMENT_TOL.get(man["potentials"][pi]["name"], 0))
+        assert (np.sqrt(((H1[pi] - Hp) ** 2).sum(axis=(1, 2))) <= tol * den).all()
+    assert np.abs(v0 - v1).max() <= 4e-6 * np.abs(v0).max()   # float atomics of the deltas
+
+
 # (rigid-body trajectories need the rigid-body state update and constraint hardening of the host layer: tests/test_gpu_scene.py)
 TRAJ = [p for p in DUMPS if os.path.basename(p).startswith("traj_") and "rb" not in os.path.basename(p) and "box" not in os.path.basename(p) and "attach" not in os.path.basename(p) and "llt" not in os.path.basename(p)]  # (rigid-body and contact trajectories: scene tests)
 
