@@ -174,6 +174,7 @@ struct BsrPart
     // static part only: CSR order cut into row-aligned chunks (kernels.hip: build_aligned). `vals` / `scol` hold ntiles tiles in that
     // storage order and store_slot maps a CSR slot to its position there.
     int64_t n_chunks_static = 0;
+    int chunk_tiles = 8;            // tiles per chunk of this pattern (chunk_tiles_for)
     DevBuf<uint32_t> store_slot;    // per CSR slot: position (tile * 64 + lane) of the block in vals / scol
     DevBuf<uint32_t> scol;          // per stored position: block column, bit 31 = last block of its row (padding: 0)
     DevBuf<uint64_t> row_pos;       // per block row: position of its first block

@@ -580,7 +580,7 @@ __global__ __launch_bounds__(BLOCK) void k_long_slots(const uint32_t* __restrict
 // is carried in or out, no tile is read by two wavefronts, and no wavefront starts with a search for its first row (that control
 // structure cost the earlier kernel 6 of 28.6 us). Rows longer than a chunk are stored after the chunks and reduced one wavefront per
 // row. The layout is computed once per pattern on the host (one pass over the row lengths).
-constexpr int SPMV_CHUNK_TILES = 8;
+constexpr int SPMV_CHUNK_TILES = 8;  // at 2 M blocks and more; smaller matrices take shorter chunks (more wavefronts): chunk_tiles_for
 __global__ __launch_bounds__(BLOCK) void k_store_fill(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ colw, const uint64_t* __restrict__ row_pos, int64_t nbr,
                                                       uint32_t* __restrict__ store_slot, uint32_t* __restrict__ scol)
 {
@@ -601,13 +601,17 @@ __global__ __launch_bounds__(BLOCK) void k_remap_slots(uint32_t* __restrict__ sl
     const uint32_t s = slots[k];
     if (s != 0xFFFFFFFFu) slots[k] = store_slot[s];
 }
+// a 157 k-DoF matrix in chunks of 8 tiles is 1750 wavefronts for 1024 SIMDs: 14.5 us per launch, latency-bound
+static int chunk_tiles_for(int64_t nnzb) { return nnzb >= (2 << 20) ? SPMV_CHUNK_TILES : (nnzb >= (1 << 20) ? 4 : 2); }
 static void build_aligned(Context& c, BsrPart& m)
 {
+    const int CT = chunk_tiles_for(m.nnzb);
+    m.chunk_tiles = CT;
     const int64_t nbr = c.nbr;
     std::vector<int64_t> rp((size_t)nbr + 1);
     MS_CHECK(hipMemcpyAsync(rp.data(), m.row_ptr.p, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
-    const uint64_t chunk = (uint64_t)SPMV_CHUNK_TILES * 64;
+    const uint64_t chunk = (uint64_t)CT * 64;
     std::vector<uint64_t> row_pos((size_t)nbr);
     std::vector<uint32_t> long_rows;  // rows that do not fit a chunk
     uint64_t cur = 0;
@@ -622,7 +626,7 @@ static void build_aligned(Context& c, BsrPart& m)
         row_pos[r] = cur;
         cur += len;
     }
-    const uint64_t n_chunk_tiles = (cur + chunk - 1) / chunk * SPMV_CHUNK_TILES;
+    const uint64_t n_chunk_tiles = (cur + chunk - 1) / chunk * CT;
     uint64_t pos = n_chunk_tiles * 64;
     std::vector<uint64_t> long_pos;
     for (uint32_t r : long_rows) {  // long rows after the chunks, each starting on a tile
@@ -631,7 +635,7 @@ static void build_aligned(Context& c, BsrPart& m)
         pos += ((uint64_t)(rp[r + 1] - rp[r]) + 63) / 64 * 64;
     }
     if (pos >= (1ull << 31)) throw Error("static matrix part too large");
-    m.n_chunks_static = (int64_t)(n_chunk_tiles / SPMV_CHUNK_TILES);
+    m.n_chunks_static = (int64_t)(n_chunk_tiles / CT);
     m.ntiles = (int64_t)(pos / 64);
     // first row of every chunk tile (bit 31: the tile starts inside a row begun in the previous tile of the same chunk)
     std::vector<int32_t> tfr((size_t)n_chunk_tiles, 0);
@@ -1801,8 +1805,8 @@ __device__ __forceinline__ double dpp_row_shr(double v)
 // tile of the chunk is carried in registers. Every row is written exactly once: no atomics, no zero fill, deterministic.
 template <int V>
 __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nblk, const float* __restrict__ vals, const uint32_t* __restrict__ scol,
-                                                    const int32_t* __restrict__ tile_first_row, int64_t n_chunks, const double* __restrict__ x, double* __restrict__ y,
-                                                    const double* __restrict__ pdot, double* __restrict__ partials)
+                                                    const int32_t* __restrict__ tile_first_row, int64_t n_chunks, const int chunk_tiles, const double* __restrict__ x,
+                                                    double* __restrict__ y, const double* __restrict__ pdot, double* __restrict__ partials)
 {
     __shared__ double sm[4];
     const int lane = threadIdx.x & 63;
@@ -1813,9 +1817,9 @@ __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nbl
     const int pbid = ((nblk & 7) == 0) ? (bid & 7) * (nblk >> 3) + (bid >> 3) : bid;
     const int64_t n_waves = (int64_t)nblk * 4;
     for (int64_t ch = (int64_t)pbid * 4 + wave; ch < n_chunks; ch += n_waves) {
-        const int64_t t_begin = ch * SPMV_CHUNK_TILES;
+        const int64_t t_begin = ch * chunk_tiles;
         double k0 = 0.0, k1 = 0.0, k2 = 0.0;  // carry into the first segment of the next tile (wave-uniform)
-        for (int u = 0; u < SPMV_CHUNK_TILES; u++) {
+        for (int u = 0; u < chunk_tiles; u++) {
             const int64_t t = t_begin + u;
             const uint32_t w = scol[t * 64 + lane];
             const float4* q = reinterpret_cast<const float4*>(vals + (size_t)t * 576);
@@ -2063,6 +2067,7 @@ struct StaticPart  // the static part as the fused SpMV kernel sees it
     const uint64_t* row_pos;
     int64_t n_chunks;
     int n_long_rows;
+    int chunk_tiles;
 };
 // One launch for y = A_static x (rows written once, see spmv_chunked_static) and the contact part's row sums (yd / chunk_partial); the
 // consumer adds them (k_pcg_step inside the solver, k_spmv_combine elsewhere). The few workgroups of the contact part and of over-long
@@ -2077,7 +2082,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_fused(int g0, int gr, int g1, St
     const int b = (int)blockIdx.x;
     if (b < g1) spmv_chunks(b, g1, d, x, pdot, partials ? partials + g0 + gr : nullptr);
     else if (b < g1 + gr) spmv_long_rows(b - g1, gr, m.vals, m.scol, m.long_rows, m.n_long_rows, m.row_ptr, m.row_pos, x, y, pdot, partials ? partials + g0 : nullptr);
-    else spmv_chunked_static<V>(b - g1 - gr, g0, m.vals, m.scol, m.tile_first_row, m.n_chunks, x, y, pdot, partials);
+    else spmv_chunked_static<V>(b - g1 - gr, g0, m.vals, m.scol, m.tile_first_row, m.n_chunks, m.chunk_tiles, x, y, pdot, partials);
 }
 __global__ __launch_bounds__(BLOCK) void k_spmv_combine(int64_t nbr, const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0,
                                                        const double* __restrict__ yd, const double* __restrict__ chunk_partial, double* __restrict__ y)
@@ -2098,7 +2103,7 @@ static int launch_spmv(Context& c, const double* x, double* y, const double* pdo
     BsrPart& m1 = c.part[1];
     const int g0 = spmv_grid(c, m0.n_chunks_static, MAX_PARTIALS / 2);
     const int gr = std::min(((m0.n_long_rows + 3) / 4 + 7) / 8 * 8, MAX_PARTIALS / 4);
-    const StaticPart sp{m0.vals.p, m0.scol.p, m0.tile_first_row.p, m0.long_rows.p, m0.row_ptr.p, m0.row_pos.p, m0.n_chunks_static, m0.n_long_rows};
+    const StaticPart sp{m0.vals.p, m0.scol.p, m0.tile_first_row.p, m0.long_rows.p, m0.row_ptr.p, m0.row_pos.p, m0.n_chunks_static, m0.n_long_rows, m0.chunk_tiles};
     DynPart d{};
     int g1 = 0;
     if (m1.nnzb > 0) {
