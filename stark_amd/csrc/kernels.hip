@@ -219,6 +219,62 @@ __global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __
         atomicAdd(&grad[3 * row + 2], g[3 * k + 2]);
     }
 }
+// EnergyBendingFlat in closed form (EnergyDiscreteShells.cpp:64-92): E = k coef / 2 |s|^2 with s = sum_i K_i (x0_i + dt v_i) is quadratic in
+// the velocities: dE/dv_i = k coef dt K_i s and d2E/dv_i dv_j = k coef dt^2 K_i K_j I3, a constant. One lane per hinge instead of the 78
+// hyper-dual evaluations of the generic kernel (0.30 -> 0.04 ms for the 196 k hinges of a 256 x 256 cloth); a lane writes the 72
+// contiguous bytes of each of its 16 blocks, neighbouring lanes the neighbouring 72.
+template <bool STORE_H>
+__global__ __launch_bounds__(BLOCK) void k_eval_bending_flat(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
+{
+    using En = E_BendingFlat;
+    const int le = blockIdx.x * BLOCK + threadIdx.x;
+    if (le >= a.e_count) return;
+    const int e = a.e_begin + le;
+    double in[En::Layout::NIN];
+    gather_inputs<En>(a, e, in);
+    const double coef = in[28], k = in[29], dt = in[30];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double K = in[24 + i];
+        s0 += K * (in[12 + 3 * i] + dt * in[3 * i]);
+        s1 += K * (in[13 + 3 * i] + dt * in[3 * i + 1]);
+        s2 += K * (in[14 + 3 * i] + dt * in[3 * i + 2]);
+    }
+    const double kc = k * coef;
+    elemE[e] = 0.5 * kc * (s0 * s0 + s1 * s1 + s2 * s2);
+    const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const double f = kc * dt * in[24 + i];
+        const size_t row = (size_t)(a.dof_row_off[i] + ce[a.dof_col[i]]);
+        atomicAdd(&grad[3 * row], f * s0);
+        atomicAdd(&grad[3 * row + 1], f * s1);
+        atomicAdd(&grad[3 * row + 2], f * s2);
+    }
+    if (STORE_H) {
+        const double h = kc * dt * dt;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const double d = h * in[24 + i] * in[24 + j];
+                double* H = elemH + ((size_t)(i * 4 + j) * a.n_elem + e) * 9;
+                H[0] = d;   H[1] = 0.0; H[2] = 0.0;
+                H[3] = 0.0; H[4] = d;   H[5] = 0.0;
+                H[6] = 0.0; H[7] = 0.0; H[8] = d;
+            }
+    }
+}
+static void launch_bending_flat(Context& c, Potential& P, int mode)
+{
+    if (P.args.e_count == 0) return;
+    double* E = c.elemE.p + P.e_off;
+    if (mode == MISTARK_EVAL_P_G)
+        hipLaunchKernelGGL((k_eval_bending_flat<false>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
+    else
+        hipLaunchKernelGGL((k_eval_bending_flat<true>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
+}
 template <class En, bool FULL>
 static void launch_tet_closed(Context& c, Potential& P, int mode)
 {
@@ -254,6 +310,7 @@ static void launch_eval_kind(Context& c, Potential& P, int mode)
     if (mode != MISTARK_EVAL_P && !c.force_generic) {
         if (P.name == E_TetStrain::name) { launch_tet_closed<E_TetStrain, true>(c, P, mode); return; }
         if (P.name == E_TetStrainEO::name) { launch_tet_closed<E_TetStrainEO, false>(c, P, mode); return; }
+        if (P.name == E_BendingFlat::name) { launch_bending_flat(c, P, mode); return; }
     }
     int k = 0;
 #define X(En)                               \
