@@ -132,6 +132,10 @@ int mistark_sim_rb_add_torque(mistark_sim* sim, int rb, const double t[3]);
  * "distance_limits", "direction", "angle_limit", "spring", "linear_velocity", "angular_velocity"): the index the next one will get.
  * mistark_sim_rb_add_constraint returns the index of the (last) base constraint it created. */
 int mistark_sim_rb_constraint_count(mistark_sim* sim, const char* base_type);
+/* RBCFixHandler::set_transformation (rigidbody_constraints_ui.h:369-379): moves the target of a "fix": anchor_point = index of its
+ * "global_point", z_lock / x_lock = indices of its two "global_direction" constraints (the counts before the fix was added: g, d, d + 1);
+ * rotation row-major 3x3. The README's spinning box calls this from its per-step script. */
+int mistark_sim_rb_fix_set_transformation(mistark_sim* sim, int anchor_point, int z_lock, int x_lock, const double translation[3], const double rotation[9]);
 /* The constraint handlers' measurements (rigidbody_constraints_ui.h): out = {violation, force or torque} of base constraint `idx`:
  * get_violation_in_m_and_force / get_violation_in_deg_and_torque / get_signed_violation_in_m_and_force /
  * get_signed_spring_displacement_in_m_and_force (which = 0) / get_signed_damper_velocity_and_force (which = 1) /

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <functional>
 #include <map>
 #include <optional>
 #include <sstream>
@@ -89,6 +90,8 @@ struct Scene
     std::vector<ContactMeshRecord> contact_meshes;
     std::vector<std::array<double, 3>> friction_pairs;  // (mesh a, mesh b, mu)
     int n_rb_collision_vertices = 0;
+    std::function<void()> before_step;  // the scene's script (Simulation::run(duration, callback) calls it before every time step)
+    void step() { if (before_step) before_step(); sim->run_one_time_step(); }
     void record_deformable(const stark::PointSetHandler& ps, const std::vector<std::array<int, 3>>& tris, const std::vector<int>& map, double thickness)
     {
         ContactMeshRecord m;
@@ -563,13 +566,19 @@ static Scene scene_clothbox(const Args& a)
     auto [bV, bT, box] = sim.presets->rigidbodies->add_box("box", 1.0, bs);
     sc.record_rigid(box.rigidbody, (int)bV.size(), bT, th);
     box.rigidbody.add_translation({ 0.0, 0.0, -0.5 * bs - gap });
-    sim.rigidbodies->add_constraint_fix(box.rigidbody);
+    auto fix = sim.rigidbodies->add_constraint_fix(box.rigidbody);
+    const double spin = a.d("spin", 0.0);  // README.md:84-91: the script turns the fixed box by 90 deg/s about z
+    if (spin != 0.0) {
+        stark::Simulation* ps = sc.sim.get();
+        const Eigen::Vector3d anchor(0.0, 0.0, -0.5 * bs - gap);
+        sc.before_step = [fix, ps, anchor, spin]() mutable { fix.set_transformation(anchor, spin * ps->get_time(), Eigen::Vector3d::UnitZ()); };
+    }
     if (mu > 0.0) {
         sim.interactions->contact->set_friction(cloth.contact, box.contact, mu);
         sc.record_friction(0, 1, mu);
     }
     std::ostringstream js;
-    js << "{\"kind\":\"clothbox\",\"n\":" << n << ",\"thickness\":" << th << ",\"gap\":" << gap << ",\"mu\":" << mu << ",\"size\":" << size << ",\"box\":" << bs
+    js << "{\"kind\":\"clothbox\",\"spin\":" << spin << ",\"n\":" << n << ",\"thickness\":" << th << ",\"gap\":" << gap << ",\"mu\":" << mu << ",\"size\":" << size << ",\"box\":" << bs
        << ",\"kmin\":" << gp.min_contact_stiffness << "}";
     sc.json = js.str();
     return sc;
@@ -1053,13 +1062,13 @@ int main(int argc, char** argv)
         // JIT-compile (or load) every kernel of the scene. Must be run once before `dump` on a cold cache: the
         // reference's cache key hashes the expression graph, which symbolic differentiation (cold cache only) mutates,
         // so a second compiled object created in the same process after a cold compile would never hit the cache.
-        sc.sim->run_one_time_step();
+        sc.step();
         return 0;
     }
     if (mode == "dump") {
         // Run `steps` time steps, then start the next one by hand, perturb v1 and snapshot
         // steps = 0: snapshot at the initial configuration (needs a primed JIT cache, see `prime`)
-        for (int s = 0; s < steps; s++) sc.sim->run_one_time_step();
+        for (int s = 0; s < steps; s++) sc.step();
         std::vector<double> u_conv(st.global_potential->get_total_n_dofs());
         st.global_potential->get_dofs(u_conv.data());
         st.callbacks->run_before_time_step();  // v1 <- 0; friction tables; rb caches
@@ -1098,7 +1107,7 @@ int main(int argc, char** argv)
         man << "{\"scene\":" << sc.json << ",\"steps\":[";
         for (cur_step = 0; cur_step < steps; cur_step++) {
             const double dt_used = st.dt;
-            sc.sim->run_one_time_step();
+            sc.step();
             man << (cur_step ? "," : "") << "{\"dt\":" << dt_used << ",\"time\":" << st.current_time << "}";
         }
         auto& lg = *st.context->logger;
@@ -1126,13 +1135,13 @@ int main(int argc, char** argv)
     if (mode == "time") {
         // warm-up steps (first step builds the sparsity pattern and JIT-loads) then timed steps
         const int warm = a.i("warmup", 1);
-        for (int s = 0; s < warm; s++) sc.sim->run_one_time_step();
+        for (int s = 0; s < warm; s++) sc.step();
         auto& lg = *st.context->logger;
         const int newton0 = lg.get_int("newton_iterations");
         const double ls0 = lg.get_timer_total("linear_system_solve");
         const int lsn0 = lg.get_timer_count("linear_system_solve");
         const double t0 = omp_get_wtime();
-        for (int s = 0; s < steps; s++) sc.sim->run_one_time_step();
+        for (int s = 0; s < steps; s++) sc.step();
         const double t1 = omp_get_wtime();
         const int newton = lg.get_int("newton_iterations") - newton0;
         const double ls = lg.get_timer_total("linear_system_solve") - ls0;

@@ -294,6 +294,7 @@ double sq_distance_point_line(const Vec3& p, const Vec3& a, const Vec3& b) { ret
 EnergyRigidBodyConstraints::EnergyRigidBodyConstraints(Stark& s, spRigidBodyDynamics r) : stark(s), rb(r)
 {
     for (int& id : id_stiffness) id = -1;
+    for (int k = 0; k < N_KINDS; k++) id_v0[k] = id_v1[k] = -1;
     stark.add_model(this);
     stark.callbacks->newton->add_is_converged_state_valid([this]() { return _is_converged_state_valid(); });
     stark.callbacks->add_on_time_step_accepted([this]() { _on_time_step_accepted(); });
@@ -307,6 +308,7 @@ int EnergyRigidBodyConstraints::add(Kind kind, int a, int b, const Vec3* vecs, i
     T.conn.push_back({id, a, K.two_bodies ? b : a});
     std::vector<Vec3>* vc[3] = {&T.v0, &T.v1, &T.v2};
     for (int i = 0; i < 3; i++) vc[i]->push_back(i < n_vecs ? (K.normalize[i] ? normalized(vecs[i]) : vecs[i]) : ZERO);
+    T.v0_rest.push_back(T.v0.back());
     std::vector<double>* sc[3] = {&T.s0, &T.s1, &T.s2};
     for (int i = 0; i < 3; i++) sc[i]->push_back(i < n_scalars ? scalars[i] : 0.0);
     T.stiffness.push_back(stiffness);
@@ -318,7 +320,7 @@ int EnergyRigidBodyConstraints::add(Kind kind, int a, int b, const Vec3* vecs, i
 void EnergyRigidBodyConstraints::register_potentials(mistark_ctx* ctx)
 {
     for (int kind = 0; kind < N_KINDS; kind++) {
-        id_stiffness[kind] = -1;
+        id_stiffness[kind] = id_v0[kind] = id_v1[kind] = -1;
         Table& T = tables[kind];
         if (T.conn.empty()) continue;
         const int64_t n = (int64_t)T.conn.size();
@@ -337,8 +339,8 @@ void EnergyRigidBodyConstraints::register_potentials(mistark_ctx* ctx)
         };
         const int dt = stark.dt_array();
         switch (kind) {  // binding order of EnergyRigidBodyConstraints.cpp:30-247
-            case GlobalPoints: vec(T.v0); vec(T.v1); id_stiffness[kind] = sca(T.stiffness); sca(T.is_active); B.add_id(dt, 1, -1); x1(1); break;
-            case GlobalDirections: vec(T.v0); vec(T.v1); id_stiffness[kind] = sca(T.stiffness); sca(T.is_active); B.add_id(dt, 1, -1); d1(1); break;
+            case GlobalPoints: vec(T.v0); id_v1[kind] = B.add(T.v1[0].data(), n, 3, 0); id_stiffness[kind] = sca(T.stiffness); sca(T.is_active); B.add_id(dt, 1, -1); x1(1); break;
+            case GlobalDirections: id_v0[kind] = B.add(T.v0[0].data(), n, 3, 0); vec(T.v1); id_stiffness[kind] = sca(T.stiffness); sca(T.is_active); B.add_id(dt, 1, -1); d1(1); break;
             case Points: vec(T.v0); vec(T.v1); id_stiffness[kind] = sca(T.stiffness); sca(T.is_active); B.add_id(dt, 1, -1); x1(1); x1(2); break;
             case PointOnAxes: vec(T.v0); vec(T.v1); vec(T.v2); id_stiffness[kind] = sca(T.stiffness); sca(T.is_active); B.add_id(dt, 1, -1); x1(1); x1(2); break;
             case Distances: vec(T.v0); vec(T.v1); sca(T.s0); id_stiffness[kind] = sca(T.stiffness); sca(T.is_active); B.add_id(dt, 1, -1); x1(1); x1(2); break;
@@ -591,6 +593,26 @@ void RigidBodies::add_constraint_fix(const RigidBodyHandler& body)
     add_constraint_global_point(body, body.get_translation());
     add_constraint_global_direction(body, {0.0, 0.0, 1.0});
     add_constraint_global_direction(body, {1.0, 0.0, 0.0});
+}
+void EnergyRigidBodyConstraints::set_global_target_point(int idx, const Vec3& p)
+{
+    Table& T = tables[GlobalPoints];
+    if (idx < 0 || idx >= (int)T.v1.size()) throw std::runtime_error("set_global_target_point(): no such constraint");
+    T.v1[idx] = p;
+    if (stark.ctx && id_v1[GlobalPoints] >= 0) stark.check(mistark_upload(stark.ctx, id_v1[GlobalPoints]));
+}
+void EnergyRigidBodyConstraints::set_global_direction_rotation(int idx, const Mat3& R)
+{
+    Table& T = tables[GlobalDirections];
+    if (idx < 0 || idx >= (int)T.v0.size()) throw std::runtime_error("set_global_direction_rotation(): no such constraint");
+    T.v0[idx] = R * T.v0_rest[idx];
+    if (stark.ctx && id_v0[GlobalDirections] >= 0) stark.check(mistark_upload(stark.ctx, id_v0[GlobalDirections]));
+}
+void RigidBodies::set_fix_transformation(int anchor_point, int z_lock, int x_lock, const Vec3& translation, const Mat3& rotation)
+{
+    constraints->set_global_target_point(anchor_point, translation);
+    constraints->set_global_direction_rotation(z_lock, rotation);
+    constraints->set_global_direction_rotation(x_lock, rotation);
 }
 void RigidBodies::add_constraint_attachment(const RigidBodyHandler& a, const RigidBodyHandler& b)
 {

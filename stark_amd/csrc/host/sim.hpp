@@ -473,6 +473,7 @@ public:
     {
         std::vector<std::array<int32_t, 3>> conn;      // idx, a, b (b unused for the global kinds)
         std::vector<Vec3> v0, v1, v2;                   // up to three vector columns (meaning per kind)
+        std::vector<Vec3> v0_rest;                      // v0 as registered (GlobalDirections: d_loc_rest, RigidBodyConstraints.h)
         std::vector<double> s0, s1, s2;                 // up to three scalar columns
         std::vector<double> stiffness, tolerance, is_active;
         bool values_dirty = false;
@@ -482,6 +483,9 @@ public:
 
     EnergyRigidBodyConstraints(Stark& stark, spRigidBodyDynamics rb);
     int add(Kind kind, int a, int b, const Vec3* vecs, int n_vecs, const double* scalars, int n_scalars, double stiffness, double tolerance);
+    // RBCGlobalPointHandler::set_global_target_point / RBCGlobalDirectionHandler::set_rotation (rigidbody_constraints_ui.h:72,91)
+    void set_global_target_point(int idx, const Vec3& p);
+    void set_global_direction_rotation(int idx, const Mat3& R);
     // The handlers' measurements (rigidbody_constraints_ui.h:75-330 with the static functions of RigidBodyConstraints.h): {violation, force or
     // torque} of constraint `idx` of `kind` at the current state; which = 1 selects the damper of a damped spring.
     std::array<double, 2> measure(Kind kind, int idx, int which = 0) const;
@@ -491,6 +495,7 @@ private:
     Stark& stark;
     spRigidBodyDynamics rb;
     int id_stiffness[N_KINDS];
+    int id_v0[N_KINDS], id_v1[N_KINDS];
     bool _is_converged_state_valid();
     void _on_time_step_accepted();
     bool _adjust_constraints_stiffness(double cap, double multiplier, bool are_positions_set);
@@ -525,6 +530,8 @@ public:
     int add_constraint_linear_velocity(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& d_glob, double target_v, double max_force, double delay = 0.01);
     int add_constraint_angular_velocity(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& d_glob, double target_w, double max_abs_torque, double delay = 0.01);
     void add_constraint_fix(const RigidBodyHandler& body);
+    // RBCFixHandler::set_transformation (rigidbody_constraints_ui.h:369-375) on the three base constraints of a fix
+    void set_fix_transformation(int anchor_point, int z_lock, int x_lock, const Vec3& translation, const Mat3& rotation);
     void add_constraint_attachment(const RigidBodyHandler& a, const RigidBodyHandler& b);
     void add_constraint_point_with_angle_limit(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob, const Vec3& d_glob, double admissible_angle_deg);
     void add_constraint_hinge(const RigidBodyHandler& a, const RigidBodyHandler& b, const Vec3& p_glob, const Vec3& d_glob);

@@ -530,6 +530,14 @@ int mistark_sim_rb_constraint_count(mistark_sim* s, const char* type)
     _ret = (int)s->sim->rigidbodies->constraints->tables[base_kind(type ? type : "")].conn.size();
     SIM_END
 }
+int mistark_sim_rb_fix_set_transformation(mistark_sim* s, int anchor_point, int z_lock, int x_lock, const double t[3], const double R[9])
+{
+    SIM_BEGIN
+    Mat3 M;
+    for (int k = 0; k < 9; k++) M[k] = R[k];
+    s->sim->rigidbodies->set_fix_transformation(anchor_point, z_lock, x_lock, Vec3{t[0], t[1], t[2]}, M);
+    SIM_END
+}
 int mistark_sim_rb_constraint_measure(mistark_sim* s, const char* type, int idx, int which, double out[2], double* tolerance)
 {
     SIM_BEGIN

@@ -62,6 +62,7 @@ def _lib():
         L.mistark_volume_params_soft_rubber.restype = None
         L.mistark_surface_params_cotton_fabric.argtypes = [C.POINTER(SurfaceParams)]
         L.mistark_surface_params_cotton_fabric.restype = None
+        L.mistark_sim_rb_fix_set_transformation.argtypes = [p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         L.mistark_sim_create.argtypes = [C.POINTER(SimSettings), C.POINTER(p)]
         L.mistark_sim_destroy.argtypes = [p]
         L.mistark_sim_destroy.restype = None
@@ -300,6 +301,23 @@ class Simulation:
 
     def rb_add_torque(self, rb, t):
         self._ck(self.L.mistark_sim_rb_add_torque(self.h, rb, _d3(t)))
+
+    def rb_add_fix(self, rb):
+        """RigidBodies::add_constraint_fix; returns the handler (anchor point, z lock, x lock) for rb_fix_set_transformation."""
+        g, d = self.rb_constraint_count("global_point"), self.rb_constraint_count("global_direction")
+        self.rb_add_constraint("fix", rb)
+        return (g, d, d + 1)
+
+    def rb_fix_set_transformation(self, fix, translation, angle_deg=0.0, axis=(0.0, 0.0, 1.0)):
+        """RBCFixHandler::set_transformation(translation, angle_deg, axis) (rigidbody_constraints_ui.h:376-379)."""
+        a = np.asarray(axis, dtype=np.float64)
+        a = a / np.linalg.norm(a)
+        th = np.deg2rad(angle_deg)
+        K = np.array([[0.0, -a[2], a[1]], [a[2], 0.0, -a[0]], [-a[1], a[0], 0.0]])
+        R = np.ascontiguousarray(np.eye(3) + np.sin(th) * K + (1.0 - np.cos(th)) * (K @ K))
+        t = np.ascontiguousarray(translation, dtype=np.float64)
+        self._ck(self.L.mistark_sim_rb_fix_set_transformation(self.h, int(fix[0]), int(fix[1]), int(fix[2]), t.ctypes.data_as(C.POINTER(C.c_double)),
+                                                              R.ctypes.data_as(C.POINTER(C.c_double))))
 
     def rb_constraint_count(self, base_type) -> int:
         return self._ck(self.L.mistark_sim_rb_constraint_count(self.h, base_type.encode()))

@@ -64,6 +64,9 @@ FIXTURES = {
     # the reference's example hanging_deformable_box (examples/main.cpp:76-107): 12 k tets, 6 steps
     "traj_cfg_example_hanging_box": ("traj", "hangingbox", "n=10 steps=6 slim=1 threads=8"),
     "traj_cfg3_blockbox_10": ("traj", "blockbox", "nx=10 ny=10 nz=10 L=0.5 gap=0.002 thickness=0.002 bx=1.5 kmin=1e6 steps=4 boxfirst=1 slim=1 threads=8"),
+    # configs[0] = the README's spinning box under a 32 x 32 cloth (README.md:53-95: thickness 2.5 mm, no friction, box turned 90 deg/s by
+    # the per-step script), 10 frames: step log and final state
+    "traj_cfg0_spinning_box_cloth_32": ("traj", "clothbox", "n=32 mu=0 spin=90 steps=10 slim=1 threads=8"),
     # configs[4] at fixture size: tet block on a fixed floor + cloth over it + chain of 4 hinged boxes over the cloth, contact + friction
     # between the layers (step log and final state)
     "traj_cfg4_mixed_small": ("traj", "mixed", "nx=4 ny=4 nz=4 nc=10 nrb=4 L=0.4 gap=0.003 thickness=0.002 bx=1.2 kmin=1e6 link=0.04 steps=5 slim=1 threads=8"),
