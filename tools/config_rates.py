@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Newton-steps/s and host stage timers of the BASELINE configs other than the bench's (configs[1], [2], [4]) on one GPU.
-Usage (GPU box): python tools/config_rates.py [cfg1] [cfg2] [cfg4]   -> one JSON line per config."""
+"""Newton-steps/s and host stage timers of the BASELINE configs other than the bench's (configs[0], [1], [2], [4]) on one GPU.
+Usage (GPU box): python tools/config_rates.py [cfg0] [cfg1] [cfg2] [cfg4]   -> one JSON line per config."""
 import json
 import os
 import sys
@@ -24,6 +24,18 @@ def contact_sim(thickness, kmin=None):
         gp.min_contact_stiffness = kmin
     sim.set_contact_global_params(gp)
     return sim
+
+
+def cfg0():
+    """README hello world: 32 x 32 cloth on a box turned by the per-step script."""
+    sim = contact_sim(0.0025)
+    sim.add_surface_grid("cloth", (0.4, 0.4), (32, 32), S.cotton_fabric())
+    box = sim.add_rigid_box("box", 1.0, (0.08, 0.08, 0.08))
+    anchor = (0.0, 0.0, -0.08)
+    sim.rb_add_translation(box, anchor)
+    fix = sim.rb_add_fix(box)
+    sim.script = lambda: sim.rb_fix_set_transformation(fix, anchor, 90.0 * sim.info().current_time, (0.0, 0.0, 1.0))
+    return sim, 10
 
 
 def cfg1():
@@ -55,13 +67,16 @@ def cfg4():
 
 
 def main():
-    names = sys.argv[1:] or ["cfg1", "cfg2", "cfg4"]
+    names = sys.argv[1:] or ["cfg0", "cfg1", "cfg2", "cfg4"]
     for name in names:
         sim, steps = globals()[name]()
+        script = getattr(sim, "script", lambda: None)
+        script()
         assert sim.run_one_step()  # warm-up: pattern construction, first detection
         a = sim.info()
         t0 = time.perf_counter()
         for _ in range(steps):
+            script()
             assert sim.run_one_step()
         wall = time.perf_counter() - t0
         b = sim.info()
