@@ -713,6 +713,11 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "proj_rec_cap") ctx->c.proj_rec_cap = value;
     else if (n == "spmv_variant") ctx->c.spmv_variant = value;
     else if (n == "proj_variant") ctx->c.proj_variant = value;
+    else if (n == "spmv_chunk_tiles") {
+        if (value < 0 || value > 64) throw Error("spmv_chunk_tiles: 0 (automatic) .. 64");
+        ctx->c.spmv_chunk_tiles = value;
+        ctx->c.part[0].dirty = true;  // the storage layout depends on it
+    }
     else throw Error("unknown option '" + n + "'");
     API_END(0)
 }

@@ -662,7 +662,7 @@ __global__ __launch_bounds__(BLOCK) void k_remap_slots(uint32_t* __restrict__ sl
 static int chunk_tiles_for(int64_t nnzb) { return nnzb >= (2 << 20) ? SPMV_CHUNK_TILES : (nnzb >= (1 << 20) ? 4 : 2); }
 static void build_aligned(Context& c, BsrPart& m)
 {
-    const int CT = chunk_tiles_for(m.nnzb);
+    const int CT = c.spmv_chunk_tiles > 0 ? c.spmv_chunk_tiles : chunk_tiles_for(m.nnzb);
     m.chunk_tiles = CT;
     const int64_t nbr = c.nbr;
     std::vector<int64_t> rp((size_t)nbr + 1);

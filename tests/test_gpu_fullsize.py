@@ -94,11 +94,13 @@ def _bsr_matvec(row_ptr, cols, vals, x):
     return A @ x
 
 
+@pytest.mark.parametrize("chunk_tiles", [0, 1, 4, 8])
 @pytest.mark.parametrize("n_cloth", [24, 40])
-def test_spmv_rows_longer_than_a_chunk(n_cloth):
-    """The static matrix part is stored in row-aligned chunks of 8 tiles (512 blocks); a rigid body attached to every point of a
-    cloth owns two block rows with one block per point (625 / 1681 here): at 24 x 24 they still fit a chunk of their own, at 40 x 40 they
-    take the over-long-row path. The device product must equal the product with the exported matrix either way."""
+def test_spmv_rows_longer_than_a_chunk(n_cloth, chunk_tiles):
+    """The static matrix part is stored in row-aligned chunks of 2, 4 or 8 tiles by matrix size (8 tiles = 512 blocks; forced here, 0 =
+    automatic); a rigid body attached to every point of a cloth owns two block rows with one block per point (625 / 1681 here): they fit
+    a chunk of their own or take the over-long-row path depending on the chunk length. The device product must equal the product with
+    the exported matrix either way."""
     from stark_amd import capi
     from stark_amd import sim as S
 
@@ -113,6 +115,7 @@ def test_spmv_rows_longer_than_a_chunk(n_cloth):
     sim.prescribe_inside_aabb(cloth, (0.5, 0.5, 0.0), (0.001, 0.001, 0.001), 1e6)
     assert sim.run_one_step()
     eng = _Eng(sim)
+    eng.set_option("spmv_chunk_tiles", chunk_tiles)
     eng.eval(capi.EVAL_P_G_H)
     eng.assemble()
     row_ptr, cols, vals = eng.get_bsr()
