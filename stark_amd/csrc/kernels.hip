@@ -659,7 +659,8 @@ __global__ __launch_bounds__(BLOCK) void k_remap_slots(uint32_t* __restrict__ sl
     if (s != 0xFFFFFFFFu) slots[k] = store_slot[s];
 }
 // a 157 k-DoF matrix in chunks of 8 tiles is 1750 wavefronts for 1024 SIMDs: 14.5 us per launch, latency-bound
-static int chunk_tiles_for(int64_t nnzb) { return nnzb >= (2 << 20) ? SPMV_CHUNK_TILES : (nnzb >= (1 << 20) ? 4 : 2); }
+// measured (us per CG iteration at 1 / 2 / 4 / 8 tiles): 0.27 M blocks 20.7 / 18.2 / 19.8 / 22.9; 0.9 M blocks 33.1 / 33.7 / 29.3 / 33.4; 2.5 M blocks: 8 tiles
+static int chunk_tiles_for(int64_t nnzb) { return nnzb >= (2 << 20) ? SPMV_CHUNK_TILES : (nnzb >= (1 << 19) ? 4 : 2); }
 static void build_aligned(Context& c, BsrPart& m)
 {
     const int CT = c.spmv_chunk_tiles > 0 ? c.spmv_chunk_tiles : chunk_tiles_for(m.nnzb);
