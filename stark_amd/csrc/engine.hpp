@@ -281,7 +281,8 @@ void prepare(Context& c);
 void ensure_pattern(Context& c);
 void contact_destroy(struct ContactSystem* cs);
 int register_potential(Context& c, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings);
-void eval(Context& c, int mode, double* E, double* grad_host);
+void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs = nullptr);
+void reduce_dot_and_max_abs(Context& c, const double* a, const double* b, int64_t n, double* dot, double* max_abs_a);
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active,
              int64_t* n_projected_now, int64_t* n_changed_now);
 void assemble(Context& c);

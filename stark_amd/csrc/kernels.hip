@@ -488,6 +488,20 @@ double reduce_dot(Context& c, const double* a, const double* b, int64_t n)
     for (int i = 0; i < g; i++) s += h[i];
     return s;
 }
+// two reductions, one read-back (a read-back idles the GPU for 15-60 us; the Newton loop has ~20 of them per iteration)
+void reduce_dot_and_max_abs(Context& c, const double* a, const double* b, int64_t n, double* dot, double* max_abs_a)
+{
+    const int g = grid_for(n, BLOCK, VEC_GRID);
+    hipLaunchKernelGGL(k_dot, dim3(g), dim3(BLOCK), 0, c.stream, a, b, n, c.partials.p);
+    hipLaunchKernelGGL(k_max_abs, dim3(g), dim3(BLOCK), 0, c.stream, a, n, c.partials.p + g);
+    double* h = host_scratch(c, 2 * MAX_PARTIALS);
+    fetch_partials(c, 2 * g, h, c.partials.p);
+    double s = 0.0, m = 0.0;
+    for (int i = 0; i < g; i++) s += h[i];
+    for (int i = 0; i < g; i++) m = std::max(m, h[g + i]);
+    *dot = s;
+    *max_abs_a = m;
+}
 static double reduce_sum(Context& c, const double* v, int64_t n)
 {
     const int g = grid_for(n, BLOCK, VEC_GRID);
@@ -993,7 +1007,7 @@ void ensure_pattern(Context& c)
 // ======================================================================================================================
 // eval()
 // ======================================================================================================================
-void eval(Context& c, int mode, double* E, double* grad_host)
+void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs)
 {
     prepare(c);
     if (mode != MISTARK_EVAL_P) {
@@ -1009,7 +1023,21 @@ void eval(Context& c, int mode, double* E, double* grad_host)
         c.matrix_current = false;
         c.n_projected_total = 0;
     }
-    double e = c.n_elem_total ? reduce_sum(c, c.elemE.p, (int64_t)c.n_elem_total) : 0.0;
+    double e = 0.0;
+    const bool with_max = grad_max_abs && mode != MISTARK_EVAL_P && c.world == 1 && c.n_elem_total > 0;
+    if (with_max) {  // energy and ||grad||_inf in one read-back
+        const int g1 = grid_for((int64_t)c.n_elem_total, BLOCK, VEC_GRID), g2 = grid_for(c.ndofs, BLOCK, VEC_GRID);
+        hipLaunchKernelGGL(k_sum, dim3(g1), dim3(BLOCK), 0, c.stream, (const double*)c.elemE.p, (int64_t)c.n_elem_total, c.partials.p);
+        hipLaunchKernelGGL(k_max_abs, dim3(g2), dim3(BLOCK), 0, c.stream, (const double*)c.grad.p, c.ndofs, c.partials.p + g1);
+        double* h = host_scratch(c, 2 * MAX_PARTIALS);
+        fetch_partials(c, g1 + g2, h, c.partials.p);
+        double m = 0.0;
+        for (int i = 0; i < g1; i++) e += h[i];
+        for (int i = 0; i < g2; i++) m = std::max(m, h[g1 + i]);
+        *grad_max_abs = m;
+    } else {
+        e = c.n_elem_total ? reduce_sum(c, c.elemE.p, (int64_t)c.n_elem_total) : 0.0;
+    }
     if (c.world > 1) {
         // one collective for the energy and the gradient: E rides behind the last DoF
         MS_CHECK(hipMemcpyAsync(c.grad.p + c.ndofs, &e, sizeof(double), hipMemcpyHostToDevice, c.stream));
@@ -1018,6 +1046,7 @@ void eval(Context& c, int mode, double* E, double* grad_host)
         fetch(c, &e, c.grad.p + c.ndofs, sizeof(double));
     }
     if (E) *E = e;
+    if (grad_max_abs && !with_max && mode != MISTARK_EVAL_P) *grad_max_abs = reduce_max_abs(c, c.grad.p, c.ndofs);
     if (grad_host && mode != MISTARK_EVAL_P) {
         MS_CHECK(hipMemcpyAsync(grad_host, c.grad.p, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
         MS_CHECK(hipStreamSynchronize(c.stream));

@@ -59,12 +59,12 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
             break;
         }
         call_void(cb ? cb->before_energy_evaluation : nullptr);
+        double residual = 0.0;
         {
             Timer t(st.t_eval_pgh);
-            eval(c, MISTARK_EVAL_P_G_H, &E0, nullptr);
+            eval(c, MISTARK_EVAL_P_G_H, &E0, nullptr, &residual);  // default residual: ||grad||_inf (solver_utils.h:28), read back with the energy
             st.n_evaluations++;
         }
-        const double residual = reduce_max_abs(c, c.grad.p, ndofs);  // default residual: ||grad||_inf (solver_utils.h:28)
         if (it == 0) res_0 = residual;
         if (!(residual == residual)) {
             // NaN gradient: the reference would spin forever here (every comparison below is false and the projection threshold
@@ -87,6 +87,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
             }
         }
 
+        double du_max_solved = 0.0;
         bool assembled = false;  // "hess == nullptr" in the reference
         bool solved = false;
         while (!solved) {
@@ -155,7 +156,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
             }
             bool descends = false;
             if (ok) {
-                du_dot_grad = reduce_dot(c, c.du.p, c.grad.p, ndofs);
+                reduce_dot_and_max_abs(c, c.du.p, c.grad.p, ndofs, &du_dot_grad, &du_max_solved);  // (max |du| is needed right after the loop)
                 descends = du_dot_grad < 0.0;
                 if (!descends && !can_project_more) {
                     result = MISTARK_STEP_DOES_NOT_DESCEND;
@@ -182,7 +183,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
         st.n_hessians += (int64_t)c.n_elem_total;
         st.n_projected_hessians += c.n_projected_total;
 
-        double du_max = reduce_max_abs(c, c.du.p, ndofs);
+        double du_max = du_max_solved;
         if (it >= s.min_iterations && du_max < s.step_tolerance) {
             result = MISTARK_SUCCESSFUL;
             break;
