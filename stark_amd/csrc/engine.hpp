@@ -221,6 +221,8 @@ struct Context
     DevBuf<int32_t> diag_slot[2];   // per block row: slot of the diagonal block in each part, -1 if absent
     int spmv_variant = 0;          // micro-benchmark ablation variant
     int spmv_chunk_tiles = 0;      // tiles per SpMV chunk, 0 = by matrix size (chunk_tiles_for); tests force 1..8
+    DevBuf<unsigned char> sel_desc;  // descriptor table of k_project_select_multi
+    std::vector<unsigned char> sel_desc_host;
     DevBuf<double> vlong_part;
     DevBuf<double> grad_hot;
     DevBuf<int32_t> hot_rows;      // global block row of every hot row

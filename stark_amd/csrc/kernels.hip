@@ -1090,6 +1090,41 @@ __global__ __launch_bounds__(BLOCK) void k_project_select(int n_elem, PotArgs a,
     list[idx] = (uint32_t)e;
 }
 
+// the same selection for ALL potentials in one launch (a round used to launch one k_project_select per potential: two dozen launches of
+// a few microseconds each, 3.6 rounds per Newton iteration on configs[3])
+struct SelDesc
+{
+    const int32_t* conn;
+    uint8_t* is_projected;
+    uint32_t* list;
+    int conn_stride, e_begin, e_count, NB, counter, first_block;
+    int dof_col[MAX_NB], dof_row_off[MAX_NB];
+};
+__global__ __launch_bounds__(BLOCK) void k_project_select_multi(const SelDesc* __restrict__ D, int n_desc, const uint8_t* __restrict__ active_blocks, int64_t* __restrict__ counters)
+{
+    __shared__ int s_k;
+    if (threadIdx.x == 0) {
+        int k = 0;
+        while (k + 1 < n_desc && (int)blockIdx.x >= D[k + 1].first_block) k++;
+        s_k = k;
+    }
+    __syncthreads();
+    const SelDesc& d = D[s_k];
+    const int le = ((int)blockIdx.x - d.first_block) * BLOCK + threadIdx.x;
+    if (le >= d.e_count) return;
+    const int e = d.e_begin + le;
+    if (d.is_projected[e]) return;
+    if (active_blocks) {
+        bool touch = false;
+        const int32_t* ce = d.conn + (size_t)e * d.conn_stride;
+        for (int k = 0; k < d.NB; k++) touch = touch || active_blocks[d.dof_row_off[k] + ce[d.dof_col[k]]];
+        if (!touch) return;
+    }
+    d.is_projected[e] = 1;
+    const unsigned long long idx = atomicAdd((unsigned long long*)&counters[d.counter], 1ull);
+    d.list[idx] = (uint32_t)e;
+}
+
 struct ProjRecords  // sharded projection: where k_project_eig records its matrix deltas (pos == nullptr: not recording)
 {
     uint32_t* pos;
@@ -1598,11 +1633,38 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     }
     // 1) selection: per-potential lists of element ids (counter 4 + potential index)
     c.proj_list.ensure(std::max<size_t>(c.n_elem_total, 1));
-    for (int pi = 0; pi < np; pi++) {
-        Potential& P = c.pots[pi];
-        if (P.args.e_count == 0) continue;
-        hipLaunchKernelGGL(k_project_select, dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.n_elem, P.args, P.NB, c.is_projected.p + P.e_off, act, c.proj_list.p + P.e_off,
-                           c.counters.p, 4 + pi);
+    {
+        // (the table lives in the context: the copy below may still read it after this scope; the read-back that follows the selection
+        // orders it before the next round overwrites it)
+        c.sel_desc_host.resize((size_t)np * sizeof(SelDesc));
+        SelDesc* desc_h = reinterpret_cast<SelDesc*>(c.sel_desc_host.data());
+        int n_desc = 0;
+        int n_blocks = 0;
+        for (int pi = 0; pi < np; pi++) {
+            Potential& P = c.pots[pi];
+            if (P.args.e_count == 0) continue;
+            SelDesc d{};
+            d.conn = P.args.conn;
+            d.is_projected = c.is_projected.p + P.e_off;
+            d.list = c.proj_list.p + P.e_off;
+            d.conn_stride = P.args.conn_stride;
+            d.e_begin = P.args.e_begin;
+            d.e_count = P.args.e_count;
+            d.NB = P.NB;
+            d.counter = 4 + pi;
+            d.first_block = n_blocks;
+            for (int k = 0; k < MAX_NB; k++) {
+                d.dof_col[k] = P.args.dof_col[k];
+                d.dof_row_off[k] = P.args.dof_row_off[k];
+            }
+            n_blocks += (P.args.e_count + BLOCK - 1) / BLOCK;
+            desc_h[n_desc++] = d;
+        }
+        if (n_desc > 0) {
+            c.sel_desc.ensure((size_t)n_desc * sizeof(SelDesc));
+            MS_CHECK(hipMemcpyAsync(c.sel_desc.p, desc_h, (size_t)n_desc * sizeof(SelDesc), hipMemcpyHostToDevice, c.stream));
+            hipLaunchKernelGGL(k_project_select_multi, dim3(n_blocks), dim3(BLOCK), 0, c.stream, (const SelDesc*)c.sel_desc.p, n_desc, act, c.counters.p);
+        }
     }
     int64_t h[128];
     fetch(c, h, c.counters.p, sizeof(h));
