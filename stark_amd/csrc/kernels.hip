@@ -1055,7 +1055,7 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
 
 // ======================================================================================================================
 // PSD projection (project_to_PD.cpp:12-32; ElementHessians.cpp:48-67,79-182).
-//   k_project_select : marks the not-yet-projected elements that touch an active block row and appends them to a list
+//   k_project_select_multi : marks the not-yet-projected elements that touch an active block row and appends them to a list
 //   k_project_eig    : one WAVEFRONT per listed element: parallel-order cyclic Jacobi on the n x n matrix held in LDS
 //                      (n/2 disjoint rotations per round, lanes own matrix entries), eigenvalues < eps clamped (or mirrored),
 //                      V L V^T rebuilt only if something changed; the difference (projected - original) is added to the
@@ -1071,27 +1071,8 @@ __device__ __forceinline__ size_t tile_val_index(uint32_t slot, int comp)
     return base + 512 + lane;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_project_select(int n_elem, PotArgs a, int NB, uint8_t* __restrict__ is_projected, const uint8_t* __restrict__ active_blocks,
-                                                          uint32_t* __restrict__ list, int64_t* __restrict__ counters, int list_counter)
-{
-    const int le = blockIdx.x * BLOCK + threadIdx.x;
-    if (le >= a.e_count) return;
-    const int e = a.e_begin + le;
-    (void)n_elem;
-    if (is_projected[e]) return;
-    if (active_blocks) {
-        bool touch = false;
-        const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
-        for (int k = 0; k < NB; k++) touch = touch || active_blocks[a.dof_row_off[k] + ce[a.dof_col[k]]];
-        if (!touch) return;
-    }
-    is_projected[e] = 1;
-    const unsigned long long idx = atomicAdd((unsigned long long*)&counters[list_counter], 1ull);
-    list[idx] = (uint32_t)e;
-}
-
-// the same selection for ALL potentials in one launch (a round used to launch one k_project_select per potential: two dozen launches of
-// a few microseconds each, 3.6 rounds per Newton iteration on configs[3])
+// selection for ALL potentials in one launch (one launch per potential was two dozen launches of a few microseconds each, 3.6 rounds per
+// Newton iteration on configs[3]): marks the not-yet-projected elements that touch an active block row and appends them to their lists
 struct SelDesc
 {
     const int32_t* conn;
