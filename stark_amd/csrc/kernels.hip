@@ -636,6 +636,7 @@ __global__ __launch_bounds__(BLOCK) void k_chunk_fill(const int64_t* __restrict_
 constexpr uint32_t LONG_SLOT = 48;  // BSR blocks with more contributions than this are summed by a whole wavefront (k_assemble_long)
 constexpr uint32_t VERY_LONG_SLOT = 4096;  // ... and beyond this by VLONG_SPLIT wavefronts and a second pass (the blocks of a rigid body under 10^4..10^5 contacts)
 constexpr int VLONG_SPLIT = 64;
+__global__ void k_copy_u32(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) { *dst = *src; }
 __global__ __launch_bounds__(BLOCK) void k_long_slots(const uint32_t* __restrict__ slot_start, int64_t nnzb, uint32_t* __restrict__ list, uint32_t* __restrict__ vlist,
                                                      int* __restrict__ count)
 {
@@ -836,10 +837,13 @@ static void build_pattern(Context& c, int part)
     MS_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp3, row_head, rscan, (int)m.nnzb, c.stream));
     c.cub_tmp.ensure(tmp3);
     MS_CHECK(hipcub::DeviceScan::InclusiveSum(c.cub_tmp.p, tmp3, row_head, rscan, (int)m.nnzb, c.stream));
-    uint32_t nrows32 = 0;
-    fetch(c, &nrows32, rscan + (m.nnzb - 1), sizeof(uint32_t));
-    fetch(c, n_long_h, c.counters.p, 2 * sizeof(int));
-    m.n_rows = nrows32;
+    // the row count joins the two block counts: one read-back instead of two
+    hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(1), 0, c.stream, (const uint32_t*)(rscan + (m.nnzb - 1)), (uint32_t*)c.counters.p + 2);
+    int counts_h[3] = {0, 0, 0};
+    fetch(c, counts_h, c.counters.p, 3 * sizeof(int));
+    n_long_h[0] = counts_h[0];
+    n_long_h[1] = counts_h[1];
+    m.n_rows = (uint32_t)counts_h[2];
     m.n_long = n_long_h[0];
     m.n_vlong = n_long_h[1];
     m.rowmap.ensure((size_t)m.n_rows);
