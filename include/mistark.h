@@ -243,7 +243,8 @@ int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settin
  * closed-form tet kernels are then cross-checked against them); "atomic_assembly" = scatter assembly with float atomics
  * instead of the deterministic gather; "proj_variant" = PSD projection cross-checks, bits: 1 = eigen-decomposition with the
  * matrix in LDS instead of registers, 2 = one launch per potential instead of one for all short lists, 4 = IEEE division /
- * square root for the rotation angles; "proj_rec_cap" = record capacity of the sharded projection exchange (tests); "spmv_chunk_tiles" = tiles per SpMV chunk (0 = by matrix size).
+ * square root for the rotation angles; "proj_rec_cap" = record capacity of the sharded projection exchange (tests); "spmv_chunk_tiles" = tiles per SpMV chunk (0 = by matrix size); "no_contact_cache" = run every contact search even when
+ * nothing it reads has changed since the previous one.
  * Returns 0, or < 0 for an unknown name. The environment variable
  * MISTARK_OPTIONS="name=value,name=value" applies the same switches inside mistark_create (for a process that cannot be
  * edited: a test suite, a profiler run); a bad entry makes mistark_create fail with -6. MISTARK_POISON=1 fills every fresh

@@ -166,6 +166,7 @@ const char* mistark_supported_potential(int i) { return (i >= 0 && i < n_kinds()
 int mistark_add_dof_set(mistark_ctx* ctx, const char* label, double* host, int64_t n_scalars)
 {
     API_BEGIN
+    ctx->c.data_version++;
     if (n_scalars % 3 != 0) throw Error("DoF set size must be a multiple of 3");
     DofSet s;
     s.label = label ? label : "";
@@ -179,6 +180,7 @@ int mistark_add_dof_set(mistark_ctx* ctx, const char* label, double* host, int64
 int mistark_resize_dof_set(mistark_ctx* ctx, int set, double* host, int64_t n_scalars)
 {
     API_BEGIN
+    ctx->c.data_version++;
     if (set < 0 || set >= (int)ctx->c.dof_sets.size()) throw Error("bad DoF set");
     if (n_scalars % 3 != 0) throw Error("DoF set size must be a multiple of 3");
     Context& c = ctx->c;
@@ -199,6 +201,7 @@ int mistark_resize_dof_set(mistark_ctx* ctx, int set, double* host, int64_t n_sc
 int mistark_array(mistark_ctx* ctx, const double* host, int64_t n_items, int stride)
 {
     API_BEGIN
+    ctx->c.data_version++;
     Context& c = ctx->c;
     if (stride <= 0) throw Error("bad stride");
     for (size_t i = 0; i < c.arrays.size(); i++) {
@@ -228,6 +231,7 @@ int mistark_array(mistark_ctx* ctx, const double* host, int64_t n_items, int str
 int mistark_array_rebind(mistark_ctx* ctx, int array, const double* host, int64_t n_items)
 {
     API_BEGIN
+    ctx->c.data_version++;
     Context& c = ctx->c;
     if (array < 0 || array >= (int)c.arrays.size()) throw Error("bad array id");
     Array& a = c.arrays[array];
@@ -252,6 +256,7 @@ static void upload_one(Context& c, Array& a)
 int mistark_upload(mistark_ctx* ctx, int array)
 {
     API_BEGIN
+    ctx->c.data_version++;
     Context& c = ctx->c;
     if (c.layout_dirty) {
         // sizes may have changed: mark and let prepare() do the copy
@@ -288,6 +293,7 @@ int mistark_download(mistark_ctx* ctx, int array)
 int mistark_array_axpby(mistark_ctx* ctx, int dst, double a, int x, double b, int y)
 {
     API_BEGIN
+    ctx->c.data_version++;
     Context& c = ctx->c;
     prepare(c);
     const int na = (int)c.arrays.size();
@@ -300,6 +306,7 @@ int mistark_array_axpby(mistark_ctx* ctx, int dst, double a, int x, double b, in
 int mistark_array_fill(mistark_ctx* ctx, int dst, double value)
 {
     API_BEGIN
+    ctx->c.data_version++;
     Context& c = ctx->c;
     prepare(c);
     if (dst < 0 || dst >= (int)c.arrays.size()) throw Error("bad array id");
@@ -310,6 +317,7 @@ int mistark_array_fill(mistark_ctx* ctx, int dst, double value)
 int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings)
 {
     API_BEGIN
+    ctx->c.data_version++;
     _ret = register_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings);
     API_END(_ret)
 }
@@ -317,12 +325,14 @@ int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* 
                              const int32_t* ops, const double* constants, int32_t n_ops, int32_t n_inputs, const int32_t* cond_ops, const double* cond_constants, int32_t n_cond_ops)
 {
     API_BEGIN
+    ctx->c.data_version++;
     _ret = register_custom_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings, ops, constants, n_ops, n_inputs, cond_ops, cond_constants, n_cond_ops);
     API_END(_ret)
 }
 int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)
 {
     API_BEGIN
+    ctx->c.data_version++;
     Context& c = ctx->c;
     if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
     const int part = dynamic ? 1 : 0;
@@ -336,6 +346,7 @@ int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)
 int mistark_potential_update_connectivity(mistark_ctx* ctx, int potential, const int32_t* conn, int32_t n_elem)
 {
     API_BEGIN
+    ctx->c.data_version++;
     Context& c = ctx->c;
     if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
     if (n_elem < 0) throw Error("bad connectivity shape");
@@ -366,6 +377,7 @@ int mistark_get_dofs(mistark_ctx* ctx, double* u_host)
 int mistark_set_dofs(mistark_ctx* ctx, const double* u_host)
 {
     API_BEGIN
+    ctx->c.data_version++;
     Context& c = ctx->c;
     prepare(c);
     MS_CHECK(hipMemcpyAsync(c.u.p, u_host, (size_t)c.ndofs * sizeof(double), hipMemcpyHostToDevice, c.stream));
@@ -385,6 +397,7 @@ int mistark_dofs_to_host_arrays(mistark_ctx* ctx)
 int mistark_dofs_from_host_arrays(mistark_ctx* ctx)
 {
     API_BEGIN
+    ctx->c.data_version++;
     Context& c = ctx->c;
     prepare(c);
     for (auto& s : c.dof_sets)
@@ -713,6 +726,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "proj_rec_cap") ctx->c.proj_rec_cap = value;
     else if (n == "spmv_variant") ctx->c.spmv_variant = value;
     else if (n == "proj_variant") ctx->c.proj_variant = value;
+    else if (n == "no_contact_cache") ctx->c.no_contact_cache = value != 0;
     else if (n == "spmv_chunk_tiles") {
         if (value < 0 || value > 64) throw Error("spmv_chunk_tiles: 0 (automatic) .. 64");
         ctx->c.spmv_chunk_tiles = value;

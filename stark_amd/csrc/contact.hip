@@ -819,6 +819,11 @@ struct ContactSystem
     bool brute_force = false;  // ablation / fallback: LDS-tiled all-pairs kernels
     int64_t n_prev = -1;  // keys of the barrier tables currently installed (-1: none)
     DevBuf<int> counters;  // [0] candidates, [1] intersections, [2] differs, [8..8+N_TABLES] bounds
+    // result of the last barrier-table search and the inputs it saw (Context::data_version, dt): an identical request is answered from here
+    bool cache_valid = false;
+    uint64_t cache_version = 0;
+    double cache_dt = 0.0;
+    int64_t cache_n = 0;
     DevBuf<int> sweep_tasks;  // (entry, first candidate, end) of the split-off parts of long sweep ranges + their count
     DevBuf<uint8_t> cub_tmp;
     DevBuf<TableDev> tables_dev;
@@ -1072,6 +1077,8 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
 {
     ContactSystem& cs = CS(c);
     if (cs.meshes.empty()) return 0;
+    if (friction) cs.cache_valid = false;
+    else if (cs.cache_valid && !c.no_contact_cache && !c.layout_dirty && cs.cache_version == c.data_version && cs.cache_dt == dt) return cs.cache_n;
     double tp = now_s();
     auto lap = [&](int k) {
         const double t = now_s();
@@ -1194,6 +1201,10 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
         cs.prev.ensure(std::max<size_t>((size_t)n, 1));
         if (n > 0) MS_CHECK(hipMemcpyAsync(cs.prev.p, sorted, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c.stream));
         cs.n_prev = n;
+        cs.cache_valid = true;
+        cs.cache_version = c.data_version;  // (after this function's own layout changes)
+        cs.cache_dt = dt;
+        cs.cache_n = n;
     }
     lap(6);
     return n;
@@ -1260,6 +1271,7 @@ extern "C" {
 int mistark_contact_init(mistark_ctx* ctx, const mistark_contact_arrays* arrays)
 {
     CAPI_BEGIN
+    ctx->c.data_version++;  // (invalidates the cached detection)
     if (!arrays) throw Error("contact: null arrays");
     const int32_t* ids = &arrays->v1;
     for (int i = 0; i < 12; i++)
@@ -1272,12 +1284,14 @@ int mistark_contact_add_mesh(mistark_ctx* ctx, int kind, int idx_in_ps, const in
 {
     int g = -1;
     CAPI_BEGIN
+    ctx->c.data_version++;  // (invalidates the cached detection)
     g = contact_add_mesh(ctx->c, kind, idx_in_ps, vertex_index, n_vertices, triangles, n_triangles, edges, n_edges);
     CAPI_END(g)
 }
 int mistark_contact_set_friction(mistark_ctx* ctx, int a, int b, double mu)
 {
     CAPI_BEGIN
+    ctx->c.data_version++;  // (invalidates the cached detection)
     ContactSystem& cs = CS(ctx->c);
     const int nm = (int)cs.meshes.size();
     if (a < 0 || b < 0 || a >= nm || b >= nm) throw Error("contact: bad group id");
@@ -1288,6 +1302,7 @@ int mistark_contact_set_friction(mistark_ctx* ctx, int a, int b, double mu)
 int mistark_contact_disable_collision(mistark_ctx* ctx, int a, int b)
 {
     CAPI_BEGIN
+    ctx->c.data_version++;  // (invalidates the cached detection)
     ContactSystem& cs = CS(ctx->c);
     const int nm = (int)cs.meshes.size();
     if (a < 0 || b < 0 || a >= nm || b >= nm) throw Error("contact: bad group id");
@@ -1299,6 +1314,7 @@ int mistark_contact_disable_collision(mistark_ctx* ctx, int a, int b)
 int mistark_contact_set_broad_phase(mistark_ctx* ctx, int brute_force)
 {
     CAPI_BEGIN
+    ctx->c.data_version++;  // (invalidates the cached detection)
     ContactSystem& cs = CS(ctx->c);
     cs.brute_force = brute_force != 0;
     cs.n_prev = -1;
@@ -1307,6 +1323,7 @@ int mistark_contact_set_broad_phase(mistark_ctx* ctx, int brute_force)
 int mistark_contact_enable(mistark_ctx* ctx, int point_triangle, int edge_edge)
 {
     CAPI_BEGIN
+    ctx->c.data_version++;  // (invalidates the cached detection)
     ContactSystem& cs = CS(ctx->c);
     cs.pt_enabled = point_triangle != 0;
     cs.ee_enabled = edge_edge != 0;

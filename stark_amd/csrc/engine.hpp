@@ -248,6 +248,10 @@ struct Context
     size_t h_pin_bytes = 0;
     uint8_t* pub = nullptr;         // coherent pinned page small read-backs are published into (kernels.hip: publish)
     uint32_t pub_seq = 0;
+    // bumped by everything that can change what a contact detection sees (DoFs, bound arrays, layout): the detector skips a search whose
+    // inputs are those of its previous one (the evaluation that opens a Newton iteration repeats the accepted line-search state)
+    uint64_t data_version = 1;
+    bool no_contact_cache = false;  // option "no_contact_cache": every detection request runs the search (cross-check)
     size_t h_scratch_n = 0;
 
     // SpMV timing

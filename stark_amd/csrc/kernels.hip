@@ -515,11 +515,13 @@ static double reduce_sum(Context& c, const double* v, int64_t n)
 void vec_axpby(Context& c, double* dst, double a, const double* x, double b, const double* y, int64_t n)
 {
     if (n == 0) return;
+    c.data_version++;  // (dst may be the DoF vector or a bound array)
     hipLaunchKernelGGL(k_axpby, dim3(grid_for(n, BLOCK, 2048)), dim3(BLOCK), 0, c.stream, dst, a, x, b, y, n);
 }
 void vec_fill(Context& c, double* dst, double v, int64_t n)
 {
     if (n == 0) return;
+    c.data_version++;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, BLOCK, 2048)), dim3(BLOCK), 0, c.stream, dst, v, n);
 }
 void vec_neg(Context& c, double* dst, const double* x, int64_t n) { vec_axpby(c, dst, -1.0, x, 0.0, nullptr, n); }
@@ -878,6 +880,7 @@ static void build_pattern(Context& c, int part)
 void prepare(Context& c)
 {
     if (!c.layout_dirty) return;
+    c.data_version++;
     if (c.layout_dirty) {
         // DoF layout
         int64_t off = 0;

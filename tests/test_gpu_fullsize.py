@@ -52,6 +52,9 @@ def test_full_size_properties():
     n = eng.ndofs
     dt = info.dt
     # contact detection is a pure function of the state: twice the same tables, and the all-pairs search finds the same set
+    # (a repeated request at an unchanged state is normally answered from the detector's cache: switched off here)
+    assert eng.contact_update(dt) == ci["n_contacts"]            # cached answer
+    eng.set_option("no_contact_cache", 1)
     n1 = eng.contact_update(dt)
     t1 = {name: eng.contact_table(name) for name in ("contact_rb_d_pt_tp_cubic", "contact_rb_d_ee_ee_cubic", "contact_rb_d_pt_pt_cubic")}
     eng.contact_set_broad_phase(True)
@@ -61,6 +64,7 @@ def test_full_size_properties():
     for name, t in t1.items():
         assert (eng.contact_table(name) == t).all(), name       # rows are sorted by pair id: identical arrays
     assert eng.contact_count_intersections(dt) == 0
+    eng.set_option("no_contact_cache", 0)
     # assembled operator: symmetric, positive on the PCG search space once projected
     E0, g = eng.eval(capi.EVAL_P_G_H)
     eng.project(1e-10)
