@@ -214,7 +214,7 @@ def main():
                 # HBM-side bytes per real SpMV launch from rocprofv3 PMC passes of this command (profiles/r01_v9_pmc_*.txt):
                 # 2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KB -> bytes.
                 # Only valid for the default workload; other sizes report null.
-                "traffic": (2 * 56750.0 + 5693.4) * 1024.0 if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
+                "traffic": (2 * 56746.5 + 5735.7) * 1024.0 if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "avg_launch_ms": spmv_ms,
                 "launches_timed": spmv_n,
