@@ -514,7 +514,10 @@ __device__ __forceinline__ int wave_bound_f(const float* __restrict__ a, int lo,
 // A wavefront scans at most SWEEP_SPLIT candidates itself: the rest of a long range (a floor triangle under a 256 x 256 cloth has 66 k
 // points in its interval) becomes tasks of SWEEP_SPLIT candidates that k_sweep_tasks spreads over the chip; one wavefront walking such a
 // range alone was 0.9 ms of a 1 ms detection.
-constexpr int SWEEP_SUB = 16;
+#ifndef MISTARK_SWEEP_SUB
+#define MISTARK_SWEEP_SUB 16
+#endif
+constexpr int SWEEP_SUB = MISTARK_SWEEP_SUB;  // lanes per sorted entry; measured 8 / 16 / 32: contact callbacks of configs[2] 1.63 / 1.73 / 1.90 ms per step, configs[3] equal within noise
 constexpr int SWEEP_SPLIT = 512;
 constexpr int SWEEP_TASK_CAP = 1 << 16;
 constexpr int SWEEP_TASK_WAVES = 4096;
