@@ -257,6 +257,9 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value);
 int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n, double* bytes_per_launch);
 /* Micro-benchmark: n back-to-back SpMV launches on the currently assembled matrix, average duration in microseconds. */
 int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us);
+/* Waits until everything queued on the engine's stream has finished (entry points that return values already do; assemble / project /
+ * axpby only enqueue). For timing from the host. */
+int mistark_sync(mistark_ctx* ctx);
 
 /* ---- multi-GPU: elements of every potential sharded by contiguous ranges over `world` ranks (one engine context per GPU) ------------
  * Energy, gradient and the assembled matrix are summed over the ranks (RCCL all-reduce on the engine's stream); the linear solve,

@@ -14,7 +14,8 @@ using namespace mistark;
     if (!ctx) return -1; \
     int _ret = 0;        \
     (void)_ret;          \
-    try {
+    try {                \
+        (void)hipSetDevice(ctx->c.device); /* the current device is per host thread: contexts may be driven from any thread */
 #define API_END(ret)                   \
     }                                  \
     catch (const std::exception& e)    \
@@ -410,7 +411,7 @@ int mistark_eval(mistark_ctx* ctx, int mode, double* E, double* grad_host)
 {
     API_BEGIN
     if (mode < 0 || mode > 2) throw Error("bad eval mode");
-    eval(ctx->c, mode, E, grad_host);
+    eval(ctx->c, mode, E, grad_host, nullptr, ctx->c.lazy_eval);
     API_END(0)
 }
 int mistark_get_element_hessians(mistark_ctx* ctx, int potential, double* values, int32_t* block_rows, int32_t* nb_out)
@@ -420,6 +421,7 @@ int mistark_get_element_hessians(mistark_ctx* ctx, int potential, double* values
     if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
     if (!c.have_hessians) throw Error("no element Hessians");
     Potential& P = c.pots[potential];
+    if (values && c.lazy_active && P.lazy_capable) throw Error("element Hessians of '" + P.name + "' were evaluated on the lazy path (float blocks only); evaluate without lazy_eval");
     const int NB = P.NB, n = 3 * NB;
     if (nb_out) *nb_out = NB;
     if (values && P.n_elem > 0) {
@@ -720,10 +722,18 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
 {
     API_BEGIN
     const std::string n = name ? name : "";
-    if (n == "force_generic") ctx->c.force_generic = value != 0;
+    if (n == "force_generic") {
+        ctx->c.force_generic = value != 0;
+        ctx->c.layout_dirty = true;  // (Potential::lazy_capable depends on it)
+    }
     else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;
     else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;
     else if (n == "proj_rec_cap") ctx->c.proj_rec_cap = value;
+    else if (n == "lazy_hessians") ctx->c.lazy_allowed = value != 0;  // newton_solve: float upper-triangle pool for the closed-form tets
+    else if (n == "kernel_dbg") { ctx->c.kernel_dbg = value; ctx->c.layout_dirty = true; }  // measurement only
+    else if (n == "lazy_eval") ctx->c.lazy_eval = value != 0;
+    else if (n == "no_grad_gather") { ctx->c.no_grad_gather = value != 0; ctx->c.layout_dirty = true; }         // staged mistark_eval calls take the lazy path too (tests)
+
     else if (n == "spmv_variant") ctx->c.spmv_variant = value;
     else if (n == "proj_variant") ctx->c.proj_variant = value;
     else if (n == "no_contact_cache") ctx->c.no_contact_cache = value != 0;
@@ -736,6 +746,12 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     API_END(0)
 }
 
+int mistark_sync(mistark_ctx* ctx)
+{
+    API_BEGIN
+    MS_CHECK(hipStreamSynchronize(ctx->c.stream));
+    API_END(0)
+}
 int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us)
 {
     API_BEGIN

@@ -166,7 +166,8 @@ __global__ __launch_bounds__(256) void k_eval_custom(PotArgs a, ProgDev p, doubl
     const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long long)a.e_count * NP) return;
     const int le = (int)(t / NP);
-    const int e = a.e_begin + le;
+    const int e = a.elem_list ? (int)a.elem_list[le] : a.e_begin + le;
+    const int pe = a.elem_list ? le : e;  // position in the pools (kernels.hip: pool_of)
     int rem = (int)(t - (long long)le * NP);
     const bool first = rem == 0;
     int i = -1, j = -1;
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(256) void k_eval_custom(PotArgs a, ProgDev p, doubl
     const HDual r = on ? run_program(p.ops, p.consts, p.n_ops, in, p.in_dof, p.n_in, i, j) : HDual(0.0);
     if (MODE == 2) {
         const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
-        elemH[((size_t)(ba * NB + bb) * a.n_elem + e) * 9 + ii * 3 + jj] = r.ab;
-        elemH[((size_t)(bb * NB + ba) * a.n_elem + e) * 9 + jj * 3 + ii] = r.ab;
+        elemH[((size_t)(ba * NB + bb) * a.n_pool + pe) * 9 + ii * 3 + jj] = r.ab;
+        elemH[((size_t)(bb * NB + ba) * a.n_pool + pe) * 9 + jj * 3 + ii] = r.ab;
     }
     if (MODE >= 1 && i == j && on) {
         const int ba = i / 3, ii = i - 3 * ba;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void k_eval_custom(PotArgs a, ProgDev p, doubl
         if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);  // (k_eval_pgh)
         else atomicAdd(&grad[3 * (size_t)(a.dof_row_off[ba] + node) + ii], r.a);
     }
-    if (first) elemE[e] = r.v;
+    if (first) elemE[pe] = r.v;
 }
 
 // Linear-scan register allocation of the temporaries of one op sequence (values >= n_in). A value defined in both arms of a branch

@@ -87,6 +87,11 @@ struct PotArgs
     int conn_stride;
     int n_elem;
     int e_begin, e_count;     // this rank's contiguous element range (multi-GPU sharding; the whole table on one GPU)
+    const uint32_t* elem_list;  // != nullptr: the kernel's element le is elem_list[le] (le < e_count) and pools are indexed by le
+    int n_pool;               // elements per block pair in the element-Hessian pool (pool stride)
+    double* gpool;            // != nullptr: gradient contributions go to gpool[(k * n_gpool + pool position) * 3 + i] (summed by k_grad_gather) instead of atomics
+    int n_gpool;
+    int dbg;                  // measurement switches (option "kernel_dbg"; results are wrong when set)
     int dof_col[MAX_NB];      // connectivity column providing the node of local DoF block k
     int dof_row_off[MAX_NB];  // first block row of the DoF set of local DoF block k
     // Gradient rows of SMALL DoF sets (a handful of rigid bodies touched by tens of thousands of contacts) are not accumulated in place:
@@ -136,6 +141,19 @@ struct Potential
     size_t h_off = 0;   // first double in the element-Hessian pool
     size_t k_off = 0;   // first 3x3 block in the element-Hessian pool (= h_off / 9)
     size_t kp_off = 0;  // first key in the key list of its matrix part
+    // "lazy" potentials (closed-form tets): inside the Newton loop their element Hessians are written as FLOAT blocks, upper block triangle
+    // only (what the float BSR assembly needs: 360 instead of 1152 bytes per tet); the double blocks of the few elements the PSD
+    // projection selects are recomputed on demand (project()). Staged API calls keep the full double pool.
+    // Gradient without atomics (closed-form tets: 12 M double atomics were 2/3 of the kernel's time at 1M tets): the kernel writes the four
+    // node gradients of an element to a pool and k_grad_gather sums, per block row, the contributions listed in the incidence lists built
+    // on the host from the connectivity (fixed order: the gradient of these potentials is bit-reproducible).
+    bool grad_gather = false;
+    DevBuf<uint32_t> inc_start, inc;  // per block row (+1): first incidence; per incidence: k * n_gpool + pool position
+    DevBuf<double> gpool;
+    std::vector<int64_t> inc_sig;     // what the incidence lists were built for
+    bool lazy_capable = false;
+    size_t hf_off = 0;  // first float in the float pool
+    int n_pool_f = 0;   // elements per block pair in the float pool (n_elem rounded up to 64: 16-byte aligned wave stores)
     int part = 0;       // 0: fixed connectivity, 1: connectivity changes inside the Newton loop (contacts)
     bool conn_dirty = true;
     const int32_t* conn_ext = nullptr;  // connectivity written on the device by the contact detector (overrides conn)
@@ -150,9 +168,10 @@ struct BsrPart
     DevBuf<uint64_t> keys, keys_alt;
     DevBuf<uint32_t> kidx, kidx_alt;
     DevBuf<uint32_t> scan, slot_start;
-    DevBuf<uint32_t> slot_of_src;   // per element block of this part (pool order, from blk_base) -> BSR slot
-    size_t blk_base = 0;            // first element block of this part in the element-Hessian pool
-    const uint32_t* sorted_src = nullptr;  // element-block ids in sorted key order (one of kidx / kidx_alt)
+    DevBuf<uint32_t> slot_of_src;   // per key of this part (potential P: kp_off + (a*NB+b)*n_elem + e) -> BSR slot
+    const uint32_t* sorted_src = nullptr;  // key positions in sorted key order (one of kidx / kidx_alt); NO_SRC for structural diagonal keys
+    DevBuf<uint32_t> sorted_desc;   // per sorted key: where the gather assembly reads the contribution (make_descriptors)
+    int desc_lazy = -1;             // lazy state the descriptors were made for (-1: none)
     int64_t nnzb = 0, ntiles = 0, n_rows = 0;
     DevBuf<uint32_t> colw;          // bit31 = last block of its row, bits 0..30 = block column
     DevBuf<uint32_t> slot_row;      // block row of each slot
@@ -182,11 +201,6 @@ struct BsrPart
     int n_long_rows = 0;
 };
 
-struct SrcRange  // element blocks [k_off, k_off + nn*n_elem) of one potential, of which elements [e_begin, e_begin+e_count) are local
-{
-    uint32_t k_off, n_elem, nn, e_begin, e_count;
-};
-
 struct PcgCtrl
 {
     int done;
@@ -213,6 +227,14 @@ struct Context
     DevBuf<double> u, grad, du, r, z, p, q, tmp_a, tmp_b;
     size_t n_elem_total = 0, hess_total = 0;
     DevBuf<double> elemE, elemH;
+    DevBuf<float> elemHf;           // float pool of the lazy potentials
+    DevBuf<double> projH;           // compact double pool of the elements a projection round recomputes (lazy potentials)
+    size_t hf_total = 0;
+    bool lazy_allowed = true;       // option "lazy_hessians": newton_solve may take the lazy path (progressive / no projection)
+    bool lazy_eval = false;         // option "lazy_eval": staged mistark_eval calls take it too (tests)
+    bool lazy_active = false;       // state of the current element Hessians
+    bool no_grad_gather = false;    // option "no_grad_gather": the closed-form tets accumulate their gradient with atomics (cross-check)
+    int kernel_dbg = 0;             // option "kernel_dbg": measurement switches inside kernels (PotArgs::dbg)
     DevBuf<uint8_t> is_projected, active_blocks;
     bool have_hessians = false;
 
@@ -269,7 +291,7 @@ struct Context
     // sharded projection: delta records of this rank, the common exchange buffer and its sort scratch (kernels.hip: exchange_projection_deltas)
     DevBuf<uint32_t> proj_rec_pos, proj_keys, proj_keys_alt, proj_idx, proj_idx_alt;
     DevBuf<float> proj_rec_val, proj_x;
-    DevBuf<SrcRange> src_ranges;
+    DevBuf<unsigned char> src_ranges;  // descriptor table of k_make_desc
     struct ContactSystem* contact = nullptr;  // device contact detector (contact.hip), created by mistark_contact_init
 
     int last_cg_iters = 0;          // iteration count of the previous solve (first-batch predictor)
@@ -287,7 +309,7 @@ void prepare(Context& c);
 void ensure_pattern(Context& c);
 void contact_destroy(struct ContactSystem* cs);
 int register_potential(Context& c, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings);
-void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs = nullptr);
+void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs = nullptr, bool lazy = false);
 void reduce_dot_and_max_abs(Context& c, const double* a, const double* b, int64_t n, double* dot, double* max_abs_a);
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active,
              int64_t* n_projected_now, int64_t* n_changed_now);

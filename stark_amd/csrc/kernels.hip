@@ -93,21 +93,25 @@ __device__ __forceinline__ void gather_inputs(const PotArgs& a, int e, double* i
     });
 }
 
+// element of a kernel's local index le, and its position in the pools (element energies, element Hessians)
+__device__ __forceinline__ int elem_of(const PotArgs& a, int le) { return a.elem_list ? (int)a.elem_list[le] : a.e_begin + le; }
+__device__ __forceinline__ int pool_of(const PotArgs& a, int le) { return a.elem_list ? le : a.e_begin + le; }
+
 // Energy only: one lane per element
 template <class En>
 __global__ __launch_bounds__(BLOCK) void k_eval_p(PotArgs a, double* __restrict__ elemE)
 {
     const int le = blockIdx.x * BLOCK + threadIdx.x;
     if (le >= a.e_count) return;
-    const int e = a.e_begin + le;
+    const int e = elem_of(a, le), pe = pool_of(a, le);
     double in[En::Layout::NIN];
     gather_inputs<En>(a, e, in);
     if (!element_active<En>(in)) {  // conditional potential, element switched off (SecondOrderCompiledPotential.cpp:185-197)
-        elemE[e] = 0.0;
+        elemE[pe] = 0.0;
         return;
     }
     Loader<double> L{in};
-    elemE[e] = En::energy(L);
+    elemE[pe] = En::energy(L);
 }
 
 // Energy + gradient + Hessian: one lane per (element, i<=j) pair of local DoFs.
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
     const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= (long long)a.e_count * NP) return;
     const int le = (int)(t / NP);
-    const int e = a.e_begin + le;
+    const int e = elem_of(a, le), pe = pool_of(a, le);
     int rem = (int)(t - (long long)le * NP);
     const bool first = rem == 0;
     int i = 0;
@@ -137,15 +141,15 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
     const HDual r = on ? En::energy(L) : HDual(0.0);
     const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
     if (STORE_H) {
-        elemH[((size_t)(ba * NB + bb) * a.n_elem + e) * 9 + ii * 3 + jj] = r.ab;
-        elemH[((size_t)(bb * NB + ba) * a.n_elem + e) * 9 + jj * 3 + ii] = r.ab;
+        elemH[((size_t)(ba * NB + bb) * a.n_pool + pe) * 9 + ii * 3 + jj] = r.ab;
+        elemH[((size_t)(bb * NB + ba) * a.n_pool + pe) * 9 + jj * 3 + ii] = r.ab;
     }
     if (i == j && on) {
         const int node = a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];
         if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);
         else atomicAdd(&grad[3 * (size_t)(a.dof_row_off[ba] + node) + ii], r.a);
     }
-    if (first) elemE[e] = r.v;
+    if (first) elemE[pe] = r.v;
 }
 // hot rows: the HOT_WAYS partial sums in fixed order, added to what the in-place accumulating kernels (closed-form tets) left there
 __global__ __launch_bounds__(BLOCK) void k_fold_hot(const double* __restrict__ grad_hot, const int32_t* __restrict__ hot_rows, int n_hot, double* __restrict__ grad)
@@ -158,7 +162,31 @@ __global__ __launch_bounds__(BLOCK) void k_fold_hot(const double* __restrict__ g
     grad[3 * (size_t)hot_rows[r] + (t - 3 * r)] += acc;
 }
 
-// Closed-form tet kernels (tet_closed.hpp): one lane per tet, 12 gradient atomics. The 16 Hessian blocks of a tet belong to 16 pools
+// grad[row] += sum of the pooled node gradients incident on the row, in list order (PotArgs::gpool). One lane per (block row, component),
+// eight loads in flight per lane.
+__global__ __launch_bounds__(BLOCK) void k_grad_gather(const double* __restrict__ gpool, const uint32_t* __restrict__ inc_start, const uint32_t* __restrict__ inc, int64_t nbr,
+                                                      double* __restrict__ grad)
+{
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= 3 * nbr) return;
+    const int64_t row = t / 3;
+    const int comp = (int)(t - 3 * row);
+    const uint32_t k0 = inc_start[row], k1 = inc_start[row + 1];
+    if (k0 == k1) return;
+    double acc = 0.0;
+    for (uint32_t kb = k0; kb < k1; kb += 8) {
+        uint32_t src[8];
+        double h[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) src[u] = kb + u < k1 ? inc[kb + u] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int u = 0; u < 8; u++) h[u] = gpool[src[u] != 0xFFFFFFFFu ? (size_t)src[u] * 3 + comp : (size_t)0];
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += src[u] != 0xFFFFFFFFu ? h[u] : 0.0;
+    }
+    grad[t] += acc;
+}
+// Closed-form tet kernels (tet_closed.hpp): one lane per tet; gradient through the pool above (or 12 atomics). The 16 Hessian blocks of a tet belong to 16 pools
 // (H[pair][element][9]); a lane storing its own 72 bytes would make every store instruction touch 64 separate segments, so each block
 // goes through LDS: the wavefront's 64 blocks of one pair are 4608 contiguous bytes and leave as nine fully coalesced stores (and nine
 // more for the transposed pair).
@@ -190,26 +218,86 @@ struct TetBlockStagedSink
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 };
-template <class En, bool FULL, bool STORE_H>
-__global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
+// The lazy pool: what the float BSR assembly needs and nothing more. The reference casts every element block to float before it adds it
+// to the matrix (BlockedSparseMatrix.h:781-814), so the block goes to memory as 9 floats, and only the 10 blocks (a <= b) of the upper
+// block triangle: the gather reads (b, a) as the transpose of (a, b). 360 bytes per tet instead of 1152. Pool layout
+// Hf[pair(a,b)][element][9]; the wavefront's 64 blocks of a pair are 2304 contiguous bytes = 144 float4, staged through LDS
+// element-major (stride 9 floats: conflict-free) and stored as three 16-byte-per-lane instructions.
+__host__ __device__ constexpr int tet_pair_index(int a, int b) { return a * 4 - a * (a - 1) / 2 + (b - a); }  // a <= b: 0..9
+struct TetBlockFloatSink
 {
-    __shared__ double stage[STORE_H ? (BLOCK / 64) * 9 * 64 : 1];
+    float* stage;     // [64 * 9] of this wavefront
+    float* Hwave;     // pool position of the wavefront's first element (pair 0); 16-byte aligned (pool stride is a multiple of 64 elements)
+    size_t hstride;   // floats between pair pools
+    int lane, n_valid, dbg;
+    __device__ __forceinline__ void put(int a, int b, const double* blk)
+    {
+#pragma unroll
+        for (int c = 0; c < 9; c++) stage[lane * 9 + c] = (float)blk[c];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        float* dst = Hwave + (size_t)tet_pair_index(a, b) * hstride;
+        if (dbg & 2) {  // measurement switch: no global stores
+        } else if (n_valid == 64) {
+            const float4* s4 = reinterpret_cast<const float4*>(stage);
+            float4* d4 = reinterpret_cast<float4*>(dst);
+            d4[lane] = s4[lane];
+            d4[64 + lane] = s4[64 + lane];
+            if (lane < 16) d4[128 + lane] = s4[128 + lane];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int idx = k * 64 + lane;
+                if (idx < n_valid * 9) dst[idx] = stage[idx];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+};
+// MODE 0: energy + gradient; 1: + Hessian blocks into the double pool H[pair(4a+b)][element][9] (all 16 blocks);
+//      2: + Hessian blocks into the float pool (TetBlockFloatSink); 3: Hessian blocks only, into a compact double pool (the elements a
+//         projection round selected: a.elem_list = that list, pools indexed by list position)
+constexpr int TET_PG = 0, TET_PGH = 1, TET_PGH_F = 2, TET_H_LIST = 3;
+template <class En, bool FULL, int MODE>
+__global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, float* __restrict__ elemHf, double* __restrict__ grad)
+{
+    __shared__ double stage[MODE == TET_PG ? 1 : (BLOCK / 64) * 9 * 64];
     const int le = blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = le < a.e_count;
-    const int e = a.e_begin + (valid ? le : a.e_count - 1);  // (lanes past the end repeat the last element and store nothing)
+    const int lev = valid ? le : a.e_count - 1;  // (lanes past the end repeat the last element and store nothing)
+    const int e = elem_of(a, lev);
     double in[En::Layout::NIN];
     gather_inputs<En>(a, e, in);
     double E, g[12];
-    if (STORE_H) {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        const int le_wave = le - lane;
-        TetBlockStagedSink sink{stage + wave * 9 * 64, elemH + (size_t)(a.e_begin + le_wave) * 9, (size_t)a.n_elem * 9, lane, min(64, a.e_count - le_wave)};
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int le_wave = le - lane;
+    const int pe_wave = pool_of(a, le_wave);
+    if (MODE == TET_PGH || MODE == TET_H_LIST) {
+        TetBlockStagedSink sink{stage + wave * 9 * 64, elemH + (size_t)pe_wave * 9, (size_t)a.n_pool * 9, lane, min(64, a.e_count - le_wave)};
+        tet_closed_eval_to<FULL>(in, E, g, sink, true);
+    } else if (MODE == TET_PGH_F) {
+        TetBlockFloatSink sink{reinterpret_cast<float*>(stage) + wave * 9 * 64, elemHf + (size_t)pe_wave * 9, (size_t)a.n_pool * 9, lane, min(64, a.e_count - le_wave), a.dbg};
         tet_closed_eval_to<FULL>(in, E, g, sink, true);
     } else {
         tet_closed_eval<FULL>(in, E, g, nullptr, 0, false);
     }
-    if (!valid) return;
-    elemE[e] = E;
+    if (!valid || MODE == TET_H_LIST) return;
+    elemE[pool_of(a, le)] = E;
+    if (a.dbg & 1) return;  // measurement switch: no gradient output
+    if (a.gpool) {  // node gradients to the pool, summed per block row by k_grad_gather (no atomics)
+        const int pe = pool_of(a, le);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            double* gp = a.gpool + ((size_t)k * a.n_gpool + pe) * 3;
+            gp[0] = g[3 * k];
+            gp[1] = g[3 * k + 1];
+            gp[2] = g[3 * k + 2];
+        }
+        return;
+    }
     const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -229,7 +317,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_bending_flat(PotArgs a, double* 
     using En = E_BendingFlat;
     const int le = blockIdx.x * BLOCK + threadIdx.x;
     if (le >= a.e_count) return;
-    const int e = a.e_begin + le;
+    const int e = elem_of(a, le), pe = pool_of(a, le);
     double in[En::Layout::NIN];
     gather_inputs<En>(a, e, in);
     const double coef = in[28], k = in[29], dt = in[30];
@@ -242,7 +330,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_bending_flat(PotArgs a, double* 
         s2 += K * (in[14 + 3 * i] + dt * in[3 * i + 2]);
     }
     const double kc = k * coef;
-    elemE[e] = 0.5 * kc * (s0 * s0 + s1 * s1 + s2 * s2);
+    elemE[pe] = 0.5 * kc * (s0 * s0 + s1 * s1 + s2 * s2);
     const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -259,7 +347,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_bending_flat(PotArgs a, double* 
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const double d = h * in[24 + i] * in[24 + j];
-                double* H = elemH + ((size_t)(i * 4 + j) * a.n_elem + e) * 9;
+                double* H = elemH + ((size_t)(i * 4 + j) * a.n_pool + pe) * 9;
                 H[0] = d;   H[1] = 0.0; H[2] = 0.0;
                 H[3] = 0.0; H[4] = d;   H[5] = 0.0;
                 H[6] = 0.0; H[7] = 0.0; H[8] = d;
@@ -280,10 +368,41 @@ static void launch_tet_closed(Context& c, Potential& P, int mode)
 {
     if (P.args.e_count == 0) return;
     double* E = c.elemE.p + P.e_off;
-    if (mode == MISTARK_EVAL_P_G)
-        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, false>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
+    const dim3 g(grid_for(P.args.e_count)), b(BLOCK);
+    struct AfterLaunch
+    {
+        Context& c;
+        Potential& P;
+        ~AfterLaunch()
+        {
+            if (P.args.gpool && !(c.kernel_dbg & 1))
+                hipLaunchKernelGGL(k_grad_gather, dim3(grid_for(3 * c.nbr)), dim3(BLOCK), 0, c.stream, (const double*)P.gpool.p, (const uint32_t*)P.inc_start.p, (const uint32_t*)P.inc.p,
+                                   c.nbr, c.grad.p);
+        }
+    } after{c, P};
+    if (mode == MISTARK_EVAL_P_G) {
+        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, TET_PG>), g, b, 0, c.stream, P.args, E, (double*)nullptr, (float*)nullptr, c.grad.p);
+    } else if (c.lazy_active) {
+        PotArgs A = P.args;
+        A.n_pool = P.n_pool_f;
+        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, TET_PGH_F>), g, b, 0, c.stream, A, E, (double*)nullptr, c.elemHf.p + P.hf_off, c.grad.p);
+    } else {
+        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, TET_PGH>), g, b, 0, c.stream, P.args, E, c.elemH.p + P.h_off, (float*)nullptr, c.grad.p);
+    }
+}
+// double Hessian blocks of the listed elements of a lazy potential into a compact pool H[pair][position in list][9] of stride n_pool
+static void launch_tet_closed_list(Context& c, Potential& P, const uint32_t* list, int n_list, double* H, int n_pool)
+{
+    PotArgs A = P.args;
+    A.elem_list = list;
+    A.e_begin = 0;
+    A.e_count = n_list;
+    A.n_pool = n_pool;
+    const dim3 g(grid_for(n_list)), b(BLOCK);
+    if (P.name == E_TetStrain::name)
+        hipLaunchKernelGGL((k_eval_tet_closed<E_TetStrain, true, TET_H_LIST>), g, b, 0, c.stream, A, (double*)nullptr, H, (float*)nullptr, (double*)nullptr);
     else
-        hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, true>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
+        hipLaunchKernelGGL((k_eval_tet_closed<E_TetStrainEO, false, TET_H_LIST>), g, b, 0, c.stream, A, (double*)nullptr, H, (float*)nullptr, (double*)nullptr);
 }
 
 template <class En>
@@ -388,7 +507,11 @@ __global__ __launch_bounds__(BLOCK) void k_max_abs(const double* __restrict__ v,
 {
     __shared__ double sm[4];
     double s = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) s = fmax(s, fabs(v[i]));
+    // a NaN entry must not vanish in fmax (fmax(s, NaN) = s): it becomes +inf, which every later max keeps, and the Newton loop tests isfinite
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) {
+        const double a = fabs(v[i]);
+        s = fmax(s, a == a ? a : INFINITY);
+    }
     s = block_max(s, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
@@ -529,7 +652,7 @@ void vec_neg(Context& c, double* dst, const double* x, int64_t n) { vec_axpby(c,
 // ======================================================================================================================
 // prepare(): DoF layout, device arrays, kernel argument blocks, sparsity pattern
 // ======================================================================================================================
-__global__ __launch_bounds__(BLOCK) void k_keys(PotArgs a, int NB, uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t pos_off, uint32_t blk_off)
+__global__ __launch_bounds__(BLOCK) void k_keys(PotArgs a, int NB, uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t pos_off)
 {
     const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
     const int nn = NB * NB;
@@ -542,7 +665,7 @@ __global__ __launch_bounds__(BLOCK) void k_keys(PotArgs a, int NB, uint64_t nbr,
     const uint64_t rb = a.dof_row_off[bb] + ce[a.dof_col[bb]];
     const uint32_t off = (uint32_t)ab * (uint32_t)a.n_elem + (uint32_t)e;
     keys[pos_off + off] = ra * nbr + rb;
-    idx[pos_off + off] = blk_off + off;  // index of the element block in the Hessian pool
+    idx[pos_off + off] = pos_off + off;  // key position: potential, block pair and element (make_descriptors turns it into a pool address)
 }
 constexpr uint32_t NO_SRC = 0xFFFFFFFFu;
 __global__ __launch_bounds__(BLOCK) void k_diag_keys(uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t pos_off)
@@ -560,13 +683,13 @@ __global__ __launch_bounds__(BLOCK) void k_heads(const uint64_t* __restrict__ ke
 }
 // scan = inclusive prefix of heads. slot = scan-1.
 __global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ scan, size_t n,
-                                                 uint64_t nbr, uint32_t* __restrict__ slot_of_src, uint32_t blk_base, uint32_t* __restrict__ colw, uint32_t* __restrict__ slot_row,
+                                                 uint64_t nbr, uint32_t* __restrict__ slot_of_src, uint32_t* __restrict__ colw, uint32_t* __restrict__ slot_row,
                                                  int32_t* __restrict__ diag_slot, uint32_t* __restrict__ slot_start, uint32_t* __restrict__ row_head)
 {
     const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n) return;
     const uint32_t slot = scan[k] - 1;
-    if (idx[k] != NO_SRC) slot_of_src[idx[k] - blk_base] = slot;
+    if (idx[k] != NO_SRC) slot_of_src[idx[k]] = slot;
     const bool head = (k == 0 || keys[k] != keys[k - 1]);
     if (k == n - 1) slot_start[slot + 1] = (uint32_t)n;
     if (head) {
@@ -599,21 +722,42 @@ __global__ __launch_bounds__(BLOCK) void k_rows(const uint32_t* __restrict__ slo
     if ((s & 63) == 0) tile_first_row[s >> 6] = (int32_t)(crow | (head ? 0u : 0x80000000u));
 }
 
-// multi-GPU: element blocks of other ranks are removed from the gather lists (NO_SRC) once per pattern
-__global__ __launch_bounds__(BLOCK) void k_filter_sources(uint32_t* __restrict__ src, size_t n, const SrcRange* __restrict__ rg, int n_rg)
+// Where the gather assembly reads a contribution from: one descriptor per sorted key. Bit 31: float pool (elemHf) instead of the double pool
+// (elemH), bit 30: read the stored block transposed (lazy potentials keep the upper block triangle only), bits 0..29: 3x3 block index in that
+// pool. NO_SRC: no data (structural diagonal keys; multi-GPU: elements of other ranks, the sum over ranks restores them).
+constexpr uint32_t DESC_FLOAT = 0x80000000u, DESC_TRANS = 0x40000000u, DESC_MASK = 0x3fffffffu;
+struct DescRange  // keys [kp_off, kp_off + nn * n_elem) of one potential
+{
+    uint32_t kp_off, n_elem, NB, e_begin, e_count;
+    uint32_t pool_blk;   // first block of the potential in its pool
+    uint32_t n_pool;     // pool stride (elements per block pair)
+    uint32_t lazy;       // float pool, upper block triangle (tet_pair_index)
+};
+__global__ __launch_bounds__(BLOCK) void k_make_desc(const uint32_t* __restrict__ sidx, size_t n, const DescRange* __restrict__ rg, int n_rg, uint32_t* __restrict__ desc)
 {
     const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n) return;
-    const uint32_t b = src[k];
-    if (b == NO_SRC) return;
-    for (int i = 0; i < n_rg; i++) {
-        const uint32_t span = rg[i].n_elem * rg[i].nn;
-        if (b >= rg[i].k_off && b < rg[i].k_off + span) {
-            const uint32_t e = (b - rg[i].k_off) % rg[i].n_elem;
-            if (e < rg[i].e_begin || e >= rg[i].e_begin + rg[i].e_count) src[k] = NO_SRC;
-            return;
+    const uint32_t kp = sidx[k];
+    uint32_t d = NO_SRC;
+    if (kp != NO_SRC) {
+        int lo = 0, hi = n_rg - 1;  // last range with kp_off <= kp
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (rg[mid].kp_off <= kp) lo = mid;
+            else hi = mid - 1;
+        }
+        const DescRange r = rg[lo];
+        const uint32_t off = kp - r.kp_off, ab = off / r.n_elem, e = off - ab * r.n_elem;
+        if (e >= r.e_begin && e < r.e_begin + r.e_count) {
+            if (r.lazy) {
+                const uint32_t a = ab / r.NB, b = ab - a * r.NB;
+                d = DESC_FLOAT | (a > b ? DESC_TRANS : 0u) | (r.pool_blk + (uint32_t)(a > b ? tet_pair_index((int)b, (int)a) : tet_pair_index((int)a, (int)b)) * r.n_pool + e);
+            } else {
+                d = r.pool_blk + ab * r.n_pool + e;
+            }
         }
     }
+    desc[k] = d;
 }
 constexpr int CHUNK_BLOCKS = 256;
 constexpr int DYN_SHORT_ROW = 32;  // contact rows of a node hold a handful of blocks; only the rows of rigid bodies in contact are long
@@ -782,7 +926,7 @@ static void build_pattern(Context& c, int part)
     for (auto& P : c.pots) {
         if (P.part != part || P.n_elem == 0) continue;
         hipLaunchKernelGGL(k_keys, dim3(grid_for((int64_t)P.n_elem * P.NB * P.NB)), dim3(BLOCK), 0, c.stream, P.args, P.NB, (uint64_t)c.nbr, m.keys.p, m.kidx.p,
-                           (uint32_t)P.kp_off, (uint32_t)P.k_off);
+                           (uint32_t)P.kp_off);
     }
     if (part == 0) hipLaunchKernelGGL(k_diag_keys, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, (uint64_t)c.nbr, m.keys.p, m.kidx.p, (uint32_t)diag_off);
     // sort (key, source) pairs
@@ -813,19 +957,10 @@ static void build_pattern(Context& c, int part)
     m.slot_start.ensure((size_t)m.nnzb + 1);
     MS_CHECK(hipMemsetAsync(m.colw.p, 0, (size_t)m.ntiles * 64 * sizeof(uint32_t), c.stream));
     uint32_t* row_head = heads;  // (heads is dead after the scan)
-    hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, (uint64_t)c.nbr, m.slot_of_src.p, (uint32_t)m.blk_base, m.colw.p, m.slot_row.p,
+    hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, (uint64_t)c.nbr, m.slot_of_src.p, m.colw.p, m.slot_row.p,
                        c.diag_slot[part].p, m.slot_start.p, row_head);
     m.sorted_src = sidx;
-    if (c.world > 1) {
-        // keep only this rank's element blocks in the gather lists (the sum over ranks restores the rest)
-        std::vector<SrcRange> rg;
-        for (auto& P : c.pots)
-            if (P.part == part && P.n_elem > 0) rg.push_back({(uint32_t)P.k_off, (uint32_t)P.n_elem, (uint32_t)(P.NB * P.NB), (uint32_t)P.args.e_begin, (uint32_t)P.args.e_count});
-        c.src_ranges.ensure(std::max<size_t>(rg.size(), 1));
-        if (!rg.empty()) MS_CHECK(hipMemcpyAsync(c.src_ranges.p, rg.data(), rg.size() * sizeof(SrcRange), hipMemcpyHostToDevice, c.stream));
-        hipLaunchKernelGGL(k_filter_sources, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, (uint32_t*)sidx, nk, (const SrcRange*)c.src_ranges.p, (int)rg.size());
-        MS_CHECK(hipStreamSynchronize(c.stream));  // rg is a temporary
-    }
+    m.desc_lazy = -1;  // (make_descriptors)
     // blocks with very many contributions
     m.long_slots.ensure((size_t)m.nnzb);
     c.counters.ensure(128);
@@ -939,21 +1074,26 @@ void prepare(Context& c)
         }
         // potentials
         // pools: static potentials first, so their offsets do not move when only the contact tables change size
-        size_t e_off = 0, h_off = 0;
+        size_t e_off = 0, h_off = 0, hf_off = 0;
         for (int part = 0; part < 2; part++) {
-        c.part[part].blk_base = h_off / 9;
         for (auto& P : c.pots) {
             if (P.part != part) continue;
+            if (P.h_off != h_off || P.hf_off != hf_off) c.part[part].desc_lazy = -1;  // pool addresses moved: make_descriptors again
             P.e_off = e_off;
             P.h_off = h_off;
             P.k_off = h_off / 9;
             e_off += (size_t)P.n_elem;
             h_off += (size_t)P.n_elem * 9 * P.NB * P.NB;
+            P.lazy_capable = P.kind != KIND_CUSTOM && !c.force_generic && (P.name == E_TetStrain::name || P.name == E_TetStrainEO::name);
+            P.hf_off = hf_off;
+            P.n_pool_f = (P.n_elem + 63) / 64 * 64;
+            if (P.lazy_capable) hf_off += (size_t)P.n_pool_f * 9 * 10;
             if (P.conn_dirty && !P.conn_ext) {
                 P.conn.ensure(std::max<size_t>(P.conn_host.size(), 1));
                 if (!P.conn_host.empty())
                     MS_CHECK(hipMemcpyAsync(P.conn.p, P.conn_host.data(), P.conn_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
                 P.conn_dirty = false;
+                P.inc_sig.clear();
                 c.part[P.part].dirty = true;
             }
             PotArgs& A = P.args;
@@ -961,6 +1101,9 @@ void prepare(Context& c)
             A.conn = P.conn_ext ? P.conn_ext : P.conn.p;
             A.conn_stride = P.conn_stride;
             A.n_elem = P.n_elem;
+            A.n_pool = P.n_elem;
+            A.elem_list = nullptr;
+            A.dbg = c.kernel_dbg;
             {
                 long long b, e;
                 shard_range(P.n_elem, c.rank, c.world, b, e);
@@ -988,12 +1131,42 @@ void prepare(Context& c)
                     nblk++;
                 }
             if (nblk != P.NB) throw Error("potential '" + P.name + "': expected " + std::to_string(P.NB) + " DoF bindings, got " + std::to_string(nblk));
+            // gradient pool + incidence lists (Potential::grad_gather)
+            P.grad_gather = P.lazy_capable && !P.conn_ext && !P.conn_host.empty() && c.world == 1 && !c.no_grad_gather;
+            std::vector<int64_t> sig{(int64_t)P.n_elem, c.nbr};
+            for (int k = 0; k < P.NB; k++) {
+                sig.push_back(A.dof_col[k]);
+                sig.push_back(A.dof_row_off[k]);
+            }
+            if (P.grad_gather && P.inc_sig == sig) {  // lists still valid (prepare() runs at every change of the contact sets)
+                A.gpool = P.gpool.p;
+                A.n_gpool = P.n_pool_f;
+            } else if (P.grad_gather) {
+                P.inc_sig = sig;
+                const int n_gpool = P.n_pool_f;
+                std::vector<uint32_t> start((size_t)c.nbr + 1, 0u), inc((size_t)P.n_elem * P.NB);
+                for (int e = 0; e < P.n_elem; e++)
+                    for (int k = 0; k < P.NB; k++) start[(size_t)(A.dof_row_off[k] + P.conn_host[(size_t)e * P.conn_stride + A.dof_col[k]]) + 1]++;
+                for (int64_t r = 0; r < c.nbr; r++) start[(size_t)r + 1] += start[(size_t)r];
+                std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+                for (int e = 0; e < P.n_elem; e++)  // element-major: the contributions of a row are summed in element order
+                    for (int k = 0; k < P.NB; k++) inc[fill[(size_t)(A.dof_row_off[k] + P.conn_host[(size_t)e * P.conn_stride + A.dof_col[k]])]++] = (uint32_t)k * (uint32_t)n_gpool + (uint32_t)e;
+                P.inc_start.ensure(start.size());
+                P.inc.ensure(std::max<size_t>(inc.size(), 1));
+                P.gpool.ensure((size_t)n_gpool * P.NB * 3);
+                MS_CHECK(hipMemcpyAsync(P.inc_start.p, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+                if (!inc.empty()) MS_CHECK(hipMemcpyAsync(P.inc.p, inc.data(), inc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
+                MS_CHECK(hipStreamSynchronize(c.stream));  // (host vectors are temporaries)
+                A.gpool = P.gpool.p;
+                A.n_gpool = n_gpool;
+            }
         }
         }
         c.n_elem_total = e_off;
         c.hess_total = h_off;
+        c.hf_total = hf_off;
         c.elemE.ensure(std::max<size_t>(e_off, 1));
-        c.elemH.ensure(std::max<size_t>(h_off, 1));
+        // (the element-Hessian pools are allocated by the first evaluation that writes them)
         c.is_projected.ensure(std::max<size_t>(e_off, 1));
         if (c.world > 1) MS_CHECK(hipMemsetAsync(c.elemE.p, 0, std::max<size_t>(e_off, 1) * sizeof(double), c.stream));  // other ranks' elements count 0
         c.dinv.ensure((size_t)c.nbr * 9);
@@ -1014,9 +1187,15 @@ void ensure_pattern(Context& c)
 // ======================================================================================================================
 // eval()
 // ======================================================================================================================
-void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs)
+void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs, bool lazy)
 {
     prepare(c);
+    if (mode == MISTARK_EVAL_P_G_H) {
+        // lazy: float upper-triangle blocks for the potentials that can recompute their double blocks on demand (Potential::lazy_capable)
+        c.lazy_active = lazy && c.world == 1 && !c.atomic_assembly && c.hf_total > 0;
+        c.elemH.ensure(std::max<size_t>(c.hess_total, 1));  // (the lazy potentials' share stays untouched address space)
+        c.elemHf.ensure(std::max<size_t>(c.lazy_active ? c.hf_total : 0, 16));  // (the gather reads element 0 of the pool that does not apply)
+    }
     if (mode != MISTARK_EVAL_P) {
         MS_CHECK(hipMemsetAsync(c.grad.p, 0, (size_t)c.ndofs * sizeof(double), c.stream));
         if (c.n_hot > 0) MS_CHECK(hipMemsetAsync(c.grad_hot.p, 0, (size_t)HOT_WAYS * 3 * c.n_hot * sizeof(double), c.stream));
@@ -1121,9 +1300,11 @@ struct ProjRecords  // sharded projection: where k_project_eig records its matri
     unsigned long long cap;
     uint32_t part_bit;  // 0x80000000 for potentials of the dynamic matrix part
 };
+// Pool addressing of the projection kernels: element e = list[li]; its blocks sit at H[(a*NB+b) * n_pool + pe], pe = e, or pe = li for a
+// compact pool (the recomputed double blocks of a lazy potential's selected elements); slot_of_src is indexed by key: (a*NB+b) * n_elem + e.
 template <int NB>
-__global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elemH, int n_elem, const uint32_t* __restrict__ list, int n_list, double eps, int mirroring,
-                                                       const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters, ProjRecords rec)
+__global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list, int n_list, double eps,
+                                                       int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters, ProjRecords rec)
 {
     constexpr int n = 3 * NB, nn = n * n, m = (n + 1) & ~1;  // m: even number of players of the round-robin schedule
     __shared__ double sA[4][nn], sV[4][nn], sC[4][m], sS[4][m], sL[4][m];
@@ -1132,14 +1313,15 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elem
     const int w = blockIdx.x * 4 + wave;
     if (w >= n_list) return;
     const int e = (int)list[w];
+    const int pe = compact ? w : e;
     double* A = sA[wave];
     double* V = sV[wave];
-    const size_t hs = (size_t)n_elem * 9;
+    const size_t hs = (size_t)n_pool * 9;
     // load (block layout [a*NB+b][e][3][3]) and symmetrise exactly as stored
     for (int t = lane; t < nn; t += 64) {
         const int i = t / n, j = t - i * n;
         const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
-        A[t] = elemH[(size_t)(ba * NB + bb) * hs + (size_t)e * 9 + ii * 3 + jj];
+        A[t] = elemH[(size_t)(ba * NB + bb) * hs + (size_t)pe * 9 + ii * 3 + jj];
         V[t] = i == j ? 1.0 : 0.0;
     }
     double fro = 0.0;
@@ -1248,7 +1430,7 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elem
         for (int k = 0; k < n; k++) acc += V[i * n + k] * sL[wave][k] * V[j * n + k];
         const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
         const size_t blk = (size_t)(ba * NB + bb) * n_elem + e;
-        double* dst = elemH + blk * 9 + ii * 3 + jj;
+        double* dst = elemH + (size_t)(ba * NB + bb) * hs + (size_t)pe * 9 + ii * 3 + jj;
         if (rec.pos) {
             const unsigned long long k = rec_base + (unsigned long long)t;
             if (k < rec.cap) {
@@ -1293,8 +1475,9 @@ struct ProjWaveShared  // LDS of ONE wavefront (waves of a block may work on dif
 };
 // w = index of this wavefront within the list (EPW elements each)
 template <int NB>
-__device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, double* __restrict__ elemH, int n_elem, const uint32_t* __restrict__ list, int n_list, double eps,
-                                                  int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters, const ProjRecords& rec)
+__device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list,
+                                                  int n_list, double eps, int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals,
+                                                  int64_t* __restrict__ counters, const ProjRecords& rec)
 {
     constexpr int n = 3 * NB, nn = n * n, m = (n + 1) & ~1, W = m, EPW = 64 / W;
     const int lane = threadIdx.x & 63;
@@ -1304,14 +1487,15 @@ __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, 
     const bool elem_ok = g < EPW && li < n_list;
     const bool valid = elem_ok && c < n;  // this lane holds a column
     const int e = elem_ok ? (int)list[li] : 0;
-    const size_t hs = (size_t)n_elem * 9;
+    const int pe = compact ? (elem_ok ? li : 0) : e;
+    const size_t hs = (size_t)n_pool * 9;
     const int bb = c / 3, jj = c - 3 * bb;
     double* M = S.M[g];
     double a[n], v[n];
 #pragma unroll
     for (int i = 0; i < n; i++) {
         const int ba = i / 3, ii = i - 3 * ba;
-        a[i] = valid ? elemH[(size_t)(ba * NB + bb) * hs + (size_t)e * 9 + ii * 3 + jj] : 0.0;
+        a[i] = valid ? elemH[(size_t)(ba * NB + bb) * hs + (size_t)pe * 9 + ii * 3 + jj] : 0.0;
         v[i] = i == c ? 1.0 : 0.0;
     }
     auto group_sum = [&](double x) {
@@ -1435,7 +1619,7 @@ __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, 
         for (int k = 0; k < n; k++) acc = fma(M[i * W + k] * wc[k], S.L[g][k], acc);  // (V_ik V_ck) l_k: symmetric in (i, c) to the bit
         const int ba = i / 3, ii = i - 3 * ba;
         const size_t blk = (size_t)(ba * NB + bb) * n_elem + e;
-        double* dst = elemH + blk * 9 + ii * 3 + jj;
+        double* dst = elemH + (size_t)(ba * NB + bb) * hs + (size_t)pe * 9 + ii * 3 + jj;
         if (rec.pos) {
             const unsigned long long k = rec_base + (unsigned long long)(i * n + c);
             if (k < rec.cap) {
@@ -1450,12 +1634,13 @@ __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, 
 }
 
 template <int NB>
-__global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__ elemH, int n_elem, const uint32_t* __restrict__ list, int n_list, double eps, int mirroring,
-                                                            const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters, ProjRecords rec)
+__global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list, int n_list, double eps,
+                                                            int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters,
+                                                            ProjRecords rec)
 {
     __shared__ ProjWaveShared<NB> S[4];
     const int wave = threadIdx.x >> 6;
-    project_cols_body<NB>(S[wave], blockIdx.x * 4 + wave, elemH, n_elem, list, n_list, eps, mirroring, slot_of_src, vals, counters, rec);
+    project_cols_body<NB>(S[wave], blockIdx.x * 4 + wave, elemH, n_elem, n_pool, compact, list, n_list, eps, mirroring, slot_of_src, vals, counters, rec);
 }
 // The short lists of one projection round (contact kinds with a few dozen rows, the rigid-body potentials, ...) in ONE launch: a lone
 // wavefront needs 100-300 us for its elements whatever their number (≈ 90 dependent rotation rounds), a dozen such launches in a row is
@@ -1468,6 +1653,7 @@ struct ProjDesc
     float* vals;
     int n_elem, nl, NB, first_wave;
     uint32_t part_bit;
+    int n_pool, compact;
 };
 constexpr int PROJ_BATCH = 40;
 struct ProjBatch
@@ -1496,12 +1682,12 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_multi(ProjBatch B, double
     rec.part_bit = D.part_bit;
     const int w = gw - D.first_wave;
     switch (D.NB) {
-        case 1: project_cols_body<1>(S[wave].s1, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
-        case 2: project_cols_body<2>(S[wave].s2, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
-        case 3: project_cols_body<3>(S[wave].s3, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
-        case 4: project_cols_body<4>(S[wave].s4, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
-        case 5: project_cols_body<5>(S[wave].s5, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
-        default: project_cols_body<6>(S[wave].s6, w, D.H, D.n_elem, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        case 1: project_cols_body<1>(S[wave].s1, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        case 2: project_cols_body<2>(S[wave].s2, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        case 3: project_cols_body<3>(S[wave].s3, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        case 4: project_cols_body<4>(S[wave].s4, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        case 5: project_cols_body<5>(S[wave].s5, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        default: project_cols_body<6>(S[wave].s6, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
     }
 }
 
@@ -1665,6 +1851,13 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         c.proj_rec_val.ensure(PROJ_REC_CAP);
     }
     int64_t total = 0;
+    size_t lazy_off = 0;
+    if (c.lazy_active) {  // compact double pool for the recomputed blocks of the lazy potentials' selections
+        size_t need = 0;
+        for (int pi = 0; pi < np; pi++)
+            if (c.pots[pi].lazy_capable) need += (size_t)(((int)h[4 + pi] + 63) / 64 * 64) * 9 * c.pots[pi].NB * c.pots[pi].NB;
+        c.projH.ensure(std::max<size_t>(need, 1));
+    }
     if (c.proj_variant & 4) mirroring |= 2;
     constexpr int SHORT_LIST = 4096;  // lists up to this length share one launch (k_project_eig_multi)
     ProjBatch batch;
@@ -1685,7 +1878,17 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         hipStream_t stream = c.stream;
         double* H = c.elemH.p + P.h_off;
         const uint32_t* list = c.proj_list.p + P.e_off;
-        const uint32_t* sos = c.part[P.part].slot_of_src.p + (P.k_off - c.part[P.part].blk_base);
+        const uint32_t* sos = c.part[P.part].slot_of_src.p + P.kp_off;
+        int n_pool = P.n_elem, compact = 0;
+        if (c.lazy_active && P.lazy_capable) {
+            // the double blocks of the selected elements were never stored: recompute them into a compact pool (the list is a small
+            // fraction of the mesh except when PPN activates every element, and then the eigen-decompositions cost 20x this)
+            n_pool = (nl + 63) / 64 * 64;
+            H = c.projH.p + lazy_off;
+            lazy_off += (size_t)n_pool * 9 * P.NB * P.NB;
+            compact = 1;
+            launch_tet_closed_list(c, P, list, nl, H, n_pool);
+        }
         float* vals = (c.matrix_current && c.world == 1) ? c.part[P.part].vals.p : nullptr;
         ProjRecords rec{};
         if (record) rec = ProjRecords{c.proj_rec_pos.p, c.proj_rec_val.p, (unsigned long long*)(c.counters.p + 3), rec_cap, P.part == 1 ? 0x80000000u : 0u};
@@ -1694,31 +1897,31 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
             const int epw = 64 / ((3 * P.NB + 1) & ~1);
             if (nl <= SHORT_LIST && !(c.proj_variant & 2)) {
                 if (batch.n == PROJ_BATCH) flush();
-                batch.d[batch.n++] = ProjDesc{H, list, sos, vals, P.n_elem, nl, P.NB, batch_waves, rec.part_bit};
+                batch.d[batch.n++] = ProjDesc{H, list, sos, vals, P.n_elem, nl, P.NB, batch_waves, rec.part_bit, n_pool, compact};
                 batch_waves += (nl + epw - 1) / epw;
                 batch_rec = rec;
                 continue;
             }
             const dim3 grid(((nl + epw - 1) / epw + 3) / 4);
             switch (P.NB) {
-                case 1: hipLaunchKernelGGL((k_project_eig_cols<1>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 2: hipLaunchKernelGGL((k_project_eig_cols<2>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 3: hipLaunchKernelGGL((k_project_eig_cols<3>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 4: hipLaunchKernelGGL((k_project_eig_cols<4>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 5: hipLaunchKernelGGL((k_project_eig_cols<5>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                default: hipLaunchKernelGGL((k_project_eig_cols<6>), grid, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 1: hipLaunchKernelGGL((k_project_eig_cols<1>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 2: hipLaunchKernelGGL((k_project_eig_cols<2>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 3: hipLaunchKernelGGL((k_project_eig_cols<3>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 4: hipLaunchKernelGGL((k_project_eig_cols<4>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 5: hipLaunchKernelGGL((k_project_eig_cols<5>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                default: hipLaunchKernelGGL((k_project_eig_cols<6>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
             }
             continue;
         }
         switch (P.NB) {
-            case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 2: hipLaunchKernelGGL((k_project_eig<2>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 3: hipLaunchKernelGGL((k_project_eig<3>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 4: hipLaunchKernelGGL((k_project_eig<4>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 5: hipLaunchKernelGGL((k_project_eig<5>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 6: hipLaunchKernelGGL((k_project_eig<6>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 7: hipLaunchKernelGGL((k_project_eig<7>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 8: hipLaunchKernelGGL((k_project_eig<8>), g, b, 0, stream, H, P.n_elem, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 2: hipLaunchKernelGGL((k_project_eig<2>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 3: hipLaunchKernelGGL((k_project_eig<3>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 4: hipLaunchKernelGGL((k_project_eig<4>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 5: hipLaunchKernelGGL((k_project_eig<5>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 6: hipLaunchKernelGGL((k_project_eig<6>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 7: hipLaunchKernelGGL((k_project_eig<7>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 8: hipLaunchKernelGGL((k_project_eig<8>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
             default: throw Error("project: unsupported block count");
         }
     }
@@ -1784,13 +1987,26 @@ __global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __res
     o[5] = o[7];
 }
 
-// Gather assembly (default): one lane per (BSR block, component) sums the contributions of that block in the fixed order of
-// the sorted pattern keys: no atomics, deterministic, double accumulation rounded once to float; 9 consecutive lanes read the
-// 72 contiguous bytes of an element block.
+// Gather assembly (default): the contributions of a BSR block are summed in the fixed order of the sorted pattern keys: no atomics,
+// deterministic, double accumulation rounded once to float (k_assemble_gather; blocks with many contributions: k_assemble_long / _vlong).
+// contribution `desc` (k_make_desc), component comp (row-major) of the 3x3 block
+// Branch-free on purpose: the callers keep eight of these in flight per lane, and loads under divergent control flow are issued one after
+// the other (measured: 630 instead of 460 us for the 1M-tet matrix). Both pools are read, the one that does not apply at its first element.
+__device__ __forceinline__ double contrib(const double* __restrict__ elemH, const float* __restrict__ elemHf, uint32_t desc, int comp, int comp_t)
+{
+    const bool none = desc == NO_SRC;  // (the structural diagonal keys carry no data)
+    const bool f = !none && (desc & DESC_FLOAT) != 0u;
+    const bool d = !none && !f;
+    const size_t blk = (size_t)(desc & DESC_MASK) * 9;
+    const float vf = elemHf[f ? blk + (size_t)((desc & DESC_TRANS) ? comp_t : comp) : (size_t)0];
+    const double vd = elemH[d ? (size_t)desc * 9 + (size_t)comp : (size_t)0];
+    return f ? (double)vf : (d ? vd : 0.0);
+}
 // one wavefront per long block (e.g. the diagonal block of a rigid body touched by thousands of contacts): lanes take
 // contributions k0 + lane, k0 + lane + 64, ... and the nine sums are reduced across the wave; the order is fixed by the sorted keys
-__global__ __launch_bounds__(BLOCK) void k_assemble_long(const double* __restrict__ elemH, const uint32_t* __restrict__ slot_start, const uint32_t* __restrict__ sorted_src,
-                                                        const uint32_t* __restrict__ list, int n_long, const uint32_t* __restrict__ store_slot, float* __restrict__ vals)
+__global__ __launch_bounds__(BLOCK) void k_assemble_long(const double* __restrict__ elemH, const float* __restrict__ elemHf, const uint32_t* __restrict__ slot_start,
+                                                        const uint32_t* __restrict__ sorted_src, const uint32_t* __restrict__ list, int n_long, const uint32_t* __restrict__ store_slot,
+                                                        float* __restrict__ vals)
 {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_long) return;
@@ -1801,9 +2017,8 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_long(const double* __restric
     for (uint32_t k = k0 + lane; k < k1; k += 64) {
         const uint32_t src = sorted_src[k];
         if (src == NO_SRC) continue;
-        const double* h = elemH + (size_t)src * 9;
 #pragma unroll
-        for (int c = 0; c < 9; c++) acc[c] += h[c];
+        for (int c = 0; c < 9; c++) acc[c] += contrib(elemH, elemHf, src, c, (c % 3) * 3 + c / 3);
     }
 #pragma unroll
     for (int c = 0; c < 9; c++) {
@@ -1814,8 +2029,8 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_long(const double* __restric
 // very long blocks: VLONG_SPLIT wavefronts per block sum contiguous ranges of its contribution list, a second pass adds the partial sums in
 // range order (deterministic like the one-wavefront version, 64 times the parallelism: 2.2 ms -> tens of us for the four diagonal blocks
 // of a floor under 136 k contact and friction rows)
-__global__ __launch_bounds__(BLOCK) void k_assemble_vlong_part(const double* __restrict__ elemH, const uint32_t* __restrict__ slot_start, const uint32_t* __restrict__ sorted_src,
-                                                              const uint32_t* __restrict__ list, int n_vlong, double* __restrict__ part)
+__global__ __launch_bounds__(BLOCK) void k_assemble_vlong_part(const double* __restrict__ elemH, const float* __restrict__ elemHf, const uint32_t* __restrict__ slot_start,
+                                                              const uint32_t* __restrict__ sorted_src, const uint32_t* __restrict__ list, int n_vlong, double* __restrict__ part)
 {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_vlong * VLONG_SPLIT) return;
@@ -1829,9 +2044,8 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_vlong_part(const double* __r
     for (uint32_t k = c0 + lane; k < c1; k += 64) {
         const uint32_t src = sorted_src[k];
         if (src == NO_SRC) continue;
-        const double* h = elemH + (size_t)src * 9;
 #pragma unroll
-        for (int c = 0; c < 9; c++) acc[c] += h[c];
+        for (int c = 0; c < 9; c++) acc[c] += contrib(elemH, elemHf, src, c, (c % 3) * 3 + c / 3);
     }
 #pragma unroll
     for (int c = 0; c < 9; c++) {
@@ -1853,31 +2067,92 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_vlong_fold(const double* __r
         if (lane == 0) vals[tile_val_index(store_slot ? store_slot[slot] : slot, c)] = (float)v;
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restrict__ elemH, const uint32_t* __restrict__ slot_start,
+// One lane per BSR block: nine double accumulators, the contributions of the block summed in list order (deterministic, one float
+// rounding at the end), four contributions in flight per lane. A float contribution is 36 contiguous bytes (three 12-byte loads), a
+// double one 72; consecutive lanes own consecutive blocks, whose contributions come from neighbouring elements, and write neighbouring
+// float4s of the tile layout. (The earlier lane-per-(block, component) version was bound by the latency of its dependent loads:
+// 360 k wavefronts with three round trips each, 460 us for the 1M-tet matrix; its float-pool variant 630-770 us.)
+struct F3
+{
+    float x, y, z;
+};
+__global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restrict__ elemH, const float* __restrict__ elemHf, const uint32_t* __restrict__ slot_start,
                                                            const uint32_t* __restrict__ sorted_src, int64_t nnzb, const uint32_t* __restrict__ store_slot, float* __restrict__ vals)
 {
-    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= nnzb * 9) return;
-    const uint32_t slot = (uint32_t)(t / 9);
-    const int comp = (int)(t - (int64_t)slot * 9);
+    const int64_t slot = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= nnzb) return;
     const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1];
     if (k1 - k0 > LONG_SLOT) return;  // k_assemble_long
-    // the contributions of a block are summed in list order (deterministic); their loads are issued eight at a time, the source ids
-    // first, so a thread has eight element-Hessian reads in flight instead of one dependent pair after the other
-    double acc = 0.0;
-    for (uint32_t kb = k0; kb < k1; kb += 8) {
-        uint32_t src[8];
-        double h[8];
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t kb = k0; kb < k1; kb += 4) {
+        uint32_t d[4];
+        F3 v[4][3];
 #pragma unroll
-        for (int u = 0; u < 8; u++) src[u] = kb + u < k1 ? sorted_src[kb + u] : NO_SRC;
+        for (int u = 0; u < 4; u++) d[u] = kb + u < k1 ? sorted_src[kb + u] : NO_SRC;
 #pragma unroll
-        for (int u = 0; u < 8; u++) h[u] = src[u] != NO_SRC ? elemH[(size_t)src[u] * 9 + comp] : 0.0;  // (the structural diagonal keys carry no data)
+        for (int u = 0; u < 4; u++) {
+            const bool f = d[u] != NO_SRC && (d[u] & DESC_FLOAT) != 0u;
+            const F3* src = reinterpret_cast<const F3*>(elemHf + (f ? (size_t)(d[u] & DESC_MASK) * 9 : (size_t)0));  // (block 0 of the pool when not a float contribution)
+            v[u][0] = src[0];
+            v[u][1] = src[1];
+            v[u][2] = src[2];
+        }
+        bool any_double = false;
 #pragma unroll
-        for (int u = 0; u < 8; u++) acc += h[u];
+        for (int u = 0; u < 4; u++) {
+            const bool f = d[u] != NO_SRC && (d[u] & DESC_FLOAT) != 0u;
+            const bool t = (d[u] & DESC_TRANS) != 0u;
+            any_double = any_double || (d[u] != NO_SRC && !f);
+            if (f) {
+                acc[0] += (double)v[u][0].x;
+                acc[1] += (double)(t ? v[u][1].x : v[u][0].y);
+                acc[2] += (double)(t ? v[u][2].x : v[u][0].z);
+                acc[3] += (double)(t ? v[u][0].y : v[u][1].x);
+                acc[4] += (double)v[u][1].y;
+                acc[5] += (double)(t ? v[u][2].y : v[u][1].z);
+                acc[6] += (double)(t ? v[u][0].z : v[u][2].x);
+                acc[7] += (double)(t ? v[u][1].z : v[u][2].y);
+                acc[8] += (double)v[u][2].z;
+            }
+        }
+        if (any_double) {  // contributions from the double pool (potentials off the lazy path; every potential on staged calls)
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (d[u] == NO_SRC || (d[u] & DESC_FLOAT)) continue;
+                const double* h = elemH + (size_t)d[u] * 9;
+#pragma unroll
+                for (int c = 0; c < 9; c++) acc[c] += h[c];
+            }
+        }
     }
-    vals[tile_val_index(store_slot ? store_slot[slot] : slot, comp)] = (float)acc;
+    const uint32_t pos = store_slot ? store_slot[slot] : (uint32_t)slot;
+    float* tile = vals + (size_t)(pos >> 6) * 576;
+    const uint32_t lane = pos & 63u;
+    reinterpret_cast<float4*>(tile)[lane] = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+    reinterpret_cast<float4*>(tile)[64 + lane] = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
+    tile[512 + lane] = (float)acc[8];
 }
 
+// descriptors of the gather lists for the current state of the pools (lazy or not): once per pattern and lazy state
+static void make_descriptors(Context& c, int part)
+{
+    BsrPart& m = c.part[part];
+    if (m.desc_lazy == (c.lazy_active ? 1 : 0) || m.n_keys == 0) return;
+    std::vector<DescRange> rg;
+    for (auto& P : c.pots) {
+        if (P.part != part || P.n_elem == 0) continue;
+        const bool lazy = c.lazy_active && P.lazy_capable;
+        rg.push_back(DescRange{(uint32_t)P.kp_off, (uint32_t)P.n_elem, (uint32_t)P.NB, (uint32_t)P.args.e_begin, (uint32_t)P.args.e_count,
+                               lazy ? (uint32_t)(P.hf_off / 9) : (uint32_t)P.k_off, lazy ? (uint32_t)P.n_pool_f : (uint32_t)P.n_elem, lazy ? 1u : 0u});
+    }
+    if (c.hess_total / 9 > DESC_MASK || c.hf_total / 9 > DESC_MASK) throw Error("element-Hessian pool too large for the gather descriptors");
+    m.sorted_desc.ensure(m.n_keys);
+    c.src_ranges.ensure(std::max<size_t>(rg.size(), 1) * sizeof(DescRange));
+    if (!rg.empty()) MS_CHECK(hipMemcpyAsync(c.src_ranges.p, rg.data(), rg.size() * sizeof(DescRange), hipMemcpyHostToDevice, c.stream));
+    hipLaunchKernelGGL(k_make_desc, dim3(grid_for((int64_t)m.n_keys)), dim3(BLOCK), 0, c.stream, m.sorted_src, m.n_keys, (const DescRange*)c.src_ranges.p, (int)rg.size(), m.sorted_desc.p);
+    MS_CHECK(hipStreamSynchronize(c.stream));  // rg is a temporary
+    m.desc_lazy = c.lazy_active ? 1 : 0;
+}
 void assemble(Context& c)
 {
     ensure_pattern(c);
@@ -1890,16 +2165,18 @@ void assemble(Context& c)
             for (auto& P : c.pots) {
                 const int64_t nblk = (int64_t)P.n_elem * P.NB * P.NB;
                 if (P.part != part || nblk == 0) continue;
-                hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p + P.h_off, nblk, m.slot_of_src.p + (P.k_off - m.blk_base), m.vals.p);
+                hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p + P.h_off, nblk, m.slot_of_src.p + P.kp_off, m.vals.p);
             }
         } else {
+            make_descriptors(c, part);
             const uint32_t* store = part == 0 ? m.store_slot.p : nullptr;
-            hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.nnzb, store, m.vals.p);
+            const uint32_t* desc = m.sorted_desc.p;
+            hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.nnzb, store, m.vals.p);
             if (m.n_long > 0)
-                hipLaunchKernelGGL(k_assemble_long, dim3((m.n_long + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.long_slots.p, m.n_long, store, m.vals.p);
+                hipLaunchKernelGGL(k_assemble_long, dim3((m.n_long + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.long_slots.p, m.n_long, store, m.vals.p);
             if (m.n_vlong > 0) {
                 c.vlong_part.ensure((size_t)m.n_vlong * VLONG_SPLIT * 9);
-                hipLaunchKernelGGL(k_assemble_vlong_part, dim3((m.n_vlong * VLONG_SPLIT + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, m.slot_start.p, m.sorted_src, m.vlong_slots.p,
+                hipLaunchKernelGGL(k_assemble_vlong_part, dim3((m.n_vlong * VLONG_SPLIT + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.vlong_slots.p,
                                    m.n_vlong, c.vlong_part.p);
                 hipLaunchKernelGGL(k_assemble_vlong_fold, dim3((m.n_vlong + 3) / 4), dim3(BLOCK), 0, c.stream, (const double*)c.vlong_part.p, m.vlong_slots.p, m.n_vlong, store, m.vals.p);
             }

@@ -62,13 +62,16 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
         double residual = 0.0;
         {
             Timer t(st.t_eval_pgh);
-            eval(c, MISTARK_EVAL_P_G_H, &E0, nullptr, &residual);  // default residual: ||grad||_inf (solver_utils.h:28), read back with the energy
+            // default residual: ||grad||_inf (solver_utils.h:28), read back with the energy. Progressive / no projection never reads the
+            // double blocks of an element it does not project: the closed-form tets write float blocks only (eval: lazy)
+            const bool lazy = c.lazy_allowed && (s.projection_mode == MISTARK_PROJ_PROGRESSIVE || s.projection_mode == MISTARK_PROJ_NEWTON) && s.linear_solver != MISTARK_SOLVER_DIRECT_LLT;
+            eval(c, MISTARK_EVAL_P_G_H, &E0, nullptr, &residual, lazy);
             st.n_evaluations++;
         }
         if (it == 0) res_0 = residual;
-        if (!(residual == residual)) {
-            // NaN gradient: the reference would spin forever here (every comparison below is false and the projection threshold
-            // becomes NaN too); report the failure instead so that the time step is halved / the run stops
+        if (!std::isfinite(residual) || !std::isfinite(E0)) {
+            // NaN / inf energy or gradient (k_max_abs turns a NaN entry into +inf): the reference would spin forever here (every comparison
+            // below is false and the projection threshold becomes NaN too); report the failure instead so that the time step is halved / the run stops
             result = MISTARK_LINEAR_SYSTEM_SOLVE_FAILURE;
             break;
         }

@@ -271,3 +271,51 @@ def stark_amd_engine_keep_empty(prob):
     from gpu_util import engine_from_problem
 
     return engine_from_problem(prob)
+
+
+@pytest.mark.parametrize("name", ["tetbeam_eo_4x1x1", "tetbeam_eo_4x1x1_big", "tetbeam_full_4x1x1", "tetbeam_softrubber_6x2x2", "contactmix_t1"])
+def test_lazy_hessian_path_matches_full(name):
+    """Inside the Newton loop the closed-form tets write FLOAT upper-triangle blocks only (360 instead of 1152 bytes per tet) and the double
+    blocks of the elements a projection round selects are recomputed on demand (option lazy_eval for staged calls). Same gradient, the same
+    matrix up to the float rounding of the contributions (which is what the reference's own assembly does: BlockedSparseMatrix.h:781-814
+    casts every element block to float before adding it), the same projection decisions, and the projected matrices agree."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    path = os.path.join(GOLDEN, name + ".npz")
+    prob, man, z = ev.load_fixture(path)
+    eps32 = np.finfo(np.float32).eps
+    out = []
+    for lazy in (0, 1):
+        eng = engine_from_problem(prob, man)
+        eng.set_option("lazy_eval", lazy)
+        E, grad = eng.eval(capi.EVAL_P_G_H)
+        assert _rel(grad, z["grad"]) < 1e-11
+        eng.assemble()
+        rp, cols, v0 = eng.get_bsr()
+        S = sp.bsr_matrix((v0.astype(np.float64), cols, rp), shape=(prob.ndofs, prob.ndofs)).tocsr()
+        Sref = sp.coo_matrix((z["A_vals"], (z["A_rows"], z["A_cols"])), shape=S.shape).tocsr()
+        assert abs(S - Sref).max() <= 64 * eps32 * abs(Sref).max()
+        xs, info = eng.pcg(man["pcg"]["abs_tol"])
+        assert abs(info.n_iterations - man["pcg"]["iterations"]) <= 1
+        # a progressive round (rows with a large gradient), then everything: deltas go into the assembled matrix
+        act = (np.abs(z["grad"]).reshape(-1, 3).max(axis=1) >= 0.3 * np.abs(z["grad"]).max()).astype(np.uint8)
+        r1 = eng.project(1e-10, False, act)
+        v1 = eng.get_bsr()[2].copy()
+        r2 = eng.project(1e-10, False, None)
+        v2 = eng.get_bsr()[2].copy()
+        out.append((grad, v0, r1, v1, r2, v2))
+        if lazy:
+            for pi, pid in eng.pot_ids.items():
+                if "TetStrain" in man["potentials"][pi]["name"]:
+                    with pytest.raises(RuntimeError):
+                        eng.element_hessians(pid, man["potentials"][pi]["n_elem"])
+        eng.close()
+    a, b = out
+    assert _rel(b[0], a[0]) < 1e-12
+    scale = np.abs(a[1]).max()
+    assert np.abs(b[1] - a[1]).max() <= 16 * eps32 * scale
+    assert b[2] == a[2] and b[4] == a[4]          # (n_projected, n_changed) of both rounds
+    assert a[4][0] > 0
+    assert np.abs(b[3] - a[3]).max() <= 64 * eps32 * scale
+    assert np.abs(b[5] - a[5]).max() <= 64 * eps32 * scale
