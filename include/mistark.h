@@ -261,16 +261,34 @@ int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us);
  * axpby only enqueue). For timing from the host. */
 int mistark_sync(mistark_ctx* ctx);
 
-/* ---- multi-GPU: elements of every potential sharded by contiguous ranges over `world` ranks (one engine context per GPU) ------------
- * Energy, gradient and the assembled matrix are summed over the ranks (RCCL all-reduce on the engine's stream); the linear solve,
- * line search and contact detection are replicated, so every rank holds the full state and runs the same host code.
- * Call right after mistark_create, before the first evaluation. */
-int mistark_shard_range(int64_t n_elements, int rank, int world, int64_t* begin, int64_t* end); /* the contiguous range of a rank */
+/* ---- multi-GPU: one problem sharded over `world` ranks, one engine context (and one process) per GPU ------------------------
+ * Block rows are partitioned over the ranks (owner map: mistark_dist_set_row_owner, or a graph partition of the potentials' connectivity).
+ * A rank evaluates every element that touches one of its rows (interface elements are evaluated by both sides: no gradient / Hessian
+ * traffic), assembles and solves ITS rows of the system (block-Jacobi PCG on a row-sharded matrix: the ghosts of the search direction
+ * from their owners and the three dot products of solve_pcg.h:180,201,217 are exchanged in every iteration, (r.r, r.z) fused), and
+ * holds the whole state (DoFs, bound arrays, contact tables), so every rank runs the same host code and takes the same decisions.
+ * All exchanges are all-gathers on the engine's stream: ncclAllGather over xGMI (RCCL), or a copy kernel for ranks inside one process.
+ * Reductions are done by every rank in rank order: identical bits everywhere. Call right after mistark_create, before the first
+ * evaluation. With N ranks mistark_get_bsr / mistark_apply_preconditioner are not available (single-rank accessors). */
+int mistark_shard_range(int64_t n, int rank, int world, int64_t* begin, int64_t* end); /* [n*rank/world, n*(rank+1)/world) */
 int mistark_dist_unique_id(char out[128]);  /* rank 0: ncclGetUniqueId, to be broadcast by the launcher (e.g. torch.distributed) */
 int mistark_dist_init_rccl(mistark_ctx* ctx, int rank, int world, const char unique_id[128]);
-/* one-rank RCCL round trip (f64 + f32 all-reduce of `inout`) through the entry points the N-rank path uses */
+/* Moves the communicator (rank, world, transport) of `from` to `ctx`; `from` becomes a single-rank context (a scene that registers
+ * again keeps its communicator: an RCCL unique id is single-use). */
+int mistark_dist_move(mistark_ctx* ctx, mistark_ctx* from);
+/* one-rank RCCL round trip (all-gather of `inout`) through the dlopen'ed entry points the N-rank path uses */
 int mistark_dist_rccl_selftest(mistark_ctx* ctx, double* inout, int64_t n);
-/* the same sharded path with several contexts inside one process (one host thread per context), used by the single-GPU tests */
+/* Explicit partition: owner[r] in [0, world) for every block row r of the flat DoF vector (e.g. slabs along the longest axis from the
+ * scene's positions). owner == NULL returns to the built-in graph partition. */
+int mistark_dist_set_row_owner(mistark_ctx* ctx, const int32_t* owner, int64_t n_block_rows);
+/* Block rows that potentials with device-side connectivity may reference on any rank; every rank keeps them as ghosts. The contact system
+ * registers the collision vertices of its deformable meshes itself; small DoF sets (rigid bodies) are always shared. */
+int mistark_dist_add_shared_rows(mistark_ctx* ctx, const int32_t* rows, int64_t n);
+/* out[0..6): block rows owned by this rank, ghosts, rows it sends, elements it evaluates, blocks of its static / contact matrix part */
+int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n);
+int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner);
+/* the same sharded path with several contexts inside one process (one host thread per context, one device, one shared stream), used by
+ * the single-GPU tests */
 typedef struct mistark_local_group mistark_local_group;
 mistark_local_group* mistark_local_group_create(int world);
 void mistark_local_group_destroy(mistark_local_group* group);

@@ -130,6 +130,12 @@ def lib():
     L.mistark_local_group_destroy.argtypes = [p]
     L.mistark_local_group_destroy.restype = None
     L.mistark_dist_init_local.argtypes = [p, p, C.c_int]
+    L.mistark_dist_set_row_owner.argtypes = [p, p, i64]
+    L.mistark_dist_add_shared_rows.argtypes = [p, p, i64]
+    L.mistark_dist_info.argtypes = [p, p, C.c_int]
+    L.mistark_dist_get_row_owner.argtypes = [p, p]
+    L.mistark_dist_move.argtypes = [p, p]
+    L.mistark_sync.argtypes = [p]
     L.mistark_get_bsr.argtypes = [p, C.POINTER(i64), C.POINTER(i64), p, p, p]
     L.mistark_spmv.argtypes = [p, p, p]
     L.mistark_apply_preconditioner.argtypes = [p, p, p]

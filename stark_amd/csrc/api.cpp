@@ -478,6 +478,7 @@ int mistark_get_bsr(mistark_ctx* ctx, int64_t* n_block_rows, int64_t* nnzb, int6
 {
     API_BEGIN
     Context& c = ctx->c;
+    if (c.world > 1) throw Error("mistark_get_bsr: single-rank accessor (a sharded context holds its own block rows in local numbering)");
     ensure_pattern(c);
     // the engine keeps A = A_static + A_dynamic (contacts) as two block-CSR parts; this parity accessor merges them on the host
     struct Blk
@@ -546,7 +547,13 @@ int mistark_spmv(mistark_ctx* ctx, const double* x_host, double* y_host)
     Context& c = ctx->c;
     if (!c.have_matrix) throw Error("matrix not assembled");
     MS_CHECK(hipMemcpyAsync(c.tmp_a.p, x_host, (size_t)c.ndofs * sizeof(double), hipMemcpyHostToDevice, c.stream));
-    spmv_device(c, c.tmp_a.p, c.tmp_b.p, nullptr, nullptr, true);
+    if (c.world > 1) {  // this rank's rows of y from its rows of A, gathered into the whole vector on every rank
+        shard_to_local(c, c.tmp_a.p, c.p.p, true);
+        spmv_device(c, c.p.p, c.q.p, nullptr, nullptr, true);
+        shard_gather_global(c, c.q.p, c.tmp_b.p);
+    } else {
+        spmv_device(c, c.tmp_a.p, c.tmp_b.p, nullptr, nullptr, true);
+    }
     MS_CHECK(hipMemcpyAsync(y_host, c.tmp_b.p, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
     API_END(0)
@@ -556,6 +563,7 @@ int mistark_apply_preconditioner(mistark_ctx* ctx, const double* x_host, double*
     API_BEGIN
     Context& c = ctx->c;
     if (!c.have_matrix) throw Error("matrix not assembled");
+    if (c.world > 1) throw Error("mistark_apply_preconditioner: single-rank accessor");
     build_preconditioner(c);
     // z = M^-1 x on the host from the device-built float inverse (parity probe only; the solver applies it on the device)
     std::vector<float> d((size_t)c.nbr * 9);
@@ -666,6 +674,13 @@ static void set_dist(Context& c, int rank, int world, std::unique_ptr<Collective
     c.rank = rank;
     c.world = world;
     c.coll = std::move(coll);
+    if (c.coll && c.coll->shared_stream()) {  // in-process group: all ranks run on the group's stream
+        MS_CHECK(hipStreamSynchronize(c.stream));
+        if (c.owns_stream && c.stream) (void)hipStreamDestroy(c.stream);
+        c.stream = c.coll->shared_stream();
+        c.owns_stream = false;
+    }
+    c.sh.sig.clear();
     c.layout_dirty = true;
     c.part[0].dirty = c.part[1].dirty = true;
 }
@@ -678,28 +693,72 @@ int mistark_dist_init_rccl(mistark_ctx* ctx, int rank, int world, const char uni
 }
 int mistark_dist_rccl_selftest(mistark_ctx* ctx, double* inout, int64_t n)
 {
-    // one-rank communicator through the same dlopen'ed entry points the N-rank path uses: sums `inout` with itself only
+    // one-rank communicator through the same dlopen'ed entry points the N-rank path uses: the all-gather of one rank returns its input
     API_BEGIN
     Context& c = ctx->c;
     MS_CHECK(hipSetDevice(c.device));
     char id[128];
     rccl_unique_id(id);
     std::unique_ptr<Collective> coll = make_rccl_collective(0, 1, id);
-    DevBuf<double> d;
-    DevBuf<float> f;
+    DevBuf<double> d, o;
     d.ensure((size_t)n);
-    f.ensure((size_t)n);
-    std::vector<float> hf((size_t)n);
-    for (int64_t i = 0; i < n; i++) hf[i] = (float)inout[i];
+    o.ensure((size_t)n);
     MS_CHECK(hipMemcpyAsync(d.p, inout, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c.stream));
-    MS_CHECK(hipMemcpyAsync(f.p, hf.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice, c.stream));
-    coll->allreduce_f64(d.p, (size_t)n, c.stream);
-    coll->allreduce_f32(f.p, (size_t)n, c.stream);
-    MS_CHECK(hipMemcpyAsync(inout, d.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
-    MS_CHECK(hipMemcpyAsync(hf.data(), f.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipMemsetAsync(o.p, 0, (size_t)n * sizeof(double), c.stream));
+    coll->allgather_f64(d.p, o.p, (size_t)n, c.stream);
+    MS_CHECK(hipMemcpyAsync(inout, o.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
-    for (int64_t i = 0; i < n; i++)
-        if (hf[i] != (float)inout[i]) throw Error("RCCL self test: float and double results differ");
+    API_END(0)
+}
+int mistark_dist_move(mistark_ctx* ctx, mistark_ctx* from)
+{
+    // a scene that registers again (objects added mid-run) builds a new context: the communicator moves over (an RCCL unique id is
+    // single-use, a second ncclCommInitRank on it would hang)
+    API_BEGIN
+    if (!from) throw Error("mistark_dist_move: null source");
+    Context& o = from->c;
+    if (o.world > 1 && !o.coll) throw Error("mistark_dist_move: the source has no communicator");
+    MS_CHECK(hipStreamSynchronize(o.stream));
+    set_dist(ctx->c, o.rank, o.world, std::move(o.coll));
+    ctx->c.sh.user_owner = o.sh.user_owner;
+    o.world = 1;
+    o.rank = 0;
+    API_END(0)
+}
+int mistark_dist_set_row_owner(mistark_ctx* ctx, const int32_t* owner, int64_t n_block_rows)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (owner && n_block_rows > 0) c.sh.user_owner.assign(owner, owner + n_block_rows);
+    else c.sh.user_owner.clear();
+    c.sh.version++;
+    c.layout_dirty = true;
+    API_END(0)
+}
+int mistark_dist_add_shared_rows(mistark_ctx* ctx, const int32_t* rows, int64_t n)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (rows && n > 0) c.sh.shared_rows.insert(c.sh.shared_rows.end(), rows, rows + n);
+    c.sh.version++;
+    c.layout_dirty = true;
+    API_END(0)
+}
+int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    const int64_t v[6] = {c.world > 1 ? c.sh.n_own : c.nbr, c.world > 1 ? c.sh.n_ghost : 0, c.world > 1 ? c.sh.n_send : 0, (int64_t)c.n_elem_total, c.part[0].nnzb, c.part[1].nnzb};
+    for (int i = 0; i < n && i < 6; i++) out[i] = v[i];
+    API_END(0)
+}
+int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    for (int64_t r = 0; r < c.nbr; r++) owner[r] = c.world > 1 ? c.sh.owner[(size_t)r] : 0;
     API_END(0)
 }
 mistark_local_group* mistark_local_group_create(int world)
@@ -714,7 +773,7 @@ int mistark_dist_init_local(mistark_ctx* ctx, mistark_local_group* group, int ra
 {
     API_BEGIN
     if (!group) throw Error("null group");
-    set_dist(ctx->c, rank, group->g->world, group->g->world > 1 ? make_local_collective(group->g, rank) : nullptr);
+    set_dist(ctx->c, rank, group->g->world, group->g->world > 1 ? make_local_collective(group->g, rank, ctx->c.device) : nullptr);
     API_END(0)
 }
 

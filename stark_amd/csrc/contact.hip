@@ -842,6 +842,19 @@ struct ContactSystem
     Table tables[N_TABLES];
     int n_v = 0, n_t = 0, n_e = 0;
 };
+// sharded runs: the block rows contact potentials may reference (the collision vertices of the deformable meshes; rigid bodies are small DoF
+// sets, shared anyway). Every rank keeps them as ghosts (shard.hip).
+void contact_shared_rows(Context& c, std::vector<int32_t>& rows)
+{
+    if (!c.contact) return;
+    ContactSystem& cs = *c.contact;
+    const int v1 = cs.arr.v1;
+    if (v1 < 0 || v1 >= (int)c.arrays.size() || c.arrays[v1].dof_set < 0) return;
+    const int64_t row0 = c.dof_sets[c.arrays[v1].dof_set].offset / 3;
+    for (const ContactSystem::Mesh& m : cs.meshes)
+        if (m.kind == MISTARK_CONTACT_DEFORMABLE)
+            for (int i = 0; i < m.n_v; i++) rows.push_back((int32_t)(row0 + cs.h_cv_src[(size_t)(m.v_off + i)]));
+}
 void contact_destroy(ContactSystem* cs)
 {
     if (cs && cs->td_pinned) (void)hipHostFree(cs->td_pinned);
@@ -921,6 +934,7 @@ int contact_add_mesh(Context& c, int kind, int idx_in_ps, const int32_t* vidx, i
     if (nv <= 0 || nt < 0 || ne < 0) throw Error("contact: bad mesh size");
     ContactSystem::Mesh m{kind, idx_in_ps, cs.n_v, nv, cs.n_t, nt, cs.n_e, ne};
     const int g = (int)cs.meshes.size();
+    c.layout_dirty = true;  // (sharded runs: the mesh's vertices become shared rows)
     for (int i = 0; i < nv; i++) {
         cs.h_cv_src.push_back(vidx[i]);
         cs.h_cv_mesh.push_back(g);

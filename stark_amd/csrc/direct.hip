@@ -93,6 +93,7 @@ __global__ __launch_bounds__(DT) void k_cholesky_solve(double* __restrict__ A, i
 bool direct_llt(Context& c, const double* rhs_dev, double* x_dev)
 {
     if (!c.have_matrix) throw Error("direct_llt: matrix not assembled");
+    if (c.world > 1) throw Error("DirectLLT is a single-rank solver (a sharded context holds its own rows only); use the block-Jacobi PCG");
     const int n = (int)c.ndofs;
     if (c.ndofs > MAX_DIRECT_DOFS)
         throw Error("DirectLLT is a dense factorisation for small systems (<= " + std::to_string(MAX_DIRECT_DOFS) + " unknowns, this one has " + std::to_string(c.ndofs) +

@@ -1,8 +1,9 @@
-// dist.hip — transports of the sum all-reduce (see dist.hpp)
+// dist.hip — transports of the all-gather every exchange of the sharded path is built from (see dist.hpp)
 #include "dist.hpp"
 
 #include <dlfcn.h>
 
+#include <chrono>
 #include <cstring>
 #include <string>
 
@@ -19,8 +20,13 @@ void LocalGroup::barrier()
         generation++;
         cv.notify_all();
     } else {
-        cv.wait(lk, [&] { return generation != gen; });
+        // (a rank that failed never arrives: give up instead of hanging the process)
+        if (!cv.wait_for(lk, std::chrono::seconds(180), [&] { return generation != gen; })) throw Error("in-process group: a rank did not reach the exchange (did it fail?)");
     }
+}
+LocalGroup::~LocalGroup()
+{
+    if (stream) (void)hipStreamDestroy(stream);
 }
 
 struct Id  // ncclUniqueId (rccl.h:43)
@@ -29,49 +35,55 @@ struct Id  // ncclUniqueId (rccl.h:43)
 };
 namespace {
 constexpr int MAX_LOCAL = 16;
-template <class T>
-struct PtrPack
+struct GatherPack
 {
-    const T* p[MAX_LOCAL];
+    const double* send[MAX_LOCAL];
+    double* recv[MAX_LOCAL];
 };
-template <class T>
-__global__ void k_sum_ranks(PtrPack<T> in, int world, size_t n, T* __restrict__ out)
+// every rank's recv[r * n + i] = rank r's send[i]
+__global__ void k_allgather_local(GatherPack pk, int world, size_t n)
 {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        T s = in.p[0][i];
-        for (int r = 1; r < world; r++) s += in.p[r][i];  // fixed order: every rank computes the same bits
-        out[i] = s;
+    const size_t total = (size_t)world * n;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(t / n);
+        const double v = pk.send[r][t - (size_t)r * n];
+        for (int q = 0; q < world; q++) pk.recv[q][t] = v;
     }
 }
 struct LocalCollective : Collective
 {
     std::shared_ptr<LocalGroup> g;
     int rank;
-    DevBuf<double> tmp;
-    LocalCollective(std::shared_ptr<LocalGroup> group, int r) : g(std::move(group)), rank(r)
+    LocalCollective(std::shared_ptr<LocalGroup> group, int r, int device) : g(std::move(group)), rank(r)
     {
         if (g->world > MAX_LOCAL) throw Error("local group too large");
+        std::lock_guard<std::mutex> lk(g->m);
+        if (!g->stream) {
+            MS_CHECK(hipSetDevice(device));
+            MS_CHECK(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+            g->device = device;
+        } else if (g->device != device) {
+            throw Error("in-process group: every rank must use the same device (the ranks share one stream)");
+        }
     }
-    template <class T>
-    void run(T* buf, size_t n, hipStream_t stream)
+    hipStream_t shared_stream() override { return g->stream; }
+    void allgather_f64(const double* send, double* recv, size_t n, hipStream_t stream) override
     {
         if (n == 0) return;
-        MS_CHECK(hipStreamSynchronize(stream));  // my contribution is complete
-        g->ptr[(size_t)rank] = buf;
-        g->barrier();
-        PtrPack<T> pk{};
-        for (int r = 0; r < g->world; r++) pk.p[r] = (const T*)g->ptr[(size_t)r];
-        tmp.ensure((n * sizeof(T) + sizeof(double) - 1) / sizeof(double));
-        const int grid = (int)std::min<size_t>((n + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_sum_ranks<T>, dim3(grid), dim3(256), 0, stream, pk, g->world, n, (T*)tmp.p);
-        MS_CHECK(hipStreamSynchronize(stream));
-        g->barrier();  // everybody has read everybody's contribution
-        MS_CHECK(hipMemcpyAsync(buf, tmp.p, n * sizeof(T), hipMemcpyDeviceToDevice, stream));
-        MS_CHECK(hipStreamSynchronize(stream));
-        g->barrier();
+        g->send[(size_t)rank] = send;
+        g->recv[(size_t)rank] = recv;
+        g->barrier();  // every rank has enqueued what produces its `send` (same stream: ordered before the kernel below)
+        if (rank == 0) {
+            GatherPack pk{};
+            for (int r = 0; r < g->world; r++) {
+                pk.send[r] = (const double*)g->send[(size_t)r];
+                pk.recv[r] = (double*)g->recv[(size_t)r];
+            }
+            const int grid = (int)std::min<size_t>(((size_t)g->world * n + 255) / 256, 1024);
+            hipLaunchKernelGGL(k_allgather_local, dim3(grid), dim3(256), 0, stream, pk, g->world, n);
+        }
+        g->barrier();  // the copy is enqueued: what the ranks enqueue from here on runs after it
     }
-    void allreduce_f64(double* buf, size_t n, hipStream_t s) override { run(buf, n, s); }
-    void allreduce_f32(float* buf, size_t n, hipStream_t s) override { run(buf, n, s); }
 };
 
 // ---- RCCL through dlopen: no link-time dependency, and no clash with a librccl another module of the process brought ---------
@@ -81,6 +93,7 @@ struct Rccl
     int (*GetUniqueId)(void*) = nullptr;
     int (*CommInitRank)(void**, int, Id, int) = nullptr;  // ncclUniqueId is passed by value
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
@@ -101,6 +114,7 @@ Rccl& rccl()
         r.GetUniqueId = (int (*)(void*))sym("ncclGetUniqueId");
         r.CommInitRank = (int (*)(void**, int, Id, int))sym("ncclCommInitRank");
         r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclAllReduce");
+        r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))sym("ncclAllGather");
         r.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
         r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
     }
@@ -123,19 +137,15 @@ struct RcclCollective : Collective
     {
         if (comm) rccl().CommDestroy(comm);
     }
-    // ncclDataType_t: ncclFloat32 = 7, ncclFloat64 = 8; ncclRedOp_t: ncclSum = 0 (rccl.h)
-    void allreduce_f64(double* buf, size_t n, hipStream_t s) override
+    // ncclDataType_t: ncclFloat64 = 8 (rccl.h)
+    void allgather_f64(const double* send, double* recv, size_t n, hipStream_t s) override
     {
-        if (n) nccl_check(rccl().AllReduce(buf, buf, n, 8, 0, comm, s), "ncclAllReduce(f64)");
-    }
-    void allreduce_f32(float* buf, size_t n, hipStream_t s) override
-    {
-        if (n) nccl_check(rccl().AllReduce(buf, buf, n, 7, 0, comm, s), "ncclAllReduce(f32)");
+        if (n) nccl_check(rccl().AllGather(send, recv, n, 8, comm, s), "ncclAllGather(f64)");
     }
 };
 }  // namespace
 
-std::unique_ptr<Collective> make_local_collective(std::shared_ptr<LocalGroup> group, int rank) { return std::make_unique<LocalCollective>(std::move(group), rank); }
+std::unique_ptr<Collective> make_local_collective(std::shared_ptr<LocalGroup> group, int rank, int device) { return std::make_unique<LocalCollective>(std::move(group), rank, device); }
 std::unique_ptr<Collective> make_rccl_collective(int rank, int world, const char uid[128]) { return std::make_unique<RcclCollective>(rank, world, uid); }
 void rccl_unique_id(char out[128])
 {

@@ -91,6 +91,10 @@ struct PotArgs
     int n_pool;               // elements per block pair in the element-Hessian pool (pool stride)
     double* gpool;            // != nullptr: gradient contributions go to gpool[(k * n_gpool + pool position) * 3 + i] (summed by k_grad_gather) instead of atomics
     int n_gpool;
+    // sharded runs (shard.hip): local index of a global block row ([0, n_own): owned, then ghosts, -1: neither); nullptr on one GPU.
+    // An element's energy counts on the rank that owns the row of its first DoF block.
+    const int32_t* lrow;
+    int n_own;
     int dbg;                  // measurement switches (option "kernel_dbg"; results are wrong when set)
     int dof_col[MAX_NB];      // connectivity column providing the node of local DoF block k
     int dof_row_off[MAX_NB];  // first block row of the DoF set of local DoF block k
@@ -134,6 +138,7 @@ struct Potential
     int n_elem = 0;
     int conn_stride = 0;
     std::vector<int32_t> conn_host;
+    uint64_t conn_version = 0;  // bumped whenever the host connectivity is uploaded again
     DevBuf<int32_t> conn;
     std::vector<mistark_binding> bindings;
     PotArgs args{};
@@ -151,6 +156,10 @@ struct Potential
     DevBuf<uint32_t> inc_start, inc;  // per block row (+1): first incidence; per incidence: k * n_gpool + pool position
     DevBuf<double> gpool;
     std::vector<int64_t> inc_sig;     // what the incidence lists were built for
+    // sharded runs: the elements this rank evaluates, [elements whose energy counts here | interface elements of other ranks]
+    DevBuf<uint32_t> elem_list;
+    int n_list = 0, n_eown = 0;
+    int n_key = 0;                    // elements in the key space / pools of this context (n_elem, or n_list when sharded with a list)
     bool lazy_capable = false;
     size_t hf_off = 0;  // first float in the float pool
     int n_pool_f = 0;   // elements per block pair in the float pool (n_elem rounded up to 64: 16-byte aligned wave stores)
@@ -199,6 +208,35 @@ struct BsrPart
     DevBuf<uint64_t> row_pos;       // per block row: position of its first block
     DevBuf<uint32_t> long_rows;     // rows longer than a chunk (stored after the chunks, one wavefront each)
     int n_long_rows = 0;
+};
+
+// Sharded problem (world > 1): block rows are partitioned over the ranks (owner map); a rank evaluates every element that
+// touches one of its rows (elements on an interface are evaluated by both sides: no gradient / Hessian traffic at all), assembles and
+// solves its rows only, and exchanges boundary values of vectors. See shard.hip.
+struct Shard
+{
+    std::vector<int32_t> user_owner;   // explicit partition (mistark_dist_set_row_owner), empty: graph partition
+    std::vector<int32_t> shared_rows;  // rows any rank may reference from potentials whose connectivity changes (contacts): ghosts everywhere
+    std::vector<int32_t> owner;        // per global block row
+    std::vector<int64_t> n_own_of, n_send_of;  // per rank
+    int64_t n_own = 0, n_ghost = 0, n_loc = 0;
+    std::vector<int32_t> grow_h;       // local index -> global block row (owned rows in ascending global order, then ghosts by owner)
+    DevBuf<int32_t> lrow, grow;
+    // boundary exchange: every rank contributes the values of the rows some other rank holds as ghosts ("send rows", padded to send_stride),
+    // the all-gather delivers all of them, a rank picks its ghosts
+    int64_t n_send = 0, send_stride = 0;
+    DevBuf<int32_t> send_rows;         // local indices of my send rows
+    DevBuf<int32_t> ghost_src;         // per ghost: owner rank * send_stride + position in the owner's send rows
+    DevBuf<double> sendbuf, recvbuf;
+    // gather of the owned parts of a vector into the global vector on every rank
+    int64_t own_stride = 0;            // max n_own over the ranks
+    DevBuf<int32_t> grow_all;          // [world][own_stride]: global block row of rank r's local row i (-1: padding)
+    DevBuf<double> gath_s, gath_r;
+    DevBuf<double> scal_s, scal_r;     // small all-gathers (scalars)
+    std::vector<int64_t> sig;          // what the partition and lists were computed for
+    int64_t version = 0;               // bumped by mistark_dist_set_row_owner / _add_shared_rows
+    int64_t version_lists = 0;         // bumped when the element lists change
+    DevBuf<int32_t> err;               // device error flag (a dynamic potential referenced a row that is neither owned nor a ghost)
 };
 
 struct PcgCtrl
@@ -287,7 +325,12 @@ struct Context
     // are summed over the ranks; everything else is replicated
     int rank = 0, world = 1;
     std::unique_ptr<struct Collective> coll;
+    bool owns_stream = true;        // false: the stream belongs to the in-process group (LocalCollective)
+    Shard sh;
+    int64_t mrows() const { return world > 1 ? sh.n_own : nbr; }  // block rows / columns of the matrix this context holds
+    int64_t mcols() const { return world > 1 ? sh.n_loc : nbr; }
     DevBuf<double> dist_scalar;
+    DevBuf<double> xl;              // sharded PCG: the solution in local numbering
     // sharded projection: delta records of this rank, the common exchange buffer and its sort scratch (kernels.hip: exchange_projection_deltas)
     DevBuf<uint32_t> proj_rec_pos, proj_keys, proj_keys_alt, proj_idx, proj_idx_alt;
     DevBuf<float> proj_rec_val, proj_x;
@@ -306,8 +349,18 @@ struct Context
 // slow staged path: tens of microseconds of idle GPU per call, dozens of calls per Newton iteration)
 void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes);
 void prepare(Context& c);
+// shard.hip
+void shard_prepare(Context& c);                                        // partition, local numbering, element lists, exchange tables (from prepare())
+void shard_halo(Context& c, double* v_local);                           // ghosts of a local vector (3 doubles per local row) from their owners
+void shard_halo_global(Context& c, double* v_global);                   // the same for a vector in global numbering (the gradient)
+void shard_gather_global(Context& c, const double* v_local, double* v_global);  // owned parts of all ranks -> global vector on every rank
+void shard_to_local(Context& c, const double* v_global, double* v_local, bool with_ghosts);
+void shard_allgather_scalars(Context& c, const double* mine, int n, double* all_host);  // all_host[r * n + i]; blocking
+double shard_sum(Context& c, double mine);
+void shard_check(Context& c);
 void ensure_pattern(Context& c);
 void contact_destroy(struct ContactSystem* cs);
+void contact_shared_rows(Context& c, std::vector<int32_t>& rows);  // contact.hip
 int register_potential(Context& c, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings);
 void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs = nullptr, bool lazy = false);
 void reduce_dot_and_max_abs(Context& c, const double* a, const double* b, int64_t n, double* dot, double* max_abs_a);

@@ -29,16 +29,18 @@ void Stark::check(int rc) const
 void Stark::ensure_registered()
 {
     if (!registration_dirty) return;
-    if (ctx) {
+    mistark_ctx* old = ctx;
+    if (old) {
         // keep the current device state: mirror it into the host arrays the new registration starts from
         for (auto* m : models)
             if (auto* pd = dynamic_cast<PointDynamics*>(m)) pd->mirror_to_host();
-        mistark_destroy(ctx);
         ctx = nullptr;
     }
     const int rc = mistark_create(settings.execution.device, &ctx);
     if (rc != 0) throw std::runtime_error("mistark_create failed (" + std::to_string(rc) + "): no MI355X visible; the hot path has no CPU fallback");
-    if (settings.execution.world > 1) {
+    if (settings.execution.world > 1 && old) {
+        check(mistark_dist_move(ctx, old));  // (a communicator is created once: an RCCL unique id is single-use)
+    } else if (settings.execution.world > 1) {
         const auto& ex = settings.execution;
         if (ex.local_group) check(mistark_dist_init_local(ctx, ex.local_group, ex.rank));
         else if (ex.rccl_unique_id.size() == 128) check(mistark_dist_init_rccl(ctx, ex.rank, ex.world, ex.rccl_unique_id.data()));
@@ -52,6 +54,7 @@ void Stark::ensure_registered()
     for (auto* m : models) m->register_potentials(ctx);
     dt_uploaded = dt;
     registration_dirty = false;
+    if (old) mistark_destroy(old);
 }
 void Stark::_initialize()
 {

@@ -96,6 +96,14 @@ __device__ __forceinline__ void gather_inputs(const PotArgs& a, int e, double* i
 // element of a kernel's local index le, and its position in the pools (element energies, element Hessians)
 __device__ __forceinline__ int elem_of(const PotArgs& a, int le) { return a.elem_list ? (int)a.elem_list[le] : a.e_begin + le; }
 __device__ __forceinline__ int pool_of(const PotArgs& a, int le) { return a.elem_list ? le : a.e_begin + le; }
+// sharded runs: an element on an interface is evaluated by every rank that owns one of its rows; its energy counts where the row of its
+// first DoF block lives
+__device__ __forceinline__ bool energy_here(const PotArgs& a, int e)
+{
+    if (!a.lrow) return true;
+    const int l = a.lrow[a.dof_row_off[0] + a.conn[(size_t)e * a.conn_stride + a.dof_col[0]]];
+    return l >= 0 && l < a.n_own;
+}
 
 // Energy only: one lane per element
 template <class En>
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_p(PotArgs a, double* __restrict_
         return;
     }
     Loader<double> L{in};
-    elemE[pe] = En::energy(L);
+    elemE[pe] = energy_here(a, e) ? En::energy(L) : 0.0;
 }
 
 // Energy + gradient + Hessian: one lane per (element, i<=j) pair of local DoFs.
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
         if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);
         else atomicAdd(&grad[3 * (size_t)(a.dof_row_off[ba] + node) + ii], r.a);
     }
-    if (first) elemE[pe] = r.v;
+    if (first) elemE[pe] = energy_here(a, e) ? r.v : 0.0;
 }
 // hot rows: the HOT_WAYS partial sums in fixed order, added to what the in-place accumulating kernels (closed-form tets) left there
 __global__ __launch_bounds__(BLOCK) void k_fold_hot(const double* __restrict__ grad_hot, const int32_t* __restrict__ hot_rows, int n_hot, double* __restrict__ grad)
@@ -285,7 +293,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __
         tet_closed_eval<FULL>(in, E, g, nullptr, 0, false);
     }
     if (!valid || MODE == TET_H_LIST) return;
-    elemE[pool_of(a, le)] = E;
+    elemE[pool_of(a, le)] = energy_here(a, e) ? E : 0.0;
     if (a.dbg & 1) return;  // measurement switch: no gradient output
     if (a.gpool) {  // node gradients to the pool, summed per block row by k_grad_gather (no atomics)
         const int pe = pool_of(a, le);
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_bending_flat(PotArgs a, double* 
         s2 += K * (in[14 + 3 * i] + dt * in[3 * i + 2]);
     }
     const double kc = k * coef;
-    elemE[pe] = 0.5 * kc * (s0 * s0 + s1 * s1 + s2 * s2);
+    elemE[pe] = energy_here(a, e) ? 0.5 * kc * (s0 * s0 + s1 * s1 + s2 * s2) : 0.0;
     const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -412,7 +420,9 @@ static void launch_eval(Context& c, Potential& P, int mode)
     constexpr int n = 3 * En::NB, NP = n * (n + 1) / 2;
     double* E = c.elemE.p + P.e_off;
     if (mode == MISTARK_EVAL_P) {
-        hipLaunchKernelGGL((k_eval_p<En>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E);
+        PotArgs A = P.args;
+        A.e_count = P.n_eown;  // (sharded: the elements whose energy counts here lead the list; P.args.e_count on one GPU)
+        if (A.e_count > 0) hipLaunchKernelGGL((k_eval_p<En>), dim3(grid_for(A.e_count)), dim3(BLOCK), 0, c.stream, A, E);
     } else if (mode == MISTARK_EVAL_P_G) {
         hipLaunchKernelGGL((k_eval_pgh<En, false>), dim3(grid_for((int64_t)P.args.e_count * NP)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
     } else {
@@ -480,10 +490,10 @@ __device__ __forceinline__ double block_max(double v, double* sm)
     return fmax(fmax(sm[0], sm[1]), fmax(sm[2], sm[3]));
 }
 // Deterministic sum of `n` per-block partials, computed redundantly by every block that needs the scalar.
-__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int n, double* sm)
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part, int n, double* sm, int stride = 1)
 {
     double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += BLOCK) s += part[i];
+    for (int i = threadIdx.x; i < n; i += BLOCK) s += part[(size_t)i * stride];
     return block_sum(s, sm);
 }
 
@@ -513,6 +523,31 @@ __global__ __launch_bounds__(BLOCK) void k_max_abs(const double* __restrict__ v,
         s = fmax(s, a == a ? a : INFINITY);
     }
     s = block_max(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// max |v| over the listed block rows (sharded: a rank's own rows of a vector in global numbering)
+__global__ __launch_bounds__(BLOCK) void k_max_abs_rows(const double* __restrict__ v, const int32_t* __restrict__ rows, int64_t n_rows, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < 3 * n_rows; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i = t / 3;
+        const double a = fabs(v[3 * (int64_t)rows[i] + (t - 3 * i)]);
+        s = fmax(s, a == a ? a : INFINITY);
+    }
+    s = block_max(s, sm);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// sum of a[row] . b[row] over the listed block rows
+__global__ __launch_bounds__(BLOCK) void k_dot_rows(const double* __restrict__ a, const double* __restrict__ b, const int32_t* __restrict__ rows, int64_t n_rows, double* __restrict__ part)
+{
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < 3 * n_rows; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t i = t / 3, j = 3 * (int64_t)rows[i] + (t - 3 * i);
+        s += a[j] * b[j];
+    }
+    s = block_sum(s, sm);
     if (threadIdx.x == 0) part[blockIdx.x] = s;
 }
 __global__ __launch_bounds__(BLOCK) void k_axpby(double* __restrict__ dst, double a, const double* __restrict__ x, double b, const double* __restrict__ y, int64_t n)
@@ -614,6 +649,20 @@ double reduce_dot(Context& c, const double* a, const double* b, int64_t n)
 // two reductions, one read-back (a read-back idles the GPU for 15-60 us; the Newton loop has ~20 of them per iteration)
 void reduce_dot_and_max_abs(Context& c, const double* a, const double* b, int64_t n, double* dot, double* max_abs_a)
 {
+    if (c.world > 1) {
+        // a (the solution) is whole on every rank, b (the gradient) complete on a rank's own rows: the dot product is the sum of the ranks' shares
+        const int g = grid_for(3 * c.sh.n_own, BLOCK, VEC_GRID), g2 = grid_for(n, BLOCK, VEC_GRID);
+        hipLaunchKernelGGL(k_dot_rows, dim3(g), dim3(BLOCK), 0, c.stream, a, b, (const int32_t*)c.sh.grow.p, c.sh.n_own, c.partials.p);
+        hipLaunchKernelGGL(k_max_abs, dim3(g2), dim3(BLOCK), 0, c.stream, a, n, c.partials.p + g);
+        double* h = host_scratch(c, 2 * MAX_PARTIALS);
+        fetch_partials(c, g + g2, h, c.partials.p);
+        double s = 0.0, m = 0.0;
+        for (int i = 0; i < g; i++) s += h[i];
+        for (int i = 0; i < g2; i++) m = std::max(m, h[g + i]);
+        *dot = shard_sum(c, s);
+        *max_abs_a = m;
+        return;
+    }
     const int g = grid_for(n, BLOCK, VEC_GRID);
     hipLaunchKernelGGL(k_dot, dim3(g), dim3(BLOCK), 0, c.stream, a, b, n, c.partials.p);
     hipLaunchKernelGGL(k_max_abs, dim3(g), dim3(BLOCK), 0, c.stream, a, n, c.partials.p + g);
@@ -652,42 +701,62 @@ void vec_neg(Context& c, double* dst, const double* x, int64_t n) { vec_axpby(c,
 // ======================================================================================================================
 // prepare(): DoF layout, device arrays, kernel argument blocks, sparsity pattern
 // ======================================================================================================================
-__global__ __launch_bounds__(BLOCK) void k_keys(PotArgs a, int NB, uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t pos_off)
+// One key per element block: (block row, block column) in the numbering of the matrix this context holds (global rows on one GPU; sharded:
+// local rows [0, n_own) x local columns [0, n_own + n_ghost)). Blocks whose row belongs to another rank get the key `sentinel` (= one past
+// the largest real key): they sort to the end and never become a matrix block.
+__global__ __launch_bounds__(BLOCK) void k_keys(PotArgs a, int NB, int n_key, uint64_t ncols, uint64_t sentinel, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t pos_off,
+                                                int32_t* __restrict__ err)
 {
     const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
     const int nn = NB * NB;
-    if (t >= (long long)a.n_elem * nn) return;
-    const int e = (int)(t / nn);
-    const int ab = (int)(t - (long long)e * nn);
+    if (t >= (long long)n_key * nn) return;
+    const int le = (int)(t / nn);
+    const int ab = (int)(t - (long long)le * nn);
     const int ba = ab / NB, bb = ab - ba * NB;
+    const int e = elem_of(a, le);
     const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
-    const uint64_t ra = a.dof_row_off[ba] + ce[a.dof_col[ba]];
-    const uint64_t rb = a.dof_row_off[bb] + ce[a.dof_col[bb]];
-    const uint32_t off = (uint32_t)ab * (uint32_t)a.n_elem + (uint32_t)e;
-    keys[pos_off + off] = ra * nbr + rb;
+    int64_t ra = a.dof_row_off[ba] + ce[a.dof_col[ba]];
+    int64_t rb = a.dof_row_off[bb] + ce[a.dof_col[bb]];
+    uint64_t key;
+    if (a.lrow) {
+        ra = a.lrow[ra];
+        rb = a.lrow[rb];
+        if (ra < 0 || ra >= a.n_own) key = sentinel;
+        else if (rb < 0) {
+            key = sentinel;
+            *err = 1;  // the column is neither owned nor a ghost: not registered as shared (shard_check)
+        } else key = (uint64_t)ra * ncols + (uint64_t)rb;
+    } else key = (uint64_t)ra * ncols + (uint64_t)rb;
+    const uint32_t off = (uint32_t)ab * (uint32_t)n_key + (uint32_t)le;
+    keys[pos_off + off] = key;
     idx[pos_off + off] = pos_off + off;  // key position: potential, block pair and element (make_descriptors turns it into a pool address)
 }
 constexpr uint32_t NO_SRC = 0xFFFFFFFFu;
-__global__ __launch_bounds__(BLOCK) void k_diag_keys(uint64_t nbr, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t pos_off)
+__global__ __launch_bounds__(BLOCK) void k_diag_keys(uint64_t nrows, uint64_t ncols, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx, uint32_t pos_off)
 {
     const uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= nbr) return;
-    keys[pos_off + r] = r * nbr + r;
+    if (r >= nrows) return;
+    keys[pos_off + r] = r * ncols + r;
     idx[pos_off + r] = NO_SRC;  // structural diagonal block, carries no data
 }
-__global__ __launch_bounds__(BLOCK) void k_heads(const uint64_t* __restrict__ keys, size_t n, uint32_t* __restrict__ head)
+__global__ __launch_bounds__(BLOCK) void k_heads(const uint64_t* __restrict__ keys, size_t n, uint64_t sentinel, uint32_t* __restrict__ head)
 {
     const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n) return;
-    head[k] = (k == 0 || keys[k] != keys[k - 1]) ? 1u : 0u;
+    head[k] = (keys[k] != sentinel && (k == 0 || keys[k] != keys[k - 1])) ? 1u : 0u;
 }
 // scan = inclusive prefix of heads. slot = scan-1.
 __global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ scan, size_t n,
-                                                 uint64_t nbr, uint32_t* __restrict__ slot_of_src, uint32_t* __restrict__ colw, uint32_t* __restrict__ slot_row,
+                                                 uint64_t nbr, uint64_t sentinel, uint32_t* __restrict__ slot_of_src, uint32_t* __restrict__ colw, uint32_t* __restrict__ slot_row,
                                                  int32_t* __restrict__ diag_slot, uint32_t* __restrict__ slot_start, uint32_t* __restrict__ row_head)
 {
     const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (k >= n) return;
+    if (keys[k] == sentinel) {  // a block of another rank's row: no matrix block (sharded runs; sentinels sort to the end)
+        if (idx[k] != NO_SRC) slot_of_src[idx[k]] = NO_SRC;
+        if (k == 0 || keys[k - 1] != sentinel) slot_start[scan[k]] = (uint32_t)k;  // (scan[k] = number of blocks: closes the last block's list)
+        return;
+    }
     const uint32_t slot = scan[k] - 1;
     if (idx[k] != NO_SRC) slot_of_src[idx[k]] = slot;
     const bool head = (k == 0 || keys[k] != keys[k - 1]);
@@ -826,7 +895,7 @@ static void build_aligned(Context& c, BsrPart& m)
 {
     const int CT = c.spmv_chunk_tiles > 0 ? c.spmv_chunk_tiles : chunk_tiles_for(m.nnzb);
     m.chunk_tiles = CT;
-    const int64_t nbr = c.nbr;
+    const int64_t nbr = c.mrows();
     std::vector<int64_t> rp((size_t)nbr + 1);
     MS_CHECK(hipMemcpyAsync(rp.data(), m.row_ptr.p, rp.size() * sizeof(int64_t), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
@@ -903,10 +972,11 @@ static void build_pattern(Context& c, int part)
     for (auto& P : c.pots) {
         if (P.part != part) continue;
         P.kp_off = nk;
-        nk += (size_t)P.n_elem * P.NB * P.NB;
+        nk += (size_t)P.n_key * P.NB * P.NB;
     }
     const size_t diag_off = nk;
-    if (part == 0) nk += (size_t)c.nbr;
+    const uint64_t nrows = (uint64_t)c.mrows(), ncols = (uint64_t)c.mcols(), sentinel = nrows * ncols;
+    if (part == 0) nk += (size_t)nrows;
     m.n_keys = nk;
     m.slot_of_src.ensure(std::max<size_t>(nk, 1));
     m.dirty = false;
@@ -924,14 +994,14 @@ static void build_pattern(Context& c, int part)
     m.kidx_alt.ensure(nk);
     m.scan.ensure(nk);
     for (auto& P : c.pots) {
-        if (P.part != part || P.n_elem == 0) continue;
-        hipLaunchKernelGGL(k_keys, dim3(grid_for((int64_t)P.n_elem * P.NB * P.NB)), dim3(BLOCK), 0, c.stream, P.args, P.NB, (uint64_t)c.nbr, m.keys.p, m.kidx.p,
-                           (uint32_t)P.kp_off);
+        if (P.part != part || P.n_key == 0) continue;
+        hipLaunchKernelGGL(k_keys, dim3(grid_for((int64_t)P.n_key * P.NB * P.NB)), dim3(BLOCK), 0, c.stream, P.args, P.NB, P.n_key, ncols, sentinel, m.keys.p, m.kidx.p,
+                           (uint32_t)P.kp_off, c.world > 1 ? c.sh.err.p : (int32_t*)nullptr);
     }
-    if (part == 0) hipLaunchKernelGGL(k_diag_keys, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, (uint64_t)c.nbr, m.keys.p, m.kidx.p, (uint32_t)diag_off);
+    if (part == 0 && nrows > 0) hipLaunchKernelGGL(k_diag_keys, dim3(grid_for((int64_t)nrows)), dim3(BLOCK), 0, c.stream, nrows, ncols, m.keys.p, m.kidx.p, (uint32_t)diag_off);
     // sort (key, source) pairs
     int bits = 1;
-    while ((1ull << bits) < (uint64_t)c.nbr * (uint64_t)c.nbr && bits < 64) bits++;
+    while (bits < 64 && (1ull << bits) <= sentinel) bits++;
     size_t tmp_bytes = 0;
     hipcub::DoubleBuffer<uint64_t> dk(m.keys.p, m.keys_alt.p);
     hipcub::DoubleBuffer<uint32_t> dv(m.kidx.p, m.kidx_alt.p);
@@ -941,7 +1011,7 @@ static void build_pattern(Context& c, int part)
     const uint64_t* skeys = dk.Current();
     const uint32_t* sidx = dv.Current();
     uint32_t* heads = (uint32_t*)(dv.Current() == m.kidx.p ? m.kidx_alt.p : m.kidx.p);  // the other value buffer is free now
-    hipLaunchKernelGGL(k_heads, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, nk, heads);
+    hipLaunchKernelGGL(k_heads, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, nk, sentinel, heads);
     size_t tmp2 = 0;
     MS_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp2, heads, m.scan.p, (int)nk, c.stream));
     c.cub_tmp.ensure(tmp2);
@@ -950,6 +1020,14 @@ static void build_pattern(Context& c, int part)
     fetch(c, &nnzb32, m.scan.p + (nk - 1), sizeof(uint32_t));
     m.nnzb = nnzb32;
     m.ntiles = (m.nnzb + 63) / 64;
+    if (m.nnzb == 0) {  // (sharded: nothing of this part in the rank's rows)
+        MS_CHECK(hipMemsetAsync(m.slot_of_src.p, 0xFF, nk * sizeof(uint32_t), c.stream));  // no block anywhere: the projection adds no delta
+        m.n_rows = 0;
+        m.n_long = m.n_vlong = 0;
+        m.n_chunks = 0;
+        m.n_keys = 0;
+        return;
+    }
     m.colw.ensure((size_t)m.ntiles * 64);
     m.slot_row.ensure((size_t)m.nnzb);
     m.tile_first_row.ensure((size_t)m.ntiles);
@@ -957,7 +1035,7 @@ static void build_pattern(Context& c, int part)
     m.slot_start.ensure((size_t)m.nnzb + 1);
     MS_CHECK(hipMemsetAsync(m.colw.p, 0, (size_t)m.ntiles * 64 * sizeof(uint32_t), c.stream));
     uint32_t* row_head = heads;  // (heads is dead after the scan)
-    hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, (uint64_t)c.nbr, m.slot_of_src.p, m.colw.p, m.slot_row.p,
+    hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, ncols, sentinel, m.slot_of_src.p, m.colw.p, m.slot_row.p,
                        c.diag_slot[part].p, m.slot_start.p, row_head);
     m.sorted_src = sidx;
     m.desc_lazy = -1;  // (make_descriptors)
@@ -987,7 +1065,7 @@ static void build_pattern(Context& c, int part)
     m.row_ptr.ensure((size_t)m.n_rows + 1);
     hipLaunchKernelGGL(k_rows, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_row.p, rscan, m.nnzb, m.rowmap.p, m.row_ptr.p, m.tile_first_row.p, m.colw.p);
     MS_CHECK(hipStreamSynchronize(c.stream));
-    if (part == 0 && m.n_rows != c.nbr) throw Error("internal: static part must contain every block row");
+    if (part == 0 && m.n_rows != c.mrows()) throw Error("internal: static part must contain every block row");
     if (part == 0) build_aligned(c, m);
     if (part == 1) {
         // row chunks of <= CHUNK_BLOCKS blocks for the chunked SpMV of the contact part (a rigid body in contact owns block rows
@@ -1005,7 +1083,7 @@ static void build_pattern(Context& c, int part)
         m.chunk_row.ensure(std::max<size_t>(nch, 1));
         m.yd.ensure(3 * std::max<size_t>((size_t)m.n_rows, 1));
         m.crow_of_row.ensure((size_t)c.nbr);
-        MS_CHECK(hipMemsetAsync(m.crow_of_row.p, 0xFF, (size_t)c.nbr * sizeof(int32_t), c.stream));
+        MS_CHECK(hipMemsetAsync(m.crow_of_row.p, 0xFF, (size_t)c.mrows() * sizeof(int32_t), c.stream));
         hipLaunchKernelGGL(k_crow_of_row, dim3(grid_for(m.n_rows)), dim3(BLOCK), 0, c.stream, m.rowmap.p, m.n_rows, m.crow_of_row.p);
         m.chunk_partial.ensure(3 * std::max<size_t>(nch, 1));
         hipLaunchKernelGGL(k_chunk_fill, dim3(grid_for(m.n_rows)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, m.row_chunk0.p, m.n_rows, m.chunk_row.p);
@@ -1072,27 +1150,15 @@ void prepare(Context& c)
                 }
             }
         }
-        // potentials
-        // pools: static potentials first, so their offsets do not move when only the contact tables change size
-        size_t e_off = 0, h_off = 0, hf_off = 0;
-        for (int part = 0; part < 2; part++) {
+        // potentials, pass 1: connectivity upload and kernel argument blocks
         for (auto& P : c.pots) {
-            if (P.part != part) continue;
-            if (P.h_off != h_off || P.hf_off != hf_off) c.part[part].desc_lazy = -1;  // pool addresses moved: make_descriptors again
-            P.e_off = e_off;
-            P.h_off = h_off;
-            P.k_off = h_off / 9;
-            e_off += (size_t)P.n_elem;
-            h_off += (size_t)P.n_elem * 9 * P.NB * P.NB;
             P.lazy_capable = P.kind != KIND_CUSTOM && !c.force_generic && (P.name == E_TetStrain::name || P.name == E_TetStrainEO::name);
-            P.hf_off = hf_off;
-            P.n_pool_f = (P.n_elem + 63) / 64 * 64;
-            if (P.lazy_capable) hf_off += (size_t)P.n_pool_f * 9 * 10;
             if (P.conn_dirty && !P.conn_ext) {
                 P.conn.ensure(std::max<size_t>(P.conn_host.size(), 1));
                 if (!P.conn_host.empty())
                     MS_CHECK(hipMemcpyAsync(P.conn.p, P.conn_host.data(), P.conn_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
                 P.conn_dirty = false;
+                P.conn_version++;
                 P.inc_sig.clear();
                 c.part[P.part].dirty = true;
             }
@@ -1103,13 +1169,12 @@ void prepare(Context& c)
             A.n_elem = P.n_elem;
             A.n_pool = P.n_elem;
             A.elem_list = nullptr;
+            A.lrow = nullptr;
             A.dbg = c.kernel_dbg;
-            {
-                long long b, e;
-                shard_range(P.n_elem, c.rank, c.world, b, e);
-                A.e_begin = (int)b;
-                A.e_count = (int)(e - b);
-            }
+            A.e_begin = 0;
+            A.e_count = P.n_elem;
+            P.n_key = P.n_elem;
+            P.n_eown = P.n_elem;
             for (size_t b = 0; b < P.bindings.size(); b++) {
                 const Array& arr = c.arrays[P.bindings[b].array];
                 A.arr[b] = arr.dev;
@@ -1131,9 +1196,28 @@ void prepare(Context& c)
                     nblk++;
                 }
             if (nblk != P.NB) throw Error("potential '" + P.name + "': expected " + std::to_string(P.NB) + " DoF bindings, got " + std::to_string(nblk));
+        }
+        // sharded runs: row partition, local numbering, the elements this rank evaluates (shard.hip)
+        if (c.world > 1) shard_prepare(c);
+        // pass 2: pools (static potentials first, so their offsets do not move when only the contact tables change size); a potential's
+        // pools hold n_key elements: all of them, or the rank's list
+        size_t e_off = 0, h_off = 0, hf_off = 0;
+        for (int part = 0; part < 2; part++) {
+        for (auto& P : c.pots) {
+            if (P.part != part) continue;
+            PotArgs& A = P.args;
+            if (P.h_off != h_off || P.hf_off != hf_off) c.part[part].desc_lazy = -1;  // pool addresses moved: make_descriptors again
+            P.e_off = e_off;
+            P.h_off = h_off;
+            P.k_off = h_off / 9;
+            e_off += (size_t)P.n_key;
+            h_off += (size_t)P.n_key * 9 * P.NB * P.NB;
+            P.hf_off = hf_off;
+            P.n_pool_f = (P.n_key + 63) / 64 * 64;
+            if (P.lazy_capable) hf_off += (size_t)P.n_pool_f * 9 * 10;
             // gradient pool + incidence lists (Potential::grad_gather)
-            P.grad_gather = P.lazy_capable && !P.conn_ext && !P.conn_host.empty() && c.world == 1 && !c.no_grad_gather;
-            std::vector<int64_t> sig{(int64_t)P.n_elem, c.nbr};
+            P.grad_gather = P.lazy_capable && !P.conn_ext && !P.conn_host.empty() && !c.no_grad_gather;
+            std::vector<int64_t> sig{(int64_t)P.n_elem, c.nbr, (int64_t)P.n_key, (int64_t)P.conn_version, (int64_t)(c.world > 1 ? c.sh.version_lists : 0)};
             for (int k = 0; k < P.NB; k++) {
                 sig.push_back(A.dof_col[k]);
                 sig.push_back(A.dof_row_off[k]);
@@ -1144,16 +1228,24 @@ void prepare(Context& c)
             } else if (P.grad_gather) {
                 P.inc_sig = sig;
                 const int n_gpool = P.n_pool_f;
-                std::vector<uint32_t> start((size_t)c.nbr + 1, 0u), inc((size_t)P.n_elem * P.NB);
-                for (int e = 0; e < P.n_elem; e++)
-                    for (int k = 0; k < P.NB; k++) start[(size_t)(A.dof_row_off[k] + P.conn_host[(size_t)e * P.conn_stride + A.dof_col[k]]) + 1]++;
+                std::vector<uint32_t> list;  // (sharded: the rank's element list)
+                if (A.elem_list) {
+                    list.resize((size_t)P.n_key);
+                    MS_CHECK(hipMemcpyAsync(list.data(), P.elem_list.p, list.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+                    MS_CHECK(hipStreamSynchronize(c.stream));
+                }
+                auto elem = [&](int le) { return A.elem_list ? (int)list[(size_t)le] : le; };
+                std::vector<uint32_t> start((size_t)c.nbr + 1, 0u), inc((size_t)P.n_key * P.NB);
+                for (int le = 0; le < P.n_key; le++)
+                    for (int k = 0; k < P.NB; k++) start[(size_t)(A.dof_row_off[k] + P.conn_host[(size_t)elem(le) * P.conn_stride + A.dof_col[k]]) + 1]++;
                 for (int64_t r = 0; r < c.nbr; r++) start[(size_t)r + 1] += start[(size_t)r];
                 std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-                for (int e = 0; e < P.n_elem; e++)  // element-major: the contributions of a row are summed in element order
-                    for (int k = 0; k < P.NB; k++) inc[fill[(size_t)(A.dof_row_off[k] + P.conn_host[(size_t)e * P.conn_stride + A.dof_col[k]])]++] = (uint32_t)k * (uint32_t)n_gpool + (uint32_t)e;
+                for (int le = 0; le < P.n_key; le++)  // element-major: the contributions of a row are summed in element order
+                    for (int k = 0; k < P.NB; k++)
+                        inc[fill[(size_t)(A.dof_row_off[k] + P.conn_host[(size_t)elem(le) * P.conn_stride + A.dof_col[k]])]++] = (uint32_t)k * (uint32_t)n_gpool + (uint32_t)le;
                 P.inc_start.ensure(start.size());
                 P.inc.ensure(std::max<size_t>(inc.size(), 1));
-                P.gpool.ensure((size_t)n_gpool * P.NB * 3);
+                P.gpool.ensure(std::max<size_t>((size_t)n_gpool * P.NB * 3, 1));
                 MS_CHECK(hipMemcpyAsync(P.inc_start.p, start.data(), start.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
                 if (!inc.empty()) MS_CHECK(hipMemcpyAsync(P.inc.p, inc.data(), inc.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
                 MS_CHECK(hipStreamSynchronize(c.stream));  // (host vectors are temporaries)
@@ -1192,7 +1284,7 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
     prepare(c);
     if (mode == MISTARK_EVAL_P_G_H) {
         // lazy: float upper-triangle blocks for the potentials that can recompute their double blocks on demand (Potential::lazy_capable)
-        c.lazy_active = lazy && c.world == 1 && !c.atomic_assembly && c.hf_total > 0;
+        c.lazy_active = lazy && !c.atomic_assembly && c.hf_total > 0;
         c.elemH.ensure(std::max<size_t>(c.hess_total, 1));  // (the lazy potentials' share stays untouched address space)
         c.elemHf.ensure(std::max<size_t>(c.lazy_active ? c.hf_total : 0, 16));  // (the gather reads element 0 of the pool that does not apply)
     }
@@ -1221,20 +1313,39 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         for (int i = 0; i < g1; i++) e += h[i];
         for (int i = 0; i < g2; i++) m = std::max(m, h[g1 + i]);
         *grad_max_abs = m;
-    } else {
+    } else if (c.world == 1) {
         e = c.n_elem_total ? reduce_sum(c, c.elemE.p, (int64_t)c.n_elem_total) : 0.0;
-    }
-    if (c.world > 1) {
-        // one collective for the energy and the gradient: E rides behind the last DoF
-        MS_CHECK(hipMemcpyAsync(c.grad.p + c.ndofs, &e, sizeof(double), hipMemcpyHostToDevice, c.stream));
-        if (mode == MISTARK_EVAL_P) c.coll->allreduce_f64(c.grad.p + c.ndofs, 1, c.stream);
-        else c.coll->allreduce_f64(c.grad.p, (size_t)c.ndofs + 1, c.stream);
-        fetch(c, &e, c.grad.p + c.ndofs, sizeof(double));
+        if (grad_max_abs && mode != MISTARK_EVAL_P) *grad_max_abs = reduce_max_abs(c, c.grad.p, c.ndofs);
+    } else {
+        // sharded: this rank's share of the energy and the largest gradient entry on ITS rows, all-gathered and reduced in rank order;
+        // then the gradient rows of the ghosts from their owners (the projection selects elements by the gradient of ALL their rows)
+        const bool wg = mode != MISTARK_EVAL_P;
+        const int g1 = grid_for((int64_t)std::max<size_t>(c.n_elem_total, 1), BLOCK, VEC_GRID), g2 = wg ? grid_for(3 * c.sh.n_own, BLOCK, VEC_GRID) : 0;
+        hipLaunchKernelGGL(k_sum, dim3(g1), dim3(BLOCK), 0, c.stream, (const double*)c.elemE.p, (int64_t)c.n_elem_total, c.partials.p);
+        if (wg) hipLaunchKernelGGL(k_max_abs_rows, dim3(g2), dim3(BLOCK), 0, c.stream, (const double*)c.grad.p, (const int32_t*)c.sh.grow.p, c.sh.n_own, c.partials.p + g1);
+        double* h = host_scratch(c, 2 * MAX_PARTIALS);
+        fetch_partials(c, g1 + g2, h, c.partials.p);
+        double mine[2] = {0.0, 0.0}, all[2 * 64];
+        for (int i = 0; i < g1; i++) mine[0] += h[i];
+        for (int i = 0; i < g2; i++) mine[1] = std::max(mine[1], h[g1 + i]);
+        shard_allgather_scalars(c, mine, 2, all);
+        double m = 0.0;
+        for (int r = 0; r < c.world; r++) {
+            e += all[2 * r];
+            m = std::max(m, all[2 * r + 1]);
+        }
+        if (grad_max_abs && wg) *grad_max_abs = m;
+        if (wg) shard_halo_global(c, c.grad.p);
     }
     if (E) *E = e;
-    if (grad_max_abs && !with_max && mode != MISTARK_EVAL_P) *grad_max_abs = reduce_max_abs(c, c.grad.p, c.ndofs);
     if (grad_host && mode != MISTARK_EVAL_P) {
-        MS_CHECK(hipMemcpyAsync(grad_host, c.grad.p, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        const double* src = c.grad.p;
+        if (c.world > 1) {  // the whole gradient for the caller: every rank contributes its rows
+            shard_to_local(c, c.grad.p, c.q.p, false);
+            shard_gather_global(c, c.q.p, c.z.p);
+            src = c.z.p;
+        }
+        MS_CHECK(hipMemcpyAsync(grad_host, src, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
         MS_CHECK(hipStreamSynchronize(c.stream));
     }
 }
@@ -1262,9 +1373,12 @@ __device__ __forceinline__ size_t tile_val_index(uint32_t slot, int comp)
 struct SelDesc
 {
     const int32_t* conn;
+    const uint32_t* elem_list;   // sharded: the rank's elements (pools and keys are indexed by the position in this list)
+    const int32_t* lrow;
     uint8_t* is_projected;
-    uint32_t* list;
-    int conn_stride, e_begin, e_count, NB, counter, first_block;
+    uint32_t* list;              // selected elements as pool / key indices
+    uint32_t* list_e;            // ... and as element numbers (what a lazy potential recomputes)
+    int conn_stride, e_count, NB, counter, first_block, n_own;
     int dof_col[MAX_NB], dof_row_off[MAX_NB];
 };
 __global__ __launch_bounds__(BLOCK) void k_project_select_multi(const SelDesc* __restrict__ D, int n_desc, const uint8_t* __restrict__ active_blocks, int64_t* __restrict__ counters)
@@ -1279,32 +1393,32 @@ __global__ __launch_bounds__(BLOCK) void k_project_select_multi(const SelDesc* _
     const SelDesc& d = D[s_k];
     const int le = ((int)blockIdx.x - d.first_block) * BLOCK + threadIdx.x;
     if (le >= d.e_count) return;
-    const int e = d.e_begin + le;
-    if (d.is_projected[e]) return;
+    const int e = d.elem_list ? (int)d.elem_list[le] : le;
+    if (d.is_projected[le]) return;
+    const int32_t* ce = d.conn + (size_t)e * d.conn_stride;
     if (active_blocks) {
         bool touch = false;
-        const int32_t* ce = d.conn + (size_t)e * d.conn_stride;
         for (int k = 0; k < d.NB; k++) touch = touch || active_blocks[d.dof_row_off[k] + ce[d.dof_col[k]]];
         if (!touch) return;
     }
-    d.is_projected[e] = 1;
+    d.is_projected[le] = 1;
     const unsigned long long idx = atomicAdd((unsigned long long*)&counters[d.counter], 1ull);
-    d.list[idx] = (uint32_t)e;
+    d.list[idx] = (uint32_t)le;
+    d.list_e[idx] = (uint32_t)e;
+    // statistics: an element counts once, on the rank its energy counts on (energy_here)
+    bool mine = true;
+    if (d.lrow) {
+        const int l = d.lrow[d.dof_row_off[0] + ce[d.dof_col[0]]];
+        mine = l >= 0 && l < d.n_own;
+    }
+    if (mine) atomicAdd((unsigned long long*)&counters[3], 1ull);
 }
 
-struct ProjRecords  // sharded projection: where k_project_eig records its matrix deltas (pos == nullptr: not recording)
-{
-    uint32_t* pos;
-    float* val;
-    unsigned long long* count;
-    unsigned long long cap;
-    uint32_t part_bit;  // 0x80000000 for potentials of the dynamic matrix part
-};
 // Pool addressing of the projection kernels: element e = list[li]; its blocks sit at H[(a*NB+b) * n_pool + pe], pe = e, or pe = li for a
 // compact pool (the recomputed double blocks of a lazy potential's selected elements); slot_of_src is indexed by key: (a*NB+b) * n_elem + e.
 template <int NB>
 __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list, int n_list, double eps,
-                                                       int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters, ProjRecords rec)
+                                                       int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters)
 {
     constexpr int n = 3 * NB, nn = n * n, m = (n + 1) & ~1;  // m: even number of players of the round-robin schedule
     __shared__ double sA[4][nn], sV[4][nn], sC[4][m], sS[4][m], sL[4][m];
@@ -1417,13 +1531,6 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elem
     const bool changed = __ballot(bad) != 0ull;
     if (lane == 0 && changed) atomicAdd((unsigned long long*)&counters[1], 1ull);
     if (!changed) return;  // untouched, like the reference (project_to_PD.cpp:25-29)
-    // sharded runs: the deltas are not added here but recorded (position in the tile storage, value), exchanged between the ranks and
-    // applied by all of them in the same order (project(): exchange_projection_deltas)
-    unsigned long long rec_base = 0;
-    if (rec.pos) {
-        if (lane == 0) rec_base = atomicAdd(rec.count, (unsigned long long)nn);
-        rec_base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(rec_base >> 32)) << 32) | (unsigned int)__builtin_amdgcn_readfirstlane((int)rec_base);
-    }
     for (int t = lane; t < nn; t += 64) {
         const int i = t / n, j = t - i * n;
         double acc = 0.0;
@@ -1431,14 +1538,9 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elem
         const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
         const size_t blk = (size_t)(ba * NB + bb) * n_elem + e;
         double* dst = elemH + (size_t)(ba * NB + bb) * hs + (size_t)pe * 9 + ii * 3 + jj;
-        if (rec.pos) {
-            const unsigned long long k = rec_base + (unsigned long long)t;
-            if (k < rec.cap) {
-                rec.pos[k] = rec.part_bit | (uint32_t)tile_val_index(slot_of_src[blk], ii * 3 + jj);
-                rec.val[k] = (float)(acc - *dst);
-            }
-        } else if (vals) {
-            atomicAdd(&vals[tile_val_index(slot_of_src[blk], ii * 3 + jj)], (float)(acc - *dst));
+        if (vals) {
+            const uint32_t slot = slot_of_src[blk];
+            if (slot != NO_SRC) atomicAdd(&vals[tile_val_index(slot, ii * 3 + jj)], (float)(acc - *dst));  // (NO_SRC: the block row belongs to another rank)
         }
         *dst = acc;
     }
@@ -1477,7 +1579,7 @@ struct ProjWaveShared  // LDS of ONE wavefront (waves of a block may work on dif
 template <int NB>
 __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list,
                                                   int n_list, double eps, int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals,
-                                                  int64_t* __restrict__ counters, const ProjRecords& rec)
+                                                  int64_t* __restrict__ counters)
 {
     constexpr int n = 3 * NB, nn = n * n, m = (n + 1) & ~1, W = m, EPW = 64 / W;
     const int lane = threadIdx.x & 63;
@@ -1602,12 +1704,6 @@ __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, 
 #pragma unroll
     for (int i = 0; i < n; i++) M[i * W + c] = v[i];
     S.L[g][c] = l;
-    unsigned long long rec_base = 0;
-    if (rec.pos) {
-        if (changed && c == 0) rec_base = atomicAdd(rec.count, (unsigned long long)nn);
-        const int first = (g * W) & 63;
-        rec_base = ((unsigned long long)(unsigned int)__shfl((int)(rec_base >> 32), first, 64) << 32) | (unsigned int)__shfl((int)rec_base, first, 64);
-    }
     if (!(changed && valid)) return;
     double wc[n];  // row c of V
 #pragma unroll
@@ -1620,14 +1716,9 @@ __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, 
         const int ba = i / 3, ii = i - 3 * ba;
         const size_t blk = (size_t)(ba * NB + bb) * n_elem + e;
         double* dst = elemH + (size_t)(ba * NB + bb) * hs + (size_t)pe * 9 + ii * 3 + jj;
-        if (rec.pos) {
-            const unsigned long long k = rec_base + (unsigned long long)(i * n + c);
-            if (k < rec.cap) {
-                rec.pos[k] = rec.part_bit | (uint32_t)tile_val_index(slot_of_src[blk], ii * 3 + jj);
-                rec.val[k] = (float)(acc - *dst);
-            }
-        } else if (vals) {
-            atomicAdd(&vals[tile_val_index(slot_of_src[blk], ii * 3 + jj)], (float)(acc - *dst));
+        if (vals) {
+            const uint32_t slot = slot_of_src[blk];
+            if (slot != NO_SRC) atomicAdd(&vals[tile_val_index(slot, ii * 3 + jj)], (float)(acc - *dst));  // (NO_SRC: the block row belongs to another rank)
         }
         *dst = acc;
     }
@@ -1635,12 +1726,11 @@ __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, 
 
 template <int NB>
 __global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list, int n_list, double eps,
-                                                            int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters,
-                                                            ProjRecords rec)
+                                                            int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters)
 {
     __shared__ ProjWaveShared<NB> S[4];
     const int wave = threadIdx.x >> 6;
-    project_cols_body<NB>(S[wave], blockIdx.x * 4 + wave, elemH, n_elem, n_pool, compact, list, n_list, eps, mirroring, slot_of_src, vals, counters, rec);
+    project_cols_body<NB>(S[wave], blockIdx.x * 4 + wave, elemH, n_elem, n_pool, compact, list, n_list, eps, mirroring, slot_of_src, vals, counters);
 }
 // The short lists of one projection round (contact kinds with a few dozen rows, the rigid-body potentials, ...) in ONE launch: a lone
 // wavefront needs 100-300 us for its elements whatever their number (≈ 90 dependent rotation rounds), a dozen such launches in a row is
@@ -1652,7 +1742,6 @@ struct ProjDesc
     const uint32_t* sos;
     float* vals;
     int n_elem, nl, NB, first_wave;
-    uint32_t part_bit;
     int n_pool, compact;
 };
 constexpr int PROJ_BATCH = 40;
@@ -1671,7 +1760,7 @@ union ProjWaveSharedAny
     ProjWaveShared<6> s6;
     __device__ ProjWaveSharedAny() {}
 };
-__global__ __launch_bounds__(BLOCK) void k_project_eig_multi(ProjBatch B, double eps, int mirroring, int64_t* __restrict__ counters, ProjRecords rec)
+__global__ __launch_bounds__(BLOCK) void k_project_eig_multi(ProjBatch B, double eps, int mirroring, int64_t* __restrict__ counters)
 {
     __shared__ ProjWaveSharedAny S[4];
     const int wave = threadIdx.x >> 6;
@@ -1679,115 +1768,31 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_multi(ProjBatch B, double
     int k = 0;
     while (k + 1 < B.n && gw >= B.d[k + 1].first_wave) k++;
     const ProjDesc& D = B.d[k];
-    rec.part_bit = D.part_bit;
     const int w = gw - D.first_wave;
     switch (D.NB) {
-        case 1: project_cols_body<1>(S[wave].s1, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
-        case 2: project_cols_body<2>(S[wave].s2, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
-        case 3: project_cols_body<3>(S[wave].s3, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
-        case 4: project_cols_body<4>(S[wave].s4, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
-        case 5: project_cols_body<5>(S[wave].s5, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
-        default: project_cols_body<6>(S[wave].s6, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters, rec); break;
+        case 1: project_cols_body<1>(S[wave].s1, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters); break;
+        case 2: project_cols_body<2>(S[wave].s2, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters); break;
+        case 3: project_cols_body<3>(S[wave].s3, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters); break;
+        case 4: project_cols_body<4>(S[wave].s4, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters); break;
+        case 5: project_cols_body<5>(S[wave].s5, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters); break;
+        default: project_cols_body<6>(S[wave].s6, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters); break;
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restrict__ grad, int64_t nbr, double thr, uint8_t* __restrict__ active, int64_t* __restrict__ counters)
+// (sharded: the gradient is complete on the rank's rows and, after the halo exchange, its ghosts; other rows hold partial sums nobody reads.
+// Inactive rows are counted over the rank's own rows.)
+__global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restrict__ grad, int64_t nbr, double thr, uint8_t* __restrict__ active, int64_t* __restrict__ counters,
+                                                        const int32_t* __restrict__ lrow, int n_own)
 {
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= nbr) return;
     const double m = fmax(fabs(grad[3 * r]), fmax(fabs(grad[3 * r + 1]), fabs(grad[3 * r + 2])));
     const bool act = m >= thr;
     active[r] = act ? 1 : 0;
-    if (!act) atomicAdd((unsigned long long*)&counters[2], 1ull);
+    const bool own = !lrow || (lrow[r] >= 0 && lrow[r] < n_own);
+    if (!act && own) atomicAdd((unsigned long long*)&counters[2], 1ull);
 }
 
-// ---- sharded projection: the matrix is replicated, the projected elements are not ---------------------------------------------------
-// Each rank holds the deltas (projected - original) of ITS elements as records (position in the tile storage, float). The ranks learn
-// each other's record counts with one small all-reduce, place their records in a common zero-filled buffer at their offset, all-reduce
-// it (sum with zeros = exchange; only the all-reduce primitive is needed), sort by position (stable: equal positions keep the rank-major
-// list order, which is the same on every rank) and add the runs to the matrix: every rank applies the same numbers in the same order,
-// so the replicated solver keeps taking identical branches. When a round touches too many elements (PPN activating the whole mesh at
-// first contact) the ranks fall back to re-assembling and all-reducing the matrix.
-constexpr unsigned long long PROJ_REC_CAP = 8ull << 20;      // records per rank and round (64 MB)
-constexpr unsigned long long PROJ_REC_TOTAL_CAP = 24ull << 20;
-__global__ __launch_bounds__(BLOCK) void k_pack_records(const uint32_t* __restrict__ pos, const float* __restrict__ val, unsigned long long n, unsigned long long offset,
-                                                        float* __restrict__ x)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    float* o = x + 3 * (offset + i);
-    o[0] = (float)(pos[i] >> 16);     // (exact in float; bit patterns themselves would not survive a floating-point sum)
-    o[1] = (float)(pos[i] & 0xffffu);
-    o[2] = val[i];
-}
-__global__ __launch_bounds__(BLOCK) void k_unpack_keys(const float* __restrict__ x, unsigned long long n, uint32_t* __restrict__ keys, uint32_t* __restrict__ idx)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    keys[i] = ((uint32_t)x[3 * i] << 16) | (uint32_t)x[3 * i + 1];
-    idx[i] = (uint32_t)i;
-}
-__global__ __launch_bounds__(BLOCK) void k_apply_records(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx, const float* __restrict__ x, unsigned long long n,
-                                                         float* __restrict__ vals0, float* __restrict__ vals1)
-{
-    const unsigned long long i = (unsigned long long)blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t key = keys[i];
-    if (i > 0 && keys[i - 1] == key) return;  // not the head of its run
-    float* dst = (key & 0x80000000u) ? vals1 + (key & 0x7fffffffu) : vals0 + key;
-    float v = *dst;
-    for (unsigned long long k = i; k < n && keys[k] == key; k++) v += x[3 * (size_t)idx[k] + 2];  // the order of the common list
-    *dst = v;
-}
-static void exchange_projection_deltas(Context& c, bool recorded, int64_t n_projected_local)
-{
-    // counts (and "a rank overflowed its record buffer") of all ranks
-    c.dist_scalar.ensure((size_t)c.world + 2);
-    std::vector<double> h((size_t)c.world + 2, 0.0);
-    unsigned long long n_local = 0;
-    if (recorded) {
-        int64_t cnt = 0;
-        fetch(c, &cnt, c.counters.p + 3, sizeof(int64_t));
-        n_local = (unsigned long long)cnt;
-    }
-    h[(size_t)c.rank] = (double)n_local;
-    h[(size_t)c.world] = (recorded && n_local > (c.proj_rec_cap > 0 ? (unsigned long long)c.proj_rec_cap : PROJ_REC_CAP)) ? 1.0 : 0.0;
-    h[(size_t)c.world + 1] = n_projected_local > 0 ? 1.0 : 0.0;
-    MS_CHECK(hipMemcpyAsync(c.dist_scalar.p, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, c.stream));
-    c.coll->allreduce_f64(c.dist_scalar.p, h.size(), c.stream);
-    fetch(c, h.data(), c.dist_scalar.p, h.size() * sizeof(double));
-    const bool any_projected = h[(size_t)c.world + 1] > 0.0;
-    if (!any_projected) return;
-    if (!recorded) {  // projection before the first assembly of this iteration: the assembly that follows sums the projected Hessians
-        c.matrix_current = false;
-        return;
-    }
-    unsigned long long total = 0, offset = 0;
-    for (int r = 0; r < c.world; r++) {
-        if (r == c.rank) offset = total;
-        total += (unsigned long long)h[(size_t)r];
-    }
-    if (h[(size_t)c.world] > 0.0 || total > PROJ_REC_TOTAL_CAP) {  // too many for the exchange: re-assemble (and all-reduce) instead
-        c.matrix_current = false;
-        return;
-    }
-    if (total == 0) return;  // elements were selected, none changed
-    c.proj_x.ensure(3 * (size_t)total);
-    MS_CHECK(hipMemsetAsync(c.proj_x.p, 0, 3 * (size_t)total * sizeof(float), c.stream));
-    if (n_local > 0)
-        hipLaunchKernelGGL(k_pack_records, dim3(grid_for((int64_t)n_local)), dim3(BLOCK), 0, c.stream, (const uint32_t*)c.proj_rec_pos.p, (const float*)c.proj_rec_val.p, n_local, offset,
-                           c.proj_x.p);
-    c.coll->allreduce_f32(c.proj_x.p, 3 * (size_t)total, c.stream);
-    c.proj_keys.ensure((size_t)total); c.proj_keys_alt.ensure((size_t)total); c.proj_idx.ensure((size_t)total); c.proj_idx_alt.ensure((size_t)total);
-    hipLaunchKernelGGL(k_unpack_keys, dim3(grid_for((int64_t)total)), dim3(BLOCK), 0, c.stream, (const float*)c.proj_x.p, total, c.proj_keys.p, c.proj_idx.p);
-    hipcub::DoubleBuffer<uint32_t> dk(c.proj_keys.p, c.proj_keys_alt.p), dv(c.proj_idx.p, c.proj_idx_alt.p);
-    size_t tmp = 0;
-    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, (int)total, 0, 32, c.stream));
-    c.cub_tmp.ensure(tmp);
-    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(c.cub_tmp.p, tmp, dk, dv, (int)total, 0, 32, c.stream));
-    hipLaunchKernelGGL(k_apply_records, dim3(grid_for((int64_t)total)), dim3(BLOCK), 0, c.stream, (const uint32_t*)dk.Current(), (const uint32_t*)dv.Current(), (const float*)c.proj_x.p, total,
-                       c.part[0].vals.p, c.part[1].vals.p);
-}
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active, int64_t* n_projected_now,
              int64_t* n_changed_now)
 {
@@ -1798,15 +1803,17 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     c.counters.ensure(128);
     MS_CHECK(hipMemsetAsync(c.counters.p, 0, 128 * sizeof(int64_t), c.stream));
     const uint8_t* act = nullptr;
+    const int32_t* lrow = c.world > 1 ? c.sh.lrow.p : nullptr;
     if (by_gradient) {
-        hipLaunchKernelGGL(k_active_blocks, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.grad.p, c.nbr, threshold, c.active_blocks.p, c.counters.p);
+        hipLaunchKernelGGL(k_active_blocks, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.grad.p, c.nbr, threshold, c.active_blocks.p, c.counters.p, lrow, (int)c.sh.n_own);
         act = c.active_blocks.p;
     } else if (active_host) {
         MS_CHECK(hipMemcpyAsync(c.active_blocks.p, active_host, (size_t)c.nbr, hipMemcpyHostToDevice, c.stream));
         act = c.active_blocks.p;
     }
-    // 1) selection: per-potential lists of element ids (counter 4 + potential index)
-    c.proj_list.ensure(std::max<size_t>(c.n_elem_total, 1));
+    // 1) selection: per-potential lists (counter 4 + potential index); counter 3: selected elements whose energy counts on this rank
+    c.proj_list.ensure(2 * std::max<size_t>(c.n_elem_total, 1));
+    uint32_t* list_e_base = c.proj_list.p + std::max<size_t>(c.n_elem_total, 1);
     {
         // (the table lives in the context: the copy below may still read it after this scope; the read-back that follows the selection
         // orders it before the next round overwrites it)
@@ -1819,10 +1826,13 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
             if (P.args.e_count == 0) continue;
             SelDesc d{};
             d.conn = P.args.conn;
+            d.elem_list = P.args.elem_list;
+            d.lrow = lrow;
+            d.n_own = (int)c.sh.n_own;
             d.is_projected = c.is_projected.p + P.e_off;
             d.list = c.proj_list.p + P.e_off;
+            d.list_e = list_e_base + P.e_off;
             d.conn_stride = P.args.conn_stride;
-            d.e_begin = P.args.e_begin;
             d.e_count = P.args.e_count;
             d.NB = P.NB;
             d.counter = 4 + pi;
@@ -1842,14 +1852,18 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     }
     int64_t h[128];
     fetch(c, h, c.counters.p, sizeof(h));
-    // 2) eigen-projection, one wavefront per selected element; deltas go straight into the assembled matrix if it is current.
-    //    Sharded: every rank projects its own elements and records the deltas; they are exchanged and applied below.
-    const bool record = c.world > 1 && c.matrix_current;
-    const unsigned long long rec_cap = c.proj_rec_cap > 0 ? (unsigned long long)c.proj_rec_cap : PROJ_REC_CAP;
-    if (record) {
-        c.proj_rec_pos.ensure(PROJ_REC_CAP);
-        c.proj_rec_val.ensure(PROJ_REC_CAP);
+    int64_t n_inactive = h[2], n_selected = h[3];
+    if (c.world > 1) {  // the counts of the whole problem (every rank takes the same decisions)
+        double mine[2] = {(double)h[2], (double)h[3]}, all[2 * 64];
+        shard_allgather_scalars(c, mine, 2, all);
+        n_inactive = n_selected = 0;
+        for (int r = 0; r < c.world; r++) {
+            n_inactive += (int64_t)all[2 * r];
+            n_selected += (int64_t)all[2 * r + 1];
+        }
     }
+    // 2) eigen-projection of the selected elements; deltas go straight into the assembled matrix if it is current (rows of other ranks:
+    //    their owners project the same element and get the same numbers)
     int64_t total = 0;
     size_t lazy_off = 0;
     if (c.lazy_active) {  // compact double pool for the recomputed blocks of the lazy potentials' selections
@@ -1863,10 +1877,9 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     ProjBatch batch;
     batch.n = 0;
     int batch_waves = 0;
-    ProjRecords batch_rec{};
     auto flush = [&]() {
         if (batch.n == 0) return;
-        hipLaunchKernelGGL(k_project_eig_multi, dim3((batch_waves + 3) / 4), dim3(BLOCK), 0, c.stream, batch, eps, mirroring, c.counters.p, batch_rec);
+        hipLaunchKernelGGL(k_project_eig_multi, dim3((batch_waves + 3) / 4), dim3(BLOCK), 0, c.stream, batch, eps, mirroring, c.counters.p);
         batch.n = 0;
         batch_waves = 0;
     };
@@ -1879,7 +1892,8 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         double* H = c.elemH.p + P.h_off;
         const uint32_t* list = c.proj_list.p + P.e_off;
         const uint32_t* sos = c.part[P.part].slot_of_src.p + P.kp_off;
-        int n_pool = P.n_elem, compact = 0;
+        const int n_key = P.n_key;
+        int n_pool = P.n_key, compact = 0;
         if (c.lazy_active && P.lazy_capable) {
             // the double blocks of the selected elements were never stored: recompute them into a compact pool (the list is a small
             // fraction of the mesh except when PPN activates every element, and then the eigen-decompositions cost 20x this)
@@ -1887,54 +1901,51 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
             H = c.projH.p + lazy_off;
             lazy_off += (size_t)n_pool * 9 * P.NB * P.NB;
             compact = 1;
-            launch_tet_closed_list(c, P, list, nl, H, n_pool);
+            launch_tet_closed_list(c, P, list_e_base + P.e_off, nl, H, n_pool);
         }
-        float* vals = (c.matrix_current && c.world == 1) ? c.part[P.part].vals.p : nullptr;
-        ProjRecords rec{};
-        if (record) rec = ProjRecords{c.proj_rec_pos.p, c.proj_rec_val.p, (unsigned long long*)(c.counters.p + 3), rec_cap, P.part == 1 ? 0x80000000u : 0u};
+        float* vals = c.matrix_current ? c.part[P.part].vals.p : nullptr;
         const dim3 g((nl + 3) / 4), b(BLOCK);
         if (!(c.proj_variant & 1) && P.NB <= 6) {  // register-resident Jacobi, several elements per wavefront
             const int epw = 64 / ((3 * P.NB + 1) & ~1);
             if (nl <= SHORT_LIST && !(c.proj_variant & 2)) {
                 if (batch.n == PROJ_BATCH) flush();
-                batch.d[batch.n++] = ProjDesc{H, list, sos, vals, P.n_elem, nl, P.NB, batch_waves, rec.part_bit, n_pool, compact};
+                batch.d[batch.n++] = ProjDesc{H, list, sos, vals, n_key, nl, P.NB, batch_waves, n_pool, compact};
                 batch_waves += (nl + epw - 1) / epw;
-                batch_rec = rec;
                 continue;
             }
             const dim3 grid(((nl + epw - 1) / epw + 3) / 4);
             switch (P.NB) {
-                case 1: hipLaunchKernelGGL((k_project_eig_cols<1>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 2: hipLaunchKernelGGL((k_project_eig_cols<2>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 3: hipLaunchKernelGGL((k_project_eig_cols<3>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 4: hipLaunchKernelGGL((k_project_eig_cols<4>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                case 5: hipLaunchKernelGGL((k_project_eig_cols<5>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-                default: hipLaunchKernelGGL((k_project_eig_cols<6>), grid, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+                case 1: hipLaunchKernelGGL((k_project_eig_cols<1>), grid, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+                case 2: hipLaunchKernelGGL((k_project_eig_cols<2>), grid, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+                case 3: hipLaunchKernelGGL((k_project_eig_cols<3>), grid, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+                case 4: hipLaunchKernelGGL((k_project_eig_cols<4>), grid, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+                case 5: hipLaunchKernelGGL((k_project_eig_cols<5>), grid, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+                default: hipLaunchKernelGGL((k_project_eig_cols<6>), grid, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
             }
             continue;
         }
         switch (P.NB) {
-            case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 2: hipLaunchKernelGGL((k_project_eig<2>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 3: hipLaunchKernelGGL((k_project_eig<3>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 4: hipLaunchKernelGGL((k_project_eig<4>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 5: hipLaunchKernelGGL((k_project_eig<5>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 6: hipLaunchKernelGGL((k_project_eig<6>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 7: hipLaunchKernelGGL((k_project_eig<7>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
-            case 8: hipLaunchKernelGGL((k_project_eig<8>), g, b, 0, stream, H, P.n_elem, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p, rec); break;
+            case 1: hipLaunchKernelGGL((k_project_eig<1>), g, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 2: hipLaunchKernelGGL((k_project_eig<2>), g, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 3: hipLaunchKernelGGL((k_project_eig<3>), g, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 4: hipLaunchKernelGGL((k_project_eig<4>), g, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 5: hipLaunchKernelGGL((k_project_eig<5>), g, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 6: hipLaunchKernelGGL((k_project_eig<6>), g, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 7: hipLaunchKernelGGL((k_project_eig<7>), g, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
+            case 8: hipLaunchKernelGGL((k_project_eig<8>), g, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p); break;
             default: throw Error("project: unsupported block count");
         }
     }
     flush();
-    c.n_projected_total += total;
-    if (c.world > 1) exchange_projection_deltas(c, record, total);
-    if (n_projected_now) *n_projected_now = total;
-    if (n_changed_now) {
+    (void)total;
+    c.n_projected_total += n_selected;
+    if (n_projected_now) *n_projected_now = n_selected;
+    if (n_changed_now) {  // (sharded: this rank's count, interface elements included)
         int64_t h2[2];
         fetch(c, h2, c.counters.p, sizeof(h2));
         *n_changed_now = h2[1];
     }
-    if (all_active) *all_active = by_gradient ? (h[2] == 0) : (active_host == nullptr);
+    if (all_active) *all_active = by_gradient ? (n_inactive == 0) : (active_host == nullptr);
 }
 
 // ======================================================================================================================
@@ -2181,7 +2192,6 @@ void assemble(Context& c)
                 hipLaunchKernelGGL(k_assemble_vlong_fold, dim3((m.n_vlong + 3) / 4), dim3(BLOCK), 0, c.stream, (const double*)c.vlong_part.p, m.vlong_slots.p, m.n_vlong, store, m.vals.p);
             }
         }
-        if (c.world > 1) c.coll->allreduce_f32(m.vals.p, (size_t)m.ntiles * 576, c.stream);
         m.have_matrix = true;
     }
     c.have_matrix = true;
@@ -2191,8 +2201,10 @@ void build_preconditioner(Context& c)
 {
     if (!c.have_matrix) throw Error("preconditioner: matrix not assembled");
     const BsrPart& d = c.part[1];
-    hipLaunchKernelGGL(k_block_diag_inverse, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.part[0].vals.p, c.diag_slot[0].p, d.nnzb ? d.vals.p : (const float*)nullptr,
-                       c.diag_slot[1].p, c.nbr, c.dinv.p);
+    const int64_t nr = c.mrows();
+    if (nr > 0)
+        hipLaunchKernelGGL(k_block_diag_inverse, dim3(grid_for(nr)), dim3(BLOCK), 0, c.stream, c.part[0].vals.p, c.diag_slot[0].p, d.nnzb ? d.vals.p : (const float*)nullptr,
+                           c.diag_slot[1].p, nr, c.dinv.p);
 }
 
 // ======================================================================================================================
@@ -2527,7 +2539,7 @@ static int launch_spmv(Context& c, const double* x, double* y, const double* pdo
     }
     hipLaunchKernelGGL(k_spmv_fused<V>, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, x, y, pdot, partials, ctrl);
     if (g1 > 0 && combine)
-        hipLaunchKernelGGL(k_spmv_combine, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, c.nbr, (const int32_t*)m1.crow_of_row.p, (const uint32_t*)m1.row_chunk0.p,
+        hipLaunchKernelGGL(k_spmv_combine, dim3(grid_for(c.mrows())), dim3(BLOCK), 0, c.stream, c.mrows(), (const int32_t*)m1.crow_of_row.p, (const uint32_t*)m1.row_chunk0.p,
                            (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, y);
     return g0 + gr + g1;
 }
@@ -2635,11 +2647,12 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_init(const double* __restrict__ b
         part_rz[blockIdx.x] = rz;
     }
 }
-__global__ __launch_bounds__(BLOCK) void k_pcg_init2(const double* __restrict__ part_bb, const double* __restrict__ part_rz, int nparts, double abs_tol, PcgCtrl* __restrict__ ctrl)
+__global__ __launch_bounds__(BLOCK) void k_pcg_init2(const double* __restrict__ part_bb, const double* __restrict__ part_rz, int nparts, double abs_tol, PcgCtrl* __restrict__ ctrl,
+                                                     int stride)
 {
     __shared__ double sm[4];
-    const double bb = sum_partials(part_bb, nparts, sm);
-    const double rz = sum_partials(part_rz, nparts, sm);
+    const double bb = sum_partials(part_bb, nparts, sm, stride);
+    const double rz = sum_partials(part_rz, nparts, sm, stride);
     if (threadIdx.x == 0) {
         ctrl->bb = bb;
         ctrl->rz[1] = rz;
@@ -2713,7 +2726,7 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, co
     }
 }
 __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double rel_tol, const double* __restrict__ part_rr, const double* __restrict__ part_rz, int nparts,
-                                                   int64_t n, const double* __restrict__ z, double* __restrict__ p, PcgCtrl* __restrict__ ctrl)
+                                                   int64_t n, const double* __restrict__ z, double* __restrict__ p, PcgCtrl* __restrict__ ctrl, int stride)
 {
     const int done = ctrl->done;
     if (done == 1) return;
@@ -2722,8 +2735,8 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
         return;
     }
     __shared__ double sm[4];
-    const double rr = sum_partials(part_rr, nparts, sm);
-    const double rz_new = sum_partials(part_rz, nparts, sm);
+    const double rr = sum_partials(part_rr, nparts, sm, stride);
+    const double rz_new = sum_partials(part_rz, nparts, sm, stride);
     const double error = sqrt(rr / ctrl->bb);
     const bool conv = error < abs_tol || error / 1.0 < rel_tol;  // error_0 = 1 for x0 = 0
     if (conv) {
@@ -2744,11 +2757,89 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
     }
 }
 
+// ---- the same PCG on a row-sharded system (the three dot products of solve_pcg.h:180,201,217) ---------------------------------
+// Every rank holds its block rows of A and the matching parts of x, r, z, q; p also carries the ghost columns. Per iteration:
+//   ghosts of p from their owners | q = A p, partial p.q | all-gather of the ranks' p.q | k_pcg_step with the sum (rank order: the same bits
+//   everywhere) | all-gather of (r.r, r.z), fused in one exchange | k_pcg_dir
+// The control block is computed redundantly and identically by every rank, so all of them stop at the same iteration; the host reads it
+// every PCG_CHECK iterations. The solution is gathered into the global vector on every rank at the end.
+__global__ __launch_bounds__(BLOCK) void k_fold_partials(const double* __restrict__ a, int na, const double* __restrict__ b, int nb, double* __restrict__ out)
+{
+    __shared__ double sm[4];
+    const double sa = sum_partials(a, na, sm);
+    const double sb = b ? sum_partials(b, nb, sm) : 0.0;
+    if (threadIdx.x == 0) {
+        out[0] = sa;
+        if (b) out[1] = sb;
+    }
+}
+static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
+{
+    Shard& S = c.sh;
+    const int64_t n_own = S.n_own;
+    const int W = c.world;
+    build_preconditioner(c);
+    const int gv = grid_for(std::max<int64_t>(n_own, 1), BLOCK, VEC_GRID);
+    BsrPart& m1 = c.part[1];
+    const bool dyn = m1.nnzb > 0;
+    double* part_pq = c.partials.p;
+    double* part_rr = c.partials.p + MAX_PARTIALS;
+    double* part_rz = c.partials.p + 2 * MAX_PARTIALS;
+    double* part_bb = c.partials.p + 3 * MAX_PARTIALS;
+    c.xl.ensure(3 * (size_t)std::max<int64_t>(S.n_loc, 1));
+    c.dist_scalar.ensure(8 + 2 * (size_t)W + 2 * (size_t)W);
+    double* mine = c.dist_scalar.p;                   // [2]
+    double* all1 = c.dist_scalar.p + 8;               // [W]
+    double* all2 = c.dist_scalar.p + 8 + W;           // [2 W]
+    double* b_l = c.tmp_a.p == rhs_global ? c.tmp_b.p : c.tmp_a.p;  // local right-hand side (any scratch vector but the caller's)
+    if (rhs_global == c.tmp_b.p) throw Error("pcg: right-hand side in a scratch vector the sharded solve needs");
+    shard_to_local(c, rhs_global, b_l, false);
+    hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(BLOCK), 0, c.stream, (const double*)b_l, c.dinv.p, n_own, c.xl.p, c.r.p, c.z.p, c.p.p, part_bb, part_rz);
+    hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)part_bb, gv, (const double*)part_rz, gv, mine);
+    c.coll->allgather_f64(mine, all2, 2, c.stream);
+    hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)all2, (const double*)(all2 + 1), W, abs_tol, c.ctrl.p, 2);
+    constexpr int PCG_CHECK = 8;
+    PcgCtrl h{};
+    int k = 1;
+    bool finished = false;
+    while (!finished) {
+        const int k_end = std::min(max_iter, k + PCG_CHECK - 1);
+        for (; k <= k_end; k++) {
+            shard_halo(c, c.p.p);
+            const int gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false);
+            hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)part_pq, gs, (const double*)nullptr, 0, mine);
+            c.coll->allgather_f64(mine, all1, 1, c.stream);
+            hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, (const double*)all1, W, c.dinv.p, n_own, c.p.p, c.q.p, c.xl.p, c.r.p, c.z.p, part_rr,
+                               part_rz, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : nullptr, (const uint32_t*)m1.row_chunk0.p, (const double*)m1.yd.p,
+                               (const double*)m1.chunk_partial.p);
+            hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)part_rr, gv, (const double*)part_rz, gv, mine);
+            c.coll->allgather_f64(mine, all2, 2, c.stream);
+            hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, (const double*)all2, (const double*)(all2 + 1), W, 3 * n_own, c.z.p, c.p.p, c.ctrl.p, 2);
+        }
+        fetch(c, &h, c.ctrl.p, sizeof(PcgCtrl));
+        finished = h.done || k > max_iter;
+    }
+    shard_gather_global(c, c.xl.p, c.du.p);
+    const int n_it = h.done ? h.n_iter : max_iter;
+    c.last_cg_iters = n_it;
+    if (info) {
+        info->converged = h.done ? h.converged : 0;
+        info->n_iterations = n_it;
+        info->found_indefiniteness = h.indef;
+        info->error = h.error;
+        info->reserved = 0;
+    }
+}
+
 // SpMV timing inside the solver: every SPMV_SAMPLE-th launch is bracketed by a pair of pooled HIP events on the engine's stream
 constexpr int SPMV_SAMPLE = 8;
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
 {
     if (!c.have_matrix) throw Error("pcg: matrix not assembled");
+    if (c.world > 1) {
+        pcg_sharded(c, rhs_dev, abs_tol, rel_tol, max_iter, stop_on_indef, info);
+        return;
+    }
     build_preconditioner(c);
     const int gv = grid_for(c.nbr, BLOCK, VEC_GRID);
     BsrPart& m1 = c.part[1];
@@ -2758,7 +2849,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     double* part_rz = c.partials.p + 2 * MAX_PARTIALS;
     double* part_bb = c.partials.p + 3 * MAX_PARTIALS;
     hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(BLOCK), 0, c.stream, rhs_dev, c.dinv.p, c.nbr, c.du.p, c.r.p, c.z.p, c.p.p, part_bb, part_rz);
-    hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, part_bb, part_rz, gv, abs_tol, c.ctrl.p);
+    hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, part_bb, part_rz, gv, abs_tol, c.ctrl.p, 1);
     // Iterations are launched in batches of PCG_BATCH; after each batch the control block is copied to a pinned slot and an
     // event recorded. The host launches batch b+1 BEFORE it waits for batch b's event, so the GPU never idles on the host's
     // convergence check, and at most one batch of device-side no-op launches (ctrl->done) is wasted after convergence.
@@ -2793,7 +2884,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
             hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, c.p.p, c.q.p, c.du.p, c.r.p, c.z.p, part_rr,
                                part_rz, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : nullptr, (const uint32_t*)m1.row_chunk0.p, (const double*)m1.yd.p,
                                (const double*)m1.chunk_partial.p);
-            hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p);
+            hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p, 1);
         }
         MS_CHECK(hipMemcpyAsync(hs[slot], c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost, c.stream));
         MS_CHECK(hipEventRecord(c.pcg_ev[slot], c.stream));
@@ -2844,7 +2935,7 @@ Context::~Context()
     if (h_scratch) (void)hipHostFree(h_scratch);
     if (h_pin) (void)hipHostFree(h_pin);
     if (pub) (void)hipHostFree(pub);
-    if (stream) (void)hipStreamDestroy(stream);
+    if (stream && owns_stream) (void)hipStreamDestroy(stream);
 }
 
 }  // namespace mistark

@@ -97,6 +97,20 @@ class Engine:
     def dist_init_local(self, group, rank: int):
         self._ck(self.L.mistark_dist_init_local(self.h, group, rank))
 
+    def dist_info(self):
+        out = (C.c_int64 * 6)()
+        self._ck(self.L.mistark_dist_info(self.h, out, 6))
+        return list(out)
+
+    def dist_row_owner(self) -> np.ndarray:
+        o = np.zeros(self.ndofs // 3, dtype=np.int32)
+        self._ck(self.L.mistark_dist_get_row_owner(self.h, o.ctypes.data))
+        return o
+
+    def dist_set_row_owner(self, owner):
+        o = np.ascontiguousarray(owner, dtype=np.int32)
+        self._ck(self.L.mistark_dist_set_row_owner(self.h, o.ctypes.data, len(o)))
+
     def dist_init_rccl(self, rank: int, world: int, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)
         self._ck(self.L.mistark_dist_init_rccl(self.h, rank, world, buf))
