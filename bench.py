@@ -73,29 +73,86 @@ def run_newton_steps(sim, S, capi, n_steps):
     return i.total_newton_iterations - n0, i.total_linear_solves - ls0, i.total_cg_iterations - cg0, i.total_linear_solve_time - tl0
 
 
+def host_cpu():
+    """CPU model, physical cores and logical CPUs of this host (from /proc/cpuinfo)."""
+    model, cores, logical = "unknown", set(), 0
+    try:
+        phys = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                cores.add((phys, v))
+    except OSError:
+        pass
+    logical = logical or (os.cpu_count() or 1)
+    return model, (len(cores) or logical), logical
+
+
 def cpu_baseline(nx, ny, nz, scene="contact"):
-    """The UNMODIFIED reference (oracle/_ref/ref_harness, built by oracle/Makefile) timed on this host's cores."""
+    """The UNMODIFIED reference (oracle/_ref/ref_harness, built by oracle/Makefile) timed on this host's cores: once with one thread per
+    physical core (capped at 64) and once with 8 threads (the figure SURVEY.md §8d asks for, comparable with the build container)."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
-    cores = os.cpu_count() or 1
-    threads = max(1, min(cores, 64))
+    model, physical, logical = host_cpu()
+    threads = max(1, min(physical, 64))
+    base = {"unit": "Newton-steps/s", "cores": threads, "kind": "reference", "cpu_model": model, "physical_cores": physical, "logical_cpus": logical}
     if not os.path.exists(harness):
-        return {"value": None, "unit": "Newton-steps/s", "cores": threads, "kind": "reference", "sample": "unavailable: oracle/_ref/ref_harness not built"}
-    args = ["nx=%d" % nx, "ny=%d" % ny, "nz=%d" % nz, "threads=%d" % threads, "codegen=/tmp/mistark_bench_codegen", "outdir=/tmp/mistark_bench_out"]
+        return dict(base, value=None, sample="unavailable: oracle/_ref/ref_harness not built")
+    common = ["nx=%d" % nx, "ny=%d" % ny, "nz=%d" % nz, "codegen=/tmp/mistark_bench_codegen", "outdir=/tmp/mistark_bench_out"]
     name = "tetblock"
     if scene == "contact":
         name = "blockbox"
-        args += ["L=1", "gap=%g" % GAP, "thickness=%g" % THICKNESS, "mu=%g" % MU, "kmin=%g" % KMIN, "bx=%g" % BOX[0], "bz=%g" % BOX[2], "boxfirst=1"]
+        common += ["L=1", "gap=%g" % GAP, "thickness=%g" % THICKNESS, "mu=%g" % MU, "kmin=%g" % KMIN, "bx=%g" % BOX[0], "bz=%g" % BOX[2], "boxfirst=1"]
+
+    def run(n_threads, steps):
+        out = subprocess.run([harness, "time", name] + common + ["threads=%d" % n_threads, "steps=%d" % steps, "warmup=1"], check=True, capture_output=True, timeout=1500).stdout.decode()
+        return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
     try:
-        subprocess.run([harness, "prime", name, "nx=2", "ny=2", "nz=2"] + args[3:], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-        out = subprocess.run([harness, "time", name] + args + ["steps=4", "warmup=1"], check=True, capture_output=True, timeout=1500).stdout.decode()
-        line = [l for l in out.splitlines() if l.startswith("{")][-1]
-        r = json.loads(line)
-        return {"value": r["newton_steps_per_s"], "unit": "Newton-steps/s", "cores": threads, "kind": "reference",
-                "sample": "same scene, %d Newton iterations over 4 time steps after 1 warm-up step (pattern build + JIT excluded)" % r["newton_iterations"],
-                "ms_per_linear_solve": r["ms_per_linear_solve"], "wall_s": r["wall_s"], "newton_iterations": r["newton_iterations"],
-                "linear_solves": r.get("linear_solves")}
+        subprocess.run([harness, "prime", name, "nx=2", "ny=2", "nz=2"] + common[3:] + ["threads=%d" % threads], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+        r = run(threads, 4)
+        res = dict(base, value=r["newton_steps_per_s"],
+                   sample="same scene, %d Newton iterations over 4 time steps after 1 warm-up step (pattern build + JIT excluded), %d threads" % (r["newton_iterations"], threads),
+                   ms_per_linear_solve=r["ms_per_linear_solve"], wall_s=r["wall_s"], newton_iterations=r["newton_iterations"], linear_solves=r.get("linear_solves"))
+        try:
+            r8 = run(8, 2)
+            res["threads_8"] = {"value": r8["newton_steps_per_s"], "ms_per_linear_solve": r8["ms_per_linear_solve"], "newton_iterations": r8["newton_iterations"], "wall_s": r8["wall_s"],
+                                "sample": "2 time steps after 1 warm-up step, 8 threads"}
+        except Exception as e:  # noqa: BLE001
+            res["threads_8"] = {"value": None, "sample": "failed: %r" % (e,)}
+        return res
     except Exception as e:  # noqa: BLE001
-        return {"value": None, "unit": "Newton-steps/s", "cores": threads, "kind": "reference", "sample": "failed: %r" % (e,)}
+        return dict(base, value=None, sample="failed: %r" % (e,))
+
+
+def profile_traffic():
+    """HBM-side bytes per real SpMV launch from the newest committed rocprofv3 PMC passes (profiles/<tag>_pmc_fetch.txt / _pmc_write.txt,
+    made by tools/profile_round.sh from this command): 2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md
+    "HBM") + WRITE_SIZE, KB -> bytes. Counters cannot be collected inside a timed run; this is a profile-derived figure and labelled so."""
+    import glob
+    import re
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch.txt"))):
+        w = f.replace("_pmc_fetch.txt", "_pmc_write.txt")
+        if not os.path.exists(w):
+            continue
+        vals = []
+        for path in (f, w):
+            m = re.findall(r"k_spmv_fused: .* avg counter value over those: ([0-9.]+)", open(path).read())
+            vals.append(float(m[-1]) if m else None)
+        if None not in vals:
+            tag = os.path.basename(f)[:-len("_pmc_fetch.txt")]
+            key = [int(x) for x in re.findall(r"\d+", tag)]
+            if best is None or key > best[0]:
+                best = (key, tag, (2.0 * vals[0] + vals[1]) * 1024.0)
+    return (best[2], "profiles/%s_pmc_{fetch,write}.txt" % best[1]) if best else (None, None)
 
 
 def main():
@@ -120,8 +177,8 @@ def main():
     dist = None
     uid = None
     if world > 1:
-        # torch.distributed (gloo) only launches / synchronises the ranks and carries the 128-byte RCCL id; the collectives of the path
-        # (energy + gradient + assembled matrix all-reduce) are issued by the engine itself on its HIP stream (stark_amd/csrc/dist.hip)
+        # torch.distributed (gloo) only launches / synchronises the ranks and carries the 128-byte RCCL id; the exchanges of the path
+        # (ncclAllGather of boundary values, dot products and energies) are issued by the engine itself on its HIP stream (stark_amd/csrc/dist.hip)
         import ctypes as C
 
         import torch.distributed as dist_mod
@@ -174,6 +231,7 @@ def main():
     stage = {k: getattr(info, "total_" + k + "_time") - getattr(info0, "total_" + k + "_time") for k in ["newton", "linear_solve", "eval_pgh", "eval_p", "project", "assembly", "callback", "step"]}
 
     if rank == 0:
+        traffic, traffic_src = profile_traffic()
         n_tets = 12 * nx * ny * nz
         achieved = (spmv_bytes / (spmv_ms * 1e-3)) / 1e9 if spmv_ms > 0 else 0.0
         out = {
@@ -196,7 +254,9 @@ def main():
                              "detection every evaluation, gravity, dt=1/30, initial gap 1.5 mm" % (nx, ny, nz, n_tets, info.ndofs)) if a.scene == "contact" else
                             ("tet block generate_tet_grid{%d,%d,%d} = %d tets / %d DoF, Soft_Rubber, bottom face clamped, gravity, dt=1/30, NO contact" % (nx, ny, nz, n_tets, info.ndofs)),
                 "step": "one Newton iteration (contact detection, eval P+g+H, assembly, block-Jacobi PCG, intersection check, line search)",
-                "parallelism": "single GPU" if world == 1 else "elements sharded by contiguous ranges over %d GPUs; RCCL all-reduce of energy+gradient, of the assembled matrix and of the projection deltas; replicated PCG, line search and contact detection" % world,
+                "parallelism": "single GPU" if world == 1 else ("block rows partitioned over %d GPUs; every rank evaluates the elements touching its rows (interface elements on both sides) and assembles "
+                                                                   "and solves its rows: row-sharded block-Jacobi PCG, ghosts of p and the dot products exchanged by ncclAllGather (RCCL over xGMI) "
+                                                                   "in every iteration; state, line search and contact detection replicated" % world),
                 "projection": "Progressive",
             },
             "ms_per_linear_solve": 1000.0 * t_ls / max(n_ls, 1),
@@ -211,10 +271,14 @@ def main():
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
-                # HBM-side bytes per real SpMV launch from rocprofv3 PMC passes of this command (profiles/r01_v9_pmc_*.txt):
-                # 2 x FETCH_SIZE (gfx950 reports half of wide coalesced reads, MI355X_MICROARCH.md "HBM") + WRITE_SIZE, KB -> bytes.
-                # Only valid for the default workload; other sizes report null.
-                "traffic": (2 * 56746.5 + 5735.7) * 1024.0 if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
+                # not measured in this run (PMC counters need their own rocprofv3 passes): taken from the newest committed profile of the same
+                # command, named in traffic_source; null for other workloads or when no such profile exists
+                "traffic": traffic if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
+                "traffic_source": traffic_src if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
+                # the matrix (99 MB) and the vectors fit the 256 MiB Infinity Cache: FETCH_SIZE counts cache hits too, so `achieved` is fabric-side
+                # bandwidth; a plain float4 stream of the same value buffer reaches 6.3 TB/s on this box (tools/spmv_sweep.py, variant 9)
+                "frac_of_stream_ceiling": achieved / 6300.0,
+                "working_set": "Infinity-Cache resident (matrix 99 MB + vectors)",
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "avg_launch_ms": spmv_ms,
                 "launches_timed": spmv_n,

@@ -271,6 +271,11 @@ int mistark_sync(mistark_ctx* ctx);
  * Reductions are done by every rank in rank order: identical bits everywhere. Call right after mistark_create, before the first
  * evaluation. With N ranks mistark_get_bsr / mistark_apply_preconditioner are not available (single-rank accessors). */
 int mistark_shard_range(int64_t n, int rank, int world, int64_t* begin, int64_t* end); /* [n*rank/world, n*(rank+1)/world) */
+/* The built-in graph partition as a host function (no GPU, no context): tables of elements given by their block rows (rows[t][e * nb[t] + k]),
+ * hub[r] != 0 marks rows kept out of the graph (given to the last rank; NULL: none). Breadth-first order from a pseudo-peripheral row, cut
+ * into `world` pieces of equal element incidence. */
+int mistark_partition_rows(int64_t n_block_rows, int world, int n_tables, const int32_t* const* rows, const int64_t* n_elem, const int32_t* nb, const uint8_t* hub,
+                           int32_t* owner_out);
 int mistark_dist_unique_id(char out[128]);  /* rank 0: ncclGetUniqueId, to be broadcast by the launcher (e.g. torch.distributed) */
 int mistark_dist_init_rccl(mistark_ctx* ctx, int rank, int world, const char unique_id[128]);
 /* Moves the communicator (rank, world, transport) of `from` to `ctx`; `from` becomes a single-rank context (a scene that registers
@@ -281,6 +286,11 @@ int mistark_dist_rccl_selftest(mistark_ctx* ctx, double* inout, int64_t n);
 /* Explicit partition: owner[r] in [0, world) for every block row r of the flat DoF vector (e.g. slabs along the longest axis from the
  * scene's positions). owner == NULL returns to the built-in graph partition. */
 int mistark_dist_set_row_owner(mistark_ctx* ctx, const int32_t* owner, int64_t n_block_rows);
+int64_t mistark_dof_set_first_row(mistark_ctx* ctx, int set);  /* first block row of a DoF set in the flat DoF vector (< 0: no such set) */
+/* A position per block row (xyz[3 r ..], NaN for rows without one: rigid bodies keep the last rank): the rows are partitioned by recursive
+ * coordinate bisection, weighted by element incidences — box-like parts with few interface rows. The host mirror passes the rest positions
+ * of its point sets. An explicit owner map takes precedence; without either the built-in graph partition is used. */
+int mistark_dist_set_row_coords(mistark_ctx* ctx, const double* xyz, int64_t n_block_rows);
 /* Block rows that potentials with device-side connectivity may reference on any rank; every rank keeps them as ghosts. The contact system
  * registers the collision vertices of its deformable meshes itself; small DoF sets (rigid bodies) are always shared. */
 int mistark_dist_add_shared_rows(mistark_ctx* ctx, const int32_t* rows, int64_t n);

@@ -132,6 +132,7 @@ def lib():
     L.mistark_dist_init_local.argtypes = [p, p, C.c_int]
     L.mistark_dist_set_row_owner.argtypes = [p, p, i64]
     L.mistark_dist_add_shared_rows.argtypes = [p, p, i64]
+    L.mistark_dist_set_row_coords.argtypes = [p, p, i64]
     L.mistark_dist_info.argtypes = [p, p, C.c_int]
     L.mistark_dist_get_row_owner.argtypes = [p, p]
     L.mistark_dist_move.argtypes = [p, p]

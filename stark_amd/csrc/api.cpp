@@ -420,6 +420,7 @@ int mistark_get_element_hessians(mistark_ctx* ctx, int potential, double* values
     Context& c = ctx->c;
     if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
     if (!c.have_hessians) throw Error("no element Hessians");
+    if (c.world > 1) throw Error("mistark_get_element_hessians: single-rank accessor (a sharded context holds the elements touching its rows)");
     Potential& P = c.pots[potential];
     if (values && c.lazy_active && P.lazy_capable) throw Error("element Hessians of '" + P.name + "' were evaluated on the lazy path (float blocks only); evaluate without lazy_eval");
     const int NB = P.NB, n = 3 * NB;
@@ -447,6 +448,7 @@ int mistark_get_element_energies(mistark_ctx* ctx, int potential, double* values
     Context& c = ctx->c;
     if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
     Potential& P = c.pots[potential];
+    if (c.world > 1) throw Error("mistark_get_element_energies: single-rank accessor");
     if (P.n_elem > 0) {
         MS_CHECK(hipMemcpyAsync(values, c.elemE.p + P.e_off, (size_t)P.n_elem * sizeof(double), hipMemcpyDeviceToHost, c.stream));
         MS_CHECK(hipStreamSynchronize(c.stream));
@@ -659,6 +661,20 @@ int mistark_shard_range(int64_t n, int rank, int world, int64_t* begin, int64_t*
     if (end) *end = e;
     return 0;
 }
+int mistark_partition_rows(int64_t n_block_rows, int world, int n_tables, const int32_t* const* rows, const int64_t* n_elem, const int32_t* nb, const uint8_t* hub, int32_t* owner_out)
+{
+    if (n_block_rows <= 0 || world < 1 || n_tables < 0 || !owner_out) return -1;
+    try {
+        std::vector<ElemTable> tables;
+        for (int t = 0; t < n_tables; t++) tables.push_back(ElemTable{rows[t], n_elem[t], nb[t]});
+        std::vector<int32_t> owner;
+        graph_partition_rows(n_block_rows, world, tables, hub, owner);
+        std::memcpy(owner_out, owner.data(), (size_t)n_block_rows * sizeof(int32_t));
+    } catch (const std::exception&) {
+        return -1;
+    }
+    return 0;
+}
 int mistark_dist_unique_id(char out[128])
 {
     try {
@@ -721,6 +737,7 @@ int mistark_dist_move(mistark_ctx* ctx, mistark_ctx* from)
     MS_CHECK(hipStreamSynchronize(o.stream));
     set_dist(ctx->c, o.rank, o.world, std::move(o.coll));
     ctx->c.sh.user_owner = o.sh.user_owner;
+    ctx->c.sh.coords = o.sh.coords;
     o.world = 1;
     o.rank = 0;
     API_END(0)
@@ -731,6 +748,23 @@ int mistark_dist_set_row_owner(mistark_ctx* ctx, const int32_t* owner, int64_t n
     Context& c = ctx->c;
     if (owner && n_block_rows > 0) c.sh.user_owner.assign(owner, owner + n_block_rows);
     else c.sh.user_owner.clear();
+    c.sh.version++;
+    c.layout_dirty = true;
+    API_END(0)
+}
+int64_t mistark_dof_set_first_row(mistark_ctx* ctx, int set)
+{
+    if (!ctx || set < 0 || set >= (int)ctx->c.dof_sets.size()) return -1;
+    int64_t off = 0;
+    for (int s = 0; s < set; s++) off += ctx->c.dof_sets[(size_t)s].n;
+    return off / 3;
+}
+int mistark_dist_set_row_coords(mistark_ctx* ctx, const double* xyz, int64_t n_block_rows)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (xyz && n_block_rows > 0) c.sh.coords.assign(xyz, xyz + 3 * n_block_rows);
+    else c.sh.coords.clear();
     c.sh.version++;
     c.layout_dirty = true;
     API_END(0)

@@ -158,7 +158,8 @@ struct Potential
     std::vector<int64_t> inc_sig;     // what the incidence lists were built for
     // sharded runs: the elements this rank evaluates, [elements whose energy counts here | interface elements of other ranks]
     DevBuf<uint32_t> elem_list;
-    int n_list = 0, n_eown = 0;
+    int n_list = 0, n_eown_list = 0;  // length of the list and of its leading part (elements whose energy counts here)
+    int n_eown = 0;                   // elements the energy-only kernels run over (n_elem, or n_eown_list)
     int n_key = 0;                    // elements in the key space / pools of this context (n_elem, or n_list when sharded with a list)
     bool lazy_capable = false;
     size_t hf_off = 0;  // first float in the float pool
@@ -216,6 +217,7 @@ struct BsrPart
 struct Shard
 {
     std::vector<int32_t> user_owner;   // explicit partition (mistark_dist_set_row_owner), empty: graph partition
+    std::vector<double> coords;        // a position per block row (mistark_dist_set_row_coords): recursive coordinate bisection
     std::vector<int32_t> shared_rows;  // rows any rank may reference from potentials whose connectivity changes (contacts): ghosts everywhere
     std::vector<int32_t> owner;        // per global block row
     std::vector<int64_t> n_own_of, n_send_of;  // per rank
@@ -358,6 +360,14 @@ void shard_to_local(Context& c, const double* v_global, double* v_local, bool wi
 void shard_allgather_scalars(Context& c, const double* mine, int n, double* all_host);  // all_host[r * n + i]; blocking
 double shard_sum(Context& c, double mine);
 void shard_check(Context& c);
+struct ElemTable  // block rows of the elements of one potential: rows[e * nb + k]
+{
+    const int32_t* rows;
+    int64_t n_elem;
+    int nb;
+};
+void rcb_partition_rows(int64_t n_block_rows, int world, const double* xyz, const std::vector<int64_t>& weight, std::vector<int32_t>& owner);
+void graph_partition_rows(int64_t n_block_rows, int world, const std::vector<ElemTable>& tables, const uint8_t* hub, std::vector<int32_t>& owner);
 void ensure_pattern(Context& c);
 void contact_destroy(struct ContactSystem* cs);
 void contact_shared_rows(Context& c, std::vector<int32_t>& rows);  // contact.hip

@@ -2,6 +2,7 @@
 #include "sim.hpp"
 #include "bind.hpp"
 
+#include <limits>
 #include <chrono>
 #include <cstdio>
 #include <stdexcept>
@@ -52,6 +53,20 @@ void Stark::ensure_registered()
     gravity_array_id = mistark_array(ctx, gravity.data(), 1, 3);
     check(gravity_array_id);
     for (auto* m : models) m->register_potentials(ctx);
+    if (settings.execution.world > 1) {
+        // sharded run: partition the block rows by the positions of the points (recursive coordinate bisection in the engine); rigid
+        // bodies (no position: NaN) keep the last rank
+        const int64_t nbr = mistark_ndofs(ctx) / 3;
+        std::vector<double> xyz((size_t)(3 * nbr), std::numeric_limits<double>::quiet_NaN());
+        for (auto* m : models)
+            if (auto* pd = dynamic_cast<PointDynamics*>(m)) {
+                const int64_t row0 = mistark_dof_set_first_row(ctx, pd->dof_set);
+                if (row0 < 0) continue;
+                for (size_t i = 0; i < pd->size(); i++)
+                    for (int d = 0; d < 3; d++) xyz[(size_t)(3 * (row0 + (int64_t)i) + d)] = pd->X[i][d];
+            }
+        check(mistark_dist_set_row_coords(ctx, xyz.data(), nbr));
+    }
     dt_uploaded = dt;
     registration_dirty = false;
     if (old) mistark_destroy(old);

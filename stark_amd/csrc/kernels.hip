@@ -2151,10 +2151,11 @@ static void make_descriptors(Context& c, int part)
     if (m.desc_lazy == (c.lazy_active ? 1 : 0) || m.n_keys == 0) return;
     std::vector<DescRange> rg;
     for (auto& P : c.pots) {
-        if (P.part != part || P.n_elem == 0) continue;
+        if (P.part != part || P.n_key == 0) continue;
         const bool lazy = c.lazy_active && P.lazy_capable;
-        rg.push_back(DescRange{(uint32_t)P.kp_off, (uint32_t)P.n_elem, (uint32_t)P.NB, (uint32_t)P.args.e_begin, (uint32_t)P.args.e_count,
-                               lazy ? (uint32_t)(P.hf_off / 9) : (uint32_t)P.k_off, lazy ? (uint32_t)P.n_pool_f : (uint32_t)P.n_elem, lazy ? 1u : 0u});
+        // (key space and pools hold the n_key elements this context evaluates: all of them, or the rank's list)
+        rg.push_back(DescRange{(uint32_t)P.kp_off, (uint32_t)P.n_key, (uint32_t)P.NB, 0u, (uint32_t)P.n_key, lazy ? (uint32_t)(P.hf_off / 9) : (uint32_t)P.k_off,
+                               lazy ? (uint32_t)P.n_pool_f : (uint32_t)P.n_key, lazy ? 1u : 0u});
     }
     if (c.hess_total / 9 > DESC_MASK || c.hf_total / 9 > DESC_MASK) throw Error("element-Hessian pool too large for the gather descriptors");
     m.sorted_desc.ensure(m.n_keys);

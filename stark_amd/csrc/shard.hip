@@ -70,33 +70,26 @@ __global__ __launch_bounds__(TB) void k_scatter_all(const double* __restrict__ r
 inline int64_t row_of(const Potential& P, int e, int k) { return (int64_t)P.args.dof_row_off[k] + P.conn_host[(size_t)e * P.conn_stride + P.args.dof_col[k]]; }
 inline bool has_host_conn(const Potential& P) { return !P.conn_ext && P.n_elem > 0 && !P.conn_host.empty(); }
 
+}  // namespace
+
 // Owner map from the connectivity graph: breadth-first order from a pseudo-peripheral row (two sweeps), components one after the other,
-// cut into `world` consecutive pieces of equal weight (element incidences). Rows of small DoF sets (rigid bodies: hubs that would
-// put the whole mesh within two hops) are left out of the graph and given to the last rank.
-void graph_partition(Context& c, std::vector<int32_t>& owner)
+// cut into `world` consecutive pieces of equal weight (element incidences). Hub rows (rows of small DoF sets: rigid bodies, which would
+// put the whole mesh within two hops) are left out of the graph and given to the last rank. Pure host code (mistark_partition_rows).
+void graph_partition_rows(int64_t nbr, int W, const std::vector<ElemTable>& tables, const uint8_t* hub, std::vector<int32_t>& owner)
 {
-    const int64_t nbr = c.nbr;
-    const int W = c.world;
-    std::vector<uint8_t> hub((size_t)nbr, 0);
-    for (auto& s : c.dof_sets) {
-        const int64_t rows = s.n / 3;
-        if (rows > 0 && rows <= HOT_SET_ROWS)
-            for (int64_t r = 0; r < rows; r++) hub[(size_t)(s.offset / 3 + r)] = 1;
-    }
-    // row -> incident elements (potential index, element) as one flat id
-    std::vector<const Potential*> pots;
-    std::vector<int64_t> pot_base;
+    auto is_hub = [&](int64_t r) { return hub && hub[(size_t)r]; };
+    std::vector<int64_t> tab_base;
     int64_t n_el = 0;
-    for (auto& P : c.pots)
-        if (P.part == 0 && has_host_conn(P)) {
-            pots.push_back(&P);
-            pot_base.push_back(n_el);
-            n_el += P.n_elem;
-        }
+    for (const ElemTable& T : tables) {
+        tab_base.push_back(n_el);
+        n_el += T.n_elem;
+    }
     std::vector<int64_t> start((size_t)nbr + 1, 0);
-    for (const Potential* P : pots)
-        for (int e = 0; e < P->n_elem; e++)
-            for (int k = 0; k < P->NB; k++) start[(size_t)row_of(*P, e, k) + 1]++;
+    for (const ElemTable& T : tables)
+        for (int64_t i = 0; i < T.n_elem * T.nb; i++) {
+            if (T.rows[i] < 0 || T.rows[i] >= nbr) throw Error("partition: block row out of range");
+            start[(size_t)T.rows[i] + 1]++;
+        }
     std::vector<int64_t> weight((size_t)nbr);
     for (int64_t r = 0; r < nbr; r++) {
         weight[(size_t)r] = 1 + start[(size_t)r + 1];
@@ -105,32 +98,29 @@ void graph_partition(Context& c, std::vector<int32_t>& owner)
     std::vector<int64_t> inc((size_t)start[(size_t)nbr]);
     {
         std::vector<int64_t> fill(start.begin(), start.end() - 1);
-        for (size_t pi = 0; pi < pots.size(); pi++)
-            for (int e = 0; e < pots[pi]->n_elem; e++)
-                for (int k = 0; k < pots[pi]->NB; k++) inc[(size_t)fill[(size_t)row_of(*pots[pi], e, k)]++] = pot_base[pi] + e;
+        for (size_t ti = 0; ti < tables.size(); ti++)
+            for (int64_t e = 0; e < tables[ti].n_elem; e++)
+                for (int k = 0; k < tables[ti].nb; k++) inc[(size_t)fill[(size_t)tables[ti].rows[e * tables[ti].nb + k]]++] = tab_base[ti] + e;
     }
-    auto pot_of = [&](int64_t id, int& e) {
-        size_t pi = (size_t)(std::upper_bound(pot_base.begin(), pot_base.end(), id) - pot_base.begin()) - 1;
-        e = (int)(id - pot_base[pi]);
-        return pots[pi];
-    };
     std::vector<int32_t> level((size_t)nbr, -1);
     std::vector<int64_t> order;
     order.reserve((size_t)nbr);
     // breadth-first sweep from `root` over unvisited (level < 0) non-hub rows; appends to out; returns the last row reached
-    auto bfs = [&](int64_t root, std::vector<int64_t>& out, std::vector<int32_t>& lev) {
+    auto bfs = [&](int64_t root, std::vector<int64_t>& out) {
         const size_t first = out.size();
         out.push_back(root);
-        lev[(size_t)root] = 0;
+        level[(size_t)root] = 0;
         for (size_t h = first; h < out.size(); h++) {
             const int64_t u = out[h];
             for (int64_t j = start[(size_t)u]; j < start[(size_t)u + 1]; j++) {
-                int e;
-                const Potential* P = pot_of(inc[(size_t)j], e);
-                for (int k = 0; k < P->NB; k++) {
-                    const int64_t v = row_of(*P, e, k);
-                    if (lev[(size_t)v] < 0 && !hub[(size_t)v]) {
-                        lev[(size_t)v] = lev[(size_t)u] + 1;
+                const int64_t id = inc[(size_t)j];
+                const size_t ti = (size_t)(std::upper_bound(tab_base.begin(), tab_base.end(), id) - tab_base.begin()) - 1;
+                const ElemTable& T = tables[ti];
+                const int32_t* rows = T.rows + (id - tab_base[ti]) * T.nb;
+                for (int k = 0; k < T.nb; k++) {
+                    const int64_t v = rows[k];
+                    if (level[(size_t)v] < 0 && !is_hub(v)) {
+                        level[(size_t)v] = level[(size_t)u] + 1;
                         out.push_back(v);
                     }
                 }
@@ -139,15 +129,15 @@ void graph_partition(Context& c, std::vector<int32_t>& owner)
         return out.back();
     };
     for (int64_t r0 = 0; r0 < nbr; r0++) {
-        if (level[(size_t)r0] >= 0 || hub[(size_t)r0]) continue;
+        if (level[(size_t)r0] >= 0 || is_hub(r0)) continue;
         // pseudo-peripheral start: the far end of a sweep from r0, and the far end of a sweep from there
         std::vector<int64_t> tmp;
-        int64_t far = bfs(r0, tmp, level);
+        int64_t far = bfs(r0, tmp);
         for (int64_t v : tmp) level[(size_t)v] = -1;
         tmp.clear();
-        far = bfs(far, tmp, level);
+        far = bfs(far, tmp);
         for (int64_t v : tmp) level[(size_t)v] = -1;
-        bfs(far, order, level);
+        bfs(far, order);
     }
     int64_t total = 0;
     for (int64_t v : order) total += weight[(size_t)v];
@@ -157,6 +147,76 @@ void graph_partition(Context& c, std::vector<int32_t>& owner)
         owner[(size_t)v] = (int32_t)std::min<int64_t>(W - 1, total > 0 ? acc * W / total : 0);
         acc += weight[(size_t)v];
     }
+}
+
+// Owner map from positions: recursive coordinate bisection. The rows with a position are split along the longest axis of their bounding box
+// into two parts whose weights (element incidences) are in the ratio of the rank counts they go to, recursively; rows without one (NaN:
+// rigid bodies) keep the last rank. Compact, box-like parts: fewer interface rows than the level sets of the graph partition.
+void rcb_partition_rows(int64_t nbr, int W, const double* xyz, const std::vector<int64_t>& weight, std::vector<int32_t>& owner)
+{
+    owner.assign((size_t)nbr, (int32_t)(W - 1));
+    std::vector<int64_t> idx;
+    for (int64_t r = 0; r < nbr; r++)
+        if (xyz[3 * r] == xyz[3 * r] && xyz[3 * r + 1] == xyz[3 * r + 1] && xyz[3 * r + 2] == xyz[3 * r + 2]) idx.push_back(r);
+    struct Job
+    {
+        size_t b, e;
+        int r0, nr;
+    };
+    std::vector<Job> jobs{{0, idx.size(), 0, W}};
+    while (!jobs.empty()) {
+        const Job j = jobs.back();
+        jobs.pop_back();
+        if (j.nr == 1 || j.e - j.b <= 1) {
+            for (size_t i = j.b; i < j.e; i++) owner[(size_t)idx[i]] = (int32_t)j.r0;
+            continue;
+        }
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (size_t i = j.b; i < j.e; i++)
+            for (int d = 0; d < 3; d++) {
+                lo[d] = std::min(lo[d], xyz[3 * idx[i] + d]);
+                hi[d] = std::max(hi[d], xyz[3 * idx[i] + d]);
+            }
+        int ax = 0;
+        for (int d = 1; d < 3; d++)
+            if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+        std::sort(idx.begin() + (long)j.b, idx.begin() + (long)j.e, [&](int64_t a, int64_t b) {
+            const double xa = xyz[3 * a + ax], xb = xyz[3 * b + ax];
+            return xa < xb || (xa == xb && a < b);
+        });
+        int64_t total = 0;
+        for (size_t i = j.b; i < j.e; i++) total += weight[(size_t)idx[i]];
+        const int n1 = j.nr / 2;
+        const int64_t target = total * n1 / j.nr;
+        int64_t acc = 0;
+        size_t cut = j.b;
+        while (cut < j.e && acc < target) acc += weight[(size_t)idx[cut++]];
+        cut = std::min(std::max(cut, j.b + 1), j.e - 1);
+        jobs.push_back({j.b, cut, j.r0, n1});
+        jobs.push_back({cut, j.e, j.r0 + n1, j.nr - n1});
+    }
+}
+
+namespace {
+void graph_partition(Context& c, std::vector<int32_t>& owner)
+{
+    const int64_t nbr = c.nbr;
+    std::vector<uint8_t> hub((size_t)nbr, 0);
+    for (auto& s : c.dof_sets) {
+        const int64_t rows = s.n / 3;
+        if (rows > 0 && rows <= HOT_SET_ROWS)
+            for (int64_t r = 0; r < rows; r++) hub[(size_t)(s.offset / 3 + r)] = 1;
+    }
+    std::vector<std::vector<int32_t>> rows;
+    std::vector<ElemTable> tables;
+    for (auto& P : c.pots)
+        if (P.part == 0 && has_host_conn(P)) {
+            rows.emplace_back((size_t)P.n_elem * P.NB);
+            for (int e = 0; e < P.n_elem; e++)
+                for (int k = 0; k < P.NB; k++) rows.back()[(size_t)e * P.NB + k] = (int32_t)row_of(P, e, k);
+            tables.push_back(ElemTable{rows.back().data(), P.n_elem, P.NB});
+        }
+    graph_partition_rows(nbr, c.world, tables, hub.data(), owner);
 }
 }  // namespace
 
@@ -169,7 +229,7 @@ void shard_prepare(Context& c)
     // ---- what the partition and the lists depend on
     std::vector<int32_t> shared = S.shared_rows;
     contact_shared_rows(c, shared);
-    std::vector<int64_t> sig{nbr, (int64_t)W, (int64_t)me, (int64_t)S.user_owner.size(), (int64_t)shared.size(), (int64_t)S.version};
+    std::vector<int64_t> sig{nbr, (int64_t)W, (int64_t)me, (int64_t)S.user_owner.size(), (int64_t)S.coords.size(), (int64_t)shared.size(), (int64_t)S.version};
     for (auto& P : c.pots) {
         sig.push_back(has_host_conn(P) ? (int64_t)P.conn_version : -1);
         sig.push_back(P.part);
@@ -186,6 +246,14 @@ void shard_prepare(Context& c)
             for (int32_t o : S.user_owner)
                 if (o < 0 || o >= W) throw Error("mistark_dist_set_row_owner: owner out of range");
             S.owner = S.user_owner;
+        } else if (!S.coords.empty()) {
+            if ((int64_t)S.coords.size() != 3 * nbr) throw Error("mistark_dist_set_row_coords: one position per block row (" + std::to_string(nbr) + ")");
+            std::vector<int64_t> weight((size_t)nbr, 1);
+            for (auto& P : c.pots)
+                if (has_host_conn(P))
+                    for (int e = 0; e < P.n_elem; e++)
+                        for (int k = 0; k < P.NB; k++) weight[(size_t)row_of(P, e, k)]++;
+            rcb_partition_rows(nbr, W, S.coords.data(), weight, S.owner);
         } else {
             graph_partition(c, S.owner);
         }
@@ -263,7 +331,7 @@ void shard_prepare(Context& c)
         MS_CHECK(hipMemsetAsync(S.err.p, 0, sizeof(int32_t), c.stream));
         // ---- element lists: [energy counts here | interface elements of other ranks]
         for (auto& P : c.pots) {
-            P.n_list = P.n_eown = 0;
+            P.n_list = P.n_eown_list = 0;
             if (!has_host_conn(P)) continue;
             std::vector<uint32_t> mine, halo;
             for (int e = 0; e < P.n_elem; e++) {
@@ -272,7 +340,7 @@ void shard_prepare(Context& c)
                 if (!touch) continue;
                 (S.owner[(size_t)row_of(P, e, 0)] == me ? mine : halo).push_back((uint32_t)e);
             }
-            P.n_eown = (int)mine.size();
+            P.n_eown_list = (int)mine.size();
             mine.insert(mine.end(), halo.begin(), halo.end());
             P.n_list = (int)mine.size();
             P.elem_list.ensure(std::max<size_t>(mine.size(), 1));
@@ -292,6 +360,7 @@ void shard_prepare(Context& c)
             A.e_begin = 0;
             A.e_count = P.n_list;
             P.n_key = P.n_list;
+            P.n_eown = P.n_eown_list;
         } else {  // connectivity written on the device (contact tables): small, evaluated by every rank; rows of other ranks are dropped
             A.elem_list = nullptr;
             A.e_begin = 0;

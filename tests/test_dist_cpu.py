@@ -1,8 +1,11 @@
-"""CPU, world_size 2 over gloo: the arithmetic of the multi-GPU path. Each rank takes the contiguous element ranges the engine
-would take (mistark_shard_range, the C function the engine's prepare() uses — host code, no GPU), evaluates ONLY those elements
-with the oracle, and the sums of energy, gradient and assembled matrix over the ranks (torch.distributed all_reduce, gloo) must
-equal the unsharded result. The GPU kernels of the same path are covered by tests/test_gpu_sharded.py."""
-import copy
+"""CPU, world_size 2 over gloo: the arithmetic of the sharded path (stark_amd/csrc/shard.hip, pcg_sharded in kernels.hip) restated with the
+oracle. The block rows are partitioned by the engine's own graph partition (mistark_partition_rows: host code, no GPU); each rank
+evaluates ONLY the elements touching its rows, and then
+  * the energies of the elements whose first block row a rank owns, all-gathered and summed in rank order, give the unsharded energy;
+  * a rank's gradient rows and matrix rows are complete without any exchange (interface elements are evaluated by both sides);
+  * the row-sharded block-Jacobi PCG — ghosts of p from their owners, p.Ap all-gathered, (r.r, r.z) fused in one all-gather, every rank
+    reducing in rank order — stops at the unsharded solve's iteration (+-1) with the same solution, identical bits on both ranks.
+The GPU kernels of the same path are covered by tests/test_gpu_sharded.py (2, 3 and 8 ranks)."""
 import ctypes as C
 import os
 import sys
@@ -15,7 +18,20 @@ sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def partition(L, nbr, world, outs, hub=None):
+    tabs = [np.ascontiguousarray(o.block_rows, dtype=np.int32) for o in outs if len(o.E)]
+    ptrs = (C.c_void_p * len(tabs))(*[t.ctypes.data for t in tabs])
+    n_elem = (C.c_int64 * len(tabs))(*[t.shape[0] for t in tabs])
+    nb = (C.c_int32 * len(tabs))(*[t.shape[1] for t in tabs])
+    owner = np.zeros(nbr, dtype=np.int32)
+    L.mistark_partition_rows.argtypes = [C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    hub_p = None if hub is None else np.ascontiguousarray(hub, dtype=np.uint8).ctypes.data
+    assert L.mistark_partition_rows(nbr, world, len(tabs), ptrs, n_elem, nb, hub_p, owner.ctypes.data) == 0
+    return owner
+
+
 def _rank_main(rank, world, port, name, result_dir):
+    import scipy.sparse as sp
     import torch
     import torch.distributed as dist
 
@@ -27,93 +43,168 @@ def _rank_main(rank, world, port, name, result_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     L = capi.lib()
     prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
-    full_E, full_g, full_outs = ev.evaluate_all(prob)
-    full_A = ev.assemble(full_outs, prob.ndofs).to_scipy() if hasattr(ev.BSR, "to_scipy") else None
-    # this rank's problem: every potential cut to its contiguous range
-    local = copy.copy(prob)
-    local.potentials = []
-    covered = 0
-    for p in prob.potentials:
-        n = p.conn.shape[0]
-        b, e = C.c_int64(), C.c_int64()
-        assert L.mistark_shard_range(n, rank, world, C.byref(b), C.byref(e)) == 0
-        q = copy.copy(p)
-        q.conn = p.conn[b.value:e.value]
-        local.potentials.append(q)
-        covered += e.value - b.value
-        # ranges of all ranks tile [0, n) without gaps or overlap
-        edges = []
-        for r in range(world):
-            bb, ee = C.c_int64(), C.c_int64()
-            L.mistark_shard_range(n, r, world, C.byref(bb), C.byref(ee))
-            edges.append((bb.value, ee.value))
-        assert edges[0][0] == 0 and edges[-1][1] == n and all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
-    E, g, outs = ev.evaluate_all(local)
-    t = torch.tensor(np.concatenate([g, [E]]))
-    dist.all_reduce(t)                                   # what ncclAllReduce does for (gradient | E) on the GPU path
-    g_sum, E_sum = t[:-1].numpy(), float(t[-1])
-    assert abs(E_sum - full_E) <= 1e-12 * max(1.0, abs(full_E))
-    assert np.abs(g_sum - full_g).max() <= 1e-12 * max(np.abs(full_g).max(), 1e-300)
-    # matrix: partial assembly in the GLOBAL pattern, summed over ranks
-    import scipy.sparse as sp
-
-    def to_csr(A):
-        return sp.bsr_matrix((A.vals.astype(np.float64), A.cols, A.row_ptr), shape=(prob.ndofs, prob.ndofs)).tocsr()
-
-    A_full = to_csr(ev.assemble(full_outs, prob.ndofs))
-    A_loc = to_csr(ev.assemble(outs, prob.ndofs)) if outs else sp.csr_matrix((prob.ndofs, prob.ndofs))
-    dense = torch.tensor(A_loc.toarray())
-    dist.all_reduce(dense)
-    assert np.abs(dense.numpy() - A_full.toarray()).max() <= 4e-7 * np.abs(A_full).max()
-    # projection round (stark_amd/csrc/kernels.hip: exchange_projection_deltas): every rank projects ITS elements, the deltas travel as
-    # (position, value) records in a common zero-filled float buffer (all-reduce = exchange), every rank sorts them by position (stable)
-    # and adds them to its copy of the summed matrix: the result must equal the matrix assembled from all projected Hessians
     n = prob.ndofs
-    recs = []
-    for o in outs:
-        Hp, changed = ev.project_to_pd(o.H)
-        d = (Hp - o.H).astype(np.float32)
-        nb = o.block_rows.shape[1]
-        for e in np.nonzero(changed)[0]:
-            for a in range(nb):
-                for b in range(nb):
-                    for i in range(3):
-                        for j in range(3):
-                            recs.append(((3 * o.block_rows[e, a] + i) * n + 3 * o.block_rows[e, b] + j, d[e, 3 * a + i, 3 * b + j]))
-    cnt = torch.zeros(world, dtype=torch.float64)
-    cnt[rank] = len(recs)
-    dist.all_reduce(cnt)
-    counts = [int(c) for c in cnt]
-    total, offset = sum(counts), sum(counts[:rank])
-    buf = torch.zeros(3 * max(total, 1), dtype=torch.float32)
-    for k, (pos, v) in enumerate(recs):
-        buf[3 * (offset + k)] = float(pos >> 16)      # positions as two exact floats, like the engine
-        buf[3 * (offset + k) + 1] = float(pos & 0xffff)
-        buf[3 * (offset + k) + 2] = float(v)
-    dist.all_reduce(buf)
-    b3 = buf.numpy().reshape(-1, 3)[:total]
-    pos = (b3[:, 0].astype(np.int64) << 16) | b3[:, 1].astype(np.int64)
-    patched = dense.numpy().astype(np.float32).reshape(-1).copy()
-    for k in np.argsort(pos, kind="stable"):
-        patched[pos[k]] += b3[k, 2]
-    full_proj = []
+    nbr = n // 3
+    full_E, full_g, full_outs = ev.evaluate_all(prob)
+    A_full = ev.assemble(full_outs, n)
+
+    def allgather(v):
+        out = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(out, v)
+        return out
+
+    # ---- partition: the same owner map on every rank, every rank owns rows
+    owner = partition(L, nbr, world, full_outs)
+    maps = allgather(torch.tensor(owner))
+    assert all((m.numpy() == owner).all() for m in maps)
+    mine = owner == rank
+    assert 0 < mine.sum() < nbr and set(np.unique(owner)) == set(range(world))
+
+    # ---- this rank's problem: the elements touching its rows; an element's energy counts where its first block row lives
+    local, E_mine = [], 0.0
     for o in full_outs:
-        Hp, _ = ev.project_to_pd(o.H)
-        full_proj.append(ev.ElementOutput(o.name, o.E, o.g, Hp, o.block_rows, o.active))
-    A_proj = to_csr(ev.assemble(full_proj, prob.ndofs)).toarray()
-    assert np.abs(patched.reshape(n, n) - A_proj).max() <= 4e-6 * np.abs(A_proj).max()
-    count = torch.tensor([float(covered)])
-    dist.all_reduce(count)
-    assert int(count.item()) == sum(p.conn.shape[0] for p in prob.potentials)
+        touch = mine[o.block_rows].any(axis=1)
+        local.append(ev.ElementOutput(o.name, o.E[touch], o.g[touch], o.H[touch], o.block_rows[touch], o.active))
+        E_mine += float(o.E[mine[o.block_rows[:, 0]]].sum())
+    Es = allgather(torch.tensor([E_mine], dtype=torch.float64))
+    E_sum = 0.0
+    for r in range(world):
+        E_sum += float(Es[r])                      # rank order: the same bits everywhere
+    assert abs(E_sum - full_E) <= 1e-12 * max(1.0, abs(full_E))
+    g_loc = np.zeros(n)
+    for o in local:
+        nb = o.block_rows.shape[1]
+        for k in range(nb):
+            np.add.at(g_loc.reshape(-1, 3), o.block_rows[:, k], o.g[:, 3 * k:3 * k + 3])
+    own3 = np.repeat(mine, 3)
+    assert np.abs(g_loc[own3] - full_g[own3]).max() <= 1e-12 * max(np.abs(full_g).max(), 1e-300)     # complete without exchange
+    A_loc = ev.assemble(local, n).to_scipy().tocsr()
+    S_full = A_full.to_scipy().tocsr()
+    rows_own = np.nonzero(own3)[0]
+    assert abs(A_loc[rows_own] - S_full[rows_own]).max() <= 4e-7 * abs(S_full).max()                    # my rows of the matrix, too
+
+    # ---- local numbering: my rows (ascending), then the ghosts grouped by owner; send rows = my rows somebody else holds as ghost
+    need = np.zeros((nbr, world), dtype=bool)
+    for o in full_outs:
+        m = np.zeros((len(o.E), world), dtype=bool)
+        for k in range(o.block_rows.shape[1]):
+            m[np.arange(len(o.E)), owner[o.block_rows[:, k]]] = True
+        for k in range(o.block_rows.shape[1]):
+            np.logical_or.at(need, o.block_rows[:, k], m)
+    own_rows = np.nonzero(mine)[0]
+    ghosts = np.concatenate([np.nonzero((owner == o) & need[:, rank])[0] for o in range(world) if o != rank]).astype(np.int64)
+    grow = np.concatenate([own_rows, ghosts])
+    lrow = -np.ones(nbr, dtype=np.int64)
+    lrow[grow] = np.arange(len(grow))
+    n_own, n_loc = len(own_rows), len(grow)
+    send_of = [np.nonzero((owner == r) & (need & ~np.eye(world, dtype=bool)[owner]).any(axis=1))[0] for r in range(world)]
+    stride = max(len(s) for s in send_of)
+    pos_in_send = -np.ones(nbr, dtype=np.int64)
+    for r in range(world):
+        pos_in_send[send_of[r]] = np.arange(len(send_of[r]))
+    ghost_src = owner[ghosts] * stride + pos_in_send[ghosts]
+    assert (pos_in_send[ghosts] >= 0).all()
+
+    def halo(v_loc):  # ghosts of a local vector from their owners: one all-gather of the padded send rows
+        buf = torch.zeros(3 * stride, dtype=torch.float64)
+        mine_send = v_loc.reshape(-1, 3)[lrow[send_of[rank]]].reshape(-1)
+        buf[:len(mine_send)] = torch.tensor(mine_send)
+        allv = torch.cat(allgather(buf)).numpy().reshape(-1, 3)
+        v_loc.reshape(-1, 3)[n_own:] = allv[ghost_src]
+
+    # my rows of A in local columns
+    Aown = A_loc[rows_own].tocoo()
+    cols_l = 3 * lrow[Aown.col // 3] + Aown.col % 3
+    assert (cols_l >= 0).all()                                   # every column of my rows is mine or a ghost
+    A_l = sp.csr_matrix((Aown.data, (Aown.row, cols_l)), shape=(3 * n_own, 3 * n_loc))
+    dinv = ev.block_diag_inverse(A_full)[own_rows]
+
+    # ---- the row-sharded PCG (solve_pcg.h:83-232 with the three dot products exchanged)
+    abs_tol, rel_tol = man["pcg"]["abs_tol"], 1e-4
+    b = -full_g[own3]
+
+    def gsum(vals):  # all-gather of this rank's partial sums, reduced in rank order
+        parts = allgather(torch.tensor(vals, dtype=torch.float64))
+        out = np.zeros(len(vals))
+        for r in range(world):
+            out += parts[r].numpy()
+        return out
+
+    x = np.zeros(3 * n_own)
+    r = b.copy()
+    zv = ev.apply_preconditioner(dinv, r)
+    p = np.zeros(3 * n_loc)
+    p[:3 * n_own] = zv
+    bb, rz = gsum([float(r @ r), float(r @ zv)])
+    its, converged = 0, bb < abs_tol * abs_tol
+    while not converged and its < 10000:
+        its += 1
+        halo(p)
+        q = A_l @ p
+        (pAp,) = gsum([float(p[:3 * n_own] @ q)])
+        if pAp <= 0.0:
+            break
+        alpha = rz / pAp
+        x += alpha * p[:3 * n_own]
+        r -= alpha * q
+        zv = ev.apply_preconditioner(dinv, r)
+        rr, rz_new = gsum([float(r @ r), float(r @ zv)])    # (r.r, r.z) fused in one exchange
+        err = np.sqrt(rr / bb)
+        if err < abs_tol or err < rel_tol:
+            converged = True
+            break
+        p[:3 * n_own] = zv + (rz_new / rz) * p[:3 * n_own]
+        rz = rz_new
+    # gather the owned parts into the whole solution on every rank
+    pad = max(int((owner == q_).sum()) for q_ in range(world))
+    buf = torch.zeros(3 * pad, dtype=torch.float64)
+    buf[:3 * n_own] = torch.tensor(x)
+    parts = allgather(buf)
+    x_full = np.zeros(n)
+    for q_ in range(world):
+        rows_q = np.nonzero(owner == q_)[0]
+        x_full.reshape(-1, 3)[rows_q] = parts[q_].numpy()[:3 * len(rows_q)].reshape(-1, 3)
+    xo, info_o = ev.solve_pcg(A_full, -full_g, abs_tol)
+    assert converged == bool(info_o.converged) and abs(its - info_o.n_iterations) <= 1
+    assert abs(its - man["pcg"]["iterations"]) <= 1               # ... and at the reference's
+    assert np.abs(x_full - xo).max() <= 1e-4 * max(np.abs(xo).max(), 1e-300)
+    same = allgather(torch.tensor(x_full))
+    assert all((s.numpy() == x_full).all() for s in same)         # identical bits on every rank
     open(os.path.join(result_dir, "ok%d" % rank), "w").write("ok")
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["tetbeam_full_4x1x1", "contactmix_t1"])
-def test_sharded_sums_equal_unsharded_gloo(name, tmp_path):
+@pytest.mark.parametrize("name", ["tetbeam_full_4x1x1", "tetbeam_eo_4x1x1_big", "cloth_shells_6"])
+def test_sharded_solve_equals_unsharded_gloo(name, tmp_path):
     import torch.multiprocessing as mp
 
     world = 2
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_rank_main, args=(world, port, name, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
+def test_partition_rows_host():
+    """mistark_partition_rows on a chain of segments: contiguous pieces of (almost) equal size, hubs to the last rank."""
+    from stark_amd import capi
+
+    L = capi.lib()
+
+    class O:
+        pass
+
+    n = 1000
+    o = O()
+    o.block_rows = np.stack([np.arange(n - 1), np.arange(1, n)], axis=1).astype(np.int32)
+    o.E = np.zeros(n - 1)
+    for world in (2, 3, 8):
+        owner = partition(L, n, world, [o])
+        counts = np.bincount(owner, minlength=world)
+        assert counts.min() >= n // world - 3 and counts.max() <= n // world + 3
+        # pieces are contiguous along the chain (in one direction or the other)
+        changes = np.count_nonzero(np.diff(owner))
+        assert changes == world - 1
+    hub = np.zeros(n, dtype=np.uint8)
+    hub[:5] = 1
+    owner = partition(L, n, 4, [o], hub)
+    assert (owner[:5] == 3).all()
