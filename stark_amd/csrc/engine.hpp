@@ -265,6 +265,8 @@ struct Context
 
     int64_t ndofs = 0, nbr = 0;
     DevBuf<double> u, grad, du, r, z, p, q, tmp_a, tmp_b;
+    DevBuf<double> p2;              // second buffer of the search direction (fused direction update: pcg())
+    bool no_fuse_dir = true;        // option "fuse_dir" = 1: the direction update formed inside the SpMV (k_spmv_dir; measured slower, kept as a variant)
     size_t n_elem_total = 0, hess_total = 0;
     DevBuf<double> elemE, elemH;
     DevBuf<float> elemHf;           // float pool of the lazy potentials
@@ -274,6 +276,9 @@ struct Context
     bool lazy_eval = false;         // option "lazy_eval": staged mistark_eval calls take it too (tests)
     bool lazy_active = false;       // state of the current element Hessians
     bool no_grad_gather = false;    // option "no_grad_gather": the closed-form tets accumulate their gradient with atomics (cross-check)
+    hipStream_t side_stream = nullptr;  // the contact part's pattern build overlaps the element evaluation (eval())
+    hipEvent_t side_ev[2] = {nullptr, nullptr};
+    bool no_pattern_overlap = false;  // option "no_pattern_overlap"
     int kernel_dbg = 0;             // option "kernel_dbg": measurement switches inside kernels (PotArgs::dbg)
     DevBuf<uint8_t> is_projected, active_blocks;
     bool have_hessians = false;
@@ -320,6 +325,7 @@ struct Context
     bool time_spmv = false;
     std::vector<hipEvent_t> ev;
     std::vector<hipEvent_t> pcg_ev;  // batch completion events of the PCG driver
+    std::vector<hipEvent_t> stage_ev;  // stage marks of newton_solve (GPU-side stage times without synchronising)
     double spmv_ms_sum = 0.0;
     int64_t spmv_n = 0;
 

@@ -802,11 +802,28 @@ struct DescRange  // keys [kp_off, kp_off + nn * n_elem) of one potential
     uint32_t n_pool;     // pool stride (elements per block pair)
     uint32_t lazy;       // float pool, upper block triangle (tet_pair_index)
 };
+__device__ __forceinline__ uint32_t make_desc(uint32_t kp, const DescRange* __restrict__ rg, int n_rg);
 __global__ __launch_bounds__(BLOCK) void k_make_desc(const uint32_t* __restrict__ sidx, size_t n, const DescRange* __restrict__ rg, int n_rg, uint32_t* __restrict__ desc)
 {
     const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (k >= n) return;
-    const uint32_t kp = sidx[k];
+    if (k < n) desc[k] = make_desc(sidx[k], rg, n_rg);
+}
+constexpr int DESC_TABLE_MAX = 64;
+struct DescTable
+{
+    DescRange r[DESC_TABLE_MAX];
+    int n;
+};
+__global__ __launch_bounds__(BLOCK) void k_make_desc_tab(const uint32_t* __restrict__ sidx, size_t n, DescTable tab, uint32_t* __restrict__ desc)
+{
+    __shared__ DescRange rg[DESC_TABLE_MAX];
+    for (int i = threadIdx.x; i < tab.n; i += BLOCK) rg[i] = tab.r[i];
+    __syncthreads();
+    const size_t k = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (k < n) desc[k] = make_desc(sidx[k], rg, tab.n);
+}
+__device__ __forceinline__ uint32_t make_desc(uint32_t kp, const DescRange* __restrict__ rg, int n_rg)
+{
     uint32_t d = NO_SRC;
     if (kp != NO_SRC) {
         int lo = 0, hi = n_rg - 1;  // last range with kp_off <= kp
@@ -826,7 +843,7 @@ __global__ __launch_bounds__(BLOCK) void k_make_desc(const uint32_t* __restrict_
             }
         }
     }
-    desc[k] = d;
+    return d;
 }
 constexpr int CHUNK_BLOCKS = 256;
 constexpr int DYN_SHORT_ROW = 32;  // contact rows of a node hold a handful of blocks; only the rows of rigid bodies in contact are long
@@ -1279,6 +1296,8 @@ void ensure_pattern(Context& c)
 // ======================================================================================================================
 // eval()
 // ======================================================================================================================
+static void build_pattern(Context& c, int part);
+static void build_pattern_part(Context& c, int part) { build_pattern(c, part); }
 void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs, bool lazy)
 {
     prepare(c);
@@ -1288,11 +1307,36 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         c.elemH.ensure(std::max<size_t>(c.hess_total, 1));  // (the lazy potentials' share stays untouched address space)
         c.elemHf.ensure(std::max<size_t>(c.lazy_active ? c.hf_total : 0, 16));  // (the gather reads element 0 of the pool that does not apply)
     }
+    // The contact part's sparsity pattern (about fifty small launches and three read-backs, all latency) is rebuilt whenever the contact sets
+    // changed; its inputs are final before the evaluation starts, so it runs on a side stream while this stream evaluates the elements
+    const bool overlap_pattern = mode == MISTARK_EVAL_P_G_H && c.world == 1 && c.part[1].dirty && !c.part[0].dirty && !c.no_pattern_overlap;
+    if (overlap_pattern) {
+        if (!c.side_stream) {
+            MS_CHECK(hipStreamCreateWithFlags(&c.side_stream, hipStreamNonBlocking));
+            MS_CHECK(hipEventCreateWithFlags(&c.side_ev[0], hipEventDisableTiming));
+            MS_CHECK(hipEventCreateWithFlags(&c.side_ev[1], hipEventDisableTiming));
+        }
+        MS_CHECK(hipEventRecord(c.side_ev[0], c.stream));  // (the contact tables were written on this stream)
+    }
     if (mode != MISTARK_EVAL_P) {
         MS_CHECK(hipMemsetAsync(c.grad.p, 0, (size_t)c.ndofs * sizeof(double), c.stream));
         if (c.n_hot > 0) MS_CHECK(hipMemsetAsync(c.grad_hot.p, 0, (size_t)HOT_WAYS * 3 * c.n_hot * sizeof(double), c.stream));
     }
     for (auto& P : c.pots) launch_eval_kind(c, P, mode);
+    if (overlap_pattern) {
+        MS_CHECK(hipStreamWaitEvent(c.side_stream, c.side_ev[0], 0));
+        hipStream_t main_stream = c.stream;
+        c.stream = c.side_stream;  // (everything build_pattern launches and reads back goes through c.stream)
+        try {
+            build_pattern_part(c, 1);
+        } catch (...) {
+            c.stream = main_stream;
+            throw;
+        }
+        c.stream = main_stream;
+        MS_CHECK(hipEventRecord(c.side_ev[1], c.side_stream));
+        MS_CHECK(hipStreamWaitEvent(c.stream, c.side_ev[1], 0));
+    }
     if (mode != MISTARK_EVAL_P && c.n_hot > 0)
         hipLaunchKernelGGL(k_fold_hot, dim3(grid_for(3 * (int64_t)c.n_hot)), dim3(BLOCK), 0, c.stream, (const double*)c.grad_hot.p, (const int32_t*)c.hot_rows.p, c.n_hot, c.grad.p);
     if (mode == MISTARK_EVAL_P_G_H) {
@@ -1785,12 +1829,14 @@ __global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restric
                                                         const int32_t* __restrict__ lrow, int n_own)
 {
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= nbr) return;
-    const double m = fmax(fabs(grad[3 * r]), fmax(fabs(grad[3 * r + 1]), fabs(grad[3 * r + 2])));
-    const bool act = m >= thr;
-    active[r] = act ? 1 : 0;
-    const bool own = !lrow || (lrow[r] >= 0 && lrow[r] < n_own);
-    if (!act && own) atomicAdd((unsigned long long*)&counters[2], 1ull);
+    const bool in = r < nbr;
+    const double m = in ? fmax(fabs(grad[3 * r]), fmax(fabs(grad[3 * r + 1]), fabs(grad[3 * r + 2]))) : 0.0;
+    const bool act = !in || m >= thr;
+    if (in) active[r] = act ? 1 : 0;
+    const bool own = in && (!lrow || (lrow[r] >= 0 && lrow[r] < n_own));
+    // (one atomic per wavefront: 172 k atomics on one address took 34 us)
+    const unsigned long long inactive = __ballot(!act && own);
+    if ((threadIdx.x & 63) == 0 && inactive) atomicAdd((unsigned long long*)&counters[2], (unsigned long long)__popcll(inactive));
 }
 
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active, int64_t* n_projected_now,
@@ -2159,10 +2205,17 @@ static void make_descriptors(Context& c, int part)
     }
     if (c.hess_total / 9 > DESC_MASK || c.hf_total / 9 > DESC_MASK) throw Error("element-Hessian pool too large for the gather descriptors");
     m.sorted_desc.ensure(m.n_keys);
-    c.src_ranges.ensure(std::max<size_t>(rg.size(), 1) * sizeof(DescRange));
-    if (!rg.empty()) MS_CHECK(hipMemcpyAsync(c.src_ranges.p, rg.data(), rg.size() * sizeof(DescRange), hipMemcpyHostToDevice, c.stream));
-    hipLaunchKernelGGL(k_make_desc, dim3(grid_for((int64_t)m.n_keys)), dim3(BLOCK), 0, c.stream, m.sorted_src, m.n_keys, (const DescRange*)c.src_ranges.p, (int)rg.size(), m.sorted_desc.p);
-    MS_CHECK(hipStreamSynchronize(c.stream));  // rg is a temporary
+    if (rg.size() <= (size_t)DESC_TABLE_MAX) {  // the table travels in the kernel arguments: no copy, no synchronisation
+        DescTable tab{};
+        tab.n = (int)rg.size();
+        for (size_t i = 0; i < rg.size(); i++) tab.r[i] = rg[i];
+        hipLaunchKernelGGL(k_make_desc_tab, dim3(grid_for((int64_t)m.n_keys)), dim3(BLOCK), 0, c.stream, m.sorted_src, m.n_keys, tab, m.sorted_desc.p);
+    } else {
+        c.src_ranges.ensure(rg.size() * sizeof(DescRange));
+        MS_CHECK(hipMemcpyAsync(c.src_ranges.p, rg.data(), rg.size() * sizeof(DescRange), hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(k_make_desc, dim3(grid_for((int64_t)m.n_keys)), dim3(BLOCK), 0, c.stream, m.sorted_src, m.n_keys, (const DescRange*)c.src_ranges.p, (int)rg.size(), m.sorted_desc.p);
+        MS_CHECK(hipStreamSynchronize(c.stream));  // rg is a temporary
+    }
     m.desc_lazy = c.lazy_active ? 1 : 0;
 }
 void assemble(Context& c)
@@ -2230,10 +2283,62 @@ __device__ __forceinline__ double dpp_row_shr(double v)
 // x gather, the nine float -> double conversions and FMAs of the reference (BlockedSparseMatrix.h:986-1138), then a segmented inclusive
 // scan over the 64 lanes (DPP row shifts + three scalar carries, no LDS) whose row-end lanes write y; a row that continues into the next
 // tile of the chunk is carried in registers. Every row is written exactly once: no atomics, no zero fill, deterministic.
-template <int V>
+// What the SpMV multiplies with. XPlain: a vector in memory. XDir: the PCG's search direction p = z + beta p_old computed on the fly, so that
+// the direction update needs no kernel of its own (k_pcg_dir: one launch, one dependent-kernel boundary and 12 MB of vector traffic per
+// iteration at 1M tets); the lane that finishes a row also stores p[row] for k_pcg_step and the next iteration. MEASURED (configs[3],
+// profiles/r02_v2_fuse_dir_kernel_stats.txt): the second gathered vector costs the SpMV 8 us (23.9 -> 32), more than the 7.3 us kernel it
+// replaces (1.40 instead of 1.32 ms per solve); identical iteration counts. Kept as option "fuse_dir" and as a cross-check of the solver.
+struct XPlain
+{
+    const double* x;
+    const double* pd;  // fused dot: sum of pd[row] . y[row] (nullptr: none)
+    __device__ __forceinline__ void load(size_t c3, double& x0, double& x1, double& x2) const
+    {
+        x0 = x[c3];
+        x1 = x[c3 + 1];
+        x2 = x[c3 + 2];
+    }
+    __device__ __forceinline__ bool has_dot() const { return pd != nullptr; }
+    __device__ __forceinline__ double row_dot(size_t r3, double y0, double y1, double y2) const { return pd[r3] * y0 + pd[r3 + 1] * y1 + pd[r3 + 2] * y2; }
+};
+struct XDir
+{
+    const double* z;
+    const double* pold;
+    double* pnew;
+    double beta;
+    __device__ __forceinline__ void load(size_t c3, double& x0, double& x1, double& x2) const
+    {
+        x0 = z[c3] + beta * pold[c3];
+        x1 = z[c3 + 1] + beta * pold[c3 + 1];
+        x2 = z[c3 + 2] + beta * pold[c3 + 2];
+    }
+    __device__ __forceinline__ bool has_dot() const { return true; }
+    // the row's own entries of p: stored (every block row ends in exactly one lane of the static part), and p[row] . y[row] for p.Ap
+    __device__ __forceinline__ double row_dot(size_t r3, double y0, double y1, double y2) const
+    {
+        double p0, p1, p2;
+        load(r3, p0, p1, p2);
+        pnew[r3] = p0;
+        pnew[r3 + 1] = p1;
+        pnew[r3 + 2] = p2;
+        return p0 * y0 + p1 * y1 + p2 * y2;
+    }
+    // (contact part: its rows are stored by the static part; here only the product is needed)
+    __device__ __forceinline__ double row_dot_nostore(size_t r3, double y0, double y1, double y2) const
+    {
+        double p0, p1, p2;
+        load(r3, p0, p1, p2);
+        return p0 * y0 + p1 * y1 + p2 * y2;
+    }
+};
+__device__ __forceinline__ double row_dot_nostore(const XPlain& X, size_t r3, double y0, double y1, double y2) { return X.row_dot(r3, y0, y1, y2); }
+__device__ __forceinline__ double row_dot_nostore(const XDir& X, size_t r3, double y0, double y1, double y2) { return X.row_dot_nostore(r3, y0, y1, y2); }
+
+template <int V, class XS>
 __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nblk, const float* __restrict__ vals, const uint32_t* __restrict__ scol,
-                                                    const int32_t* __restrict__ tile_first_row, int64_t n_chunks, const int chunk_tiles, const double* __restrict__ x,
-                                                    double* __restrict__ y, const double* __restrict__ pdot, double* __restrict__ partials)
+                                                    const int32_t* __restrict__ tile_first_row, int64_t n_chunks, const int chunk_tiles, const XS X,
+                                                    double* __restrict__ y, double* __restrict__ partials)
 {
     __shared__ double sm[4];
     const int lane = threadIdx.x & 63;
@@ -2253,7 +2358,8 @@ __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nbl
             const float4 a = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[lane], b = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[64 + lane];
             const float cc = (V == 3) ? 1.f : vals[(size_t)t * 576 + 512 + lane];
             const size_t c3 = 3 * (size_t)(w & 0x7fffffffu);
-            const double x0 = x[c3], x1 = x[c3 + 1], x2 = x[c3 + 2];
+            double x0, x1, x2;
+            X.load(c3, x0, x1, x2);
             double y0 = (double)a.x * x0 + (double)a.y * x1 + (double)a.z * x2;
             double y1 = (double)a.w * x0 + (double)b.x * x1 + (double)b.y * x2;
             double y2 = (double)b.z * x0 + (double)b.w * x1 + (double)cc * x2;
@@ -2298,10 +2404,7 @@ __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nbl
                 yr[0] = y0;
                 yr[1] = y1;
                 yr[2] = y2;
-                if (pdot) {
-                    const double* pr = pdot + 3 * (size_t)row;
-                    acc += pr[0] * y0 + pr[1] * y1 + pr[2] * y2;
-                }
+                if (X.has_dot()) acc += X.row_dot(3 * (size_t)row, y0, y1, y2);
             }
         }
     }
@@ -2311,9 +2414,10 @@ __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nbl
     }
 }
 // Rows longer than a chunk (a rigid body attached to very many points): stored after the chunks, one wavefront per row.
+template <class XS>
 __device__ __forceinline__ void spmv_long_rows(const int bid, const int nblk, const float* __restrict__ vals, const uint32_t* __restrict__ scol, const uint32_t* __restrict__ list,
-                                               int n_list, const int64_t* __restrict__ row_ptr, const uint64_t* __restrict__ row_pos, const double* __restrict__ x,
-                                               double* __restrict__ y, const double* __restrict__ pdot, double* __restrict__ partials)
+                                               int n_list, const int64_t* __restrict__ row_ptr, const uint64_t* __restrict__ row_pos, const XS X, double* __restrict__ y,
+                                               double* __restrict__ partials)
 {
     __shared__ double sm[4];
     const int lane = threadIdx.x & 63;
@@ -2331,7 +2435,8 @@ __device__ __forceinline__ void spmv_long_rows(const int bid, const int nblk, co
             const float4 qa = reinterpret_cast<const float4*>(tv)[l];
             const float4 qb = reinterpret_cast<const float4*>(tv)[64 + l];
             const float cc = tv[512 + l];
-            const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
+            double x0, x1, x2;
+            X.load(3 * col, x0, x1, x2);
             a0 += (double)qa.x * x0 + (double)qa.y * x1 + (double)qa.z * x2;
             a1 += (double)qa.w * x0 + (double)qb.x * x1 + (double)qb.y * x2;
             a2 += (double)qb.z * x0 + (double)qb.w * x1 + (double)cc * x2;
@@ -2344,10 +2449,7 @@ __device__ __forceinline__ void spmv_long_rows(const int bid, const int nblk, co
             yr[0] = a0;
             yr[1] = a1;
             yr[2] = a2;
-            if (pdot) {
-                const double* pr = pdot + 3 * (size_t)r;
-                acc += pr[0] * a0 + pr[1] * a1 + pr[2] * a2;
-            }
+            if (X.has_dot()) acc += X.row_dot(3 * (size_t)r, a0, a1, a2);
         }
     }
     if (partials) {
@@ -2380,8 +2482,8 @@ struct DynPart  // the contact part as the fused SpMV kernel sees it
     int64_t n_chunks;
     int64_t n_rows;
 };
-__device__ __forceinline__ void spmv_chunks(const int bid, const int nblk, const DynPart& d, const double* __restrict__ x, const double* __restrict__ pdot,
-                                            double* __restrict__ partials)
+template <class XS>
+__device__ __forceinline__ void spmv_chunks(const int bid, const int nblk, const DynPart& d, const XS X, double* __restrict__ partials)
 {
     // These few workgroups run beside thousands of static-part wavefronts that saturate the memory system, where every dependent load
     // costs 1.5-2 us: their chains must be short or they become the critical path of the whole launch (measured: +4.5 us with one lane
@@ -2405,7 +2507,8 @@ __device__ __forceinline__ void spmv_chunks(const int bid, const int nblk, const
                 const float4 qa = reinterpret_cast<const float4*>(tv)[l];
                 const float4 qb = reinterpret_cast<const float4*>(tv)[64 + l];
                 const float cc = tv[512 + l];
-                const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
+                double x0, x1, x2;
+                X.load(3 * col, x0, x1, x2);
                 a0 += (double)qa.x * x0 + (double)qa.y * x1 + (double)qa.z * x2;
                 a1 += (double)qa.w * x0 + (double)qb.x * x1 + (double)qb.y * x2;
                 a2 += (double)qb.z * x0 + (double)qb.w * x1 + (double)cc * x2;
@@ -2418,10 +2521,7 @@ __device__ __forceinline__ void spmv_chunks(const int bid, const int nblk, const
                 out[0] = a0;
                 out[1] = a1;
                 out[2] = a2;
-                if (pdot) {
-                    const size_t rg = (size_t)d.rowmap[r];
-                    dot += pdot[3 * rg] * a0 + pdot[3 * rg + 1] * a1 + pdot[3 * rg + 2] * a2;
-                }
+                if (X.has_dot()) dot += row_dot_nostore(X, 3 * (size_t)d.rowmap[r], a0, a1, a2);
             }
         }
     } else {
@@ -2439,7 +2539,8 @@ __device__ __forceinline__ void spmv_chunks(const int bid, const int nblk, const
                     const float4 qa = reinterpret_cast<const float4*>(tv)[l];
                     const float4 qb = reinterpret_cast<const float4*>(tv)[64 + l];
                     const float cc = tv[512 + l];
-                    const double x0 = x[3 * col], x1 = x[3 * col + 1], x2 = x[3 * col + 2];
+                    double x0, x1, x2;
+                    X.load(3 * col, x0, x1, x2);
                     a0 += (double)qa.x * x0 + (double)qa.y * x1 + (double)qa.z * x2;
                     a1 += (double)qa.w * x0 + (double)qb.x * x1 + (double)qb.y * x2;
                     a2 += (double)qb.z * x0 + (double)qb.w * x1 + (double)cc * x2;
@@ -2453,10 +2554,7 @@ __device__ __forceinline__ void spmv_chunks(const int bid, const int nblk, const
                 out[0] = a0;
                 out[1] = a1;
                 out[2] = a2;
-                if (pdot) {
-                    const size_t rg = (size_t)d.rowmap[r];
-                    dot += pdot[3 * rg] * a0 + pdot[3 * rg + 1] * a1 + pdot[3 * rg + 2] * a2;
-                }
+                if (X.has_dot()) dot += row_dot_nostore(X, 3 * (size_t)d.rowmap[r], a0, a1, a2);
             }
         }
     }
@@ -2507,9 +2605,75 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_fused(int g0, int gr, int g1, St
 {
     if (ctrl && ctrl->done) return;
     const int b = (int)blockIdx.x;
-    if (b < g1) spmv_chunks(b, g1, d, x, pdot, partials ? partials + g0 + gr : nullptr);
-    else if (b < g1 + gr) spmv_long_rows(b - g1, gr, m.vals, m.scol, m.long_rows, m.n_long_rows, m.row_ptr, m.row_pos, x, y, pdot, partials ? partials + g0 : nullptr);
-    else spmv_chunked_static<V>(b - g1 - gr, g0, m.vals, m.scol, m.tile_first_row, m.n_chunks, m.chunk_tiles, x, y, pdot, partials);
+    const XPlain X{x, pdot};
+    if (b < g1) spmv_chunks(b, g1, d, X, partials ? partials + g0 + gr : nullptr);
+    else if (b < g1 + gr) spmv_long_rows(b - g1, gr, m.vals, m.scol, m.long_rows, m.n_long_rows, m.row_ptr, m.row_pos, X, y, partials ? partials + g0 : nullptr);
+    else spmv_chunked_static<V>(b - g1 - gr, g0, m.vals, m.scol, m.tile_first_row, m.n_chunks, m.chunk_tiles, X, y, partials);
+}
+// The PCG's iteration k as the solver launches it: what k_pcg_dir did for iteration k-1 (sums of r.r and r.z, convergence test, beta) in the
+// prologue of every workgroup (all of them compute the same numbers from the same partial sums; workgroup 0 records them), then
+// q = A p with p = z + beta p_old formed on the fly and stored by the lanes that finish a row.
+struct DirArgs
+{
+    const double* z;
+    const double* pold;
+    double* pnew;
+    const double* part_rr;
+    const double* part_rz;
+    int nparts, k;
+    double abs_tol, rel_tol;
+};
+// convergence test and beta from the partial sums step k-1 left; returns false when the solve is over (and records why)
+__device__ __forceinline__ bool pcg_direction(const DirArgs& a, PcgCtrl* __restrict__ ctrl, double* sm, double& beta)
+{
+    const int done = ctrl->done;
+    if (done == 1) return false;
+    if (done == 2) {  // indefiniteness stop decided in k_pcg_step of the previous iteration
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->done = 1;
+        return false;
+    }
+    beta = 0.0;
+    if (a.k == 1) return true;  // p_1 = z_0
+    const int kp = a.k - 1;     // the iteration whose step left the partial sums
+    const double rr = sum_partials(a.part_rr, a.nparts, sm);
+    const double rz_new = sum_partials(a.part_rz, a.nparts, sm);
+    const double error = sqrt(rr / ctrl->bb);
+    const bool conv = error < a.abs_tol || error / 1.0 < a.rel_tol;  // error_0 = 1 for x0 = 0
+    if (conv) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctrl->error = error;
+            ctrl->n_iter = kp;
+            ctrl->converged = 1;
+            ctrl->done = 1;
+        }
+        return false;
+    }
+    beta = rz_new / ctrl->rz[kp & 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctrl->rz[(kp + 1) & 1] = rz_new;
+        ctrl->error = error;
+        ctrl->n_iter = kp;
+    }
+    return true;
+}
+__global__ __launch_bounds__(BLOCK) void k_spmv_dir(int g0, int gr, int g1, StaticPart m, DynPart d, DirArgs a, double* __restrict__ y, double* __restrict__ partials,
+                                                   PcgCtrl* __restrict__ ctrl)
+{
+    __shared__ double sm[4];
+    double beta;
+    if (!pcg_direction(a, ctrl, sm, beta)) return;
+    const int b = (int)blockIdx.x;
+    const XDir X{a.z, a.pold, a.pnew, beta};
+    if (b < g1) spmv_chunks(b, g1, d, X, partials + g0 + gr);
+    else if (b < g1 + gr) spmv_long_rows(b - g1, gr, m.vals, m.scol, m.long_rows, m.n_long_rows, m.row_ptr, m.row_pos, X, y, partials + g0);
+    else spmv_chunked_static<0>(b - g1 - gr, g0, m.vals, m.scol, m.tile_first_row, m.n_chunks, m.chunk_tiles, X, y, partials);
+}
+// the same test at the end of a batch of iterations (the host looks at the control block there)
+__global__ __launch_bounds__(BLOCK) void k_pcg_check(DirArgs a, PcgCtrl* __restrict__ ctrl)
+{
+    __shared__ double sm[4];
+    double beta;
+    (void)pcg_direction(a, ctrl, sm, beta);
 }
 __global__ __launch_bounds__(BLOCK) void k_spmv_combine(int64_t nbr, const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0,
                                                        const double* __restrict__ yd, const double* __restrict__ chunk_partial, double* __restrict__ y)
@@ -2542,6 +2706,22 @@ static int launch_spmv(Context& c, const double* x, double* y, const double* pdo
     if (g1 > 0 && combine)
         hipLaunchKernelGGL(k_spmv_combine, dim3(grid_for(c.mrows())), dim3(BLOCK), 0, c.stream, c.mrows(), (const int32_t*)m1.crow_of_row.p, (const uint32_t*)m1.row_chunk0.p,
                            (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, y);
+    return g0 + gr + g1;
+}
+static int launch_spmv_dir(Context& c, const DirArgs& a, double* y, double* partials)
+{
+    const BsrPart& m0 = c.part[0];
+    BsrPart& m1 = c.part[1];
+    const int g0 = spmv_grid(c, m0.n_chunks_static, MAX_PARTIALS / 2);
+    const int gr = std::min(((m0.n_long_rows + 3) / 4 + 7) / 8 * 8, MAX_PARTIALS / 4);
+    const StaticPart sp{m0.vals.p, m0.scol.p, m0.tile_first_row.p, m0.long_rows.p, m0.row_ptr.p, m0.row_pos.p, m0.n_chunks_static, m0.n_long_rows, m0.chunk_tiles};
+    DynPart d{};
+    int g1 = 0;
+    if (m1.nnzb > 0) {
+        g1 = (int)std::min<int64_t>(((m1.n_chunks + 3) / 4 + (m1.n_rows + BLOCK / 4 - 1) / (BLOCK / 4) + 7) / 8 * 8, MAX_PARTIALS / 4);
+        d = DynPart{m1.vals.p, m1.colw.p, m1.row_ptr.p, m1.row_chunk0.p, m1.chunk_row.p, m1.rowmap.p, m1.yd.p, m1.chunk_partial.p, m1.n_chunks, m1.n_rows};
+    }
+    hipLaunchKernelGGL(k_spmv_dir, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, a, y, partials, c.ctrl.p);
     return g0 + gr + g1;
 }
 // reference point for the micro-benchmark (variant 9): a plain grid-stride float4 read of the matrix values, i.e. what streaming the
@@ -2832,6 +3012,13 @@ static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, do
     }
 }
 
+__global__ void k_copy_ctrl(const PcgCtrl* __restrict__ src, PcgCtrl* __restrict__ dst_host)
+{
+    if (threadIdx.x == 0) {
+        *dst_host = *src;
+        __threadfence_system();
+    }
+}
 // SpMV timing inside the solver: every SPMV_SAMPLE-th launch is bracketed by a pair of pooled HIP events on the engine's stream
 constexpr int SPMV_SAMPLE = 8;
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
@@ -2849,7 +3036,10 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     double* part_rr = c.partials.p + MAX_PARTIALS;
     double* part_rz = c.partials.p + 2 * MAX_PARTIALS;
     double* part_bb = c.partials.p + 3 * MAX_PARTIALS;
-    hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(BLOCK), 0, c.stream, rhs_dev, c.dinv.p, c.nbr, c.du.p, c.r.p, c.z.p, c.p.p, part_bb, part_rz);
+    const bool fuse_dir = !c.no_fuse_dir;
+    c.p2.ensure((size_t)c.ndofs);
+    // (fused: iteration 1 reads p_0 = buffer 0 with beta = 0; k_pcg_init leaves z there, so 0 * p_0 is finite)
+    hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(BLOCK), 0, c.stream, rhs_dev, c.dinv.p, c.nbr, c.du.p, c.r.p, c.z.p, fuse_dir ? c.p2.p : c.p.p, part_bb, part_rz);
     hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, part_bb, part_rz, gv, abs_tol, c.ctrl.p, 1);
     // Iterations are launched in batches of PCG_BATCH; after each batch the control block is copied to a pinned slot and an
     // event recorded. The host launches batch b+1 BEFORE it waits for batch b's event, so the GPU never idles on the host's
@@ -2877,17 +3067,30 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
                 }
                 MS_CHECK(hipEventRecord(c.ev[e0], c.stream));
             }
-            const int gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false);
+            // p_k = z + beta p_{k-1} lives in buffer k & 1 (the SpMV forms it on the fly and stores it)
+            double* pk = (k & 1) ? c.p.p : c.p2.p;
+            const double* pprev = (k & 1) ? c.p2.p : c.p.p;
+            int gs;
+            if (fuse_dir) {
+                gs = launch_spmv_dir(c, DirArgs{c.z.p, pprev, pk, part_rr, part_rz, gv, k, abs_tol, rel_tol}, c.q.p, part_pq);
+            } else {
+                pk = c.p.p;
+                gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false);
+            }
             if (sample) {
                 MS_CHECK(hipEventRecord(c.ev[e0 + 1], c.stream));
                 sampled[slot].push_back(k);
             }
-            hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, c.p.p, c.q.p, c.du.p, c.r.p, c.z.p, part_rr,
+            hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, (const double*)pk, c.q.p, c.du.p, c.r.p, c.z.p, part_rr,
                                part_rz, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : nullptr, (const uint32_t*)m1.row_chunk0.p, (const double*)m1.yd.p,
                                (const double*)m1.chunk_partial.p);
-            hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p, 1);
+            if (!fuse_dir) hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p, 1);
         }
-        MS_CHECK(hipMemcpyAsync(hs[slot], c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost, c.stream));
+        // (fused: the test of the batch's last iteration would only run with the next batch's first SpMV; the host reads the control block now)
+        if (fuse_dir) hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(BLOCK), 0, c.stream, DirArgs{c.z.p, nullptr, nullptr, part_rr, part_rz, gv, k_end + 1, abs_tol, rel_tol}, c.ctrl.p);
+        // the control block goes to the pinned slot through a one-wavefront kernel (a copy command sits on another engine: 4 us + a 5.6 us
+        // gap before the next batch's first kernel, every four iterations)
+        hipLaunchKernelGGL(k_copy_ctrl, dim3(1), dim3(64), 0, c.stream, (const PcgCtrl*)c.ctrl.p, hs[slot]);
         MS_CHECK(hipEventRecord(c.pcg_ev[slot], c.stream));
         return k_end;
     };
@@ -2933,9 +3136,15 @@ Context::~Context()
     contact_destroy(contact);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : pcg_ev) (void)hipEventDestroy(e);
+    for (auto e : stage_ev) (void)hipEventDestroy(e);
     if (h_scratch) (void)hipHostFree(h_scratch);
     if (h_pin) (void)hipHostFree(h_pin);
     if (pub) (void)hipHostFree(pub);
+    if (side_stream) {
+        (void)hipStreamDestroy(side_stream);
+        (void)hipEventDestroy(side_ev[0]);
+        (void)hipEventDestroy(side_ev[1]);
+    }
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
 }
 

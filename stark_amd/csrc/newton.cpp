@@ -20,12 +20,45 @@ struct Timer
     explicit Timer(double& a) : acc(a), t0(std::chrono::steady_clock::now()) {}
     ~Timer() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
 };
+// GPU-side stage times without synchronising: mark(stage) records an event on the engine's stream ("from here on the queued work
+// belongs to `stage`"); collect() runs after the solve's final synchronisation and adds the time between consecutive marks to the stage
+// of the earlier one. (Host timers around asynchronous launches would charge a stage's GPU time to whoever synchronises next; the
+// earlier version synchronised after every stage instead, which left the GPU idle while the host prepared the next one.)
+enum Stage { ST_EVAL_PGH, ST_EVAL_P, ST_ASSEMBLY, ST_PROJECT, ST_SOLVE, ST_OTHER, ST_COUNT };
+struct GpuStages
+{
+    Context& c;
+    std::vector<std::pair<int, size_t>> marks;
+    size_t used = 0;
+    explicit GpuStages(Context& ctx) : c(ctx) {}
+    void mark(int stage)
+    {
+        if (used == c.stage_ev.size()) {
+            hipEvent_t e;
+            MS_CHECK(hipEventCreate(&e));
+            c.stage_ev.push_back(e);
+        }
+        MS_CHECK(hipEventRecord(c.stage_ev[used], c.stream));
+        marks.emplace_back(stage, used++);
+    }
+    void collect(double* seconds /*[ST_COUNT]*/)
+    {
+        if (marks.empty()) return;
+        MS_CHECK(hipEventSynchronize(c.stage_ev[marks.back().second]));
+        for (size_t i = 0; i + 1 < marks.size(); i++) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c.stage_ev[marks[i].second], c.stage_ev[marks[i + 1].second]) == hipSuccess) seconds[marks[i].first] += 1e-3 * ms;
+        }
+    }
+};
 }  // namespace
 
 int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_newton_callbacks* cb, mistark_newton_stats& st)
 {
     Timer t_total(st.t_total);
     prepare(c);
+    GpuStages gs(c);
+    double stage_s[ST_COUNT] = {0, 0, 0, 0, 0, 0};
     const int64_t ndofs = c.ndofs;
     auto sync = [&]() { MS_CHECK(hipStreamSynchronize(c.stream)); };
     auto call_void = [&](void (*f)(void*)) {
@@ -61,12 +94,13 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
         call_void(cb ? cb->before_energy_evaluation : nullptr);
         double residual = 0.0;
         {
-            Timer t(st.t_eval_pgh);
+            gs.mark(ST_EVAL_PGH);
             // default residual: ||grad||_inf (solver_utils.h:28), read back with the energy. Progressive / no projection never reads the
             // double blocks of an element it does not project: the closed-form tets write float blocks only (eval: lazy)
             const bool lazy = c.lazy_allowed && (s.projection_mode == MISTARK_PROJ_PROGRESSIVE || s.projection_mode == MISTARK_PROJ_NEWTON) && s.linear_solver != MISTARK_SOLVER_DIRECT_LLT;
             eval(c, MISTARK_EVAL_P_G_H, &E0, nullptr, &residual, lazy);
             st.n_evaluations++;
+            gs.mark(ST_OTHER);
         }
         if (it == 0) res_0 = residual;
         if (!std::isfinite(residual) || !std::isfinite(E0)) {
@@ -97,14 +131,13 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
             // ---- _project_and_assemble ------------------------------------------------------------------------
             bool all_projected = false;
             if (s.projection_mode == MISTARK_PROJ_PROGRESSIVE && !assembled) {
-                Timer t(st.t_assembly);
+                gs.mark(ST_ASSEMBLY);
                 assemble(c);
-                MS_CHECK(hipStreamSynchronize(c.stream));  // stage timers measure GPU work, not launch time (the next stage synchronises anyway)
                 assembled = true;
             }
             bool reassemble = !assembled;  // projections performed after assembly update the matrix in place (update_global)
             {
-                Timer t(st.t_project);
+                gs.mark(ST_PROJECT);
                 switch (s.projection_mode) {
                     case MISTARK_PROJ_NEWTON: break;
                     case MISTARK_PROJ_PROJECTED_NEWTON: {
@@ -132,17 +165,16 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                     default: throw Error("unknown projection mode");
                 }
             }
-            if (reassemble || !c.matrix_current) {  // (sharded runs: a projection round too large for the delta exchange asks for this)
-                Timer t(st.t_assembly);
+            if (reassemble || !c.matrix_current) {
+                gs.mark(ST_ASSEMBLY);
                 assemble(c);
-                MS_CHECK(hipStreamSynchronize(c.stream));  // stage timers measure GPU work, not launch time (the next stage synchronises anyway)
                 assembled = true;
             }
 
             // ---- _solve_linear_system ---------------------------------------------------------------------------
             mistark_pcg_info info{};
             {
-                Timer t(st.t_linear_solve);
+                gs.mark(ST_SOLVE);
                 const double forcing = std::min(1e-2, residual * std::min(0.5, std::sqrt(residual)));
                 const double abs_tol = std::max(forcing, s.cg_abs_tolerance);
                 vec_neg(c, c.tmp_a.p, c.grad.p, ndofs);
@@ -150,6 +182,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                 else pcg(c, c.tmp_a.p, abs_tol, s.cg_rel_tolerance, s.cg_max_iterations, s.cg_stop_on_indefiniteness, &info);
                 st.cg_iterations += info.n_iterations;
                 st.n_linear_solves++;
+                gs.mark(ST_OTHER);
             }
             const bool ok = info.converged != 0;
             const bool can_project_more = (s.projection_mode != MISTARK_PROJ_NEWTON) && !all_projected;
@@ -236,9 +269,10 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                 for (; k < s.max_backtracking_armijo_iterations; ++k) {
                     call_void(cb ? cb->before_energy_evaluation : nullptr);
                     {
-                        Timer t(st.t_eval_p);
+                        gs.mark(ST_EVAL_P);
                         eval(c, MISTARK_EVAL_P, &E1, nullptr);
                         st.n_evaluations++;
+                        gs.mark(ST_OTHER);
                     }
                     if (E1 < E_threshold) break;
                     step *= 0.5;
@@ -263,7 +297,14 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
     }
     st.newton_iterations = it;
     if (st.n_hessians > 0) st.projected_hessians_ratio = (double)st.n_projected_hessians / (double)st.n_hessians;
+    gs.mark(ST_OTHER);
     sync();
+    gs.collect(stage_s);
+    st.t_eval_pgh += stage_s[ST_EVAL_PGH];
+    st.t_eval_p += stage_s[ST_EVAL_P];
+    st.t_assembly += stage_s[ST_ASSEMBLY];
+    st.t_project += stage_s[ST_PROJECT];
+    st.t_linear_solve += stage_s[ST_SOLVE];
     return result;
 }
 

@@ -319,3 +319,26 @@ def test_lazy_hessian_path_matches_full(name):
     assert a[4][0] > 0
     assert np.abs(b[3] - a[3]).max() <= 64 * eps32 * scale
     assert np.abs(b[5] - a[5]).max() <= 64 * eps32 * scale
+
+
+@pytest.mark.parametrize("name", ["tetbeam_softrubber_6x2x2", "contactmix_t1", "rbchain"])
+def test_pcg_fused_direction_variant(name):
+    """Option fuse_dir: the search direction p = z + beta p formed inside the SpMV instead of by k_pcg_dir (a measured-slower variant kept as a
+    cross-check of the solver's control flow): same iteration count, same solution."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    out = []
+    for fuse in (0, 1):
+        eng = engine_from_problem(prob, man)
+        eng.set_option("fuse_dir", fuse)
+        eng.eval(capi.EVAL_P_G_H)
+        eng.assemble()
+        x, info = eng.pcg(man["pcg"]["abs_tol"])
+        x2, info2 = eng.pcg(1e-10, 1e-9, 7)      # stops at the iteration cap: the last test runs without a following SpMV
+        out.append((x, info.n_iterations, info.converged, x2, info2.n_iterations, info2.converged))
+        eng.close()
+    a, b = out
+    assert a[1] == b[1] and a[2] == b[2] and a[4] == b[4] and a[5] == b[5]
+    assert _rel(b[0], a[0]) < 1e-12 and _rel(b[3], a[3]) < 1e-12
