@@ -186,6 +186,12 @@ int mistark_sim_get_info(mistark_sim* sim, mistark_sim_info* info);
 int mistark_sim_get_points(mistark_sim* sim, int which, double* out);
 /* writes x0 / v0 (which: 1, 2) from the caller's buffer and uploads the state */
 int mistark_sim_set_points(mistark_sim* sim, int which, const double* in);
+/* The part of a time step before the Newton solve (Stark.cpp:145-156: before_time_step callbacks = friction tables at the start-of-step
+ * geometry, rigid-body caches, v1 = 0) and the Newton callback that precedes every evaluation (contact tables at the current DoFs), as
+ * separate calls: what the reference's harness does to take a stage snapshot at a given state (callbacks->run_before_time_step();
+ * set_dofs; newton->run_before_energy_evaluation()). */
+int mistark_sim_begin_time_step(mistark_sim* sim);
+int mistark_sim_before_energy_evaluation(mistark_sim* sim);
 /* the engine context (valid after the first step or after mistark_sim_prepare) */
 int mistark_sim_prepare(mistark_sim* sim);
 mistark_ctx* mistark_sim_engine(mistark_sim* sim);

@@ -1080,6 +1080,96 @@ int main(int argc, char** argv)
         dump_snapshot(sc, a.s("out", "/tmp/mistark_fixture"), a);
         return 0;
     }
+    if (mode == "slimdump") {
+        // Stage outputs of the reference at FULL size (BASELINE configs at their own sizes), at a state anyone can reproduce without the
+        // evaluator inputs: after `steps` time steps (0: the initial configuration), start the next step by hand, set every velocity DoF to the
+        // closed-form perturbation u_i = amp sin(1.3 i + 0.7), refresh the contact tables, and record: E, the whole gradient, its max
+        // norm, per-potential element counts and energies, the connectivity tables of the contact / friction potentials (= the contact
+        // sets), the pattern size, the SpMV probe y = A sin(0.37 i), and the PCG outcome at the Newton forcing tolerance.
+        const std::string dir = a.s("out", "/tmp/mistark_slim");
+        fs::create_directories(dir);
+        for (int s = 0; s < steps; s++) sc.step();
+        {
+            // grid scenes start with exactly parallel edges, where the edge-edge classification of the (lagged, start-of-step) friction
+            // tables hangs on the orientation of the collision edges, i.e. on find_surface's hash order: a closed-form displacement of
+            // every point, x0_i[d] += xamp sin(0.9 (3 i + d) + 0.3), takes the start geometry out of that degenerate position
+            const double xamp = a.d("xamp", 0.0);
+            auto& ps = *sc.sim->deformables->point_sets;
+            if (xamp != 0.0)
+                for (int i = 0; i < (int)ps.size(); i++)
+                    for (int d = 0; d < 3; d++) ps.x0.data[(size_t)i][d] += xamp * std::sin(0.9 * (3.0 * i + d) + 0.3);
+        }
+        st.callbacks->run_before_time_step();
+        auto gp = st.global_potential;
+        const int ndofs = gp->get_total_n_dofs();
+        {
+            std::vector<double> u(ndofs);
+            const double amp = a.d("amp", 0.01);
+            for (int i = 0; i < ndofs; i++) u[i] = amp * std::sin(1.3 * i + 0.7);
+            gp->set_dofs(u.data());
+        }
+        st.callbacks->newton->run_before_energy_evaluation();
+        std::ostringstream man;
+        man.precision(17);
+        man << "{\"scene\":" << sc.json << ",\"dt\":" << st.dt << ",\"ndofs\":" << ndofs << ",\"amp\":" << a.d("amp", 0.01) << ",\"xamp\":" << a.d("xamp", 0.0) << ",\"steps\":" << steps << ",\n\"potentials\":[";
+        const auto& potentials = gp->get_potentials();
+        for (int pi = 0; pi < (int)potentials.size(); pi++) {
+            const symx::Potential& pot = *potentials[pi];
+            auto mws = pot.get_mws();
+            const int n_elem = mws->conn.n_elements();
+            const std::string nm = pot.get_name();
+            man << (pi ? "," : "") << "{\"name\":" << jstr(nm) << ",\"n_elem\":" << n_elem << ",\"conn_stride\":" << mws->conn.stride << "}";
+            if (n_elem > 0 && (nm.find("contact_") == 0 || nm.find("friction_") == 0))
+                npy_i32(dir + "/t_" + nm + ".npy", mws->conn.data(), { (size_t)n_elem, (size_t)mws->conn.stride });
+        }
+        man << "],\n";
+        if (sc.sim->interactions && sc.sim->interactions->contact) man << "\"contact_stiffness\":" << sc.sim->interactions->contact->get_contact_stiffness() << ",\n";
+        symx::SecondOrderCompiledGlobal g(gp, st.context);
+        double E = 0.0;
+        Eigen::VectorXd grad(ndofs);
+        const int nthreads = st.context->n_threads;
+        auto eh = g.evaluate_P__dP_du__local_d2P_du2(E, grad);
+        man << "\"E\":" << E << ",\"n_hessians\":" << eh->size() << ",\"residual\":" << grad.cwiseAbs().maxCoeff() << ",\n";
+        npy_f64(dir + "/grad.npy", grad.data(), { (size_t)ndofs });
+        auto A = eh->assemble_global(nthreads, ndofs);
+        std::vector<Eigen::Triplet<double>> trip;
+        A->to_triplets(trip);
+        man << "\"nnz_scalar\":" << trip.size() << ",\n";
+        trip.clear();
+        trip.shrink_to_fit();
+        const double residual = grad.cwiseAbs().maxCoeff();
+        const double forcing = std::min(1e-2, residual * std::min(0.5, std::sqrt(residual)));
+        const double abs_tol = std::max(forcing, 1e-12);
+        A->set_preconditioner(bsm::Preconditioner::BlockDiagonal);
+        A->prepare_preconditioning(nthreads);
+        Eigen::VectorXd xin(ndofs), yout(ndofs);
+        for (int i = 0; i < ndofs; i++) xin[i] = std::sin(0.37 * i);
+        A->spmxv_from_ptr(yout.data(), xin.data(), nthreads);
+        npy_f64(dir + "/spmv_y.npy", yout.data(), { (size_t)ndofs });
+        Eigen::VectorXd du = Eigen::VectorXd::Zero(ndofs);
+        Eigen::VectorXd rhs = -grad;
+        bsm::PCGContext ctx;
+        bsm::PCGInfo info = bsm::solve_pcg(*A, du.data(), rhs.data(), ndofs, abs_tol, 1e-4, 10000, nthreads, true, ctx);
+        man << "\"pcg\":{\"abs_tol\":" << abs_tol << ",\"rel_tol\":1e-4,\"converged\":" << (info.converged ? 1 : 0) << ",\"iterations\":" << info.n_iterations
+            << ",\"error\":" << info.error << ",\"indefinite\":" << (info.found_indefiniteness ? 1 : 0) << ",\"x_dot_rhs\":" << du.dot(rhs) << ",\"x_norm\":" << du.norm() << "},\n";
+        // the same system with every element Hessian projected to PSD (project_to_PD.cpp:12-82, eps 1e-10): the solve a projected Newton step does
+        {
+            eh->project_to_PD_inplace__all(1e-10, false);
+            auto Ap = eh->assemble_global(nthreads, ndofs);
+            Ap->set_preconditioner(bsm::Preconditioner::BlockDiagonal);
+            Ap->prepare_preconditioning(nthreads);
+            Ap->spmxv_from_ptr(yout.data(), xin.data(), nthreads);
+            npy_f64(dir + "/spmv_y_proj.npy", yout.data(), { (size_t)ndofs });
+            Eigen::VectorXd dup = Eigen::VectorXd::Zero(ndofs);
+            bsm::PCGContext ctx2;
+            bsm::PCGInfo ip = bsm::solve_pcg(*Ap, dup.data(), rhs.data(), ndofs, abs_tol, 1e-4, 10000, nthreads, true, ctx2);
+            man << "\"pcg_projected\":{\"abs_tol\":" << abs_tol << ",\"rel_tol\":1e-4,\"converged\":" << (ip.converged ? 1 : 0) << ",\"iterations\":" << ip.n_iterations
+                << ",\"error\":" << ip.error << ",\"indefinite\":" << (ip.found_indefiniteness ? 1 : 0) << ",\"x_dot_rhs\":" << dup.dot(rhs) << ",\"x_norm\":" << dup.norm() << "},\n";
+        }
+        man << "\"end\":0}\n";
+        std::ofstream(dir + "/slim.json") << man.str();
+        return 0;
+    }
     if (mode == "traj") {
         // Evaluation-point trace of `steps` time steps. SolverCallbacks::run_is_converged short-circuits on its `false`
         // default (solver_utils.h:51-58) so it cannot be used as a per-iteration hook; before_energy_evaluation runs

@@ -7,7 +7,7 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end from kernels order by start"))
 def sh(x): return x.split("(")[0].replace("void ", "").replace("mistark::", "").split("<")[0]
-PCG = {"k_spmv_fused", "k_pcg_step", "k_pcg_dir", "k_pcg_init", "k_pcg_init2", "k_block_diag_inverse", "k_spmv_combine"}
+PCG = {"k_spmv_fused", "k_spmv_dir", "k_pcg_step", "k_pcg_dir", "k_pcg_init", "k_pcg_init2", "k_block_diag_inverse", "k_spmv_combine", "k_copy_ctrl", "k_pcg_check"}
 solves = []
 cur = None
 for i, (name, s, e) in enumerate(rows):
@@ -21,7 +21,7 @@ for i, (name, s, e) in enumerate(rows):
             cur["busy"] += e - s
             cur["end"] = e
             cur["last"] = i
-            if k == "k_spmv_fused":
+            if k in ("k_spmv_fused", "k_spmv_dir"):
                 cur["spmv"] += 1
                 if e - s > 5000:
                     cur["spmv_real"] += 1

@@ -101,6 +101,24 @@ int cb_converged_valid(void* u) { bool v = true; for (auto& f : ((CbCtx*)u)->cb-
 double cb_max_step(void* u) { double s = 1.0; for (auto& f : ((CbCtx*)u)->cb->max_allowed_step) s = std::min(s, f()); return s; }
 }  // namespace
 
+// The first half of run_one_step up to the Newton solve, and the Newton callback that precedes every evaluation, as separate calls: a
+// stage-by-stage comparison with the reference (tests/test_gpu_fullsize.py) puts the engine at a dumped state the way the reference's
+// harness does (callbacks->run_before_time_step(); set_dofs; newton->run_before_energy_evaluation()).
+void Stark::begin_time_step()
+{
+    if (!is_init) _initialize();
+    ensure_registered();
+    for (auto& f : callbacks->before_time_step) f();
+    ensure_registered();
+    if (dt != dt_uploaded) {
+        check(mistark_upload(ctx, dt_array_id));
+        dt_uploaded = dt;
+    }
+}
+void Stark::before_energy_evaluation()
+{
+    for (auto& f : callbacks->newton->before_energy_evaluation) f();
+}
 bool Stark::run_one_step()
 {
     struct StepTimer

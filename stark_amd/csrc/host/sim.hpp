@@ -127,6 +127,8 @@ public:
     ~Stark();
     Stark(const Stark&) = delete;
     bool run_one_step();
+    void begin_time_step();           // before_time_step callbacks (friction tables, rigid-body caches, v1 = 0), without solving
+    void before_energy_evaluation();  // the Newton callback of that name (contact tables at the current DoFs)
     bool run(double duration, std::function<void()> callback = nullptr);
     void add_model(Registrable* m) { models.push_back(m); registration_dirty = true; }
     void mark_registration_dirty() { registration_dirty = true; }

@@ -660,6 +660,18 @@ int mistark_sim_run_one_step(mistark_sim* s)
     _ret = s->sim->get_stark().run_one_step() ? 1 : 0;
     SIM_END
 }
+int mistark_sim_begin_time_step(mistark_sim* s)
+{
+    SIM_BEGIN
+    s->sim->get_stark().begin_time_step();
+    SIM_END
+}
+int mistark_sim_before_energy_evaluation(mistark_sim* s)
+{
+    SIM_BEGIN
+    s->sim->get_stark().before_energy_evaluation();
+    SIM_END
+}
 int mistark_sim_prepare(mistark_sim* s)
 {
     SIM_BEGIN

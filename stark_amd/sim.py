@@ -88,6 +88,8 @@ def _lib():
         L.mistark_sim_run_one_step.argtypes = [p]
         L.mistark_sim_set_newton_settings.argtypes = [p, C.POINTER(capi.NewtonSettings)]
         L.mistark_sim_prepare.argtypes = [p]
+        L.mistark_sim_begin_time_step.argtypes = [p]
+        L.mistark_sim_before_energy_evaluation.argtypes = [p]
         L.mistark_sim_engine.argtypes = [p]
         L.mistark_sim_engine.restype = p
         L.mistark_sim_get_info.argtypes = [p, C.POINTER(SimInfo)]
@@ -392,6 +394,12 @@ class Simulation:
 
     def run_one_step(self) -> bool:
         return self._ck(self.L.mistark_sim_run_one_step(self.h)) == 1
+
+    def begin_time_step(self):
+        self._ck(self.L.mistark_sim_begin_time_step(self.h))
+
+    def before_energy_evaluation(self):
+        self._ck(self.L.mistark_sim_before_energy_evaluation(self.h))
 
     def prepare(self):
         self._ck(self.L.mistark_sim_prepare(self.h))

@@ -70,6 +70,12 @@ FIXTURES = {
     # configs[4] at fixture size: tet block on a fixed floor + cloth over it + chain of 4 hinged boxes over the cloth, contact + friction
     # between the layers (step log and final state)
     "traj_cfg4_mixed_small": ("traj", "mixed", "nx=4 ny=4 nz=4 nc=10 nrb=4 L=0.4 gap=0.003 thickness=0.002 bx=1.2 kmin=1e6 link=0.04 steps=5 slim=1 threads=8"),
+    # BASELINE configs[3], [2], [4] at their FULL sizes: stage outputs of the reference at a closed-form state (`slimdump`: all velocity DoFs =
+    # amp sin(1.3 i + 0.7) at the initial configuration): E, the whole gradient, the contact / friction tables, pattern size, SpMV probes
+    # (every 4th entry, float32: the matrix is float) of the assembled and of the PSD-projected matrix, PCG outcomes on both
+    "slim_cfg3_blockbox_44x44x43": ("slimdump", "blockbox", "nx=44 ny=44 nz=43 L=1 gap=0.0015 thickness=0.001 mu=0.5 kmin=1e8 bx=3 bz=0.1 boxfirst=1 threads=8 steps=0 amp=0.01 xamp=2e-4"),
+    "slim_cfg2_clothbox_256": ("slimdump", "clothbox", "n=256 size=1 box=2 gap=0.0015 thickness=0.001 mu=0.5 threads=8 steps=0 amp=0.005 xamp=2e-4"),
+    "slim_cfg4_mixed_26x26x25": ("slimdump", "mixed", "threads=8 steps=0 amp=0.01 xamp=2e-4"),
     # contact scenes (cfg 1 / cfg 4 at fixture size): cloth resting on a fixed rigid box, soft block pressed on a fixed rigid box
     "traj_clothbox_8": ("traj", "clothbox", "n=8 gap=0.004 steps=4"),
     "traj_blockbox_3": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=1"),
@@ -87,7 +93,7 @@ def pack(name):
     args = args.split()
     tmp = tempfile.mkdtemp(prefix="mistark_fx_")
     try:
-        scene_args = [a for a in args if not a.startswith(("steps=", "amp="))]
+        scene_args = [a for a in args if not a.startswith(("steps=", "amp=", "xamp="))]
         if mode != "geom":
             run([HARNESS, "prime", scene] + scene_args)
         run([HARNESS, mode, scene] + args + ["out=" + tmp])
@@ -96,6 +102,8 @@ def pack(name):
             p = os.path.join(tmp, fn)
             if fn.endswith(".npy"):
                 data[fn[:-4]] = np.load(p)
+                if mode == "slimdump" and fn.startswith("spmv_y"):
+                    data[fn[:-4]] = data[fn[:-4]][::4].astype(np.float32)
             elif fn.endswith(".json"):
                 txt = open(p).read()
                 json.loads(txt)  # validate
