@@ -29,6 +29,13 @@ typedef struct mistark_ctx mistark_ctx;
 /* ---- context -------------------------------------------------------------------------------------------------- */
 int mistark_create(int device, mistark_ctx** out);
 void mistark_destroy(mistark_ctx* ctx);
+/* A registration-only context: no GPU is touched (process-wide from the first call on), DoF sets / arrays / potentials are recorded,
+ * every evaluation entry point fails. For checking on a machine without a GPU what a caller registers (mistark_describe). */
+int mistark_create_dry(mistark_ctx** out);
+/* The registration as JSON (DoF sets; per potential: name, connectivity stride, element count, bindings as [array, stride, connectivity
+ * column, items] with arrays named "dof:<label>" or "a<k>" in order of first use). Returns the length needed including the terminator;
+ * writes at most cap bytes. */
+int64_t mistark_describe(mistark_ctx* ctx, char* buf, int64_t cap);
 const char* mistark_last_error(mistark_ctx* ctx);
 /* Version / build info string (static storage). */
 const char* mistark_version(void);
@@ -44,6 +51,9 @@ int mistark_resize_dof_set(mistark_ctx* ctx, int set, double* host, int64_t n_sc
  * Arrays are identified by (host pointer, stride); binding the host pointer of a DoF set yields a view of the DoF
  * vector. Returns the array id (>= 0). Re-binding an existing (pointer, stride) updates n_items. */
 int mistark_array(mistark_ctx* ctx, const double* host, int64_t n_items, int stride);
+/* The view of DoF set `set` as an array of the given stride, by set index instead of by host address (an EMPTY set has no address to be
+ * recognised by: SymX identifies DoF maps by container identity, DataMap::id, data_maps.h:97-105). Returns the array id. */
+int mistark_dof_array(mistark_ctx* ctx, int set, int stride);
 /* Re-point an array id at a (possibly reallocated / resized) host buffer. */
 int mistark_array_rebind(mistark_ctx* ctx, int array, const double* host, int64_t n_items);
 /* host -> device / device -> host copies of one array (all arrays if array < 0). */

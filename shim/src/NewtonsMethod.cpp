@@ -1,0 +1,333 @@
+// symx::NewtonsMethod on libmistark: implementation of shim/include/mistark_symx/NewtonsMethod.h over the C ABI (include/mistark.h).
+// Replaces symx/src/solver/NewtonsMethod.cpp (and with it second_order/*, the JIT and BlockedSparseMatrix) in a STARK build.
+//
+// What crosses the boundary and when:
+//   first solve()            every DoF set (GlobalPotential::get_dof_maps: host pointer, size, label), every bound array
+//                            (MappedWorkspace::maps: DataMap id / data / n_elements / stride), every potential (name, connectivity,
+//                            bindings in mws.make_* order); potentials without a hand-written kernel as SymX op sequences
+//   every solve()            sizes and pointers re-read (the caller owns and may resize everything), host arrays uploaded, settings
+//                            translated, mistark_newton_solve, DoFs written back to the caller's arrays
+//   every Newton callback    the DoFs are brought to the caller's arrays first (STARK's callbacks read them there: contact detection,
+//                            validity checks), and after before_energy_evaluation the tables the callback may have refilled
+//                            (connectivity of every potential whose size or address changed, all arrays) go back to the device
+// MISTARK_SHIM_DRY=1: registration only on a registration-only context (no GPU; solve() returns Successful without touching the DoFs);
+// MISTARK_SHIM_DESCRIBE=<file>: the registration (mistark_describe) is written there after every solve.
+#include "mistark_symx/NewtonsMethod.h"
+
+#include <compile/Sequence.h>
+#include <fmt/format.h>
+
+#include <algorithm>
+
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "mistark.h"
+
+namespace symx
+{
+	struct NewtonsMethod::Impl
+	{
+		mistark_ctx* ctx = nullptr;
+		bool dry = false;
+		NewtonsMethod* self = nullptr;
+		struct Arr
+		{
+			int id = -1;
+			const double* host = nullptr;
+			int64_t n = -1;
+		};
+		std::map<std::pair<std::uintptr_t, int>, Arr> arrays;  // (DataMap id, stride) -> engine array
+		struct Pot
+		{
+			int id = -1;
+			const int32_t* conn = nullptr;
+			int32_t n_elem = -1;
+		};
+		std::vector<Pot> pots;
+		std::vector<std::pair<const double*, int64_t>> dof_sets;
+
+		void check(int rc, const char* what) const
+		{
+			if (rc < 0) throw std::runtime_error(std::string("mistark shim: ") + what + ": " + (ctx ? mistark_last_error(ctx) : "no context"));
+		}
+		~Impl()
+		{
+			if (ctx) mistark_destroy(ctx);
+		}
+
+		void create()
+		{
+			const char* dry_env = std::getenv("MISTARK_SHIM_DRY");
+			dry = dry_env && dry_env[0] == '1';
+			if (dry) {
+				check(mistark_create_dry(&ctx), "mistark_create_dry");
+			} else {
+				const char* dev = std::getenv("MISTARK_DEVICE");
+				const int rc = mistark_create(dev ? std::atoi(dev) : 0, &ctx);
+				if (rc != 0) throw std::runtime_error("mistark shim: mistark_create failed (" + std::to_string(rc) + "): no MI355X visible; the hot path has no CPU fallback");
+			}
+		}
+
+		// DoF sets, arrays and potentials as the caller holds them right now. Returns true when anything changed on the engine side.
+		void sync(GlobalPotential& gp, bool upload)
+		{
+			if (!ctx) create();
+			// ---- DoF sets (GlobalPotential::add_dof, GlobalPotential.h:55-61)
+			const auto& dof_maps = gp.get_dof_maps();
+			for (int i = 0; i < gp.get_n_dof_sets(); i++) {
+				double* host = dof_maps[(size_t)i].data();
+				const int64_t n = gp.get_n_dofs(i);
+				if (i >= (int)dof_sets.size()) {
+					check(mistark_add_dof_set(ctx, gp.get_dof_label(i).c_str(), host, n), "mistark_add_dof_set");
+					dof_sets.emplace_back(host, n);
+				} else if (dof_sets[(size_t)i].first != host || dof_sets[(size_t)i].second != n) {
+					check(mistark_resize_dof_set(ctx, i, host, n), "mistark_resize_dof_set");
+					dof_sets[(size_t)i] = {host, n};
+				}
+			}
+			// ---- potentials
+			const auto& potentials = gp.get_potentials();
+			for (size_t pi = 0; pi < potentials.size(); pi++) {
+				const Potential& pot = *potentials[pi];
+				auto mws = pot.get_mws();
+				if (mws->has_summation()) throw std::runtime_error("mistark shim: potential '" + pot.get_name() + "' uses a summation loop (fem integrators): not supported by the engine");
+				std::vector<mistark_binding> bs;
+				for (const auto& m : mws->maps) {
+					const auto key = std::make_pair(m.id(), (int)m.stride);
+					Arr& a = arrays[key];
+					const double* host = m.data();
+					const int64_t n = m.connectivity_index < 0 ? 1 : (int64_t)m.n_elements();
+					int dof_set = -1;  // a DoF map is recognised by the identity of its container (DataMap::id), as SymX does
+					for (int i = 0; i < gp.get_n_dof_sets(); i++)
+						if (dof_maps[(size_t)i].id() == key.first) dof_set = i;
+					if (a.id < 0) {
+						a.id = dof_set >= 0 ? mistark_dof_array(ctx, dof_set, m.stride) : mistark_array(ctx, host, n, m.stride);
+						check(a.id, "mistark_array");
+					} else if (dof_set < 0 && (a.host != host || a.n != n)) {
+						check(mistark_array_rebind(ctx, a.id, host, n), "mistark_array_rebind");
+					}
+					a.host = host;
+					a.n = n;
+					bs.push_back(mistark_binding{a.id, m.stride, m.connectivity_index});
+				}
+				const int32_t n_elem = mws->conn.n_elements();
+				const int32_t* conn = n_elem > 0 ? mws->conn.data() : nullptr;
+				const std::string& name = pot.get_name();
+				if (pi >= pots.size()) {
+					Pot P;
+					bool known = false;
+					for (int k = 0; k < mistark_n_supported_potentials() && !known; k++) known = name == mistark_supported_potential(k);
+					if (known) {
+						P.id = mistark_potential(ctx, name.c_str(), conn, n_elem, mws->conn.stride, bs.data(), (int)bs.size());
+					} else {
+						// no hand-written kernel under this name (a user-defined energy): SymX's own straight-line op sequence, interpreted on
+						// the device (symx/src/compile/Sequence.h:24-41)
+						auto flatten = [](const Scalar& expr, std::vector<int32_t>& rows, std::vector<double>& consts) {
+							Sequence seq({expr});
+							for (const auto& op : seq.ops) {
+								rows.insert(rows.end(), {(int32_t)op.type, op.dst, op.a, op.b, op.cond});
+								consts.push_back(op.constant);
+							}
+							return seq.get_n_inputs();
+						};
+						std::vector<int32_t> ops, cops;
+						std::vector<double> cst, ccst;
+						const int n_in = flatten(pot.get_expression(), ops, cst);
+						if (pot.has_conditional()) flatten(pot.get_condition(), cops, ccst);
+						P.id = mistark_potential_custom(ctx, name.c_str(), conn, n_elem, mws->conn.stride, bs.data(), (int)bs.size(), ops.data(), cst.data(), (int)cst.size(), n_in,
+						                                cops.empty() ? nullptr : cops.data(), ccst.empty() ? nullptr : ccst.data(), (int)ccst.size());
+					}
+					check(P.id, ("potential '" + name + "'").c_str());
+					// tables refilled inside the Newton loop (EnergyFrictionalContact.cpp:117-119) go to the small dynamic matrix part
+					if (name.rfind("contact_", 0) == 0 || name.rfind("friction_", 0) == 0) check(mistark_potential_set_dynamic(ctx, P.id, 1), "mistark_potential_set_dynamic");
+					P.conn = conn;
+					P.n_elem = n_elem;
+					pots.push_back(P);
+				} else if (pots[pi].conn != conn || pots[pi].n_elem != n_elem || name.rfind("contact_", 0) == 0 || name.rfind("friction_", 0) == 0) {
+					// (the reference refills its contact tables in place: the same address may hold other rows)
+					check(mistark_potential_update_connectivity(ctx, pots[pi].id, conn, n_elem), "mistark_potential_update_connectivity");
+					pots[pi].conn = conn;
+					pots[pi].n_elem = n_elem;
+				}
+			}
+			if (upload && !dry) check(mistark_upload(ctx, -1), "mistark_upload");
+		}
+
+		// ---- C callbacks of mistark_newton_solve -> SolverCallbacks (solver_utils.h:29-117). STARK's callbacks read the DoFs from the
+		//      caller's arrays: bring them there first.
+		void dofs_to_host() { check(mistark_dofs_to_host_arrays(ctx), "mistark_dofs_to_host_arrays"); }
+		static Impl& I(void* u) { return *static_cast<Impl*>(u); }
+		static void cb_before_eval(void* u)
+		{
+			Impl& s = I(u);
+			s.dofs_to_host();
+			s.self->callbacks->run_before_energy_evaluation();
+			s.sync(*s.self->global_potential, /*upload=*/true);  // tables and data the callback refilled
+		}
+		static int cb_initial_valid(void* u) { I(u).dofs_to_host(); return I(u).self->callbacks->run_is_initial_state_valid() ? 1 : 0; }
+		static int cb_intermediate_valid(void* u) { I(u).dofs_to_host(); return I(u).self->callbacks->run_is_intermediate_state_valid() ? 1 : 0; }
+		static void cb_on_invalid(void* u) { I(u).dofs_to_host(); I(u).self->callbacks->run_on_intermediate_state_invalid(); }
+		static void cb_on_armijo(void* u) { I(u).dofs_to_host(); I(u).self->callbacks->run_on_armijo_fail(); }
+		static int cb_is_converged(void* u) { I(u).dofs_to_host(); return I(u).self->callbacks->run_is_converged() ? 1 : 0; }
+		static int cb_converged_valid(void* u) { I(u).dofs_to_host(); return I(u).self->callbacks->run_is_converged_state_valid() ? 1 : 0; }
+		static double cb_max_step(void* u) { I(u).dofs_to_host(); return I(u).self->callbacks->run_max_allowed_step(); }
+	};
+
+	NewtonsMethod::NewtonsMethod(spGlobalPotential global_potential, spContext context, spSolverCallbacks callbacks)
+		: callbacks(callbacks), impl(std::make_unique<Impl>()), global_potential(global_potential), context(context)
+	{
+		if (!this->callbacks) this->callbacks = SolverCallbacks::create(context);
+		impl->self = this;
+	}
+	NewtonsMethod::~NewtonsMethod() = default;
+	std::shared_ptr<NewtonsMethod> NewtonsMethod::create(spGlobalPotential global_potential, spContext context, spSolverCallbacks callbacks)
+	{
+		return std::make_shared<NewtonsMethod>(global_potential, context, callbacks);
+	}
+	mistark_ctx* NewtonsMethod::engine() const { return impl->ctx; }
+
+	SolverReturn NewtonsMethod::solve()
+	{
+		auto _t = this->context->logger->time("newton_solve");
+		Impl& s = *impl;
+		s.sync(*global_potential, /*upload=*/true);
+		if (const char* path = std::getenv("MISTARK_SHIM_DESCRIBE")) {
+			const int64_t n = mistark_describe(s.ctx, nullptr, 0);
+			std::string buf((size_t)n, '\0');
+			mistark_describe(s.ctx, buf.data(), n);
+			std::ofstream(path) << buf.c_str() << std::endl;
+		}
+		this->stats = SolveStats();
+		if (s.dry) return SolverReturn::Successful;
+		s.check(mistark_dofs_from_host_arrays(s.ctx), "mistark_dofs_from_host_arrays");
+
+		mistark_newton_settings ns;
+		mistark_newton_default_settings(&ns);
+		const NewtonSettings& S = this->settings;
+		ns.max_iterations = S.max_iterations;
+		ns.min_iterations = S.min_iterations;
+		ns.residual_tolerance_abs = S.residual_tolerance_abs;
+		ns.residual_tolerance_rel = S.residual_tolerance_rel;
+		ns.step_tolerance = S.step_tolerance;
+		ns.max_iterations_as_success = S.max_iterations_as_success ? 1 : 0;
+		ns.step_cap = S.step_cap;
+		ns.enable_armijo_backtracking = S.enable_armijo_backtracking ? 1 : 0;
+		ns.line_search_armijo_beta = S.line_search_armijo_beta;
+		ns.max_backtracking_armijo_iterations = S.max_backtracking_armijo_iterations;
+		ns.max_backtracking_invalid_state_iterations = S.max_backtracking_invalid_state_iterations;
+		switch (S.projection_mode) {
+			case ProjectionToPD::Newton: ns.projection_mode = MISTARK_PROJ_NEWTON; break;
+			case ProjectionToPD::ProjectedNewton: ns.projection_mode = MISTARK_PROJ_PROJECTED_NEWTON; break;
+			case ProjectionToPD::ProjectOnDemand: ns.projection_mode = MISTARK_PROJ_ON_DEMAND; break;
+			case ProjectionToPD::Progressive: ns.projection_mode = MISTARK_PROJ_PROGRESSIVE; break;
+		}
+		ns.projection_eps = S.projection_eps;
+		ns.project_to_pd_use_mirroring = S.project_to_pd_use_mirroring ? 1 : 0;
+		ns.project_on_demand_countdown = S.project_on_demand_countdown;
+		ns.ppn_tightening_factor = S.ppn_tightening_factor;
+		ns.ppn_release_factor = S.ppn_release_factor;
+		ns.linear_solver = S.linear_solver == LinearSolver::DirectLLT ? MISTARK_SOLVER_DIRECT_LLT : MISTARK_SOLVER_BDPCG;
+		ns.cg_max_iterations = S.cg_max_iterations;
+		ns.cg_abs_tolerance = S.cg_abs_tolerance;
+		ns.cg_rel_tolerance = S.cg_rel_tolerance;
+		ns.cg_stop_on_indefiniteness = S.cg_stop_on_indefiniteness ? 1 : 0;
+		ns.bailout_residual = S.bailout_residual;
+
+		mistark_newton_callbacks cb{};
+		cb.user = &s;
+		cb.before_energy_evaluation = Impl::cb_before_eval;
+		cb.is_initial_state_valid = Impl::cb_initial_valid;
+		cb.is_intermediate_state_valid = Impl::cb_intermediate_valid;
+		cb.on_intermediate_state_invalid = Impl::cb_on_invalid;
+		cb.on_armijo_fail = Impl::cb_on_armijo;
+		cb.is_converged = Impl::cb_is_converged;
+		cb.is_converged_state_valid = Impl::cb_converged_valid;
+		cb.max_allowed_step = Impl::cb_max_step;
+
+		mistark_newton_stats st{};
+		const int rc = mistark_newton_solve(s.ctx, &ns, &cb, &st);
+		s.check(rc, "mistark_newton_solve");
+		s.dofs_to_host();  // the reference leaves the solution in the caller's DoF arrays (NewtonsMethod.cpp:608-640)
+		this->stats.newton_iterations = st.newton_iterations;
+		this->stats.cg_iterations = st.cg_iterations;
+		this->stats.ls_cap_iterations = st.ls_cap_iterations;
+		this->stats.ls_max_iterations = st.ls_max_iterations;
+		this->stats.ls_inv_iterations = st.ls_inv_iterations;
+		this->stats.ls_bt_iterations = st.ls_bt_iterations;
+		this->stats.n_hessians = (uint64_t)st.n_hessians;
+		this->stats.n_projected_hessians = (uint64_t)st.n_projected_hessians;
+		this->stats.projected_hessians_ratio = st.projected_hessians_ratio;
+		// the series the reference logs per solve (NewtonsMethod.cpp:236-251): STARK's console line and YAML output read them
+		auto& lg = *this->context->logger;
+		lg.add_and_append("n_hessians", (int)st.n_hessians);
+		lg.add_and_append("n_projected_hessians", (int)st.n_projected_hessians);
+		lg.add_and_append("projected_hessians_ratio", st.projected_hessians_ratio);
+		lg.add_and_append("cg_iterations", st.cg_iterations);
+		lg.add_and_append("newton_iterations", st.newton_iterations);
+		lg.add_and_append("ls_cap", st.ls_cap_iterations);
+		lg.add_and_append("ls_max", st.ls_max_iterations);
+		lg.add_and_append("ls_inv", st.ls_inv_iterations);
+		lg.add_and_append("ls_bt", st.ls_bt_iterations);
+		// stage times of the engine under the reference's timer names (NewtonsMethod.cpp:268,274,390; SecondOrderCompiledGlobal)
+		lg.add("mistark_linear_system_solve_s", st.t_linear_solve);
+		lg.add("mistark_assembly_s", st.t_assembly);
+		lg.add("mistark_project_to_PD_s", st.t_project);
+		lg.add("mistark_evaluate_P_grad_hess_s", st.t_eval_pgh);
+		lg.add("mistark_evaluate_P_s", st.t_eval_p);
+		lg.add("mistark_linear_solves", st.n_linear_solves);
+		// SolverReturn and the MISTARK_* result codes share their numbering (solver_utils.h:15-26, mistark.h:158-166)
+		return static_cast<SolverReturn>(rc);
+	}
+
+	// The summary table of the reference (NewtonsMethod.cpp:643-718): the "Solve" block from the logged series, then the runtime block from
+	// the logger's timers (callbacks, newton_solve) followed by the engine's own stage times.
+	void NewtonsMethod::print_summary(double total_time) const
+	{
+		auto* out = this->context->output.get();
+		const auto& lg = *this->context->logger;
+		const int total_n_newton = (int)lg.get_stats("newton_iterations").total;
+		if (total_n_newton == 0) {
+			out->print_with_new_line("No Newton iterations were performed. No summary to show.\n");
+			return;
+		}
+		out->print_with_new_line("");
+		out->print_with_new_line(fmt::format("  {:<24} {:>10} {:>8} {:>8} {:>8}", "Solve", "Total", "Avg", "Min", "Max"));
+		out->print_with_new_line(fmt::format("  {}", std::string(62, '-')));
+		const std::vector<std::pair<std::string, std::string>> rows = {{"Newton iterations", "newton_iterations"}, {"CG iterations", "cg_iterations"}, {"Line search cap", "ls_cap"},
+		                                                                {"Line search max", "ls_max"},          {"Line search inv", "ls_inv"},      {"Line search bt", "ls_bt"}};
+		for (const auto& [label, key] : rows) {
+			auto st = lg.get_stats(key);
+			out->print_with_new_line(fmt::format("  {:<24} {:>10} {:>8.1f} {:>8} {:>8}", label, (long long)st.total, st.avg, (int)st.min, (int)st.max));
+		}
+		auto sr = lg.get_stats("projected_hessians_ratio");
+		out->print_with_new_line(fmt::format("  {:<24} {:>10} {:>8.1f}% {:>7.1f}% {:>7.1f}%", "Projected hessians", "", 100.0 * sr.avg, 100.0 * sr.min, 100.0 * sr.max));
+		if (total_time <= 0.0) {
+			total_time = 0.0;
+			for (const auto& label : lg.get_timer_labels()) total_time += lg.get_timer_total(label);
+		}
+		out->print_with_new_line(fmt::format("  {}", std::string(62, '-')));
+		out->print_with_new_line("");
+		out->print_with_new_line(fmt::format("  {:<40} {:>10}  {:>6}", "Runtime", "Time (s)", "%"));
+		out->print_with_new_line(fmt::format("  {}", std::string(60, '-')));
+		struct Entry { std::string label; double time; };
+		std::vector<Entry> entries;
+		for (const auto& label : lg.get_timer_labels()) entries.push_back({label, lg.get_timer_total(label)});
+		for (const char* k : {"linear_system_solve", "assembly", "project_to_PD", "evaluate_P_grad_hess", "evaluate_P"})
+			entries.push_back({std::string("  mistark: ") + k, lg.get_double(std::string("mistark_") + k + "_s")});
+		std::sort(entries.begin(), entries.end(), [](const Entry& a, const Entry& b) { return a.time > b.time; });
+		for (const auto& e : entries) {
+			if (total_time > 0 && e.time / total_time < 0.001) continue;
+			out->print_with_new_line(fmt::format("  {:<40} {:>10.6f}  {:>5.1f}%", e.label, e.time, total_time > 0 ? 100.0 * e.time / total_time : 0.0));
+		}
+		out->print_with_new_line(fmt::format("  {}", std::string(60, '-')));
+		out->print_with_new_line(fmt::format("  {:<40} {:>10.6f}  {:>5.1f}%", "Total", total_time, 100.0));
+		out->print_new_line();
+	}
+}

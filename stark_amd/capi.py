@@ -137,6 +137,10 @@ def lib():
     L.mistark_dist_get_row_owner.argtypes = [p, p]
     L.mistark_dist_move.argtypes = [p, p]
     L.mistark_sync.argtypes = [p]
+    L.mistark_dof_array.argtypes = [p, C.c_int, C.c_int]
+    L.mistark_create_dry.argtypes = [C.POINTER(p)]
+    L.mistark_describe.argtypes = [p, p, i64]
+    L.mistark_describe.restype = i64
     L.mistark_get_bsr.argtypes = [p, C.POINTER(i64), C.POINTER(i64), p, p, p]
     L.mistark_spmv.argtypes = [p, p, p]
     L.mistark_apply_preconditioner.argtypes = [p, p, p]

@@ -152,12 +152,63 @@ int mistark_create(int device, mistark_ctx** out)
     }
     return 0;
 }
+int mistark_create_dry(mistark_ctx** out)
+{
+    if (!out) return -1;
+    dry_mode() = true;  // (process-wide: device buffers of every context stay empty from here on)
+    mistark_ctx* ctx = new mistark_ctx();
+    ctx->c.dry = true;
+    *out = ctx;
+    return 0;
+}
 void mistark_destroy(mistark_ctx* ctx)
 {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->c.device);
-    (void)hipStreamSynchronize(ctx->c.stream);
+    if (!ctx->c.dry) {
+        (void)hipSetDevice(ctx->c.device);
+        (void)hipStreamSynchronize(ctx->c.stream);
+    }
     delete ctx;
+}
+// What has been registered, as JSON: DoF sets, arrays, potentials with their bindings. Arrays are named by the DoF set they view or by the
+// order in which they were first bound ("a0", "a1", ...): two registrations of the same scene by different callers compare equal.
+int64_t mistark_describe(mistark_ctx* ctx, char* buf, int64_t cap)
+{
+    if (!ctx) return -1;
+    Context& c = ctx->c;
+    std::string o = "{\"dof_sets\":[";
+    for (size_t i = 0; i < c.dof_sets.size(); i++) o += std::string(i ? "," : "") + "{\"label\":\"" + c.dof_sets[i].label + "\",\"n\":" + std::to_string(c.dof_sets[i].n) + "}";
+    o += "],\"potentials\":[";
+    std::vector<int> alias(c.arrays.size(), -1);
+    int n_alias = 0;
+    auto name_of = [&](int a) {
+        const Array& A = c.arrays[(size_t)a];
+        int set = A.dof_set;
+        if (set < 0)
+            for (size_t k = 0; k < c.dof_sets.size(); k++)
+                if (A.host && A.host == c.dof_sets[k].host) set = (int)k;
+        if (set >= 0) return "dof:" + c.dof_sets[(size_t)set].label;
+        if (alias[(size_t)a] < 0) alias[(size_t)a] = n_alias++;
+        return "a" + std::to_string(alias[(size_t)a]);
+    };
+    for (size_t i = 0; i < c.pots.size(); i++) {
+        const Potential& P = c.pots[i];
+        o += std::string(i ? "," : "") + "{\"name\":\"" + P.name + "\",\"conn_stride\":" + std::to_string(P.conn_stride) + ",\"n_elem\":" + std::to_string(P.n_elem) +
+             ",\"dynamic\":" + std::to_string(P.part) + ",\"bindings\":[";
+        for (size_t b = 0; b < P.bindings.size(); b++) {
+            const mistark_binding& B = P.bindings[b];
+            o += std::string(b ? "," : "") + "[\"" + name_of(B.array) + "\"," + std::to_string(B.stride) + "," + std::to_string(B.conn_col) + "," +
+                 std::to_string(c.arrays[(size_t)B.array].n_items) + "]";
+        }
+        o += "]}";
+    }
+    o += "]}";
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>(o.size(), (size_t)cap - 1);
+        std::memcpy(buf, o.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)o.size() + 1;
 }
 const char* mistark_last_error(mistark_ctx* ctx) { return ctx ? ctx->c.last_error.c_str() : "null context"; }
 
@@ -221,10 +272,28 @@ int mistark_array(mistark_ctx* ctx, const double* host, int64_t n_items, int str
     a.n_items = n_items;
     a.stride = stride;
     for (size_t s = 0; s < c.dof_sets.size(); s++)
-        if ((const double*)c.dof_sets[s].host == host) {
+        if (host != nullptr && (const double*)c.dof_sets[s].host == host) {  // (empty containers all have the null address: mistark_dof_array)
             a.dof_set = (int)s;
             if (c.dof_sets[s].n != n_items * stride) throw Error("array bound on a DoF set must cover the whole set");
         }
+    c.layout_dirty = true;
+    _ret = (int)c.arrays.size() - 1;
+    API_END(_ret)
+}
+int mistark_dof_array(mistark_ctx* ctx, int set, int stride)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (set < 0 || set >= (int)c.dof_sets.size()) throw Error("bad DoF set");
+    if (stride <= 0 || c.dof_sets[set].n % stride != 0) throw Error("bad stride for a view of this DoF set");
+    for (size_t i = 0; i < c.arrays.size(); i++)
+        if (c.arrays[i].dof_set == set && c.arrays[i].stride == stride) return (int)i;
+    c.arrays.emplace_back();
+    Array& a = c.arrays.back();
+    a.host = c.dof_sets[set].host;
+    a.n_items = c.dof_sets[set].n / stride;
+    a.stride = stride;
+    a.dof_set = set;
     c.layout_dirty = true;
     _ret = (int)c.arrays.size() - 1;
     API_END(_ret)

@@ -28,6 +28,13 @@ struct Error : std::runtime_error
         }                                                                                                                \
     } while (0)
 
+// Registration-only ("dry") contexts (mistark_create_dry): no GPU is touched, device buffers stay empty. Used to check on a machine without
+// a GPU what a caller registers (tests/test_shim_cpu.py: the reference's own classes through the SymX shim against the host mirror).
+inline bool& dry_mode()
+{
+    static bool dry = false;
+    return dry;
+}
 // Growable device buffer
 template <class T>
 struct DevBuf
@@ -60,6 +67,7 @@ struct DevBuf
     void ensure(size_t n)
     {
         if (n <= cap) return;
+        if (dry_mode()) return;
         if (p) MS_CHECK(hipFree(p));
         p = nullptr;
         size_t want = n + n / 8 + 64;
@@ -255,6 +263,7 @@ struct PcgCtrl
 struct Context
 {
     int device = 0;
+    bool dry = false;               // registration only (mistark_create_dry)
     hipStream_t stream = nullptr;
     std::string last_error;
 

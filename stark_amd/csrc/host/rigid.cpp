@@ -358,7 +358,15 @@ void EnergyRigidBodyConstraints::register_potentials(mistark_ctx* ctx)
                 break;
             default: break;
         }
-        B.potential(KINDS[kind].name, T.conn);
+        if (KINDS[kind].two_bodies) {
+            B.potential(KINDS[kind].name, T.conn);
+        } else {
+            // one body: the reference's table is {idx, rb} (EnergyRigidBodyConstraints.cpp:30,47: LabelledConnectivity<2>); the third
+            // column of the host table repeats the body and is not handed over
+            std::vector<std::array<int32_t, 2>> c2;
+            for (const auto& r : T.conn) c2.push_back({r[0], r[1]});
+            B.potential(KINDS[kind].name, c2);
+        }
     }
 }
 bool EnergyRigidBodyConstraints::_is_converged_state_valid()

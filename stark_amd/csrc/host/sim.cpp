@@ -37,7 +37,9 @@ void Stark::ensure_registered()
             if (auto* pd = dynamic_cast<PointDynamics*>(m)) pd->mirror_to_host();
         ctx = nullptr;
     }
-    const int rc = mistark_create(settings.execution.device, &ctx);
+    // device < 0: a registration-only context (no GPU needed; tests/test_shim_cpu.py compares what this mirror registers with what the
+    // reference's own classes register through the SymX shim)
+    const int rc = settings.execution.device < 0 ? mistark_create_dry(&ctx) : mistark_create(settings.execution.device, &ctx);
     if (rc != 0) throw std::runtime_error("mistark_create failed (" + std::to_string(rc) + "): no MI355X visible; the hot path has no CPU fallback");
     if (settings.execution.world > 1 && old) {
         check(mistark_dist_move(ctx, old));  // (a communicator is created once: an RCCL unique id is single-use)

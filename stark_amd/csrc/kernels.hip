@@ -1109,6 +1109,7 @@ static void build_pattern(Context& c, int part)
 
 void prepare(Context& c)
 {
+    if (c.dry) throw Error("registration-only context (mistark_create_dry): nothing can be evaluated");
     if (!c.layout_dirty) return;
     c.data_version++;
     if (c.layout_dirty) {
@@ -3134,6 +3135,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
 Context::~Context()
 {
     contact_destroy(contact);
+    if (dry) return;
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : pcg_ev) (void)hipEventDestroy(e);
     for (auto e : stage_ev) (void)hipEventDestroy(e);

@@ -1,0 +1,95 @@
+// Test driver of the SymX shim (shim/): the UNMODIFIED reference (stark/src/**, compiled against shim/include/symx in place) builds scenes
+// through its own stark::Simulation; the first time step makes the shim's symx::NewtonsMethod register everything with libmistark.
+//   MISTARK_SHIM_DRY=1 MISTARK_SHIM_DESCRIBE=<file> shim_check <scene>     registration only (no GPU): the JSON of mistark_describe
+//   shim_check <scene> [steps]                                             on a machine with an MI355X: real time steps on the engine
+// Built by oracle/Makefile (target _ref/shim_check) only where /root/reference exists; test infrastructure, not shipped.
+#include <stark>
+
+#include <fstream>
+#include <iostream>
+
+int main(int argc, char** argv)
+{
+    const std::string scene = argc > 1 ? argv[1] : "blockbox";
+    const int steps = argc > 2 ? std::atoi(argv[2]) : 1;
+    stark::Settings settings = stark::Settings();
+    settings.output.simulation_name = "shim_check";
+    settings.output.output_directory = "/tmp/mistark_shim_out";
+    settings.output.codegen_directory = "/tmp/mistark_shim_codegen";
+    settings.output.enable_frame_writes = false;
+    settings.output.enable_output = false;
+    settings.execution.n_threads = 1;
+    settings.simulation.init_frictional_contact = scene == "blockbox" || scene == "mixed";
+    stark::Simulation sim(settings);
+    if (scene == "blockbox") {
+        // the scene of tests/test_shim_cpu.py: rigid box (registered first) + fixed, 2 x 2 x 2 Soft_Rubber block, frictional contact
+        auto gp = stark::EnergyFrictionalContact::GlobalParams();
+        gp.default_contact_thickness = 1e-3;
+        sim.interactions->contact->set_global_params(gp);
+        auto [bV, bT, box] = sim.presets->rigidbodies->add_box("box", 1.0, { 1.0, 1.0, 0.1 });
+        sim.rigidbodies->add_constraint_fix(box.rigidbody);
+        auto [sV, sT] = stark::generate_tet_grid({ 0.0, 0.0, 0.6 }, { 1.0, 1.0, 1.0 }, { 2, 2, 2 });
+        auto block = sim.presets->deformables->add_volume("block", sV, sT, stark::Volume::Params::Soft_Rubber());
+        sim.interactions->contact->set_friction(block.contact, box.contact, 0.5);
+    } else if (scene == "mixed") {
+        // BASELINE configs[4] in small (oracle/ref_harness.cpp scene_mixed; tests/test_gpu_scene.py _build_mixed): floor, chain of hinged
+        // boxes, tet block, cloth; contact and friction between the layers
+        const int nx = 2, nc = 4, nrb = 3;
+        const double L = 0.4, gap = 0.003, th = 0.002, mu = 0.5, bx = 1.2, bz = 0.1, link = 0.04, cloth_size = 1.2;
+        auto gp = stark::EnergyFrictionalContact::GlobalParams();
+        gp.default_contact_thickness = th;
+        gp.min_contact_stiffness = 1e6;
+        sim.interactions->contact->set_global_params(gp);
+        auto ct = sim.interactions->contact;
+        auto [fV, fT, floor] = sim.presets->rigidbodies->add_box("floor", 1.0, { bx, bx, bz });
+        sim.rigidbodies->add_constraint_fix(floor.rigidbody);
+        const double z_block = 0.5 * bz + gap + 0.5 * L, z_cloth = 0.5 * bz + gap + L + gap, z_chain = z_cloth + gap + 0.5 * link, pitch = 1.5 * link;
+        std::vector<stark::RigidBodyHandler> links;
+        std::vector<stark::EnergyFrictionalContact::Handler> link_contacts;
+        for (int i = 0; i < nrb; i++) {
+            auto [V, T, h] = sim.presets->rigidbodies->add_box("link", 0.2, { link, link, link });
+            h.rigidbody.set_translation({ (i - 0.5 * (nrb - 1)) * pitch, 0.0, z_chain });
+            links.push_back(h.rigidbody);
+            link_contacts.push_back(h.contact);
+        }
+        sim.rigidbodies->add_constraint_fix(links[0]);
+        for (int i = 0; i + 1 < nrb; i++) {
+            sim.rigidbodies->add_constraint_hinge(links[i], links[i + 1], Eigen::Vector3d((i + 0.5 - 0.5 * (nrb - 1)) * pitch, 0.0, z_chain), Eigen::Vector3d::UnitY());
+            ct->disable_collision(link_contacts[i], link_contacts[i + 1]);
+        }
+        auto [sV, sT] = stark::generate_tet_grid({ 0.0, 0.0, z_block }, { L, L, L }, { nx, nx, nx });
+        auto soft = sim.presets->deformables->add_volume("block", sV, sT, stark::Volume::Params::Soft_Rubber());
+        auto [cV, cT, cloth] = sim.presets->deformables->add_surface_grid("cloth", { cloth_size * L, cloth_size * L }, { nc, nc }, stark::Surface::Params::Cotton_Fabric());
+        cloth.point_set.add_displacement({ 0.0, 0.0, z_cloth });
+        ct->set_friction(floor.contact, soft.contact, mu);
+        ct->set_friction(soft.contact, cloth.contact, mu);
+        for (int i = 0; i < nrb; i++) ct->set_friction(link_contacts[i], cloth.contact, mu);
+    } else if (scene == "tetbeam") {
+        auto [sV, sT] = stark::generate_tet_grid({ 0.0, 0.0, 0.0 }, { 4.0, 1.0, 1.0 }, { 4, 1, 1 });
+        auto beam = sim.presets->deformables->add_volume("beam", sV, sT, stark::Volume::Params::Soft_Rubber());
+        sim.deformables->prescribed_positions->add_inside_aabb(beam.point_set, { -2.0, 0.0, 0.0 }, { 2e-3, 2.0, 2.0 }, stark::EnergyPrescribedPositions::Params().set_stiffness(1e7));
+    } else if (scene == "cloth") {
+        auto [cV, cT, cloth] = sim.presets->deformables->add_surface_grid("cloth", { 0.4, 0.4 }, { 4, 4 }, stark::Surface::Params::Cotton_Fabric());
+        sim.deformables->prescribed_positions->add_inside_aabb(cloth.point_set, { -0.2, 0.0, 0.0 }, { 2e-3, 2.0, 2.0 }, stark::EnergyPrescribedPositions::Params().set_stiffness(1e7));
+    } else {
+        std::cerr << "unknown scene " << scene << std::endl;
+        return 2;
+    }
+    for (int s = 0; s < steps; s++) sim.run_one_time_step();
+    std::cout << "shim_check: " << steps << " step(s) of '" << scene << "' done" << std::endl;
+    if (argc > 3) {
+        // what the run produced: Newton iterations per solve (the series the shim logs like the reference, NewtonsMethod.cpp:249) and the
+        // positions of all points
+        auto& st = sim.get_stark();
+        std::ofstream f(argv[3]);
+        f.precision(17);
+        f << "{\"newton_iterations\":[";
+        const auto& it = st.context->logger->get_int_series("newton_iterations");
+        for (size_t i = 0; i < it.size(); i++) f << (i ? "," : "") << it[i];
+        f << "],\"time\":" << st.current_time << ",\"x\":[";
+        auto& ps = *sim.deformables->point_sets;
+        for (int i = 0; i < (int)ps.size(); i++) f << (i ? "," : "") << "[" << ps.x0.data[(size_t)i][0] << "," << ps.x0.data[(size_t)i][1] << "," << ps.x0.data[(size_t)i][2] << "]";
+        f << "]}\n";
+    }
+    return 0;
+}

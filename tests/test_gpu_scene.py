@@ -8,6 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _load(name):
@@ -647,3 +648,46 @@ def test_readme_spinning_box_cloth():
     ci = sim.contact_info()
     assert ci["n_contacts"] > 100
     sim.close()
+
+
+@pytest.mark.parametrize("scene", ["tetbeam", "blockbox"])
+def test_unmodified_reference_runs_on_the_engine_through_the_shim(scene, tmp_path):
+    """The B-upper boundary end to end: oracle/_ref/shim_check is the UNMODIFIED reference (stark/src/** compiled in place
+    against shim/include/symx) linked with the shim's symx::NewtonsMethod and libmistark.so. Its own stark::Simulation builds the scene,
+    runs its own callbacks (for the contact scene: the reference's HOST collision detection fills the contact tables, the engine
+    evaluates them), and every Newton solve runs on the MI355X. The same scene through this repo's host mirror (device-side detection)
+    must take the same Newton iteration counts and end in the same state. Skipped where the binary was not built (no /root/reference)."""
+    import subprocess
+
+    from stark_amd import sim as S
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "shim_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_check not built")
+    steps = 4
+    out = str(tmp_path / "shim.json")
+    r = subprocess.run([exe, scene, str(steps), out], capture_output=True, timeout=600)
+    assert r.returncode == 0, (r.stdout.decode()[-1500:], r.stderr.decode()[-1500:])
+    ref = json.load(open(out))
+    st = S.default_settings()
+    st.init_frictional_contact = 1 if scene == "blockbox" else 0
+    sim = S.Simulation(st)
+    if scene == "blockbox":
+        gp = S.contact_global_params()
+        gp.default_contact_thickness = 1e-3
+        sim.set_contact_global_params(gp)
+        rb = sim.add_rigid_box("box", 1.0, (1.0, 1.0, 0.1))
+        sim.rb_add_constraint("fix", rb)
+        ps = sim.add_volume_grid("block", (0.0, 0.0, 0.6), (1.0, 1.0, 1.0), (2, 2, 2), S.soft_rubber())
+        sim.set_friction(sim.contact_group("d", ps), sim.contact_group("rb", rb), 0.5)
+    else:
+        ps = sim.add_volume_grid("beam", (0.0, 0.0, 0.0), (4.0, 1.0, 1.0), (4, 1, 1), S.soft_rubber())
+        sim.prescribe_inside_aabb(ps, (-2.0, 0.0, 0.0), (2e-3, 2.0, 2.0), 1e7)
+    its = []
+    for _ in range(steps):
+        assert sim.run_one_step()
+        its.append(sim.info().last_stats.newton_iterations)
+    x = sim.points("x0")
+    sim.close()
+    assert ref["newton_iterations"] == its
+    assert np.abs(np.array(ref["x"]) - x).max() <= 1e-6 * max(1.0, np.abs(x).max())
