@@ -17,6 +17,7 @@
 #include "engine.hpp"
 #include "registry.hpp"
 #include "tet_closed.hpp"
+#include "tri_closed.hpp"
 
 namespace mistark {
 
@@ -315,6 +316,65 @@ __global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __
         atomicAdd(&grad[3 * row + 2], g[3 * k + 2]);
     }
 }
+// Membrane triangles through their invariants (tri_closed.hpp): one lane per triangle, six hyper-dual evaluations of psi(C) instead of 45 of
+// the whole energy; the nine 3x3 blocks go to the double pool as 72 contiguous bytes per lane and block (neighbouring lanes: neighbouring
+// elements), the node gradients to the gradient pool (k_grad_gather) or, without one, to atomics.
+template <class En, bool FULL, bool STORE_H>
+__global__ __launch_bounds__(BLOCK) void k_eval_tri_closed(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
+{
+    const int le = blockIdx.x * BLOCK + threadIdx.x;
+    if (le >= a.e_count) return;
+    const int e = elem_of(a, le), pe = pool_of(a, le);
+    double in[En::Layout::NIN];
+    gather_inputs<En>(a, e, in);
+    double E, g[9], H[3][3][9];
+    tri_closed_eval<FULL>(in, E, g, H, STORE_H);
+    elemE[pe] = energy_here(a, e) ? E : 0.0;
+    if (a.gpool) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            double* gp = a.gpool + ((size_t)k * a.n_gpool + pe) * 3;
+            gp[0] = g[3 * k];
+            gp[1] = g[3 * k + 1];
+            gp[2] = g[3 * k + 2];
+        }
+    } else {
+        const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const size_t row = (size_t)(a.dof_row_off[k] + ce[a.dof_col[k]]);
+            atomicAdd(&grad[3 * row], g[3 * k]);
+            atomicAdd(&grad[3 * row + 1], g[3 * k + 1]);
+            atomicAdd(&grad[3 * row + 2], g[3 * k + 2]);
+        }
+    }
+    if (STORE_H) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                double* dst = elemH + ((size_t)(i * 3 + j) * a.n_pool + pe) * 9;
+#pragma unroll
+                for (int c = 0; c < 9; c++) dst[c] = H[i][j][c];
+            }
+    }
+}
+static void launch_grad_gather(Context& c, Potential& P)
+{
+    if (P.args.gpool && !(c.kernel_dbg & 1))
+        hipLaunchKernelGGL(k_grad_gather, dim3(grid_for(3 * c.nbr)), dim3(BLOCK), 0, c.stream, (const double*)P.gpool.p, (const uint32_t*)P.inc_start.p, (const uint32_t*)P.inc.p, c.nbr,
+                           c.grad.p);
+}
+template <class En, bool FULL>
+static void launch_tri_closed(Context& c, Potential& P, int mode)
+{
+    if (P.args.e_count == 0) return;
+    double* E = c.elemE.p + P.e_off;
+    const dim3 g(grid_for(P.args.e_count)), b(BLOCK);
+    if (mode == MISTARK_EVAL_P_G) hipLaunchKernelGGL((k_eval_tri_closed<En, FULL, false>), g, b, 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
+    else hipLaunchKernelGGL((k_eval_tri_closed<En, FULL, true>), g, b, 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
+    launch_grad_gather(c, P);
+}
 // EnergyBendingFlat in closed form (EnergyDiscreteShells.cpp:64-92): E = k coef / 2 |s|^2 with s = sum_i K_i (x0_i + dt v_i) is quadratic in
 // the velocities: dE/dv_i = k coef dt K_i s and d2E/dv_i dv_j = k coef dt^2 K_i K_j I3, a constant. One lane per hinge instead of the 78
 // hyper-dual evaluations of the generic kernel (0.30 -> 0.04 ms for the 196 k hinges of a 256 x 256 cloth); a lane writes the 72
@@ -440,6 +500,8 @@ static void launch_eval_kind(Context& c, Potential& P, int mode)
         if (P.name == E_TetStrain::name) { launch_tet_closed<E_TetStrain, true>(c, P, mode); return; }
         if (P.name == E_TetStrainEO::name) { launch_tet_closed<E_TetStrainEO, false>(c, P, mode); return; }
         if (P.name == E_BendingFlat::name) { launch_bending_flat(c, P, mode); return; }
+        if (P.name == E_TriangleStrain::name) { launch_tri_closed<E_TriangleStrain, true>(c, P, mode); return; }
+        if (P.name == E_TriangleStrainEO::name) { launch_tri_closed<E_TriangleStrainEO, false>(c, P, mode); return; }
     }
     int k = 0;
 #define X(En)                               \
@@ -1234,7 +1296,8 @@ void prepare(Context& c)
             P.n_pool_f = (P.n_key + 63) / 64 * 64;
             if (P.lazy_capable) hf_off += (size_t)P.n_pool_f * 9 * 10;
             // gradient pool + incidence lists (Potential::grad_gather)
-            P.grad_gather = P.lazy_capable && !P.conn_ext && !P.conn_host.empty() && !c.no_grad_gather;
+            const bool closed_tri = P.kind != KIND_CUSTOM && !c.force_generic && (P.name == E_TriangleStrain::name || P.name == E_TriangleStrainEO::name);
+            P.grad_gather = (P.lazy_capable || closed_tri) && !P.conn_ext && !P.conn_host.empty() && !c.no_grad_gather;
             std::vector<int64_t> sig{(int64_t)P.n_elem, c.nbr, (int64_t)P.n_key, (int64_t)P.conn_version, (int64_t)(c.world > 1 ? c.sh.version_lists : 0)};
             for (int k = 0; k < P.NB; k++) {
                 sig.push_back(A.dof_col[k]);
