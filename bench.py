@@ -185,7 +185,7 @@ def main():
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(int(os.environ.get("MISTARK_BENCH_DEVICE", local_rank)))
         dist.init_process_group(backend="gloo")
         box = [None]
         if rank == 0:
@@ -196,7 +196,9 @@ def main():
         dist.broadcast_object_list(box, src=0)
         uid = box[0]
 
-    sim = build_scene(S, nx, ny, nz, local_rank, a.scene)
+    # (MISTARK_BENCH_DEVICE: all ranks on one device — only to exercise the N > 1 launch path on a single-GPU box)
+    device = int(os.environ.get("MISTARK_BENCH_DEVICE", local_rank))
+    sim = build_scene(S, nx, ny, nz, device, a.scene)
     if world > 1:
         sim.set_dist_rccl(rank, world, uid)
 

@@ -8,8 +8,8 @@ W, n_newton, n_cg = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 rows = list(db.execute("select name, start, end from kernels order by start"))
 def sh(x): return x.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("mistark::", "")[:48]
 stages = {
-    "cg: spmv": ["k_spmv_fused"], "cg: step": ["k_pcg_step"], "cg: dir": ["k_pcg_dir"], "cg: fold partials": ["k_fold_partials"],
-    "cg/halo: pack+unpack": ["k_pack_rows", "k_unpack_ghosts"], "exchange (in-process copy kernel)": ["k_allgather_local"],
+    "cg: spmv": ["k_spmv_fused"], "cg: step": ["k_pcg_step"], "cg: dir (+ ghosts)": ["k_pcg_dir"], "cg: fold / fold + pack": ["k_fold_partials", "k_fold_pack"],
+    "halo (gradient): pack+unpack": ["k_pack_rows", "k_unpack_ghosts"], "exchange (in-process copy kernel)": ["k_allgather_local"],
     "eval tets": ["k_eval_tet_closed", "k_grad_gather"], "eval other": ["k_eval_pgh", "k_eval_p<", "k_fold_hot", "k_eval_custom"],
     "assembly": ["k_assemble"], "projection": ["k_project", "k_active_blocks"], "contact detection": ["k_contact", "k_bp_", "k_sweep", "k_table_bounds", "k_route"],
     "pattern (contact part)": ["k_keys", "k_heads", "k_slots", "k_rows", "k_chunk", "k_crow", "k_long_slots", "k_make_desc", "k_copy_u32"],

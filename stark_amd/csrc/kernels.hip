@@ -1510,7 +1510,13 @@ __global__ __launch_bounds__(BLOCK) void k_project_select_multi(const SelDesc* _
         if (!touch) return;
     }
     d.is_projected[le] = 1;
-    const unsigned long long idx = atomicAdd((unsigned long long*)&counters[d.counter], 1ull);
+    // the selected lanes of a wavefront (all of one potential: a workgroup belongs to one descriptor) append with ONE atomic
+    const unsigned long long sel = __ballot(1);
+    const int lane = threadIdx.x & 63, leader = __ffsll((long long)sel) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd((unsigned long long*)&counters[d.counter], (unsigned long long)__popcll(sel));
+    base = ((unsigned long long)(unsigned int)__shfl((int)(base >> 32), leader, 64) << 32) | (unsigned int)__shfl((int)base, leader, 64);
+    const unsigned long long idx = base + (unsigned long long)__popcll(sel & ((1ull << lane) - 1ull));
     d.list[idx] = (uint32_t)le;
     d.list_e[idx] = (uint32_t)e;
     // statistics: an element counts once, on the rank its energy counts on (energy_here)
@@ -1519,7 +1525,8 @@ __global__ __launch_bounds__(BLOCK) void k_project_select_multi(const SelDesc* _
         const int l = d.lrow[d.dof_row_off[0] + ce[d.dof_col[0]]];
         mine = l >= 0 && l < d.n_own;
     }
-    if (mine) atomicAdd((unsigned long long*)&counters[3], 1ull);
+    const unsigned long long m = __ballot(mine);
+    if (lane == leader && m) atomicAdd((unsigned long long*)&counters[3], (unsigned long long)__popcll(m));
 }
 
 // Pool addressing of the projection kernels: element e = list[li]; its blocks sit at H[(a*NB+b) * n_pool + pe], pe = e, or pe = li for a
@@ -1898,9 +1905,15 @@ __global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restric
     const bool act = !in || m >= thr;
     if (in) active[r] = act ? 1 : 0;
     const bool own = in && (!lrow || (lrow[r] >= 0 && lrow[r] < n_own));
-    // (one atomic per wavefront: 172 k atomics on one address took 34 us)
+    // (atomics on ONE address serialise at ~10 ns each: one per row took 34 us, one per wavefront still 30; one per workgroup)
+    __shared__ int s_cnt[BLOCK / 64];
     const unsigned long long inactive = __ballot(!act && own);
-    if ((threadIdx.x & 63) == 0 && inactive) atomicAdd((unsigned long long*)&counters[2], (unsigned long long)__popcll(inactive));
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(inactive);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int n = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (n) atomicAdd((unsigned long long*)&counters[2], (unsigned long long)n);
+    }
 }
 
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active, int64_t* n_projected_now,
@@ -3003,9 +3016,13 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
 }
 
 // ---- the same PCG on a row-sharded system (the three dot products of solve_pcg.h:180,201,217) ---------------------------------
-// Every rank holds its block rows of A and the matching parts of x, r, z, q; p also carries the ghost columns. Per iteration:
-//   ghosts of p from their owners | q = A p, partial p.q | all-gather of the ranks' p.q | k_pcg_step with the sum (rank order: the same bits
-//   everywhere) | all-gather of (r.r, r.z), fused in one exchange | k_pcg_dir
+// Every rank holds its block rows of A and the matching parts of x, r, z, q; p also carries the ghost columns. One iteration is TWO
+// exchanges (all-gathers on the engine's stream) and five launches:
+//   q = A p (ghosts of p are current), partial p.q | fold | all-gather of the ranks' p.q                                   [exchange 1: 8 bytes]
+//   k_pcg_step with the sum (every rank adds the W numbers in rank order: the same bits everywhere): x, r, z; partial r.r, r.z
+//   k_fold_pack: this rank's (r.r, r.z) and the z of the rows other ranks hold as ghosts, in one buffer | all-gather      [exchange 2]
+//   k_pcg_dir_sharded: sums, convergence test, beta; p = z + beta p on the rank's rows AND on its ghosts (their z has just arrived, their
+//   old p is here): the direction needs no exchange of its own
 // The control block is computed redundantly and identically by every rank, so all of them stop at the same iteration; the host reads it
 // every PCG_CHECK iterations. The solution is gathered into the global vector on every rank at the end.
 __global__ __launch_bounds__(BLOCK) void k_fold_partials(const double* __restrict__ a, int na, const double* __restrict__ b, int nb, double* __restrict__ out)
@@ -3016,6 +3033,100 @@ __global__ __launch_bounds__(BLOCK) void k_fold_partials(const double* __restric
     if (threadIdx.x == 0) {
         out[0] = sa;
         if (b) out[1] = sb;
+    }
+}
+// out = [sum a, sum b, z of the send rows (3 each)]: workgroup 0 folds, the others pack
+__global__ __launch_bounds__(BLOCK) void k_fold_pack(const double* __restrict__ a, const double* __restrict__ b, int n, const double* __restrict__ z, const int32_t* __restrict__ send_rows,
+                                                     int64_t n_send, double* __restrict__ out)
+{
+    if (blockIdx.x == 0) {
+        __shared__ double sm[4];
+        const double sa = sum_partials(a, n, sm);
+        const double sb = sum_partials(b, n, sm);
+        if (threadIdx.x == 0) {
+            out[0] = sa;
+            out[1] = sb;
+        }
+        return;
+    }
+    const int64_t t = (int64_t)(blockIdx.x - 1) * BLOCK + threadIdx.x;
+    if (t >= 3 * n_send) return;
+    const int64_t i = t / 3;
+    out[2 + t] = z[3 * (int64_t)send_rows[i] + (t - 3 * i)];
+}
+// ghosts of p from the gathered buffer (stride S doubles per rank: two scalars, then the rank's send rows): p_ghost = z_ghost + beta p_ghost
+__device__ __forceinline__ void ghosts_from_gathered(const double* __restrict__ recv, int64_t S, const int32_t* __restrict__ ghost_src, int64_t send_stride, int64_t n_ghost, int64_t n_own,
+                                                     double beta, double* __restrict__ p)
+{
+    for (int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x; t < 3 * n_ghost; t += (int64_t)gridDim.x * BLOCK) {
+        const int64_t g = t / 3, c = t - 3 * g;
+        const int64_t src = ghost_src[g], o = src / send_stride, pos = src - o * send_stride;
+        const double zg = recv[o * S + 2 + 3 * pos + c];
+        double* pg = p + 3 * (n_own + g) + c;
+        *pg = beta == 0.0 ? zg : zg + beta * *pg;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_pcg_init2_sharded(const double* __restrict__ recv, int W, int64_t S, double abs_tol, PcgCtrl* __restrict__ ctrl, const int32_t* __restrict__ ghost_src,
+                                                             int64_t send_stride, int64_t n_ghost, int64_t n_own, double* __restrict__ p)
+{
+    double bb = 0.0, rz = 0.0;
+    for (int r = 0; r < W; r++) {  // rank order: the same bits on every rank
+        bb += recv[r * S];
+        rz += recv[r * S + 1];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctrl->bb = bb;
+        ctrl->rz[1] = rz;
+        ctrl->rz[0] = 0.0;
+        ctrl->indef = 0;
+        ctrl->n_iter = 0;
+        ctrl->converged = 0;
+        ctrl->done = 0;
+        ctrl->error = 1.0;
+        if (bb < abs_tol * abs_tol) {
+            ctrl->done = 1;
+            ctrl->converged = 1;
+            ctrl->error = 0.0;
+        } else if (1.0 < abs_tol) {
+            ctrl->done = 1;
+            ctrl->converged = 1;
+        }
+    }
+    ghosts_from_gathered(recv, S, ghost_src, send_stride, n_ghost, n_own, 0.0, p);  // p_0 = z_0 on the ghosts too
+}
+__global__ __launch_bounds__(BLOCK) void k_pcg_dir_sharded(int k, double abs_tol, double rel_tol, const double* __restrict__ recv, int W, int64_t S, int64_t n, const double* __restrict__ z,
+                                                           double* __restrict__ p, PcgCtrl* __restrict__ ctrl, const int32_t* __restrict__ ghost_src, int64_t send_stride, int64_t n_ghost,
+                                                           int64_t n_own)
+{
+    const int done = ctrl->done;
+    if (done == 1) return;
+    if (done == 2) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->done = 1;
+        return;
+    }
+    double rr = 0.0, rz_new = 0.0;
+    for (int r = 0; r < W; r++) {
+        rr += recv[r * S];
+        rz_new += recv[r * S + 1];
+    }
+    const double error = sqrt(rr / ctrl->bb);
+    const bool conv = error < abs_tol || error / 1.0 < rel_tol;
+    if (conv) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            ctrl->error = error;
+            ctrl->n_iter = k;
+            ctrl->converged = 1;
+            ctrl->done = 1;
+        }
+        return;
+    }
+    const double beta = rz_new / ctrl->rz[k & 1];
+    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) p[i] = z[i] + beta * p[i];
+    ghosts_from_gathered(recv, S, ghost_src, send_stride, n_ghost, n_own, beta, p);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctrl->rz[(k + 1) & 1] = rz_new;
+        ctrl->error = error;
+        ctrl->n_iter = k;
     }
 }
 static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
@@ -3032,17 +3143,23 @@ static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, do
     double* part_rz = c.partials.p + 2 * MAX_PARTIALS;
     double* part_bb = c.partials.p + 3 * MAX_PARTIALS;
     c.xl.ensure(3 * (size_t)std::max<int64_t>(S.n_loc, 1));
-    c.dist_scalar.ensure(8 + 2 * (size_t)W + 2 * (size_t)W);
-    double* mine = c.dist_scalar.p;                   // [2]
-    double* all1 = c.dist_scalar.p + 8;               // [W]
-    double* all2 = c.dist_scalar.p + 8 + W;           // [2 W]
-    double* b_l = c.tmp_a.p == rhs_global ? c.tmp_b.p : c.tmp_a.p;  // local right-hand side (any scratch vector but the caller's)
+    const int64_t SS = 2 + 3 * S.send_stride;  // doubles per rank in the second exchange
+    c.dist_scalar.ensure(8 + (size_t)W + (size_t)SS * (size_t)(W + 1));
+    double* mine1 = c.dist_scalar.p;                    // [1]
+    double* all1 = c.dist_scalar.p + 8;                 // [W]
+    double* mine2 = c.dist_scalar.p + 8 + W;            // [SS]
+    double* all2 = mine2 + SS;                          // [W * SS]
     if (rhs_global == c.tmp_b.p) throw Error("pcg: right-hand side in a scratch vector the sharded solve needs");
+    double* b_l = c.tmp_b.p;  // local right-hand side
     shard_to_local(c, rhs_global, b_l, false);
+    const int g_pack = 1 + grid_for(std::max<int64_t>(3 * S.n_send, 1));
+    const int g_dir = std::max(gv, grid_for(std::max<int64_t>(3 * S.n_ghost, 1), BLOCK, VEC_GRID));
+    if (3 * S.n_send < SS - 2) MS_CHECK(hipMemsetAsync(mine2, 0, (size_t)SS * sizeof(double), c.stream));  // (padding of the shorter send lists)
     hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(BLOCK), 0, c.stream, (const double*)b_l, c.dinv.p, n_own, c.xl.p, c.r.p, c.z.p, c.p.p, part_bb, part_rz);
-    hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)part_bb, gv, (const double*)part_rz, gv, mine);
-    c.coll->allgather_f64(mine, all2, 2, c.stream);
-    hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)all2, (const double*)(all2 + 1), W, abs_tol, c.ctrl.p, 2);
+    hipLaunchKernelGGL(k_fold_pack, dim3(g_pack), dim3(BLOCK), 0, c.stream, (const double*)part_bb, (const double*)part_rz, gv, (const double*)c.z.p, (const int32_t*)S.send_rows.p, S.n_send, mine2);
+    c.coll->allgather_f64(mine2, all2, (size_t)SS, c.stream);
+    hipLaunchKernelGGL(k_pcg_init2_sharded, dim3(g_dir), dim3(BLOCK), 0, c.stream, (const double*)all2, W, SS, abs_tol, c.ctrl.p, (const int32_t*)S.ghost_src.p, S.send_stride, S.n_ghost, n_own,
+                       c.p.p);
     constexpr int PCG_CHECK = 8;
     PcgCtrl h{};
     int k = 1;
@@ -3050,16 +3167,17 @@ static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, do
     while (!finished) {
         const int k_end = std::min(max_iter, k + PCG_CHECK - 1);
         for (; k <= k_end; k++) {
-            shard_halo(c, c.p.p);
             const int gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false);
-            hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)part_pq, gs, (const double*)nullptr, 0, mine);
-            c.coll->allgather_f64(mine, all1, 1, c.stream);
+            hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)part_pq, gs, (const double*)nullptr, 0, mine1);
+            c.coll->allgather_f64(mine1, all1, 1, c.stream);
             hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, (const double*)all1, W, c.dinv.p, n_own, c.p.p, c.q.p, c.xl.p, c.r.p, c.z.p, part_rr,
                                part_rz, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : nullptr, (const uint32_t*)m1.row_chunk0.p, (const double*)m1.yd.p,
                                (const double*)m1.chunk_partial.p);
-            hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)part_rr, gv, (const double*)part_rz, gv, mine);
-            c.coll->allgather_f64(mine, all2, 2, c.stream);
-            hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, (const double*)all2, (const double*)(all2 + 1), W, 3 * n_own, c.z.p, c.p.p, c.ctrl.p, 2);
+            hipLaunchKernelGGL(k_fold_pack, dim3(g_pack), dim3(BLOCK), 0, c.stream, (const double*)part_rr, (const double*)part_rz, gv, (const double*)c.z.p, (const int32_t*)S.send_rows.p, S.n_send,
+                               mine2);
+            c.coll->allgather_f64(mine2, all2, (size_t)SS, c.stream);
+            hipLaunchKernelGGL(k_pcg_dir_sharded, dim3(g_dir), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, (const double*)all2, W, SS, 3 * n_own, (const double*)c.z.p, c.p.p, c.ctrl.p,
+                               (const int32_t*)S.ghost_src.p, S.send_stride, S.n_ghost, n_own);
         }
         fetch(c, &h, c.ctrl.p, sizeof(PcgCtrl));
         finished = h.done || k > max_iter;

@@ -3,8 +3,9 @@ oracle. The block rows are partitioned by the engine's own graph partition (mist
 evaluates ONLY the elements touching its rows, and then
   * the energies of the elements whose first block row a rank owns, all-gathered and summed in rank order, give the unsharded energy;
   * a rank's gradient rows and matrix rows are complete without any exchange (interface elements are evaluated by both sides);
-  * the row-sharded block-Jacobi PCG — ghosts of p from their owners, p.Ap all-gathered, (r.r, r.z) fused in one all-gather, every rank
-    reducing in rank order — stops at the unsharded solve's iteration (+-1) with the same solution, identical bits on both ranks.
+  * the row-sharded block-Jacobi PCG — two exchanges per iteration: p.Ap, and (r.r, r.z) fused with the z of the interface rows, from
+    which every rank advances the ghosts of the search direction itself; every rank reducing in rank order — stops at the unsharded
+    solve's iteration (+-1) with the same solution, identical bits on both ranks.
 The GPU kernels of the same path are covered by tests/test_gpu_sharded.py (2, 3 and 8 ranks)."""
 import ctypes as C
 import os
@@ -105,12 +106,19 @@ def _rank_main(rank, world, port, name, result_dir):
     ghost_src = owner[ghosts] * stride + pos_in_send[ghosts]
     assert (pos_in_send[ghosts] >= 0).all()
 
-    def halo(v_loc):  # ghosts of a local vector from their owners: one all-gather of the padded send rows
-        buf = torch.zeros(3 * stride, dtype=torch.float64)
-        mine_send = v_loc.reshape(-1, 3)[lrow[send_of[rank]]].reshape(-1)
-        buf[:len(mine_send)] = torch.tensor(mine_send)
-        allv = torch.cat(allgather(buf)).numpy().reshape(-1, 3)
-        v_loc.reshape(-1, 3)[n_own:] = allv[ghost_src]
+    def exchange2(partials, z_loc):
+        """The second exchange of an iteration, as the engine packs it (k_fold_pack): this rank's two partial sums and the z of the rows
+        other ranks hold as ghosts, in ONE all-gather. Returns the sums (reduced in rank order) and the ghosts' z."""
+        buf = torch.zeros(2 + 3 * stride, dtype=torch.float64)
+        buf[0], buf[1] = partials
+        mine_send = z_loc.reshape(-1, 3)[lrow[send_of[rank]]].reshape(-1)
+        buf[2:2 + len(mine_send)] = torch.tensor(mine_send)
+        allb = torch.stack(allgather(buf)).numpy()
+        sums = np.zeros(2)
+        for r in range(world):
+            sums += allb[r, :2]
+        zg = allb[:, 2:].reshape(world * stride, 3)[ghost_src]
+        return sums, zg
 
     # my rows of A in local columns
     Aown = A_loc[rows_own].tocoo()
@@ -134,26 +142,28 @@ def _rank_main(rank, world, port, name, result_dir):
     r = b.copy()
     zv = ev.apply_preconditioner(dinv, r)
     p = np.zeros(3 * n_loc)
+    (bb, rz), zg = exchange2([float(r @ r), float(r @ zv)], zv)
     p[:3 * n_own] = zv
-    bb, rz = gsum([float(r @ r), float(r @ zv)])
+    p[3 * n_own:] = zg.reshape(-1)                            # p_0 = z_0, on the ghosts too
     its, converged = 0, bb < abs_tol * abs_tol
     while not converged and its < 10000:
         its += 1
-        halo(p)
-        q = A_l @ p
-        (pAp,) = gsum([float(p[:3 * n_own] @ q)])
+        q = A_l @ p                                           # (the ghosts of p are current: no exchange of p itself)
+        (pAp,) = gsum([float(p[:3 * n_own] @ q)])             # exchange 1: one number per rank
         if pAp <= 0.0:
             break
         alpha = rz / pAp
         x += alpha * p[:3 * n_own]
         r -= alpha * q
         zv = ev.apply_preconditioner(dinv, r)
-        rr, rz_new = gsum([float(r @ r), float(r @ zv)])    # (r.r, r.z) fused in one exchange
+        (rr, rz_new), zg = exchange2([float(r @ r), float(r @ zv)], zv)   # exchange 2: (r.r, r.z) and the boundary z, fused
         err = np.sqrt(rr / bb)
         if err < abs_tol or err < rel_tol:
             converged = True
             break
-        p[:3 * n_own] = zv + (rz_new / rz) * p[:3 * n_own]
+        beta = rz_new / rz
+        p[:3 * n_own] = zv + beta * p[:3 * n_own]
+        p[3 * n_own:] = zg.reshape(-1) + beta * p[3 * n_own:]  # the owner computes exactly this for the same row: no exchange needed
         rz = rz_new
     # gather the owned parts into the whole solution on every rank
     pad = max(int((owner == q_).sum()) for q_ in range(world))

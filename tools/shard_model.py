@@ -50,4 +50,5 @@ for e in err:
 for r, o in enumerate(out):
     print("rank %d: rows %d ghosts %d send rows %d elements evaluated %d matrix blocks %d + %d | %d Newton its, %d solves, %d CG its, %.3f s" % (
         r, *o["info"], o["newton"], o["n_ls"], o["n_cg"], o["dt"]))
+print("TOTALS %d %d" % (sum(o["newton"] for o in out) + 4 * W, sum(o["n_cg"] for o in out)))
 print("W=%d: %.1f Newton-steps/s with all ranks serialised on one GPU (not a scaling figure)" % (W, out[0]["newton"] / max(o["dt"] for o in out)))
