@@ -136,8 +136,9 @@ static stark::Settings base_settings(const Args& a, const std::string& name)
     settings.output.simulation_name = name;
     settings.output.output_directory = a.s("outdir", "/tmp/mistark_oracle_out");
     settings.output.codegen_directory = a.s("codegen", "/tmp/mistark_oracle_codegen");
-    settings.output.enable_frame_writes = false;
-    settings.output.enable_output = a.i("verbose", 0) != 0;
+    settings.output.enable_frame_writes = a.i("frames", 0) != 0;  // mode `frames`: the reference writes its VTK frames (one per time step at fps = 30)
+    if (a.i("frames", 0) != 0) settings.output.fps = 30;
+    settings.output.enable_output = a.i("verbose", 0) != 0 || a.i("frames", 0) != 0;
     settings.output.console_verbosity = symx::Verbosity::Summary;
     settings.output.file_verbosity = symx::Verbosity::Minimal;
     settings.execution.n_threads = a.i("threads", 1);
@@ -1078,6 +1079,13 @@ int main(int argc, char** argv)
         perturb_dofs(st, a.d("amp", 0.05));
         st.callbacks->newton->run_before_energy_evaluation();
         dump_snapshot(sc, a.s("out", "/tmp/mistark_fixture"), a);
+        return 0;
+    }
+    if (mode == "frames") {
+        // frame files exactly as the reference writes them (DeformablesMeshOutput / RigidBodiesMeshOutput through Stark::_write_frame,
+        // Stark.cpp:314-338): the initial frame and one per time step; also the YAML log (Logger::save_to_disk) and the run summary
+        for (int s = 0; s < steps; s++) sc.step();
+        st.print();
         return 0;
     }
     if (mode == "slimdump") {

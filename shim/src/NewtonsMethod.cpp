@@ -266,8 +266,8 @@ namespace symx
 		this->stats.projected_hessians_ratio = st.projected_hessians_ratio;
 		// the series the reference logs per solve (NewtonsMethod.cpp:236-251): STARK's console line and YAML output read them
 		auto& lg = *this->context->logger;
-		lg.add_and_append("n_hessians", (int)st.n_hessians);
-		lg.add_and_append("n_projected_hessians", (int)st.n_projected_hessians);
+		lg.add_and_append("n_hessians", (double)st.n_hessians);
+		lg.add_and_append("n_projected_hessians", (double)st.n_projected_hessians);
 		lg.add_and_append("projected_hessians_ratio", st.projected_hessians_ratio);
 		lg.add_and_append("cg_iterations", st.cg_iterations);
 		lg.add_and_append("newton_iterations", st.newton_iterations);

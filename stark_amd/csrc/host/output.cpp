@@ -91,6 +91,11 @@ void MeshOutput::add_triangle_mesh(const std::string& label, const PointSetHandl
 {
     add(label, 3, set.get_idx(), -1, {}, conn.empty() ? nullptr : conn[0].data(), conn.size());
 }
+void MeshOutput::add_triangle_mesh(const std::string& label, const PointSetHandler& set, const std::vector<std::array<int, 3>>& conn, const std::vector<int>& point_set_map)
+{
+    add(label, 3, set.get_idx(), -1, {}, conn.empty() ? nullptr : conn[0].data(), conn.size());
+    meshes.back().point_set_map = point_set_map;
+}
 void MeshOutput::add_tet_mesh(const std::string& label, const PointSetHandler& set, const std::vector<std::array<int, 4>>& conn)
 {
     add(label, 4, set.get_idx(), -1, {}, conn.empty() ? nullptr : conn[0].data(), conn.size());
@@ -112,7 +117,9 @@ void MeshOutput::_write_frame()
         std::vector<int> conn;
         for (const Mesh* m : g.second) {
             const int off = (int)V.size();
-            if (m->point_set >= 0) {
+            if (m->point_set >= 0 && !m->point_set_map.empty()) {
+                for (int loc : m->point_set_map) V.push_back(dyn->x1[dyn->get_begin(m->point_set) + loc]);
+            } else if (m->point_set >= 0) {
                 for (int i = dyn->get_begin(m->point_set); i < dyn->get_end(m->point_set); i++) V.push_back(dyn->x1[i]);
             } else {
                 for (const Vec3& x : m->local_vertices) V.push_back(rb->get_position_at(m->rigid_body, x));

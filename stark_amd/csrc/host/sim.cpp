@@ -880,13 +880,13 @@ Volume::Handler DeformablesPresets::add_volume(const std::string& label, const s
     auto inertia = deformables->lumped_inertia->add(ps, T, p.inertia);
     auto strain = deformables->tet_strain->add(ps, T, p.strain);
     ContactHandler contact;
-    if (interactions->contact->is_active()) {
-        std::vector<std::array<int, 3>> surface;
-        std::vector<int> tri_to_tet_map;
-        find_surface(surface, tri_to_tet_map, V, T);
-        contact = interactions->contact->add_triangles(ps, surface, tri_to_tet_map, p.contact);
-    }
-    if (!label.empty() && interactions->output) interactions->output->add_tet_mesh(label, ps, T);
+    std::vector<std::array<int, 3>> surface;
+    std::vector<int> tri_to_tet_map;
+    const bool with_output = !label.empty() && interactions->output;
+    if (interactions->contact->is_active() || with_output) find_surface(surface, tri_to_tet_map, V, T);
+    if (interactions->contact->is_active()) contact = interactions->contact->add_triangles(ps, surface, tri_to_tet_map, p.contact);
+    // the frame of a volume is its surface with the surface's own vertices (DeformablesPresets.cpp:74-76)
+    if (with_output) interactions->output->add_triangle_mesh(label, ps, surface, tri_to_tet_map);
     return {ps, inertia, strain, contact};
 }
 Volume::VCH DeformablesPresets::add_volume_grid(const std::string& label, const Vec3& dim, const std::array<int, 3>& sub, const Volume::Params& p)

@@ -682,6 +682,9 @@ public:
     void add_point_set(const std::string& label, const PointSetHandler& set);
     void add_segment_mesh(const std::string& label, const PointSetHandler& set, const std::vector<std::array<int, 2>>& conn);
     void add_triangle_mesh(const std::string& label, const PointSetHandler& set, const std::vector<std::array<int, 3>>& conn);
+    // triangles in the numbering of a vertex subset (point_set_map: local vertex -> index in the point set): the surface of a volume, written
+    // with its own vertices only (DeformablesMeshOutput.cpp:49-60, DeformablesPresets.cpp:74-76)
+    void add_triangle_mesh(const std::string& label, const PointSetHandler& set, const std::vector<std::array<int, 3>>& conn, const std::vector<int>& point_set_map);
     void add_tet_mesh(const std::string& label, const PointSetHandler& set, const std::vector<std::array<int, 4>>& conn);
     void add_triangle_mesh(const std::string& label, const RigidBodyHandler& rb, const std::vector<Vec3>& local_vertices, const std::vector<std::array<int, 3>>& conn);
     int frames_written = 0;
@@ -694,6 +697,7 @@ private:
         int point_set = -1, rigid_body = -1;
         std::vector<Vec3> local_vertices;  // rigid bodies
         std::vector<int> conn;
+        std::vector<int> point_set_map;    // non-empty: the mesh uses these points of the set only, in this order
     };
     Stark& stark;
     spPointDynamics dyn;

@@ -76,6 +76,8 @@ FIXTURES = {
     "slim_cfg3_blockbox_44x44x43": ("slimdump", "blockbox", "nx=44 ny=44 nz=43 L=1 gap=0.0015 thickness=0.001 mu=0.5 kmin=1e8 bx=3 bz=0.1 boxfirst=1 threads=8 steps=0 amp=0.01 xamp=2e-4"),
     "slim_cfg2_clothbox_256": ("slimdump", "clothbox", "n=256 size=1 box=2 gap=0.0015 thickness=0.001 mu=0.5 threads=8 steps=0 amp=0.005 xamp=2e-4"),
     "slim_cfg4_mixed_26x26x25": ("slimdump", "mixed", "threads=8 steps=0 amp=0.01 xamp=2e-4"),
+    # what the reference WRITES for a run: its VTK frames, its YAML log and its run summary (tet beam, 2 time steps)
+    "frames_tetbeam_4x1x1": ("frames", "tetbeam", "nx=4 ny=1 nz=1 eo=0 steps=2 frames=1"),
     # contact scenes (cfg 1 / cfg 4 at fixture size): cloth resting on a fixed rigid box, soft block pressed on a fixed rigid box
     "traj_clothbox_8": ("traj", "clothbox", "n=8 gap=0.004 steps=4"),
     "traj_blockbox_3": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=1"),
@@ -93,10 +95,14 @@ def pack(name):
     args = args.split()
     tmp = tempfile.mkdtemp(prefix="mistark_fx_")
     try:
-        scene_args = [a for a in args if not a.startswith(("steps=", "amp=", "xamp="))]
+        scene_args = [a for a in args if not a.startswith(("steps=", "amp=", "xamp=", "frames="))]
         if mode != "geom":
             run([HARNESS, "prime", scene] + scene_args)
-        run([HARNESS, mode, scene] + args + ["out=" + tmp])
+        if mode == "frames":
+            out = subprocess.run([HARNESS, mode, scene] + args + ["outdir=" + tmp], check=True, capture_output=True).stdout
+            open(os.path.join(tmp, "console.txt"), "wb").write(out)
+        else:
+            run([HARNESS, mode, scene] + args + ["out=" + tmp])
         data = {}
         for fn in sorted(os.listdir(tmp)):
             p = os.path.join(tmp, fn)
@@ -104,6 +110,9 @@ def pack(name):
                 data[fn[:-4]] = np.load(p)
                 if mode == "slimdump" and fn.startswith("spmv_y"):
                     data[fn[:-4]] = data[fn[:-4]][::4].astype(np.float32)
+            elif mode == "frames" and fn.endswith((".vtk", ".yaml", ".txt")):
+                key = fn.replace(".", "_") if not fn.endswith(".yaml") else "log_yaml"
+                data[key] = np.frombuffer(open(p, "rb").read(), dtype=np.uint8)
             elif fn.endswith(".json"):
                 txt = open(p).read()
                 json.loads(txt)  # validate

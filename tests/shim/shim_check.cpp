@@ -13,11 +13,15 @@ int main(int argc, char** argv)
     const std::string scene = argc > 1 ? argv[1] : "blockbox";
     const int steps = argc > 2 ? std::atoi(argv[2]) : 1;
     stark::Settings settings = stark::Settings();
-    settings.output.simulation_name = "shim_check";
     settings.output.output_directory = "/tmp/mistark_shim_out";
     settings.output.codegen_directory = "/tmp/mistark_shim_codegen";
-    settings.output.enable_frame_writes = false;
-    settings.output.enable_output = false;
+    // argv[4]: an output directory; the reference then writes its frames (VTK), its YAML log and its run summary there, fed by the shim
+    const bool with_output = argc > 4;
+    if (with_output) settings.output.output_directory = argv[4];
+    settings.output.simulation_name = with_output ? scene : "shim_check";
+    settings.output.enable_frame_writes = with_output;
+    settings.output.enable_output = with_output;
+    settings.output.fps = 30;
     settings.execution.n_threads = 1;
     settings.simulation.init_frictional_contact = scene == "blockbox" || scene == "mixed";
     stark::Simulation sim(settings);
@@ -77,6 +81,7 @@ int main(int argc, char** argv)
     }
     for (int s = 0; s < steps; s++) sim.run_one_time_step();
     std::cout << "shim_check: " << steps << " step(s) of '" << scene << "' done" << std::endl;
+    if (with_output) sim.get_stark().print();  // run summary + final YAML log (Stark.cpp:254-282)
     if (argc > 3) {
         // what the run produced: Newton iterations per solve (the series the shim logs like the reference, NewtonsMethod.cpp:249) and the
         // positions of all points

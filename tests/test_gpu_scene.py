@@ -691,3 +691,99 @@ def test_unmodified_reference_runs_on_the_engine_through_the_shim(scene, tmp_pat
     sim.close()
     assert ref["newton_iterations"] == its
     assert np.abs(np.array(ref["x"]) - x).max() <= 1e-6 * max(1.0, np.abs(x).max())
+
+
+def _read_vtk(raw):
+    """Legacy binary VTK unstructured grid -> (points float32 [n, 3], cell rows [m, 1 + nodes], cell types [m])."""
+    head, rest = raw.split(b"POINTS ", 1)
+    assert head.startswith(b"# vtk DataFile Version") and b"BINARY" in head and b"UNSTRUCTURED_GRID" in head
+    n = int(rest.split(b" ", 1)[0])
+    data = rest.split(b"\n", 1)[1]
+    pts = np.frombuffer(data[:12 * n], dtype=">f4").reshape(n, 3)
+    cells = data[12 * n:].split(b"CELLS ", 1)[1]
+    m, size = [int(v) for v in cells.split(b"\n", 1)[0].split()]
+    body = cells.split(b"\n", 1)[1]
+    conn = np.frombuffer(body[:4 * size], dtype=">i4").reshape(m, size // m)
+    types = body[4 * size:].split(b"CELL_TYPES ", 1)[1]
+    k = int(types.split(b"\n", 1)[0])
+    ct = np.frombuffer(types.split(b"\n", 1)[1][:4 * k], dtype=">i4")
+    return pts, conn, ct
+
+
+def _yaml_accumulators(txt):
+    import re
+
+    acc = txt.split("accumulators:", 1)[1].split("timers:", 1)[0]
+    return {k: float(v) for k, v in re.findall(r'"([^"]+)":\s*([-0-9.e+]+)', acc)}
+
+
+def test_frames_match_reference_written_frames(tmp_path):
+    """the frames the reference WROTE for the tet beam (tests/golden/frames_tetbeam_4x1x1.npz: its VTK files, byte for byte as
+    DeformablesMeshOutput produced them: the SURFACE of the volume with the surface's own vertices) against the frames of the host mirror's
+    writer for the same run: same file names, point / cell counts and cell types, the same triangles as coordinate triples (same winding),
+    identical in frame 0, within the solver tolerance in frame 1 (after a solve)."""
+    from stark_amd import sim as S
+
+    z = np.load(os.path.join(GOLDEN, "frames_tetbeam_4x1x1.npz"))
+    st = S.default_settings()
+    st.init_frictional_contact = 0
+    st.enable_frame_writes = 1
+    st.fps = 30
+    st.output_directory = str(tmp_path).encode()
+    st.simulation_name = b"tetbeam"
+    sim = S.Simulation(st)
+    ps = sim.add_volume_grid("beam", (0.0, 0.0, 0.0), (4.0, 1.0, 1.0), (4, 1, 1), S.soft_rubber())
+    sim.prescribe_inside_aabb(ps, (-2.0, 0.0, 0.0), (2e-3, 2.0, 2.0), 1e7)
+    for _ in range(2):
+        assert sim.run_one_step()
+    sim.close()
+    ref_files = sorted(k[:-4] + ".vtk" for k in z.files if k.endswith("_vtk"))
+    assert sorted(f for f in os.listdir(tmp_path) if f.endswith(".vtk")) == ref_files
+    def triangles(pts, conn):
+        # cells as coordinate triples, every triangle rotated to start at its smallest corner (winding kept), rows sorted: the reference
+        # numbers the surface's vertices and orders its triangles by find_surface's hash order
+        t = pts[conn[:, 1:]].astype(np.float64)                       # [m, 3, 3]
+        key = np.lexsort((t[:, :, 2], t[:, :, 1], t[:, :, 0]), axis=1)[:, 0]
+        t = np.stack([np.roll(t[i], -key[i], axis=0) for i in range(len(t))]).reshape(len(t), 9)
+        return t[np.lexsort(t.T[::-1])]
+
+    for f in ref_files:
+        rp, rc, rt = _read_vtk(bytes(z[f[:-4] + "_vtk"]))
+        op, oc, ot = _read_vtk(open(os.path.join(tmp_path, f), "rb").read())
+        assert op.shape == rp.shape and oc.shape == rc.shape and (ot == rt).all() and (oc[:, 0] == rc[:, 0]).all(), f
+        tol = 0.0 if f.endswith("_0.vtk") else 1e-5
+        assert np.abs(triangles(op, oc) - triangles(rp, rc)).max() <= tol, f
+
+
+def test_reference_writes_its_own_log_and_frames_through_the_shim(tmp_path):
+    """The other half of 8(f)-3: with the shim the reference's OWN Stark.cpp / Logger / mesh writers produce the console line, the YAML log,
+    the run summary and the frames (Stark.cpp:172-207,254-282; NewtonsMethod.cpp:643-718 restated in shim/src/NewtonsMethod.cpp) from what the
+    engine reports. Against what the reference wrote when it solved on the CPU: the same accumulators (Newton / CG iteration totals,
+    element Hessians evaluated, time steps), the same summary rows, the same frames."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "shim_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_check not built")
+    z = np.load(os.path.join(GOLDEN, "frames_tetbeam_4x1x1.npz"))
+    out = str(tmp_path / "run.json")
+    r = subprocess.run([exe, "tetbeam", "2", out, str(tmp_path)], capture_output=True, timeout=600)
+    assert r.returncode == 0, (r.stdout.decode()[-1500:], r.stderr.decode()[-1500:])
+    console = r.stdout.decode()
+    ref_console = bytes(z["console_txt"]).decode()
+    # the per-step console line of Stark.cpp:183-189 and the "Solve" block of the summary
+    assert console.count("#newton:") == ref_console.count("#newton:") == 2
+    for row in ("Newton iterations", "CG iterations", "Line search bt", "Projected hessians"):
+        ours = [l for l in console.splitlines() if l.strip().startswith(row)]
+        ref = [l for l in ref_console.splitlines() if l.strip().startswith(row)]
+        assert ours and ours[0].split()[:len(row.split()) + 1] == ref[0].split()[:len(row.split()) + 1], (row, ours, ref)
+    ya = [f for f in os.listdir(tmp_path) if f.endswith(".yaml")]
+    assert len(ya) == 1
+    acc = _yaml_accumulators(open(os.path.join(tmp_path, ya[0])).read())
+    ref_acc = _yaml_accumulators(bytes(z["log_yaml"]).decode())
+    for k in ("newton_iterations", "cg_iterations", "n_hessians", "n_projected_hessians", "time_steps", "ls_bt", "ls_inv"):
+        assert acc[k] == ref_acc[k], (k, acc[k], ref_acc[k])
+    for f in sorted(k[:-4] + ".vtk" for k in z.files if k.endswith("_vtk")):
+        rp, rc, rt = _read_vtk(bytes(z[f[:-4] + "_vtk"]))
+        op, oc, ot = _read_vtk(open(os.path.join(tmp_path, f), "rb").read())
+        assert (oc == rc).all() and (ot == rt).all() and np.abs(op - rp).max() <= (0.0 if f.endswith("_0.vtk") else 1e-5), f
