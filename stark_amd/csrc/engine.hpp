@@ -311,6 +311,12 @@ struct Context
     DevBuf<uint8_t> cub_tmp;
     DevBuf<float> dinv;             // 9 floats per block row
     DevBuf<double> dense;           // DirectLLT: the matrix as a dense column-major array (small systems only)
+    // DirectLLT beyond that: block-tridiagonal Cholesky of the RCM-ordered matrix (direct.hip)
+    DevBuf<double> llt_D, llt_S, llt_y;
+    DevBuf<int32_t> llt_perm;
+    DevBuf<int> llt_info;
+    int llt_mb = 0;
+    uint64_t pattern_version = 1, llt_pattern_version = 0;  // bumped by every pattern build
     bool have_matrix = false;
     bool matrix_current = false;    // the assembled matrix reflects the current element Hessians
     DevBuf<uint32_t> proj_list;     // element ids selected for projection (per potential, at e_off)

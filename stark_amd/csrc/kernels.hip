@@ -1047,6 +1047,7 @@ static void build_aligned(Context& c, BsrPart& m)
 static void build_pattern(Context& c, int part)
 {
     BsrPart& m = c.part[part];
+    c.pattern_version++;
     size_t nk = 0;
     for (auto& P : c.pots) {
         if (P.part != part) continue;

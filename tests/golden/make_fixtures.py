@@ -56,6 +56,9 @@ FIXTURES = {
     "traj_cloth_flat_8": ("traj", "cloth", "n=8 flat=1 eo=0 steps=3"),
     # the same beam with the reference's DirectLLT linear solver (exact Newton steps)
     "traj_tetbeam_llt_6x2x2": ("traj", "tetbeam", "nx=6 ny=2 nz=2 eo=1 steps=3 solver=llt"),
+    # DirectLLT beyond the one-workgroup dense path (> 3072 unknowns: block-tridiagonal Cholesky): a 6 000-tet beam and configs[1] at full size
+    "traj_tetbeam_llt_20x5x5": ("traj", "tetbeam", "nx=20 ny=5 nz=5 eo=0 steps=3 slim=1 solver=llt threads=8"),
+    "traj_cfg1_tetbeam_llt_52x13x13": ("traj", "tetbeam", "nx=52 ny=13 nz=13 eo=0 steps=1 slim=1 solver=llt threads=8"),
     # configs[1] at FULL size (105 k tets, Soft_Rubber with damping + strain limiting, clamped end, no contact) and a mid-size configs[3]
     # (12 k-tet block on a fixed box, contact + friction): step log and final state only
     "traj_cfg1_tetbeam_52x13x13": ("traj", "tetbeam", "nx=52 ny=13 nz=13 eo=0 steps=3 slim=1 threads=8"),

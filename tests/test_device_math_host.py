@@ -5,6 +5,7 @@ energies / gradients / Hessians of the unmodified reference. The GPU tests (-m g
 import ctypes
 import glob
 import os
+import sys
 import subprocess
 import tempfile
 
@@ -15,7 +16,10 @@ from oracle import evaluator as ev
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-DUMPS = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "geometry" not in os.path.basename(p) and "_cfg" not in os.path.basename(p))  # (traj_cfg*: step log + final state only, scene tests)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fixture_list import stage_dumps  # noqa: E402
+
+DUMPS = stage_dumps()
 ELEMENT_TOL = {"EnergyDiscreteShells": 1e-8}  # see tests/test_oracle_golden.py
 
 

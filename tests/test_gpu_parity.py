@@ -8,6 +8,7 @@ within 10*rel_tol; Newton on contact-free scenes: identical iteration counts, ev
 import glob
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -18,7 +19,10 @@ from oracle import evaluator as ev
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-DUMPS = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "geometry" not in os.path.basename(p) and "_cfg" not in os.path.basename(p))  # (traj_cfg*: step log + final state only, scene tests)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fixture_list import stage_dumps  # noqa: E402
+
+DUMPS = stage_dumps()
 ELEMENT_TOL = {"EnergyDiscreteShells": 1e-8}  # ill-conditioned acos near 1, see tests/test_oracle_golden.py
 
 

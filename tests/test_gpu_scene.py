@@ -48,14 +48,17 @@ def test_tetbeam_scene_trajectory():
     sim.close()
 
 
-def test_tetbeam_direct_llt_trajectory():
-    """symx::LinearSolver::DirectLLT (NewtonsMethod.cpp:395-418; a dense device Cholesky here): the reference's trajectory of the beam with
-    exact Newton steps: same iteration counts (one per step). Positions to 5e-7: the Hessian is stored in float on both sides but summed
-    in a different order (float rounding of A), and a single Newton step per time step does not correct that."""
+@pytest.mark.parametrize("name", ["traj_tetbeam_llt_6x2x2", "traj_tetbeam_llt_20x5x5", "traj_cfg1_tetbeam_llt_52x13x13"])
+def test_tetbeam_direct_llt_trajectory(name):
+    """symx::LinearSolver::DirectLLT (NewtonsMethod.cpp:395-418, Eigen::SimplicialLLT in the reference): the reference's trajectory of the
+    beam with exact Newton steps: same iteration counts. Up to 3072 unknowns a dense Cholesky in one workgroup (6x2x2), beyond that the
+    block-tridiagonal Cholesky of the RCM-ordered matrix on rocSOLVER / rocBLAS (20x5x5: 3 768 unknowns; configs[1] at full size: 57 528).
+    Positions to 5e-7: the Hessian is stored in float on both sides but summed in a different order (float rounding of A), and a single
+    Newton step per time step does not correct that."""
     from stark_amd import capi
     from stark_amd import sim as S
 
-    z, traj, man = _load("traj_tetbeam_llt_6x2x2")
+    z, traj, man = _load(name)
     sc = traj["scene"]
     st = S.default_settings()
     st.newton.linear_solver = 1  # MISTARK_SOLVER_DIRECT_LLT
@@ -77,13 +80,16 @@ def test_tetbeam_direct_llt_trajectory():
     sim.close()
 
 
-def test_direct_llt_refuses_large_systems():
+def test_direct_llt_refuses_systems_beyond_its_memory_limit(monkeypatch):
+    """The dense blocks of the band are checked against MISTARK_DIRECT_MAX_GB before anything is allocated: an explicit error, not a switch
+    of solver."""
     from stark_amd import sim as S
 
+    monkeypatch.setenv("MISTARK_DIRECT_MAX_GB", "0.001")
     st = S.default_settings()
     st.newton.linear_solver = 1
     sim = S.Simulation(st)
-    sim.add_volume_grid("beam", (0, 0, 0), (4, 1, 1), (24, 6, 6), S.soft_rubber())   # > 3072 unknowns
+    sim.add_volume_grid("beam", (0, 0, 0), (4, 1, 1), (24, 6, 6), S.soft_rubber())   # > 3072 unknowns: the block-tridiagonal path
     with pytest.raises(S.SimError, match="DirectLLT"):
         sim.run_one_step()
     sim.close()

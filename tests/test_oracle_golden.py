@@ -7,6 +7,7 @@ relative; assembled blocks: float eps * contributions; PCG: same iteration count
 import glob
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -15,7 +16,10 @@ import scipy.sparse as sp
 from oracle import evaluator as ev
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-DUMPS = sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "geometry" not in os.path.basename(p) and "_cfg" not in os.path.basename(p))  # (traj_cfg*: step log + final state only, scene tests)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from fixture_list import stage_dumps  # noqa: E402
+
+DUMPS = stage_dumps()
 
 
 # EnergyDiscreteShells evaluates acos((1-1e-12) n0.n1) on (nearly) flat hinges: d acos/dx = -1/sqrt(1-x^2) with
