@@ -824,6 +824,12 @@ struct ContactSystem
     DevBuf<int> counters;  // [0] candidates, [1] intersections, [2] differs, [8..8+N_TABLES] bounds
     // result of the last barrier-table search and the inputs it saw (Context::data_version, dt): an identical request is answered from here
     bool cache_valid = false;
+    // the sorted box list of the last search: reused when the next search sees the same state with the same enlargement (the intersection
+    // check of a line-search candidate and the proximity search of the energy evaluation that follows it)
+    bool bp_valid = false;
+    uint64_t bp_version = 0;
+    double bp_dt = 0.0;
+    float bp_enl = -1.f;
     uint64_t cache_version = 0;
     double cache_dt = 0.0;
     int64_t cache_n = 0;
@@ -968,6 +974,7 @@ void upload(Context& c, DevBuf<T>& dst, const std::vector<T>& src)
 void upload_meshes(Context& c, ContactSystem& cs)
 {
     if (!cs.meshes_dirty) return;
+    cs.bp_valid = false;
     const int nm = (int)cs.meshes.size();
     std::vector<int32_t> kind(nm), idx(nm);
     for (int g = 0; g < nm; g++) {
@@ -1109,7 +1116,8 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     const float enl_f = nextafterf((float)enl, INFINITY) + 1.1920929e-07f;  // (float)enl + eps (AABBs.cpp:38), rounded up
     ContactDev d = dev_view(c, cs);
     lap(0);
-    update_vertices(c, cs, d, dt, enl_f);
+    bool boxes_current = cs.bp_valid && !cs.brute_force && !c.no_contact_cache && cs.bp_version == c.data_version && cs.bp_dt == dt && cs.bp_enl == enl_f;
+    if (!boxes_current) update_vertices(c, cs, d, dt, enl_f);
     if (cs.key_cap == 0) {
         cs.key_cap = 1 << 18;
         cs.keys.ensure(cs.key_cap);
@@ -1120,7 +1128,12 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     for (;;) {
         MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
         if (!cs.brute_force) {
-            sort_boxes(c, cs, d);
+            if (!boxes_current) sort_boxes(c, cs, d);
+            boxes_current = false;
+            cs.bp_valid = true;
+            cs.bp_version = c.data_version;
+            cs.bp_dt = dt;
+            cs.bp_enl = enl_f;
             if (friction) launch_sweep<true, true>(c, cs, d, enl * enl);
             else launch_sweep<true, false>(c, cs, d, enl * enl);
         } else {
@@ -1143,6 +1156,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
         n = h[0];
         if (!cs.brute_force && h[35] > cs.bp_cap) {  // (counters[32 + 3]) the banded box list did not fit: grow and search again
             cs.bp_cap = h[35] + h[35] / 4;
+            cs.bp_valid = false;
             continue;
         }
         if ((size_t)n <= cs.key_cap) break;
@@ -1233,7 +1247,12 @@ int64_t count_intersections(Context& c, double dt)
     prepare(c);
     upload_meshes(c, cs);
     ContactDev d = dev_view(c, cs);
-    update_vertices(c, cs, d, dt, 0.f);
+    // The boxes carry the enlargement of the proximity search (a superset of the candidates of tight boxes; the edge-triangle test itself
+    // is exact): the proximity search of the evaluation that follows an accepted candidate then reuses the sorted list as it is.
+    const double enl = 2.0 * max_thickness(c, cs);
+    const float enl_f = cs.brute_force ? 0.f : nextafterf((float)enl, INFINITY) + 1.1920929e-07f;
+    const bool boxes_current = cs.bp_valid && !cs.brute_force && !c.no_contact_cache && cs.bp_version == c.data_version && cs.bp_dt == dt && cs.bp_enl == enl_f;
+    if (!boxes_current) update_vertices(c, cs, d, dt, enl_f);
     MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 8 * sizeof(int), c.stream));
     if (!cs.brute_force) {
         if (cs.key_cap == 0) {
@@ -1241,16 +1260,21 @@ int64_t count_intersections(Context& c, double dt)
             cs.keys.ensure(cs.key_cap);
             cs.keys_alt.ensure(cs.key_cap);
         }
-        for (;;) {
-            sort_boxes(c, cs, d);
+        for (bool first = true;; first = false) {
+            if (!(first && boxes_current)) sort_boxes(c, cs, d);
             launch_sweep<false, false>(c, cs, d, 0.0);
             int hb[40];
             fetch(c, hb, cs.counters.p, sizeof(hb));
             if (hb[35] > cs.bp_cap) {
                 cs.bp_cap = hb[35] + hb[35] / 4;
+                cs.bp_valid = false;
                 MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 8 * sizeof(int), c.stream));
                 continue;
             }
+            cs.bp_valid = true;
+            cs.bp_version = c.data_version;
+            cs.bp_dt = dt;
+            cs.bp_enl = enl_f;
             return hb[1];
         }
     } else {

@@ -24,6 +24,7 @@ namespace mistark {
 constexpr int BLOCK = 256;
 constexpr int MAX_PARTIALS = 4096;   // max grid of any kernel that emits per-block partial sums
 constexpr int VEC_GRID = 512;
+constexpr int PCG_GRID = 1024;  // vector kernels of the PCG (per-block partial sums: <= MAX_PARTIALS)
 
 static inline int grid_for(int64_t n, int per_block = BLOCK, int cap = 1 << 30)
 {
@@ -559,6 +560,26 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ part, 
     return block_sum(s, sm);
 }
 
+// two sums at once (one pair of barriers)
+__device__ __forceinline__ void sum_partials2(const double* __restrict__ pa, const double* __restrict__ pb, int n, double* sm /*[8]*/, int stride, double& a, double& b)
+{
+    double sa = 0.0, sb = 0.0;
+    for (int i = threadIdx.x; i < n; i += BLOCK) {
+        sa += pa[(size_t)i * stride];
+        sb += pb[(size_t)i * stride];
+    }
+    sa = wave_sum(sa);
+    sb = wave_sum(sb);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        sm[w] = sa;
+        sm[4 + w] = sb;
+    }
+    __syncthreads();
+    a = sm[0] + sm[1] + sm[2] + sm[3];
+    b = sm[4] + sm[5] + sm[6] + sm[7];
+}
 __global__ __launch_bounds__(BLOCK) void k_sum(const double* __restrict__ v, int64_t n, double* __restrict__ part)
 {
     __shared__ double sm[4];
@@ -2931,16 +2952,41 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_init2(const double* __restrict__ 
         }
     }
 }
+// (The loads of a thread's first block row are issued BEFORE the reduction of the partial sums every workgroup starts with: that
+// reduction is a chain of dependent steps of 1.5-2 us during which the memory system would otherwise idle; with one row per thread, which is
+// how the solver sizes the grid, that is all of the kernel's loads.)
+struct StepRow
+{
+    double q0, q1, q2, r0, r1, r2, x0, x1, x2, p0, p1, p2;
+    float d[9];
+};
+__device__ __forceinline__ void step_load(StepRow& w, int64_t row, const float* __restrict__ dinv, const double* __restrict__ p, const double* __restrict__ q,
+                                          const double* __restrict__ x, const double* __restrict__ r, const int32_t* __restrict__ crow_of_row,
+                                          const uint32_t* __restrict__ row_chunk0, const double* __restrict__ yd, const double* __restrict__ chunk_partial)
+{
+    const size_t i = 3 * (size_t)row;
+    w.q0 = q[i]; w.q1 = q[i + 1]; w.q2 = q[i + 2];
+    w.r0 = r[i]; w.r1 = r[i + 1]; w.r2 = r[i + 2];
+    w.x0 = x[i]; w.x1 = x[i + 1]; w.x2 = x[i + 2];
+    w.p0 = p[i]; w.p1 = p[i + 1]; w.p2 = p[i + 2];
+#pragma unroll
+    for (int u = 0; u < 9; u++) w.d[u] = dinv[9 * row + u];
+    if (crow_of_row) dyn_row(crow_of_row, row_chunk0, yd, chunk_partial, row, w.q0, w.q1, w.q2);  // + contact part (k_spmv_fused)
+}
 __global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, const double* __restrict__ part_pq, int n_pq, const float* __restrict__ dinv, int64_t nbr,
                                                     const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ x, double* __restrict__ r,
                                                     double* __restrict__ z, double* __restrict__ part_rr, double* __restrict__ part_rz, PcgCtrl* __restrict__ ctrl,
                                                     const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0, const double* __restrict__ yd,
                                                     const double* __restrict__ chunk_partial)
 {
-    if (ctrl->done) return;
+    const int done = ctrl->done;
+    const double rz = ctrl->rz[k & 1];
+    int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    StepRow w;
+    if (row < nbr) step_load(w, row, dinv, p, q, x, r, crow_of_row, row_chunk0, yd, chunk_partial);
+    if (done) return;
     __shared__ double sm[4];
     const double pAp = sum_partials(part_pq, n_pq, sm);
-    const double rz = ctrl->rz[k & 1];
     if (pAp <= 0.0) {
         if (stop_on_indef) {
             if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -2960,22 +3006,22 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, co
     }
     const double alpha = rz / pAp;
     double rr = 0.0, rzn = 0.0;
-    for (int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x; row < nbr; row += (int64_t)gridDim.x * BLOCK) {
+    for (; row < nbr;) {
         const size_t i = 3 * (size_t)row;
-        double q0 = q[i], q1 = q[i + 1], q2 = q[i + 2];
-        if (crow_of_row) dyn_row(crow_of_row, row_chunk0, yd, chunk_partial, row, q0, q1, q2);  // + contact part (k_spmv_fused)
-        const double r0 = r[i] - alpha * q0, r1 = r[i + 1] - alpha * q1, r2 = r[i + 2] - alpha * q2;
-        x[i] += alpha * p[i];
-        x[i + 1] += alpha * p[i + 1];
-        x[i + 2] += alpha * p[i + 2];
+        const double r0 = w.r0 - alpha * w.q0, r1 = w.r1 - alpha * w.q1, r2 = w.r2 - alpha * w.q2;
+        x[i] = w.x0 + alpha * w.p0;
+        x[i + 1] = w.x1 + alpha * w.p1;
+        x[i + 2] = w.x2 + alpha * w.p2;
         r[i] = r0; r[i + 1] = r1; r[i + 2] = r2;
-        const float* d = dinv + 9 * row;
+        const float* d = w.d;
         const double z0 = (double)d[0] * r0 + (double)d[1] * r1 + (double)d[2] * r2;
         const double z1 = (double)d[3] * r0 + (double)d[4] * r1 + (double)d[5] * r2;
         const double z2 = (double)d[6] * r0 + (double)d[7] * r1 + (double)d[8] * r2;
         z[i] = z0; z[i + 1] = z1; z[i + 2] = z2;
         rr += r0 * r0 + r1 * r1 + r2 * r2;
         rzn += r0 * z0 + r1 * z1 + r2 * z2;
+        row += (int64_t)gridDim.x * BLOCK;
+        if (row < nbr) step_load(w, row, dinv, p, q, x, r, crow_of_row, row_chunk0, yd, chunk_partial);
     }
     rr = block_sum(rr, sm);
     rzn = block_sum(rzn, sm);
@@ -2988,15 +3034,25 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
                                                    int64_t n, const double* __restrict__ z, double* __restrict__ p, PcgCtrl* __restrict__ ctrl, int stride)
 {
     const int done = ctrl->done;
+    const double bb = ctrl->bb, rz_old = ctrl->rz[k & 1];
+    // the first row's loads before the reduction (see k_pcg_step)
+    const int64_t nrow = n / 3;
+    int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    double z0 = 0.0, z1 = 0.0, z2 = 0.0, p0 = 0.0, p1 = 0.0, p2 = 0.0;
+    if (row < nrow) {
+        const size_t i = 3 * (size_t)row;
+        z0 = z[i]; z1 = z[i + 1]; z2 = z[i + 2];
+        p0 = p[i]; p1 = p[i + 1]; p2 = p[i + 2];
+    }
     if (done == 1) return;
     if (done == 2) {  // indefiniteness stop decided in k_pcg_step of this iteration
         if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->done = 1;
         return;
     }
-    __shared__ double sm[4];
-    const double rr = sum_partials(part_rr, nparts, sm, stride);
-    const double rz_new = sum_partials(part_rz, nparts, sm, stride);
-    const double error = sqrt(rr / ctrl->bb);
+    __shared__ double sm[8];
+    double rr, rz_new;
+    sum_partials2(part_rr, part_rz, nparts, sm, stride, rr, rz_new);
+    const double error = sqrt(rr / bb);
     const bool conv = error < abs_tol || error / 1.0 < rel_tol;  // error_0 = 1 for x0 = 0
     if (conv) {
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -3007,8 +3063,19 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
         }
         return;
     }
-    const double beta = rz_new / ctrl->rz[k & 1];
-    for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) p[i] = z[i] + beta * p[i];
+    const double beta = rz_new / rz_old;
+    while (row < nrow) {
+        const size_t i = 3 * (size_t)row;
+        p[i] = z0 + beta * p0;
+        p[i + 1] = z1 + beta * p1;
+        p[i + 2] = z2 + beta * p2;
+        row += (int64_t)gridDim.x * BLOCK;
+        if (row < nrow) {
+            const size_t j = 3 * (size_t)row;
+            z0 = z[j]; z1 = z[j + 1]; z2 = z[j + 2];
+            p0 = p[j]; p1 = p[j + 1]; p2 = p[j + 2];
+        }
+    }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         ctrl->rz[(k + 1) & 1] = rz_new;
         ctrl->error = error;
@@ -3212,7 +3279,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         return;
     }
     build_preconditioner(c);
-    const int gv = grid_for(c.nbr, BLOCK, VEC_GRID);
+    const int gv = grid_for(c.nbr, BLOCK, PCG_GRID);  // one block row per thread up to 262 144 block rows
     BsrPart& m1 = c.part[1];
     const bool dyn = m1.nnzb > 0;
     double* part_pq = c.partials.p;
