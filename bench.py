@@ -201,7 +201,6 @@ def main():
     sim = build_scene(S, nx, ny, nz, device, a.scene)
     if world > 1:
         sim.set_dist_rccl(rank, world, uid)
-
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -210,6 +209,12 @@ def main():
     # warm-up (includes sparsity-pattern construction and first-touch allocations)
     if a.warmup > 0:
         run_newton_steps(sim, S, capi, a.warmup)
+    # A/B runs of engine options (measurement only; the engine exists after the first step): MISTARK_BENCH_OPTS="no_eager_assembly=1,fuse_dir=1"
+    for kv in filter(None, os.environ.get("MISTARK_BENCH_OPTS", "").split(",")):
+        k, v = kv.split("=")
+        if capi.lib().mistark_set_option(sim.engine_handle(), k.encode(), int(v)) != 0:
+            raise RuntimeError("%s: %s" % (kv, capi.lib().mistark_last_error(sim.engine_handle())))
+
     sim.spmv_timing(reset=1)  # start SpMV event timing for the timed region
     barrier()
     info0 = sim.info()

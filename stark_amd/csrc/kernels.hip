@@ -2434,6 +2434,21 @@ struct XDir
 __device__ __forceinline__ double row_dot_nostore(const XPlain& X, size_t r3, double y0, double y1, double y2) { return X.row_dot(r3, y0, y1, y2); }
 __device__ __forceinline__ double row_dot_nostore(const XDir& X, size_t r3, double y0, double y1, double y2) { return X.row_dot_nostore(r3, y0, y1, y2); }
 
+// v_mov_b32_dpp on both halves; BOUND: lanes without a source receive 0, otherwise (and in rows the mask disables) 0 as well (old = 0)
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ double dpp_mov(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, BOUND);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, BOUND);
+    return __hiloint2double(hi, lo);
+}
+// v of the lane whose byte address (4 * lane) is given (ds_bpermute_b32 on both halves)
+__device__ __forceinline__ double lane_gather(double v, int addr)
+{
+    const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 template <int V, class XS>
 __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nblk, const float* __restrict__ vals, const uint32_t* __restrict__ scol,
                                                     const int32_t* __restrict__ tile_first_row, int64_t n_chunks, const int chunk_tiles, const XS X,
@@ -2474,24 +2489,31 @@ __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nbl
             const unsigned long long heads = (tails << 1) | 1ull;
             const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
             const int start = 63 - __clzll(heads & le);
-            // segmented inclusive scan without LDS traffic: DPP row shifts inside each 16-lane row, then three scalar carries
+            // Row sums as differences of prefix sums: a plain (unsegmented) inclusive scan over the 64 lanes -- four DPP row shifts inside the
+            // 16-lane rows, then row_bcast:15 and row_bcast:31, no conditionals -- and one cross-lane read of the exclusive prefix at the
+            // first lane of the lane's row. (The segmented scan this replaces spent two thirds of the loop's 233 instructions on masks,
+            // selects and lane reads; the sums of at most 64 blocks differ from the segment sums by rounding errors ~1e-16 of the tile's
+            // total, far below the float matrix entries.)
+            const double v0 = y0, v1 = y1, v2 = y2;
+#define MS_SCAN_STEP(CTRL, RM, BOUND)               \
+            {                                       \
+                const double u0 = dpp_mov<CTRL, RM, BOUND>(y0), u1 = dpp_mov<CTRL, RM, BOUND>(y1), u2 = dpp_mov<CTRL, RM, BOUND>(y2); \
+                y0 += u0; y1 += u1; y2 += u2;       \
+            }
+            MS_SCAN_STEP(0x111, 0xf, true)
+            MS_SCAN_STEP(0x112, 0xf, true)
+            MS_SCAN_STEP(0x114, 0xf, true)
+            MS_SCAN_STEP(0x118, 0xf, true)
+            MS_SCAN_STEP(0x142, 0xa, false)  // row_bcast:15 -> rows 1 and 3
+            MS_SCAN_STEP(0x143, 0xc, false)  // row_bcast:31 -> rows 2 and 3
+#undef MS_SCAN_STEP
             {
-                const int l16 = lane & 15;
-#define MS_SEG_STEP(D, CTRL)                                                     \
-                {                                                                    \
-                    const double u0 = dpp_row_shr<CTRL>(y0), u1 = dpp_row_shr<CTRL>(y1), u2 = dpp_row_shr<CTRL>(y2); \
-                    if (l16 >= D && lane - D >= start) { y0 += u0; y1 += u1; y2 += u2; } \
-                }
-                MS_SEG_STEP(1, 0x111)
-                MS_SEG_STEP(2, 0x112)
-                MS_SEG_STEP(4, 0x114)
-                MS_SEG_STEP(8, 0x118)
-#undef MS_SEG_STEP
-#pragma unroll
-                for (int r = 1; r < 4; r++) {
-                    const double c0 = read_lane(y0, 16 * r - 1), c1 = read_lane(y1, 16 * r - 1), c2 = read_lane(y2, 16 * r - 1);
-                    if ((lane >> 4) == r && start < 16 * r) { y0 += c0; y1 += c1; y2 += c2; }
-                }
+                // exclusive prefix at the first lane of this lane's row = everything before the row
+                const int addr = start << 2;
+                const double e0 = y0 - v0, e1 = y1 - v1, e2 = y2 - v2;
+                y0 -= lane_gather(e0, addr);
+                y1 -= lane_gather(e1, addr);
+                y2 -= lane_gather(e2, addr);
             }
             // first segment: take over the carry of the previous tile of this chunk
             if (tile_cont && start == 0) { y0 += k0; y1 += k1; y2 += k2; }
