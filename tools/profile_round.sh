@@ -13,6 +13,7 @@ rm -rf /tmp/prof_kt
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o r -- python bench.py --no-cpu-baseline > /tmp/kt.log 2>&1
 db=$(find /tmp/prof_kt -name "*.db" | head -1)
 python profiles/summarize_rocpd.py $db > gpurun_out/${tag}_kernel_stats.txt
+python profiles/iter_rocpd.py $db > gpurun_out/${tag}_iter.txt
 { python profiles/solve_rocpd.py $db; python profiles/idle_rocpd.py $db 8 0.5; } > gpurun_out/${tag}_timeline.txt
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/prof_pmc
