@@ -244,3 +244,50 @@ def test_sharded_contact_scene_real_partition(world):
         assert all(abs(a - b) <= 1 for a, b in zip(its, ref_its)), (its, ref_its)
         assert np.abs(x - ref_x).max() <= 1e-5
     assert all((r[1] == res[0][1]).all() and r[0] == res[0][0] for r in res)
+
+
+def test_sharded_full_size_headline_scene():
+    """configs[3] at full size (998 976 tets, 517 050 DoF, frictional contact) on 4 ranks: two time steps against the same scene on one
+    rank — Newton iteration counts (+-1), CG iterations per solve, end state; identical bits on all ranks; the partition is balanced."""
+    import ctypes as C
+
+    from bench import build_scene
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    world, steps = 4, 2
+
+    def run(sim):
+        its, cg = [], 0
+        for _ in range(steps):
+            assert sim.run_one_step()
+            st = sim.info().last_stats
+            its.append(st.newton_iterations)
+            cg += st.cg_iterations
+        return its, cg, sim.points("x0")
+
+    single = build_scene(S, 44, 44, 43, 0)
+    ref_its, ref_cg, ref_x = run(single)
+    single.close()
+    assert sum(ref_its) > 0
+    L = capi.lib()
+    group = L.mistark_local_group_create(world)
+
+    def rank_fn(r):
+        sim = build_scene(S, 44, 44, 43, 0)
+        sim.set_dist_local(group, r, world)
+        out = run(sim)
+        info = (C.c_int64 * 6)()
+        L.mistark_dist_info(sim.engine_handle(), info, 6)
+        sim.close()
+        return out + (list(info),)
+
+    res = run_ranks(world, rank_fn)
+    L.mistark_local_group_destroy(group)
+    rows = [r[3][0] for r in res]
+    assert sum(rows) == 517050 // 3 and max(rows) - min(rows) <= 0.02 * max(rows)
+    for its, cg, x, _ in res:
+        assert all(abs(a - b) <= 1 for a, b in zip(its, ref_its)), (its, ref_its)
+        assert abs(cg - ref_cg) <= 0.05 * ref_cg + 5 * sum(ref_its)
+        assert np.abs(x - ref_x).max() <= 1e-5
+    assert all((r[2] == res[0][2]).all() and r[0] == res[0][0] and r[1] == res[0][1] for r in res)
