@@ -3052,8 +3052,20 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, co
         part_rz[blockIdx.x] = rzn;
     }
 }
+// the control block as the host will read it (pinned memory): written by the one thread that also writes the device copy
+__device__ __forceinline__ void publish_ctrl(PcgCtrl* __restrict__ host_slot, int done, int converged, int indef, int n_iter, double error)
+{
+    host_slot->converged = converged;
+    host_slot->indef = indef;
+    host_slot->n_iter = n_iter;
+    host_slot->error = error;
+    host_slot->done = done;
+    __threadfence_system();
+}
+// host_slot: non-null on the last iteration of a batch (the host looks at the control block there: no copy kernel, no extra boundary)
 __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double rel_tol, const double* __restrict__ part_rr, const double* __restrict__ part_rz, int nparts,
-                                                   int64_t n, const double* __restrict__ z, double* __restrict__ p, PcgCtrl* __restrict__ ctrl, int stride)
+                                                   int64_t n, const double* __restrict__ z, double* __restrict__ p, PcgCtrl* __restrict__ ctrl, int stride,
+                                                   PcgCtrl* __restrict__ host_slot)
 {
     const int done = ctrl->done;
     const double bb = ctrl->bb, rz_old = ctrl->rz[k & 1];
@@ -3066,9 +3078,16 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
         z0 = z[i]; z1 = z[i + 1]; z2 = z[i + 2];
         p0 = p[i]; p1 = p[i + 1]; p2 = p[i + 2];
     }
-    if (done == 1) return;
+    const bool scribe = blockIdx.x == 0 && threadIdx.x == 0;
+    if (done == 1) {
+        if (scribe && host_slot) publish_ctrl(host_slot, 1, ctrl->converged, ctrl->indef, ctrl->n_iter, ctrl->error);
+        return;
+    }
     if (done == 2) {  // indefiniteness stop decided in k_pcg_step of this iteration
-        if (blockIdx.x == 0 && threadIdx.x == 0) ctrl->done = 1;
+        if (scribe) {
+            ctrl->done = 1;
+            if (host_slot) publish_ctrl(host_slot, 1, ctrl->converged, ctrl->indef, ctrl->n_iter, ctrl->error);
+        }
         return;
     }
     __shared__ double sm[8];
@@ -3077,11 +3096,12 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
     const double error = sqrt(rr / bb);
     const bool conv = error < abs_tol || error / 1.0 < rel_tol;  // error_0 = 1 for x0 = 0
     if (conv) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (scribe) {
             ctrl->error = error;
             ctrl->n_iter = k;
             ctrl->converged = 1;
             ctrl->done = 1;
+            if (host_slot) publish_ctrl(host_slot, 1, 1, ctrl->indef, k, error);
         }
         return;
     }
@@ -3098,10 +3118,11 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
             p0 = p[j]; p1 = p[j + 1]; p2 = p[j + 2];
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (scribe) {
         ctrl->rz[(k + 1) & 1] = rz_new;
         ctrl->error = error;
         ctrl->n_iter = k;
+        if (host_slot) publish_ctrl(host_slot, 0, 0, ctrl->indef, k, error);
     }
 }
 
@@ -3292,7 +3313,7 @@ __global__ void k_copy_ctrl(const PcgCtrl* __restrict__ src, PcgCtrl* __restrict
     }
 }
 // SpMV timing inside the solver: every SPMV_SAMPLE-th launch is bracketed by a pair of pooled HIP events on the engine's stream
-constexpr int SPMV_SAMPLE = 8;
+constexpr int SPMV_SAMPLE = 32;  // (an event pair costs the stream ~12 us: sampled sparsely so that measuring does not change what is measured)
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
 {
     if (!c.have_matrix) throw Error("pcg: matrix not assembled");
@@ -3356,13 +3377,15 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
             hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, (const double*)pk, c.q.p, c.du.p, c.r.p, c.z.p, part_rr,
                                part_rz, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : nullptr, (const uint32_t*)m1.row_chunk0.p, (const double*)m1.yd.p,
                                (const double*)m1.chunk_partial.p);
-            if (!fuse_dir) hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p, 1);
+            if (!fuse_dir)
+                hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p, 1,
+                                   k == k_end ? hs[slot] : (PcgCtrl*)nullptr);
         }
         // (fused: the test of the batch's last iteration would only run with the next batch's first SpMV; the host reads the control block now)
         if (fuse_dir) hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(BLOCK), 0, c.stream, DirArgs{c.z.p, nullptr, nullptr, part_rr, part_rz, gv, k_end + 1, abs_tol, rel_tol}, c.ctrl.p);
-        // the control block goes to the pinned slot through a one-wavefront kernel (a copy command sits on another engine: 4 us + a 5.6 us
-        // gap before the next batch's first kernel, every four iterations)
-        hipLaunchKernelGGL(k_copy_ctrl, dim3(1), dim3(64), 0, c.stream, (const PcgCtrl*)c.ctrl.p, hs[slot]);
+        // the control block reaches the pinned slot from the batch's last k_pcg_dir itself (round 1: a copy command on another engine, 4 us
+        // + a 5.6 us gap; then a one-wavefront copy kernel, 4 us + its boundary, every four iterations); the fused variant still copies
+        if (fuse_dir) hipLaunchKernelGGL(k_copy_ctrl, dim3(1), dim3(64), 0, c.stream, (const PcgCtrl*)c.ctrl.p, hs[slot]);
         MS_CHECK(hipEventRecord(c.pcg_ev[slot], c.stream));
         return k_end;
     };
