@@ -94,6 +94,11 @@ int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* 
 /* Marks a potential whose connectivity changes inside the Newton loop (the reference's contact tables are refilled in
  * before_energy_evaluation, EnergyFrictionalContact.cpp:117-119). Its Hessian blocks go to a second, small block-CSR part
  * (A = A_static + A_dynamic) so that a connectivity update only re-patterns that part, not the whole matrix. */
+/* Introspection of a registration (what MappedWorkspace holds for a potential, MappedWorkspace.h:329-333): the connectivity table as
+ * registered (conn may be NULL to query the sizes; device-side contact tables: mistark_contact_get_table), and the caller's array behind
+ * binding `binding` (pointer, items, stride). */
+int mistark_potential_table(mistark_ctx* ctx, int potential, int32_t* conn, int64_t* n_elem, int32_t* conn_stride);
+int mistark_potential_binding_data(mistark_ctx* ctx, int potential, int binding, const double** host, int64_t* n_items, int32_t* stride);
 int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic);
 /* LabelledConnectivity::clear() + push_back() (symx/src/compile/LabelledConnectivity.h): replaces the rows of a potential. */
 int mistark_potential_update_connectivity(mistark_ctx* ctx, int potential, const int32_t* conn, int32_t n_elem);
@@ -253,7 +258,7 @@ int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settin
  * closed-form tet kernels are then cross-checked against them); "atomic_assembly" = scatter assembly with float atomics
  * instead of the deterministic gather; "proj_variant" = PSD projection cross-checks, bits: 1 = eigen-decomposition with the
  * matrix in LDS instead of registers, 2 = one launch per potential instead of one for all short lists, 4 = IEEE division /
- * square root for the rotation angles; "proj_rec_cap" = record capacity of the sharded projection exchange (tests); "spmv_chunk_tiles" = tiles per SpMV chunk (0 = by matrix size); "no_contact_cache" = run every contact search even when
+ * square root for the rotation angles; "spmv_chunk_tiles" = tiles per SpMV chunk (0 = by matrix size); "no_contact_cache" = run every contact search even when
  * nothing it reads has changed since the previous one.
  * Returns 0, or < 0 for an unknown name. The environment variable
  * MISTARK_OPTIONS="name=value,name=value" applies the same switches inside mistark_create (for a process that cannot be

@@ -30,6 +30,10 @@ typedef struct mistark_sim_settings
     int32_t fps;
     char output_directory[256];
     char simulation_name[64];
+    /* Settings::Execution (stark/src/core/Settings.h:33-38): stop conditions of mistark_sim_run (Stark.cpp:84-116) */
+    double allowed_execution_time;
+    double end_simulation_time;
+    int32_t end_frame;
 } mistark_sim_settings;
 void mistark_sim_default_settings(mistark_sim_settings* s);
 
@@ -102,6 +106,15 @@ int mistark_sim_attach_edge_edge(mistark_sim* sim, int set_0, int set_1, const i
 /* rb_points_loc == NULL: the points' current positions in the body frame (EnergyAttachments.cpp:322-333) */
 int mistark_sim_attach_rigid_body(mistark_sim* sim, int rb, int point_set, const double* rb_points_loc, const int32_t* points, int64_t n, double stiffness, double tolerance);
 /* EnergyAttachments::get_params(handler).stiffness (doubled by the tolerance check) */
+/* EnergyAttachments::add_by_distance (EnergyAttachments.cpp:229-297): every point of `points` (local to set_0) closer than `distance` to the
+ * triangle mesh over set_1 (triangle indices local to set_1, current positions) is attached at the nearest vertex, edge or face.
+ * handlers_out: the point-point, point-edge and point-triangle groups. */
+int mistark_sim_attach_by_distance(mistark_sim* sim, int set_0, int set_1, const int32_t* points, int64_t n_points, const int32_t* triangles, int64_t n_triangles, double distance,
+                                   double stiffness, double tolerance, int32_t handlers_out[3]);
+/* (:334-360) the same against a triangle mesh given in a rigid body's local frame; the attachment points on the body are the nearest
+ * points of the mesh. Returns the handler index. */
+int mistark_sim_attach_rigid_body_by_distance(mistark_sim* sim, int rb, int point_set, const double* loc_vertices, int64_t n_vertices, const int32_t* triangles, int64_t n_triangles,
+                                              const int32_t* points, int64_t n_points, double distance, double stiffness, double tolerance);
 int mistark_sim_attachment_stiffness(mistark_sim* sim, int handler, double* stiffness);
 
 /* PointSetHandler::add_displacement / add_rotation (also at rest pose), before the first step */

@@ -724,10 +724,57 @@ static Scene scene_attachzoo(const Args& a)
     return sc;
 }
 
+// EnergyAttachments::add_by_distance (SURVEY.md §8(f) rank 4 remainder): a patch of cloth glued onto a larger cloth wherever it is closer
+// than a distance (it overhangs one corner, so vertices, boundary edges and faces are all nearest entities), and a free rigid box glued
+// under the cloth by the distance to its surface mesh. No contact.
+static Scene scene_attachdist(const Args& a)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, "attachdist");
+    settings.simulation.init_frictional_contact = false;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const int n = a.i("n", 6);
+    const double d = a.d("size", 0.4), hd = 0.5 * d;
+    const double k = a.d("k", 1e4), tol = a.d("tol", std::numeric_limits<double>::max());
+    const double gap = a.d("gap", 0.004), dist = a.d("dist", 0.08), box_dist = a.d("box_dist", 0.02);
+    auto [cV, cT, cloth] = sim.presets->deformables->add_surface_grid("cloth", { d, d }, { n, n }, stark::Surface::Params::Cotton_Fabric());
+    std::vector<int> corners;
+    for (int i = 0; i < (int)cV.size(); i++)
+        if (std::abs(std::abs(cV[i].x()) - hd) < 1e-9 && std::abs(cV[i].y() + hd) < 1e-9) corners.push_back(i);
+    sim.deformables->prescribed_positions->add(cloth.point_set, corners, stark::EnergyPrescribedPositions::Params().set_stiffness(1e6));
+    auto att = stark::EnergyAttachments::Params().set_stiffness(k).set_tolerance(tol);
+
+    // the patch: a little above the cloth, turned, hanging over the corner (+hd, +hd)
+    auto [pV, pT, patch] = sim.presets->deformables->add_surface_grid("patch", { 0.45 * d, 0.45 * d }, { 3, 3 }, stark::Surface::Params::Cotton_Fabric());
+    patch.point_set.add_rotation(a.d("turn", 17.0), Eigen::Vector3d::UnitZ());
+    patch.point_set.add_displacement({ 0.41 * d, 0.37 * d, gap });
+    std::vector<int> all_patch((size_t)pV.size());
+    for (int i = 0; i < (int)pV.size(); i++) all_patch[i] = i;
+    sim.interactions->attachments->add_by_distance(patch.point_set, cloth.point_set, all_patch, cT, dist, att);
+
+    // the box: its top face just under the cloth's middle
+    const double bs = a.d("box", 0.12);
+    auto [xV, xT, box] = sim.presets->rigidbodies->add_box("box", a.d("box_mass", 0.2), bs);
+    box.rigidbody.add_rotation(a.d("box_turn", 25.0), Eigen::Vector3d::UnitZ());
+    box.rigidbody.add_translation({ -0.11 * d, -0.07 * d, -0.5 * bs - gap });
+    std::vector<int> all_cloth((size_t)cV.size());
+    for (int i = 0; i < (int)cV.size(); i++) all_cloth[i] = i;
+    sim.interactions->attachments->add_by_distance(box.rigidbody, cloth.point_set, xV, xT, all_cloth, box_dist, att);
+
+    std::ostringstream js;
+    js.precision(17);
+    js << "{\"kind\":\"attachdist\",\"n\":" << n << ",\"size\":" << d << ",\"k\":" << k << ",\"tol\":" << (tol > 1e300 ? -1.0 : tol) << ",\"gap\":" << gap
+       << ",\"dist\":" << dist << ",\"box_dist\":" << box_dist << ",\"turn\":" << a.d("turn", 17.0) << ",\"box\":" << bs << ",\"box_mass\":" << a.d("box_mass", 0.2) << ",\"box_turn\":" << a.d("box_turn", 25.0) << "}";
+    sc.json = js.str();
+    return sc;
+}
+
 static Scene make_scene(const std::string& name, const Args& a)
 {
     if (name == "hangingnet") return scene_hangingnet(a);
     if (name == "attachzoo") return scene_attachzoo(a);
+    if (name == "attachdist") return scene_attachdist(a);
     if (name == "clothbox") return scene_clothbox(a);
     if (name == "blockbox") return scene_blockbox(a);
     if (name == "mixed") return scene_mixed(a);

@@ -399,6 +399,31 @@ int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* 
     _ret = register_custom_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings, ops, constants, n_ops, n_inputs, cond_ops, cond_constants, n_cond_ops);
     API_END(_ret)
 }
+int mistark_potential_table(mistark_ctx* ctx, int potential, int32_t* conn, int64_t* n_elem, int32_t* conn_stride)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
+    const Potential& P = c.pots[(size_t)potential];
+    if (P.conn_ext) throw Error("mistark_potential_table: the table of '" + P.name + "' lives on the device (mistark_contact_get_table)");
+    if (n_elem) *n_elem = P.n_elem;
+    if (conn_stride) *conn_stride = P.conn_stride;
+    if (conn && !P.conn_host.empty()) std::memcpy(conn, P.conn_host.data(), std::min(P.conn_host.size(), (size_t)P.n_elem * P.conn_stride) * sizeof(int32_t));
+    API_END(0)
+}
+int mistark_potential_binding_data(mistark_ctx* ctx, int potential, int binding, const double** host, int64_t* n_items, int32_t* stride)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
+    const Potential& P = c.pots[(size_t)potential];
+    if (binding < 0 || binding >= (int)P.bindings.size()) throw Error("bad binding index");
+    const Array& A = c.arrays[(size_t)P.bindings[(size_t)binding].array];
+    if (host) *host = A.host;
+    if (n_items) *n_items = A.n_items;
+    if (stride) *stride = A.stride;
+    API_END(0)
+}
 int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)
 {
     API_BEGIN
@@ -890,7 +915,6 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     }
     else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;
     else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;
-    else if (n == "proj_rec_cap") ctx->c.proj_rec_cap = value;
     else if (n == "lazy_hessians") ctx->c.lazy_allowed = value != 0;  // newton_solve: float upper-triangle pool for the closed-form tets
     else if (n == "kernel_dbg") { ctx->c.kernel_dbg = value; ctx->c.layout_dirty = true; }  // measurement only
     else if (n == "lazy_eval") ctx->c.lazy_eval = value != 0;

@@ -304,7 +304,6 @@ struct Context
     DevBuf<int32_t> hot_rows;      // global block row of every hot row
     int n_hot = 0;
     int proj_variant = 0;          // PSD projection, bits: 1 = matrix in LDS (k_project_eig) instead of registers, 2 = no batching of short lists, 4 = IEEE div/sqrt
-    long long proj_rec_cap = 0;    // tuning / tests: records per rank of the sharded projection exchange (0 = default)
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather
     bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path
@@ -355,8 +354,6 @@ struct Context
     DevBuf<double> dist_scalar;
     DevBuf<double> xl;              // sharded PCG: the solution in local numbering
     // sharded projection: delta records of this rank, the common exchange buffer and its sort scratch (kernels.hip: exchange_projection_deltas)
-    DevBuf<uint32_t> proj_rec_pos, proj_keys, proj_keys_alt, proj_idx, proj_idx_alt;
-    DevBuf<float> proj_rec_val, proj_x;
     DevBuf<unsigned char> src_ranges;  // descriptor table of k_make_desc
     struct ContactSystem* contact = nullptr;  // device contact detector (contact.hip), created by mistark_contact_init
 

@@ -1,5 +1,6 @@
 // host/attachments.cpp — rods and attachments of the host layer (see sim.hpp): stark::EnergySegmentStrain, stark::EnergyAttachments and
 // the Line presets. The energies themselves are the device potentials of the same registry names (csrc/energies.hpp).
+#include <limits>
 #include <stdexcept>
 
 #include "bind.hpp"
@@ -214,6 +215,131 @@ EnergyAttachments::Handler EnergyAttachments::add(const RigidBodyHandler& body, 
     std::vector<Vec3> loc(points.size());
     for (size_t i = 0; i < points.size(); i++) loc[i] = body.transform_global_to_local_point(dyn->x1[set.get_global_index(points[i])]);
     return add(body, set, loc, points, params);
+}
+// ---- add_by_distance (EnergyAttachments.cpp:229-297, 334-360): the reference asks tmd::TriangleMeshDistance (extern/TriangleMeshDistance,
+// header-only, a sphere-tree over the triangles) for the nearest triangle, its nearest entity and the barycentric coordinates there. The
+// answer is a property of the geometry, not of the search structure: here every triangle is tested (scene set-up code, run once), with
+// the closest-point regions of Ericson, Real-Time Collision Detection 5.1.5, in the order tmd evaluates them, so that a point on a
+// region boundary is classified the same way. Among triangles at exactly the same distance (a shared vertex or edge) either search
+// reports the same vertex / the same edge; the edge's two ends may come in the other order, with the weights swapped accordingly.
+namespace
+{
+enum Nearest { N_V0, N_V1, N_V2, N_E01, N_E12, N_E02, N_F };
+struct NearestOnTriangle
+{
+    double dist_sq;
+    Nearest entity;
+    Vec3 bary, point;
+};
+NearestOnTriangle nearest_on_triangle(const Vec3& p, const Vec3& a, const Vec3& b, const Vec3& c)
+{
+    NearestOnTriangle r{};
+    auto finish = [&](Nearest e, const Vec3& w) {
+        r.entity = e;
+        r.bary = w;
+        r.point = w[0] * a + w[1] * b + w[2] * c;
+        if (e == N_V0) r.point = a;
+        if (e == N_V1) r.point = b;
+        if (e == N_V2) r.point = c;
+        if (e == N_E01) r.point = w[0] * a + w[1] * b;
+        if (e == N_E12) r.point = w[1] * b + w[2] * c;
+        if (e == N_E02) r.point = w[0] * a + w[2] * c;
+        r.dist_sq = dot(p - r.point, p - r.point);
+        return r;
+    };
+    const Vec3 ab = b - a, ac = c - a, bc = c - b;
+    // projections of p on the three edge lines, as numerator / denominator pairs (the sign pattern picks the Voronoi region)
+    const double s_n = dot(p - a, ab), s_d = dot(p - b, a - b);
+    const double t_n = dot(p - a, ac), t_d = dot(p - c, a - c);
+    if (s_n <= 0.0 && t_n <= 0.0) return finish(N_V0, {1.0, 0.0, 0.0});
+    const double u_n = dot(p - b, bc), u_d = dot(p - c, b - c);
+    if (s_d <= 0.0 && u_n <= 0.0) return finish(N_V1, {0.0, 1.0, 0.0});
+    if (t_d <= 0.0 && u_d <= 0.0) return finish(N_V2, {0.0, 0.0, 1.0});
+    const Vec3 n = cross(ab, ac);
+    const double vc = dot(n, cross(a - p, b - p));
+    if (vc <= 0.0 && s_n >= 0.0 && s_d >= 0.0) {
+        const double w = s_n / (s_n + s_d);
+        return finish(N_E01, {1.0 - w, w, 0.0});
+    }
+    const double va = dot(n, cross(b - p, c - p));
+    if (va <= 0.0 && u_n >= 0.0 && u_d >= 0.0) {
+        const double w = u_n / (u_n + u_d);
+        return finish(N_E12, {0.0, 1.0 - w, w});
+    }
+    const double vb = dot(n, cross(c - p, a - p));
+    if (vb <= 0.0 && t_n >= 0.0 && t_d >= 0.0) {
+        const double w = t_n / (t_n + t_d);
+        return finish(N_E02, {1.0 - w, 0.0, w});
+    }
+    const double u = va / (va + vb + vc), v = vb / (va + vb + vc);
+    return finish(N_F, {u, v, 1.0 - u - v});
+}
+struct NearestOnMesh
+{
+    double distance = std::numeric_limits<double>::max();
+    int triangle = -1;
+    NearestOnTriangle hit{};
+};
+NearestOnMesh nearest_on_mesh(const Vec3& p, const std::vector<Vec3>& vertices, const std::vector<std::array<int, 3>>& triangles)
+{
+    NearestOnMesh best;
+    double best_sq = std::numeric_limits<double>::max();
+    for (size_t t = 0; t < triangles.size(); t++) {
+        const auto& tri = triangles[t];
+        const NearestOnTriangle h = nearest_on_triangle(p, vertices[tri[0]], vertices[tri[1]], vertices[tri[2]]);
+        if (h.dist_sq < best_sq) {
+            best_sq = h.dist_sq;
+            best.triangle = (int)t;
+            best.hit = h;
+        }
+    }
+    best.distance = std::sqrt(best_sq);
+    return best;
+}
+}  // namespace
+EnergyAttachments::MultiHandler EnergyAttachments::add_by_distance(const PointSetHandler& set_0, const PointSetHandler& set_1, const std::vector<int>& points,
+                                                                   const std::vector<std::array<int, 3>>& triangles, double distance, const Params& params)
+{
+    // the mesh is set_1 at its current positions (:235), triangle indices local to set_1
+    std::vector<Vec3> verts((size_t)set_1.size());
+    for (int i = 0; i < set_1.size(); i++) verts[i] = set_1.get_position(i);
+    std::vector<int> pp0, pp1, pe_p, pt_p;
+    std::vector<std::array<int, 2>> pe_e;
+    std::vector<std::array<double, 2>> pe_b;
+    std::vector<std::array<int, 3>> pt_t;
+    std::vector<std::array<double, 3>> pt_b;
+    for (const int loc : points) {
+        const NearestOnMesh d = nearest_on_mesh(set_0.get_position(loc), verts, triangles);
+        if (d.triangle < 0 || !(d.distance < distance)) continue;
+        const auto& tri = triangles[d.triangle];
+        const Vec3& w = d.hit.bary;
+        switch (d.hit.entity) {
+            case N_V0: pp0.push_back(loc); pp1.push_back(tri[0]); break;
+            case N_V1: pp0.push_back(loc); pp1.push_back(tri[1]); break;
+            case N_V2: pp0.push_back(loc); pp1.push_back(tri[2]); break;
+            case N_E01: pe_p.push_back(loc); pe_e.push_back({tri[0], tri[1]}); pe_b.push_back({w[0], w[1]}); break;
+            case N_E12: pe_p.push_back(loc); pe_e.push_back({tri[1], tri[2]}); pe_b.push_back({w[1], w[2]}); break;
+            case N_E02: pe_p.push_back(loc); pe_e.push_back({tri[0], tri[2]}); pe_b.push_back({w[0], w[2]}); break;
+            case N_F: pt_p.push_back(loc); pt_t.push_back(tri); pt_b.push_back({w[0], w[1], w[2]}); break;
+        }
+    }
+    // three handlers, empty groups included (:291-296)
+    return MultiHandler{{add(set_0, set_1, pp0, pp1, params), add(set_0, set_1, pe_p, pe_e, pe_b, params), add(set_0, set_1, pt_p, pt_t, pt_b, params)}};
+}
+EnergyAttachments::Handler EnergyAttachments::add_by_distance(const RigidBodyHandler& body, const PointSetHandler& set, const std::vector<Vec3>& loc_vertices,
+                                                              const std::vector<std::array<int, 3>>& triangles, const std::vector<int>& set_points, double distance, const Params& params)
+{
+    std::vector<Vec3> glob(loc_vertices.size());
+    for (size_t i = 0; i < loc_vertices.size(); i++) glob[i] = body.transform_local_to_global_point(loc_vertices[i]);
+    std::vector<int> pts;
+    std::vector<Vec3> loc;
+    for (const int p : set_points) {
+        const NearestOnMesh d = nearest_on_mesh(set.get_position(p), glob, triangles);
+        if (d.triangle < 0 || !(d.distance < distance)) continue;
+        pts.push_back(p);
+        loc.push_back(body.transform_global_to_local_point(d.hit.point));
+    }
+    return add(body, set, loc, pts, params);
 }
 EnergyAttachments::Params EnergyAttachments::get_params(const Handler& h) const
 {

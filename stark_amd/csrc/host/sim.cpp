@@ -230,7 +230,8 @@ bool Stark::run(double duration, std::function<void()> callback)
     const double begin_time = current_time;
     const double t0 = now_s();
     bool success = false;
-    while (current_time <= settings.execution.end_simulation_time && (current_time - begin_time) <= duration && (now_s() - t0) <= settings.execution.allowed_execution_time) {
+    while (current_time <= settings.execution.end_simulation_time && (current_time - begin_time) <= duration && current_frame <= settings.execution.end_frame &&
+           (now_s() - t0) <= settings.execution.allowed_execution_time) {
         if (callback) callback();
         success = run_one_step();
         if (!success) break;

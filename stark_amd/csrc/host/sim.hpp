@@ -52,6 +52,7 @@ struct Settings
     {
         double allowed_execution_time = std::numeric_limits<double>::max();
         double end_simulation_time = std::numeric_limits<double>::max();
+        int end_frame = std::numeric_limits<int>::max();
         int device = 0;                   // MI355X ordinal (replaces n_threads)
         bool mirror_state_to_host = true; // refresh PointDynamics host arrays after every accepted step
         // multi-GPU sharding (include/mistark.h "multi-GPU"): one Simulation per GPU, all built identically
@@ -640,6 +641,15 @@ public:
                 const std::vector<std::array<double, 2>>& bary_0, const std::vector<std::array<double, 2>>& bary_1, const Params& params);
     Handler add(const RigidBodyHandler& rb, const PointSetHandler& set, const std::vector<Vec3>& rb_points_loc, const std::vector<int>& set_points, const Params& params);
     Handler add(const RigidBodyHandler& rb, const PointSetHandler& set, const std::vector<int>& points, const Params& params);
+    // EnergyAttachments.cpp:229-297, 334-360: attach the points closer than `distance` to a triangle mesh at its nearest vertex / edge / face
+    struct MultiHandler
+    {
+        std::array<Handler, 3> handlers;  // point-point, point-edge, point-triangle
+    };
+    MultiHandler add_by_distance(const PointSetHandler& set_0, const PointSetHandler& set_1, const std::vector<int>& points, const std::vector<std::array<int, 3>>& triangles,
+                                 double distance, const Params& params);
+    Handler add_by_distance(const RigidBodyHandler& rb, const PointSetHandler& set, const std::vector<Vec3>& loc_vertices, const std::vector<std::array<int, 3>>& triangles,
+                            const std::vector<int>& set_points, double distance, const Params& params);
     Params get_params(const Handler& h) const;
     void set_params(const Handler& h, const Params& p);
     void register_potentials(mistark_ctx* ctx) override;

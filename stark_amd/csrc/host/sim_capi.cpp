@@ -97,6 +97,9 @@ void mistark_sim_default_settings(mistark_sim_settings* s)
     s->fps = d.output.fps;
     std::memset(s->output_directory, 0, sizeof(s->output_directory));
     std::memset(s->simulation_name, 0, sizeof(s->simulation_name));
+    s->allowed_execution_time = d.execution.allowed_execution_time;
+    s->end_simulation_time = d.execution.end_simulation_time;
+    s->end_frame = d.execution.end_frame;
 }
 void mistark_volume_params_soft_rubber(mistark_volume_params* p)
 {
@@ -156,6 +159,9 @@ int mistark_sim_create(const mistark_sim_settings* in, mistark_sim** out)
     st.output.fps = d.fps;
     st.output.output_directory = std::string(d.output_directory, strnlen(d.output_directory, sizeof(d.output_directory)));
     st.output.simulation_name = std::string(d.simulation_name, strnlen(d.simulation_name, sizeof(d.simulation_name)));
+    st.execution.allowed_execution_time = d.allowed_execution_time;
+    st.execution.end_simulation_time = d.end_simulation_time;
+    st.execution.end_frame = d.end_frame;
     auto* s = new mistark_sim();
     try {
         s->sim = std::make_unique<Simulation>(st);
@@ -385,6 +391,29 @@ int mistark_sim_attach_rigid_body(mistark_sim* s, int rb, int ps, const double* 
     } else {
         _ret = keep(s, att->add(the_body(s, rb), the_set(s, ps), points, attachment_params(k, tol)));
     }
+    SIM_END
+}
+int mistark_sim_attach_by_distance(mistark_sim* s, int set_0, int set_1, const int32_t* pts, int64_t n_points, const int32_t* tris, int64_t n_triangles, double distance, double k, double tol,
+                                   int32_t handlers_out[3])
+{
+    SIM_BEGIN
+    const std::vector<int> points(pts, pts + n_points);
+    std::vector<std::array<int, 3>> T((size_t)n_triangles);
+    for (int64_t i = 0; i < n_triangles; i++) T[i] = {tris[3 * i], tris[3 * i + 1], tris[3 * i + 2]};
+    auto mh = s->sim->interactions->attachments->add_by_distance(the_set(s, set_0), the_set(s, set_1), points, T, distance, attachment_params(k, tol));
+    for (int i = 0; i < 3; i++) handlers_out[i] = keep(s, mh.handlers[i]);
+    SIM_END
+}
+int mistark_sim_attach_rigid_body_by_distance(mistark_sim* s, int rb, int ps, const double* loc_vertices, int64_t n_vertices, const int32_t* tris, int64_t n_triangles, const int32_t* pts,
+                                              int64_t n_points, double distance, double k, double tol)
+{
+    SIM_BEGIN
+    const std::vector<int> points(pts, pts + n_points);
+    std::vector<Vec3> V((size_t)n_vertices);
+    for (int64_t i = 0; i < n_vertices; i++) V[i] = v3(loc_vertices + 3 * i);
+    std::vector<std::array<int, 3>> T((size_t)n_triangles);
+    for (int64_t i = 0; i < n_triangles; i++) T[i] = {tris[3 * i], tris[3 * i + 1], tris[3 * i + 2]};
+    _ret = keep(s, s->sim->interactions->attachments->add_by_distance(the_body(s, rb), the_set(s, ps), V, T, points, distance, attachment_params(k, tol)));
     SIM_END
 }
 int mistark_sim_attachment_stiffness(mistark_sim* s, int handler, double* stiffness)

@@ -12,7 +12,8 @@ class SimSettings(C.Structure):
     _fields_ = [("gravity", C.c_double * 3), ("max_time_step_size", C.c_double), ("use_adaptive_time_step", C.c_int32),
                 ("time_step_size_success_multiplier", C.c_double), ("time_step_size_lower_bound", C.c_double), ("device", C.c_int32),
                 ("mirror_state_to_host", C.c_int32), ("enable_output", C.c_int32), ("init_frictional_contact", C.c_int32), ("newton", capi.NewtonSettings),
-                ("enable_frame_writes", C.c_int32), ("fps", C.c_int32), ("output_directory", C.c_char * 256), ("simulation_name", C.c_char * 64)]
+                ("enable_frame_writes", C.c_int32), ("fps", C.c_int32), ("output_directory", C.c_char * 256), ("simulation_name", C.c_char * 64),
+                ("allowed_execution_time", C.c_double), ("end_simulation_time", C.c_double), ("end_frame", C.c_int32)]
 
 
 class VolumeParams(C.Structure):
@@ -84,6 +85,8 @@ def _lib():
         L.mistark_sim_attach_point_triangle.argtypes = [p, C.c_int, C.c_int, p, p, p, C.c_int64, C.c_double, C.c_double]
         L.mistark_sim_attach_edge_edge.argtypes = [p, C.c_int, C.c_int, p, p, p, p, C.c_int64, C.c_double, C.c_double]
         L.mistark_sim_attach_rigid_body.argtypes = [p, C.c_int, C.c_int, p, p, C.c_int64, C.c_double, C.c_double]
+        L.mistark_sim_attach_by_distance.argtypes = [p, C.c_int, C.c_int, p, C.c_int64, p, C.c_int64, C.c_double, C.c_double, C.c_double, p]
+        L.mistark_sim_attach_rigid_body_by_distance.argtypes = [p, C.c_int, C.c_int, p, C.c_int64, p, C.c_int64, p, C.c_int64, C.c_double, C.c_double, C.c_double]
         L.mistark_sim_attachment_stiffness.argtypes = [p, C.c_int, C.POINTER(C.c_double)]
         L.mistark_sim_run_one_step.argtypes = [p]
         L.mistark_sim_set_newton_settings.argtypes = [p, C.POINTER(capi.NewtonSettings)]
@@ -277,6 +280,21 @@ class Simulation:
         a = np.ascontiguousarray(points, dtype=np.int32)
         loc = None if rb_points_loc is None else np.ascontiguousarray(rb_points_loc, dtype=np.float64).reshape(-1, 3)
         return self._ck(self.L.mistark_sim_attach_rigid_body(self.h, rb, point_set, None if loc is None else loc.ctypes.data, a.ctypes.data, len(a), stiffness, tolerance))
+
+    def attach_by_distance(self, set_0, set_1, points, triangles, distance, stiffness, tolerance=0.0):
+        """EnergyAttachments::add_by_distance: returns the (point-point, point-edge, point-triangle) handlers."""
+        a = np.ascontiguousarray(points, dtype=np.int32)
+        t = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        out = (C.c_int32 * 3)()
+        self._ck(self.L.mistark_sim_attach_by_distance(self.h, set_0, set_1, a.ctypes.data, len(a), t.ctypes.data, len(t), distance, stiffness, tolerance, out))
+        return list(out)
+
+    def attach_rigid_body_by_distance(self, rb, point_set, loc_vertices, triangles, points, distance, stiffness, tolerance=0.0) -> int:
+        v = np.ascontiguousarray(loc_vertices, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        a = np.ascontiguousarray(points, dtype=np.int32)
+        return self._ck(self.L.mistark_sim_attach_rigid_body_by_distance(self.h, rb, point_set, v.ctypes.data, len(v), t.ctypes.data, len(t), a.ctypes.data, len(a), distance, stiffness,
+                                                                         tolerance))
 
     def attachment_stiffness(self, handler) -> float:
         k = C.c_double()

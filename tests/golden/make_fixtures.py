@@ -49,6 +49,8 @@ FIXTURES = {
     # rods + attachments (§8(f) rank 1): both segment-strain potentials and the five attachment potentials
     "attachzoo": ("dump", "attachzoo", "steps=2 amp=0.05"),
     "traj_attachzoo": ("traj", "attachzoo", "steps=4"),
+    "attachdist": ("dump", "attachdist", "steps=1 amp=0.02"),
+    "traj_attachdist": ("traj", "attachdist", "steps=4"),
     # the reference's example scene hanging_net (examples/main.cpp:12-39) at 12 x 12
     "traj_hangingnet_12": ("traj", "hangingnet", "n=12 steps=4"),
     # Newton trajectories (iterates after every Newton iteration)

@@ -793,3 +793,38 @@ def test_reference_writes_its_own_log_and_frames_through_the_shim(tmp_path):
         rp, rc, rt = _read_vtk(bytes(z[f[:-4] + "_vtk"]))
         op, oc, ot = _read_vtk(open(os.path.join(tmp_path, f), "rb").read())
         assert (oc == rc).all() and (ot == rt).all() and np.abs(op - rp).max() <= (0.0 if f.endswith("_0.vtk") else 1e-5), f
+
+
+def test_run_stop_conditions(tmp_path):
+    """Stark::run (Stark.cpp:79-132): the loop ends when the frame count passes Settings::execution.end_frame, when the simulation time
+    passes end_simulation_time, or when `duration` is used up — whichever comes first."""
+    from stark_amd import sim as S
+
+    def beam(**kw):
+        st = S.default_settings()
+        st.init_frictional_contact = 0
+        st.enable_frame_writes = 1
+        st.fps = 30
+        st.output_directory = str(tmp_path).encode()
+        st.simulation_name = b"stop"
+        for k, v in kw.items():
+            setattr(st, k, v)
+        sim = S.Simulation(st)
+        ps = sim.add_volume_grid("beam", (0.0, 0.0, 0.0), (1.0, 0.25, 0.25), (4, 1, 1), S.soft_rubber())
+        sim.prescribe_inside_aabb(ps, (-0.5, 0.0, 0.0), (2e-3, 2.0, 2.0), 1e7)
+        return sim
+
+    sim = beam(end_frame=2)                       # frames 0, 1, 2 are written, then frame 3 > end_frame stops the loop
+    assert sim.run(10.0)
+    i = sim.info()
+    assert 3 <= i.current_time_step <= 4 and i.current_time < 0.2
+    sim.close()
+    sim = beam(end_simulation_time=0.1)
+    assert sim.run(10.0)
+    t = sim.info().current_time
+    assert 0.1 < t <= 0.1 + 1.0 / 30.0 + 1e-9     # the step that crosses the limit is the last one
+    sim.close()
+    sim = beam()
+    assert sim.run(0.05)
+    assert 0.05 < sim.info().current_time <= 0.05 + 1.0 / 30.0 + 1e-9
+    sim.close()
