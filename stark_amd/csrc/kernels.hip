@@ -24,6 +24,9 @@ namespace mistark {
 constexpr int BLOCK = 256;
 constexpr int MAX_PARTIALS = 4096;   // max grid of any kernel that emits per-block partial sums
 constexpr int VEC_GRID = 512;
+// Jacobi sweeps stop when off(A)^2 <= tol * ||A||_F^2. Convergence is quadratic (a sweep squares off/||A||), so 1e-24 (off/||A|| <= 1e-12:
+// eigenvalues and the rebuilt matrix to 1e-12 relative, three orders below the parity tolerance) saves the last sweep of 1e-30.
+constexpr double JACOBI_OFF_TOL = 1e-24;
 constexpr int PCG_GRID = 1024;  // vector kernels of the PCG (per-block partial sums: <= MAX_PARTIALS)
 
 static inline int grid_for(int64_t n, int per_block = BLOCK, int cap = 1 << 30)
@@ -1587,7 +1590,7 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig(double* __restrict__ elem
         }
         off = wave_sum(off);
         off = read_lane(off, 0);
-        if (off <= 1e-30 * fro) break;
+        if (off <= JACOBI_OFF_TOL * fro) break;
         for (int r = 0; r < m - 1; r++) {
             // ---- rotations of this round: lane k < m/2 owns the pair (p, q)
             if (lane < m) {
@@ -1769,7 +1772,7 @@ __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, 
 #pragma unroll
         for (int i = 0; i < n; i++) off += i == c ? 0.0 : a[i] * a[i];
         off = group_sum(off);
-        if (off <= 1e-30 * fro) active = false;
+        if (off <= JACOBI_OFF_TOL * fro) active = false;
         if (__ballot(active) == 0ull) break;
         int pr[n];  // (2 r - i) mod (m - 1) of the rows, advanced by 2 per round (uniform values: scalar registers)
 #pragma unroll

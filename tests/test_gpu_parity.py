@@ -136,7 +136,8 @@ def test_stages_match_reference(path, variant):
 def test_projection_variants_agree(name, proj_variant):
     """The PSD projection has a register-resident kernel (default), the earlier LDS kernel (bit 1), per-potential launches instead of
     the batched one (bit 2) and IEEE division/square root for the rotation angles (bit 4): every combination gives the reference's
-    projected Hessians and the same "changed" count, and agrees with the default path to 1e-12."""
+    projected Hessians and the same "changed" count, and agrees with the default path to 1e-10 (the Jacobi sweeps stop at
+    off(A) <= 1e-12 ||A||; the variants' rotations differ in rounding, so they stop at different points below that)."""
     from gpu_util import engine_from_problem
     from stark_amd import capi
 
@@ -157,7 +158,7 @@ def test_projection_variants_agree(name, proj_variant):
     for pi in H0:
         Hp = z["p%d_hvals_proj" % pi]
         den = np.maximum(np.sqrt((Hp ** 2).sum(axis=(1, 2))), 1e-300)
-        assert (np.sqrt(((H0[pi] - H1[pi]) ** 2).sum(axis=(1, 2))) <= 1e-12 * den).all()
+        assert (np.sqrt(((H0[pi] - H1[pi]) ** 2).sum(axis=(1, 2))) <= 1e-10 * den).all()
         tol = max(1e-9, 10 * ELEMENT_TOL.get(man["potentials"][pi]["name"], 0))
         assert (np.sqrt(((H1[pi] - Hp) ** 2).sum(axis=(1, 2))) <= tol * den).all()
     assert np.abs(v0 - v1).max() <= 4e-6 * np.abs(v0).max()   # float atomics of the deltas
