@@ -919,6 +919,8 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "kernel_dbg") { ctx->c.kernel_dbg = value; ctx->c.layout_dirty = true; }  // measurement only
     else if (n == "lazy_eval") ctx->c.lazy_eval = value != 0;
     else if (n == "no_pattern_overlap") ctx->c.no_pattern_overlap = value != 0;
+    else if (n == "no_eval_overlap") ctx->c.no_eval_overlap = value != 0;
+    else if (n == "no_bounded_pattern") { ctx->c.no_bounded_pattern = value != 0; ctx->c.part[1].dirty = true; }
     else if (n == "fuse_dir") ctx->c.no_fuse_dir = value == 0;
     else if (n == "no_grad_gather") { ctx->c.no_grad_gather = value != 0; ctx->c.layout_dirty = true; }         // staged mistark_eval calls take the lazy path too (tests)
 

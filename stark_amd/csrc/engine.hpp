@@ -288,6 +288,10 @@ struct Context
     hipStream_t side_stream = nullptr;  // the contact part's pattern build overlaps the element evaluation (eval())
     hipEvent_t side_ev[2] = {nullptr, nullptr};
     bool no_pattern_overlap = false;  // option "no_pattern_overlap"
+    hipStream_t aux_stream = nullptr;   // the small potentials of an evaluation run beside the large ones (eval())
+    hipEvent_t aux_ev[2] = {nullptr, nullptr};
+    bool no_eval_overlap = false;     // option "no_eval_overlap"
+    bool no_bounded_pattern = false;  // measurement / cross-check: the contact part's pattern with a read-back per stage, like the static part's
     int kernel_dbg = 0;             // option "kernel_dbg": measurement switches inside kernels (PotArgs::dbg)
     DevBuf<uint8_t> is_projected, active_blocks;
     bool have_hessians = false;

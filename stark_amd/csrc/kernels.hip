@@ -27,6 +27,7 @@ constexpr int VEC_GRID = 512;
 // Jacobi sweeps stop when off(A)^2 <= tol * ||A||_F^2. Convergence is quadratic (a sweep squares off/||A||), so 1e-24 (off/||A|| <= 1e-12:
 // eigenvalues and the rebuilt matrix to 1e-12 relative, three orders below the parity tolerance) saves the last sweep of 1e-30.
 constexpr double JACOBI_OFF_TOL = 1e-24;
+constexpr int64_t EVAL_SMALL_POTENTIAL = 32768;  // potentials with fewer elements are evaluated on the auxiliary stream (eval())
 constexpr int PCG_GRID = 1024;  // vector kernels of the PCG (per-block partial sums: <= MAX_PARTIALS)
 
 static inline int grid_for(int64_t n, int per_block = BLOCK, int cap = 1 << 30)
@@ -197,7 +198,9 @@ __global__ __launch_bounds__(BLOCK) void k_grad_gather(const double* __restrict_
 #pragma unroll
         for (int u = 0; u < 8; u++) acc += src[u] != 0xFFFFFFFFu ? h[u] : 0.0;
     }
-    grad[t] += acc;
+    // (atomic: the small potentials of the same evaluation run on another stream and add to the same rows with atomics; one addition per row
+    // and potential here, so rows that only closed-form elements touch keep their bits from run to run)
+    atomicAdd(&grad[t], acc);
 }
 // Closed-form tet kernels (tet_closed.hpp): one lane per tet; gradient through the pool above (or 12 atomics). The 16 Hessian blocks of a tet belong to 16 pools
 // (H[pair][element][9]); a lane storing its own 72 bytes would make every store instruction touch 64 separate segments, so each block
@@ -858,9 +861,12 @@ __global__ __launch_bounds__(BLOCK) void k_slots(const uint64_t* __restrict__ ke
     }
 }
 // rscan = inclusive prefix of row_head over slots: compact row of a slot = rscan-1
-__global__ __launch_bounds__(BLOCK) void k_rows(const uint32_t* __restrict__ slot_row, const uint32_t* __restrict__ rscan, int64_t nnzb, int32_t* __restrict__ rowmap,
-                                                int64_t* __restrict__ row_ptr, int32_t* __restrict__ tile_first_row, uint32_t* __restrict__ colw)
+// (n_dev: the count lives on the device — the contact part's pattern is built without intermediate read-backs, every kernel of the chain
+// is launched over the capacity and reads the actual count itself; nullptr: the host's count)
+__global__ __launch_bounds__(BLOCK) void k_rows(const uint32_t* __restrict__ slot_row, const uint32_t* __restrict__ rscan, int64_t nnzb, const uint32_t* __restrict__ n_dev,
+                                                int32_t* __restrict__ rowmap, int64_t* __restrict__ row_ptr, int32_t* __restrict__ tile_first_row, uint32_t* __restrict__ colw)
 {
+    if (n_dev) nnzb = (int64_t)*n_dev;
     const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (s >= nnzb) return;
     const uint32_t r1 = rscan[s];
@@ -933,21 +939,27 @@ __device__ __forceinline__ uint32_t make_desc(uint32_t kp, const DescRange* __re
 }
 constexpr int CHUNK_BLOCKS = 256;
 constexpr int DYN_SHORT_ROW = 32;  // contact rows of a node hold a handful of blocks; only the rows of rigid bodies in contact are long
-__global__ __launch_bounds__(BLOCK) void k_crow_of_row(const int32_t* __restrict__ rowmap, int64_t n_rows, int32_t* __restrict__ crow_of_row)
+__global__ __launch_bounds__(BLOCK) void k_crow_of_row(const int32_t* __restrict__ rowmap, int64_t n_rows, const uint32_t* __restrict__ n_dev, int32_t* __restrict__ crow_of_row)
 {
+    if (n_dev) n_rows = (int64_t)*n_dev;
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r < n_rows) crow_of_row[rowmap[r]] = (int32_t)r;
 }
-__global__ __launch_bounds__(BLOCK) void k_chunk_count(const int64_t* __restrict__ row_ptr, int64_t n_rows, uint32_t* __restrict__ cnt)
+// cnt[0 .. n_fill]: chunks per row, zero from n_rows on (n_fill = n_rows, or the capacity when the count lives on the device)
+__global__ __launch_bounds__(BLOCK) void k_chunk_count(const int64_t* __restrict__ row_ptr, int64_t n_rows, const uint32_t* __restrict__ n_dev, int64_t n_fill, uint32_t* __restrict__ cnt)
 {
+    if (n_dev) n_rows = (int64_t)*n_dev;
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (r > n_rows) return;
+    if (r > n_fill) return;
     const int64_t len = r < n_rows ? row_ptr[r + 1] - row_ptr[r] : 0;
     cnt[r] = len > DYN_SHORT_ROW ? (uint32_t)((len + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS) : 0u;  // short rows are summed by one lane each (spmv_chunks)
 }
-__global__ __launch_bounds__(BLOCK) void k_chunk_fill(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ row_chunk0, int64_t n_rows, int32_t* __restrict__ chunk_row)
+__global__ __launch_bounds__(BLOCK) void k_chunk_fill(const int64_t* __restrict__ row_ptr, const uint32_t* __restrict__ row_chunk0, int64_t n_rows, const uint32_t* __restrict__ n_dev,
+                                                      int32_t* __restrict__ chunk_row, uint32_t* __restrict__ n_chunks_out)
 {
+    if (n_dev) n_rows = (int64_t)*n_dev;
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r == 0 && n_chunks_out) *n_chunks_out = row_chunk0[n_rows];
     if (r >= n_rows) return;
     for (uint32_t k = row_chunk0[r]; k < row_chunk0[r + 1]; k++) chunk_row[k] = (int32_t)r;
 }
@@ -955,9 +967,10 @@ constexpr uint32_t LONG_SLOT = 48;  // BSR blocks with more contributions than t
 constexpr uint32_t VERY_LONG_SLOT = 4096;  // ... and beyond this by VLONG_SPLIT wavefronts and a second pass (the blocks of a rigid body under 10^4..10^5 contacts)
 constexpr int VLONG_SPLIT = 64;
 __global__ void k_copy_u32(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst) { *dst = *src; }
-__global__ __launch_bounds__(BLOCK) void k_long_slots(const uint32_t* __restrict__ slot_start, int64_t nnzb, uint32_t* __restrict__ list, uint32_t* __restrict__ vlist,
-                                                     int* __restrict__ count)
+__global__ __launch_bounds__(BLOCK) void k_long_slots(const uint32_t* __restrict__ slot_start, int64_t nnzb, const uint32_t* __restrict__ n_dev, uint32_t* __restrict__ list,
+                                                     uint32_t* __restrict__ vlist, int* __restrict__ count)
 {
+    if (n_dev) nnzb = (int64_t)*n_dev;
     const int64_t s = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (s >= nnzb) return;
     const uint32_t len = slot_start[s + 1] - slot_start[s];
@@ -1094,9 +1107,9 @@ static void build_pattern(Context& c, int part)
     if (nk >= (1ull << 31)) throw Error("pattern too large");
     m.keys.ensure(nk);
     m.keys_alt.ensure(nk);
-    m.kidx.ensure(nk);
-    m.kidx_alt.ensure(nk);
-    m.scan.ensure(nk);
+    m.kidx.ensure(nk + 1);
+    m.kidx_alt.ensure(nk + 1);
+    m.scan.ensure(nk + 1);
     for (auto& P : c.pots) {
         if (P.part != part || P.n_key == 0) continue;
         hipLaunchKernelGGL(k_keys, dim3(grid_for((int64_t)P.n_key * P.NB * P.NB)), dim3(BLOCK), 0, c.stream, P.args, P.NB, P.n_key, ncols, sentinel, m.keys.p, m.kidx.p,
@@ -1120,6 +1133,72 @@ static void build_pattern(Context& c, int part)
     MS_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp2, heads, m.scan.p, (int)nk, c.stream));
     c.cub_tmp.ensure(tmp2);
     MS_CHECK(hipcub::DeviceScan::InclusiveSum(c.cub_tmp.p, tmp2, heads, m.scan.p, (int)nk, c.stream));
+    c.counters.ensure(128);
+    if (part == 1 && c.world == 1 && !c.no_bounded_pattern) {
+        // ---- the contact part, rebuilt whenever the contact sets change: NO intermediate read-back. Every buffer is sized by its bound
+        // (nk contributions give at most nk blocks, rows and row chunks), every kernel of the chain is launched over the bound and reads
+        // the actual count on the device; the five counts reach the host in one read-back at the end (before: four round trips of
+        // 25-40 us each inside a chain of tiny kernels).
+        const size_t cap = nk, cap_tiles = (nk + 63) / 64;
+        uint32_t* cnt = (uint32_t*)c.counters.p;  // [0] long blocks, [1] very long blocks, [2] rows, [3] row chunks, [4] blocks
+        MS_CHECK(hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), c.stream));
+        hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(1), 0, c.stream, (const uint32_t*)(m.scan.p + (nk - 1)), cnt + 4);
+        m.colw.ensure(cap_tiles * 64);
+        m.slot_row.ensure(cap);
+        m.tile_first_row.ensure(cap_tiles);
+        m.vals.ensure(cap_tiles * 576);
+        m.slot_start.ensure(cap + 1);
+        m.long_slots.ensure(cap);
+        m.vlong_slots.ensure(cap / VERY_LONG_SLOT + 64);
+        m.rowmap.ensure(cap);
+        m.row_ptr.ensure(cap + 1);
+        m.row_chunk0.ensure(cap + 2);
+        m.chunk_row.ensure(2 * cap + 1);
+        m.yd.ensure(3 * cap);
+        m.chunk_partial.ensure(3 * (2 * cap + 1));
+        m.crow_of_row.ensure((size_t)c.nbr);
+        MS_CHECK(hipMemsetAsync(m.colw.p, 0, cap_tiles * 64 * sizeof(uint32_t), c.stream));
+        uint32_t* row_head = heads;  // (heads is dead after the scan; slots beyond the last block must read 0 in the row scan)
+        MS_CHECK(hipMemsetAsync(row_head, 0, (nk + 1) * sizeof(uint32_t), c.stream));
+        hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, ncols, sentinel, m.slot_of_src.p, m.colw.p, m.slot_row.p,
+                           c.diag_slot[part].p, m.slot_start.p, row_head);
+        m.sorted_src = sidx;
+        m.desc_lazy = -1;
+        hipLaunchKernelGGL(k_long_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, m.slot_start.p, (int64_t)0, (const uint32_t*)(cnt + 4), m.long_slots.p, m.vlong_slots.p, (int*)cnt);
+        uint32_t* rscan = m.scan.p;  // (scan is dead after k_slots)
+        size_t tmp3 = 0;
+        MS_CHECK(hipcub::DeviceScan::InclusiveSum(nullptr, tmp3, row_head, rscan, (int)nk, c.stream));
+        c.cub_tmp.ensure(tmp3);
+        MS_CHECK(hipcub::DeviceScan::InclusiveSum(c.cub_tmp.p, tmp3, row_head, rscan, (int)nk, c.stream));
+        hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(1), 0, c.stream, (const uint32_t*)(rscan + (nk - 1)), cnt + 2);
+        hipLaunchKernelGGL(k_rows, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, m.slot_row.p, rscan, (int64_t)0, (const uint32_t*)(cnt + 4), m.rowmap.p, m.row_ptr.p, m.tile_first_row.p,
+                           m.colw.p);
+        uint32_t* ccnt = row_head;  // reuse (nk + 1 entries)
+        hipLaunchKernelGGL(k_chunk_count, dim3(grid_for(nk + 1)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, (int64_t)0, (const uint32_t*)(cnt + 2), (int64_t)nk, ccnt);
+        size_t tmp5 = 0;
+        MS_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp5, ccnt, m.row_chunk0.p, (int)nk + 1, c.stream));
+        c.cub_tmp.ensure(tmp5);
+        MS_CHECK(hipcub::DeviceScan::ExclusiveSum(c.cub_tmp.p, tmp5, ccnt, m.row_chunk0.p, (int)nk + 1, c.stream));
+        MS_CHECK(hipMemsetAsync(m.crow_of_row.p, 0xFF, (size_t)c.mrows() * sizeof(int32_t), c.stream));
+        hipLaunchKernelGGL(k_crow_of_row, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, m.rowmap.p, (int64_t)0, (const uint32_t*)(cnt + 2), m.crow_of_row.p);
+        hipLaunchKernelGGL(k_chunk_fill, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, m.row_chunk0.p, (int64_t)0, (const uint32_t*)(cnt + 2), m.chunk_row.p, cnt + 3);
+        uint32_t h[5] = {0, 0, 0, 0, 0};
+        fetch(c, h, cnt, sizeof(h));
+        m.n_long = (int)h[0];
+        m.n_vlong = (int)h[1];
+        m.n_rows = h[2];
+        m.n_chunks = h[3];
+        m.nnzb = h[4];
+        m.ntiles = (m.nnzb + 63) / 64;
+        if (m.nnzb == 0) {
+            MS_CHECK(hipMemsetAsync(m.slot_of_src.p, 0xFF, nk * sizeof(uint32_t), c.stream));
+            m.n_rows = 0;
+            m.n_long = m.n_vlong = 0;
+            m.n_chunks = 0;
+            m.n_keys = 0;
+        }
+        return;
+    }
     uint32_t nnzb32 = 0;
     fetch(c, &nnzb32, m.scan.p + (nk - 1), sizeof(uint32_t));
     m.nnzb = nnzb32;
@@ -1148,7 +1227,7 @@ static void build_pattern(Context& c, int part)
     c.counters.ensure(128);
     MS_CHECK(hipMemsetAsync(c.counters.p, 0, sizeof(int64_t), c.stream));
     m.vlong_slots.ensure((size_t)nk / VERY_LONG_SLOT + 64);  // (a pattern of nk contributions holds at most nk / VERY_LONG_SLOT of them)
-    hipLaunchKernelGGL(k_long_slots, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_start.p, m.nnzb, m.long_slots.p, m.vlong_slots.p, (int*)c.counters.p);
+    hipLaunchKernelGGL(k_long_slots, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_start.p, (int64_t)m.nnzb, (const uint32_t*)nullptr, m.long_slots.p, m.vlong_slots.p, (int*)c.counters.p);
     int n_long_h[2] = {0, 0};
     // compact rows
     uint32_t* rscan = m.scan.p;  // (scan is dead after k_slots)
@@ -1167,7 +1246,7 @@ static void build_pattern(Context& c, int part)
     m.n_vlong = n_long_h[1];
     m.rowmap.ensure((size_t)m.n_rows);
     m.row_ptr.ensure((size_t)m.n_rows + 1);
-    hipLaunchKernelGGL(k_rows, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_row.p, rscan, m.nnzb, m.rowmap.p, m.row_ptr.p, m.tile_first_row.p, m.colw.p);
+    hipLaunchKernelGGL(k_rows, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_row.p, rscan, (int64_t)m.nnzb, (const uint32_t*)nullptr, m.rowmap.p, m.row_ptr.p, m.tile_first_row.p, m.colw.p);
     MS_CHECK(hipStreamSynchronize(c.stream));
     if (part == 0 && m.n_rows != c.mrows()) throw Error("internal: static part must contain every block row");
     if (part == 0) build_aligned(c, m);
@@ -1176,7 +1255,7 @@ static void build_pattern(Context& c, int part)
         // with thousands of blocks; see k_spmv_chunks)
         m.row_chunk0.ensure((size_t)m.n_rows + 1);
         uint32_t* cnt = (uint32_t*)row_head;  // reuse
-        hipLaunchKernelGGL(k_chunk_count, dim3(grid_for(m.n_rows + 1)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, m.n_rows, cnt);
+        hipLaunchKernelGGL(k_chunk_count, dim3(grid_for(m.n_rows + 1)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, (int64_t)m.n_rows, (const uint32_t*)nullptr, (int64_t)m.n_rows, cnt);
         size_t tmp5 = 0;
         MS_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp5, cnt, m.row_chunk0.p, (int)m.n_rows + 1, c.stream));
         c.cub_tmp.ensure(tmp5);
@@ -1188,9 +1267,9 @@ static void build_pattern(Context& c, int part)
         m.yd.ensure(3 * std::max<size_t>((size_t)m.n_rows, 1));
         m.crow_of_row.ensure((size_t)c.nbr);
         MS_CHECK(hipMemsetAsync(m.crow_of_row.p, 0xFF, (size_t)c.mrows() * sizeof(int32_t), c.stream));
-        hipLaunchKernelGGL(k_crow_of_row, dim3(grid_for(m.n_rows)), dim3(BLOCK), 0, c.stream, m.rowmap.p, m.n_rows, m.crow_of_row.p);
+        hipLaunchKernelGGL(k_crow_of_row, dim3(grid_for(m.n_rows)), dim3(BLOCK), 0, c.stream, m.rowmap.p, (int64_t)m.n_rows, (const uint32_t*)nullptr, m.crow_of_row.p);
         m.chunk_partial.ensure(3 * std::max<size_t>(nch, 1));
-        hipLaunchKernelGGL(k_chunk_fill, dim3(grid_for(m.n_rows)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, m.row_chunk0.p, m.n_rows, m.chunk_row.p);
+        hipLaunchKernelGGL(k_chunk_fill, dim3(grid_for(m.n_rows)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, m.row_chunk0.p, (int64_t)m.n_rows, (const uint32_t*)nullptr, m.chunk_row.p, (uint32_t*)nullptr);
     }
 }
 
@@ -1411,7 +1490,35 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         MS_CHECK(hipMemsetAsync(c.grad.p, 0, (size_t)c.ndofs * sizeof(double), c.stream));
         if (c.n_hot > 0) MS_CHECK(hipMemsetAsync(c.grad_hot.p, 0, (size_t)HOT_WAYS * 3 * c.n_hot * sizeof(double), c.stream));
     }
-    for (auto& P : c.pots) launch_eval_kind(c, P, mode);
+    // The handful of large potentials (a million tets: 230 us) and the dozens of small ones (rigid bodies, the 35 contact and friction
+    // tables: 5-12 us each, latency, one after the other) share nothing but the gradient, which both sides add to atomically: the small
+    // ones go to their own stream and disappear behind the large ones.
+    // (energy-only evaluations are too short for it: the two stream joins cost more than they hide)
+    const bool split = c.world == 1 && !c.no_eval_overlap && c.pots.size() > 1 && mode != MISTARK_EVAL_P;
+    hipStream_t main_stream = c.stream;
+    if (split) {
+        if (!c.aux_stream) {
+            MS_CHECK(hipStreamCreateWithFlags(&c.aux_stream, hipStreamNonBlocking));
+            MS_CHECK(hipEventCreateWithFlags(&c.aux_ev[0], hipEventDisableTiming));
+            MS_CHECK(hipEventCreateWithFlags(&c.aux_ev[1], hipEventDisableTiming));
+        }
+        MS_CHECK(hipEventRecord(c.aux_ev[0], main_stream));  // (zero fill of the gradient, uploads, the contact tables)
+        MS_CHECK(hipStreamWaitEvent(c.aux_stream, c.aux_ev[0], 0));
+    }
+    try {
+        for (auto& P : c.pots) {
+            c.stream = (split && P.n_elem < EVAL_SMALL_POTENTIAL) ? c.aux_stream : main_stream;
+            launch_eval_kind(c, P, mode);
+        }
+    } catch (...) {
+        c.stream = main_stream;
+        throw;
+    }
+    c.stream = main_stream;
+    if (split) {
+        MS_CHECK(hipEventRecord(c.aux_ev[1], c.aux_stream));
+        MS_CHECK(hipStreamWaitEvent(main_stream, c.aux_ev[1], 0));
+    }
     if (overlap_pattern) {
         MS_CHECK(hipStreamWaitEvent(c.side_stream, c.side_ev[0], 0));
         hipStream_t main_stream = c.stream;
@@ -3439,6 +3546,11 @@ Context::~Context()
     if (h_scratch) (void)hipHostFree(h_scratch);
     if (h_pin) (void)hipHostFree(h_pin);
     if (pub) (void)hipHostFree(pub);
+    if (aux_stream) {
+        (void)hipStreamDestroy(aux_stream);
+        (void)hipEventDestroy(aux_ev[0]);
+        (void)hipEventDestroy(aux_ev[1]);
+    }
     if (side_stream) {
         (void)hipStreamDestroy(side_stream);
         (void)hipEventDestroy(side_ev[0]);
