@@ -3423,7 +3423,7 @@ __global__ void k_copy_ctrl(const PcgCtrl* __restrict__ src, PcgCtrl* __restrict
     }
 }
 // SpMV timing inside the solver: every SPMV_SAMPLE-th launch is bracketed by a pair of pooled HIP events on the engine's stream
-constexpr int SPMV_SAMPLE = 32;  // (an event pair costs the stream ~12 us: sampled sparsely so that measuring does not change what is measured)
+constexpr int SPMV_SAMPLE = 16;  // (an event pair costs the stream ~12 us: sampled sparsely so that measuring does not change what is measured)
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
 {
     if (!c.have_matrix) throw Error("pcg: matrix not assembled");
