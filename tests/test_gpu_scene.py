@@ -234,12 +234,19 @@ def test_cloth_on_box_contact_trajectory():
     sim.close()
 
 
-@pytest.mark.parametrize("name", ["traj_blockbox_3", "traj_blockbox_3_nofriction", "traj_cfg3_blockbox_10"])
-def test_block_on_box_contact_trajectory(name):
+@pytest.mark.parametrize("name,options", [("traj_blockbox_3", ""), ("traj_blockbox_3_nofriction", ""), ("traj_cfg3_blockbox_10", ""),
+                                          # the same trajectory with the round-2 overlaps switched off one by one (small potentials beside the large
+                                          # ones, device-side counts in the contact part's pattern, pattern beside the evaluation, lazy float pool,
+                                          # repeated-search caches): the reference's iteration counts either way
+                                          ("traj_cfg3_blockbox_10", "no_eval_overlap"), ("traj_cfg3_blockbox_10", "no_bounded_pattern"),
+                                          ("traj_cfg3_blockbox_10", "no_pattern_overlap"), ("traj_cfg3_blockbox_10", "no_contact_cache")])
+def test_block_on_box_contact_trajectory(name, options, monkeypatch):
     """configs[3] at fixture size (and at 12 k tets): Soft_Rubber tet block landing on a fixed rigid box (collision surface from
     find_surface), with friction (box registered first) and without (block first)."""
     from stark_amd import sim as S
 
+    if options:
+        monkeypatch.setenv("MISTARK_OPTIONS", options + "=1")
     z, traj, man = _load(name)
     sc = traj["scene"]
     sim = _contact_sim(S, sc)
