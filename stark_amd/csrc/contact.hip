@@ -640,9 +640,18 @@ __global__ __launch_bounds__(CB) void k_sweep_tasks(ContactDev d, Bands B, const
 
 // ---- sorted keys -> tables -----------------------------------------------------------------------------------------------------------
 // bounds[t] = first sorted key of table t (t = 0..N_TABLES), same[0] = 1 iff the list equals the previous one
-__global__ __launch_bounds__(CB) void k_table_bounds(const uint64_t* __restrict__ keys, int n, const uint64_t* __restrict__ prev, int n_prev, int* __restrict__ bounds,
-                                                    int* __restrict__ differs)
+// keys[n .. n_pad) = padding that sorts last (n = the count the search left on the device)
+__global__ __launch_bounds__(CB) void k_pad_keys(uint64_t* __restrict__ keys, const int* __restrict__ n_dev, int n_pad)
 {
+    const int i = blockIdx.x * CB + threadIdx.x;
+    if (i >= *n_dev && i < n_pad) keys[i] = ~0ull;
+}
+// (n_dev: the number of keys as the search left it on the device, capped by n — the list was sorted over a padded length before the host
+// knew the count)
+__global__ __launch_bounds__(CB) void k_table_bounds(const uint64_t* __restrict__ keys, int n, const int* __restrict__ n_dev, const uint64_t* __restrict__ prev, int n_prev,
+                                                    int* __restrict__ bounds, int* __restrict__ differs)
+{
+    if (n_dev) n = min(n, *n_dev);
     const int i = blockIdx.x * CB + threadIdx.x;
     if (i > n) return;
     const int t_here = i < n ? (int)(keys[i] >> 58) : N_TABLES;
@@ -821,8 +830,9 @@ struct ContactSystem
     int64_t n_updates = 0;
     bool brute_force = false;  // ablation / fallback: LDS-tiled all-pairs kernels
     int64_t n_prev = -1;  // keys of the barrier tables currently installed (-1: none)
-    DevBuf<int> counters;  // [0] candidates, [1] intersections, [2] differs, [8..8+N_TABLES] bounds
+    DevBuf<int> counters;  // [0] candidates, [1] intersections, [2] differs, [8..8+N_TABLES] bounds, [48..51] box list (k_bp_fill; [51] = entries needed)
     // result of the last barrier-table search and the inputs it saw (Context::data_version, dt): an identical request is answered from here
+    int n_last = 0;  // keys found by the last search (sizes the padded sort of the next one)
     bool cache_valid = false;
     // the sorted box list of the last search: reused when the next search sees the same state with the same enlargement (the intersection
     // check of a line-search candidate and the proximity search of the energy evaluation that follows it)
@@ -1075,7 +1085,7 @@ void sort_boxes(Context& c, ContactSystem& cs, const ContactDev& d)
     cs.cub_tmp.ensure(tmp);
     MS_CHECK(hipcub::DeviceScan::ExclusiveSum(cs.cub_tmp.p, tmp, cs.bp_cnt.p, cs.bp_off.p, n + 1, c.stream));
     MS_CHECK(hipMemsetAsync(cs.bp_keys.p, 0xFF, (size_t)cap * sizeof(uint64_t), c.stream));  // padding entries sort last
-    hipLaunchKernelGGL(k_bp_fill, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, (const uint32_t*)cs.bp_off.p, cs.bp_keys.p, cs.bp_idx.p, cap, cs.counters.p + 32);
+    hipLaunchKernelGGL(k_bp_fill, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, (const uint32_t*)cs.bp_off.p, cs.bp_keys.p, cs.bp_idx.p, cap, cs.counters.p + 48);
     hipcub::DoubleBuffer<uint64_t> dk(cs.bp_keys.p, cs.bp_keys_alt.p);
     hipcub::DoubleBuffer<uint32_t> dv(cs.bp_idx.p, cs.bp_idx_alt.p);
     MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, cap, 0, 40, c.stream));
@@ -1125,8 +1135,33 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     }
     int h[64];
     int n = 0;
+    const int t0 = friction ? N_CONTACT_TABLES : 0, t1 = friction ? N_TABLES : N_CONTACT_TABLES;
+    const uint64_t* sorted = cs.keys.p;
+    const bool compare = !friction && cs.n_prev >= 0;
+    if (compare) cs.prev.ensure(std::max<size_t>((size_t)cs.n_prev, 1));
+    auto sort_and_bound = [&](int n_sort, const int* n_dev) {
+        hipcub::DoubleBuffer<uint64_t> dk(cs.keys.p, cs.keys_alt.p);
+        if (n_sort > 1) {
+            size_t tmp = 0;
+            MS_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, dk, n_sort, 0, 64, c.stream));
+            cs.cub_tmp.ensure(tmp);
+            MS_CHECK(hipcub::DeviceRadixSort::SortKeys(cs.cub_tmp.p, tmp, dk, n_sort, 0, 64, c.stream));
+        }
+        sorted = dk.Current();
+        hipLaunchKernelGGL(k_table_bounds, dim3((n_sort + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, sorted, n_sort, n_dev, compare ? cs.prev.p : sorted, compare ? (int)cs.n_prev : -1,
+                           cs.counters.p + 8, cs.counters.p + 2);
+    };
     for (;;) {
         MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
+        // One read-back per search: the key list is sorted over a padded length chosen from the previous search's count (padding keys sort
+        // last and carry a table id no table has), the table boundaries are found with the count still on the device, and count,
+        // boundaries and "same as before" flag come back together. A count beyond the padded length takes the two-step path below.
+        int n_pad = 0;
+        if (!c.no_contact_cache) {
+            n_pad = 4096;
+            while (n_pad < 2 * std::max(cs.n_last, 0) + 1024) n_pad *= 2;
+            n_pad = (int)std::min<size_t>((size_t)n_pad, cs.key_cap);
+        }
         if (!cs.brute_force) {
             if (!boxes_current) sort_boxes(c, cs, d);
             boxes_current = false;
@@ -1150,38 +1185,40 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
             else hipLaunchKernelGGL(k_detect_ee<false>, g, dim3(CB), 0, c.stream, d, enl * enl, chunk, cs.keys.p, cs.counters.p, (int)cs.key_cap);
         }
         }
+        if (n_pad > 0) {
+            hipLaunchKernelGGL(k_pad_keys, dim3((n_pad + CB - 1) / CB), dim3(CB), 0, c.stream, cs.keys.p, (const int*)cs.counters.p, n_pad);
+            sort_and_bound(n_pad, (const int*)cs.counters.p);
+        }
         lap(1);
-        fetch(c, h, cs.counters.p, 40 * sizeof(int));
+        fetch(c, h, cs.counters.p, 64 * sizeof(int));
         lap(2);
         n = h[0];
-        if (!cs.brute_force && h[35] > cs.bp_cap) {  // (counters[32 + 3]) the banded box list did not fit: grow and search again
-            cs.bp_cap = h[35] + h[35] / 4;
+        if (!cs.brute_force && h[51] > cs.bp_cap) {  // (counters[48 + 3]) the banded box list did not fit: grow and search again
+            cs.bp_cap = h[51] + h[51] / 4;
             cs.bp_valid = false;
             continue;
         }
-        if ((size_t)n <= cs.key_cap) break;
-        cs.key_cap = (size_t)n + n / 2;  // the list did not fit: grow and search again
-        cs.keys.ensure(cs.key_cap);
-        cs.keys_alt.ensure(cs.key_cap);
-        cs.n_prev = -1;
+        if ((size_t)n > cs.key_cap) {
+            cs.key_cap = (size_t)n + n / 2;  // the list did not fit: grow and search again
+            cs.keys.ensure(cs.key_cap);
+            cs.keys_alt.ensure(cs.key_cap);
+            cs.n_prev = -1;
+            continue;
+        }
+        if (n_pad == 0 || n > n_pad) {  // count first, then sort exactly that many (first searches, bursts, option no_contact_cache)
+            if (n_pad > 0) {  // the padded sort moved the first n_pad keys into the other buffer: search again with a longer padding
+                cs.n_last = n;
+                continue;
+            }
+            MS_CHECK(hipMemsetAsync(cs.counters.p + 2, 0, sizeof(int), c.stream));
+            sort_and_bound(n, nullptr);
+            lap(3);
+            fetch(c, h, cs.counters.p, 64 * sizeof(int));
+            lap(4);
+        }
+        break;
     }
-    const int t0 = friction ? N_CONTACT_TABLES : 0, t1 = friction ? N_TABLES : N_CONTACT_TABLES;
-    const uint64_t* sorted = cs.keys.p;
-    if (n > 1) {
-        hipcub::DoubleBuffer<uint64_t> dk(cs.keys.p, cs.keys_alt.p);
-        size_t tmp = 0;
-        MS_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, dk, n, 0, 64, c.stream));
-        cs.cub_tmp.ensure(tmp);
-        MS_CHECK(hipcub::DeviceRadixSort::SortKeys(cs.cub_tmp.p, tmp, dk, n, 0, 64, c.stream));
-        sorted = dk.Current();
-    }
-    const bool compare = !friction && cs.n_prev >= 0;
-    if (compare) cs.prev.ensure(std::max<size_t>((size_t)cs.n_prev, 1));
-    hipLaunchKernelGGL(k_table_bounds, dim3((n + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, sorted, n, compare ? cs.prev.p : sorted, compare ? (int)cs.n_prev : -1,
-                       cs.counters.p + 8, cs.counters.p + 2);
-    lap(3);
-    fetch(c, h, cs.counters.p, 64 * sizeof(int));
-    lap(4);
+    cs.n_last = n;
     const int* bounds = h + 8;
     const bool unchanged = compare && n == cs.n_prev && h[2] == 0;
     if (unchanged) return n;
@@ -1263,10 +1300,10 @@ int64_t count_intersections(Context& c, double dt)
         for (bool first = true;; first = false) {
             if (!(first && boxes_current)) sort_boxes(c, cs, d);
             launch_sweep<false, false>(c, cs, d, 0.0);
-            int hb[40];
+            int hb[64];
             fetch(c, hb, cs.counters.p, sizeof(hb));
-            if (hb[35] > cs.bp_cap) {
-                cs.bp_cap = hb[35] + hb[35] / 4;
+            if (hb[51] > cs.bp_cap) {
+                cs.bp_cap = hb[51] + hb[51] / 4;
                 cs.bp_valid = false;
                 MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 8 * sizeof(int), c.stream));
                 continue;
