@@ -7,6 +7,8 @@
 //   SpMV                 : one wavefront per chunk of complete rows, coalesced 16-B loads, in-wave segmented reduction
 //   PCG                  : 3 kernels per iteration, device-resident convergence control, look-ahead batches
 //   PSD projection       : per-element cyclic Jacobi eigen-decomposition; sharded runs exchange the matrix deltas
+#include <atomic>
+#include <chrono>
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
@@ -3167,8 +3169,10 @@ __device__ __forceinline__ void publish_ctrl(PcgCtrl* __restrict__ host_slot, in
 {
     host_slot->converged = converged;
     host_slot->indef = indef;
-    host_slot->n_iter = n_iter;
     host_slot->error = error;
+    __threadfence_system();
+    // (the host spins on these two: written last)
+    host_slot->n_iter = n_iter;
     host_slot->done = done;
     __threadfence_system();
 }
@@ -3422,6 +3426,7 @@ __global__ void k_copy_ctrl(const PcgCtrl* __restrict__ src, PcgCtrl* __restrict
         __threadfence_system();
     }
 }
+static double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // SpMV timing inside the solver: every SPMV_SAMPLE-th launch is bracketed by a pair of pooled HIP events on the engine's stream
 constexpr int SPMV_SAMPLE = 16;  // (an event pair costs the stream ~12 us: sampled sparsely so that measuring does not change what is measured)
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
@@ -3458,6 +3463,10 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     int k = 1;
     auto launch_batch = [&](int slot) {
         const int k_end = std::min(max_iter, k + PCG_BATCH - 1);
+        // (the slot is written by the batch's last direction kernel; the host waits for it by watching the slot itself — an event record
+        // between batches is a marker packet the next SpMV waits behind: 5 us per batch)
+        hs[slot]->done = 0;
+        hs[slot]->n_iter = -1;
         sampled[slot].clear();
         for (; k <= k_end; k++) {
             const bool sample = c.time_spmv && (k % SPMV_SAMPLE) == 0;
@@ -3495,8 +3504,10 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         if (fuse_dir) hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(BLOCK), 0, c.stream, DirArgs{c.z.p, nullptr, nullptr, part_rr, part_rz, gv, k_end + 1, abs_tol, rel_tol}, c.ctrl.p);
         // the control block reaches the pinned slot from the batch's last k_pcg_dir itself (round 1: a copy command on another engine, 4 us
         // + a 5.6 us gap; then a one-wavefront copy kernel, 4 us + its boundary, every four iterations); the fused variant still copies
-        if (fuse_dir) hipLaunchKernelGGL(k_copy_ctrl, dim3(1), dim3(64), 0, c.stream, (const PcgCtrl*)c.ctrl.p, hs[slot]);
-        MS_CHECK(hipEventRecord(c.pcg_ev[slot], c.stream));
+        if (fuse_dir) {
+            hipLaunchKernelGGL(k_copy_ctrl, dim3(1), dim3(64), 0, c.stream, (const PcgCtrl*)c.ctrl.p, hs[slot]);
+            MS_CHECK(hipEventRecord(c.pcg_ev[slot], c.stream));
+        }
         return k_end;
     };
     auto drain = [&](int slot, int last_real_iter) {
@@ -3517,7 +3528,17 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         const bool more = k <= max_iter;
         int k_end_next = 0;
         if (more) k_end_next = launch_batch(slot ^ 1);  // keep the GPU fed while the host looks at the previous batch
-        MS_CHECK(hipEventSynchronize(c.pcg_ev[slot]));
+        if (fuse_dir) {
+            MS_CHECK(hipEventSynchronize(c.pcg_ev[slot]));
+        } else {
+            const volatile PcgCtrl* v = hs[slot];
+            const double t_wait = now_seconds();
+            for (uint64_t spins = 0; !(v->done || v->n_iter >= k_end_cur); spins++) {
+                __builtin_ia32_pause();
+                if ((spins & 0xfffff) == 0xfffff && now_seconds() - t_wait > 60.0) throw Error("pcg: the device did not report batch " + std::to_string(k_end_cur) + " within 60 s");
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
         h = hs[slot];
         if (c.time_spmv) drain(slot, h->done ? h->n_iter : k_end_cur);
         if (h->done || !more) break;
