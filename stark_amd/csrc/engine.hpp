@@ -258,6 +258,8 @@ struct PcgCtrl
     double error;
     double bb;
     double rz[2];
+    int epoch;  // (pinned copy only) which solve published this: a look-ahead batch of the previous solve may still be on its way
+    int pad_;
 };
 
 struct Context
@@ -322,6 +324,7 @@ struct Context
     uint64_t pattern_version = 1, llt_pattern_version = 0;  // bumped by every pattern build
     bool have_matrix = false;
     bool matrix_current = false;    // the assembled matrix reflects the current element Hessians
+    int pcg_epoch = 0;              // solves started (PcgCtrl::epoch)
     DevBuf<uint32_t> proj_list;     // element ids selected for projection (per potential, at e_off)
 
     // reductions / PCG

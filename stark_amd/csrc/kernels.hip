@@ -3165,21 +3165,22 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, co
     }
 }
 // the control block as the host will read it (pinned memory): written by the one thread that also writes the device copy
-__device__ __forceinline__ void publish_ctrl(PcgCtrl* __restrict__ host_slot, int done, int converged, int indef, int n_iter, double error)
+__device__ __forceinline__ void publish_ctrl(PcgCtrl* __restrict__ host_slot, int epoch, int done, int converged, int indef, int n_iter, double error)
 {
     host_slot->converged = converged;
     host_slot->indef = indef;
     host_slot->error = error;
     __threadfence_system();
-    // (the host spins on these two: written last)
     host_slot->n_iter = n_iter;
     host_slot->done = done;
+    __threadfence_system();
+    host_slot->epoch = epoch;  // (the host looks at this first: written last)
     __threadfence_system();
 }
 // host_slot: non-null on the last iteration of a batch (the host looks at the control block there: no copy kernel, no extra boundary)
 __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double rel_tol, const double* __restrict__ part_rr, const double* __restrict__ part_rz, int nparts,
                                                    int64_t n, const double* __restrict__ z, double* __restrict__ p, PcgCtrl* __restrict__ ctrl, int stride,
-                                                   PcgCtrl* __restrict__ host_slot)
+                                                   PcgCtrl* __restrict__ host_slot, int epoch)
 {
     const int done = ctrl->done;
     const double bb = ctrl->bb, rz_old = ctrl->rz[k & 1];
@@ -3194,13 +3195,13 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
     }
     const bool scribe = blockIdx.x == 0 && threadIdx.x == 0;
     if (done == 1) {
-        if (scribe && host_slot) publish_ctrl(host_slot, 1, ctrl->converged, ctrl->indef, ctrl->n_iter, ctrl->error);
+        if (scribe && host_slot) publish_ctrl(host_slot, epoch, 1, ctrl->converged, ctrl->indef, ctrl->n_iter, ctrl->error);
         return;
     }
     if (done == 2) {  // indefiniteness stop decided in k_pcg_step of this iteration
         if (scribe) {
             ctrl->done = 1;
-            if (host_slot) publish_ctrl(host_slot, 1, ctrl->converged, ctrl->indef, ctrl->n_iter, ctrl->error);
+            if (host_slot) publish_ctrl(host_slot, epoch, 1, ctrl->converged, ctrl->indef, ctrl->n_iter, ctrl->error);
         }
         return;
     }
@@ -3215,7 +3216,7 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
             ctrl->n_iter = k;
             ctrl->converged = 1;
             ctrl->done = 1;
-            if (host_slot) publish_ctrl(host_slot, 1, 1, ctrl->indef, k, error);
+            if (host_slot) publish_ctrl(host_slot, epoch, 1, 1, ctrl->indef, k, error);
         }
         return;
     }
@@ -3236,7 +3237,7 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_dir(int k, double abs_tol, double
         ctrl->rz[(k + 1) & 1] = rz_new;
         ctrl->error = error;
         ctrl->n_iter = k;
-        if (host_slot) publish_ctrl(host_slot, 0, 0, ctrl->indef, k, error);
+        if (host_slot) publish_ctrl(host_slot, epoch, 0, 0, ctrl->indef, k, error);
     }
 }
 
@@ -3459,12 +3460,14 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         MS_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c.pcg_ev.push_back(e);
     }
+    const int epoch = ++c.pcg_epoch;
     std::vector<int> sampled[2];
     int k = 1;
     auto launch_batch = [&](int slot) {
         const int k_end = std::min(max_iter, k + PCG_BATCH - 1);
         // (the slot is written by the batch's last direction kernel; the host waits for it by watching the slot itself — an event record
         // between batches is a marker packet the next SpMV waits behind: 5 us per batch)
+        hs[slot]->epoch = epoch - 1;  // (whatever a straggler of the previous solve writes here carries the previous epoch, too)
         hs[slot]->done = 0;
         hs[slot]->n_iter = -1;
         sampled[slot].clear();
@@ -3498,7 +3501,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
                                (const double*)m1.chunk_partial.p);
             if (!fuse_dir)
                 hipLaunchKernelGGL(k_pcg_dir, dim3(gv), dim3(BLOCK), 0, c.stream, k, abs_tol, rel_tol, part_rr, part_rz, gv, c.ndofs, c.z.p, c.p.p, c.ctrl.p, 1,
-                                   k == k_end ? hs[slot] : (PcgCtrl*)nullptr);
+                                   k == k_end ? hs[slot] : (PcgCtrl*)nullptr, epoch);
         }
         // (fused: the test of the batch's last iteration would only run with the next batch's first SpMV; the host reads the control block now)
         if (fuse_dir) hipLaunchKernelGGL(k_pcg_check, dim3(1), dim3(BLOCK), 0, c.stream, DirArgs{c.z.p, nullptr, nullptr, part_rr, part_rz, gv, k_end + 1, abs_tol, rel_tol}, c.ctrl.p);
@@ -3533,7 +3536,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         } else {
             const volatile PcgCtrl* v = hs[slot];
             const double t_wait = now_seconds();
-            for (uint64_t spins = 0; !(v->done || v->n_iter >= k_end_cur); spins++) {
+            for (uint64_t spins = 0; !(v->epoch == epoch && (v->done || v->n_iter >= k_end_cur)); spins++) {
                 __builtin_ia32_pause();
                 if ((spins & 0xfffff) == 0xfffff && now_seconds() - t_wait > 60.0) throw Error("pcg: the device did not report batch " + std::to_string(k_end_cur) + " within 60 s");
             }

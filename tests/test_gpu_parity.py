@@ -347,3 +347,27 @@ def test_pcg_fused_direction_variant(name):
     a, b = out
     assert a[1] == b[1] and a[2] == b[2] and a[4] == b[4] and a[5] == b[5]
     assert _rel(b[0], a[0]) < 1e-12 and _rel(b[3], a[3]) < 1e-12
+
+
+def test_pcg_back_to_back_solves_do_not_see_each_others_lookahead():
+    """Many solves in a row (the look-ahead batch of one solve publishes its "done" into a pinned slot the next solve watches, too: the
+    published block carries the solve's epoch): every solve reports what it reported the first time, to the bit."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, "tetbeam_softrubber_6x2x2.npz"))
+    eng = engine_from_problem(prob, man)
+    eng.eval(capi.EVAL_P_G_H)
+    eng.assemble()
+    tols = [1e-2, 1e-10, 1e-4, 1e-12, 1e-6, 1e-3, 1e-9]
+    alone = []
+    for t in tols:
+        du, info = eng.pcg(t, 1e-14, 5000)
+        alone.append((info.n_iterations, info.converged, du.copy()))
+    assert len({a[0] for a in alone}) >= 4                      # the tolerances really give different iteration counts
+    for rep in range(20):
+        for t, (n_it, conv, du_ref) in zip(tols, alone):
+            du, info = eng.pcg(t, 1e-14, 5000)
+            assert (info.n_iterations, info.converged) == (n_it, conv)
+            assert (du == du_ref).all()
+    eng.close()
