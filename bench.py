@@ -227,6 +227,11 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    import ctypes as _C0
+    _ov = _C0.c_double()
+    spmv_ev_overhead_ms = _ov.value if capi.lib().mistark_spmv_event_overhead(sim.engine_handle(), _C0.byref(_ov)) == 0 and _ov.value > 0 else None
+    if spmv_ev_overhead_ms is None and _ov.value > 0:
+        spmv_ev_overhead_ms = _ov.value
     spmv_ms, spmv_n, spmv_bytes = sim.spmv_timing(reset=-1)
     spmv_b2b_ms = None
     if rank == 0:
@@ -289,6 +294,10 @@ def main():
                 "algorithmic_bytes_per_launch": spmv_bytes,
                 "avg_launch_ms": spmv_ms,
                 "launches_timed": spmv_n,
+                # every timed launch is followed by an EMPTY event bracket on the same stream: what two event records cost by themselves
+                # (marker packets). Reported for information only: `achieved` / `frac` use the raw bracket, which therefore UNDERSTATES the
+                # kernel (rocprofv3's duration of the same launches lies between the raw bracket and raw minus this figure)
+                "event_pair_overhead_ms": spmv_ev_overhead_ms,
                 # the same launch 100 times back to back after the timed region (one event pair around the batch, no dispatch gap per
                 # launch): what rocprofv3 reports as the kernel's own duration
                 "back_to_back_launch_ms": spmv_b2b_ms,

@@ -270,6 +270,9 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value);
 /* Average duration in ms of the SpMV kernel over the launches since the last reset, measured with HIP events on the
  * engine's stream; n = number of launches measured. Used by bench.py for the roofline figure. */
 int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n, double* bytes_per_launch);
+/* Average duration in ms of the EMPTY event brackets recorded right behind the timed launches: what a pair of event records costs the
+ * stream by itself (call before the reset of mistark_spmv_timing). */
+int mistark_spmv_event_overhead(mistark_ctx* ctx, double* avg_ms);
 /* Micro-benchmark: n back-to-back SpMV launches on the currently assembled matrix, average duration in microseconds. */
 int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us);
 /* Waits until everything queued on the engine's stream has finished (entry points that return values already do; assemble / project /

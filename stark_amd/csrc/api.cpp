@@ -950,6 +950,13 @@ int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us)
     API_END(0)
 }
 
+int mistark_spmv_event_overhead(mistark_ctx* ctx, double* avg_ms)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (avg_ms) *avg_ms = c.spmv_n > 0 ? c.spmv_empty_ms_sum / (double)c.spmv_n : 0.0;
+    API_END(0)
+}
 int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n, double* bytes_per_launch)
 {
     API_BEGIN
@@ -961,6 +968,7 @@ int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n,
         *bytes_per_launch = (double)(c.part[0].nnzb + c.part[1].nnzb) * 40.0 + ((double)c.nbr + 1.0) * 8.0 + 48.0 * (double)c.nbr + 56.0 * (double)c.part[1].n_rows;
     if (reset) {
         c.spmv_ms_sum = 0.0;
+        c.spmv_empty_ms_sum = 0.0;
         c.spmv_n = 0;
         c.time_spmv = reset > 0;
     }

@@ -348,6 +348,7 @@ struct Context
     std::vector<hipEvent_t> pcg_ev;  // batch completion events of the PCG driver
     std::vector<hipEvent_t> stage_ev;  // stage marks of newton_solve (GPU-side stage times without synchronising)
     double spmv_ms_sum = 0.0;
+    double spmv_empty_ms_sum = 0.0;  // empty event brackets recorded right behind the sampled launches
     int64_t spmv_n = 0;
 
     // multi-GPU: elements of every potential are sharded by contiguous ranges; E, gradient and the assembled matrix

@@ -3473,9 +3473,9 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         sampled[slot].clear();
         for (; k <= k_end; k++) {
             const bool sample = c.time_spmv && (k % SPMV_SAMPLE) == 0;
-            const size_t e0 = (size_t)slot * 2 * PCG_BATCH + 2 * sampled[slot].size();
+            const size_t e0 = (size_t)slot * 3 * PCG_BATCH + 3 * sampled[slot].size();
             if (sample) {
-                while (c.ev.size() < (size_t)4 * PCG_BATCH) {
+                while (c.ev.size() < (size_t)6 * PCG_BATCH) {
                     hipEvent_t e;
                     MS_CHECK(hipEventCreate(&e));
                     c.ev.push_back(e);
@@ -3494,6 +3494,9 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
             }
             if (sample) {
                 MS_CHECK(hipEventRecord(c.ev[e0 + 1], c.stream));
+                // an empty bracket right behind: what a pair of event records costs the stream by itself (the marker packets' own processing
+                // is inside every bracketed duration; bench.py reports both figures)
+                MS_CHECK(hipEventRecord(c.ev[e0 + 2], c.stream));
                 sampled[slot].push_back(k);
             }
             hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, (const double*)pk, c.q.p, c.du.p, c.r.p, c.z.p, part_rr,
@@ -3517,9 +3520,11 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         for (size_t i = 0; i < sampled[slot].size(); i++) {
             if (sampled[slot][i] > last_real_iter) continue;  // early-exit launch after convergence
             float ms = 0.f;
-            const size_t e0 = (size_t)slot * 2 * PCG_BATCH + 2 * i;
-            if (hipEventElapsedTime(&ms, c.ev[e0], c.ev[e0 + 1]) == hipSuccess) {
+            const size_t e0 = (size_t)slot * 3 * PCG_BATCH + 3 * i;
+            float ms_empty = 0.f;
+            if (hipEventElapsedTime(&ms, c.ev[e0], c.ev[e0 + 1]) == hipSuccess && hipEventElapsedTime(&ms_empty, c.ev[e0 + 1], c.ev[e0 + 2]) == hipSuccess) {
                 c.spmv_ms_sum += ms;
+                c.spmv_empty_ms_sum += ms_empty;
                 c.spmv_n++;
             }
         }
