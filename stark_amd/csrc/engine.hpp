@@ -406,7 +406,8 @@ void assemble(Context& c);
 void build_preconditioner(Context& c);
 double spmv_bench(Context& c, int n);
 void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed);
-void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info);
+// rhs_scale: the system solved is A x = rhs_scale * rhs (the Newton loop passes the gradient and -1; single GPU only)
+void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info, double rhs_scale = 1.0);
 bool direct_llt(Context& c, const double* rhs_dev, double* x_dev);  // direct.hip
 // custom.hip
 std::shared_ptr<CustomProgram> make_custom_program(const std::string& name, const int32_t* strides, int n_bindings, const int32_t* ops, const double* consts, int n_ops, int n_inputs,

@@ -2218,11 +2218,29 @@ __global__ __launch_bounds__(BLOCK) void k_assemble(const double* __restrict__ e
     const uint32_t slot = slot_of_src[blk];
     atomicAdd(&vals[tile_val_index(slot, comp)], (float)elemH[t]);
 }
+// closed-form inverse of a SYMMETRIC 3x3 in float, reciprocal of the determinant through double (BlockedSparseMatrix.h:1198-1214)
+__device__ __forceinline__ void sym3_inverse(const float* m, float* o)
+{
+    const float tmp0 = m[4] * m[8];
+    const float tmp1 = m[5] * m[5];
+    const float tmp2 = m[2] * m[5];
+    const float tmp3 = m[1] * m[1];
+    const float tmp4 = m[2] * m[2];
+    const float det = m[0] * tmp0 - m[0] * tmp1 + 2 * m[1] * tmp2 - m[4] * tmp4 - m[8] * tmp3;
+    const float tmp5 = (float)(1.0 / (double)det);
+    o[8] = tmp5 * (m[0] * m[4] - tmp3);
+    o[4] = tmp5 * (m[0] * m[8] - tmp4);
+    o[0] = tmp5 * (tmp0 - tmp1);
+    o[3] = -tmp5 * (m[1] * m[8] - tmp2);
+    o[1] = o[3];
+    o[6] = tmp5 * (m[1] * m[5] - m[4] * m[2]);
+    o[2] = o[6];
+    o[7] = -tmp5 * (m[0] * m[5] - m[1] * m[2]);
+    o[5] = o[7];
+}
 __global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __restrict__ vals, const int32_t* __restrict__ diag_slot, const float* __restrict__ vals_dyn,
                                                               const int32_t* __restrict__ diag_slot_dyn, int64_t nbr, float* __restrict__ dinv)
 {
-    // closed-form inverse of a SYMMETRIC 3x3 in float, reciprocal of the determinant through double
-    // (BlockedSparseMatrix.h:1198-1214)
     const int64_t r = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= nbr) return;
     const uint32_t s = (uint32_t)diag_slot[r];
@@ -2236,23 +2254,7 @@ __global__ __launch_bounds__(BLOCK) void k_block_diag_inverse(const float* __res
             for (int k = 0; k < 9; k++) m[k] += vals_dyn[tile_val_index((uint32_t)sd, k)];
         }
     }
-    const float tmp0 = m[4] * m[8];
-    const float tmp1 = m[5] * m[5];
-    const float tmp2 = m[2] * m[5];
-    const float tmp3 = m[1] * m[1];
-    const float tmp4 = m[2] * m[2];
-    const float det = m[0] * tmp0 - m[0] * tmp1 + 2 * m[1] * tmp2 - m[4] * tmp4 - m[8] * tmp3;
-    const float tmp5 = (float)(1.0 / (double)det);
-    float* o = dinv + 9 * r;
-    o[8] = tmp5 * (m[0] * m[4] - tmp3);
-    o[4] = tmp5 * (m[0] * m[8] - tmp4);
-    o[0] = tmp5 * (tmp0 - tmp1);
-    o[3] = -tmp5 * (m[1] * m[8] - tmp2);
-    o[1] = o[3];
-    o[6] = tmp5 * (m[1] * m[5] - m[4] * m[2]);
-    o[2] = o[6];
-    o[7] = -tmp5 * (m[0] * m[5] - m[1] * m[2]);
-    o[5] = o[7];
+    sym3_inverse(m, dinv + 9 * r);
 }
 
 // Gather assembly (default): the contributions of a BSR block are summed in the fixed order of the sorted pattern keys: no atomics,
@@ -3061,6 +3063,50 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_init(const double* __restrict__ b
         part_rz[blockIdx.x] = rz;
     }
 }
+// The prologue of a solve in one launch plus k_pcg_init2 (single-GPU path): b = scale * rhs (the Newton loop solves A du = -g), the
+// block-Jacobi preconditioner of the rows (k_block_diag_inverse), x = 0, r = b, z = p = M^-1 r. Before: negation, preconditioner and
+// k_pcg_init as three launches with their boundaries. (Folding k_pcg_init2 in as well — the workgroup that draws the last ticket adds
+// the partial sums — was measured and is slower: 674 same-address atomics serialise at ~50 ns each.)
+__global__ __launch_bounds__(BLOCK) void k_pcg_prologue(const double* __restrict__ rhs, double scale, const float* __restrict__ vals, const int32_t* __restrict__ diag_slot,
+                                                        const float* __restrict__ vals_dyn, const int32_t* __restrict__ diag_slot_dyn, int64_t nbr, float* __restrict__ dinv,
+                                                        double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ p, double* __restrict__ part_bb,
+                                                        double* __restrict__ part_rz)
+{
+    __shared__ double sm[4];
+    double bb = 0.0, rz = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x; row < nbr; row += (int64_t)gridDim.x * BLOCK) {
+        float m[9], d[9];
+        const uint32_t s = (uint32_t)diag_slot[row];
+#pragma unroll
+        for (int k = 0; k < 9; k++) m[k] = vals[tile_val_index(s, k)];
+        if (vals_dyn) {
+            const int32_t sd = diag_slot_dyn[row];
+            if (sd >= 0) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) m[k] += vals_dyn[tile_val_index((uint32_t)sd, k)];
+            }
+        }
+        sym3_inverse(m, d);
+#pragma unroll
+        for (int k = 0; k < 9; k++) dinv[9 * row + k] = d[k];
+        const double r0 = scale * rhs[3 * row], r1 = scale * rhs[3 * row + 1], r2 = scale * rhs[3 * row + 2];
+        const double z0 = (double)d[0] * r0 + (double)d[1] * r1 + (double)d[2] * r2;
+        const double z1 = (double)d[3] * r0 + (double)d[4] * r1 + (double)d[5] * r2;
+        const double z2 = (double)d[6] * r0 + (double)d[7] * r1 + (double)d[8] * r2;
+        x[3 * row] = 0.0; x[3 * row + 1] = 0.0; x[3 * row + 2] = 0.0;
+        r[3 * row] = r0; r[3 * row + 1] = r1; r[3 * row + 2] = r2;
+        z[3 * row] = z0; z[3 * row + 1] = z1; z[3 * row + 2] = z2;
+        p[3 * row] = z0; p[3 * row + 1] = z1; p[3 * row + 2] = z2;
+        bb += r0 * r0 + r1 * r1 + r2 * r2;
+        rz += r0 * z0 + r1 * z1 + r2 * z2;
+    }
+    bb = block_sum(bb, sm);
+    rz = block_sum(rz, sm);
+    if (threadIdx.x == 0) {
+        part_bb[blockIdx.x] = bb;
+        part_rz[blockIdx.x] = rz;
+    }
+}
 __global__ __launch_bounds__(BLOCK) void k_pcg_init2(const double* __restrict__ part_bb, const double* __restrict__ part_rz, int nparts, double abs_tol, PcgCtrl* __restrict__ ctrl,
                                                      int stride)
 {
@@ -3430,14 +3476,14 @@ __global__ void k_copy_ctrl(const PcgCtrl* __restrict__ src, PcgCtrl* __restrict
 static double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // SpMV timing inside the solver: every SPMV_SAMPLE-th launch is bracketed by a pair of pooled HIP events on the engine's stream
 constexpr int SPMV_SAMPLE = 16;  // (an event pair costs the stream ~12 us: sampled sparsely so that measuring does not change what is measured)
-void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
+void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info, double rhs_scale)
 {
     if (!c.have_matrix) throw Error("pcg: matrix not assembled");
     if (c.world > 1) {
+        if (rhs_scale != 1.0) throw Error("pcg: a scaled right-hand side is a single-GPU shortcut");
         pcg_sharded(c, rhs_dev, abs_tol, rel_tol, max_iter, stop_on_indef, info);
         return;
     }
-    build_preconditioner(c);
     const int gv = grid_for(c.nbr, BLOCK, PCG_GRID);  // one block row per thread up to 262 144 block rows
     BsrPart& m1 = c.part[1];
     const bool dyn = m1.nnzb > 0;
@@ -3448,7 +3494,12 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     const bool fuse_dir = !c.no_fuse_dir;
     c.p2.ensure((size_t)c.ndofs);
     // (fused: iteration 1 reads p_0 = buffer 0 with beta = 0; k_pcg_init leaves z there, so 0 * p_0 is finite)
-    hipLaunchKernelGGL(k_pcg_init, dim3(gv), dim3(BLOCK), 0, c.stream, rhs_dev, c.dinv.p, c.nbr, c.du.p, c.r.p, c.z.p, fuse_dir ? c.p2.p : c.p.p, part_bb, part_rz);
+    {
+        const BsrPart& d1 = c.part[1];
+        hipLaunchKernelGGL(k_pcg_prologue, dim3(gv), dim3(BLOCK), 0, c.stream, rhs_dev, rhs_scale, (const float*)c.part[0].vals.p, (const int32_t*)c.diag_slot[0].p,
+                           d1.nnzb ? (const float*)d1.vals.p : (const float*)nullptr, (const int32_t*)c.diag_slot[1].p, c.nbr, c.dinv.p, c.du.p, c.r.p, c.z.p, fuse_dir ? c.p2.p : c.p.p,
+                           part_bb, part_rz);
+    }
     hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, part_bb, part_rz, gv, abs_tol, c.ctrl.p, 1);
     // Iterations are launched in batches of PCG_BATCH; after each batch the control block is copied to a pinned slot and an
     // event recorded. The host launches batch b+1 BEFORE it waits for batch b's event, so the GPU never idles on the host's

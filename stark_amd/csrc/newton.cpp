@@ -177,9 +177,15 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                 gs.mark(ST_SOLVE);
                 const double forcing = std::min(1e-2, residual * std::min(0.5, std::sqrt(residual)));
                 const double abs_tol = std::max(forcing, s.cg_abs_tolerance);
-                vec_neg(c, c.tmp_a.p, c.grad.p, ndofs);
-                if (s.linear_solver == MISTARK_SOLVER_DIRECT_LLT) info.converged = direct_llt(c, c.tmp_a.p, c.du.p) ? 1 : 0;  // NewtonsMethod.cpp:395-418
-                else pcg(c, c.tmp_a.p, abs_tol, s.cg_rel_tolerance, s.cg_max_iterations, s.cg_stop_on_indefiniteness, &info);
+                if (s.linear_solver == MISTARK_SOLVER_DIRECT_LLT) {
+                    vec_neg(c, c.tmp_a.p, c.grad.p, ndofs);
+                    info.converged = direct_llt(c, c.tmp_a.p, c.du.p) ? 1 : 0;  // NewtonsMethod.cpp:395-418
+                } else if (c.world > 1) {
+                    vec_neg(c, c.tmp_a.p, c.grad.p, ndofs);
+                    pcg(c, c.tmp_a.p, abs_tol, s.cg_rel_tolerance, s.cg_max_iterations, s.cg_stop_on_indefiniteness, &info);
+                } else {
+                    pcg(c, c.grad.p, abs_tol, s.cg_rel_tolerance, s.cg_max_iterations, s.cg_stop_on_indefiniteness, &info, -1.0);  // A du = -g
+                }
                 st.cg_iterations += info.n_iterations;
                 st.n_linear_solves++;
                 gs.mark(ST_OTHER);
