@@ -1094,6 +1094,15 @@ void sort_boxes(Context& c, ContactSystem& cs, const ContactDev& d)
     cs.s_idx = dv.Current();
     hipLaunchKernelGGL(k_bp_gather, dim3((cap + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, (const uint64_t*)dk.Current(), cs.s_idx, cap, cs.s_aabb.p, cs.s_lo.p, cs.seg.p);
 }
+// first capacity of the contact key list (it grows on demand; MISTARK_CONTACT_KEY_CAP: a small value makes the tests walk the growth path)
+size_t initial_key_cap()
+{
+    if (const char* e = std::getenv("MISTARK_CONTACT_KEY_CAP")) {
+        const long v = std::atol(e);
+        if (v > 0) return (size_t)v;
+    }
+    return (size_t)1 << 18;
+}
 template <bool PROX, bool FR>
 void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, double enl2)
 {
@@ -1129,7 +1138,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     bool boxes_current = cs.bp_valid && !cs.brute_force && !c.no_contact_cache && cs.bp_version == c.data_version && cs.bp_dt == dt && cs.bp_enl == enl_f;
     if (!boxes_current) update_vertices(c, cs, d, dt, enl_f);
     if (cs.key_cap == 0) {
-        cs.key_cap = 1 << 18;
+        cs.key_cap = initial_key_cap();
         cs.keys.ensure(cs.key_cap);
         cs.keys_alt.ensure(cs.key_cap);
     }
@@ -1293,7 +1302,7 @@ int64_t count_intersections(Context& c, double dt)
     MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 8 * sizeof(int), c.stream));
     if (!cs.brute_force) {
         if (cs.key_cap == 0) {
-            cs.key_cap = 1 << 18;
+            cs.key_cap = initial_key_cap();
             cs.keys.ensure(cs.key_cap);
             cs.keys_alt.ensure(cs.key_cap);
         }

@@ -142,3 +142,21 @@ def test_detects_intersections_and_moving_contacts():
     assert np.isfinite(E)
     eng.assemble()
     eng.close()
+
+
+@pytest.mark.parametrize("cap", [64, 200])
+def test_key_list_and_padded_sort_grow_on_demand(cap, monkeypatch):
+    """A key list that starts far too short (64 or 200 entries for 297 + 292 contacts) and a padded sort that therefore cannot hold the
+    first search: the searches repeat with grown buffers and end with the reference's tables."""
+    monkeypatch.setenv("MISTARK_CONTACT_KEY_CAP", str(cap))
+    eng, prob, man, z, scene, st = build("contactmix_t0")
+    dt = float(np.asarray(st["dt"]).ravel()[0])
+    eng.contact_update_friction()
+    eng.contact_update(dt)
+    for pi, p in enumerate(man["potentials"]):
+        if not is_contact(p["name"]) or not p["name"].startswith("contact_"):
+            continue
+        ref = prob.potentials[pi].conn
+        ours = eng.contact_table(p["name"])
+        assert ours.shape == ref.shape and (sorted_rows(ours) == sorted_rows(ref)).all(), p["name"]
+    eng.close()
