@@ -170,6 +170,7 @@ struct Potential
     int n_eown = 0;                   // elements the energy-only kernels run over (n_elem, or n_eown_list)
     int n_key = 0;                    // elements in the key space / pools of this context (n_elem, or n_list when sharded with a list)
     bool lazy_capable = false;
+    bool ti_projection = false;  // translation-invariant energy: PSD projection on the reduced matrix (k_project_eig_ti)
     size_t hf_off = 0;  // first float in the float pool
     int n_pool_f = 0;   // elements per block pair in the float pool (n_elem rounded up to 64: 16-byte aligned wave stores)
     int part = 0;       // 0: fixed connectivity, 1: connectivity changes inside the Newton loop (contacts)

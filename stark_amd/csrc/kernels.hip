@@ -1339,6 +1339,9 @@ void prepare(Context& c)
         // potentials, pass 1: connectivity upload and kernel argument blocks
         for (auto& P : c.pots) {
             P.lazy_capable = P.kind != KIND_CUSTOM && !c.force_generic && (P.name == E_TetStrain::name || P.name == E_TetStrainEO::name);
+            // energies of node-position differences only: their Hessians annihilate the rigid translations (k_project_eig_ti)
+            P.ti_projection = P.name == E_TetStrain::name || P.name == E_TetStrainEO::name || P.name == E_TriangleStrain::name || P.name == E_TriangleStrainEO::name ||
+                              P.name == E_DiscreteShells::name || P.name == E_BendingFlat::name;
             if (P.conn_dirty && !P.conn_ext) {
                 P.conn.ensure(std::max<size_t>(P.conn_host.size(), 1));
                 if (!P.conn_host.empty())
@@ -1973,6 +1976,232 @@ __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, 
     }
 }
 
+// ---- the same projection for TRANSLATION-INVARIANT elements (tets, membrane triangles: the energy depends on differences of node positions
+// only), on a matrix of 3 (NB - 1) instead of 3 NB rows. Such an element Hessian H annihilates the three rigid translations exactly, so in
+// the node basis Q = [q_0 .. q_{NB-2} | 1/sqrt(NB)] (Helmert: orthonormal, the first NB - 1 columns sum to zero) it reads
+//     (Q x I3)^T H (Q x I3) = [ A'  0 ; 0  0 ],      A' = 3 (NB - 1) square,
+// its eigenvalues are those of A' plus three zeros, and its eigenvectors the back-transformed ones of A' plus the translations. The
+// reference's dense eigen-solver finds the three zeros as +-1e-16 ||H|| and clamps them like any eigenvalue below eps (to eps, or to their
+// mirror image): here they are clamped as exact zeros. What is saved: Jacobi on 9 x 9 instead of 12 x 12 costs (9/12)^3 of the rotations,
+// 9 instead of 11 rounds per sweep, and six elements share a wavefront instead of five (membrane triangles: 6 x 6 instead of 9 x 9).
+// Differences to the full-size path: <= eps in the null directions (the clamped value of a numerical zero), rounding elsewhere; every
+// element counts as changed (it always has three eigenvalues below eps), which is what the reference reports for them, too.
+template <int NB>
+struct ProjTiShared  // LDS of ONE wavefront
+{
+    static constexpr int n = 3 * (NB - 1), m = (n + 1) & ~1, W = m, EPW = 64 / W;
+    double M[EPW + 1][m * W];   // row exchange during the sweeps, then the eigenvectors
+    double P[EPW + 1][m * W];   // the rebuilt reduced matrix
+    double2 CS[EPW + 1][m];
+    double L[EPW + 1][m];
+    double R[64 + W];
+};
+// Helmert basis of NB nodes: column k < NB - 1 (column NB - 1 is the constant 1 / sqrt(NB))
+__device__ __forceinline__ double helmert(int i, int k)
+{
+    const double s = rsqrt((double)((k + 1) * (k + 2)));
+    return i <= k ? s : (i == k + 1 ? -(double)(k + 1) * s : 0.0);
+}
+template <int NB>
+__device__ __forceinline__ void project_ti_body(ProjTiShared<NB>& S, int w, double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list, int n_list,
+                                                double eps, int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters)
+{
+    constexpr int n = 3 * (NB - 1), m = (n + 1) & ~1, W = m, EPW = 64 / W;
+    const int lane = threadIdx.x & 63;
+    const int g = lane / W, c = lane - g * W;
+    if (w * EPW >= n_list) return;  // (whole wavefront)
+    const int li = w * EPW + g;
+    const bool elem_ok = g < EPW && li < n_list;
+    const bool valid = elem_ok && c < n;  // this lane holds a column of the reduced matrix
+    const int e = elem_ok ? (int)list[li] : 0;
+    const int pe = compact ? (elem_ok ? li : 0) : e;
+    const size_t hs = (size_t)n_pool * 9;
+    double* M = S.M[g];
+    double* Pm = S.P[g];
+    double a[n], v[n];
+    {
+        // column c = (node-basis vector ap, component cc) of A' = (Q x I)^T H (Q x I), formed while loading
+        const int ap = valid ? c / 3 : 0, cc = valid ? c - 3 * (c / 3) : 0;
+        double qa[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) qa[i] = helmert(i, ap);
+        double T[NB][3];
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+#pragma unroll
+            for (int ci = 0; ci < 3; ci++) {
+                double t = 0.0;
+#pragma unroll
+                for (int b = 0; b < NB; b++) t += qa[b] * (valid ? elemH[(size_t)(i * NB + b) * hs + (size_t)pe * 9 + ci * 3 + cc] : 0.0);
+                T[i][ci] = t;
+            }
+#pragma unroll
+        for (int ip = 0; ip < NB - 1; ip++)
+#pragma unroll
+            for (int ci = 0; ci < 3; ci++) {
+                double t = 0.0;
+#pragma unroll
+                for (int i = 0; i < NB; i++) t += helmert(i, ip) * T[i][ci];
+                a[ip * 3 + ci] = t;
+            }
+#pragma unroll
+        for (int i = 0; i < n; i++) v[i] = i == c ? 1.0 : 0.0;
+    }
+    auto group_sum = [&](double x) {
+        S.R[lane] = x;
+        double sum = 0.0;
+#pragma unroll
+        for (int k = 0; k < W; k++) sum += S.R[g * W + k];
+        return sum;
+    };
+    double fro = 0.0;
+#pragma unroll
+    for (int i = 0; i < n; i++) fro += a[i] * a[i];
+    fro = group_sum(fro);
+    bool active = elem_ok;
+    auto rsqrt_nr = [](double x) {
+        double y = __builtin_amdgcn_rsq(x);
+        y = y * (1.5 - 0.5 * x * y * y);
+        return y * (1.5 - 0.5 * x * y * y);
+    };
+    auto rcp_nr = [](double x) {
+        const double y = __builtin_amdgcn_rcp(x);
+        return fma(y, fma(-x, y, 1.0), y);
+    };
+    auto shfl64 = [](double x, int addr) {  // addr = 4 * source lane
+        const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x)), hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
+        return __hiloint2double(hi, lo);
+    };
+    // (the sweeps: as in project_cols_body)
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0.0;
+#pragma unroll
+        for (int i = 0; i < n; i++) off += i == c ? 0.0 : a[i] * a[i];
+        off = group_sum(off);
+        if (off <= JACOBI_OFF_TOL * fro) active = false;
+        if (__ballot(active) == 0ull) break;
+        int pr[n];
+#pragma unroll
+        for (int i = 0; i < n; i++) pr[i] = (2 * (m - 1) - i) % (m - 1);
+#pragma unroll 1
+        for (int r = 0; r < m - 1; r++) {
+            const int partner = rr_partner(m, r, c);
+            const int src = ((g * W + partner) & 63) << 2;
+            const bool is_lo = c < partner;
+            const double d_own = pick<n>(a, c), x_own = pick<n>(a, partner);
+            const double d_oth = shfl64(d_own, src), x_oth = shfl64(x_own, src);
+            double cs = 1.0, sg = 0.0;
+            if (active && c < n && partner < n) {
+                const double app = is_lo ? d_own : d_oth, aqq = is_lo ? d_oth : d_own, apq = is_lo ? x_own : x_oth;
+                if (fabs(apq) > 1e-300) {
+                    if (mirroring & 2) {
+                        const double theta = (aqq - app) / (2.0 * apq);
+                        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        cs = 1.0 / sqrt(t * t + 1.0);
+                        const double sn = t * cs;
+                        sg = is_lo ? -sn : sn;
+                    } else {
+                        const double theta = (aqq - app) * rcp_nr(2.0 * apq);
+                        const double s2 = fma(theta, theta, 1.0);
+                        double y = __builtin_amdgcn_rsq(s2);
+                        y = y * (1.5 - 0.5 * s2 * y * y);
+                        const double root = s2 < 1e300 ? s2 * y : fabs(theta);
+                        const double t = copysign(rcp_nr(fabs(theta) + root), theta);
+                        cs = rsqrt_nr(t * t + 1.0);
+                        const double sn = t * cs;
+                        sg = is_lo ? -sn : sn;
+                    }
+                }
+            }
+            S.CS[g][c] = make_double2(cs, sg);
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                a[i] = cs * a[i] + sg * shfl64(a[i], src);
+                v[i] = cs * v[i] + sg * shfl64(v[i], src);
+                M[i * W + c] = a[i];
+            }
+#pragma unroll
+            for (int i = 0; i < n; i++) {
+                const int pi = i == m - 1 ? r : (pr[i] == i ? m - 1 : pr[i]);
+                pr[i] = pr[i] + 2 >= m - 1 ? pr[i] + 2 - (m - 1) : pr[i] + 2;
+                const double2 rot = S.CS[g][i];
+                const double y = pi < n ? M[pi * W + c] : 0.0;
+                a[i] = rot.x * a[i] + rot.y * y;
+            }
+        }
+    }
+    double l = pick<n>(a, c);
+    if (valid && l < eps) l = (mirroring & 1) ? -l : eps;
+    const double null_val = (mirroring & 1) ? 0.0 : eps;  // what the three exact zeros become
+    if (elem_ok && c == 0) atomicAdd((unsigned long long*)&counters[1], 1ull);
+    // the rebuilt reduced matrix P = V diag(l) V^T (column c in this lane, symmetric in (i, c) to the bit), through LDS
+#pragma unroll
+    for (int i = 0; i < n; i++) M[i * W + c] = v[i];
+    S.L[g][c] = l;
+    if (valid) {
+        double wc[n];
+#pragma unroll
+        for (int k = 0; k < n; k++) wc[k] = M[c * W + k];
+#pragma unroll 1
+        for (int i = 0; i < n; i++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < n; k++) acc = fma(M[i * W + k] * wc[k], S.L[g][k], acc);
+            Pm[i * W + c] = acc;
+        }
+    }
+    if (!elem_ok) return;
+    // back to the node basis: H' = (Q x I) P (Q x I)^T + null_val / NB on the (ci == cc) entries of every block. Output column oc = (node a,
+    // component cc); every unordered pair of entries is computed once, by the lane of the smaller index, and written to both places.
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
+        const int oc = pass == 0 ? c : n + c;
+        if (pass == 0 ? c >= n : c >= 3) continue;
+        const int ao = oc / 3, cc = oc - 3 * ao;
+        double U[NB - 1][3];  // sum over the column's node-basis index
+#pragma unroll
+        for (int ip = 0; ip < NB - 1; ip++)
+#pragma unroll
+            for (int ci = 0; ci < 3; ci++) {
+                double t = 0.0;
+#pragma unroll
+                for (int bp = 0; bp < NB - 1; bp++) t += helmert(ao, bp) * Pm[(ip * 3 + ci) * W + (bp * 3 + cc)];
+                U[ip][ci] = t;
+            }
+#pragma unroll 1
+        for (int i = 0; i < NB; i++) {
+#pragma unroll
+            for (int ci = 0; ci < 3; ci++) {
+                const int orow = i * 3 + ci;
+                if (orow < oc) continue;  // (computed by the lane of column orow)
+                double acc = ci == cc ? null_val / (double)NB : 0.0;
+#pragma unroll
+                for (int ip = 0; ip < NB - 1; ip++) acc += helmert(i, ip) * U[ip][ci];
+                // entry (row (i, ci), column (ao, cc)) and its mirror image
+#pragma unroll
+                for (int side = 0; side < 2; side++) {
+                    if (side == 1 && orow == oc) break;
+                    const int bi = side == 0 ? i : ao, bj = side == 0 ? ao : i, ii = side == 0 ? ci : cc, jj = side == 0 ? cc : ci;
+                    double* dst = elemH + (size_t)(bi * NB + bj) * hs + (size_t)pe * 9 + ii * 3 + jj;
+                    if (vals) {
+                        const uint32_t slot = slot_of_src[(size_t)(bi * NB + bj) * n_elem + e];
+                        if (slot != NO_SRC) atomicAdd(&vals[tile_val_index(slot, ii * 3 + jj)], (float)(acc - *dst));
+                    }
+                    *dst = acc;
+                }
+            }
+        }
+    }
+}
+template <int NB>
+__global__ __launch_bounds__(BLOCK) void k_project_eig_ti(double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list, int n_list, double eps,
+                                                          int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters)
+{
+    __shared__ ProjTiShared<NB> S[4];
+    const int wave = threadIdx.x >> 6;
+    project_ti_body<NB>(S[wave], blockIdx.x * 4 + wave, elemH, n_elem, n_pool, compact, list, n_list, eps, mirroring, slot_of_src, vals, counters);
+}
+
 template <int NB>
 __global__ __launch_bounds__(BLOCK) void k_project_eig_cols(double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list, int n_list, double eps,
                                                             int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters)
@@ -2168,6 +2397,13 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
                 if (batch.n == PROJ_BATCH) flush();
                 batch.d[batch.n++] = ProjDesc{H, list, sos, vals, n_key, nl, P.NB, batch_waves, n_pool, compact};
                 batch_waves += (nl + epw - 1) / epw;
+                continue;
+            }
+            if (P.ti_projection && !(c.proj_variant & 8) && (P.NB == 3 || P.NB == 4)) {  // translation-invariant elements: reduced matrix (k_project_eig_ti)
+                const int epw_ti = 64 / ((3 * (P.NB - 1) + 1) & ~1);
+                const dim3 grid_ti(((nl + epw_ti - 1) / epw_ti + 3) / 4);
+                if (P.NB == 4) hipLaunchKernelGGL((k_project_eig_ti<4>), grid_ti, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p);
+                else hipLaunchKernelGGL((k_project_eig_ti<3>), grid_ti, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p);
                 continue;
             }
             const dim3 grid(((nl + epw - 1) / epw + 3) / 4);

@@ -131,11 +131,12 @@ def test_stages_match_reference(path, variant):
     eng.close()
 
 
-@pytest.mark.parametrize("proj_variant", [1, 2, 4, 7])
+@pytest.mark.parametrize("proj_variant", [1, 2, 4, 7, 10])
 @pytest.mark.parametrize("name", ["tetbeam_eo_4x1x1_big", "contactmix_t1", "rbchain", "cloth_shells_6"])
 def test_projection_variants_agree(name, proj_variant):
     """The PSD projection has a register-resident kernel (default), the earlier LDS kernel (bit 1), per-potential launches instead of
-    the batched one (bit 2) and IEEE division/square root for the rotation angles (bit 4): every combination gives the reference's
+    the batched one (bit 2; tets and membrane triangles then take the reduced-matrix kernel for translation-invariant elements, unless
+    bit 8 is set) and IEEE division/square root for the rotation angles (bit 4): every combination gives the reference's
     projected Hessians and the same "changed" count, and agrees with the default path to 1e-10 (the Jacobi sweeps stop at
     off(A) <= 1e-12 ||A||; the variants' rotations differ in rounding, so they stop at different points below that)."""
     from gpu_util import engine_from_problem
