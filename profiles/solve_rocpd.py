@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per linear solve (k_block_diag_inverse ... last PCG kernel): wall span on the GPU, busy time, launched / effective CG iterations and
+"""Per linear solve (k_pcg_prologue, or k_block_diag_inverse in traces of earlier builds, ... last PCG kernel): wall span on the GPU, busy time, launched / effective CG iterations and
 the idle time before the next kernel, from a rocprofv3 --kernel-trace rocpd database. usage: python profiles/solve_rocpd.py <db>"""
 import sqlite3
 import sys
@@ -7,12 +7,13 @@ import sys
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name, start, end from kernels order by start"))
 def sh(x): return x.split("(")[0].replace("void ", "").replace("mistark::", "").split("<")[0]
-PCG = {"k_spmv_fused", "k_spmv_dir", "k_pcg_step", "k_pcg_dir", "k_pcg_init", "k_pcg_init2", "k_block_diag_inverse", "k_spmv_combine", "k_copy_ctrl", "k_pcg_check"}
+PCG = {"k_spmv_fused", "k_spmv_dir", "k_pcg_step", "k_pcg_dir", "k_pcg_init", "k_pcg_init2", "k_pcg_prologue", "k_block_diag_inverse", "k_spmv_combine", "k_copy_ctrl", "k_pcg_check"}
+FIRST = "k_pcg_prologue" if any(sh(r[0]) == "k_pcg_prologue" for r in rows) else "k_block_diag_inverse"
 solves = []
 cur = None
 for i, (name, s, e) in enumerate(rows):
     k = sh(name)
-    if k == "k_block_diag_inverse":
+    if k == FIRST:
         if cur: solves.append(cur)
         cur = dict(start=s, end=e, busy=e - s, spmv=0, spmv_real=0, spmv_t=0, step_t=0, dir_t=0, gaps=0, last=i)
     elif cur is not None and (k in PCG or name.startswith("__amd_rocclr_copyBuffer")) and s - cur["end"] < 300000:
