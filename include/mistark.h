@@ -258,8 +258,14 @@ int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settin
  * closed-form tet kernels are then cross-checked against them); "atomic_assembly" = scatter assembly with float atomics
  * instead of the deterministic gather; "proj_variant" = PSD projection cross-checks, bits: 1 = eigen-decomposition with the
  * matrix in LDS instead of registers, 2 = one launch per potential instead of one for all short lists, 4 = IEEE division /
- * square root for the rotation angles; "spmv_chunk_tiles" = tiles per SpMV chunk (0 = by matrix size); "no_contact_cache" = run every contact search even when
- * nothing it reads has changed since the previous one.
+ * square root for the rotation angles, 8 = the full-size matrix for translation-invariant elements too (default: their reduced
+ * matrix); "spmv_chunk_tiles" = tiles per SpMV chunk (0 = by matrix size); "no_contact_cache" = run every contact search in full
+ * (no answer from the installed tables, no shared box list, count read back before the sort); "lazy_hessians" = 0: the Newton loop
+ * keeps the double element-Hessian pool (default 1: float upper triangles, doubles recomputed for projected elements);
+ * "lazy_eval" = staged mistark_eval calls take the lazy path too; "no_grad_gather" = gradient of the closed-form elements by atomics;
+ * "no_pattern_overlap" / "no_eval_overlap" / "no_bounded_pattern" = switch off, one by one, the side stream for the contact part's
+ * pattern, the auxiliary stream for small potentials, the device-side counts of the pattern build; "fuse_dir" = direction update
+ * inside the SpMV (measured slower, a cross-check); "kernel_dbg" = measurement switches inside kernels.
  * Returns 0, or < 0 for an unknown name. The environment variable
  * MISTARK_OPTIONS="name=value,name=value" applies the same switches inside mistark_create (for a process that cannot be
  * edited: a test suite, a profiler run); a bad entry makes mistark_create fail with -6. MISTARK_POISON=1 fills every fresh
