@@ -3711,7 +3711,7 @@ __global__ void k_copy_ctrl(const PcgCtrl* __restrict__ src, PcgCtrl* __restrict
 }
 static double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 // SpMV timing inside the solver: every SPMV_SAMPLE-th launch is bracketed by a pair of pooled HIP events on the engine's stream
-constexpr int SPMV_SAMPLE = 16;  // (an event pair costs the stream ~12 us: sampled sparsely so that measuring does not change what is measured)
+constexpr int SPMV_SAMPLE = 32;  // (a sampled launch costs the stream ~14 us of marker packets: 1.3 % of the timed region at every 16th launch, measured)
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info, double rhs_scale)
 {
     if (!c.have_matrix) throw Error("pcg: matrix not assembled");
