@@ -372,3 +372,34 @@ def test_pcg_back_to_back_solves_do_not_see_each_others_lookahead():
             assert (info.n_iterations, info.converged) == (n_it, conv)
             assert (du == du_ref).all()
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["tetbeam_eo_4x1x1_big", "cloth_shells_6"])
+def test_reduced_matrix_projection_with_mirroring(name):
+    """project_to_pd_use_mirroring (negative eigenvalues become their mirror image instead of eps): the reduced-matrix kernel for
+    translation-invariant elements against the full-size kernel on the same elements, and both against a numpy eigen-decomposition."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    out = []
+    for variant in (2, 10):
+        eng = engine_from_problem(prob, man)
+        eng.set_option("proj_variant", variant)
+        eng.eval(capi.EVAL_P_G_H)
+        H0 = {pi: eng.element_hessians(pid, man["potentials"][pi]["n_elem"])[0] for pi, pid in eng.pot_ids.items()}
+        eng.project(1e-10, True, None)
+        H = {pi: eng.element_hessians(pid, man["potentials"][pi]["n_elem"])[0] for pi, pid in eng.pot_ids.items()}
+        out.append((H0, H))
+        eng.close()
+    (H0, Ha), (_, Hb) = out
+    checked = 0
+    for pi in Ha:
+        den = np.maximum(np.sqrt((H0[pi] ** 2).sum(axis=(1, 2))), 1e-300)
+        assert (np.sqrt(((Ha[pi] - Hb[pi]) ** 2).sum(axis=(1, 2))) <= 1e-10 * den).all()
+        w, V = np.linalg.eigh(0.5 * (H0[pi] + H0[pi].transpose(0, 2, 1)))
+        wm = np.where(w < 1e-10, -w, w)
+        ref = np.einsum("eik,ek,ejk->eij", V, wm, V)
+        assert (np.sqrt(((Ha[pi] - ref) ** 2).sum(axis=(1, 2))) <= 1e-9 * den).all()
+        checked += len(den)
+    assert checked > 0
