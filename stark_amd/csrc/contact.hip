@@ -833,6 +833,18 @@ struct ContactSystem
     DevBuf<int> counters;  // [0] candidates, [1] intersections, [2] differs, [8..8+N_TABLES] bounds, [48..51] box list (k_bp_fill; [51] = entries needed)
     // result of the last barrier-table search and the inputs it saw (Context::data_version, dt): an identical request is answered from here
     int n_last = 0;  // keys found by the last search (sizes the padded sort of the next one)
+    // The intersection check of a line-search candidate runs the proximity search of the evaluation that follows it, too (same state, same
+    // boxes; one read-back for both): the result waits here until detect_and_route asks for exactly that state.
+    struct Speculated
+    {
+        bool valid = false;
+        uint64_t version = 0;
+        double dt = 0.0;
+        float enl = -1.f;
+        int n = 0;
+        int h[64];
+        const uint64_t* sorted = nullptr;
+    } spec;
     bool cache_valid = false;
     // the sorted box list of the last search: reused when the next search sees the same state with the same enlargement (the intersection
     // check of a line-search candidate and the proximity search of the energy evaluation that follows it)
@@ -1115,6 +1127,29 @@ void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, double enl
     hipLaunchKernelGGL((k_sweep_tasks<PROX, FR>), dim3(SWEEP_TASK_WAVES / (CB / 64)), dim3(CB), 0, c.stream, d, cs.bands, cs.s_idx, (const float*)cs.s_aabb.p, (const int*)cs.seg.p, pt_on,
                        ee_on, enl2, cs.keys.p, cs.counters.p, (int)cs.key_cap, (const int*)task_count, (const int*)cs.sweep_tasks.p);
 }
+// padded length of the key sort for the next search
+int padded_key_count(const ContactSystem& cs)
+{
+    int n_pad = 4096;
+    while (n_pad < 2 * std::max(cs.n_last, 0) + 1024) n_pad *= 2;
+    return (int)std::min<size_t>((size_t)n_pad, cs.key_cap);
+}
+// keys[0, n_sort) sorted (n_dev: the count on the device, the rest is padding), table boundaries and "same as the installed list" flag into
+// counters[8..] / counters[2]; returns the sorted list
+const uint64_t* sort_and_bound(Context& c, ContactSystem& cs, int n_sort, const int* n_dev, bool compare)
+{
+    hipcub::DoubleBuffer<uint64_t> dk(cs.keys.p, cs.keys_alt.p);
+    if (n_sort > 1) {
+        size_t tmp = 0;
+        MS_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, dk, n_sort, 0, 64, c.stream));
+        cs.cub_tmp.ensure(tmp);
+        MS_CHECK(hipcub::DeviceRadixSort::SortKeys(cs.cub_tmp.p, tmp, dk, n_sort, 0, 64, c.stream));
+    }
+    const uint64_t* sorted = dk.Current();
+    hipLaunchKernelGGL(k_table_bounds, dim3((n_sort + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, sorted, n_sort, n_dev, compare ? cs.prev.p : sorted, compare ? (int)cs.n_prev : -1,
+                       cs.counters.p + 8, cs.counters.p + 2);
+    return sorted;
+}
 // Runs detection and installs the tables [t0, t1). Returns the number of rows.
 int64_t detect_and_route(Context& c, double dt, bool friction)
 {
@@ -1148,29 +1183,19 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     const uint64_t* sorted = cs.keys.p;
     const bool compare = !friction && cs.n_prev >= 0;
     if (compare) cs.prev.ensure(std::max<size_t>((size_t)cs.n_prev, 1));
-    auto sort_and_bound = [&](int n_sort, const int* n_dev) {
-        hipcub::DoubleBuffer<uint64_t> dk(cs.keys.p, cs.keys_alt.p);
-        if (n_sort > 1) {
-            size_t tmp = 0;
-            MS_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, dk, n_sort, 0, 64, c.stream));
-            cs.cub_tmp.ensure(tmp);
-            MS_CHECK(hipcub::DeviceRadixSort::SortKeys(cs.cub_tmp.p, tmp, dk, n_sort, 0, 64, c.stream));
-        }
-        sorted = dk.Current();
-        hipLaunchKernelGGL(k_table_bounds, dim3((n_sort + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, sorted, n_sort, n_dev, compare ? cs.prev.p : sorted, compare ? (int)cs.n_prev : -1,
-                           cs.counters.p + 8, cs.counters.p + 2);
-    };
-    for (;;) {
+    const bool speculated = !friction && cs.spec.valid && !c.no_contact_cache && !cs.brute_force && cs.spec.version == c.data_version && cs.spec.dt == dt && cs.spec.enl == enl_f;
+    if (speculated) {  // the intersection check of this very state has searched already
+        std::memcpy(h, cs.spec.h, sizeof(h));
+        n = cs.spec.n;
+        sorted = cs.spec.sorted;
+    }
+    cs.spec.valid = false;  // (any search below reuses the key buffers)
+    for (; !speculated;) {
         MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
         // One read-back per search: the key list is sorted over a padded length chosen from the previous search's count (padding keys sort
         // last and carry a table id no table has), the table boundaries are found with the count still on the device, and count,
         // boundaries and "same as before" flag come back together. A count beyond the padded length takes the two-step path below.
-        int n_pad = 0;
-        if (!c.no_contact_cache) {
-            n_pad = 4096;
-            while (n_pad < 2 * std::max(cs.n_last, 0) + 1024) n_pad *= 2;
-            n_pad = (int)std::min<size_t>((size_t)n_pad, cs.key_cap);
-        }
+        const int n_pad = c.no_contact_cache ? 0 : padded_key_count(cs);
         if (!cs.brute_force) {
             if (!boxes_current) sort_boxes(c, cs, d);
             boxes_current = false;
@@ -1196,7 +1221,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
         }
         if (n_pad > 0) {
             hipLaunchKernelGGL(k_pad_keys, dim3((n_pad + CB - 1) / CB), dim3(CB), 0, c.stream, cs.keys.p, (const int*)cs.counters.p, n_pad);
-            sort_and_bound(n_pad, (const int*)cs.counters.p);
+            sorted = sort_and_bound(c, cs, n_pad, (const int*)cs.counters.p, compare);
         }
         lap(1);
         fetch(c, h, cs.counters.p, 64 * sizeof(int));
@@ -1220,7 +1245,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
                 continue;
             }
             MS_CHECK(hipMemsetAsync(cs.counters.p + 2, 0, sizeof(int), c.stream));
-            sort_and_bound(n, nullptr);
+            sorted = sort_and_bound(c, cs, n, nullptr, compare);
             lap(3);
             fetch(c, h, cs.counters.p, 64 * sizeof(int));
             lap(4);
@@ -1306,9 +1331,23 @@ int64_t count_intersections(Context& c, double dt)
             cs.keys.ensure(cs.key_cap);
             cs.keys_alt.ensure(cs.key_cap);
         }
+        cs.spec.valid = false;
+        const bool speculate = !c.no_contact_cache;
         for (bool first = true;; first = false) {
             if (!(first && boxes_current)) sort_boxes(c, cs, d);
             launch_sweep<false, false>(c, cs, d, 0.0);
+            // ... and, behind it, the proximity search of the evaluation that follows an accepted candidate (same state, same boxes), up
+            // to the table boundaries: its counts come back with the intersection count, detect_and_route then only routes
+            const uint64_t* sorted = nullptr;
+            int n_pad = 0;
+            if (speculate) {
+                const bool compare = cs.n_prev >= 0;
+                if (compare) cs.prev.ensure(std::max<size_t>((size_t)cs.n_prev, 1));
+                launch_sweep<true, false>(c, cs, d, enl * enl);
+                n_pad = padded_key_count(cs);
+                hipLaunchKernelGGL(k_pad_keys, dim3((n_pad + CB - 1) / CB), dim3(CB), 0, c.stream, cs.keys.p, (const int*)cs.counters.p, n_pad);
+                sorted = sort_and_bound(c, cs, n_pad, (const int*)cs.counters.p, compare);
+            }
             int hb[64];
             fetch(c, hb, cs.counters.p, sizeof(hb));
             if (hb[51] > cs.bp_cap) {
@@ -1321,6 +1360,16 @@ int64_t count_intersections(Context& c, double dt)
             cs.bp_version = c.data_version;
             cs.bp_dt = dt;
             cs.bp_enl = enl_f;
+            if (speculate && (size_t)hb[0] <= cs.key_cap && hb[0] <= n_pad) {
+                cs.spec.valid = true;
+                cs.spec.version = c.data_version;
+                cs.spec.dt = dt;
+                cs.spec.enl = enl_f;
+                cs.spec.n = hb[0];
+                cs.spec.sorted = sorted;
+                std::memcpy(cs.spec.h, hb, sizeof(hb));
+            }
+            if (speculate) cs.n_last = hb[0];
             return hb[1];
         }
     } else {
