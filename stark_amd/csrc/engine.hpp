@@ -326,6 +326,7 @@ struct Context
     bool have_matrix = false;
     bool matrix_current = false;    // the assembled matrix reflects the current element Hessians
     int pcg_epoch = 0;              // solves started (PcgCtrl::epoch)
+    std::vector<int32_t> hot_rows_host;  // what hot_rows holds (prepare uploads it only when it changes)
     DevBuf<uint32_t> proj_list;     // element ids selected for projection (per potential, at e_off)
 
     // reductions / PCG

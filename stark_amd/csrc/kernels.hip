@@ -1289,6 +1289,7 @@ void prepare(Context& c)
             off += s.n;
         }
         const bool resized = off != c.ndofs;
+        bool queued_uploads = resized;  // anything copied from host memory in this call (decides the closing synchronisation)
         c.ndofs = off;
         c.nbr = off / 3;
         if (c.ndofs == 0) throw Error("no degrees of freedom");
@@ -1316,9 +1317,10 @@ void prepare(Context& c)
             c.n_hot = (int)hot_rows.size();
             c.hot_rows.ensure(std::max<size_t>(hot_rows.size(), 1));
             c.grad_hot.ensure(std::max<size_t>((size_t)HOT_WAYS * 3 * hot_rows.size(), 1));
-            if (!hot_rows.empty()) {
-                MS_CHECK(hipMemcpyAsync(c.hot_rows.p, hot_rows.data(), hot_rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
-                MS_CHECK(hipStreamSynchronize(c.stream));  // (hot_rows is a local)
+            if (!hot_rows.empty() && hot_rows != c.hot_rows_host) {  // (unchanged across the layout refreshes a change of the contact tables asks for)
+                c.hot_rows_host = hot_rows;
+                MS_CHECK(hipMemcpyAsync(c.hot_rows.p, c.hot_rows_host.data(), hot_rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+                queued_uploads = true;
             }
         }
         // arrays
@@ -1333,6 +1335,7 @@ void prepare(Context& c)
                 if (a.need_upload && na > 0 && a.host) {
                     MS_CHECK(hipMemcpyAsync(a.dev, a.host, na * sizeof(double), hipMemcpyHostToDevice, c.stream));
                     a.need_upload = false;
+                    queued_uploads = true;
                 }
             }
         }
@@ -1346,6 +1349,7 @@ void prepare(Context& c)
                 P.conn.ensure(std::max<size_t>(P.conn_host.size(), 1));
                 if (!P.conn_host.empty())
                     MS_CHECK(hipMemcpyAsync(P.conn.p, P.conn_host.data(), P.conn_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+                queued_uploads = true;
                 P.conn_dirty = false;
                 P.conn_version++;
                 P.inc_sig.clear();
@@ -1452,7 +1456,8 @@ void prepare(Context& c)
         c.is_projected.ensure(std::max<size_t>(e_off, 1));
         if (c.world > 1) MS_CHECK(hipMemsetAsync(c.elemE.p, 0, std::max<size_t>(e_off, 1) * sizeof(double), c.stream));  // other ranks' elements count 0
         c.dinv.ensure((size_t)c.nbr * 9);
-        MS_CHECK(hipStreamSynchronize(c.stream));
+        // (a refresh that only followed new contact-table sizes copied nothing from the host: no reason to wait for the stream)
+        if (queued_uploads) MS_CHECK(hipStreamSynchronize(c.stream));
         c.layout_dirty = false;
         c.have_hessians = false;
     }
