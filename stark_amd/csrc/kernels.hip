@@ -1891,10 +1891,8 @@ __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, 
         off = group_sum(off);
         if (off <= JACOBI_OFF_TOL * fro) active = false;
         if (__ballot(active) == 0ull) break;
-        int pr[n];  // (2 r - i) mod (m - 1) of the rows, advanced by 2 per round (uniform values: scalar registers)
+        // (rounds unrolled: the row rotations then address the lane's own registers with constant indices, see project_ti_body)
 #pragma unroll
-        for (int i = 0; i < n; i++) pr[i] = (2 * (m - 1) - i) % (m - 1);
-#pragma unroll 1
         for (int r = 0; r < m - 1; r++) {
             const int partner = rr_partner(m, r, c);
             const int src = ((g * W + partner) & 63) << 2;
@@ -1929,21 +1927,22 @@ __device__ __forceinline__ void project_cols_body(ProjWaveShared<NB>& S, int w, 
                 }
             }
             S.CS[g][c] = make_double2(cs, sg);
-            // columns: A <- A J, V <- V J; the updated column of A goes to LDS row by row
+            // columns: A <- A J, V <- V J
 #pragma unroll
             for (int i = 0; i < n; i++) {
                 a[i] = cs * a[i] + sg * shfl64(a[i], src);
                 v[i] = cs * v[i] + sg * shfl64(v[i], src);
-                M[i * W + c] = a[i];
             }
-            // rows: A <- J^T A
+            // rows: A <- J^T A, pair by pair
 #pragma unroll
             for (int i = 0; i < n; i++) {
-                const int pi = i == m - 1 ? r : (pr[i] == i ? m - 1 : pr[i]);  // = rr_partner(m, r, i)
-                pr[i] = pr[i] + 2 >= m - 1 ? pr[i] + 2 - (m - 1) : pr[i] + 2;
-                const double2 rot = S.CS[g][i];
-                const double y = pi < n ? M[pi * W + c] : 0.0;
-                a[i] = rot.x * a[i] + rot.y * y;
+                const int pi = rr_partner(m, r, i);
+                if (pi > i && pi < n) {
+                    const double2 ri = S.CS[g][i], rp = S.CS[g][pi];
+                    const double ai = a[i], ap_ = a[pi];
+                    a[i] = ri.x * ai + ri.y * ap_;
+                    a[pi] = rp.x * ap_ + rp.y * ai;
+                }
             }
         }
     }
@@ -2077,7 +2076,10 @@ __device__ __forceinline__ void project_ti_body(ProjTiShared<NB>& S, int w, doub
         const int lo = __builtin_amdgcn_ds_bpermute(addr, __double2loint(x)), hi = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(x));
         return __hiloint2double(hi, lo);
     };
-    // (the sweeps: as in project_cols_body)
+    // The sweeps: as in project_cols_body, but with the rounds of a sweep unrolled. The row rotations of a round touch, in every column, the
+    // two entries of each rotated pair — both in the lane's own registers; with the round index a compile-time constant so are their
+    // indices, and the column no longer travels through LDS to be indexed at run time (a write, a read and the index arithmetic per entry
+    // and round). Only the rotations themselves (c, s per column) still go through LDS.
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0.0;
 #pragma unroll
@@ -2085,10 +2087,7 @@ __device__ __forceinline__ void project_ti_body(ProjTiShared<NB>& S, int w, doub
         off = group_sum(off);
         if (off <= JACOBI_OFF_TOL * fro) active = false;
         if (__ballot(active) == 0ull) break;
-        int pr[n];
 #pragma unroll
-        for (int i = 0; i < n; i++) pr[i] = (2 * (m - 1) - i) % (m - 1);
-#pragma unroll 1
         for (int r = 0; r < m - 1; r++) {
             const int partner = rr_partner(m, r, c);
             const int src = ((g * W + partner) & 63) << 2;
@@ -2119,19 +2118,22 @@ __device__ __forceinline__ void project_ti_body(ProjTiShared<NB>& S, int w, doub
                 }
             }
             S.CS[g][c] = make_double2(cs, sg);
+            // columns: A <- A J, V <- V J
 #pragma unroll
             for (int i = 0; i < n; i++) {
                 a[i] = cs * a[i] + sg * shfl64(a[i], src);
                 v[i] = cs * v[i] + sg * shfl64(v[i], src);
-                M[i * W + c] = a[i];
             }
+            // rows: A <- J^T A, pair by pair (indices are constants after unrolling)
 #pragma unroll
             for (int i = 0; i < n; i++) {
-                const int pi = i == m - 1 ? r : (pr[i] == i ? m - 1 : pr[i]);
-                pr[i] = pr[i] + 2 >= m - 1 ? pr[i] + 2 - (m - 1) : pr[i] + 2;
-                const double2 rot = S.CS[g][i];
-                const double y = pi < n ? M[pi * W + c] : 0.0;
-                a[i] = rot.x * a[i] + rot.y * y;
+                const int pi = rr_partner(m, r, i);
+                if (pi > i && pi < n) {
+                    const double2 ri = S.CS[g][i], rp = S.CS[g][pi];
+                    const double ai = a[i], ap_ = a[pi];
+                    a[i] = ri.x * ai + ri.y * ap_;
+                    a[pi] = rp.x * ap_ + rp.y * ai;
+                }
             }
         }
     }
