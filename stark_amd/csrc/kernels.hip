@@ -2200,13 +2200,13 @@ __device__ __forceinline__ void project_ti_body(ProjTiShared<NB>& S, int w, doub
         }
     }
 }
+// (one wavefront per workgroup: a wavefront needs 13.5 KB of LDS, and 160 KB hold eleven single-wavefront workgroups but only two of four)
 template <int NB>
-__global__ __launch_bounds__(BLOCK) void k_project_eig_ti(double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list, int n_list, double eps,
-                                                          int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters)
+__global__ __launch_bounds__(64) void k_project_eig_ti(double* __restrict__ elemH, int n_elem, int n_pool, int compact, const uint32_t* __restrict__ list, int n_list, double eps,
+                                                       int mirroring, const uint32_t* __restrict__ slot_of_src, float* __restrict__ vals, int64_t* __restrict__ counters)
 {
-    __shared__ ProjTiShared<NB> S[4];
-    const int wave = threadIdx.x >> 6;
-    project_ti_body<NB>(S[wave], blockIdx.x * 4 + wave, elemH, n_elem, n_pool, compact, list, n_list, eps, mirroring, slot_of_src, vals, counters);
+    __shared__ ProjTiShared<NB> S;
+    project_ti_body<NB>(S, blockIdx.x, elemH, n_elem, n_pool, compact, list, n_list, eps, mirroring, slot_of_src, vals, counters);
 }
 
 template <int NB>
@@ -2408,9 +2408,9 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
             }
             if (P.ti_projection && !(c.proj_variant & 8) && (P.NB == 3 || P.NB == 4)) {  // translation-invariant elements: reduced matrix (k_project_eig_ti)
                 const int epw_ti = 64 / ((3 * (P.NB - 1) + 1) & ~1);
-                const dim3 grid_ti(((nl + epw_ti - 1) / epw_ti + 3) / 4);
-                if (P.NB == 4) hipLaunchKernelGGL((k_project_eig_ti<4>), grid_ti, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p);
-                else hipLaunchKernelGGL((k_project_eig_ti<3>), grid_ti, b, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p);
+                const dim3 grid_ti((nl + epw_ti - 1) / epw_ti), b_ti(64);
+                if (P.NB == 4) hipLaunchKernelGGL((k_project_eig_ti<4>), grid_ti, b_ti, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p);
+                else hipLaunchKernelGGL((k_project_eig_ti<3>), grid_ti, b_ti, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p);
                 continue;
             }
             const dim3 grid(((nl + epw - 1) / epw + 3) / 4);
