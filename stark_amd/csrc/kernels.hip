@@ -2228,6 +2228,7 @@ struct ProjDesc
     float* vals;
     int n_elem, nl, NB, first_wave;
     int n_pool, compact;
+    int ti;  // translation-invariant elements: reduced matrix (project_ti_body)
 };
 constexpr int PROJ_BATCH = 40;
 struct ProjBatch
@@ -2243,6 +2244,8 @@ union ProjWaveSharedAny
     ProjWaveShared<4> s4;
     ProjWaveShared<5> s5;
     ProjWaveShared<6> s6;
+    ProjTiShared<3> t3;
+    ProjTiShared<4> t4;
     __device__ ProjWaveSharedAny() {}
 };
 __global__ __launch_bounds__(BLOCK) void k_project_eig_multi(ProjBatch B, double eps, int mirroring, int64_t* __restrict__ counters)
@@ -2254,6 +2257,11 @@ __global__ __launch_bounds__(BLOCK) void k_project_eig_multi(ProjBatch B, double
     while (k + 1 < B.n && gw >= B.d[k + 1].first_wave) k++;
     const ProjDesc& D = B.d[k];
     const int w = gw - D.first_wave;
+    if (D.ti) {
+        if (D.NB == 4) project_ti_body<4>(S[wave].t4, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters);
+        else project_ti_body<3>(S[wave].t3, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters);
+        return;
+    }
     switch (D.NB) {
         case 1: project_cols_body<1>(S[wave].s1, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters); break;
         case 2: project_cols_body<2>(S[wave].s2, w, D.H, D.n_elem, D.n_pool, D.compact, D.list, D.nl, eps, mirroring, D.sos, D.vals, counters); break;
@@ -2400,13 +2408,15 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         const dim3 g((nl + 3) / 4), b(BLOCK);
         if (!(c.proj_variant & 1) && P.NB <= 6) {  // register-resident Jacobi, several elements per wavefront
             const int epw = 64 / ((3 * P.NB + 1) & ~1);
+            const bool ti = P.ti_projection && !(c.proj_variant & 8) && (P.NB == 3 || P.NB == 4);
             if (nl <= SHORT_LIST && !(c.proj_variant & 2)) {
                 if (batch.n == PROJ_BATCH) flush();
-                batch.d[batch.n++] = ProjDesc{H, list, sos, vals, n_key, nl, P.NB, batch_waves, n_pool, compact};
-                batch_waves += (nl + epw - 1) / epw;
+                const int epw_b = ti ? 64 / ((3 * (P.NB - 1) + 1) & ~1) : epw;
+                batch.d[batch.n++] = ProjDesc{H, list, sos, vals, n_key, nl, P.NB, batch_waves, n_pool, compact, ti ? 1 : 0};
+                batch_waves += (nl + epw_b - 1) / epw_b;
                 continue;
             }
-            if (P.ti_projection && !(c.proj_variant & 8) && (P.NB == 3 || P.NB == 4)) {  // translation-invariant elements: reduced matrix (k_project_eig_ti)
+            if (ti) {  // translation-invariant elements: reduced matrix (k_project_eig_ti)
                 const int epw_ti = 64 / ((3 * (P.NB - 1) + 1) & ~1);
                 const dim3 grid_ti((nl + epw_ti - 1) / epw_ti), b_ti(64);
                 if (P.NB == 4) hipLaunchKernelGGL((k_project_eig_ti<4>), grid_ti, b_ti, 0, stream, H, n_key, n_pool, compact, list, nl, eps, mirroring, sos, vals, c.counters.p);
