@@ -2766,6 +2766,14 @@ struct XPlain
     }
     __device__ __forceinline__ bool has_dot() const { return pd != nullptr; }
     __device__ __forceinline__ double row_dot(size_t r3, double y0, double y1, double y2) const { return pd[r3] * y0 + pd[r3 + 1] * y1 + pd[r3 + 2] * y2; }
+    // the same in two halves: the row's entries of pd are loaded EARLY (with the tile's gathers), the product is formed after the row sums
+    __device__ __forceinline__ void row_pre(size_t r3, double& p0, double& p1, double& p2) const
+    {
+        p0 = pd[r3];
+        p1 = pd[r3 + 1];
+        p2 = pd[r3 + 2];
+    }
+    __device__ __forceinline__ double row_dot_pre(size_t, double p0, double p1, double p2, double y0, double y1, double y2) const { return p0 * y0 + p1 * y1 + p2 * y2; }
 };
 struct XDir
 {
@@ -2785,6 +2793,14 @@ struct XDir
     {
         double p0, p1, p2;
         load(r3, p0, p1, p2);
+        pnew[r3] = p0;
+        pnew[r3 + 1] = p1;
+        pnew[r3 + 2] = p2;
+        return p0 * y0 + p1 * y1 + p2 * y2;
+    }
+    __device__ __forceinline__ void row_pre(size_t r3, double& p0, double& p1, double& p2) const { load(r3, p0, p1, p2); }
+    __device__ __forceinline__ double row_dot_pre(size_t r3, double p0, double p1, double p2, double y0, double y1, double y2) const
+    {
         pnew[r3] = p0;
         pnew[r3 + 1] = p1;
         pnew[r3 + 2] = p2;
@@ -2839,8 +2855,22 @@ __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nbl
             const float4 a = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[lane], b = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[64 + lane];
             const float cc = (V == 3) ? 1.f : vals[(size_t)t * 576 + 512 + lane];
             const size_t c3 = 3 * (size_t)(w & 0x7fffffffu);
+            const int32_t tfr_w = tile_first_row[t];  // bit 31: the tile starts inside a row begun in the previous tile
             double x0, x1, x2;
             X.load(c3, x0, x1, x2);
+            // which lanes end a row, and which row: known from the column words alone, so the row's entries of the dot-product vector are
+            // requested NOW, with the gathers (issued after the row sums they were a dependent load at the tail of every tile: 30 us of a
+            // 217 us launch on the 8 M-tet matrix, where they come from HBM)
+            const bool tail = (w >> 31) != 0;
+            const int tfr = tfr_w & 0x7fffffff;
+            const bool tile_cont = tfr_w < 0;
+            const unsigned long long tails = __ballot(tail);
+            const unsigned long long heads = (tails << 1) | 1ull;
+            const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+            const int start = 63 - __clzll(heads & le);
+            const int row = tfr + __popcll(tails & ((1ull << lane) - 1ull));
+            double pr0 = 0.0, pr1 = 0.0, pr2 = 0.0;
+            if (V != 1 && V != 3 && tail && X.has_dot()) X.row_pre(3 * (size_t)row, pr0, pr1, pr2);
             double y0 = (double)a.x * x0 + (double)a.y * x1 + (double)a.z * x2;
             double y1 = (double)a.w * x0 + (double)b.x * x1 + (double)b.y * x2;
             double y2 = (double)b.z * x0 + (double)b.w * x1 + (double)cc * x2;
@@ -2848,14 +2878,6 @@ __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nbl
                 acc += y0 + y1 + y2;
                 continue;
             }
-            const bool tail = (w >> 31) != 0;
-            const int32_t tfr_w = tile_first_row[t];  // bit 31: the tile starts inside a row begun in the previous tile
-            const int tfr = tfr_w & 0x7fffffff;
-            const bool tile_cont = tfr_w < 0;
-            const unsigned long long tails = __ballot(tail);
-            const unsigned long long heads = (tails << 1) | 1ull;
-            const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-            const int start = 63 - __clzll(heads & le);
             // Row sums as differences of prefix sums: a plain (unsegmented) inclusive scan over the 64 lanes -- four DPP row shifts inside the
             // 16-lane rows, then row_bcast:15 and row_bcast:31, no conditionals -- and one cross-lane read of the exclusive prefix at the
             // first lane of the lane's row. (The segmented scan this replaces spent two thirds of the loop's 233 instructions on masks,
@@ -2887,12 +2909,11 @@ __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nbl
             // last segment open (the row ends in the next tile of the chunk; never at the end of a chunk): hand it on in registers
             if (((tails >> 63) & 1ull) == 0ull) { k0 = read_lane(y0, 63); k1 = read_lane(y1, 63); k2 = read_lane(y2, 63); }
             if (tail) {
-                const int row = tfr + __popcll(tails & ((1ull << lane) - 1ull));
                 double* yr = y + 3 * (size_t)row;
                 yr[0] = y0;
                 yr[1] = y1;
                 yr[2] = y2;
-                if (X.has_dot()) acc += X.row_dot(3 * (size_t)row, y0, y1, y2);
+                if (X.has_dot()) acc += X.row_dot_pre(3 * (size_t)row, pr0, pr1, pr2, y0, y1, y2);
             }
         }
     }

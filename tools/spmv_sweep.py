@@ -1,9 +1,11 @@
-"""Developer tool: SpMV micro-benchmark sweep on the 1M-tet block matrix (run on the GPU box).
+"""Developer tool: SpMV micro-benchmark sweep on the 1M-tet block matrix (run on the GPU box); GRID=88,88,86 in the environment: the 8M-tet
+matrix (790 MB: out of reach of the Infinity Cache).
 
 Variants (mistark_set_option "spmv_variant"): 0 = the solver's launch (static chunks + contact part, contact rows left to the consumer),
 1 = the same without the row reduction (loads + block products), 3 = without the matrix value loads, 9 = plain float4 stream of the value
 buffer (floor of the memory system for this matrix), 11 = loads + gather + products in the simplest possible loop."""
 import ctypes as C
+import os
 import sys
 
 sys.path.insert(0, ".")
@@ -11,7 +13,8 @@ from bench import build_scene
 from stark_amd import capi
 from stark_amd import sim as S
 
-sim = build_scene(S, 44, 44, 43, 0)
+nx, ny, nz = [int(v) for v in os.environ.get("GRID", "44,44,43").split(",")]
+sim = build_scene(S, nx, ny, nz, 0)
 sim.run_one_step()
 L = capi.lib()
 h = sim.engine_handle()
