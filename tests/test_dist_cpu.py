@@ -184,7 +184,7 @@ def _rank_main(rank, world, port, name, result_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name", ["tetbeam_full_4x1x1", "tetbeam_eo_4x1x1_big", "cloth_shells_6"])
+@pytest.mark.parametrize("name", ["tetbeam_full_4x1x1", "tetbeam_eo_4x1x1_big", "cloth_shells_6", "contactmix_t1", "rbchain", "attachzoo"])
 def test_sharded_solve_equals_unsharded_gloo(name, tmp_path):
     import torch.multiprocessing as mp
 
