@@ -277,7 +277,7 @@ def main():
             "host_timers_s": {k: round(v, 6) for k, v in stage.items()},
             "contact": sim.contact_info() if a.scene == "contact" else None,
             "roofline": {
-                "kernel": "k_spmv_fused (3x3-block CSR in row-aligned chunks, float values, double vectors)",
+                "kernel": "k_spmv_fused (3x3-block CSR in row-aligned chunks, float values, double vectors)" + ("" if world == 1 else " — rank 0's rows of the sharded matrix: bytes and duration of ONE GPU's launch"),
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": 8000.0,

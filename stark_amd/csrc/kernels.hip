@@ -3710,10 +3710,26 @@ static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, do
     PcgCtrl h{};
     int k = 1;
     bool finished = false;
+    std::vector<int> sampled_k;
     while (!finished) {
         const int k_end = std::min(max_iter, k + PCG_CHECK - 1);
         for (; k <= k_end; k++) {
+            // (SpMV timing for the bench's roofline figure, as in pcg(): one launch in 32 between a pair of events, an empty pair behind it)
+            const bool sample = c.time_spmv && (k % 32) == 0 && sampled_k.size() < 64;
+            if (sample) {
+                while (c.ev.size() < 3 * (sampled_k.size() + 1)) {
+                    hipEvent_t e;
+                    MS_CHECK(hipEventCreate(&e));
+                    c.ev.push_back(e);
+                }
+                MS_CHECK(hipEventRecord(c.ev[3 * sampled_k.size()], c.stream));
+            }
             const int gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false);
+            if (sample) {
+                MS_CHECK(hipEventRecord(c.ev[3 * sampled_k.size() + 1], c.stream));
+                MS_CHECK(hipEventRecord(c.ev[3 * sampled_k.size() + 2], c.stream));
+                sampled_k.push_back(k);
+            }
             hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)part_pq, gs, (const double*)nullptr, 0, mine1);
             c.coll->allgather_f64(mine1, all1, 1, c.stream);
             hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, (const double*)all1, W, c.dinv.p, n_own, c.p.p, c.q.p, c.xl.p, c.r.p, c.z.p, part_rr,
@@ -3727,6 +3743,15 @@ static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, do
         }
         fetch(c, &h, c.ctrl.p, sizeof(PcgCtrl));
         finished = h.done || k > max_iter;
+    }
+    for (size_t i = 0; i < sampled_k.size(); i++) {  // (the fetch above waited for the stream)
+        if (h.done && sampled_k[i] > h.n_iter) continue;  // a no-op launch after convergence
+        float ms = 0.f, ms_empty = 0.f;
+        if (hipEventElapsedTime(&ms, c.ev[3 * i], c.ev[3 * i + 1]) == hipSuccess && hipEventElapsedTime(&ms_empty, c.ev[3 * i + 1], c.ev[3 * i + 2]) == hipSuccess) {
+            c.spmv_ms_sum += ms;
+            c.spmv_empty_ms_sum += ms_empty;
+            c.spmv_n++;
+        }
     }
     shard_gather_global(c, c.xl.p, c.du.p);
     const int n_it = h.done ? h.n_iter : max_iter;
