@@ -20,43 +20,38 @@ struct mistark_ctx;
 
 namespace symx
 {
+	// Public surface = what stark/src and user code touch of the reference's class: SolveStats (NewtonsMethod.h:32-43), the two public fields,
+	// create / solve / get_last_solve_stats / print_summary (:79-87). Everything behind it lives in shim/src/NewtonsMethod.cpp.
 	class NewtonsMethod
 	{
 	public:
-		/* Definitions (NewtonsMethod.h:32-43) */
 		struct SolveStats
 		{
-			int newton_iterations = 0;
-			int cg_iterations = 0;
-			int ls_cap_iterations = 0;
-			int ls_max_iterations = 0;
-			int ls_inv_iterations = 0;
-			int ls_bt_iterations = 0;
-			uint64_t n_hessians = 0;
-			uint64_t n_projected_hessians = 0;
+			// (names and types are the interface: Stark.cpp:176-207 and the summary printer read them)
+			int newton_iterations = 0, cg_iterations = 0;
+			int ls_cap_iterations = 0, ls_max_iterations = 0, ls_inv_iterations = 0, ls_bt_iterations = 0;
+			uint64_t n_hessians = 0, n_projected_hessians = 0;
 			double projected_hessians_ratio = 0.0;
 		};
 
-		/* Fields */
-		spSolverCallbacks callbacks;
-		NewtonSettings settings;
+		spSolverCallbacks callbacks;   // Stark.cpp:295 hands these over at creation; user code may add to them later
+		NewtonSettings settings;       // Stark.cpp:296 overwrites this before the first solve
 
-		/* Methods */
-		NewtonsMethod(spGlobalPotential global_potential, spContext context, spSolverCallbacks callbacks = nullptr);
+		NewtonsMethod(spGlobalPotential gp, spContext ctx, spSolverCallbacks cbs = nullptr);
 		~NewtonsMethod();
-		static std::shared_ptr<NewtonsMethod> create(spGlobalPotential global_potential, spContext context, spSolverCallbacks callbacks = nullptr);
-		SolverReturn solve();
-		const SolveStats& get_last_solve_stats() const { return this->stats; }
+		static std::shared_ptr<NewtonsMethod> create(spGlobalPotential gp, spContext ctx, spSolverCallbacks cbs = nullptr);
+
+		SolverReturn solve();                                                  // register / refresh, solve on the engine, DoFs back
+		const SolveStats& get_last_solve_stats() const { return stats; }
 		void print_summary(double total_time = -1.0) const;
 
-		/* Extension: the engine context behind this solver (nullptr before the first solve) */
-		mistark_ctx* engine() const;
+		mistark_ctx* engine() const;                                           // extension: nullptr before the first solve
 
 	private:
 		struct Impl;
 		std::unique_ptr<Impl> impl;
-		spGlobalPotential global_potential = nullptr;
-		spContext context = nullptr;
+		spGlobalPotential global_potential;
+		spContext context;
 		SolveStats stats;
 	};
 	using spNewtonsMethod = std::shared_ptr<NewtonsMethod>;
