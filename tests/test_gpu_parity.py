@@ -403,3 +403,25 @@ def test_reduced_matrix_projection_with_mirroring(name):
         assert (np.sqrt(((Ha[pi] - ref) ** 2).sum(axis=(1, 2))) <= 1e-9 * den).all()
         checked += len(den)
     assert checked > 0
+
+
+@pytest.mark.parametrize("n_bad", [1, -1])
+def test_newton_reports_nan_state_instead_of_accepting_it(n_bad):
+    """A NaN in one DoF (or in all of them) makes the gradient NaN: its largest magnitude must come back as non-finite (a max that drops
+    NaNs would report 0 = "converged") and the Newton solve must end with a failure code, not Successful and not an endless loop."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, "tetbeam_softrubber_6x2x2.npz"))
+    eng = engine_from_problem(prob, man)
+    u = eng.get_dofs()
+    if n_bad == 1:
+        u[7] = np.nan
+    else:
+        u[:] = np.nan
+    eng.set_dofs(u)
+    E, g = eng.eval(capi.EVAL_P_G)
+    assert not np.isfinite(g).all()
+    res, st = eng.newton_solve()
+    assert res == "LinearSystemSolveFailure" and st.newton_iterations <= 1
+    eng.close()
