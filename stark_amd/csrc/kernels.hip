@@ -1516,8 +1516,12 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         MS_CHECK(hipStreamWaitEvent(c.aux_stream, c.aux_ev[0], 0));
     }
     try {
+        // "small" = below EVAL_SMALL_POTENTIAL elements, or below a quarter of the largest potential (a million tets hide 172 k inertia nodes, too)
+        int64_t n_max = 0;
+        for (auto& P : c.pots) n_max = std::max<int64_t>(n_max, P.n_elem);
+        const int64_t small = std::max<int64_t>(EVAL_SMALL_POTENTIAL, n_max / 4);
         for (auto& P : c.pots) {
-            c.stream = (split && P.n_elem < EVAL_SMALL_POTENTIAL) ? c.aux_stream : main_stream;
+            c.stream = (split && P.n_elem < small) ? c.aux_stream : main_stream;
             launch_eval_kind(c, P, mode);
         }
     } catch (...) {
