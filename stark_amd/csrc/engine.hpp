@@ -292,7 +292,7 @@ struct Context
     hipEvent_t side_ev[2] = {nullptr, nullptr};
     bool no_pattern_overlap = false;  // option "no_pattern_overlap"
     hipStream_t aux_stream = nullptr;   // the small potentials of an evaluation run beside the large ones (eval())
-    hipEvent_t aux_ev[2] = {nullptr, nullptr};
+    hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool no_eval_overlap = false;     // option "no_eval_overlap"
     bool no_bounded_pattern = false;  // measurement / cross-check: the contact part's pattern with a read-back per stage, like the static part's
     int kernel_dbg = 0;             // option "kernel_dbg": measurement switches inside kernels (PotArgs::dbg)
@@ -325,6 +325,8 @@ struct Context
     uint64_t pattern_version = 1, llt_pattern_version = 0;  // bumped by every pattern build
     bool have_matrix = false;
     bool matrix_current = false;    // the assembled matrix reflects the current element Hessians
+    bool static_assembled = false;  // eval() has gathered the static part already, on the auxiliary stream (aux_ev[2] marks its end)
+    bool no_eager_assembly = false; // option "no_eager_assembly"
     int pcg_epoch = 0;              // solves started (PcgCtrl::epoch)
     std::vector<int32_t> hot_rows_host;  // what hot_rows holds (prepare uploads it only when it changes)
     DevBuf<uint32_t> proj_list;     // element ids selected for projection (per potential, at e_off)

@@ -1476,6 +1476,7 @@ void ensure_pattern(Context& c)
 // ======================================================================================================================
 static void build_pattern(Context& c, int part);
 static void build_pattern_part(Context& c, int part) { build_pattern(c, part); }
+static void assemble_part(Context& c, int part);
 void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs, bool lazy)
 {
     prepare(c);
@@ -1532,6 +1533,29 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
     if (split) {
         MS_CHECK(hipEventRecord(c.aux_ev[1], c.aux_stream));
         MS_CHECK(hipStreamWaitEvent(main_stream, c.aux_ev[1], 0));
+    }
+    // The static part of the matrix can be gathered as soon as the element Hessians are there: on the auxiliary stream (idle by now),
+    // beside this stream's gradient gather, reductions and the read-back the Newton loop takes its convergence decision from. assemble()
+    // then waits for it and only adds the contact part. (Not for staged calls: their projection may run before the assembly.)
+    c.static_assembled = false;
+    if (split && mode == MISTARK_EVAL_P_G_H && lazy && !c.atomic_assembly && !c.no_eager_assembly && !c.part[0].dirty && c.part[0].nnzb > 0) {
+        if (!c.aux_ev[2]) {
+            MS_CHECK(hipEventCreateWithFlags(&c.aux_ev[2], hipEventDisableTiming));
+            MS_CHECK(hipEventCreateWithFlags(&c.aux_ev[3], hipEventDisableTiming));
+        }
+        MS_CHECK(hipEventRecord(c.aux_ev[3], main_stream));  // (every element kernel is in this stream's queue, or joined into it)
+        MS_CHECK(hipStreamWaitEvent(c.aux_stream, c.aux_ev[3], 0));
+        c.have_hessians = true;
+        c.stream = c.aux_stream;
+        try {
+            assemble_part(c, 0);
+        } catch (...) {
+            c.stream = main_stream;
+            throw;
+        }
+        c.stream = main_stream;
+        MS_CHECK(hipEventRecord(c.aux_ev[2], c.aux_stream));
+        c.static_assembled = true;
     }
     if (overlap_pattern) {
         MS_CHECK(hipStreamWaitEvent(c.side_stream, c.side_ev[0], 0));
@@ -2301,6 +2325,7 @@ __global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restric
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active, int64_t* n_projected_now,
              int64_t* n_changed_now)
 {
+    if (c.static_assembled) MS_CHECK(hipStreamWaitEvent(c.stream, c.aux_ev[2], 0));  // (the deltas below go into the matrix the auxiliary stream is still gathering)
     ensure_pattern(c);
     if (!c.have_hessians) throw Error("project: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
     const int np = (int)c.pots.size();
@@ -2408,7 +2433,8 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
             compact = 1;
             launch_tet_closed_list(c, P, list_e_base + P.e_off, nl, H, n_pool);
         }
-        float* vals = c.matrix_current ? c.part[P.part].vals.p : nullptr;
+        // patched in place where the matrix already holds these Hessians: all of it after assemble(), its static part after eval()'s early gather
+        float* vals = (c.matrix_current || (c.static_assembled && P.part == 0)) ? c.part[P.part].vals.p : nullptr;
         const dim3 g((nl + 3) / 4), b(BLOCK);
         if (!(c.proj_variant & 1) && P.NB <= 6) {  // register-resident Jacobi, several elements per wavefront
             const int epw = 64 / ((3 * P.NB + 1) & ~1);
@@ -2688,13 +2714,11 @@ static void make_descriptors(Context& c, int part)
     }
     m.desc_lazy = c.lazy_active ? 1 : 0;
 }
-void assemble(Context& c)
+static void assemble_part(Context& c, int part)
 {
-    ensure_pattern(c);
-    if (!c.have_hessians) throw Error("assemble: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
-    for (int part = 0; part < 2; part++) {
+    {
         BsrPart& m = c.part[part];
-        if (m.nnzb == 0) continue;
+        if (m.nnzb == 0) return;
         if (c.atomic_assembly && c.world == 1) {
             MS_CHECK(hipMemsetAsync(m.vals.p, 0, (size_t)m.ntiles * 576 * sizeof(float), c.stream));
             for (auto& P : c.pots) {
@@ -2718,6 +2742,17 @@ void assemble(Context& c)
         }
         m.have_matrix = true;
     }
+}
+void assemble(Context& c)
+{
+    ensure_pattern(c);
+    if (!c.have_hessians) throw Error("assemble: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
+    if (c.static_assembled) MS_CHECK(hipStreamWaitEvent(c.stream, c.aux_ev[2], 0));  // eval() gathered the static part on the auxiliary stream
+    for (int part = 0; part < 2; part++) {
+        if (part == 0 && c.static_assembled) continue;
+        assemble_part(c, part);
+    }
+    c.static_assembled = false;
     c.have_matrix = true;
     c.matrix_current = true;
 }
@@ -3931,8 +3966,8 @@ Context::~Context()
     if (pub) (void)hipHostFree(pub);
     if (aux_stream) {
         (void)hipStreamDestroy(aux_stream);
-        (void)hipEventDestroy(aux_ev[0]);
-        (void)hipEventDestroy(aux_ev[1]);
+        for (auto& e : aux_ev)
+            if (e) (void)hipEventDestroy(e);
     }
     if (side_stream) {
         (void)hipStreamDestroy(side_stream);
