@@ -920,6 +920,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "lazy_eval") ctx->c.lazy_eval = value != 0;
     else if (n == "no_pattern_overlap") ctx->c.no_pattern_overlap = value != 0;
     else if (n == "no_eval_overlap") ctx->c.no_eval_overlap = value != 0;
+    else if (n == "contact_speculation") ctx->c.contact_speculation = value != 0;
     else if (n == "no_eager_assembly") ctx->c.no_eager_assembly = value != 0;
     else if (n == "no_bounded_pattern") { ctx->c.no_bounded_pattern = value != 0; ctx->c.part[1].dirty = true; }
     else if (n == "fuse_dir") ctx->c.no_fuse_dir = value == 0;

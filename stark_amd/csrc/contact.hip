@@ -1332,7 +1332,7 @@ int64_t count_intersections(Context& c, double dt)
             cs.keys_alt.ensure(cs.key_cap);
         }
         cs.spec.valid = false;
-        const bool speculate = !c.no_contact_cache;
+        const bool speculate = !c.no_contact_cache && c.contact_speculation;  // (option; off by default)
         for (bool first = true;; first = false) {
             if (!(first && boxes_current)) sort_boxes(c, cs, d);
             launch_sweep<false, false>(c, cs, d, 0.0);

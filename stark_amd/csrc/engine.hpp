@@ -294,6 +294,7 @@ struct Context
     hipStream_t aux_stream = nullptr;   // the small potentials of an evaluation run beside the large ones (eval())
     hipEvent_t aux_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool no_eval_overlap = false;     // option "no_eval_overlap"
+    bool contact_speculation = false; // option "contact_speculation": the intersection check runs the proximity search of the next evaluation ahead
     bool no_bounded_pattern = false;  // measurement / cross-check: the contact part's pattern with a read-back per stage, like the static part's
     int kernel_dbg = 0;             // option "kernel_dbg": measurement switches inside kernels (PotArgs::dbg)
     DevBuf<uint8_t> is_projected, active_blocks;

@@ -239,7 +239,8 @@ def test_cloth_on_box_contact_trajectory():
                                           # ones, device-side counts in the contact part's pattern, pattern beside the evaluation, lazy float pool,
                                           # repeated-search caches): the reference's iteration counts either way
                                           ("traj_cfg3_blockbox_10", "no_eval_overlap"), ("traj_cfg3_blockbox_10", "no_bounded_pattern"),
-                                          ("traj_cfg3_blockbox_10", "no_pattern_overlap"), ("traj_cfg3_blockbox_10", "no_contact_cache")])
+                                          ("traj_cfg3_blockbox_10", "no_pattern_overlap"), ("traj_cfg3_blockbox_10", "no_contact_cache"),
+                                          ("traj_cfg3_blockbox_10", "contact_speculation"), ("traj_cfg3_blockbox_10", "no_eager_assembly")])
 def test_block_on_box_contact_trajectory(name, options, monkeypatch):
     """configs[3] at fixture size (and at 12 k tets): Soft_Rubber tet block landing on a fixed rigid box (collision surface from
     find_surface), with friction (box registered first) and without (block first)."""
