@@ -219,7 +219,8 @@ int mistark_add_dof_set(mistark_ctx* ctx, const char* label, double* host, int64
 {
     API_BEGIN
     ctx->c.data_version++;
-    if (n_scalars % 3 != 0) throw Error("DoF set size must be a multiple of 3");
+    if (n_scalars < 0 || n_scalars % 3 != 0) throw Error("DoF set size must be a non-negative multiple of 3");
+    if (n_scalars > 0 && !host) throw Error("DoF set without a host array");
     DofSet s;
     s.label = label ? label : "";
     s.host = host;
@@ -234,7 +235,8 @@ int mistark_resize_dof_set(mistark_ctx* ctx, int set, double* host, int64_t n_sc
     API_BEGIN
     ctx->c.data_version++;
     if (set < 0 || set >= (int)ctx->c.dof_sets.size()) throw Error("bad DoF set");
-    if (n_scalars % 3 != 0) throw Error("DoF set size must be a multiple of 3");
+    if (n_scalars < 0 || n_scalars % 3 != 0) throw Error("DoF set size must be a non-negative multiple of 3");
+    if (n_scalars > 0 && !host) throw Error("DoF set without a host array");
     Context& c = ctx->c;
     const double* old = c.dof_sets[set].host;
     c.dof_sets[set].host = host;
@@ -256,6 +258,7 @@ int mistark_array(mistark_ctx* ctx, const double* host, int64_t n_items, int str
     ctx->c.data_version++;
     Context& c = ctx->c;
     if (stride <= 0) throw Error("bad stride");
+    if (n_items < 0) throw Error("negative item count");
     for (size_t i = 0; i < c.arrays.size(); i++) {
         if (host != nullptr && c.arrays[i].host == host && c.arrays[i].stride == stride) {
             if (c.arrays[i].n_items != n_items) {
