@@ -303,6 +303,9 @@ EnergyAttachments::MultiHandler EnergyAttachments::add_by_distance(const PointSe
     // the mesh is set_1 at its current positions (:235), triangle indices local to set_1
     std::vector<Vec3> verts((size_t)set_1.size());
     for (int i = 0; i < set_1.size(); i++) verts[i] = set_1.get_position(i);
+    for (const auto& t : triangles)
+        for (int k = 0; k < 3; k++)
+            if (t[k] < 0 || t[k] >= set_1.size()) throw std::runtime_error("EnergyAttachments::add_by_distance: triangle vertex outside the point set");
     std::vector<int> pp0, pp1, pe_p, pt_p;
     std::vector<std::array<int, 2>> pe_e;
     std::vector<std::array<double, 2>> pe_b;
@@ -331,6 +334,9 @@ EnergyAttachments::Handler EnergyAttachments::add_by_distance(const RigidBodyHan
 {
     std::vector<Vec3> glob(loc_vertices.size());
     for (size_t i = 0; i < loc_vertices.size(); i++) glob[i] = body.transform_local_to_global_point(loc_vertices[i]);
+    for (const auto& t : triangles)
+        for (int k = 0; k < 3; k++)
+            if (t[k] < 0 || (size_t)t[k] >= glob.size()) throw std::runtime_error("EnergyAttachments::add_by_distance: triangle vertex outside the vertex list");
     std::vector<int> pts;
     std::vector<Vec3> loc;
     for (const int p : set_points) {

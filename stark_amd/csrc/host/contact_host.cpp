@@ -90,19 +90,30 @@ EnergyFrictionalContact::Handler EnergyFrictionalContact::add_triangles(const Ri
     stark.mark_registration_dirty();
     return Handler{this, group};
 }
+// (Handler::exit_if_not_valid in the reference: a handle that names no registered collision mesh is an error, here an exception)
+static void check_contact_handle(int idx, size_t n_objects, const char* what)
+{
+    if (idx < 0 || (size_t)idx >= n_objects) throw std::runtime_error(std::string("EnergyFrictionalContact::") + what + ": invalid contact handler");
+}
 void EnergyFrictionalContact::set_contact_thickness(const Handler& obj, double t)
 {
     if (t <= 0.0) throw std::runtime_error("Contact thickness must be positive in EnergyFrictionalContact.");
+    check_contact_handle(obj.get_idx(), contact_thicknesses.size(), "set_contact_thickness");
     contact_thicknesses[obj.get_idx()] = t;
     stark.mark_registration_dirty();
 }
 void EnergyFrictionalContact::set_friction(const Handler& a, const Handler& b, double mu)
 {
+    check_contact_handle(a.get_idx(), contact_thicknesses.size(), "set_friction");
+    check_contact_handle(b.get_idx(), contact_thicknesses.size(), "set_friction");
+    if (mu < 0.0) throw std::runtime_error("EnergyFrictionalContact::set_friction: negative friction coefficient");
     friction_pairs.push_back({(double)std::min(a.get_idx(), b.get_idx()), (double)std::max(a.get_idx(), b.get_idx()), mu});
     stark.mark_registration_dirty();
 }
 void EnergyFrictionalContact::disable_collision(const Handler& a, const Handler& b)
 {
+    check_contact_handle(a.get_idx(), contact_thicknesses.size(), "disable_collision");
+    check_contact_handle(b.get_idx(), contact_thicknesses.size(), "disable_collision");
     disabled_pairs.push_back({std::min(a.get_idx(), b.get_idx()), std::max(a.get_idx(), b.get_idx())});
     stark.mark_registration_dirty();
 }

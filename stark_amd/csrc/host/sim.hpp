@@ -194,7 +194,13 @@ public:
     int size() const { return (int)X.size(); }
     int get_begin(int s) const { return set_begin[s]; }
     int get_end(int s) const { return set_begin[s + 1]; }
-    int get_global_index(int s, int local) const { return set_begin[s] + local; }
+    int get_global_index(int s, int local) const
+    {
+        // IntervalVector::_assert_existing_set / _assert_local_idx (stark/src/models/IntervalVector.h:194-199): the reference exits, this throws
+        if (s < 0 || s + 1 >= (int)set_begin.size()) throw std::runtime_error("PointDynamics: point set " + std::to_string(s) + " does not exist");
+        if (local < 0 || set_begin[s] + local >= set_begin[s + 1]) throw std::runtime_error("PointDynamics: local index " + std::to_string(local) + " out of the range of point set " + std::to_string(s));
+        return set_begin[s] + local;
+    }
     Vec3 get_x1(int global_index, double dt) const { return x0[global_index] + dt * v1[global_index]; }
     void mirror_to_host();   // device -> host for x0, v0, v1 (x1 recomputed)
     void upload_state();     // host -> device after the user edited positions / velocities / forces

@@ -83,3 +83,30 @@ def test_unknown_option_and_null_context(ctx):
     assert L.mistark_set_option(h, b"no_eval_overlap", 1) == 0
     assert L.mistark_set_option(None, b"no_eval_overlap", 1) < 0
     assert L.mistark_last_error(None) == b"null context"
+
+
+def test_scene_facade_rejects_bad_handles_and_indices():
+    """The host mirror of stark::Simulation on a registration-only context: handles that name nothing and indices outside their point set
+    are errors where the reference exits (Handler::exit_if_not_valid, IntervalVector::_assert_local_idx), not out-of-range reads later."""
+    from stark_amd import sim as S
+
+    st = S.default_settings()
+    st.device = -1
+    st.init_frictional_contact = 0
+    sim = S.Simulation(st)
+    a = sim.add_surface_grid("a", (1.0, 1.0), (2, 2), S.cotton_fabric())
+    b = sim.add_surface_grid("b", (1.0, 1.0), (2, 2), S.cotton_fabric())
+    for call in (lambda: sim.prescribe_points(99, [0], 1e6),
+                 lambda: sim.prescribe_points(a, [1000], 1e6),
+                 lambda: sim.prescribe_points(a, [-1], 1e6),
+                 lambda: sim.attach_point_point(a, b, [0], [500], 1e3),
+                 lambda: sim.attach_point_point(a, b, [0, 1], [0], 1e3),
+                 lambda: sim.attach_by_distance(a, b, [0], [[0, 1, 77]], 0.1, 1e3),
+                 lambda: sim.rb_add_translation(42, (0.0, 0.0, 1.0)),
+                 lambda: sim.set_friction(5, 6, 0.5)):
+        with pytest.raises(S.SimError):
+            call()
+    sim.prescribe_points(a, [0, 8], 1e6)          # (the valid calls still work afterwards)
+    sim.attach_point_point(a, b, [0], [8], 1e3)
+    sim.prepare()
+    sim.close()
