@@ -1346,6 +1346,22 @@ void prepare(Context& c)
             P.ti_projection = P.name == E_TetStrain::name || P.name == E_TetStrainEO::name || P.name == E_TriangleStrain::name || P.name == E_TriangleStrainEO::name ||
                               P.name == E_DiscreteShells::name || P.name == E_BendingFlat::name;
             if (P.conn_dirty && !P.conn_ext) {
+                // every index the kernels will follow, against the size of the array it indexes (the reference would read out of bounds; here
+                // the result would be a memory fault on the device): once per connectivity upload
+                for (size_t b = 0; b < P.bindings.size(); b++) {
+                    const mistark_binding& B = P.bindings[b];
+                    if (B.conn_col < 0 || P.conn_host.empty()) continue;
+                    bool seen = false;  // (several bindings usually share a column and a size)
+                    for (size_t b2 = 0; b2 < b; b2++) seen = seen || (P.bindings[b2].conn_col == B.conn_col && c.arrays[P.bindings[b2].array].n_items == c.arrays[B.array].n_items);
+                    if (seen) continue;
+                    const int64_t n_items = c.arrays[B.array].n_items;
+                    for (int64_t e = 0; e < P.n_elem; e++) {
+                        const int32_t idx = P.conn_host[(size_t)e * P.conn_stride + B.conn_col];
+                        if (idx < 0 || idx >= n_items)
+                            throw Error("potential '" + P.name + "': connectivity entry " + std::to_string(idx) + " (element " + std::to_string(e) + ", column " + std::to_string(B.conn_col) +
+                                        ") is outside the array of " + std::to_string(n_items) + " items it indexes");
+                    }
+                }
                 P.conn.ensure(std::max<size_t>(P.conn_host.size(), 1));
                 if (!P.conn_host.empty())
                     MS_CHECK(hipMemcpyAsync(P.conn.p, P.conn_host.data(), P.conn_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));

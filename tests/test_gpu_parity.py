@@ -425,3 +425,24 @@ def test_newton_reports_nan_state_instead_of_accepting_it(n_bad):
     res, st = eng.newton_solve()
     assert res == "LinearSystemSolveFailure" and st.newton_iterations <= 1
     eng.close()
+
+
+def test_connectivity_entry_outside_its_array_is_an_error_not_a_memory_fault():
+    """An element that points past the end of an array it is bound to: refused when the connectivity is uploaded (first evaluation), with the
+    potential, the element and the column in the message."""
+    import copy
+
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+    from stark_amd.engine import EngineError
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, "tetbeam_softrubber_6x2x2.npz"))
+    bad = copy.deepcopy(prob)
+    k = [i for i, p in enumerate(bad.potentials) if p.name == "EnergyTetStrain"][0]
+    col = [b.conn for b in bad.potentials[k].bindings if b.conn >= 0][-1]
+    bad.potentials[k].conn[3, col] = 10 ** 6
+    eng = engine_from_problem(bad, man)
+    with pytest.raises(EngineError) as ei:
+        eng.eval(capi.EVAL_P_G_H)
+    assert "EnergyTetStrain" in str(ei.value) and "element 3" in str(ei.value)
+    eng.close()
