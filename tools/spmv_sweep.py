@@ -19,7 +19,7 @@ sim.run_one_step()
 L = capi.lib()
 h = sim.engine_handle()
 _, _, nbytes = sim.spmv_timing()
-for variant in [0, 1, 3, 9, 11]:
+for variant in [int(v) for v in os.environ.get("VARIANTS", "0,1,3,9,11").split(",")]:
   for cap in [int(a) for a in sys.argv[1:]] or [512, 1024, 2048, 4096]:
     L.mistark_set_option(h, b"spmv_grid_cap", cap)
     L.mistark_set_option(h, b"spmv_variant", variant)
