@@ -279,6 +279,10 @@ int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n,
 /* Average duration in ms of the EMPTY event brackets recorded right behind the timed launches: what a pair of event records costs the
  * stream by itself (call before the reset of mistark_spmv_timing). */
 int mistark_spmv_event_overhead(mistark_ctx* ctx, double* avg_ms);
+/* The same sampled launches on the device's constant clock: every workgroup records when it started and finished, the host takes
+ * max(end) - min(start) — the launch's execution time inside the solver loop, which is what rocprofv3's kernel trace reports, without
+ * the dispatch latency and marker packets an event bracket contains (call before the reset of mistark_spmv_timing). */
+int mistark_spmv_device_clock(mistark_ctx* ctx, double* avg_ms, int64_t* n);
 /* Micro-benchmark: n back-to-back SpMV launches on the currently assembled matrix, average duration in microseconds. */
 int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us);
 /* Waits until everything queued on the engine's stream has finished (entry points that return values already do; assemble / project /

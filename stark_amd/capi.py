@@ -138,6 +138,7 @@ def lib():
     L.mistark_dist_move.argtypes = [p, p]
     L.mistark_sync.argtypes = [p]
     L.mistark_spmv_event_overhead.argtypes = [p, C.POINTER(C.c_double)]
+    L.mistark_spmv_device_clock.argtypes = [p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.mistark_dof_array.argtypes = [p, C.c_int, C.c_int]
     L.mistark_create_dry.argtypes = [C.POINTER(p)]
     L.mistark_describe.argtypes = [p, p, i64]

@@ -962,6 +962,17 @@ int mistark_spmv_event_overhead(mistark_ctx* ctx, double* avg_ms)
     if (avg_ms) *avg_ms = c.spmv_n > 0 ? c.spmv_empty_ms_sum / (double)c.spmv_n : 0.0;
     API_END(0)
 }
+int mistark_spmv_device_clock(mistark_ctx* ctx, double* avg_ms, int64_t* n)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    int khz = 0;
+    MS_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c.device));
+    if (khz <= 0) throw Error("spmv_device_clock: the device reports no wall clock rate");
+    if (avg_ms) *avg_ms = c.spmv_clk_n > 0 ? c.spmv_clk_ticks / (double)c.spmv_clk_n / (double)khz : 0.0;
+    if (n) *n = c.spmv_clk_n;
+    API_END(0)
+}
 int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n, double* bytes_per_launch)
 {
     API_BEGIN
@@ -975,6 +986,8 @@ int mistark_spmv_timing(mistark_ctx* ctx, int reset, double* avg_ms, int64_t* n,
         c.spmv_ms_sum = 0.0;
         c.spmv_empty_ms_sum = 0.0;
         c.spmv_n = 0;
+        c.spmv_clk_ticks = 0.0;
+        c.spmv_clk_n = 0;
         c.time_spmv = reset > 0;
     }
     API_END(0)

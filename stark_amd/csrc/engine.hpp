@@ -355,6 +355,9 @@ struct Context
     double spmv_ms_sum = 0.0;
     double spmv_empty_ms_sum = 0.0;  // empty event brackets recorded right behind the sampled launches
     int64_t spmv_n = 0;
+    uint64_t* spmv_clk = nullptr;  // pinned: per-workgroup (start, end) of the sampled launches on the device's constant clock
+    double spmv_clk_ticks = 0.0;
+    int64_t spmv_clk_n = 0;
 
     // multi-GPU: elements of every potential are sharded by contiguous ranges; E, gradient and the assembled matrix
     // are summed over the ranks; everything else is replicated

@@ -3165,14 +3165,25 @@ struct StaticPart  // the static part as the fused SpMV kernel sees it
 // [g1, g1 + gr): over-long static rows, the rest: chunks of the static part. partials keep the order static | long | contact.
 template <int V>
 __global__ __launch_bounds__(BLOCK) void k_spmv_fused(int g0, int gr, int g1, StaticPart m, DynPart d, const double* __restrict__ x, double* __restrict__ y,
-                                                     const double* __restrict__ pdot, double* __restrict__ partials, const PcgCtrl* __restrict__ ctrl)
+                                                     const double* __restrict__ pdot, double* __restrict__ partials, const PcgCtrl* __restrict__ ctrl,
+                                                     uint64_t* __restrict__ clk)
 {
     if (ctrl && ctrl->done) return;
     const int b = (int)blockIdx.x;
+    // sampled launches (clk != null, pinned host memory): every workgroup records when it started and finished on the device's constant
+    // clock; the host takes max(end) - min(start), the launch's execution time without anything the stream does around it
+    const uint64_t t_start = clk ? wall_clock64() : 0;
     const XPlain X{x, pdot};
     if (b < g1) spmv_chunks(b, g1, d, X, partials ? partials + g0 + gr : nullptr);
     else if (b < g1 + gr) spmv_long_rows(b - g1, gr, m.vals, m.scol, m.long_rows, m.n_long_rows, m.row_ptr, m.row_pos, X, y, partials ? partials + g0 : nullptr);
     else spmv_chunked_static<V>(b - g1 - gr, g0, m.vals, m.scol, m.tile_first_row, m.n_chunks, m.chunk_tiles, X, y, partials);
+    if (clk) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            clk[2 * b] = t_start;
+            clk[2 * b + 1] = wall_clock64();
+        }
+    }
 }
 // The PCG's iteration k as the solver launches it: what k_pcg_dir did for iteration k-1 (sums of r.r and r.z, convergence test, beta) in the
 // prologue of every workgroup (all of them compute the same numbers from the same partial sums; workgroup 0 records them), then
@@ -3252,7 +3263,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_combine(int64_t nbr, const int32
 }
 // y = (A_static + A_dynamic) x; partial sums of pdot . y go to partials[0 .. return value)
 template <int V>
-static int launch_spmv(Context& c, const double* x, double* y, const double* pdot, double* partials, const PcgCtrl* ctrl, bool combine = true)
+static int launch_spmv(Context& c, const double* x, double* y, const double* pdot, double* partials, const PcgCtrl* ctrl, bool combine = true, uint64_t* clk = nullptr)
 {
     const BsrPart& m0 = c.part[0];
     BsrPart& m1 = c.part[1];
@@ -3266,7 +3277,7 @@ static int launch_spmv(Context& c, const double* x, double* y, const double* pdo
         g1 = (int)std::min<int64_t>(((m1.n_chunks + 3) / 4 + (m1.n_rows + BLOCK / 4 - 1) / (BLOCK / 4) + 7) / 8 * 8, MAX_PARTIALS / 4);
         d = DynPart{m1.vals.p, m1.colw.p, m1.row_ptr.p, m1.row_chunk0.p, m1.chunk_row.p, m1.rowmap.p, m1.yd.p, m1.chunk_partial.p, m1.n_chunks, m1.n_rows};
     }
-    hipLaunchKernelGGL(k_spmv_fused<V>, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, x, y, pdot, partials, ctrl);
+    hipLaunchKernelGGL(k_spmv_fused<V>, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, x, y, pdot, partials, ctrl, clk);
     if (g1 > 0 && combine)
         hipLaunchKernelGGL(k_spmv_combine, dim3(grid_for(c.mrows())), dim3(BLOCK), 0, c.stream, c.mrows(), (const int32_t*)m1.crow_of_row.p, (const uint32_t*)m1.row_chunk0.p,
                            (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, y);
@@ -3867,6 +3878,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     }
     const int epoch = ++c.pcg_epoch;
     std::vector<int> sampled[2];
+    int clk_grid[2] = {0, 0};
     int k = 1;
     auto launch_batch = [&](int slot) {
         const int k_end = std::min(max_iter, k + PCG_BATCH - 1);
@@ -3895,7 +3907,14 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
                 gs = launch_spmv_dir(c, DirArgs{c.z.p, pprev, pk, part_rr, part_rz, gv, k, abs_tol, rel_tol}, c.q.p, part_pq);
             } else {
                 pk = c.p.p;
-                gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false);
+                uint64_t* clk = nullptr;
+                if (sample) {
+                    if (!c.spmv_clk) MS_CHECK(hipHostMalloc((void**)&c.spmv_clk, sizeof(uint64_t) * 2 * PCG_BATCH * 2 * MAX_PARTIALS, hipHostMallocDefault));
+                    clk = c.spmv_clk + ((size_t)slot * PCG_BATCH + sampled[slot].size()) * 2 * MAX_PARTIALS;
+                    std::memset(clk, 0, sizeof(uint64_t) * 2 * MAX_PARTIALS);
+                }
+                gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false, clk);
+                if (sample) clk_grid[slot] = gs;
             }
             if (sample) {
                 MS_CHECK(hipEventRecord(c.ev[e0 + 1], c.stream));
@@ -3931,6 +3950,20 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
                 c.spmv_ms_sum += ms;
                 c.spmv_empty_ms_sum += ms_empty;
                 c.spmv_n++;
+            }
+            if (c.spmv_clk && clk_grid[slot] > 0) {  // the same launch on the device clock
+                const uint64_t* clk = c.spmv_clk + ((size_t)slot * PCG_BATCH + i) * 2 * MAX_PARTIALS;
+                uint64_t t0 = ~0ull, t1 = 0;
+                bool complete = true;
+                for (int b = 0; b < clk_grid[slot]; b++) {
+                    if (clk[2 * b] == 0 || clk[2 * b + 1] == 0) { complete = false; break; }
+                    t0 = std::min(t0, clk[2 * b]);
+                    t1 = std::max(t1, clk[2 * b + 1]);
+                }
+                if (complete && t1 > t0) {
+                    c.spmv_clk_ticks += (double)(t1 - t0);
+                    c.spmv_clk_n++;
+                }
             }
         }
     };
@@ -3980,6 +4013,7 @@ Context::~Context()
     if (h_scratch) (void)hipHostFree(h_scratch);
     if (h_pin) (void)hipHostFree(h_pin);
     if (pub) (void)hipHostFree(pub);
+    if (spmv_clk) (void)hipHostFree(spmv_clk);
     if (aux_stream) {
         (void)hipStreamDestroy(aux_stream);
         for (auto& e : aux_ev)

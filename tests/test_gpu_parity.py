@@ -374,6 +374,34 @@ def test_pcg_back_to_back_solves_do_not_see_each_others_lookahead():
     eng.close()
 
 
+def test_sampled_spmv_launches_report_a_device_clock_duration_and_leave_the_solve_alone():
+    """bench.py's roofline timing: every 32nd SpMV of a solve is bracketed by HIP events AND stamps per-workgroup start / end times of the
+    device's constant clock into pinned memory. The solve's bits do not depend on the sampling, the clock figure is positive and below
+    the event bracket around the same launches (which also contains the dispatch and the marker packets)."""
+    import ctypes as C
+
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, "tetbeam_softrubber_6x2x2.npz"))
+    eng = engine_from_problem(prob, man)
+    eng.eval(capi.EVAL_P_G_H)
+    eng.assemble()
+    du0, info0 = eng.pcg(1e-300, 1e-300, 100)                    # (runs to the iteration cap)
+    assert info0.n_iterations >= 64                              # several sampled launches
+    eng.spmv_timing(reset=1)
+    for rep in range(4):
+        du, info = eng.pcg(1e-300, 1e-300, 100)
+        assert info.n_iterations == info0.n_iterations and (du == du0).all()
+    ms, n = C.c_double(), C.c_int64()
+    assert eng.L.mistark_spmv_device_clock(eng.h, C.byref(ms), C.byref(n)) == 0
+    ev_ms, ev_n, nbytes = eng.spmv_timing(reset=-1)
+    assert n.value == ev_n == 4 * (info0.n_iterations // 32)
+    assert 0.0 < ms.value < ev_ms < 1.0
+    assert eng.L.mistark_spmv_device_clock(eng.h, C.byref(ms), C.byref(n)) == 0 and n.value == 0   # reset with the event timing
+    eng.close()
+
+
 @pytest.mark.parametrize("name", ["tetbeam_eo_4x1x1_big", "cloth_shells_6"])
 def test_reduced_matrix_projection_with_mirroring(name):
     """project_to_pd_use_mirroring (negative eigenvalues become their mirror image instead of eps): the reduced-matrix kernel for
