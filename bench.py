@@ -215,7 +215,7 @@ def main():
         if capi.lib().mistark_set_option(sim.engine_handle(), k.encode(), int(v)) != 0:
             raise RuntimeError("%s: %s" % (kv, capi.lib().mistark_last_error(sim.engine_handle())))
 
-    sim.spmv_timing(reset=1)  # start SpMV event timing for the timed region
+    sim.spmv_timing(reset=-1 if os.environ.get("MISTARK_BENCH_NO_SPMV_SAMPLING") else 1)  # start SpMV timing for the timed region (the variable: A/B of what the sampling itself costs)
     barrier()
     info0 = sim.info()
     t0 = time.perf_counter()
