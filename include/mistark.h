@@ -234,6 +234,27 @@ typedef struct mistark_newton_stats
     double t_total;
 } mistark_newton_stats;
 
+/* One record per Newton iteration of the last mistark_newton_solve: what the reference appends to its Logger series inside the loop
+ * (NewtonsMethod.cpp:198-207 "n_hessians", "n_projected_hessians", "cg_iterations" = the iterations of the LAST linear solve of the
+ * iteration, :488-594 "ls_cap", "ls_max", "ls_inv", "ls_bt") and prints at Verbosity::Full (r0, du). `logged` = the iteration got past
+ * its linear solves (the first group of series has an entry), `line_search` = its line search ran (the ls_* series have one). */
+typedef struct mistark_newton_iteration
+{
+    double residual;             /* r0 at the iteration's evaluation */
+    double du_max;               /* max |du| of the accepted solve */
+    int32_t linear_solves;       /* solves of this iteration (progressive projection retries included) */
+    int32_t cg_iterations_last;  /* the reference's per-iteration "cg_iterations" */
+    int32_t cg_iterations_all;   /* over all solves of the iteration */
+    int32_t logged;
+    int64_t n_hessians;
+    int64_t n_projected_hessians;
+    int32_t line_search;
+    int32_t ls_cap, ls_max, ls_inv, ls_bt;
+    int32_t reserved;
+} mistark_newton_iteration;
+/* Copies up to `cap` records into `out`; *n = number of records the last solve produced. */
+int mistark_newton_iteration_log(mistark_ctx* ctx, mistark_newton_iteration* out, int32_t cap, int32_t* n);
+
 /* symx::SolverCallbacks (solver_utils.h:29-117). Any pointer may be NULL. Callbacks run on the calling thread; they may
  * call mistark_* functions on the same context (e.g. download positions, update contact connectivity). */
 typedef struct mistark_newton_callbacks

@@ -139,7 +139,7 @@ static stark::Settings base_settings(const Args& a, const std::string& name)
     settings.output.enable_frame_writes = a.i("frames", 0) != 0;  // mode `frames`: the reference writes its VTK frames (one per time step at fps = 30)
     if (a.i("frames", 0) != 0) settings.output.fps = 30;
     settings.output.enable_output = a.i("verbose", 0) != 0 || a.i("frames", 0) != 0;
-    settings.output.console_verbosity = symx::Verbosity::Summary;
+    settings.output.console_verbosity = (symx::Verbosity)a.i("verbosity", (int)symx::Verbosity::Summary);  // 3 = Full: one line per Newton iteration
     settings.output.file_verbosity = symx::Verbosity::Minimal;
     settings.execution.n_threads = a.i("threads", 1);
     settings.simulation.max_time_step_size = a.d("dt", 1.0 / 30.0);
@@ -1282,18 +1282,27 @@ int main(int argc, char** argv)
         const int warm = a.i("warmup", 1);
         for (int s = 0; s < warm; s++) sc.step();
         auto& lg = *st.context->logger;
-        const int newton0 = lg.get_int("newton_iterations");
-        const double ls0 = lg.get_timer_total("linear_system_solve");
-        const int lsn0 = lg.get_timer_count("linear_system_solve");
+        // (the logger's labels exist once a step has run)
+        const int newton0 = warm > 0 ? lg.get_int("newton_iterations") : 0;
+        const double ls0 = warm > 0 ? lg.get_timer_total("linear_system_solve") : 0.0;
+        const int lsn0 = warm > 0 ? lg.get_timer_count("linear_system_solve") : 0;
+        // (per time step: Newton iterations, linear solves and CG iterations as the reference's logger counts them)
+        std::ostringstream per_step;
         const double t0 = omp_get_wtime();
-        for (int s = 0; s < steps; s++) sc.step();
+        for (int s = 0; s < steps; s++) {
+            const bool have = warm > 0 || s > 0;
+            const int n_a = have ? lg.get_int("newton_iterations") : 0, l_a = have ? lg.get_timer_count("linear_system_solve") : 0, c_a = have ? lg.get_int("cg_iterations") : 0;
+            sc.step();
+            per_step << (s ? "," : "") << "[" << lg.get_int("newton_iterations") - n_a << "," << lg.get_timer_count("linear_system_solve") - l_a << ","
+                     << lg.get_int("cg_iterations") - c_a << "]";
+        }
         const double t1 = omp_get_wtime();
         const int newton = lg.get_int("newton_iterations") - newton0;
         const double ls = lg.get_timer_total("linear_system_solve") - ls0;
         const int lsn = lg.get_timer_count("linear_system_solve") - lsn0;
-        std::printf("{\"scene\":%s,\"threads\":%d,\"steps\":%d,\"newton_iterations\":%d,\"wall_s\":%.6f,\"newton_steps_per_s\":%.6f,\"linear_solve_s\":%.6f,\"ms_per_linear_solve\":%.6f,\"linear_solves\":%d,\"ndofs\":%d}\n",
+        std::printf("{\"scene\":%s,\"threads\":%d,\"steps\":%d,\"newton_iterations\":%d,\"wall_s\":%.6f,\"newton_steps_per_s\":%.6f,\"linear_solve_s\":%.6f,\"ms_per_linear_solve\":%.6f,\"linear_solves\":%d,\"ndofs\":%d,\"per_step\":[%s]}\n",
             sc.json.c_str(), st.settings.execution.n_threads, steps, newton, t1 - t0, newton / (t1 - t0), ls, lsn > 0 ? 1000.0 * ls / lsn : 0.0, lsn,
-            st.global_potential->get_total_n_dofs());
+            st.global_potential->get_total_n_dofs(), per_step.str().c_str());
         return 0;
     }
     std::cerr << "unknown mode " << mode << std::endl;

@@ -264,17 +264,29 @@ namespace symx
 		this->stats.n_hessians = (uint64_t)st.n_hessians;
 		this->stats.n_projected_hessians = (uint64_t)st.n_projected_hessians;
 		this->stats.projected_hessians_ratio = st.projected_hessians_ratio;
-		// the series the reference logs per solve (NewtonsMethod.cpp:236-251): STARK's console line and YAML output read them
+		// The series the reference logs: one entry per Newton iteration inside the loop (NewtonsMethod.cpp:198-207: Hessian counts and the CG
+		// iterations of the iteration's LAST solve; :488-594: the four line-search series), one per solve after it (:249). STARK's console
+		// line and YAML output read them.
 		auto& lg = *this->context->logger;
-		lg.add_and_append("n_hessians", (double)st.n_hessians);
-		lg.add_and_append("n_projected_hessians", (double)st.n_projected_hessians);
-		lg.add_and_append("projected_hessians_ratio", st.projected_hessians_ratio);
-		lg.add_and_append("cg_iterations", st.cg_iterations);
+		int32_t n_rec = 0;
+		s.check(mistark_newton_iteration_log(s.ctx, nullptr, 0, &n_rec), "mistark_newton_iteration_log");
+		std::vector<mistark_newton_iteration> rec((size_t)n_rec);
+		if (n_rec > 0) s.check(mistark_newton_iteration_log(s.ctx, rec.data(), n_rec, &n_rec), "mistark_newton_iteration_log");
+		for (const mistark_newton_iteration& r : rec) {
+			if (r.logged) {
+				lg.add_and_append("n_hessians", (double)r.n_hessians);
+				lg.add_and_append("n_projected_hessians", (double)r.n_projected_hessians);
+				lg.add_and_append("projected_hessians_ratio", r.n_hessians > 0 ? (double)r.n_projected_hessians / (double)r.n_hessians : 0.0);
+				lg.add_and_append("cg_iterations", r.cg_iterations_last);
+			}
+			if (r.line_search) {
+				lg.add_and_append("ls_cap", r.ls_cap);
+				lg.add_and_append("ls_max", r.ls_max);
+				lg.add_and_append("ls_inv", r.ls_inv);
+				lg.add_and_append("ls_bt", r.ls_bt);
+			}
+		}
 		lg.add_and_append("newton_iterations", st.newton_iterations);
-		lg.add_and_append("ls_cap", st.ls_cap_iterations);
-		lg.add_and_append("ls_max", st.ls_max_iterations);
-		lg.add_and_append("ls_inv", st.ls_inv_iterations);
-		lg.add_and_append("ls_bt", st.ls_bt_iterations);
 		// stage times of the engine under the reference's timer names (NewtonsMethod.cpp:268,274,390; SecondOrderCompiledGlobal)
 		lg.add("mistark_linear_system_solve_s", st.t_linear_solve);
 		lg.add("mistark_assembly_s", st.t_assembly);

@@ -54,6 +54,15 @@ class NewtonStats(C.Structure):
     ]
 
 
+class NewtonIteration(C.Structure):
+    """mistark_newton_iteration: one record per Newton iteration of the last solve (the reference's per-iteration Logger series)."""
+    _fields_ = [
+        ("residual", C.c_double), ("du_max", C.c_double), ("linear_solves", C.c_int32), ("cg_iterations_last", C.c_int32), ("cg_iterations_all", C.c_int32),
+        ("logged", C.c_int32), ("n_hessians", C.c_int64), ("n_projected_hessians", C.c_int64), ("line_search", C.c_int32), ("ls_cap", C.c_int32),
+        ("ls_max", C.c_int32), ("ls_inv", C.c_int32), ("ls_bt", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 VOIDCB = C.CFUNCTYPE(None, C.c_void_p)
 INTCB = C.CFUNCTYPE(C.c_int, C.c_void_p)
 DBLCB = C.CFUNCTYPE(C.c_double, C.c_void_p)
@@ -151,6 +160,7 @@ def lib():
     L.mistark_newton_default_settings.argtypes = [C.POINTER(NewtonSettings)]
     L.mistark_newton_default_settings.restype = None
     L.mistark_newton_solve.argtypes = [p, C.POINTER(NewtonSettings), C.POINTER(NewtonCallbacks), C.POINTER(NewtonStats)]
+    L.mistark_newton_iteration_log.argtypes = [p, C.POINTER(NewtonIteration), C.c_int32, C.POINTER(C.c_int32)]
     L.mistark_set_option.argtypes = [p, C.c_char_p, C.c_int]
     L.mistark_spmv_bench.argtypes = [p, C.c_int, C.POINTER(dbl)]
     L.mistark_spmv_timing.argtypes = [p, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl)]

@@ -731,6 +731,14 @@ void mistark_newton_default_settings(mistark_newton_settings* s)
     s->linear_solver = MISTARK_SOLVER_BDPCG;
 }
 
+int mistark_newton_iteration_log(mistark_ctx* ctx, mistark_newton_iteration* out, int32_t cap, int32_t* n)
+{
+    API_BEGIN
+    const std::vector<mistark_newton_iteration>& log = ctx->c.newton_log;
+    if (n) *n = (int32_t)log.size();
+    if (out && cap > 0) std::memcpy(out, log.data(), sizeof(mistark_newton_iteration) * std::min<size_t>((size_t)cap, log.size()));
+    API_END(0)
+}
 int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settings, const mistark_newton_callbacks* callbacks, mistark_newton_stats* stats)
 {
     API_BEGIN

@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <limits>
 
 #include "engine.hpp"
@@ -78,10 +80,13 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
     };
 
     double E0 = 0.0, du_dot_grad = 0.0, res_0 = std::numeric_limits<double>::max();
+    // MISTARK_NEWTON_TRACE=1: one line per Newton iteration and per linear solve on stderr (what the reference prints at Verbosity::Full)
+    static const bool trace = std::getenv("MISTARK_NEWTON_TRACE") != nullptr;
     int result = MISTARK_RUNNING;
     int pdn_countdown = 0;
     double ppn_threshold = -1.0;
 
+    c.newton_log.clear();
     if (!call_bool(cb ? cb->is_initial_state_valid : nullptr, true)) result = MISTARK_INVALID_INITIAL_STATE;
 
     int it = -1;
@@ -103,6 +108,9 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
             gs.mark(ST_OTHER);
         }
         if (it == 0) res_0 = residual;
+        c.newton_log.push_back(mistark_newton_iteration{});
+        c.newton_log.back().residual = residual;
+        if (trace) std::fprintf(stderr, "         %d. r0: %.2e | \n", it, residual);
         if (!std::isfinite(residual) || !std::isfinite(E0)) {
             // NaN / inf energy or gradient (k_max_abs turns a NaN entry into +inf): the reference would spin forever here (every comparison
             // below is false and the projection threshold becomes NaN too); report the failure instead so that the time step is halved / the run stops
@@ -188,6 +196,11 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                 }
                 st.cg_iterations += info.n_iterations;
                 st.n_linear_solves++;
+                c.newton_log.back().linear_solves++;
+                c.newton_log.back().cg_iterations_last = info.n_iterations;
+                c.newton_log.back().cg_iterations_all += info.n_iterations;
+                if (trace) std::fprintf(stderr, "            solve: #CG %5d | tol %.2e | %s%s| ppn threshold %.2e\n", info.n_iterations, abs_tol, info.converged ? "converged " : "",
+                                        info.found_indefiniteness ? "indefinite " : "", ppn_threshold);
                 gs.mark(ST_OTHER);
             }
             const bool ok = info.converged != 0;
@@ -224,14 +237,23 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
 
         st.n_hessians += (int64_t)c.n_elem_total;
         st.n_projected_hessians += c.n_projected_total;
+        {
+            mistark_newton_iteration& rec = c.newton_log.back();
+            rec.logged = 1;
+            rec.n_hessians = (int64_t)c.n_elem_total;
+            rec.n_projected_hessians = c.n_projected_total;
+            rec.du_max = du_max_solved;
+        }
 
         double du_max = du_max_solved;
+        if (trace) std::fprintf(stderr, "            du: %.1e | E0: %.10e\n", du_max, E0);
         if (it >= s.min_iterations && du_max < s.step_tolerance) {
             result = MISTARK_SUCCESSFUL;
             break;
         }
 
         // ---- _line_search_inplace ---------------------------------------------------------------------------------
+        const int ls0[4] = {st.ls_cap_iterations, st.ls_max_iterations, st.ls_inv_iterations, st.ls_bt_iterations};
         {
             double* u0 = c.tmp_b.p;  // dofs_before_ls
             MS_CHECK(hipMemcpyAsync(u0, c.u.p, (size_t)ndofs * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
@@ -291,6 +313,14 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                     result = MISTARK_TOO_MANY_ARMIJO_ITERATIONS;
                 }
             }
+        }
+        {
+            mistark_newton_iteration& rec = c.newton_log.back();
+            rec.line_search = 1;
+            rec.ls_cap = st.ls_cap_iterations - ls0[0];
+            rec.ls_max = st.ls_max_iterations - ls0[1];
+            rec.ls_inv = st.ls_inv_iterations - ls0[2];
+            rec.ls_bt = st.ls_bt_iterations - ls0[3];
         }
         // user convergence (NewtonsMethod.cpp:221)
         if (it >= s.min_iterations && call_bool(cb ? cb->is_converged : nullptr, false)) {

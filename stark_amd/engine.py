@@ -284,6 +284,14 @@ class Engine:
         rc = self._ck(self.L.mistark_newton_solve(self.h, C.byref(s), C.byref(callbacks) if callbacks is not None else None, C.byref(st)))
         return capi.SOLVER_RETURN[rc], st
 
+    def newton_iteration_log(self):
+        """Per-iteration records of the last newton_solve (capi.NewtonIteration)."""
+        n = C.c_int32()
+        self._ck(self.L.mistark_newton_iteration_log(self.h, None, 0, C.byref(n)))
+        rec = (capi.NewtonIteration * max(n.value, 1))()
+        self._ck(self.L.mistark_newton_iteration_log(self.h, rec, n.value, C.byref(n)))
+        return list(rec)[:n.value]
+
     def set_option(self, name: str, value: int):
         self._ck(self.L.mistark_set_option(self.h, name.encode(), int(value)))
 

@@ -442,6 +442,18 @@ class Simulation:
     def engine_handle(self):
         return C.c_void_p(self.L.mistark_sim_engine(self.h))
 
+    def newton_iteration_log(self):
+        """Per-iteration records (capi.NewtonIteration) of the last Newton solve of the last time step attempt."""
+        from . import capi
+
+        n = C.c_int32()
+        if self.L.mistark_newton_iteration_log(self.engine_handle(), None, 0, C.byref(n)) < 0:
+            raise SimError("newton_iteration_log failed")
+        rec = (capi.NewtonIteration * max(n.value, 1))()
+        if self.L.mistark_newton_iteration_log(self.engine_handle(), rec, n.value, C.byref(n)) < 0:
+            raise SimError("newton_iteration_log failed")
+        return list(rec)[:n.value]
+
     def spmv_timing(self, reset=0):
         ms, n, b = C.c_double(), C.c_int64(), C.c_double()
         rc = self.L.mistark_spmv_timing(self.engine_handle(), reset, C.byref(ms), C.byref(n), C.byref(b))

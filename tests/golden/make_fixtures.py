@@ -81,6 +81,10 @@ FIXTURES = {
     "slim_cfg3_blockbox_44x44x43": ("slimdump", "blockbox", "nx=44 ny=44 nz=43 L=1 gap=0.0015 thickness=0.001 mu=0.5 kmin=1e8 bx=3 bz=0.1 boxfirst=1 threads=8 steps=0 amp=0.01 xamp=2e-4"),
     "slim_cfg2_clothbox_256": ("slimdump", "clothbox", "n=256 size=1 box=2 gap=0.0015 thickness=0.001 mu=0.5 threads=8 steps=0 amp=0.005 xamp=2e-4"),
     "slim_cfg4_mixed_26x26x25": ("slimdump", "mixed", "threads=8 steps=0 amp=0.01 xamp=2e-4"),
+    # configs[3] at FULL size over its first time steps: the reference's own per-step log (Newton iterations, linear solves) with 8 and with 4
+    # threads — its float accumulation order depends on the thread count, and from the fourth step on the two runs differ: that spread is
+    # what an independent implementation can be held to — and the per-iteration CG series + the end state of its first time step (two attempts: the first one hardens the rigid-body constraint)
+    "steplog_cfg3_blockbox_44x44x43": ("steplog", "blockbox", "nx=44 ny=44 nz=43 L=1 gap=0.0015 thickness=0.001 mu=0.5 kmin=1e8 bx=3 bz=0.1 boxfirst=1 steps=5"),
     # what the reference WRITES for a run: its VTK frames, its YAML log and its run summary (tet beam, 2 time steps)
     "frames_tetbeam_4x1x1": ("frames", "tetbeam", "nx=4 ny=1 nz=1 eo=0 steps=2 frames=1"),
     # contact scenes (cfg 1 / cfg 4 at fixture size): cloth resting on a fixed rigid box, soft block pressed on a fixed rigid box
@@ -103,6 +107,23 @@ def pack(name):
         scene_args = [a for a in args if not a.startswith(("steps=", "amp=", "xamp=", "frames="))]
         if mode != "geom":
             run([HARNESS, "prime", scene] + scene_args)
+        if mode == "steplog":
+            data = {}
+            for threads in (8, 4):
+                out = subprocess.run([HARNESS, "time", scene] + args + ["warmup=0", "threads=%d" % threads, "outdir=" + tmp], check=True, capture_output=True).stdout.decode()
+                txt = [l for l in out.splitlines() if l.startswith("{")][-1]
+                json.loads(txt)
+                data["time_t%d_json" % threads] = np.frombuffer(txt.encode(), dtype=np.uint8)
+            run([HARNESS, "traj", scene] + scene_args + ["steps=2", "slim=1", "threads=8", "out=" + tmp])  # (the first attempt ends in an invalid converged state: constraint hardening, the step is redone)
+            txt = open(os.path.join(tmp, "traj.json")).read()
+            json.loads(txt)
+            data["traj_json"] = np.frombuffer(txt.encode(), dtype=np.uint8)
+            for k in ("x_end", "v_end"):
+                data[k + "_every64"] = np.load(os.path.join(tmp, k + ".npy"))[::64]
+            data["harness_args"] = np.frombuffer((mode + " " + scene + " " + " ".join(args)).encode(), dtype=np.uint8)
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), **data)
+            print(name, "%.1f KB" % (os.path.getsize(os.path.join(OUT, name + ".npz")) / 1024))
+            return
         if mode == "frames":
             out = subprocess.run([HARNESS, mode, scene] + args + ["outdir=" + tmp], check=True, capture_output=True).stdout
             open(os.path.join(tmp, "console.txt"), "wb").write(out)

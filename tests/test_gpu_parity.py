@@ -191,7 +191,7 @@ def test_newton_trajectory_matches_reference(path):
 
     cb = capi.NewtonCallbacks()
     cb.before_energy_evaluation = capi.VOIDCB(before_eval)
-    newton_its, cg_total = [], 0
+    newton_its, cg_total, cg_series, ls_bt_series = [], 0, [], []
     for s in range(len(traj["steps"])):
         eng.fill(a_v1, 0.0)                      # before_time_step: v1 <- 0 (PointDynamics.cpp:58-62)
         pts_before = len(pts)
@@ -199,12 +199,20 @@ def test_newton_trajectory_matches_reference(path):
         assert res == "Successful"
         newton_its.append(st.newton_iterations)
         cg_total += st.cg_iterations
+        log = eng.newton_iteration_log()
+        assert sum(r.linear_solves for r in log) == st.n_linear_solves and sum(r.cg_iterations_all for r in log) == st.cg_iterations
+        assert sum(r.ls_bt for r in log) == st.ls_bt_iterations and sum(r.n_hessians for r in log if r.logged) == st.n_hessians
+        cg_series += [r.cg_iterations_last for r in log if r.logged]
+        ls_bt_series += [r.ls_bt for r in log if r.line_search]
         eng.axpby(a_x0, 1.0, a_x0, prob.dt, a_v1)  # on_time_step_accepted: x0 += dt v1; v0 = v1 (PointDynamics.cpp:64-78)
         eng.axpby(a_v0, 1.0, a_v1)
         # a duplicate at a step boundary (v1 = 0 again) must be kept, as in the reference trace
         assert len(pts) > pts_before
     assert newton_its == traj["newton_iterations"]
     assert abs(cg_total - sum(traj["cg_iterations"])) <= max(2, 0.05 * sum(traj["cg_iterations"]))
+    # the reference's Logger series, entry by entry: CG iterations of every Newton iteration's last solve, Armijo backtracks of every line search
+    assert len(cg_series) == len(traj["cg_iterations"]) and all(abs(a - b) <= 1 for a, b in zip(cg_series, traj["cg_iterations"])), (cg_series, traj["cg_iterations"])
+    assert ls_bt_series == traj["ls_bt"]
     ref = z["iterates"]
     assert len(pts) == ref.shape[0]
     for a, b in zip(pts, ref):
