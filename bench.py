@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 GAP, THICKNESS, MU, KMIN, BOX = 0.0015, 1e-3, 0.5, 1e8, (3.0, 3.0, 0.1)
 
 
-def build_scene(S, nx, ny, nz, device, scene="contact", eo=False):
+def build_scene(S, nx, ny, nz, device, scene="contact", eo=False, offset=(0.0, 0.0)):
     st = S.default_settings()
     st.device = device
     st.mirror_state_to_host = 0      # state stays in HBM between steps
@@ -45,7 +45,8 @@ def build_scene(S, nx, ny, nz, device, scene="contact", eo=False):
     # (box registered first: see oracle/ref_harness.cpp scene_blockbox on why the order matters for the reference's friction)
     rb = sim.add_rigid_box("box", 1.0, BOX)
     sim.rb_add_constraint("fix", rb)
-    ps = sim.add_volume_grid("block", (0.0, 0.0, 0.5 * BOX[2] + GAP + 0.5), (1.0, 1.0, 1.0), (nx, ny, nz), p)
+    # (offset: tests move the block off the box's diagonal, above which the centred grid has nodes exactly on a contact-classification tie)
+    ps = sim.add_volume_grid("block", (offset[0], offset[1], 0.5 * BOX[2] + GAP + 0.5), (1.0, 1.0, 1.0), (nx, ny, nz), p)
     sim.set_friction(sim.contact_group("d", ps), sim.contact_group("rb", rb), MU)
     return sim
 

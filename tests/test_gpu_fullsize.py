@@ -55,7 +55,7 @@ def _build_cfg(S, sc):
         rb = sim.add_rigid_box("box", 1.0, (sc["bx"], sc["bx"], sc["bz"]))
         sim.rb_add_constraint("fix", rb)
         L = sc["L"]
-        ps = sim.add_volume_grid("block", (0.0, 0.0, 0.5 * sc["bz"] + sc["gap"] + 0.5 * L), (L, L, L), (sc["nx"], sc["ny"], sc["nz"]), Sm.soft_rubber())
+        ps = sim.add_volume_grid("block", (sc.get("ox", 0.0), sc.get("oy", 0.0), 0.5 * sc["bz"] + sc["gap"] + 0.5 * L), (L, L, L), (sc["nx"], sc["ny"], sc["nz"]), Sm.soft_rubber())
         sim.set_friction(sim.contact_group("d", ps), sim.contact_group("rb", rb), sc["mu"])
     elif sc["kind"] == "clothbox":
         ps = sim.add_surface_grid("cloth", (sc["size"], sc["size"]), (sc["n"], sc["n"]), Sm.cotton_fabric())
@@ -379,17 +379,65 @@ def test_full_size_mixed_scene():
     sim.close()
 
 
-def test_full_size_first_time_steps_against_the_reference_log():
-    """BASELINE configs[3] at full size over its first five time-step attempts, against what the UNMODIFIED reference logged for the same scene
-    (fixture `steplog_cfg3_blockbox_44x44x43`: `ref_harness time` with 8 and with 4 threads + `traj slim` of the first two attempts).
+def _step_log(sim, n_attempts, z=None, check_after=1):
+    """(Newton iterations, linear solves, sum of the last solves' CG iterations) per time-step attempt + the per-iteration CG series; the
+    state after attempt `check_after` against the fixture's sampled end state (relative to the step's displacement / velocity)."""
+    per_step, series, prev, dev = [], [], (0, 0), None
+    for s in range(n_attempts):
+        assert sim.run_one_step()
+        i = sim.info()
+        cur = (i.total_newton_iterations, i.total_linear_solves)
+        log = sim.newton_iteration_log()
+        assert sum(r.linear_solves for r in log) == cur[1] - prev[1] and len(log) == cur[0] - prev[0] + 1
+        per_step.append([cur[0] - prev[0], cur[1] - prev[1], sum(r.cg_iterations_last for r in log if r.logged)])
+        series.append([r.cg_iterations_last for r in log if r.logged])
+        prev = cur
+        if z is not None and s == check_after:
+            x, v, X = sim.points("x0")[::64], sim.points("v0")[::64], sim.points("X")[::64]
+            xr, vr = z["x_end_every64"], z["v_end_every64"]
+            dev = (np.abs(x - xr).max() / np.abs(xr - X).max(), np.abs(v - vr).max() / np.abs(vr).max(), i.current_time)
+    return per_step, series, dev
 
-    What can be pinned: the first attempt (6 Newton iterations, ends in "invalid converged state": the rigid floor's constraint is hardened and
-    the step redone) has the reference's iteration and solve counts, and its first four linear solves take the reference's CG iteration
-    counts; the state after the first accepted step agrees to 1 % of the step's displacement / velocity (measured 0.3 %). Beyond that
-    the reference is not reproducible by itself: the rigid body's block rows sum ~10^5 contact contributions in FLOAT in thread order (its
-    8- and 4-thread runs differ from the fourth attempt on: 21 vs 17 linear solves), the CG iterates inherit 1e-3 relative differences,
-    and the progressive projection's retry storms (8 indefinite solves in one Newton iteration) start one attempt earlier or later. The
-    totals are held to the spread between the reference's own two runs, widened."""
+
+def test_full_size_first_time_steps_equal_the_reference_log_off_the_degenerate_placement():
+    """BASELINE configs[3] at full size (998 976 tets, IPC contact + friction on the rigid floor), the block moved 1.37 mm / -0.53 mm off
+    the box's axes, over its first eight time-step attempts, against the log of the UNMODIFIED reference (fixture
+    `steplog_cfg3_offset_44x44x43`: `ref_harness time` with 8 and 4 threads — identical — and `traj slim` of the first two attempts):
+    Newton iterations, linear solves (progressive-projection retries included: 27 solves in the eighth attempt) and the CG iterations of
+    every Newton iteration's last solve are EQUAL, attempt by attempt; the CG series of the first two attempts entry by entry; the state after
+    the first accepted step to 1e-4 of the step's displacement and velocity."""
+    import json
+
+    import bench
+    from stark_amd import sim as S
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "steplog_cfg3_offset_44x44x43.npz"))
+    ref = [json.loads(bytes(z["time_t%d_json" % t]).decode()) for t in (8, 4)]
+    traj = json.loads(bytes(z["traj_json"]).decode())
+    assert ref[0]["per_step"] == ref[1]["per_step"] and ref[0]["ndofs"] == 517050
+    sc = ref[0]["scene"]
+    sim = bench.build_scene(S, sc["nx"], sc["ny"], sc["nz"], 0, offset=(sc["ox"], sc["oy"]))
+    per_step, series, dev = _step_log(sim, len(ref[0]["per_step"]), z)
+    assert per_step == ref[0]["per_step"], (per_step, ref[0]["per_step"])
+    n0 = len(series[0])
+    assert series[0] + series[1] == traj["cg_iterations"] and [n0 - 1, len(series[1]) - 1] == traj["newton_iterations"]
+    print("end state of the first accepted step: relative deviation x %.2e v %.2e" % dev[:2])
+    assert abs(dev[2] - 1.0 / 30.0) < 1e-12 and dev[0] <= 1e-4 and dev[1] <= 1e-4
+    sim.close()
+
+
+def test_full_size_first_time_steps_on_the_centred_placement():
+    """The placement bench.py measures (block centred on the box). Here the bottom-face nodes with x = -y lie EXACTLY above the diagonal
+    edge of the box's top face, and 78 of the 264 edge-edge pairs have their closest point exactly at an edge endpoint: whether such a pair
+    is an edge-edge or an edge-point contact is decided by the last bit of a product, i.e. by how a compiler contracted the multiply-adds
+    (energy and gradient are the same either way — E and max |grad| of the first evaluation equal the reference's to all printed digits —
+    the Hessian puts the curvature on another node). On this placement the reference does not reproduce itself either: the same build with
+    the same thread count logged 21 linear solves in the fourth attempt in most runs and 17 in another (thread-order-dependent float sums
+    next to exact ties); off the axes its logs are identical and the engine's equal them (test above). Replayed at the reference's OWN iterates the engine
+    reproduces every later Newton step to 1e-5 (tools/steplog_cfg3.py). What is pinned here: the first attempt
+    (6 Newton iterations, ends in "invalid converged state": the floor's constraint is hardened, the step redone) has the reference's
+    counts and its first four solves the reference's CG iterations; the state after the first accepted step agrees to 1 % of the step
+    (measured 0.3 %); the totals over five attempts stay within the spread of the reference's own two runs, widened."""
     import json
 
     import bench
@@ -400,31 +448,12 @@ def test_full_size_first_time_steps_against_the_reference_log():
     traj = json.loads(bytes(z["traj_json"]).decode())
     assert [r["ndofs"] for r in ref] == [517050, 517050] and ref[0]["per_step"][:3] == ref[1]["per_step"][:3]
     sim = bench.build_scene(S, 44, 44, 43, 0)
-    per_step, prev = [], (0, 0)
-    for s in range(5):
-        assert sim.run_one_step()
-        i = sim.info()
-        cur = (i.total_newton_iterations, i.total_linear_solves)
-        per_step.append([c - p for c, p in zip(cur, prev)])
-        prev = cur
-        log = sim.newton_iteration_log()
-        assert sum(r.linear_solves for r in log) == per_step[-1][1] and len(log) == per_step[-1][0] + 1
-        if s == 0:
-            assert per_step[0] == ref[0]["per_step"][0][:2] == [5, 6]
-            assert [r.cg_iterations_last for r in log][:4] == traj["cg_iterations"][:4] == [3, 19, 22, 4]
-            assert abs(log[0].residual - 1.945e3) < 1.0            # (the reference prints "r0: 1.95e+03")
-            assert i.current_time == 0.0                            # invalid converged state: the step is redone
-        if s == 1:
-            assert abs(per_step[1][0] - ref[0]["per_step"][1][0]) <= 1 and abs(per_step[1][1] - ref[0]["per_step"][1][1]) <= 1
-            assert abs(i.current_time - 1.0 / 30.0) < 1e-12
-            x, v, X = sim.points("x0")[::64], sim.points("v0")[::64], sim.points("X")[::64]
-            xr, vr = z["x_end_every64"], z["v_end_every64"]
-            disp = np.abs(xr - X).max()
-            assert disp > 5e-3
-            assert np.abs(x - xr).max() <= 1e-2 * disp
-            assert np.abs(v - vr).max() <= 1e-2 * np.abs(vr).max()
-    newton = sum(p[0] for p in per_step)
-    solves = sum(p[1] for p in per_step)
+    per_step, series, dev = _step_log(sim, 5, z)
+    assert per_step[0][:2] == ref[0]["per_step"][0][:2] == [5, 6]
+    assert series[0][:4] == traj["cg_iterations"][:4] == [3, 19, 22, 4]
+    assert abs(per_step[1][0] - ref[0]["per_step"][1][0]) <= 1 and abs(per_step[1][1] - ref[0]["per_step"][1][1]) <= 1
+    assert abs(dev[2] - 1.0 / 30.0) < 1e-12 and dev[0] <= 1e-2 and dev[1] <= 1e-2
+    newton, solves = sum(p[0] for p in per_step), sum(p[1] for p in per_step)
     ref_newton = [r["newton_iterations"] for r in ref]
     ref_solves = [r["linear_solves"] for r in ref]
     assert 0.75 * min(ref_newton) <= newton <= 1.25 * max(ref_newton), (per_step, ref_newton)
