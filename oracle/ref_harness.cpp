@@ -566,7 +566,8 @@ static Scene scene_clothbox(const Args& a)
     sc.record_deformable(cloth.point_set, cT, cloth.point_set.all(), th);
     auto [bV, bT, box] = sim.presets->rigidbodies->add_box("box", 1.0, bs);
     sc.record_rigid(box.rigidbody, (int)bV.size(), bT, th);
-    box.rigidbody.add_translation({ 0.0, 0.0, -0.5 * bs - gap });
+    const double ox = a.d("ox", 0.0), oy = a.d("oy", 0.0);  // (the box moved off the cloth's axes: see scene_blockbox)
+    box.rigidbody.add_translation({ ox, oy, -0.5 * bs - gap });
     auto fix = sim.rigidbodies->add_constraint_fix(box.rigidbody);
     const double spin = a.d("spin", 0.0);  // README.md:84-91: the script turns the fixed box by 90 deg/s about z
     if (spin != 0.0) {
@@ -580,7 +581,7 @@ static Scene scene_clothbox(const Args& a)
     }
     std::ostringstream js;
     js << "{\"kind\":\"clothbox\",\"spin\":" << spin << ",\"n\":" << n << ",\"thickness\":" << th << ",\"gap\":" << gap << ",\"mu\":" << mu << ",\"size\":" << size << ",\"box\":" << bs
-       << ",\"kmin\":" << gp.min_contact_stiffness << "}";
+       << ",\"kmin\":" << gp.min_contact_stiffness << ",\"ox\":" << ox << ",\"oy\":" << oy << "}";
     sc.json = js.str();
     return sc;
 }

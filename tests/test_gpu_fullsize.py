@@ -60,7 +60,7 @@ def _build_cfg(S, sc):
     elif sc["kind"] == "clothbox":
         ps = sim.add_surface_grid("cloth", (sc["size"], sc["size"]), (sc["n"], sc["n"]), Sm.cotton_fabric())
         rb = sim.add_rigid_box("box", 1.0, sc["box"])
-        sim.rb_add_translation(rb, (0.0, 0.0, -0.5 * sc["box"] - sc["gap"]))
+        sim.rb_add_translation(rb, (sc.get("ox", 0.0), sc.get("oy", 0.0), -0.5 * sc["box"] - sc["gap"]))
         sim.rb_add_constraint("fix", rb)
         sim.set_friction(sim.contact_group("d", ps), sim.contact_group("rb", rb), sc["mu"])
     else:
