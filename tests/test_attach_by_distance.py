@@ -147,9 +147,11 @@ def test_add_by_distance_scene_trajectory():
         assert sim.info().last_newton_result == 0
         its.append(sim.info().last_stats.newton_iterations)
     # The first step pulls the patch onto the cloth from rest through k = 1e4 springs: linear solves of 300-400 CG iterations, where the
-    # float rounding of the matrix decides the last Newton iterations (the reference takes 15, this engine 13); from then on identical.
+    # float rounding of the matrix decides the last Newton iterations (the reference takes 15, this engine 13 or 14 from run to run: its
+    # gradient rows sum a handful of double atomics in arrival order); the second step inherits that (8, about one run in fifteen 7);
+    # from then on identical.
     ref = traj["newton_iterations"]
-    assert abs(its[0] - ref[0]) <= 2 and its[1:] == ref[1:], (its, ref)
+    assert abs(its[0] - ref[0]) <= 2 and abs(its[1] - ref[1]) <= 1 and its[2:] == ref[2:], (its, ref)
     x = sim.points("x0")
     # (the same ill-conditioned first step: rows that carry generic potentials sum their gradient terms with double atomics in arrival order,
     # and 300-400 CG iterations turn those last bits into 0.5e-4 .. 1.7e-4 of the extent from run to run; 1e-3 holds the trajectory without flaking)
