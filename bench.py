@@ -156,6 +156,23 @@ def profile_traffic():
     return (best[2], "profiles/%s_pmc_{fetch,write}.txt" % best[1]) if best else (None, None)
 
 
+def profile_kernel_trace():
+    """Average duration of the SpMV launches that did work in the newest committed rocprofv3 kernel trace of this command
+    (profiles/<tag>_kernel_stats.txt, last line, written by profiles/summarize_rocpd.py): (ms, source) or (None, None)."""
+    import glob
+    import re
+
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_kernel_stats.txt"))):
+        m = re.findall(r"k_spmv launches > 5 us \(real work\): n=(\d+) avg=([0-9.]+) us", open(f).read())
+        if m:
+            tag = os.path.basename(f)[:-len("_kernel_stats.txt")]
+            key = [int(x) for x in re.findall(r"\d+", tag)]
+            if best is None or key > best[0]:
+                best = (key, tag, float(m[-1][1]) * 1e-3)
+    return (best[2], "profiles/%s_kernel_stats.txt" % best[1]) if best else (None, None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,6 +266,7 @@ def main():
 
     if rank == 0:
         traffic, traffic_src = profile_traffic()
+        trace_ms, trace_src = profile_kernel_trace()
         n_tets = 12 * nx * ny * nz
         # The kernel's duration inside the solver loop: the device-clock figure (what rocprofv3's kernel trace reports for the same launches:
         # profiles/*_timeline.txt) when the engine delivered it, else the raw event bracket; both are reported below
@@ -309,6 +327,10 @@ def main():
                 "event_bracket_launches": spmv_n,
                 "achieved_event_bracket": achieved_events,
                 "frac_event_bracket": achieved_events / 8000.0,
+                # not measured in this run: the same kernel's launches with real work in the newest committed rocprofv3 kernel trace of this command
+                # (under the tracer; its duration spans the dispatch packet, the device clock above spans first wavefront in to last wavefront out)
+                "rocprofv3_profile_launch_ms": trace_ms if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
+                "rocprofv3_profile_source": trace_src if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
                 # every bracketed launch is followed by an EMPTY event bracket on the same stream: what two event records cost by themselves
                 "event_pair_overhead_ms": spmv_ev_overhead_ms,
                 # the same launch 100 times back to back after the timed region (one event pair around the batch, no dispatch gap per
