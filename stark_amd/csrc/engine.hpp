@@ -162,6 +162,8 @@ struct Potential
     // on the host from the connectivity (fixed order: the gradient of these potentials is bit-reproducible).
     bool grad_gather = false;
     DevBuf<uint32_t> inc_start, inc;  // per block row (+1): first incidence; per incidence: k * n_gpool + pool position
+    DevBuf<uint32_t> inc_long;        // block rows with more than GRAD_LONG_ROW incidences
+    int n_inc_long = 0;
     DevBuf<double> gpool;
     std::vector<int64_t> inc_sig;     // what the incidence lists were built for
     // sharded runs: the elements this rank evaluates, [elements whose energy counts here | interface elements of other ranks]
@@ -355,6 +357,7 @@ struct Context
     double spmv_ms_sum = 0.0;
     double spmv_empty_ms_sum = 0.0;  // empty event brackets recorded right behind the sampled launches
     int64_t spmv_n = 0;
+    DevBuf<double> grad_aux;  // gradient contributions of the potentials evaluated on the auxiliary stream (eval())
     std::vector<mistark_newton_iteration> newton_log;  // per-iteration records of the last newton_solve
     uint64_t* spmv_clk = nullptr;  // pinned: per-workgroup (start, end) of the sampled launches on the device's constant clock
     double spmv_clk_ticks = 0.0;

@@ -24,6 +24,7 @@
 namespace mistark {
 
 constexpr int BLOCK = 256;
+constexpr int GRAD_LONG_ROW = 256;   // gradient incidences of a block row beyond which a wavefront sums the row (k_grad_gather_long)
 constexpr int MAX_PARTIALS = 4096;   // max grid of any kernel that emits per-block partial sums
 constexpr int VEC_GRID = 512;
 // Jacobi sweeps stop when off(A)^2 <= tol * ||A||_F^2. Convergence is quadratic (a sweep squares off/||A||), so 1e-24 (off/||A|| <= 1e-12:
@@ -160,7 +161,9 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
         elemH[((size_t)(ba * NB + bb) * a.n_pool + pe) * 9 + ii * 3 + jj] = r.ab;
         elemH[((size_t)(bb * NB + ba) * a.n_pool + pe) * 9 + jj * 3 + ii] = r.ab;
     }
-    if (i == j && on) {
+    if (i == j && a.gpool) {  // node gradients to the pool, summed per block row in list order by k_grad_gather (an element switched off: zeros)
+        a.gpool[((size_t)ba * a.n_gpool + pe) * 3 + ii] = on ? r.a : 0.0;
+    } else if (i == j && on) {
         const int node = a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];
         if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);
         else atomicAdd(&grad[3 * (size_t)(a.dof_row_off[ba] + node) + ii], r.a);
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(BLOCK) void k_grad_gather(const double* __restrict_
     const int64_t row = t / 3;
     const int comp = (int)(t - 3 * row);
     const uint32_t k0 = inc_start[row], k1 = inc_start[row + 1];
-    if (k0 == k1) return;
+    if (k0 == k1 || k1 - k0 > GRAD_LONG_ROW) return;  // (long rows: k_grad_gather_long)
     double acc = 0.0;
     for (uint32_t kb = k0; kb < k1; kb += 8) {
         uint32_t src[8];
@@ -203,6 +206,34 @@ __global__ __launch_bounds__(BLOCK) void k_grad_gather(const double* __restrict_
     // (atomic: the small potentials of the same evaluation run on another stream and add to the same rows with atomics; one addition per row
     // and potential here, so rows that only closed-form elements touch keep their bits from run to run)
     atomicAdd(&grad[t], acc);
+}
+// Rows with more than GRAD_LONG_ROW incidences (a rigid body attached to hundreds of points): one wavefront per row, lanes stride over the
+// list, fixed-order wavefront reduction: deterministic like the short rows.
+__global__ __launch_bounds__(BLOCK) void k_grad_gather_long(const double* __restrict__ gpool, const uint32_t* __restrict__ inc_start, const uint32_t* __restrict__ inc,
+                                                           const uint32_t* __restrict__ long_rows, int n_long, double* __restrict__ grad)
+{
+    const int w = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= n_long) return;
+    const uint32_t row = long_rows[w];
+    const uint32_t k0 = inc_start[row], k1 = inc_start[row + 1];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (uint32_t k = k0 + lane; k < k1; k += 64) {
+        const double* g = gpool + (size_t)inc[k] * 3;
+        a0 += g[0];
+        a1 += g[1];
+        a2 += g[2];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        a0 += __shfl_down(a0, d, 64);
+        a1 += __shfl_down(a1, d, 64);
+        a2 += __shfl_down(a2, d, 64);
+    }
+    if (lane == 0) {
+        atomicAdd(&grad[3 * (size_t)row], a0);
+        atomicAdd(&grad[3 * (size_t)row + 1], a1);
+        atomicAdd(&grad[3 * (size_t)row + 2], a2);
+    }
 }
 // Closed-form tet kernels (tet_closed.hpp): one lane per tet; gradient through the pool above (or 12 atomics). The 16 Hessian blocks of a tet belong to 16 pools
 // (H[pair][element][9]); a lane storing its own 72 bytes would make every store instruction touch 64 separate segments, so each block
@@ -370,9 +401,12 @@ __global__ __launch_bounds__(BLOCK) void k_eval_tri_closed(PotArgs a, double* __
 }
 static void launch_grad_gather(Context& c, Potential& P)
 {
-    if (P.args.gpool && !(c.kernel_dbg & 1))
-        hipLaunchKernelGGL(k_grad_gather, dim3(grid_for(3 * c.nbr)), dim3(BLOCK), 0, c.stream, (const double*)P.gpool.p, (const uint32_t*)P.inc_start.p, (const uint32_t*)P.inc.p, c.nbr,
-                           c.grad.p);
+    if (!P.args.gpool || (c.kernel_dbg & 1)) return;
+    hipLaunchKernelGGL(k_grad_gather, dim3(grid_for(3 * c.nbr)), dim3(BLOCK), 0, c.stream, (const double*)P.gpool.p, (const uint32_t*)P.inc_start.p, (const uint32_t*)P.inc.p, c.nbr,
+                       c.grad.p);
+    if (P.n_inc_long > 0)
+        hipLaunchKernelGGL(k_grad_gather_long, dim3((P.n_inc_long + BLOCK / 64 - 1) / (BLOCK / 64)), dim3(BLOCK), 0, c.stream, (const double*)P.gpool.p, (const uint32_t*)P.inc_start.p,
+                           (const uint32_t*)P.inc.p, (const uint32_t*)P.inc_long.p, P.n_inc_long, c.grad.p);
 }
 template <class En, bool FULL>
 static void launch_tri_closed(Context& c, Potential& P, int mode)
@@ -412,6 +446,13 @@ __global__ __launch_bounds__(BLOCK) void k_eval_bending_flat(PotArgs a, double* 
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const double f = kc * dt * in[24 + i];
+        if (a.gpool) {
+            double* gp = a.gpool + ((size_t)i * a.n_gpool + pe) * 3;
+            gp[0] = f * s0;
+            gp[1] = f * s1;
+            gp[2] = f * s2;
+            continue;
+        }
         const size_t row = (size_t)(a.dof_row_off[i] + ce[a.dof_col[i]]);
         atomicAdd(&grad[3 * row], f * s0);
         atomicAdd(&grad[3 * row + 1], f * s1);
@@ -439,6 +480,7 @@ static void launch_bending_flat(Context& c, Potential& P, int mode)
         hipLaunchKernelGGL((k_eval_bending_flat<false>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
     else
         hipLaunchKernelGGL((k_eval_bending_flat<true>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
+    launch_grad_gather(c, P);
 }
 template <class En, bool FULL>
 static void launch_tet_closed(Context& c, Potential& P, int mode)
@@ -452,9 +494,7 @@ static void launch_tet_closed(Context& c, Potential& P, int mode)
         Potential& P;
         ~AfterLaunch()
         {
-            if (P.args.gpool && !(c.kernel_dbg & 1))
-                hipLaunchKernelGGL(k_grad_gather, dim3(grid_for(3 * c.nbr)), dim3(BLOCK), 0, c.stream, (const double*)P.gpool.p, (const uint32_t*)P.inc_start.p, (const uint32_t*)P.inc.p,
-                                   c.nbr, c.grad.p);
+            launch_grad_gather(c, P);
         }
     } after{c, P};
     if (mode == MISTARK_EVAL_P_G) {
@@ -497,6 +537,7 @@ static void launch_eval(Context& c, Potential& P, int mode)
     } else {
         hipLaunchKernelGGL((k_eval_pgh<En, true>), dim3(grid_for((int64_t)P.args.e_count * NP)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
     }
+    if (mode != MISTARK_EVAL_P) launch_grad_gather(c, P);
 }
 
 static void launch_eval_kind(Context& c, Potential& P, int mode)
@@ -1426,11 +1467,18 @@ void prepare(Context& c)
             if (P.lazy_capable) hf_off += (size_t)P.n_pool_f * 9 * 10;
             // gradient pool + incidence lists (Potential::grad_gather)
             const bool closed_tri = P.kind != KIND_CUSTOM && !c.force_generic && (P.name == E_TriangleStrain::name || P.name == E_TriangleStrainEO::name);
-            P.grad_gather = (P.lazy_capable || closed_tri) && !P.conn_ext && !P.conn_host.empty() && !c.no_grad_gather;
+            // ... and the generic kernels' potentials with several nodes per element (a single node per element: one addition per row, nothing to
+            // order); the rows of rigid bodies attached to many points are summed by k_grad_gather_long
+            const bool generic_pool = P.kind != KIND_CUSTOM && P.NB >= 2;
+            P.grad_gather = (P.lazy_capable || closed_tri || generic_pool) && !P.conn_ext && !P.conn_host.empty() && !c.no_grad_gather;
             std::vector<int64_t> sig{(int64_t)P.n_elem, c.nbr, (int64_t)P.n_key, (int64_t)P.conn_version, (int64_t)(c.world > 1 ? c.sh.version_lists : 0)};
             for (int k = 0; k < P.NB; k++) {
                 sig.push_back(A.dof_col[k]);
                 sig.push_back(A.dof_row_off[k]);
+            }
+            if (!P.grad_gather) {
+                A.gpool = nullptr;
+                P.inc_sig.clear();
             }
             if (P.grad_gather && P.inc_sig == sig) {  // lists still valid (prepare() runs at every change of the contact sets)
                 A.gpool = P.gpool.p;
@@ -1453,6 +1501,12 @@ void prepare(Context& c)
                 for (int le = 0; le < P.n_key; le++)  // element-major: the contributions of a row are summed in element order
                     for (int k = 0; k < P.NB; k++)
                         inc[fill[(size_t)(A.dof_row_off[k] + P.conn_host[(size_t)elem(le) * P.conn_stride + A.dof_col[k]])]++] = (uint32_t)k * (uint32_t)n_gpool + (uint32_t)le;
+                std::vector<uint32_t> long_rows;
+                for (int64_t r = 0; r < c.nbr; r++)
+                    if (start[(size_t)r + 1] - start[(size_t)r] > (uint32_t)GRAD_LONG_ROW) long_rows.push_back((uint32_t)r);
+                P.n_inc_long = (int)long_rows.size();
+                P.inc_long.ensure(std::max<size_t>(long_rows.size(), 1));
+                if (!long_rows.empty()) MS_CHECK(hipMemcpyAsync(P.inc_long.p, long_rows.data(), long_rows.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
                 P.inc_start.ensure(start.size());
                 P.inc.ensure(std::max<size_t>(inc.size(), 1));
                 P.gpool.ensure(std::max<size_t>((size_t)n_gpool * P.NB * 3, 1));
@@ -1531,24 +1585,34 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         }
         MS_CHECK(hipEventRecord(c.aux_ev[0], main_stream));  // (zero fill of the gradient, uploads, the contact tables)
         MS_CHECK(hipStreamWaitEvent(c.aux_stream, c.aux_ev[0], 0));
+        // the auxiliary stream's potentials add to their own copy of the gradient, folded in after the join: with one addition per row and
+        // kernel (pooled potentials, single-node potentials) the sum of a row no longer depends on which stream got there first
+        c.grad_aux.ensure((size_t)c.ndofs);
+        MS_CHECK(hipMemsetAsync(c.grad_aux.p, 0, (size_t)c.ndofs * sizeof(double), c.aux_stream));
     }
+    double* const grad_main = c.grad.p;
     try {
         // "small" = below EVAL_SMALL_POTENTIAL elements, or below a quarter of the largest potential (a million tets hide 172 k inertia nodes, too)
         int64_t n_max = 0;
         for (auto& P : c.pots) n_max = std::max<int64_t>(n_max, P.n_elem);
         const int64_t small = std::max<int64_t>(EVAL_SMALL_POTENTIAL, n_max / 4);
         for (auto& P : c.pots) {
-            c.stream = (split && P.n_elem < small) ? c.aux_stream : main_stream;
+            const bool aux = split && P.n_elem < small;
+            c.stream = aux ? c.aux_stream : main_stream;
+            c.grad.p = aux ? c.grad_aux.p : grad_main;
             launch_eval_kind(c, P, mode);
         }
     } catch (...) {
         c.stream = main_stream;
+        c.grad.p = grad_main;
         throw;
     }
     c.stream = main_stream;
+    c.grad.p = grad_main;
     if (split) {
         MS_CHECK(hipEventRecord(c.aux_ev[1], c.aux_stream));
         MS_CHECK(hipStreamWaitEvent(main_stream, c.aux_ev[1], 0));
+        vec_axpby(c, c.grad.p, 1.0, c.grad.p, 1.0, c.grad_aux.p, c.ndofs);
     }
     // The static part of the matrix can be gathered as soon as the element Hessians are there: on the auxiliary stream (idle by now),
     // beside this stream's gradient gather, reductions and the read-back the Newton loop takes its convergence decision from. assemble()
