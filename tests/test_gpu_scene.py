@@ -196,14 +196,18 @@ def _contact_sim(S, sc):
 
 
 def _run_and_compare(sim, z, traj, tol=1e-6, its_slack=0):
-    its = []
+    its, cg_series = [], []
     for step in range(len(traj["steps"])):
         assert sim.run_one_step()
         i = sim.info()
         assert abs(i.current_time - traj["steps"][step]["time"]) < 1e-12, (step, i.last_newton_result)
         its.append(i.last_stats.newton_iterations)
+        cg_series += [r.cg_iterations_last for r in sim.newton_iteration_log() if r.logged]
     if its_slack == 0:
         assert its == traj["newton_iterations"]
+        # the reference's Logger series "cg_iterations" (the last solve of every Newton iteration), entry by entry
+        ref_cg = traj["cg_iterations"]
+        assert len(cg_series) == len(ref_cg) and all(abs(a - b) <= max(2, 0.15 * b) for a, b in zip(cg_series, ref_cg)), (cg_series, ref_cg)
     else:
         assert all(abs(a - b) <= its_slack for a, b in zip(its, traj["newton_iterations"])), (its, traj["newton_iterations"])
     x = sim.points("x0")
