@@ -283,14 +283,17 @@ int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settin
  * matrix); "spmv_chunk_tiles" = tiles per SpMV chunk (0 = by matrix size); "no_contact_cache" = run every contact search in full
  * (no answer from the installed tables, no shared box list, count read back before the sort); "lazy_hessians" = 0: the Newton loop
  * keeps the double element-Hessian pool (default 1: float upper triangles, doubles recomputed for projected elements);
- * "lazy_eval" = staged mistark_eval calls take the lazy path too; "no_grad_gather" = gradient of the closed-form elements by atomics;
+ * "lazy_eval" = staged mistark_eval calls take the lazy path too; "no_grad_gather" = gradient by atomics in arrival order instead of
+ * the per-potential pools summed in list order;
  * "no_pattern_overlap" / "no_eval_overlap" / "no_bounded_pattern" = switch off, one by one, the side stream for the contact part's
  * pattern, the auxiliary stream for small potentials, the device-side counts of the pattern build; "fuse_dir" = direction update
  * inside the SpMV (measured slower, a cross-check); "kernel_dbg" = measurement switches inside kernels.
  * Returns 0, or < 0 for an unknown name. The environment variable
  * MISTARK_OPTIONS="name=value,name=value" applies the same switches inside mistark_create (for a process that cannot be
  * edited: a test suite, a profiler run); a bad entry makes mistark_create fail with -6. MISTARK_POISON=1 fills every fresh
- * device allocation with a NaN pattern (finds reads of memory nobody wrote; the GPU test suite passes with it). */
+ * device allocation with a NaN pattern (finds reads of memory nobody wrote; the GPU test suite passes with it).
+ * MISTARK_NEWTON_TRACE=1 prints one line per Newton iteration and linear solve on stderr (residual, CG iterations, tolerance,
+ * converged / indefinite, projection threshold, max |du|): what the reference prints at symx::Verbosity::Full. */
 int mistark_set_option(mistark_ctx* ctx, const char* name, int value);
 
 /* ---- timers ------------------------------------------------------------------------------------------------------- */
