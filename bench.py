@@ -96,7 +96,7 @@ def host_cpu():
     return model, (len(cores) or logical), logical
 
 
-def cpu_baseline(nx, ny, nz, scene="contact"):
+def cpu_baseline(nx, ny, nz, scene="contact", offset=(0.0, 0.0)):
     """The UNMODIFIED reference (oracle/_ref/ref_harness, built by oracle/Makefile) timed on this host's cores: once with one thread per
     physical core (capped at 64) and once with 8 threads (the figure SURVEY.md §8d asks for, comparable with the build container)."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
@@ -109,7 +109,8 @@ def cpu_baseline(nx, ny, nz, scene="contact"):
     name = "tetblock"
     if scene == "contact":
         name = "blockbox"
-        common += ["L=1", "gap=%g" % GAP, "thickness=%g" % THICKNESS, "mu=%g" % MU, "kmin=%g" % KMIN, "bx=%g" % BOX[0], "bz=%g" % BOX[2], "boxfirst=1"]
+        common += ["L=1", "gap=%g" % GAP, "thickness=%g" % THICKNESS, "mu=%g" % MU, "kmin=%g" % KMIN, "bx=%g" % BOX[0], "bz=%g" % BOX[2], "boxfirst=1",
+                   "ox=%.17g" % offset[0], "oy=%.17g" % offset[1]]
 
     def run(n_threads, steps):
         out = subprocess.run([harness, "time", name] + common + ["threads=%d" % n_threads, "steps=%d" % steps, "warmup=1"], check=True, capture_output=True, timeout=1500).stdout.decode()
@@ -181,8 +182,11 @@ def main():
     ap.add_argument("--grid", type=str, default="44,44,43", help="hexahedra per dimension (12 tets each)")
     ap.add_argument("--scene", type=str, default="contact", choices=["contact", "clamped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--offset", type=str, default="0,0", help="block moved off the box's axes by (ox, oy) metres: the placement on which the reference reproduces itself "
+                                                              "and the engine's Newton / solve / CG counts equal its log (DESIGN.md section 5); default: centred")
     a = ap.parse_args()
     nx, ny, nz = [int(v) for v in a.grid.split(",")]
+    offset = tuple(float(v) for v in a.offset.split(","))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -216,7 +220,7 @@ def main():
 
     # (MISTARK_BENCH_DEVICE: all ranks on one device — only to exercise the N > 1 launch path on a single-GPU box)
     device = int(os.environ.get("MISTARK_BENCH_DEVICE", local_rank))
-    sim = build_scene(S, nx, ny, nz, device, a.scene)
+    sim = build_scene(S, nx, ny, nz, device, a.scene, offset=offset)
     if world > 1:
         sim.set_dist_rccl(rank, world, uid)
     def barrier():
@@ -295,7 +299,7 @@ def main():
             "config": {
                 "workload": ("configs[3]: tet block generate_tet_grid{%d,%d,%d} = %d tets / %d DoF, Soft_Rubber stable Neo-Hookean (full EnergyTetStrain) + lumped "
                              "inertia on a fixed rigid box {3,3,0.1}, IPC barrier + lagged friction (thickness 1e-3, mu 0.5, kmin 1e8), device proximity/intersection "
-                             "detection every evaluation, gravity, dt=1/30, initial gap 1.5 mm" % (nx, ny, nz, n_tets, info.ndofs)) if a.scene == "contact" else
+                             "detection every evaluation, gravity, dt=1/30, initial gap 1.5 mm%s" % (nx, ny, nz, n_tets, info.ndofs, "" if offset == (0.0, 0.0) else ", block moved (%g, %g) m off the box's axes" % offset)) if a.scene == "contact" else
                             ("tet block generate_tet_grid{%d,%d,%d} = %d tets / %d DoF, Soft_Rubber, bottom face clamped, gravity, dt=1/30, NO contact" % (nx, ny, nz, n_tets, info.ndofs)),
                 "step": "one Newton iteration (contact detection, eval P+g+H, assembly, block-Jacobi PCG, intersection check, line search)",
                 "parallelism": "single GPU" if world == 1 else ("block rows partitioned over %d GPUs; every rank evaluates the elements touching its rows (interface elements on both sides) and assembles "
@@ -346,7 +350,7 @@ def main():
             },
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nx, ny, nz, a.scene)
+            out["cpu_baseline"] = cpu_baseline(nx, ny, nz, a.scene, offset)
         else:
             out["cpu_baseline"] = {"value": None, "unit": "Newton-steps/s", "cores": 0, "kind": "reference", "sample": "skipped (N>1 or --no-cpu-baseline)"}
         print(json.dumps(out))
