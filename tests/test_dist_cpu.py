@@ -189,7 +189,11 @@ def test_sharded_solve_equals_unsharded_gloo(name, tmp_path):
     import torch.multiprocessing as mp
 
     world = 2
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+
+    with socket.socket() as sock:   # a port the OS considers free right now (a fixed one can sit in TIME_WAIT from the previous test)
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     mp.spawn(_rank_main, args=(world, port, name, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
 
