@@ -332,7 +332,7 @@ def main():
                 "launches_timed": 100 if no_sample else (spmv_clk_n if spmv_clk_ms else spmv_n),
                 "timing": "HIP events around 100 back-to-back launches after the timed region (no sampled launch fell into it)" if no_sample else
                           ("device clock: every workgroup of a sampled launch (every 32nd SpMV of the timed region) stamps its start and end with s_memrealtime, "
-                           "duration = max(end) - min(start); agrees with rocprofv3's kernel trace of the same launches") if spmv_clk_ms else "HIP event bracket",
+                           "duration = max(end) - min(start); agrees with rocprofv3's kernel trace of the same launches" + ("" if world == 1 else "; rank 0's launches of the sharded solve")) if spmv_clk_ms else "HIP event bracket",
                 # the same launches bracketed by a pair of HIP events on the engine's stream (dispatch latency and the marker packets included)
                 "event_bracket_launch_ms": spmv_ms,
                 "event_bracket_launches": spmv_n,

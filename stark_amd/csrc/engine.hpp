@@ -360,6 +360,7 @@ struct Context
     DevBuf<double> grad_aux;  // gradient contributions of the potentials evaluated on the auxiliary stream (eval())
     std::vector<mistark_newton_iteration> newton_log;  // per-iteration records of the last newton_solve
     uint64_t* spmv_clk = nullptr;  // pinned: per-workgroup (start, end) of the sampled launches on the device's constant clock
+    uint64_t* spmv_clk_sharded = nullptr;  // the same for pcg_sharded (up to 64 samples per solve)
     double spmv_clk_ticks = 0.0;
     int64_t spmv_clk_n = 0;
 

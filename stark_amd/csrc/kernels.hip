@@ -3840,7 +3840,7 @@ static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, do
     PcgCtrl h{};
     int k = 1;
     bool finished = false;
-    std::vector<int> sampled_k;
+    std::vector<int> sampled_k, sampled_grid;
     while (!finished) {
         const int k_end = std::min(max_iter, k + PCG_CHECK - 1);
         for (; k <= k_end; k++) {
@@ -3854,11 +3854,18 @@ static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, do
                 }
                 MS_CHECK(hipEventRecord(c.ev[3 * sampled_k.size()], c.stream));
             }
-            const int gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false);
+            uint64_t* clk = nullptr;
+            if (sample) {  // (and on the device clock, as in pcg(): per-workgroup start / end stamps in pinned memory)
+                if (!c.spmv_clk_sharded) MS_CHECK(hipHostMalloc((void**)&c.spmv_clk_sharded, sizeof(uint64_t) * 64 * 2 * MAX_PARTIALS, hipHostMallocDefault));
+                clk = c.spmv_clk_sharded + sampled_k.size() * 2 * MAX_PARTIALS;
+                std::memset(clk, 0, sizeof(uint64_t) * 2 * MAX_PARTIALS);
+            }
+            const int gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false, clk);
             if (sample) {
                 MS_CHECK(hipEventRecord(c.ev[3 * sampled_k.size() + 1], c.stream));
                 MS_CHECK(hipEventRecord(c.ev[3 * sampled_k.size() + 2], c.stream));
                 sampled_k.push_back(k);
+                sampled_grid.push_back(gs);
             }
             hipLaunchKernelGGL(k_fold_partials, dim3(1), dim3(BLOCK), 0, c.stream, (const double*)part_pq, gs, (const double*)nullptr, 0, mine1);
             c.coll->allgather_f64(mine1, all1, 1, c.stream);
@@ -3881,6 +3888,18 @@ static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, do
             c.spmv_ms_sum += ms;
             c.spmv_empty_ms_sum += ms_empty;
             c.spmv_n++;
+        }
+        const uint64_t* clk = c.spmv_clk_sharded + i * 2 * MAX_PARTIALS;
+        uint64_t t0 = ~0ull, t1 = 0;
+        bool complete = true;
+        for (int b = 0; b < sampled_grid[i]; b++) {
+            if (clk[2 * b] == 0 || clk[2 * b + 1] == 0) { complete = false; break; }
+            t0 = std::min(t0, clk[2 * b]);
+            t1 = std::max(t1, clk[2 * b + 1]);
+        }
+        if (complete && t1 > t0) {
+            c.spmv_clk_ticks += (double)(t1 - t0);
+            c.spmv_clk_n++;
         }
     }
     shard_gather_global(c, c.xl.p, c.du.p);
@@ -4078,6 +4097,7 @@ Context::~Context()
     if (h_pin) (void)hipHostFree(h_pin);
     if (pub) (void)hipHostFree(pub);
     if (spmv_clk) (void)hipHostFree(spmv_clk);
+    if (spmv_clk_sharded) (void)hipHostFree(spmv_clk_sharded);
     if (aux_stream) {
         (void)hipStreamDestroy(aux_stream);
         for (auto& e : aux_ev)

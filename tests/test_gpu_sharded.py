@@ -291,3 +291,38 @@ def test_sharded_full_size_headline_scene():
         assert abs(cg - ref_cg) <= 0.05 * ref_cg + 5 * sum(ref_its)
         assert np.abs(x - ref_x).max() <= 1e-5
     assert all((r[2] == res[0][2]).all() and r[0] == res[0][0] and r[1] == res[0][1] for r in res)
+
+
+def test_sharded_pcg_samples_its_spmv_on_the_device_clock_too():
+    """bench.py --gpus N reads the roofline figure of rank 0's SpMV launches the same way as on one GPU: the sharded PCG brackets every 32nd
+    launch with HIP events AND lets its workgroups stamp the device clock. Two in-process ranks, solves forced to the iteration cap: the
+    sampling changes no bit of the solution, both figures are there, the clock's below the event bracket."""
+    import ctypes as C
+
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, "tetbeam_softrubber_6x2x2.npz"))
+    L = capi.lib()
+    group = L.mistark_local_group_create(2)
+
+    def rank_fn(r):
+        eng = engine_from_problem(prob, man)
+        eng.dist_init_local(group, r)
+        eng.eval(capi.EVAL_P_G_H)
+        eng.assemble()
+        du0, info0 = eng.pcg(1e-300, 1e-300, 100)
+        eng.spmv_timing(reset=1)
+        du, info = eng.pcg(1e-300, 1e-300, 100)
+        ms, n = C.c_double(), C.c_int64()
+        assert eng.L.mistark_spmv_device_clock(eng.h, C.byref(ms), C.byref(n)) == 0
+        ev_ms, ev_n, _ = eng.spmv_timing(reset=-1)
+        eng.close()
+        return (du0 == du).all(), info0.n_iterations, info.n_iterations, ms.value, n.value, ev_ms, ev_n
+
+    res = run_ranks(2, rank_fn)
+    L.mistark_local_group_destroy(group)
+    for same, it0, it1, clk_ms, clk_n, ev_ms, ev_n in res:
+        assert same and it0 == it1 >= 64
+        assert clk_n == ev_n == it1 // 32
+        assert 0.0 < clk_ms < ev_ms < 1.0
