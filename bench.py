@@ -207,6 +207,7 @@ def main():
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: gloo must not go looking for an interface through a hostname that may not resolve
         torch.cuda.set_device(int(os.environ.get("MISTARK_BENCH_DEVICE", local_rank)))
         dist.init_process_group(backend="gloo")
         box = [None]
