@@ -14,8 +14,9 @@ using namespace mistark;
     if (!ctx) return -1; \
     int _ret = 0;        \
     (void)_ret;          \
+    ::mistark::DryScope _dry(ctx->c.dry); \
     try {                \
-        (void)hipSetDevice(ctx->c.device); /* the current device is per host thread: contexts may be driven from any thread */
+        if (!ctx->c.dry) (void)hipSetDevice(ctx->c.device); /* the current device is per host thread: contexts may be driven from any thread */
 #define API_END(ret)                   \
     }                                  \
     catch (const std::exception& e)    \
@@ -155,8 +156,7 @@ int mistark_create(int device, mistark_ctx** out)
 int mistark_create_dry(mistark_ctx** out)
 {
     if (!out) return -1;
-    dry_mode() = true;  // (process-wide: device buffers of every context stay empty from here on)
-    mistark_ctx* ctx = new mistark_ctx();
+    mistark_ctx* ctx = new mistark_ctx();  // (Context::dry reaches DevBuf::ensure through the DryScope of every entry point)
     ctx->c.dry = true;
     *out = ctx;
     return 0;
@@ -176,8 +176,24 @@ int64_t mistark_describe(mistark_ctx* ctx, char* buf, int64_t cap)
 {
     if (!ctx) return -1;
     Context& c = ctx->c;
+    auto esc = [](const std::string& in) {  // JSON string escaping (labels and names are the caller's)
+        std::string out;
+        for (unsigned char ch : in) {
+            if (ch == '"' || ch == '\\') {
+                out += '\\';
+                out += (char)ch;
+            } else if (ch < 0x20) {
+                char b[8];
+                std::snprintf(b, sizeof b, "\\u%04x", ch);
+                out += b;
+            } else {
+                out += (char)ch;
+            }
+        }
+        return out;
+    };
     std::string o = "{\"dof_sets\":[";
-    for (size_t i = 0; i < c.dof_sets.size(); i++) o += std::string(i ? "," : "") + "{\"label\":\"" + c.dof_sets[i].label + "\",\"n\":" + std::to_string(c.dof_sets[i].n) + "}";
+    for (size_t i = 0; i < c.dof_sets.size(); i++) o += std::string(i ? "," : "") + "{\"label\":\"" + esc(c.dof_sets[i].label) + "\",\"n\":" + std::to_string(c.dof_sets[i].n) + "}";
     o += "],\"potentials\":[";
     std::vector<int> alias(c.arrays.size(), -1);
     int n_alias = 0;
@@ -187,13 +203,13 @@ int64_t mistark_describe(mistark_ctx* ctx, char* buf, int64_t cap)
         if (set < 0)
             for (size_t k = 0; k < c.dof_sets.size(); k++)
                 if (A.host && A.host == c.dof_sets[k].host) set = (int)k;
-        if (set >= 0) return "dof:" + c.dof_sets[(size_t)set].label;
+        if (set >= 0) return "dof:" + esc(c.dof_sets[(size_t)set].label);
         if (alias[(size_t)a] < 0) alias[(size_t)a] = n_alias++;
         return "a" + std::to_string(alias[(size_t)a]);
     };
     for (size_t i = 0; i < c.pots.size(); i++) {
         const Potential& P = c.pots[i];
-        o += std::string(i ? "," : "") + "{\"name\":\"" + P.name + "\",\"conn_stride\":" + std::to_string(P.conn_stride) + ",\"n_elem\":" + std::to_string(P.n_elem) +
+        o += std::string(i ? "," : "") + "{\"name\":\"" + esc(P.name) + "\",\"conn_stride\":" + std::to_string(P.conn_stride) + ",\"n_elem\":" + std::to_string(P.n_elem) +
              ",\"dynamic\":" + std::to_string(P.part) + ",\"bindings\":[";
         for (size_t b = 0; b < P.bindings.size(); b++) {
             const mistark_binding& B = P.bindings[b];
@@ -769,6 +785,9 @@ int mistark_shard_range(int64_t n, int rank, int world, int64_t* begin, int64_t*
 int mistark_partition_rows(int64_t n_block_rows, int world, int n_tables, const int32_t* const* rows, const int64_t* n_elem, const int32_t* nb, const uint8_t* hub, int32_t* owner_out)
 {
     if (n_block_rows <= 0 || world < 1 || n_tables < 0 || !owner_out) return -1;
+    if (n_tables > 0 && (!rows || !n_elem || !nb)) return -1;
+    for (int t = 0; t < n_tables; t++)
+        if (n_elem[t] < 0 || nb[t] <= 0 || (n_elem[t] > 0 && !rows[t])) return -1;
     try {
         std::vector<ElemTable> tables;
         for (int t = 0; t < n_tables; t++) tables.push_back(ElemTable{rows[t], n_elem[t], nb[t]});
@@ -887,6 +906,7 @@ int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n)
 {
     API_BEGIN
     Context& c = ctx->c;
+    if (!out && n > 0) throw Error("mistark_dist_info: null output");
     prepare(c);
     const int64_t v[6] = {c.world > 1 ? c.sh.n_own : c.nbr, c.world > 1 ? c.sh.n_ghost : 0, c.world > 1 ? c.sh.n_send : 0, (int64_t)c.n_elem_total, c.part[0].nnzb, c.part[1].nnzb};
     for (int i = 0; i < n && i < 6; i++) out[i] = v[i];
@@ -896,6 +916,7 @@ int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner)
 {
     API_BEGIN
     Context& c = ctx->c;
+    if (!owner) throw Error("mistark_dist_get_row_owner: null output");
     prepare(c);
     for (int64_t r = 0; r < c.nbr; r++) owner[r] = c.world > 1 ? c.sh.owner[(size_t)r] : 0;
     API_END(0)

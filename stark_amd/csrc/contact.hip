@@ -1393,6 +1393,7 @@ using namespace mistark;
 
 #define CAPI_BEGIN       \
     if (!ctx) return -1; \
+    ::mistark::DryScope _dry(ctx->c.dry); \
     try {
 #define CAPI_END(ret)                 \
     }                                 \

@@ -30,11 +30,22 @@ struct Error : std::runtime_error
 
 // Registration-only ("dry") contexts (mistark_create_dry): no GPU is touched, device buffers stay empty. Used to check on a machine without
 // a GPU what a caller registers (tests/test_shim_cpu.py: the reference's own classes through the SymX shim against the host mirror).
+// The flag is a property of the CONTEXT (Context::dry); every C-ABI entry point publishes its context's flag to the calling thread for the
+// duration of the call (DryScope), which is where DevBuf::ensure — that knows no context — reads it. A dry context therefore never changes
+// what a real context of the same process allocates.
 inline bool& dry_mode()
 {
-    static bool dry = false;
+    static thread_local bool dry = false;
     return dry;
 }
+struct DryScope
+{
+    bool prev;
+    explicit DryScope(bool dry) : prev(dry_mode()) { dry_mode() = dry; }
+    ~DryScope() { dry_mode() = prev; }
+    DryScope(const DryScope&) = delete;
+    DryScope& operator=(const DryScope&) = delete;
+};
 // Growable device buffer
 template <class T>
 struct DevBuf

@@ -397,6 +397,7 @@ int mistark_sim_attach_by_distance(mistark_sim* s, int set_0, int set_1, const i
                                    int32_t handlers_out[3])
 {
     SIM_BEGIN
+    if (n_points < 0 || n_triangles < 0 || (n_points > 0 && !pts) || (n_triangles > 0 && !tris) || !handlers_out) throw std::runtime_error("attach_by_distance: null array or negative size");
     const std::vector<int> points(pts, pts + n_points);
     std::vector<std::array<int, 3>> T((size_t)n_triangles);
     for (int64_t i = 0; i < n_triangles; i++) T[i] = {tris[3 * i], tris[3 * i + 1], tris[3 * i + 2]};
@@ -408,6 +409,8 @@ int mistark_sim_attach_rigid_body_by_distance(mistark_sim* s, int rb, int ps, co
                                               int64_t n_points, double distance, double k, double tol)
 {
     SIM_BEGIN
+    if (n_points < 0 || n_triangles < 0 || n_vertices < 0 || (n_points > 0 && !pts) || (n_triangles > 0 && !tris) || (n_vertices > 0 && !loc_vertices))
+        throw std::runtime_error("attach_rigid_body_by_distance: null array or negative size");
     const std::vector<int> points(pts, pts + n_points);
     std::vector<Vec3> V((size_t)n_vertices);
     for (int64_t i = 0; i < n_vertices; i++) V[i] = v3(loc_vertices + 3 * i);

@@ -695,7 +695,8 @@ static double* host_scratch(Context& c, size_t n)
 {
     if (c.h_scratch_n < n) {
         if (c.h_scratch) (void)hipHostFree(c.h_scratch);
-        MS_CHECK(hipHostMalloc((void**)&c.h_scratch, std::max<size_t>(n, 4096) * sizeof(double)));
+        // (coherent + mapped: pcg() watches a control slot in here that the device writes while kernels are still running)
+        MS_CHECK(hipHostMalloc((void**)&c.h_scratch, std::max<size_t>(n, 4096) * sizeof(double), hipHostMallocCoherent | hipHostMallocMapped));
         c.h_scratch_n = std::max<size_t>(n, 4096);
     }
     return c.h_scratch;
@@ -4062,9 +4063,29 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         } else {
             const volatile PcgCtrl* v = hs[slot];
             const double t_wait = now_seconds();
-            for (uint64_t spins = 0; !(v->epoch == epoch && (v->done || v->n_iter >= k_end_cur)); spins++) {
+            auto reported = [&] { return v->epoch == epoch && (v->done || v->n_iter >= k_end_cur); };
+            for (uint64_t spins = 0; !reported(); spins++) {
                 __builtin_ia32_pause();
-                if ((spins & 0xfffff) == 0xfffff && now_seconds() - t_wait > 60.0) throw Error("pcg: the device did not report batch " + std::to_string(k_end_cur) + " within 60 s");
+                if ((spins & 0xfffff) != 0xfffff) continue;
+                // now and then a real look at the stream, as publish() does: a failed launch surfaces as its error, and a stream that has
+                // drained without the slot being written (host memory the device's writes do not reach while kernels run) is answered from
+                // the device's own control block instead of a time-out
+                const hipError_t q = hipStreamQuery(c.stream);
+                if (q != hipErrorNotReady) {
+                    MS_CHECK(q);
+                    if (!reported()) {
+                        PcgCtrl dev{};
+                        MS_CHECK(hipMemcpy(&dev, c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost));
+                        hs[slot]->converged = dev.converged;
+                        hs[slot]->indef = dev.indef;
+                        hs[slot]->error = dev.error;
+                        hs[slot]->n_iter = dev.done ? dev.n_iter : k_end_cur;
+                        hs[slot]->done = dev.done ? 1 : 0;
+                        hs[slot]->epoch = epoch;
+                    }
+                    break;
+                }
+                if (now_seconds() - t_wait > 60.0) throw Error("pcg: the device did not report batch " + std::to_string(k_end_cur) + " within 60 s");
             }
             std::atomic_thread_fence(std::memory_order_acquire);
         }

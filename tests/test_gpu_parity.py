@@ -482,3 +482,35 @@ def test_connectivity_entry_outside_its_array_is_an_error_not_a_memory_fault():
         eng.eval(capi.EVAL_P_G_H)
     assert "EnergyTetStrain" in str(ei.value) and "element 3" in str(ei.value)
     eng.close()
+
+
+def test_a_registration_only_context_does_not_disable_device_buffers_of_real_ones():
+    """mistark_create_dry used to switch device allocation off for the whole process: a real context created afterwards ran
+    its kernels on null buffers. The flag belongs to the context now; a dry context alive beside a real one changes nothing."""
+    import ctypes as C
+
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    L = capi.lib()
+    dry = C.c_void_p()
+    assert L.mistark_create_dry(C.byref(dry)) == 0
+    v = np.zeros(12)
+    L.mistark_add_dof_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    assert L.mistark_add_dof_set(dry, b"soft.v1", v.ctypes.data, 12) >= 0
+    try:
+        prob, man, z = ev.load_fixture(os.path.join(GOLDEN, "tetbeam_eo_4x1x1.npz"))
+        eng = engine_from_problem(prob, man)
+        E, grad = eng.eval(capi.EVAL_P_G_H)
+        Eo, go, _ = ev.evaluate_all(prob)
+        assert abs(E - Eo) <= 1e-11 * abs(Eo)
+        assert np.abs(grad - go).max() <= 1e-11 * np.abs(go).max()
+        # ... and the dry one still refuses to evaluate
+        L.mistark_eval.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        e = C.c_double()
+        assert L.mistark_eval(dry, capi.EVAL_P, C.byref(e), None) != 0
+        E2, _ = eng.eval(capi.EVAL_P_G_H)
+        assert E2 == E
+        eng.close()
+    finally:
+        L.mistark_destroy(dry)
