@@ -198,9 +198,16 @@ def main():
 
     dist = None
     uid = None
+    comm = None
+    transport = None
+    ipc_selftest_us = None
+    # (MISTARK_BENCH_DEVICE: all ranks on one device — only to exercise the N > 1 launch path on a single-GPU box)
+    device = int(os.environ.get("MISTARK_BENCH_DEVICE", local_rank))
     if world > 1:
-        # torch.distributed (gloo) only launches / synchronises the ranks and carries the 128-byte RCCL id; the exchanges of the path
-        # (ncclAllGather of boundary values, dot products and energies) are issued by the engine itself on its HIP stream (stark_amd/csrc/dist.hip)
+        # torch.distributed (gloo) only launches / synchronises the ranks and carries the transport's bootstrap data (64-byte window handles, or
+        # the 128-byte RCCL id); the exchanges of the path (boundary values, dot products, energies) are issued by the engine itself on its
+        # HIP stream (stark_amd/csrc/dist.hip): stores into the peers' IPC windows (default), or ncclAllGather (MISTARK_BENCH_TRANSPORT=rccl,
+        # and the fallback when the windows cannot be set up — RCCL needs one device per rank)
         import ctypes as C
 
         import torch.distributed as dist_mod
@@ -208,22 +215,44 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: gloo must not go looking for an interface through a hostname that may not resolve
-        torch.cuda.set_device(int(os.environ.get("MISTARK_BENCH_DEVICE", local_rank)))
+        torch.cuda.set_device(device)
         dist.init_process_group(backend="gloo")
-        box = [None]
-        if rank == 0:
-            buf = C.create_string_buffer(128)
-            if capi.lib().mistark_dist_unique_id(buf) != 0:
-                raise RuntimeError("ncclGetUniqueId failed")
-            box[0] = buf.raw
-        dist.broadcast_object_list(box, src=0)
-        uid = box[0]
 
-    # (MISTARK_BENCH_DEVICE: all ranks on one device — only to exercise the N > 1 launch path on a single-GPU box)
-    device = int(os.environ.get("MISTARK_BENCH_DEVICE", local_rank))
+        def allgather_bytes(b):
+            out = [None] * world
+            dist.all_gather_object(out, b)
+            return out
+
+        transport = os.environ.get("MISTARK_BENCH_TRANSPORT", "ipc")
+        if transport == "ipc":
+            err = None
+            try:
+                n_rows = (nx + 1) * (ny + 1) * (nz + 1) + nx * ny * nz + 64
+                comm = capi.IpcComm(device, rank, world, max(64 * 3 * n_rows, 32 << 20), allgather_bytes)
+                ipc_selftest_us = comm.selftest(1024, 50)
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+            errs = allgather_bytes(err)
+            if any(errs):
+                if rank == 0:
+                    print("bench: IPC windows unavailable (%s); falling back to RCCL" % [e for e in errs if e][0], file=sys.stderr)
+                comm, transport = None, "rccl"
+        if transport == "rccl":
+            box = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(128)
+                if capi.lib().mistark_dist_unique_id(buf) != 0:
+                    raise RuntimeError("ncclGetUniqueId failed")
+                box[0] = buf.raw
+            dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+
     sim = build_scene(S, nx, ny, nz, device, a.scene, offset=offset)
     if world > 1:
-        sim.set_dist_rccl(rank, world, uid)
+        if comm is not None:
+            sim.set_dist_ipc(comm, rank, world)
+        else:
+            sim.set_dist_rccl(rank, world, uid)
     def barrier():
         if dist is not None:
             dist.barrier()
@@ -304,8 +333,14 @@ def main():
                             ("tet block generate_tet_grid{%d,%d,%d} = %d tets / %d DoF, Soft_Rubber, bottom face clamped, gravity, dt=1/30, NO contact" % (nx, ny, nz, n_tets, info.ndofs)),
                 "step": "one Newton iteration (contact detection, eval P+g+H, assembly, block-Jacobi PCG, intersection check, line search)",
                 "parallelism": "single GPU" if world == 1 else ("block rows partitioned over %d GPUs; every rank evaluates the elements touching its rows (interface elements on both sides) and assembles "
-                                                                   "and solves its rows: row-sharded block-Jacobi PCG, ghosts of p and the dot products exchanged by ncclAllGather (RCCL over xGMI) "
-                                                                   "in every iteration; state, line search and contact detection replicated" % world),
+                                                                   "and solves its rows: row-sharded block-Jacobi PCG, ghosts of p and the dot products exchanged %s "
+                                                                   "in every iteration; state, line search and contact detection replicated" %
+                                                                   (world, "by stores into the peers' IPC windows (hipIpc; 8-byte tagged granules, no library call)" if transport == "ipc" else "by ncclAllGather (RCCL over xGMI)")),
+                "transport": transport,
+                # wall time of one all-gather of 1024 doubles through the windows on an idle stream (push kernel + polling kernel + the host's
+                # stream synchronisation), measured by the transport's self-test before the scene is built
+                "ipc_allgather_1024_doubles_us": ipc_selftest_us,
+                "ranks_on_one_device": bool(os.environ.get("MISTARK_BENCH_DEVICE")) if world > 1 else None,
                 "projection": "Progressive",
             },
             "ms_per_linear_solve": 1000.0 * t_ls / max(n_ls, 1),
@@ -357,6 +392,9 @@ def main():
         print(json.dumps(out))
     sim.close()
     if dist is not None:
+        dist.barrier()  # (nobody unmaps a window another rank may still be storing into)
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

@@ -319,7 +319,8 @@ int mistark_sync(mistark_ctx* ctx);
  * traffic), assembles and solves ITS rows of the system (block-Jacobi PCG on a row-sharded matrix: the ghosts of the search direction
  * from their owners and the three dot products of solve_pcg.h:180,201,217 are exchanged in every iteration, (r.r, r.z) fused), and
  * holds the whole state (DoFs, bound arrays, contact tables), so every rank runs the same host code and takes the same decisions.
- * All exchanges are all-gathers on the engine's stream: ncclAllGather over xGMI (RCCL), or a copy kernel for ranks inside one process.
+ * All exchanges are all-gathers on the engine's stream: stores into IPC windows of the peers (below), ncclAllGather over xGMI (RCCL), or a copy
+ * kernel for ranks inside one process.
  * Reductions are done by every rank in rank order: identical bits everywhere. Call right after mistark_create, before the first
  * evaluation. With N ranks mistark_get_bsr / mistark_apply_preconditioner are not available (single-rank accessors). */
 int mistark_shard_range(int64_t n, int rank, int world, int64_t* begin, int64_t* end); /* [n*rank/world, n*(rank+1)/world) */
@@ -349,6 +350,26 @@ int mistark_dist_add_shared_rows(mistark_ctx* ctx, const int32_t* rows, int64_t 
 /* out[0..6): block rows owned by this rank, ghosts, rows it sends, elements it evaluates, blocks of its static / contact matrix part */
 int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n);
 int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner);
+/* ---- IPC windows: one process per rank, no library in the data path -----------------------------------------------------------------
+ * Every rank owns a window of device memory that the other ranks map with hipIpcOpenMemHandle (the peers' GPUs through the xGMI aperture,
+ * or the same GPU when several ranks share one device — how a one-GPU box runs the real multi-process launch path). An exchange is: the
+ * producing kernel stores its values into every rank's window as 8-byte {sequence tag, 32 data bits} granules (system-scope write-through
+ * stores), the consuming kernel polls its own window until the granules carry the tag. No host involvement, no library launch, no separate
+ * flag: one exchange costs the one-way store latency. Waits are bounded (MISTARK_IPC_TIMEOUT_S, default 30 s): a peer that never delivers
+ * turns into an error at the host's next synchronisation point instead of a hung GPU.
+ *   create (allocates and zeroes the window; `handle_out` = its 64-byte hipIpcMemHandle_t)  ->  the launcher all-gathers the handles (bench.py:
+ *   torch.distributed / gloo)  ->  connect (handles of all ranks in rank order, n_bytes = world * 64)  ->  mistark_dist_init_ipc(ctx, comm).
+ * window_bytes: at least 48 bytes per DoF of the largest problem (smaller messages than a slot travel in one piece, longer ones in several);
+ * 0 = the minimum. The communicator must outlive the contexts using it. */
+typedef struct mistark_ipc_comm mistark_ipc_comm;
+mistark_ipc_comm* mistark_ipc_comm_create(int device, int rank, int world, int64_t window_bytes, char handle_out[64]);
+int mistark_ipc_comm_connect(mistark_ipc_comm* comm, const char* handles, int64_t n_bytes);
+const char* mistark_ipc_comm_last_error(mistark_ipc_comm* comm);
+void mistark_ipc_comm_destroy(mistark_ipc_comm* comm);
+int mistark_dist_init_ipc(mistark_ctx* ctx, mistark_ipc_comm* comm);
+/* `iters` all-gathers of n doubles with predictable values, every received value checked; avg_us = wall time of one exchange on an idle
+ * stream. Collective: every rank calls it with the same arguments. */
+int mistark_ipc_comm_selftest(mistark_ipc_comm* comm, int64_t n, int iters, double* avg_us);
 /* the same sharded path with several contexts inside one process (one host thread per context, one device, one shared stream), used by
  * the single-GPU tests */
 typedef struct mistark_local_group mistark_local_group;

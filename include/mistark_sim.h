@@ -177,6 +177,7 @@ int mistark_sim_get_contact_info(mistark_sim* sim, double* contact_stiffness, in
 /* multi-GPU sharding (mistark.h): every rank builds the same scene, then one of these before the first step */
 int mistark_sim_set_dist_rccl(mistark_sim* sim, int rank, int world, const char unique_id[128]);
 int mistark_sim_set_dist_local(mistark_sim* sim, mistark_local_group* group, int rank, int world);
+int mistark_sim_set_dist_ipc(mistark_sim* sim, mistark_ipc_comm* comm, int rank, int world);  /* a connected communicator (mistark.h "IPC windows") */
 
 /* Replace the Newton settings used by the following steps (stark::core::Settings::newton). */
 int mistark_sim_set_newton_settings(mistark_sim* sim, const mistark_newton_settings* s);

@@ -139,6 +139,15 @@ def lib():
     L.mistark_local_group_destroy.argtypes = [p]
     L.mistark_local_group_destroy.restype = None
     L.mistark_dist_init_local.argtypes = [p, p, C.c_int]
+    L.mistark_ipc_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, i64, p]
+    L.mistark_ipc_comm_create.restype = p
+    L.mistark_ipc_comm_connect.argtypes = [p, p, i64]
+    L.mistark_ipc_comm_last_error.argtypes = [p]
+    L.mistark_ipc_comm_last_error.restype = C.c_char_p
+    L.mistark_ipc_comm_destroy.argtypes = [p]
+    L.mistark_ipc_comm_destroy.restype = None
+    L.mistark_ipc_comm_selftest.argtypes = [p, i64, C.c_int, C.POINTER(dbl)]
+    L.mistark_dist_init_ipc.argtypes = [p, p]
     L.mistark_dist_set_row_owner.argtypes = [p, p, i64]
     L.mistark_dist_add_shared_rows.argtypes = [p, p, i64]
     L.mistark_dist_set_row_coords.argtypes = [p, p, i64]
@@ -166,6 +175,37 @@ def lib():
     L.mistark_spmv_timing.argtypes = [p, C.c_int, C.POINTER(dbl), C.POINTER(i64), C.POINTER(dbl)]
     _lib = L
     return L
+
+
+class IpcComm:
+    """One rank's end of the IPC-window transport (include/mistark.h "IPC windows"): create -> all-gather the 64-byte handles through the
+    launcher -> connect. `allgather_bytes(b)` must return the list of every rank's bytes in rank order (torch.distributed.all_gather_object)."""
+
+    def __init__(self, device, rank, world, window_bytes, allgather_bytes):
+        L = lib()
+        buf = C.create_string_buffer(64)
+        self.h = L.mistark_ipc_comm_create(device, rank, world, int(window_bytes), buf)
+        if not self.h:
+            raise RuntimeError("mistark_ipc_comm_create failed (rank %d)" % rank)
+        self.rank, self.world = rank, world
+        handles = allgather_bytes(buf.raw)
+        if len(handles) != world or any(len(x) != 64 for x in handles):
+            raise RuntimeError("IPC handles: expected %d x 64 bytes" % world)
+        blob = b"".join(handles)
+        if L.mistark_ipc_comm_connect(self.h, blob, len(blob)) != 0:
+            raise RuntimeError("mistark_ipc_comm_connect: %s" % L.mistark_ipc_comm_last_error(self.h).decode())
+
+    def selftest(self, n=1024, iters=20):
+        """Collective. Returns the average wall time of one all-gather of n doubles in microseconds (every value checked)."""
+        us = C.c_double()
+        if lib().mistark_ipc_comm_selftest(self.h, n, iters, C.byref(us)) != 0:
+            raise RuntimeError("IPC self-test: %s" % lib().mistark_ipc_comm_last_error(self.h).decode())
+        return us.value
+
+    def close(self):
+        if self.h:
+            lib().mistark_ipc_comm_destroy(self.h)
+            self.h = None
 
 
 def exported_symbols():

@@ -1,5 +1,6 @@
 // api.cpp — extern "C" entry points of libmistark.so (see include/mistark.h for the contract and reference citations).
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <cstdio>
 #include <cstdlib>
@@ -920,6 +921,92 @@ int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner)
     prepare(c);
     for (int64_t r = 0; r < c.nbr; r++) owner[r] = c.world > 1 ? c.sh.owner[(size_t)r] : 0;
     API_END(0)
+}
+// ---- IPC windows: one process per rank, exchanges by stores into the peers' windows (dist.hip) ----
+struct mistark_ipc_comm
+{
+    std::shared_ptr<IpcComm> m;
+    std::string last_error;
+};
+mistark_ipc_comm* mistark_ipc_comm_create(int device, int rank, int world, int64_t window_bytes, char handle_out[64])
+{
+    if (!handle_out) return nullptr;
+    try {
+        auto* h = new mistark_ipc_comm();
+        try {
+            h->m = ipc_comm_create(device, rank, world, (size_t)std::max<int64_t>(window_bytes, 0), handle_out);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "mistark_ipc_comm_create: %s\n", e.what());
+            delete h;
+            return nullptr;
+        }
+        return h;
+    } catch (...) {
+        return nullptr;
+    }
+}
+int mistark_ipc_comm_connect(mistark_ipc_comm* comm, const char* handles, int64_t n_bytes)
+{
+    if (!comm || !comm->m) return -1;
+    try {
+        if (!handles || n_bytes != (int64_t)ipc_comm_world(*comm->m) * 64) throw Error("mistark_ipc_comm_connect: world x 64 bytes of handles, in rank order");
+        ipc_comm_connect(*comm->m, handles);
+    } catch (const std::exception& e) {
+        comm->last_error = e.what();
+        return -1;
+    }
+    return 0;
+}
+const char* mistark_ipc_comm_last_error(mistark_ipc_comm* comm) { return comm ? comm->last_error.c_str() : "null communicator"; }
+void mistark_ipc_comm_destroy(mistark_ipc_comm* comm) { delete comm; }
+int mistark_dist_init_ipc(mistark_ctx* ctx, mistark_ipc_comm* comm)
+{
+    API_BEGIN
+    if (!comm || !comm->m) throw Error("null communicator");
+    if (ipc_comm_device(*comm->m) != ctx->c.device) throw Error("mistark_dist_init_ipc: the communicator's window lives on another device than the context");
+    set_dist(ctx->c, ipc_comm_rank(*comm->m), ipc_comm_world(*comm->m), ipc_comm_world(*comm->m) > 1 ? make_ipc_collective(comm->m) : nullptr);
+    API_END(0)
+}
+// `iters` all-gathers of n doubles with values every rank can predict, checked on the device's results; the average wall time of one
+// exchange (push + wait on a stream that is otherwise idle) in microseconds. Every rank must call it with the same arguments.
+int mistark_ipc_comm_selftest(mistark_ipc_comm* comm, int64_t n, int iters, double* avg_us)
+{
+    if (!comm || !comm->m || n <= 0 || iters <= 0) return -1;
+    try {
+        IpcComm& m = *comm->m;
+        const int W = ipc_comm_world(m), me = ipc_comm_rank(m);
+        MS_CHECK(hipSetDevice(ipc_comm_device(m)));
+        std::unique_ptr<Collective> coll = make_ipc_collective(comm->m);
+        hipStream_t s;
+        MS_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        DevBuf<double> send, recv;
+        send.ensure((size_t)n);
+        recv.ensure((size_t)n * (size_t)W);
+        std::vector<double> h((size_t)n), out((size_t)n * (size_t)W);
+        double total = 0.0;
+        for (int it = 0; it < iters; it++) {
+            for (int64_t i = 0; i < n; i++) h[(size_t)i] = 1e6 * me + 1e3 * it + (double)i + 0.25;
+            MS_CHECK(hipMemcpyAsync(send.p, h.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, s));
+            MS_CHECK(hipStreamSynchronize(s));
+            const auto t0 = std::chrono::steady_clock::now();
+            coll->allgather_f64(send.p, recv.p, (size_t)n, s);
+            MS_CHECK(hipStreamSynchronize(s));
+            total += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            coll->check();
+            MS_CHECK(hipMemcpy(out.data(), recv.p, out.size() * sizeof(double), hipMemcpyDeviceToHost));
+            for (int r = 0; r < W; r++)
+                for (int64_t i = 0; i < n; i++)
+                    if (out[(size_t)r * (size_t)n + (size_t)i] != 1e6 * r + 1e3 * it + (double)i + 0.25)
+                        throw Error("IPC self-test: rank " + std::to_string(me) + " received a wrong value from rank " + std::to_string(r) + " (exchange " + std::to_string(it) + ", entry " +
+                                    std::to_string(i) + ")");
+        }
+        (void)hipStreamDestroy(s);
+        if (avg_us) *avg_us = 1e6 * total / iters;
+    } catch (const std::exception& e) {
+        comm->last_error = e.what();
+        return -1;
+    }
+    return 0;
 }
 mistark_local_group* mistark_local_group_create(int world)
 {

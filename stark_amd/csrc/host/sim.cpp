@@ -46,6 +46,7 @@ void Stark::ensure_registered()
     } else if (settings.execution.world > 1) {
         const auto& ex = settings.execution;
         if (ex.local_group) check(mistark_dist_init_local(ctx, ex.local_group, ex.rank));
+        else if (ex.ipc_comm) check(mistark_dist_init_ipc(ctx, ex.ipc_comm));
         else if (ex.rccl_unique_id.size() == 128) check(mistark_dist_init_rccl(ctx, ex.rank, ex.world, ex.rccl_unique_id.data()));
         else throw std::runtime_error("multi-GPU run without a communicator id");
     }

@@ -59,6 +59,7 @@ struct Settings
         int rank = 0, world = 1;
         std::string rccl_unique_id;        // 128 bytes from mistark_dist_unique_id (rank 0), shared by the launcher
         mistark_local_group* local_group = nullptr;  // in-process group instead of RCCL (tests)
+        mistark_ipc_comm* ipc_comm = nullptr;        // IPC windows instead of RCCL (mistark.h "IPC windows")
     } execution;
     Settings() { mistark_newton_default_settings(&newton); }
 };

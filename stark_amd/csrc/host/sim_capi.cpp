@@ -667,6 +667,7 @@ int mistark_sim_set_dist_rccl(mistark_sim* s, int rank, int world, const char un
     ex.world = world;
     ex.rccl_unique_id.assign(unique_id, unique_id + 128);
     ex.local_group = nullptr;
+    ex.ipc_comm = nullptr;
     s->sim->get_stark().mark_registration_dirty();
     SIM_END
 }
@@ -677,6 +678,18 @@ int mistark_sim_set_dist_local(mistark_sim* s, mistark_local_group* group, int r
     ex.rank = rank;
     ex.world = world;
     ex.local_group = group;
+    s->sim->get_stark().mark_registration_dirty();
+    SIM_END
+}
+int mistark_sim_set_dist_ipc(mistark_sim* s, mistark_ipc_comm* comm, int rank, int world)
+{
+    SIM_BEGIN
+    if (!comm) throw std::runtime_error("set_dist_ipc: null communicator");
+    auto& ex = s->sim->get_stark().settings.execution;
+    ex.rank = rank;
+    ex.world = world;
+    ex.local_group = nullptr;
+    ex.ipc_comm = comm;
     s->sim->get_stark().mark_registration_dirty();
     SIM_END
 }

@@ -743,7 +743,10 @@ static bool publish(Context& c, void* dst_host, const void* src_dev, size_t byte
 void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes)
 {
     if (bytes == 0) return;
-    if (publish(c, dst_host, src_dev, bytes)) return;
+    if (publish(c, dst_host, src_dev, bytes)) {
+        if (c.coll) c.coll->check();  // (a bounded wait of an exchange that gave up: an error, not NaNs travelling on)
+        return;
+    }
     if (c.h_pin_bytes < bytes) {
         if (c.h_pin) (void)hipHostFree(c.h_pin);
         c.h_pin_bytes = std::max<size_t>(bytes, 1 << 16);
@@ -752,6 +755,7 @@ void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes)
     MS_CHECK(hipMemcpyAsync(c.h_pin, src_dev, bytes, hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
     std::memcpy(dst_host, c.h_pin, bytes);
+    if (c.coll) c.coll->check();
 }
 static void fetch_partials(Context& c, int n, double* out_host, const double* part_dev)
 {

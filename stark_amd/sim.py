@@ -125,6 +125,7 @@ def _lib():
         L.mistark_sim_disable_collision.argtypes = [p, C.c_int, C.c_int]
         L.mistark_sim_set_dist_rccl.argtypes = [p, C.c_int, C.c_int, p]
         L.mistark_sim_set_dist_local.argtypes = [p, p, C.c_int, C.c_int]
+        L.mistark_sim_set_dist_ipc.argtypes = [p, p, C.c_int, C.c_int]
         L.mistark_sim_get_contact_info.argtypes = [p, D, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _bound = True
     return L
@@ -382,6 +383,11 @@ class Simulation:
 
     def set_dist_local(self, group, rank, world):
         self._ck(self.L.mistark_sim_set_dist_local(self.h, group, rank, world))
+
+    def set_dist_ipc(self, comm, rank, world):
+        """comm: a connected capi.IpcComm (IPC windows, one process per rank; include/mistark.h)."""
+        self._comm = comm  # (must outlive the engine)
+        self._ck(self.L.mistark_sim_set_dist_ipc(self.h, comm.h, rank, world))
 
     # ---- frictional contact ----------------------------------------------------------------------------------------------
     def set_contact_global_params(self, p: ContactGlobalParams):
