@@ -229,7 +229,7 @@ def main():
             try:
                 n_rows = (nx + 1) * (ny + 1) * (nz + 1) + nx * ny * nz + 64
                 comm = capi.IpcComm(device, rank, world, max(64 * 3 * n_rows, 32 << 20), allgather_bytes)
-                ipc_selftest_us = comm.selftest(1024, 50)
+                ipc_selftest_us = comm.selftest(1024, 50)[1]
             except Exception as e:  # noqa: BLE001
                 err = repr(e)
             errs = allgather_bytes(err)
@@ -258,6 +258,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1 and os.environ.get("MISTARK_BENCH_DEVICE") is not None:
+        # all ranks on ONE device (test boxes): kernels that poll for a peer's data hold their workgroup slots, so the ranks' SpMV grids
+        # together must leave room for the kernels they are waiting for (2048 resident 256-thread workgroups per MI355X)
+        sim.prepare()
+        if capi.lib().mistark_set_option(sim.engine_handle(), b"spmv_grid_cap", max(8, (1024 // world) // 8 * 8)) != 0:
+            raise RuntimeError("spmv_grid_cap")
     # warm-up (includes sparsity-pattern construction and first-touch allocations)
     if a.warmup > 0:
         run_newton_steps(sim, S, capi, a.warmup)
@@ -291,6 +297,26 @@ def main():
     if capi.lib().mistark_spmv_device_clock(sim.engine_handle(), _C0.byref(_clk_ms), _C0.byref(_clk_n)) == 0 and _clk_n.value > 0:
         spmv_clk_ms, spmv_clk_n = _clk_ms.value, _clk_n.value
     spmv_ms, spmv_n, spmv_bytes = sim.spmv_timing(reset=-1)
+    # N > 1 over windows: solo durations of the fused PCG iteration's two kernels on every rank's rows (the ranks take turns: valid on a box
+    # where all ranks share one GPU, too)
+    fused_kernels_us = None
+    if world > 1 and comm is not None:
+        import ctypes as _C1
+        mine = None
+        capi.lib().mistark_set_option(sim.engine_handle(), b"spmv_grid_cap", 0)  # (a rank measuring alone needs no cap: the grid a GPU of its own would get)
+        for turn in range(world):  # one rank at a time, the others idle on the host: solo kernel durations
+            if turn == rank:
+                buf = (_C1.c_double * 3)()
+                if capi.lib().mistark_dist_fused_bench(sim.engine_handle(), 200, buf) == 0:
+                    mine = [round(buf[i], 2) for i in range(3)]
+                else:
+                    mine = capi.lib().mistark_last_error(sim.engine_handle()).decode()
+            dist.barrier()
+        every = allgather_bytes(mine)
+        if all(isinstance(v, list) for v in every):
+            fused_kernels_us = {"spmv_with_halo": [v[0] for v in every], "reduce_and_push": [v[1] for v in every], "vector_kernel": [v[2] for v in every]}
+        else:
+            fused_kernels_us = {"unavailable": [v for v in every if not isinstance(v, list)][0]}
     spmv_b2b_ms = None
     if rank == 0:
         import ctypes as _C
@@ -337,8 +363,8 @@ def main():
                                                                    "in every iteration; state, line search and contact detection replicated" %
                                                                    (world, "by stores into the peers' IPC windows (hipIpc; 8-byte tagged granules, no library call)" if transport == "ipc" else "by ncclAllGather (RCCL over xGMI)")),
                 "transport": transport,
-                # wall time of one all-gather of 1024 doubles through the windows on an idle stream (push kernel + polling kernel + the host's
-                # stream synchronisation), measured by the transport's self-test before the scene is built
+                # wall time of one all-gather of 1024 doubles through the windows in a train of 50 enqueued back to back (push kernel + polling
+                # kernel: two boundaries, the one-way latency and the ranks' skew), measured by the transport's self-test before the scene is built
                 "ipc_allgather_1024_doubles_us": ipc_selftest_us,
                 "ranks_on_one_device": bool(os.environ.get("MISTARK_BENCH_DEVICE")) if world > 1 else None,
                 "projection": "Progressive",
@@ -346,6 +372,11 @@ def main():
             "ms_per_linear_solve": 1000.0 * t_ls / max(n_ls, 1),
             "cg_iterations_per_solve": n_cg / max(n_ls, 1),
             "linear_solves": n_ls,
+            "cg_iterations": n_cg,
+            # N > 1: what ONE CG iteration costs a rank in kernels (solo, microseconds, per rank): the iteration is these three launches, with one
+            # exposed wait (the vector kernel's for the slowest rank's reduction) and the halo hidden behind the SpMV's interior rows
+            "sharded_cg_kernels_us": fused_kernels_us,
+            "newton_iterations": newton,
             "host_timers_s": {k: round(v, 6) for k, v in stage.items()},
             "contact": sim.contact_info() if a.scene == "contact" else None,
             "roofline": {

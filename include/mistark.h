@@ -347,7 +347,8 @@ int mistark_dist_set_row_coords(mistark_ctx* ctx, const double* xyz, int64_t n_b
 /* Block rows that potentials with device-side connectivity may reference on any rank; every rank keeps them as ghosts. The contact system
  * registers the collision vertices of its deformable meshes itself; small DoF sets (rigid bodies) are always shared. */
 int mistark_dist_add_shared_rows(mistark_ctx* ctx, const int32_t* rows, int64_t n);
-/* out[0..6): block rows owned by this rank, ghosts, rows it sends, elements it evaluates, blocks of its static / contact matrix part */
+/* out[0..8): block rows owned by this rank, ghosts, rows it sends, elements it evaluates, blocks of its static / contact matrix part, linear
+ * solves that took the fused iteration (one exposed exchange, ranks exchanging through windows) and the five-launch one */
 int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n);
 int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner);
 /* ---- IPC windows: one process per rank, no library in the data path -----------------------------------------------------------------
@@ -367,9 +368,15 @@ int mistark_ipc_comm_connect(mistark_ipc_comm* comm, const char* handles, int64_
 const char* mistark_ipc_comm_last_error(mistark_ipc_comm* comm);
 void mistark_ipc_comm_destroy(mistark_ipc_comm* comm);
 int mistark_dist_init_ipc(mistark_ctx* ctx, mistark_ipc_comm* comm);
-/* `iters` all-gathers of n doubles with predictable values, every received value checked; avg_us = wall time of one exchange on an idle
- * stream. Collective: every rank calls it with the same arguments. */
-int mistark_ipc_comm_selftest(mistark_ipc_comm* comm, int64_t n, int iters, double* avg_us);
+/* `iters` all-gathers of n doubles with predictable values, every received value checked; avg_us[0] = wall time of one exchange + stream
+ * synchronisation, avg_us[1] = of one exchange in a train enqueued back to back. Collective: every rank calls it with the same arguments. */
+int mistark_ipc_comm_selftest(mistark_ipc_comm* comm, int64_t n, int iters, double avg_us[2]);
+/* Measurement: solo durations (microseconds) of the three kernels of the fused PCG iteration on THIS rank's rows — out[0] = the SpMV with its
+ * halo polls, out[1] = the one-workgroup reduction that pushes the rank's three sums, out[2] = the vector kernel — replayed from the rank's
+ * last converged solve on the messages still in its window (every poll answered at once). Not a collective: the caller lets the ranks take
+ * turns (a host barrier between them), so the figures are kernels running alone even when all ranks share one GPU; no rank may start a solve
+ * in between. Needs ranks that exchange through windows and a converged solve on the current matrix. */
+int mistark_dist_fused_bench(mistark_ctx* ctx, int n_launches, double* out);
 /* the same sharded path with several contexts inside one process (one host thread per context, one device, one shared stream), used by
  * the single-GPU tests */
 typedef struct mistark_local_group mistark_local_group;

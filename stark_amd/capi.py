@@ -146,8 +146,9 @@ def lib():
     L.mistark_ipc_comm_last_error.restype = C.c_char_p
     L.mistark_ipc_comm_destroy.argtypes = [p]
     L.mistark_ipc_comm_destroy.restype = None
-    L.mistark_ipc_comm_selftest.argtypes = [p, i64, C.c_int, C.POINTER(dbl)]
+    L.mistark_ipc_comm_selftest.argtypes = [p, i64, C.c_int, C.POINTER(dbl)]  # double[2]
     L.mistark_dist_init_ipc.argtypes = [p, p]
+    L.mistark_dist_fused_bench.argtypes = [p, C.c_int, C.POINTER(dbl)]
     L.mistark_dist_set_row_owner.argtypes = [p, p, i64]
     L.mistark_dist_add_shared_rows.argtypes = [p, p, i64]
     L.mistark_dist_set_row_coords.argtypes = [p, p, i64]
@@ -196,11 +197,12 @@ class IpcComm:
             raise RuntimeError("mistark_ipc_comm_connect: %s" % L.mistark_ipc_comm_last_error(self.h).decode())
 
     def selftest(self, n=1024, iters=20):
-        """Collective. Returns the average wall time of one all-gather of n doubles in microseconds (every value checked)."""
-        us = C.c_double()
-        if lib().mistark_ipc_comm_selftest(self.h, n, iters, C.byref(us)) != 0:
+        """Collective. Every value checked; returns (wall time of one all-gather of n doubles + stream synchronisation, of one all-gather in a
+        train enqueued back to back) in microseconds."""
+        us = (C.c_double * 2)()
+        if lib().mistark_ipc_comm_selftest(self.h, n, iters, us) != 0:
             raise RuntimeError("IPC self-test: %s" % lib().mistark_ipc_comm_last_error(self.h).decode())
-        return us.value
+        return us[0], us[1]
 
     def close(self):
         if self.h:

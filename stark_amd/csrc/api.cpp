@@ -909,8 +909,9 @@ int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n)
     Context& c = ctx->c;
     if (!out && n > 0) throw Error("mistark_dist_info: null output");
     prepare(c);
-    const int64_t v[6] = {c.world > 1 ? c.sh.n_own : c.nbr, c.world > 1 ? c.sh.n_ghost : 0, c.world > 1 ? c.sh.n_send : 0, (int64_t)c.n_elem_total, c.part[0].nnzb, c.part[1].nnzb};
-    for (int i = 0; i < n && i < 6; i++) out[i] = v[i];
+    const int64_t v[8] = {c.world > 1 ? c.sh.n_own : c.nbr, c.world > 1 ? c.sh.n_ghost : 0, c.world > 1 ? c.sh.n_send : 0, (int64_t)c.n_elem_total, c.part[0].nnzb, c.part[1].nnzb,
+                          c.n_fused_solves, c.n_unfused_solves};
+    for (int i = 0; i < n && i < 8; i++) out[i] = v[i];
     API_END(0)
 }
 int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner)
@@ -967,8 +968,9 @@ int mistark_dist_init_ipc(mistark_ctx* ctx, mistark_ipc_comm* comm)
     set_dist(ctx->c, ipc_comm_rank(*comm->m), ipc_comm_world(*comm->m), ipc_comm_world(*comm->m) > 1 ? make_ipc_collective(comm->m) : nullptr);
     API_END(0)
 }
-// `iters` all-gathers of n doubles with values every rank can predict, checked on the device's results; the average wall time of one
-// exchange (push + wait on a stream that is otherwise idle) in microseconds. Every rank must call it with the same arguments.
+// `iters` all-gathers of n doubles with values every rank can predict, checked on the device's results; avg_us[0]: the average wall time of
+// one exchange followed by a stream synchronisation, avg_us[1]: of one exchange in a train of `iters` enqueued back to back (microseconds).
+// Every rank must call it with the same arguments.
 int mistark_ipc_comm_selftest(mistark_ipc_comm* comm, int64_t n, int iters, double* avg_us)
 {
     if (!comm || !comm->m || n <= 0 || iters <= 0) return -1;
@@ -1000,13 +1002,37 @@ int mistark_ipc_comm_selftest(mistark_ipc_comm* comm, int64_t n, int iters, doub
                         throw Error("IPC self-test: rank " + std::to_string(me) + " received a wrong value from rank " + std::to_string(r) + " (exchange " + std::to_string(it) + ", entry " +
                                     std::to_string(i) + ")");
         }
+        // the same exchanges back to back, one synchronisation at the end: what an exchange costs a stream that keeps running (a rank's push
+        // is enqueued behind its previous wait: the figure holds the one-way latency, two kernel boundaries and the ranks' skew)
+        MS_CHECK(hipStreamSynchronize(s));
+        const auto t1 = std::chrono::steady_clock::now();
+        for (int it = 0; it < iters; it++) coll->allgather_f64(send.p, recv.p, (size_t)n, s);
+        MS_CHECK(hipStreamSynchronize(s));
+        const double piped = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        coll->check();
         (void)hipStreamDestroy(s);
-        if (avg_us) *avg_us = 1e6 * total / iters;
+        if (avg_us) {
+            avg_us[0] = 1e6 * total / iters;
+            avg_us[1] = 1e6 * piped / iters;
+        }
     } catch (const std::exception& e) {
         comm->last_error = e.what();
         return -1;
     }
     return 0;
+}
+// Solo durations (microseconds) of the fused PCG iteration's three kernels on THIS rank's shard: out[0] = S (SpMV with halo polls), out[1] = R
+// (one-workgroup reduction and push), out[2] = V (vector kernel), replayed from the last converged solve. Not a collective: the caller lets the
+// ranks take turns (bench.py: torch.distributed barriers between them), so that on a box where all ranks share ONE GPU the other ranks' queues
+// are empty while one measures; no rank may start a solve in between.
+int mistark_dist_fused_bench(mistark_ctx* ctx, int n_launches, double* out)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (c.world < 2 || !c.coll || !c.coll->ipc()) throw Error("mistark_dist_fused_bench: ranks that exchange through windows only");
+    if (!out || n_launches <= 0) throw Error("mistark_dist_fused_bench: bad arguments");
+    fused_pcg_replay(c, n_launches, &out[0], &out[1], &out[2]);
+    API_END(0)
 }
 mistark_local_group* mistark_local_group_create(int world)
 {
@@ -1048,6 +1074,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "spmv_variant") ctx->c.spmv_variant = value;
     else if (n == "proj_variant") ctx->c.proj_variant = value;
     else if (n == "no_contact_cache") ctx->c.no_contact_cache = value != 0;
+    else if (n == "no_fused_pcg") ctx->c.no_fused_pcg = value != 0;  // sharded runs over windows: the five-launch iteration with two all-gathers instead of the fused one
     else if (n == "spmv_chunk_tiles") {
         if (value < 0 || value > 64) throw Error("spmv_chunk_tiles: 0 (automatic) .. 64");
         ctx->c.spmv_chunk_tiles = value;

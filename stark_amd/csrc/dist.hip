@@ -195,7 +195,7 @@ __global__ __launch_bounds__(IPC_TB) void k_ipc_wait(const unsigned long long* _
     const size_t total = (size_t)world * n;
     for (size_t t = (size_t)blockIdx.x * IPC_TB + threadIdx.x; t < total; t += (size_t)gridDim.x * IPC_TB) {
         const size_t r = t / n, i = t - r * n;
-        recv[t] = granule_wait_f64(mine + slot0 + r * slot_granules + 2 * i, tag, err, t0, budget);
+        recv[t] = granule_wait_f64(mine + slot0 + r * slot_granules + 2 * i, tag, err, t0, budget, 1u | (tag << 8));
     }
 }
 struct IpcCollective : Collective
@@ -208,13 +208,18 @@ struct IpcCollective : Collective
     const IpcView* ipc() override { return &m->view; }
     void check() override
     {
-        if (__atomic_load_n(m->err, __ATOMIC_ACQUIRE) != 0)
-            throw Error("multi-GPU (IPC windows): an exchange gave up waiting for a peer (rank " + std::to_string(m->rank) + " of " + std::to_string(m->world) +
+        const unsigned int code = __atomic_load_n(m->err, __ATOMIC_ACQUIRE);
+        if (code != 0)
+            throw Error("multi-GPU (IPC windows): an exchange gave up waiting for a peer (rank " + std::to_string(m->rank) + " of " + std::to_string(m->world) + ", wait code " +
+                        std::to_string(code & 0xffu) + ", iteration " + std::to_string(code >> 8) +
                         "): a peer process failed, or the ranks did not issue the same sequence of exchanges");
     }
     void allgather_f64(const double* send, double* recv, size_t n, hipStream_t s) override
     {
         if (n == 0) return;
+        check();  // (an earlier exchange that gave up: fail here, not many exchanges later)
+        static const bool dbg = std::getenv("MISTARK_DEBUG_FUSED") != nullptr;
+        if (dbg) std::fprintf(stderr, "[ipc r%d] all-gather %u of %zu doubles\n", m->rank, m->seq + 1, n);
         const int W = m->world;
         IpcPeers pk{};
         for (int r = 0; r < W; r++) pk.win[r] = m->view.win[r];
@@ -254,6 +259,23 @@ struct IpcCollective : Collective
 };
 }  // namespace
 
+// general region: 3/4 of the window, 2 parities x world slots; the rest for kernels that exchange by themselves
+static void ipc_layout(IpcComm& m)
+{
+    const size_t fast = m.granules / 4;
+    const size_t gen = m.granules - fast;
+    m.cap = gen / (2 * (size_t)m.world * 2);
+    m.view.rank = m.rank;
+    m.view.world = m.world;
+    m.view.fast_off = gen;
+    m.view.fast_granules = fast;
+    m.view.err = m.err;
+    int khz = 0;
+    MS_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m.device));
+    double seconds = 30.0;
+    if (const char* env = std::getenv("MISTARK_IPC_TIMEOUT_S")) seconds = std::max(0.05, std::atof(env));
+    m.view.timeout_ticks = (unsigned long long)(seconds * 1e3 * (double)std::max(khz, 1000));
+}
 std::shared_ptr<IpcComm> ipc_comm_create(int device, int rank, int world, size_t window_bytes, char handle_out[64])
 {
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is expected to be 64 bytes");
@@ -283,20 +305,7 @@ std::shared_ptr<IpcComm> ipc_comm_create(int device, int rank, int world, size_t
     MS_CHECK(hipHostMalloc((void**)&m->err, 64, hipHostMallocCoherent | hipHostMallocMapped));
     *m->err = 0;
     std::memcpy(handle_out, &h, 64);
-    // general region: 3/4 of the window, 2 parities x world slots
-    const size_t fast = m->granules / 4;
-    const size_t gen = m->granules - fast;
-    m->cap = gen / (2 * (size_t)world * 2);
-    m->view.rank = rank;
-    m->view.world = world;
-    m->view.fast_off = gen;
-    m->view.fast_granules = fast;
-    m->view.err = m->err;
-    int khz = 0;
-    MS_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device));
-    double seconds = 30.0;
-    if (const char* env = std::getenv("MISTARK_IPC_TIMEOUT_S")) seconds = std::max(0.05, std::atof(env));
-    m->view.timeout_ticks = (unsigned long long)(seconds * 1e3 * (double)std::max(khz, 1000));
+    ipc_layout(*m);
     return m;
 }
 void ipc_comm_connect(IpcComm& m, const char* handles)
@@ -323,6 +332,9 @@ int ipc_comm_rank(const IpcComm& comm) { return comm.rank; }
 int ipc_comm_world(const IpcComm& comm) { return comm.world; }
 int ipc_comm_device(const IpcComm& comm) { return comm.device; }
 
+// (Ranks inside one process cannot use the windows: HIP maps the streams of a process onto a few hardware queues, and a polling kernel of one
+// rank that shares a queue with the stream of the rank it waits for blocks that rank's push — measured: the in-process variant dead-locked
+// until the poll's time-out. Separate processes own separate queues.)
 std::unique_ptr<Collective> make_local_collective(std::shared_ptr<LocalGroup> group, int rank, int device) { return std::make_unique<LocalCollective>(std::move(group), rank, device); }
 std::unique_ptr<Collective> make_rccl_collective(int rank, int world, const char uid[128]) { return std::make_unique<RcclCollective>(rank, world, uid); }
 void rccl_unique_id(char out[128])

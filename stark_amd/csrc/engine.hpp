@@ -251,6 +251,8 @@ struct Shard
     int64_t n_send = 0, send_stride = 0;
     DevBuf<int32_t> send_rows;         // local indices of my send rows
     DevBuf<int32_t> ghost_src;         // per ghost: owner rank * send_stride + position in the owner's send rows
+    DevBuf<int32_t> send_pos_of_row;   // per own row: its position among my send rows, -1: no other rank holds it as a ghost
+    DevBuf<uint32_t> send_mask;        // per send row: the ranks that hold it as a ghost (bit r)
     DevBuf<double> sendbuf, recvbuf;
     // gather of the owned parts of a vector into the global vector on every rank
     int64_t own_stride = 0;            // max n_own over the ranks
@@ -274,6 +276,7 @@ struct PcgCtrl
     double rz[2];
     int epoch;  // (pinned copy only) which solve published this: a look-ahead batch of the previous solve may still be on its way
     int pad_;
+    double alpha[2];  // sharded PCG with one exchange per iteration (pcg_sharded_fused): the step lengths of the last two iterations
 };
 
 struct Context
@@ -385,6 +388,17 @@ struct Context
     int64_t mcols() const { return world > 1 ? sh.n_loc : nbr; }
     DevBuf<double> dist_scalar;
     DevBuf<double> xl;              // sharded PCG: the solution in local numbering
+    // sharded PCG through the windows (pcg_sharded_fused): the running tag of its messages, and the option to keep the unfused iteration
+    uint32_t fused_tag = 0;
+    bool no_fused_pcg = false;      // option "no_fused_pcg"
+    int64_t n_fused_solves = 0, n_unfused_solves = 0;  // sharded solves by iteration kind (mistark_dist_info)
+    struct FusedReplay  // the last converged fused solve, for fused_pcg_replay (kernels.hip)
+    {
+        bool valid = false;
+        uint32_t base = 0;
+        int n = 0;
+        uint64_t pattern = 0;
+    } fused_replay;
     // sharded projection: delta records of this rank, the common exchange buffer and its sort scratch (kernels.hip: exchange_projection_deltas)
     DevBuf<unsigned char> src_ranges;  // descriptor table of k_make_desc
     struct ContactSystem* contact = nullptr;  // device contact detector (contact.hip), created by mistark_contact_init
@@ -429,6 +443,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
 void assemble(Context& c);
 void build_preconditioner(Context& c);
 double spmv_bench(Context& c, int n);
+void fused_pcg_replay(Context& c, int n_launches, double* s_us, double* r_us, double* v_us);
 void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed);
 // rhs_scale: the system solved is A x = rhs_scale * rhs (the Newton loop passes the gradient and -1; single GPU only)
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info, double rhs_scale = 1.0);

@@ -16,6 +16,7 @@
 #include <cstring>
 
 #include "dist.hpp"
+#include "ipc_dev.hpp"
 #include "engine.hpp"
 #include "registry.hpp"
 #include "tet_closed.hpp"
@@ -3331,21 +3332,30 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_combine(int64_t nbr, const int32
     y[3 * row + 2] += q2;
 }
 // y = (A_static + A_dynamic) x; partial sums of pdot . y go to partials[0 .. return value)
-template <int V>
-static int launch_spmv(Context& c, const double* x, double* y, const double* pdot, double* partials, const PcgCtrl* ctrl, bool combine = true, uint64_t* clk = nullptr)
+// grid of the fused SpMV launch on the current matrix: workgroups of the static chunks, of over-long static rows, of the contact part
+static void spmv_launch_shape(Context& c, int& g0, int& gr, int& g1, StaticPart& sp, DynPart& d)
 {
     const BsrPart& m0 = c.part[0];
     BsrPart& m1 = c.part[1];
-    const int g0 = spmv_grid(c, m0.n_chunks_static, MAX_PARTIALS / 2);
-    const int gr = std::min(((m0.n_long_rows + 3) / 4 + 7) / 8 * 8, MAX_PARTIALS / 4);
-    const StaticPart sp{m0.vals.p, m0.scol.p, m0.tile_first_row.p, m0.long_rows.p, m0.row_ptr.p, m0.row_pos.p, m0.n_chunks_static, m0.n_long_rows, m0.chunk_tiles};
-    DynPart d{};
-    int g1 = 0;
+    g0 = spmv_grid(c, m0.n_chunks_static, MAX_PARTIALS / 2);
+    gr = std::min(((m0.n_long_rows + 3) / 4 + 7) / 8 * 8, MAX_PARTIALS / 4);
+    sp = StaticPart{m0.vals.p, m0.scol.p, m0.tile_first_row.p, m0.long_rows.p, m0.row_ptr.p, m0.row_pos.p, m0.n_chunks_static, m0.n_long_rows, m0.chunk_tiles};
+    d = DynPart{};
+    g1 = 0;
     if (m1.nnzb > 0) {
         // workgroups for the chunks of long rows (one per wavefront) + for the short rows (four lanes each); a multiple of 8 keeps the XCD placement of the static part
         g1 = (int)std::min<int64_t>(((m1.n_chunks + 3) / 4 + (m1.n_rows + BLOCK / 4 - 1) / (BLOCK / 4) + 7) / 8 * 8, MAX_PARTIALS / 4);
         d = DynPart{m1.vals.p, m1.colw.p, m1.row_ptr.p, m1.row_chunk0.p, m1.chunk_row.p, m1.rowmap.p, m1.yd.p, m1.chunk_partial.p, m1.n_chunks, m1.n_rows};
     }
+}
+template <int V>
+static int launch_spmv(Context& c, const double* x, double* y, const double* pdot, double* partials, const PcgCtrl* ctrl, bool combine = true, uint64_t* clk = nullptr)
+{
+    BsrPart& m1 = c.part[1];
+    int g0, gr, g1;
+    StaticPart sp;
+    DynPart d;
+    spmv_launch_shape(c, g0, gr, g1, sp, d);
     hipLaunchKernelGGL(k_spmv_fused<V>, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, x, y, pdot, partials, ctrl, clk);
     if (g1 > 0 && combine)
         hipLaunchKernelGGL(k_spmv_combine, dim3(grid_for(c.mrows())), dim3(BLOCK), 0, c.stream, c.mrows(), (const int32_t*)m1.crow_of_row.p, (const uint32_t*)m1.row_chunk0.p,
@@ -3919,6 +3929,557 @@ static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, do
     }
 }
 
+// ---- the row-sharded PCG with ONE exposed exchange per iteration, for ranks that exchange through windows (dist.hpp: IpcView) --------------
+// The five launches and two all-gathers of pcg_sharded become THREE launches whose workgroups push and poll the windows themselves. The
+// arithmetic is the preconditioned CG of Chronopoulos & Gear (u = M^-1 r, w = A u, s = A p by recurrence), in which both dot products of
+// an iteration are taken on the same vectors, so that p.Ap is not a reduction of its own (the three reductions of
+// solve_pcg.h:180,201,217 are gamma = r.u, rr = r.r, and p.Ap = delta - beta gamma / alpha_prev with delta = w.u):
+//   V_k  (k_cg_vec)    every workgroup adds, in rank order, the ranks' (gamma, rr, delta)_{k-1} (message M2_{k-1}: 3 doubles per rank):
+//                      convergence test of iteration k-1, beta, p.Ap (indefiniteness test), alpha; then p = u + beta p, s = w + beta s,
+//                      x += alpha p, r -= alpha s, u = M^-1 r on its rows; partial (r.u, r.r) per workgroup to local memory; the new u of the rows
+//                      other ranks hold as ghosts is pushed to exactly those ranks                                         [message M1_k]
+//   S_k  (k_spmv_halo) w = A u: columns of its own rows from memory, ghost columns straight from the window (the lane polls the granules of
+//                      that ghost: rows without ghost columns never wait, so the halo hides behind the interior of the matrix); partial w.u per
+//                      workgroup to local memory
+//   R_k  (k_cg_reduce) one workgroup: the rank's (gamma, rr, delta)_k from the partial sums, pushed to every rank                   [message M2_k]
+// (First version: every workgroup of V and S pushed its partial sums to every rank and every workgroup of V added them all — thousands of
+// uncached 8-byte reads per workgroup: 15 us per V launch at 43 k rows, three times the kernel it was to replace. The one-workgroup
+// reduction costs a launch and brings V to the few microseconds its vector traffic takes.)
+// The only wait that is not hidden is V_{k+1}'s for the slowest rank's R_k. Every rank adds the same numbers in the same order: identical
+// bits, identical decisions, no all-reduce. Messages live in the fast region of the windows, two slots (parity of k) per message kind and
+// source rank; a slot is rewritten two iterations later, when every reader has passed it (see "slot reuse" in dist.hip; between solves
+// the all-gather of the solution separates the last readers from the next solve's first push).
+struct CgFast
+{
+    IpcView v;
+    size_t m1[2], m2[2];  // granule offset, inside every window, of rank 0's slot of the message kinds, per parity
+    size_t m1_stride;     // granules per source rank in M1 (3 doubles per send row); M2 holds 3 doubles = 6 granules per rank
+    int64_t send_stride;
+};
+constexpr size_t M2_STRIDE = 6;
+// u of a send row to the ranks that hold it as a ghost
+__device__ __forceinline__ void push_halo_row(const CgFast& f, int par, uint32_t tag, int sp, uint32_t mask, double u0, double u1, double u2)
+{
+    const size_t at = f.m1[par] + (size_t)f.v.rank * f.m1_stride + 6 * (size_t)sp;
+    while (mask) {
+        const int q = __ffs(mask) - 1;
+        mask &= mask - 1;
+        unsigned long long* g = f.v.win[q] + at;
+        granule_store_f64(g, tag, u0);
+        granule_store_f64(g + 2, tag, u1);
+        granule_store_f64(g + 4, tag, u2);
+    }
+}
+// prologue: x = 0, r = b, u = M^-1 r (the preconditioner is built); p = s = 0; control block; halo of u (message M1_0)
+__global__ __launch_bounds__(BLOCK) void k_cg_prologue(CgFast f, uint32_t tag_out, const double* __restrict__ b, const float* __restrict__ dinv, int64_t n_own, double* __restrict__ x,
+                                                       double* __restrict__ r, double* __restrict__ u, double* __restrict__ p, double* __restrict__ s, PcgCtrl* __restrict__ ctrl,
+                                                       const int32_t* __restrict__ send_pos_of_row, const uint32_t* __restrict__ send_mask, double* __restrict__ part_ru,
+                                                       double* __restrict__ part_rr)
+{
+    __shared__ double sm[4];
+    double bb = 0.0, ru = 0.0;
+    for (int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x; row < n_own; row += (int64_t)gridDim.x * BLOCK) {
+        const size_t i = 3 * (size_t)row;
+        const double r0 = b[i], r1 = b[i + 1], r2 = b[i + 2];
+        const float* d = dinv + 9 * row;
+        const double u0 = (double)d[0] * r0 + (double)d[1] * r1 + (double)d[2] * r2;
+        const double u1 = (double)d[3] * r0 + (double)d[4] * r1 + (double)d[5] * r2;
+        const double u2 = (double)d[6] * r0 + (double)d[7] * r1 + (double)d[8] * r2;
+        x[i] = 0.0; x[i + 1] = 0.0; x[i + 2] = 0.0;
+        p[i] = 0.0; p[i + 1] = 0.0; p[i + 2] = 0.0;
+        s[i] = 0.0; s[i + 1] = 0.0; s[i + 2] = 0.0;
+        r[i] = r0; r[i + 1] = r1; r[i + 2] = r2;
+        u[i] = u0; u[i + 1] = u1; u[i + 2] = u2;
+        bb += r0 * r0 + r1 * r1 + r2 * r2;
+        ru += r0 * u0 + r1 * u1 + r2 * u2;
+        const int sp = send_pos_of_row[row];
+        if (sp >= 0) push_halo_row(f, 0, tag_out, sp, send_mask[sp], u0, u1, u2);
+    }
+    bb = block_sum(bb, sm);
+    ru = block_sum(ru, sm);
+    if (threadIdx.x == 0) {
+        part_ru[blockIdx.x] = ru;
+        part_rr[blockIdx.x] = bb;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ctrl->bb = 0.0;
+        ctrl->rz[0] = ctrl->rz[1] = 0.0;
+        ctrl->alpha[0] = ctrl->alpha[1] = 0.0;
+        ctrl->indef = 0;
+        ctrl->n_iter = 0;
+        ctrl->converged = 0;
+        ctrl->done = 0;
+        ctrl->error = 1.0;
+    }
+}
+// R_k: this rank's (gamma, rr, delta) of iteration k, summed from the partial sums of its vector kernel and its SpMV, to every rank
+__global__ __launch_bounds__(BLOCK) void k_cg_reduce(CgFast f, int par, uint32_t tag_out, const double* __restrict__ part_ru, const double* __restrict__ part_rr, int gv,
+                                                     const double* __restrict__ part_wu, int gs, const PcgCtrl* __restrict__ ctrl, int replay)
+{
+    if (!replay && ctrl->done) return;
+    __shared__ double sm[8];
+    double gamma, rr;
+    sum_partials2(part_ru, part_rr, gv, sm, 1, gamma, rr);
+    __syncthreads();
+    const double delta = sum_partials(part_wu, gs, sm);
+    if (threadIdx.x < (unsigned)f.v.world) {
+        unsigned long long* g = f.v.win[threadIdx.x] + f.m2[par] + (size_t)f.v.rank * M2_STRIDE;
+        granule_store_f64(g, tag_out, gamma);
+        granule_store_f64(g + 2, tag_out, rr);
+        granule_store_f64(g + 4, tag_out, delta);
+    }
+}
+struct VecRow
+{
+    double u0, u1, u2, w0, w1, w2, p0, p1, p2, s0, s1, s2, x0, x1, x2, r0, r1, r2;
+    float d[9];
+    int sp;
+};
+__device__ __forceinline__ void vec_load(VecRow& v, int64_t row, const float* __restrict__ dinv, const double* __restrict__ u, const double* __restrict__ w, const double* __restrict__ p,
+                                         const double* __restrict__ s, const double* __restrict__ x, const double* __restrict__ r, const int32_t* __restrict__ crow_of_row,
+                                         const uint32_t* __restrict__ row_chunk0, const double* __restrict__ yd, const double* __restrict__ chunk_partial,
+                                         const int32_t* __restrict__ send_pos_of_row)
+{
+    const size_t i = 3 * (size_t)row;
+    v.u0 = u[i]; v.u1 = u[i + 1]; v.u2 = u[i + 2];
+    v.w0 = w[i]; v.w1 = w[i + 1]; v.w2 = w[i + 2];
+    v.p0 = p[i]; v.p1 = p[i + 1]; v.p2 = p[i + 2];
+    v.s0 = s[i]; v.s1 = s[i + 1]; v.s2 = s[i + 2];
+    v.x0 = x[i]; v.x1 = x[i + 1]; v.x2 = x[i + 2];
+    v.r0 = r[i]; v.r1 = r[i + 1]; v.r2 = r[i + 2];
+#pragma unroll
+    for (int k = 0; k < 9; k++) v.d[k] = dinv[9 * row + k];
+    v.sp = send_pos_of_row[row];
+    if (crow_of_row) dyn_row(crow_of_row, row_chunk0, yd, chunk_partial, row, v.w0, v.w1, v.w2);  // + contact part of w (k_spmv_halo left it in yd / chunk_partial)
+}
+// V_k, k >= 1 (check_only: the convergence test of iteration k - 1 and nothing else, behind the last iteration the caller allows).
+// replay (mistark_dist_fused_bench): the kernel of a FINISHED solve launched again on the messages still in the window — every poll is
+// answered at once, no decision is taken, the control block stays as it is: the kernel's own duration.
+__global__ __launch_bounds__(BLOCK) void k_cg_vec(int k, int check_only, int stop_on_indef, double abs_tol, double rel_tol, CgFast f, uint32_t tag_m2_in, uint32_t tag_out,
+                                                  const float* __restrict__ dinv, int64_t n_own, double* __restrict__ u, const double* __restrict__ w, double* __restrict__ p,
+                                                  double* __restrict__ s, double* __restrict__ x, double* __restrict__ r, PcgCtrl* __restrict__ ctrl,
+                                                  const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0, const double* __restrict__ yd,
+                                                  const double* __restrict__ chunk_partial, const int32_t* __restrict__ send_pos_of_row, const uint32_t* __restrict__ send_mask,
+                                                  double* __restrict__ part_ru, double* __restrict__ part_rr, PcgCtrl* __restrict__ host_slot, int epoch, int replay)
+{
+    const bool scribe = blockIdx.x == 0 && threadIdx.x == 0 && !replay;
+    if (!replay && ctrl->done) {
+        if (scribe && host_slot) publish_ctrl(host_slot, epoch, 1, ctrl->converged, ctrl->indef, ctrl->n_iter, ctrl->error);
+        return;
+    }
+    const int i = k - 1, par_in = i & 1, par_out = k & 1;
+    int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    VecRow v;
+    // (the thread's row is requested before the sums below: they wait for the slowest rank's reduction)
+    if (!check_only && row < n_own) vec_load(v, row, dinv, u, w, p, s, x, r, crow_of_row, row_chunk0, yd, chunk_partial, send_pos_of_row);
+    __shared__ double sm[3 * MAX_IPC_RANKS + 4];
+    const int W = f.v.world;
+    if (threadIdx.x < (unsigned)(3 * W)) {  // one lane per (rank, component); added below in rank order
+        const unsigned long long* g = f.v.win[f.v.rank] + f.m2[par_in] + 2 * (size_t)threadIdx.x;  // (rank-major: 6 granules per rank)
+        sm[threadIdx.x] = granule_wait_f64(g, tag_m2_in, f.v.err, wall_clock64(), f.v.timeout_ticks, 2u | ((unsigned)k << 8));
+    }
+    __syncthreads();
+    double gamma = 0.0, rr = 0.0, delta = 0.0;
+    for (int q = 0; q < W; q++) {
+        gamma += sm[3 * q];
+        rr += sm[3 * q + 1];
+        delta += sm[3 * q + 2];
+    }
+    double error = 1.0;
+    if (replay) {
+        // (no exits)
+    } else if (i == 0) {  // rr = b.b: the two exits before the first iteration (solve_pcg.h:125-131,150-156)
+        const bool zero_rhs = rr < abs_tol * abs_tol;
+        if (zero_rhs || 1.0 < abs_tol) {
+            if (scribe) {
+                ctrl->bb = rr;
+                ctrl->error = zero_rhs ? 0.0 : 1.0;
+                ctrl->n_iter = 0;
+                ctrl->converged = 1;
+                ctrl->done = 1;
+                if (host_slot) publish_ctrl(host_slot, epoch, 1, 1, 0, 0, zero_rhs ? 0.0 : 1.0);
+            }
+            return;
+        }
+    } else {
+        error = sqrt(rr / ctrl->bb);
+        if (error < abs_tol || error / 1.0 < rel_tol) {  // error_0 = 1 for x0 = 0
+            if (scribe) {
+                ctrl->error = error;
+                ctrl->n_iter = i;
+                ctrl->converged = 1;
+                ctrl->done = 1;
+                if (host_slot) publish_ctrl(host_slot, epoch, 1, 1, ctrl->indef, i, error);
+            }
+            return;
+        }
+    }
+    if (check_only) {
+        if (scribe) {
+            ctrl->error = error;
+            ctrl->n_iter = i;
+            if (host_slot) publish_ctrl(host_slot, epoch, 0, 0, ctrl->indef, k, error);
+        }
+        return;
+    }
+    double beta = 0.0, pAp = delta;
+    if (i > 0) {
+        beta = gamma / ctrl->rz[(i - 1) & 1];
+        pAp = delta - beta * gamma / ctrl->alpha[(i - 1) & 1];
+    }
+    if (pAp <= 0.0 && !replay) {  // solve_pcg.h:183-190
+        if (stop_on_indef) {
+            if (scribe) {
+                ctrl->indef = 1;
+                ctrl->n_iter = k;
+                ctrl->converged = 0;
+                ctrl->done = 1;
+                if (host_slot) publish_ctrl(host_slot, epoch, 1, 0, 1, k, error);
+            }
+            return;  // every workgroup of every rank takes the same decision: x stays untouched
+        }
+        if (scribe) ctrl->indef = 1;
+    }
+    const double alpha = gamma / pAp;
+    double ru = 0.0, rrn = 0.0;
+    while (row < n_own) {
+        const size_t j = 3 * (size_t)row;
+        const double p0 = beta == 0.0 ? v.u0 : v.u0 + beta * v.p0, p1 = beta == 0.0 ? v.u1 : v.u1 + beta * v.p1, p2 = beta == 0.0 ? v.u2 : v.u2 + beta * v.p2;
+        const double s0 = beta == 0.0 ? v.w0 : v.w0 + beta * v.s0, s1 = beta == 0.0 ? v.w1 : v.w1 + beta * v.s1, s2 = beta == 0.0 ? v.w2 : v.w2 + beta * v.s2;
+        const double r0 = v.r0 - alpha * s0, r1 = v.r1 - alpha * s1, r2 = v.r2 - alpha * s2;
+        p[j] = p0; p[j + 1] = p1; p[j + 2] = p2;
+        s[j] = s0; s[j + 1] = s1; s[j + 2] = s2;
+        x[j] = v.x0 + alpha * p0; x[j + 1] = v.x1 + alpha * p1; x[j + 2] = v.x2 + alpha * p2;
+        r[j] = r0; r[j + 1] = r1; r[j + 2] = r2;
+        const float* d = v.d;
+        const double u0 = (double)d[0] * r0 + (double)d[1] * r1 + (double)d[2] * r2;
+        const double u1 = (double)d[3] * r0 + (double)d[4] * r1 + (double)d[5] * r2;
+        const double u2 = (double)d[6] * r0 + (double)d[7] * r1 + (double)d[8] * r2;
+        u[j] = u0; u[j + 1] = u1; u[j + 2] = u2;
+        rrn += r0 * r0 + r1 * r1 + r2 * r2;
+        ru += r0 * u0 + r1 * u1 + r2 * u2;
+        if (v.sp >= 0) push_halo_row(f, par_out, tag_out, v.sp, send_mask[v.sp], u0, u1, u2);
+        row += (int64_t)gridDim.x * BLOCK;
+        if (row < n_own) vec_load(v, row, dinv, u, w, p, s, x, r, crow_of_row, row_chunk0, yd, chunk_partial, send_pos_of_row);
+    }
+    __syncthreads();
+    rrn = block_sum(rrn, sm);
+    ru = block_sum(ru, sm);
+    if (threadIdx.x == 0) {
+        part_ru[blockIdx.x] = ru;
+        part_rr[blockIdx.x] = rrn;
+    }
+    if (scribe) {
+        if (i == 0) ctrl->bb = rr;
+        ctrl->rz[i & 1] = gamma;
+        ctrl->alpha[i & 1] = alpha;
+        ctrl->error = error;
+        ctrl->n_iter = i;
+        if (host_slot) publish_ctrl(host_slot, epoch, 0, 0, ctrl->indef, k, error);
+    }
+}
+// x of the SpMV for k_spmv_halo: own columns from memory, ghost columns from the window (M1 of this iteration), polled by the lane that needs them
+struct XHalo
+{
+    const double* x;                // u, own rows
+    const unsigned long long* mine; // own window
+    size_t halo0;                   // granule offset of rank 0's halo values (the M1 slot of this parity)
+    size_t m1_stride;
+    const int32_t* ghost_src;       // per ghost: owner * send_stride + position among the owner's send rows
+    int64_t send_stride;
+    size_t own3;                    // 3 * n_own
+    uint32_t tag;
+    unsigned int* err;
+    unsigned long long t0, budget;
+    unsigned int code;              // which wait this is, for the error message (5 | iteration << 8)
+    __device__ __forceinline__ void load(size_t c3, double& x0, double& x1, double& x2) const
+    {
+        if (c3 < own3) {
+            x0 = x[c3];
+            x1 = x[c3 + 1];
+            x2 = x[c3 + 2];
+        } else {
+            const int64_t src = ghost_src[(c3 - own3) / 3], o = src / send_stride, pos = src - o * send_stride;
+            const unsigned long long* g = mine + halo0 + (size_t)o * m1_stride + 6 * (size_t)pos;
+            x0 = granule_wait_f64(g, tag, err, t0, budget, code);
+            x1 = granule_wait_f64(g + 2, tag, err, t0, budget, code);
+            x2 = granule_wait_f64(g + 4, tag, err, t0, budget, code);
+        }
+    }
+    __device__ __forceinline__ bool has_dot() const { return true; }
+    __device__ __forceinline__ double row_dot(size_t r3, double y0, double y1, double y2) const { return x[r3] * y0 + x[r3 + 1] * y1 + x[r3 + 2] * y2; }
+    __device__ __forceinline__ void row_pre(size_t r3, double& p0, double& p1, double& p2) const
+    {
+        p0 = x[r3];
+        p1 = x[r3 + 1];
+        p2 = x[r3 + 2];
+    }
+    __device__ __forceinline__ double row_dot_pre(size_t, double p0, double p1, double p2, double y0, double y1, double y2) const { return p0 * y0 + p1 * y1 + p2 * y2; }
+};
+__device__ __forceinline__ double row_dot_nostore(const XHalo& X, size_t r3, double y0, double y1, double y2) { return X.row_dot(r3, y0, y1, y2); }
+// S_k: w = A u (+ the contact part's row sums, as k_spmv_fused leaves them); the workgroups' partial sums of w.u stay in local memory
+__global__ __launch_bounds__(BLOCK) void k_spmv_halo(int g0, int gr, int g1, StaticPart m, DynPart d, XHalo X, double* __restrict__ y, double* __restrict__ partials,
+                                                    const PcgCtrl* __restrict__ ctrl, uint64_t* __restrict__ clk, int replay)
+{
+    if (!replay && ctrl->done) return;
+    const int b = (int)blockIdx.x;
+    const uint64_t t_start = wall_clock64();
+    X.t0 = t_start;
+    if (b < g1) spmv_chunks(b, g1, d, X, partials + g0 + gr);
+    else if (b < g1 + gr) spmv_long_rows(b - g1, gr, m.vals, m.scol, m.long_rows, m.n_long_rows, m.row_ptr, m.row_pos, X, y, partials + g0);
+    else spmv_chunked_static<0>(b - g1 - gr, g0, m.vals, m.scol, m.tile_first_row, m.n_chunks, m.chunk_tiles, X, y, partials);
+    if (clk) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            clk[2 * b] = t_start;
+            clk[2 * b + 1] = wall_clock64();
+        }
+    }
+}
+static double now_seconds();
+namespace {
+// everything the launches of one fused solve share
+struct FusedSolve
+{
+    Context& c;
+    CgFast f;
+    int g0, gr, g1, gs, gv;
+    StaticPart sp;
+    DynPart d;
+    uint32_t base;
+    double *u, *w, *p, *s, *x, *r, *part_wu, *part_ru, *part_rr;
+    uint32_t tag_m1(int i) const { return base + 2u * (uint32_t)i + 1u; }
+    uint32_t tag_m2(int i) const { return base + 2u * (uint32_t)i + 2u; }
+    void launch_S(int i, uint64_t* clk, int replay) const
+    {
+        const Shard& S = c.sh;
+        XHalo X{};
+        X.x = u;
+        X.mine = f.v.win[f.v.rank];
+        X.halo0 = f.m1[i & 1];
+        X.m1_stride = f.m1_stride;
+        X.ghost_src = S.ghost_src.p;
+        X.send_stride = std::max<int64_t>(S.send_stride, 1);
+        X.own3 = 3 * (size_t)S.n_own;
+        X.tag = tag_m1(i);
+        X.err = f.v.err;
+        X.budget = f.v.timeout_ticks;
+        X.code = 5u | ((unsigned)i << 8);
+        hipLaunchKernelGGL(k_spmv_halo, dim3(gs), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, X, w, part_wu, (const PcgCtrl*)c.ctrl.p, clk, replay);
+    }
+    void launch_R(int i, int replay) const
+    {
+        hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(BLOCK), 0, c.stream, f, i & 1, tag_m2(i), (const double*)part_ru, (const double*)part_rr, gv, (const double*)part_wu, gs,
+                           (const PcgCtrl*)c.ctrl.p, replay);
+    }
+    void launch_V(int k, bool check_only, int stop_on_indef, double abs_tol, double rel_tol, PcgCtrl* host_slot, int epoch, int replay) const
+    {
+        const Shard& S = c.sh;
+        BsrPart& m1 = c.part[1];
+        const bool dyn = m1.nnzb > 0;
+        hipLaunchKernelGGL(k_cg_vec, dim3(gv), dim3(BLOCK), 0, c.stream, k, check_only ? 1 : 0, stop_on_indef, abs_tol, rel_tol, f, tag_m2(k - 1), tag_m1(k), (const float*)c.dinv.p, S.n_own,
+                           u, (const double*)w, p, s, x, r, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : (const int32_t*)nullptr, (const uint32_t*)m1.row_chunk0.p,
+                           (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, (const int32_t*)S.send_pos_of_row.p, (const uint32_t*)S.send_mask.p, part_ru, part_rr, host_slot,
+                           epoch, replay);
+    }
+};
+// false: no windows, too many ranks, or the halo does not fit the fast region
+bool fused_setup(Context& c, FusedSolve& F)
+{
+    const IpcView* view = c.coll ? c.coll->ipc() : nullptr;
+    if (!view || c.no_fused_pcg || c.world > MAX_IPC_RANKS) return false;
+    Shard& S = c.sh;
+    const int W = c.world;
+    spmv_launch_shape(c, F.g0, F.gr, F.g1, F.sp, F.d);
+    F.gs = F.g0 + F.gr + F.g1;
+    F.gv = grid_for(std::max<int64_t>(S.n_own, 1), BLOCK, PCG_GRID);
+    F.f = CgFast{};
+    F.f.v = *view;
+    F.f.send_stride = S.send_stride;
+    F.f.m1_stride = 6 * (size_t)std::max<int64_t>(S.send_stride, 1);
+    const size_t per_parity = (size_t)W * (F.f.m1_stride + M2_STRIDE);
+    if (2 * per_parity > view->fast_granules) return false;
+    for (int par = 0; par < 2; par++) {
+        F.f.m1[par] = view->fast_off + (size_t)par * per_parity;
+        F.f.m2[par] = F.f.m1[par] + (size_t)W * F.f.m1_stride;
+    }
+    c.xl.ensure(3 * (size_t)std::max<int64_t>(S.n_loc, 1));
+    c.p2.ensure(3 * (size_t)std::max<int64_t>(S.n_loc, 1));
+    F.u = c.z.p;
+    F.w = c.q.p;
+    F.p = c.p.p;
+    F.s = c.p2.p;
+    F.x = c.xl.p;
+    F.r = c.r.p;
+    F.part_wu = c.partials.p;
+    F.part_ru = c.partials.p + MAX_PARTIALS;
+    F.part_rr = c.partials.p + 2 * MAX_PARTIALS;
+    F.base = c.fused_tag;
+    return true;
+}
+}  // namespace
+// false: this solve cannot take the fused iteration
+static bool pcg_sharded_fused(Context& c, const double* rhs_global, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info)
+{
+    FusedSolve F{c};
+    if (!fused_setup(c, F)) return false;
+    Shard& S = c.sh;
+    const int me = c.rank;
+    build_preconditioner(c);
+    static const bool dbg = std::getenv("MISTARK_DEBUG_FUSED") != nullptr;
+    if (dbg)
+        std::fprintf(stderr, "[fused r%d] gv=%d gs=%d (g0 %d gr %d g1 %d) n_own=%lld send_stride=%lld tag base %u max_iter %d\n", me, F.gv, F.gs, F.g0, F.gr, F.g1, (long long)S.n_own,
+                     (long long)S.send_stride, c.fused_tag, max_iter);
+    if (rhs_global == c.tmp_b.p) throw Error("pcg: right-hand side in a scratch vector the sharded solve needs");
+    double* b_l = c.tmp_b.p;
+    shard_to_local(c, rhs_global, b_l, false);
+    hipLaunchKernelGGL(k_cg_prologue, dim3(F.gv), dim3(BLOCK), 0, c.stream, F.f, F.tag_m1(0), (const double*)b_l, (const float*)c.dinv.p, S.n_own, F.x, F.r, F.u, F.p, F.s, c.ctrl.p,
+                       (const int32_t*)S.send_pos_of_row.p, (const uint32_t*)S.send_mask.p, F.part_ru, F.part_rr);
+    std::vector<int> sampled_i;
+    auto launch_S = [&](int i) {
+        uint64_t* clk = nullptr;
+        if (c.time_spmv && i > 0 && (i % 32) == 0 && sampled_i.size() < 64) {  // (device-clock sample for the bench's roofline figure, as in pcg())
+            if (!c.spmv_clk_sharded) MS_CHECK(hipHostMalloc((void**)&c.spmv_clk_sharded, sizeof(uint64_t) * 64 * 2 * MAX_PARTIALS, hipHostMallocDefault));
+            clk = c.spmv_clk_sharded + sampled_i.size() * 2 * MAX_PARTIALS;
+            std::memset(clk, 0, sizeof(uint64_t) * 2 * MAX_PARTIALS);
+            sampled_i.push_back(i);
+        }
+        F.launch_S(i, clk, 0);
+    };
+    // batches of [S_{k-1}, R_{k-1}, V_k] with one look-ahead batch in flight, as in pcg(): the last V of a batch writes the control block to a
+    // pinned slot the host watches
+    constexpr int BATCH = 8;
+    PcgCtrl* hs[2] = {reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048), reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048 + 64)};
+    const int epoch = ++c.pcg_epoch;
+    int k = 1;  // next V to launch
+    bool tail_done = false;  // the check-only V behind iteration max_iter has been launched
+    auto launch_batch = [&](int slot) {
+        hs[slot]->epoch = epoch - 1;
+        hs[slot]->done = 0;
+        hs[slot]->n_iter = -1;
+        const int k_end = std::min(max_iter + 1, k + BATCH - 1);
+        for (; k <= k_end; k++) {
+            const bool check_only = k == max_iter + 1;
+            launch_S(k - 1);      // w_{k-1}
+            F.launch_R(k - 1, 0);  // (gamma, rr, delta)_{k-1} to every rank
+            F.launch_V(k, check_only, stop_on_indef, abs_tol, rel_tol, k == k_end ? hs[slot] : (PcgCtrl*)nullptr, epoch, 0);
+            if (check_only) tail_done = true;
+        }
+        return k_end;
+    };
+    PcgCtrl h{};
+    int slot = 0;
+    int k_end_cur = launch_batch(0);
+    for (;;) {
+        const bool more = !tail_done;
+        int k_end_next = 0;
+        if (more) k_end_next = launch_batch(slot ^ 1);
+        const volatile PcgCtrl* v = hs[slot];
+        const double t_wait = now_seconds();
+        auto reported = [&] { return v->epoch == epoch && (v->done || v->n_iter >= k_end_cur); };
+        for (uint64_t spins = 0; !reported(); spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xfffff) != 0xfffff) continue;
+            c.coll->check();
+            const hipError_t q = hipStreamQuery(c.stream);
+            if (q != hipErrorNotReady) {
+                MS_CHECK(q);
+                if (!reported()) {
+                    PcgCtrl dev{};
+                    MS_CHECK(hipMemcpy(&dev, c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost));
+                    hs[slot]->converged = dev.converged;
+                    hs[slot]->indef = dev.indef;
+                    hs[slot]->error = dev.error;
+                    hs[slot]->n_iter = dev.done ? dev.n_iter : k_end_cur;
+                    hs[slot]->done = dev.done ? 1 : 0;
+                    hs[slot]->epoch = epoch;
+                }
+                break;
+            }
+            if (now_seconds() - t_wait > 120.0) throw Error("sharded pcg: the device did not report iteration " + std::to_string(k_end_cur) + " within 120 s");
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        h = *hs[slot];
+        if (dbg) std::fprintf(stderr, "[fused r%d] batch to %d: done %d conv %d indef %d n_iter %d err %g (k next %d)\n", me, k_end_cur, h.done, h.converged, h.indef, h.n_iter, h.error, k);
+        if (h.done || !more) break;
+        slot ^= 1;
+        k_end_cur = k_end_next;
+    }
+    // the next solve's tags start behind the last one any rank can have used in this one (a rank launches at most two batches beyond the
+    // iteration that ended the solve; computed from the iteration count, which is the same number on every rank)
+    c.fused_tag = F.base + 2u * (uint32_t)((h.done ? h.n_iter : max_iter) + 2 * BATCH + 4);
+    shard_gather_global(c, F.x, c.du.p);  // (also the barrier between this solve's last window readers and the next solve's first push)
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    c.coll->check();
+    if (c.time_spmv) {
+        for (size_t q = 0; q < sampled_i.size(); q++) {
+            if (h.done && sampled_i[q] >= h.n_iter) continue;  // (a no-op launch after the solve was over)
+            const uint64_t* clk = c.spmv_clk_sharded + q * 2 * MAX_PARTIALS;
+            uint64_t t0 = ~0ull, t1 = 0;
+            bool complete = true;
+            for (int b = 0; b < F.gs; b++) {
+                if (clk[2 * b] == 0 || clk[2 * b + 1] == 0) { complete = false; break; }
+                t0 = std::min(t0, clk[2 * b]);
+                t1 = std::max(t1, clk[2 * b + 1]);
+            }
+            if (complete && t1 > t0) {
+                c.spmv_clk_ticks += (double)(t1 - t0);
+                c.spmv_clk_n++;
+            }
+        }
+    }
+    const int n_it = h.done ? h.n_iter : max_iter;
+    c.last_cg_iters = n_it;
+    if (info) {
+        info->converged = h.done ? h.converged : 0;
+        info->n_iterations = n_it;
+        info->found_indefiniteness = h.indef;
+        info->error = h.error;
+        info->reserved = 0;
+    }
+    // what mistark_dist_fused_bench replays: S_n, R_n and V_{n+1} of a converged solve found the messages M1_n / M2_n complete, and nobody has
+    // pushed behind them
+    c.fused_replay.valid = h.done && h.converged && !h.indef && n_it >= 1;
+    c.fused_replay.base = F.base;
+    c.fused_replay.n = n_it;
+    c.fused_replay.pattern = c.pattern_version;
+    return true;
+}
+// Solo durations of the three kernels of the fused iteration on this rank's shard: n launches each of S_n, R_n and V_{n+1} of the last
+// converged solve, back to back (see `replay` in k_cg_vec), between HIP events. NO other rank may start a solve meanwhile (the caller takes
+// turns: mistark_dist_fused_bench).
+void fused_pcg_replay(Context& c, int n_launches, double* s_us, double* r_us, double* v_us)
+{
+    if (!c.fused_replay.valid || c.fused_replay.pattern != c.pattern_version) throw Error("fused replay: no converged fused solve on the current matrix to replay");
+    FusedSolve F{c};
+    if (!fused_setup(c, F)) throw Error("fused replay: the fused iteration is not available");
+    F.base = c.fused_replay.base;
+    const int n = c.fused_replay.n;
+    hipEvent_t e[4];
+    for (auto& x : e) MS_CHECK(hipEventCreate(&x));
+    for (int w = 0; w < 3; w++) {
+        F.launch_S(n, nullptr, 1);
+        F.launch_R(n, 1);
+        F.launch_V(n + 1, false, 0, 0.0, 0.0, nullptr, 0, 1);
+    }
+    MS_CHECK(hipEventRecord(e[0], c.stream));
+    for (int i = 0; i < n_launches; i++) F.launch_S(n, nullptr, 1);
+    MS_CHECK(hipEventRecord(e[1], c.stream));
+    for (int i = 0; i < n_launches; i++) F.launch_R(n, 1);
+    MS_CHECK(hipEventRecord(e[2], c.stream));
+    for (int i = 0; i < n_launches; i++) F.launch_V(n + 1, false, 0, 0.0, 0.0, nullptr, 0, 1);
+    MS_CHECK(hipEventRecord(e[3], c.stream));
+    MS_CHECK(hipEventSynchronize(e[3]));
+    float ms[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < 3; i++) MS_CHECK(hipEventElapsedTime(&ms[i], e[i], e[i + 1]));
+    for (auto& x : e) (void)hipEventDestroy(x);
+    c.coll->check();
+    c.fused_replay.valid = false;  // (V has moved the vectors on)
+    if (s_us) *s_us = 1e3 * ms[0] / n_launches;
+    if (r_us) *r_us = 1e3 * ms[1] / n_launches;
+    if (v_us) *v_us = 1e3 * ms[2] / n_launches;
+}
+
 __global__ void k_copy_ctrl(const PcgCtrl* __restrict__ src, PcgCtrl* __restrict__ dst_host)
 {
     if (threadIdx.x == 0) {
@@ -3934,7 +4495,12 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     if (!c.have_matrix) throw Error("pcg: matrix not assembled");
     if (c.world > 1) {
         if (rhs_scale != 1.0) throw Error("pcg: a scaled right-hand side is a single-GPU shortcut");
-        pcg_sharded(c, rhs_dev, abs_tol, rel_tol, max_iter, stop_on_indef, info);
+        if (pcg_sharded_fused(c, rhs_dev, abs_tol, rel_tol, max_iter, stop_on_indef, info)) {
+            c.n_fused_solves++;
+        } else {
+            pcg_sharded(c, rhs_dev, abs_tol, rel_tol, max_iter, stop_on_indef, info);
+            c.n_unfused_solves++;
+        }
         return;
     }
     const int gv = grid_for(c.nbr, BLOCK, PCG_GRID);  // one block row per thread up to 262 144 block rows

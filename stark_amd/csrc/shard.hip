@@ -291,11 +291,16 @@ void shard_prepare(Context& c)
         S.send_stride = std::max<int64_t>(1, *std::max_element(S.n_send_of.begin(), S.n_send_of.end()));
         S.own_stride = std::max<int64_t>(1, *std::max_element(S.n_own_of.begin(), S.n_own_of.end()));
         S.grow_h.clear();
-        std::vector<int32_t> send_rows;
+        std::vector<int32_t> send_rows, send_pos_of_row;
+        std::vector<uint32_t> send_mask;
         for (int64_t r = 0; r < nbr; r++)
             if (S.owner[(size_t)r] == me) {
                 S.grow_h.push_back((int32_t)r);
-                if (pos_in_send[(size_t)r] >= 0) send_rows.push_back(local_of[(size_t)r]);
+                send_pos_of_row.push_back(pos_in_send[(size_t)r]);
+                if (pos_in_send[(size_t)r] >= 0) {
+                    send_rows.push_back(local_of[(size_t)r]);
+                    send_mask.push_back(need[(size_t)r] & ~(1u << me));
+                }
             }
         std::vector<int32_t> ghost_src;
         for (int o = 0; o < W; o++) {
@@ -320,6 +325,9 @@ void shard_prepare(Context& c)
         up(S.grow, S.grow_h);
         up(S.send_rows, send_rows);
         up(S.ghost_src, ghost_src);
+        up(S.send_pos_of_row, send_pos_of_row);
+        S.send_mask.ensure(std::max<size_t>(send_mask.size(), 1));
+        if (!send_mask.empty()) MS_CHECK(hipMemcpyAsync(S.send_mask.p, send_mask.data(), send_mask.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c.stream));
         up(S.grow_all, grow_all);
         S.sendbuf.ensure(3 * (size_t)S.send_stride);
         S.recvbuf.ensure(3 * (size_t)S.send_stride * (size_t)W);

@@ -97,9 +97,14 @@ class Engine:
     def dist_init_local(self, group, rank: int):
         self._ck(self.L.mistark_dist_init_local(self.h, group, rank))
 
+    def dist_init_ipc(self, comm):
+        """comm: a connected capi.IpcComm (one process per rank; include/mistark.h "IPC windows")."""
+        self._comm = comm  # (must outlive the engine)
+        self._ck(self.L.mistark_dist_init_ipc(self.h, comm.h))
+
     def dist_info(self):
-        out = (C.c_int64 * 6)()
-        self._ck(self.L.mistark_dist_info(self.h, out, 6))
+        out = (C.c_int64 * 8)()
+        self._ck(self.L.mistark_dist_info(self.h, out, 8))
         return list(out)
 
     def dist_row_owner(self) -> np.ndarray:

@@ -1,0 +1,111 @@
+"""GPU (run with `-m gpu`): the N > 1 launch path of bench.py with REAL OS processes — torch.distributed.run, gloo rendezvous, exchange of the
+IPC window handles, mistark_dist_init_ipc, row-sharded evaluation / assembly / PCG — on the ONE MI355X of the test box (all ranks on device
+0: MISTARK_BENCH_DEVICE; RCCL refuses two ranks on one device, the IPC-window transport does not care). The sharded run must take the
+single-rank run's decisions: the same Newton iterations, linear solves (progressive-projection retries included) and contact counts, and the
+same CG iterations up to the +-1 per solve the parity rule allows (the reductions are solve_pcg.h:180,201,217)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GRID = "12,12,12"
+ARGS = ["--steps", "8", "--warmup", "2", "--grid", GRID, "--no-cpu-baseline"]
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ)
+    env["MISTARK_BENCH_DEVICE"] = "0"
+    env["MISTARK_IPC_TIMEOUT_S"] = "20"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("MISTARK_BENCH_TRANSPORT", None)
+    return env
+
+
+def _torchrun(n, script, args, extra_env=None):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, script)] + args
+    env = _env()
+    env.update(extra_env or {})
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, timeout=900)
+
+
+def _launch(n, script, args):
+    r = _torchrun(n, script, args)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]  # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+def _worker(n, args, extra_env=None):
+    r = _torchrun(n, "tests/mp_sharded_worker.py", args, extra_env)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "MP-OK" in out, (out[-2000:], r.stderr.decode()[-3000:])
+    return out
+
+
+@pytest.fixture(scope="module")
+def single():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + ARGS, cwd=ROOT, env=_env(), capture_output=True, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    return json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_transport_selftest_between_processes(n):
+    out = _launch(n, "tools/ipc_selftest.py", [])
+    assert out["world"] == n and out["one_device"]
+    assert all(a > 0 and b > 0 for a, b in out["allgather_us_by_doubles [synchronised, in a train]"].values())
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_bench_launch_path_with_n_processes_takes_the_single_rank_decisions(single, n):
+    out = _launch(n, "bench.py", ["--gpus", str(n)] + ARGS)
+    assert out["n_gpus"] == n and out["config"]["transport"] == "ipc" and out["config"]["ranks_on_one_device"]
+    assert out["newton_iterations"] == single["newton_iterations"] == 8
+    assert out["linear_solves"] == single["linear_solves"]
+    assert abs(out["cg_iterations"] - single["cg_iterations"]) <= single["linear_solves"]
+    for k in ("n_contacts", "n_friction_contacts", "n_detections"):
+        assert out["contact"][k] == single["contact"][k], k
+    assert out["roofline"]["achieved"] > 0
+
+
+# ---- the cases of tests/test_gpu_sharded.py between real processes: the fused PCG iteration (kernels exchanging through the windows) -------
+@pytest.mark.parametrize("n", [2, 3, 8])
+@pytest.mark.parametrize("name", ["tetbeam_full_4x1x1", "tetbeam_eo_4x1x1_big", "cloth_shells_6", "contactmix_t1", "rbchain"])
+def test_stages_between_processes_equal_single_rank(name, n):
+    _worker(n, ["stages", name])
+
+
+def test_stages_between_processes_with_the_unfused_iteration_too():
+    """option no_fused_pcg: the five-launch iteration with two all-gathers through the windows' general region"""
+    _worker(2, ["stages", "contactmix_t1"], {"MP_ENGINE_OPTS": "no_fused_pcg=1"})
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_newton_between_processes(n):
+    _worker(n, ["newton"])
+
+
+@pytest.mark.parametrize("n", [3, 8])
+def test_contact_scene_between_processes(n):
+    """2 331 block rows, recursive coordinate bisection, frictional contact against a rigid box: Newton counts per step (+-1) and end state
+    against one rank; identical bits on all ranks"""
+    _worker(n, ["scene"])
+
+
+def test_full_size_headline_scene_between_processes():
+    """configs[3] at full size (998 976 tets) on 4 processes sharing the one GPU"""
+    _worker(4, ["fullsize"])
