@@ -180,6 +180,59 @@ def _rank_main(rank, world, port, name, result_dir):
     assert np.abs(x_full - xo).max() <= 1e-4 * max(np.abs(xo).max(), 1e-300)
     same = allgather(torch.tensor(x_full))
     assert all((s.numpy() == x_full).all() for s in same)         # identical bits on every rank
+
+    # ---- the same solve as the engine runs it between processes that exchange through windows (kernels.hip: pcg_sharded_fused): the
+    # recurrences of Chronopoulos & Gear (u = M^-1 r, w = A u, s = A p by recurrence), so that ONE message per iteration carries the three
+    # sums (gamma = r.u, rr = r.r, delta = w.u; p.Ap = delta - beta gamma / alpha_prev) and the halo of u travels on its own, hidden behind
+    # the interior rows of the SpMV. Here: two all-gathers per iteration of which only the scalar one is a dependency of the next step.
+    def halo_of(u_loc):
+        buf = torch.zeros(3 * stride, dtype=torch.float64)
+        mine_send = u_loc.reshape(-1, 3)[lrow[send_of[rank]]].reshape(-1)
+        buf[:len(mine_send)] = torch.tensor(mine_send)
+        allb = torch.stack(allgather(buf)).numpy()
+        return allb.reshape(world * stride, 3)[ghost_src].reshape(-1)
+
+    x2 = np.zeros(3 * n_own)
+    r = b.copy()
+    u = ev.apply_preconditioner(dinv, r)
+    p_ = np.zeros(3 * n_own)
+    s_ = np.zeros(3 * n_own)
+    u_loc = np.concatenate([u, halo_of(u)])                       # message M1_0
+    w = A_l @ u_loc
+    gamma, rr, delta = gsum([float(r @ u), float(r @ r), float(w @ u)])   # message M2_0
+    bb2 = rr
+    its2, conv2 = 0, bb2 < abs_tol * abs_tol
+    gamma_prev = alpha_prev = None
+    while not conv2 and its2 < 10000:
+        beta = 0.0 if gamma_prev is None else gamma / gamma_prev
+        pAp = delta if gamma_prev is None else delta - beta * gamma / alpha_prev
+        its2 += 1
+        if pAp <= 0.0:
+            break
+        alpha = gamma / pAp
+        p_ = u + beta * p_
+        s_ = w + beta * s_
+        x2 += alpha * p_
+        r -= alpha * s_
+        u = ev.apply_preconditioner(dinv, r)
+        u_loc = np.concatenate([u, halo_of(u)])                   # M1_k
+        w = A_l @ u_loc
+        gamma_prev, alpha_prev = gamma, alpha
+        gamma, rr, delta = gsum([float(r @ u), float(r @ r), float(w @ u)])   # M2_k
+        err = np.sqrt(rr / bb2)
+        if err < abs_tol or err < rel_tol:
+            conv2 = True
+    buf = torch.zeros(3 * pad, dtype=torch.float64)
+    buf[:3 * n_own] = torch.tensor(x2)
+    parts = allgather(buf)
+    x2_full = np.zeros(n)
+    for q_ in range(world):
+        rows_q = np.nonzero(owner == q_)[0]
+        x2_full.reshape(-1, 3)[rows_q] = parts[q_].numpy()[:3 * len(rows_q)].reshape(-1, 3)
+    assert conv2 == bool(info_o.converged) and abs(its2 - info_o.n_iterations) <= 1, (its2, info_o.n_iterations)
+    assert np.abs(x2_full - xo).max() <= 1e-4 * max(np.abs(xo).max(), 1e-300)
+    same = allgather(torch.tensor(x2_full))
+    assert all((s.numpy() == x2_full).all() for s in same)
     open(os.path.join(result_dir, "ok%d" % rank), "w").write("ok")
     dist.destroy_process_group()
 
