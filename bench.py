@@ -96,15 +96,14 @@ def host_cpu():
     return model, (len(cores) or logical), logical
 
 
-def cpu_baseline(nx, ny, nz, scene="contact", offset=(0.0, 0.0)):
-    """The UNMODIFIED reference (oracle/_ref/ref_harness, built by oracle/Makefile) timed on this host's cores: once with one thread per
-    physical core (capped at 64) and once with 8 threads (the figure SURVEY.md §8d asks for, comparable with the build container)."""
+def cpu_baseline(nx, ny, nz, scene="contact", offset=(0.0, 0.0), sweep=(8, 16, 32, 64), steps=2):
+    """The UNMODIFIED reference (oracle/_ref/ref_harness, built by oracle/Makefile) timed on this host's cores at several thread counts
+    (it does not scale monotonically: 8 threads beat 64 on this scene); `value` is the BEST of them, every leg is reported."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     model, physical, logical = host_cpu()
-    threads = max(1, min(physical, 64))
-    base = {"unit": "Newton-steps/s", "cores": threads, "kind": "reference", "cpu_model": model, "physical_cores": physical, "logical_cpus": logical}
+    base = {"unit": "Newton-steps/s", "cores": None, "kind": "reference", "cpu_model": model, "physical_cores": physical, "logical_cpus": logical}
     if not os.path.exists(harness):
-        return dict(base, value=None, sample="unavailable: oracle/_ref/ref_harness not built")
+        return dict(base, value=None, cores=0, sample="unavailable: oracle/_ref/ref_harness not built")
     common = ["nx=%d" % nx, "ny=%d" % ny, "nz=%d" % nz, "codegen=/tmp/mistark_bench_codegen", "outdir=/tmp/mistark_bench_out"]
     name = "tetblock"
     if scene == "contact":
@@ -112,25 +111,30 @@ def cpu_baseline(nx, ny, nz, scene="contact", offset=(0.0, 0.0)):
         common += ["L=1", "gap=%g" % GAP, "thickness=%g" % THICKNESS, "mu=%g" % MU, "kmin=%g" % KMIN, "bx=%g" % BOX[0], "bz=%g" % BOX[2], "boxfirst=1",
                    "ox=%.17g" % offset[0], "oy=%.17g" % offset[1]]
 
-    def run(n_threads, steps):
-        out = subprocess.run([harness, "time", name] + common + ["threads=%d" % n_threads, "steps=%d" % steps, "warmup=1"], check=True, capture_output=True, timeout=1500).stdout.decode()
+    def run(n_threads, n_steps):
+        out = subprocess.run([harness, "time", name] + common + ["threads=%d" % n_threads, "steps=%d" % n_steps, "warmup=1"], check=True, capture_output=True, timeout=1500).stdout.decode()
         return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
+    threads = sorted({max(1, min(t, logical)) for t in sweep})
     try:
-        subprocess.run([harness, "prime", name, "nx=2", "ny=2", "nz=2"] + common[3:] + ["threads=%d" % threads], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-        r = run(threads, 4)
-        res = dict(base, value=r["newton_steps_per_s"],
-                   sample="same scene, %d Newton iterations over 4 time steps after 1 warm-up step (pattern build + JIT excluded), %d threads" % (r["newton_iterations"], threads),
-                   ms_per_linear_solve=r["ms_per_linear_solve"], wall_s=r["wall_s"], newton_iterations=r["newton_iterations"], linear_solves=r.get("linear_solves"))
-        try:
-            r8 = run(8, 2)
-            res["threads_8"] = {"value": r8["newton_steps_per_s"], "ms_per_linear_solve": r8["ms_per_linear_solve"], "newton_iterations": r8["newton_iterations"], "wall_s": r8["wall_s"],
-                                "sample": "2 time steps after 1 warm-up step, 8 threads"}
-        except Exception as e:  # noqa: BLE001
-            res["threads_8"] = {"value": None, "sample": "failed: %r" % (e,)}
-        return res
+        subprocess.run([harness, "prime", name, "nx=2", "ny=2", "nz=2"] + common[3:] + ["threads=%d" % threads[0]], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     except Exception as e:  # noqa: BLE001
-        return dict(base, value=None, sample="failed: %r" % (e,))
+        return dict(base, value=None, cores=0, sample="failed: %r" % (e,))
+    legs = {}
+    for t in threads:
+        try:
+            r = run(t, steps)
+            legs[str(t)] = {"value": r["newton_steps_per_s"], "ms_per_linear_solve": r["ms_per_linear_solve"], "newton_iterations": r["newton_iterations"],
+                            "linear_solves": r.get("linear_solves"), "wall_s": r["wall_s"]}
+        except Exception as e:  # noqa: BLE001
+            legs[str(t)] = {"value": None, "sample": "failed: %r" % (e,)}
+    ok = {t: v for t, v in legs.items() if v.get("value")}
+    if not ok:
+        return dict(base, value=None, cores=0, sample="failed", by_threads=legs)
+    best = max(ok, key=lambda t: ok[t]["value"])
+    return dict(base, value=ok[best]["value"], cores=int(best), ms_per_linear_solve=ok[best]["ms_per_linear_solve"], newton_iterations=ok[best]["newton_iterations"],
+                linear_solves=ok[best]["linear_solves"], wall_s=ok[best]["wall_s"], by_threads=legs,
+                sample="same scene, %d time steps after 1 warm-up step (pattern build + JIT excluded) at %s threads; value = the best leg (%s threads)" % (steps, "/".join(str(t) for t in threads), best))
 
 
 def profile_traffic():
@@ -174,6 +178,48 @@ def profile_kernel_trace():
     return (best[2], "profiles/%s_kernel_stats.txt" % best[1]) if best else (None, None)
 
 
+PINNED_OFFSET = (0.00137, -0.00053)   # the placement on which the reference reproduces itself and the engine's counts equal its log
+HBM_GRID = (88, 88, 86)               # 7.99 M tets: the matrix (790 MB) is out of reach of the 256 MiB Infinity Cache
+
+
+def pinned_placement_run(S, capi, nx, ny, nz, device, steps, warmup, with_cpu):
+    """The same workload with the block moved PINNED_OFFSET off the box's axes: the scene the parity tests pin entry by entry against the
+    reference's step log (tests/test_gpu_fullsize.py). Same measurement as the headline figure, reported beside it."""
+    sim = build_scene(S, nx, ny, nz, device, "contact", offset=PINNED_OFFSET)
+    run_newton_steps(sim, S, capi, warmup)
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    newton, n_ls, n_cg, t_ls = run_newton_steps(sim, S, capi, steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    sim.close()
+    out = {"offset": list(PINNED_OFFSET), "value": newton / el, "unit": "Newton-steps/s", "ms_per_step": 1e3 * el / max(newton, 1), "ms_per_linear_solve": 1e3 * t_ls / max(n_ls, 1),
+           "linear_solves": n_ls, "cg_iterations": n_cg, "newton_iterations": newton, "steps": steps, "warmup": warmup,
+           "pinned_by": "tests/test_gpu_fullsize.py::test_full_size_first_time_steps_equal_the_reference_log_off_the_degenerate_placement"}
+    if with_cpu:
+        out["cpu_baseline"] = cpu_baseline(nx, ny, nz, "contact", PINNED_OFFSET, sweep=(8,), steps=2)
+    return out
+
+
+def hbm_resident_pass(S, capi, device):
+    """SpMV-only pass on the same scene at HBM_GRID (one Newton step to have an assembled matrix, then 50 back-to-back launches between HIP
+    events): the roofline figure with the matrix streaming from HBM instead of the Infinity Cache."""
+    import ctypes as C
+    nx, ny, nz = HBM_GRID
+    sim = build_scene(S, nx, ny, nz, device, "contact")
+    run_newton_steps(sim, S, capi, 1)
+    _, _, nbytes = sim.spmv_timing(reset=-1)
+    us = C.c_double()
+    if capi.lib().mistark_spmv_bench(sim.engine_handle(), 50, C.byref(us)) != 0:
+        raise RuntimeError(capi.lib().mistark_last_error(sim.engine_handle()))
+    ndofs = sim.info().ndofs
+    sim.close()
+    gbs = nbytes / (us.value * 1e-6) / 1e9
+    return {"grid": "%d,%d,%d" % HBM_GRID, "tets": 12 * nx * ny * nz, "dofs": ndofs, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": us.value * 1e-3, "launches_timed": 50,
+            "achieved": gbs, "unit": "GB/s", "frac": gbs / 8000.0, "timing": "HIP events around 50 back-to-back launches (mistark_spmv_bench)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -182,6 +228,7 @@ def main():
     ap.add_argument("--grid", type=str, default="44,44,43", help="hexahedra per dimension (12 tets each)")
     ap.add_argument("--scene", type=str, default="contact", choices=["contact", "clamped"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements of the default workload (pinned placement, HBM-resident SpMV pass)")
     ap.add_argument("--offset", type=str, default="0,0", help="block moved off the box's axes by (ox, oy) metres: the placement on which the reference reproduces itself "
                                                               "and the engine's Newton / solve / CG counts equal its log (DESIGN.md section 5); default: centred")
     a = ap.parse_args()
@@ -330,14 +377,22 @@ def main():
         traffic, traffic_src = profile_traffic()
         trace_ms, trace_src = profile_kernel_trace()
         n_tets = 12 * nx * ny * nz
-        # The kernel's duration inside the solver loop: the device-clock figure (what rocprofv3's kernel trace reports for the same launches:
-        # profiles/*_timeline.txt) when the engine delivered it, else the raw event bracket; both are reported below
+        default_workload = a.scene == "contact" and (nx, ny, nz) == (44, 44, 43) and world == 1
         achieved_events = (spmv_bytes / (spmv_ms * 1e-3)) / 1e9 if spmv_ms > 0 else 0.0
-        achieved = (spmv_bytes / (spmv_clk_ms * 1e-3)) / 1e9 if spmv_clk_ms else achieved_events
-        # a very short timed region may hold no sampled launch (only every 32nd SpMV of a solve is sampled): the back-to-back figure then
-        no_sample = not spmv_clk_ms and not spmv_ms > 0 and spmv_b2b_ms
-        if no_sample:
-            achieved = (spmv_bytes / (spmv_b2b_ms * 1e-3)) / 1e9
+        achieved_clock = (spmv_bytes / (spmv_clk_ms * 1e-3)) / 1e9 if spmv_clk_ms else None
+        achieved_b2b = (spmv_bytes / (spmv_b2b_ms * 1e-3)) / 1e9 if spmv_b2b_ms else None
+        # The headline figure uses the duration a reader can reproduce: the SpMV launches that did work in the committed rocprofv3 kernel trace of
+        # THIS command (profiles/<tag>_kernel_stats.txt, last line). The live figures of this run are reported beside it: the device clock
+        # (first wavefront in to last wavefront out: shorter than the trace's dispatch-packet span), the HIP event bracket (longer: dispatch
+        # and marker packets inside), and the back-to-back batch. Other workloads (no committed trace): the device clock, else the events.
+        if default_workload and trace_ms:
+            achieved, basis, basis_ms, basis_n = (spmv_bytes / (trace_ms * 1e-3)) / 1e9, "rocprofv3 kernel trace of this command: " + trace_src, trace_ms, None
+        elif achieved_clock:
+            achieved, basis, basis_ms, basis_n = achieved_clock, "device clock of sampled launches inside the timed region", spmv_clk_ms, spmv_clk_n
+        elif achieved_events > 0:
+            achieved, basis, basis_ms, basis_n = achieved_events, "HIP event bracket of sampled launches inside the timed region", spmv_ms, spmv_n
+        else:  # a very short timed region may hold no sampled launch (only every 32nd SpMV of a solve is sampled)
+            achieved, basis, basis_ms, basis_n = achieved_b2b or 0.0, "HIP events around 100 back-to-back launches after the timed region", spmv_b2b_ms, 100
         out = {
             "metric": "Newton-steps/s",
             # N>1: ONE scene, elements of every potential sharded over the GPUs (strong scaling: the work is fixed)
@@ -380,48 +435,58 @@ def main():
             "host_timers_s": {k: round(v, 6) for k, v in stage.items()},
             "contact": sim.contact_info() if a.scene == "contact" else None,
             "roofline": {
-                "kernel": "k_spmv_fused (3x3-block CSR in row-aligned chunks, float values, double vectors)" + ("" if world == 1 else " — rank 0's rows of the sharded matrix: bytes and duration of ONE GPU's launch"),
+                "kernel": "k_spmv_fused (3x3-block CSR in row-aligned chunks, float values, double vectors)" if world == 1 else
+                          "k_spmv_halo (the same SpMV over rank 0's rows of the sharded matrix, ghost columns polled from the IPC window): bytes and duration of ONE GPU's launch",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": 8000.0,
                 "unit": "GB/s",
                 "frac": achieved / 8000.0,
+                "basis": basis,
+                "avg_launch_ms": basis_ms,
+                "launches_timed": basis_n,
+                "algorithmic_bytes_per_launch": spmv_bytes,
                 # not measured in this run (PMC counters need their own rocprofv3 passes): taken from the newest committed profile of the same
                 # command, named in traffic_source; null for other workloads or when no such profile exists
-                "traffic": traffic if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
-                "traffic_source": traffic_src if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
+                "traffic": traffic if default_workload else None,
+                "traffic_source": traffic_src if default_workload else None,
                 # the matrix (99 MB) and the vectors fit the 256 MiB Infinity Cache: FETCH_SIZE counts cache hits too, so `achieved` is fabric-side
                 # bandwidth; a plain float4 stream of the same value buffer reaches 6.3 TB/s on this box (tools/spmv_sweep.py, variant 9)
                 "frac_of_stream_ceiling": achieved / 6300.0,
-                "working_set": "Infinity-Cache resident (matrix 99 MB + vectors)",
-                "algorithmic_bytes_per_launch": spmv_bytes,
-                "avg_launch_ms": spmv_b2b_ms if no_sample else (spmv_clk_ms if spmv_clk_ms else spmv_ms),
-                "launches_timed": 100 if no_sample else (spmv_clk_n if spmv_clk_ms else spmv_n),
-                "timing": "HIP events around 100 back-to-back launches after the timed region (no sampled launch fell into it)" if no_sample else
-                          ("device clock: every workgroup of a sampled launch (every 32nd SpMV of the timed region) stamps its start and end with s_memrealtime, "
-                           "duration = max(end) - min(start); agrees with rocprofv3's kernel trace of the same launches" + ("" if world == 1 else "; rank 0's launches of the sharded solve")) if spmv_clk_ms else "HIP event bracket",
-                # the same launches bracketed by a pair of HIP events on the engine's stream (dispatch latency and the marker packets included)
-                "event_bracket_launch_ms": spmv_ms,
-                "event_bracket_launches": spmv_n,
-                "achieved_event_bracket": achieved_events,
-                "frac_event_bracket": achieved_events / 8000.0,
-                # not measured in this run: the same kernel's launches with real work in the newest committed rocprofv3 kernel trace of this command
-                # (under the tracer; its duration spans the dispatch packet, the device clock above spans first wavefront in to last wavefront out)
-                "rocprofv3_profile_launch_ms": trace_ms if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
-                "rocprofv3_profile_source": trace_src if (a.scene == "contact" and (nx, ny, nz) == (44, 44, 43)) else None,
-                # every bracketed launch is followed by an EMPTY event bracket on the same stream: what two event records cost by themselves
-                "event_pair_overhead_ms": spmv_ev_overhead_ms,
-                # the same launch 100 times back to back after the timed region (one event pair around the batch, no dispatch gap per
-                # launch): what rocprofv3 reports as the kernel's own duration
-                "back_to_back_launch_ms": spmv_b2b_ms,
+                "working_set": "Infinity-Cache resident (matrix 99 MB + vectors)" if (nx, ny, nz) == (44, 44, 43) else None,
+                # ---- measured live in THIS run, every 32nd SpMV launch of the timed region:
+                "live": {
+                    # every workgroup of a sampled launch stamps its start and end on the device's constant clock (s_memrealtime); duration = max(end) - min(start)
+                    "device_clock": {"launch_ms": spmv_clk_ms, "launches": spmv_clk_n, "achieved": achieved_clock, "frac": achieved_clock / 8000.0 if achieved_clock else None},
+                    # the same launches between a pair of HIP events on the engine's stream (dispatch latency and the marker packets included);
+                    # event_pair_overhead_ms: an EMPTY bracket recorded right behind each
+                    "event_bracket": {"launch_ms": spmv_ms, "launches": spmv_n, "achieved": achieved_events, "frac": achieved_events / 8000.0, "event_pair_overhead_ms": spmv_ev_overhead_ms},
+                    # 100 launches back to back after the timed region, one event pair around the batch
+                    "back_to_back": {"launch_ms": spmv_b2b_ms, "launches": 100, "achieved": achieved_b2b, "frac": achieved_b2b / 8000.0 if achieved_b2b else None},
+                },
+                # the committed rocprofv3 kernel trace of this command (under the tracer; its duration spans the dispatch packet)
+                "rocprofv3_profile_launch_ms": trace_ms if default_workload else None,
+                "rocprofv3_profile_source": trace_src if default_workload else None,
             },
         }
+        if default_workload and offset == (0.0, 0.0) and not a.no_extras:
+            sim.close()
+            sim = None
+            try:
+                out["roofline"]["hbm_resident"] = hbm_resident_pass(S, capi, device)
+            except Exception as e:  # noqa: BLE001
+                out["roofline"]["hbm_resident"] = {"unavailable": repr(e)}
+            try:
+                out["pinned_placement"] = pinned_placement_run(S, capi, nx, ny, nz, device, a.steps, a.warmup, not a.no_cpu_baseline)
+            except Exception as e:  # noqa: BLE001
+                out["pinned_placement"] = {"unavailable": repr(e)}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nx, ny, nz, a.scene, offset)
         else:
             out["cpu_baseline"] = {"value": None, "unit": "Newton-steps/s", "cores": 0, "kind": "reference", "sample": "skipped (N>1 or --no-cpu-baseline)"}
         print(json.dumps(out))
-    sim.close()
+    if sim is not None:
+        sim.close()
     if dist is not None:
         dist.barrier()  # (nobody unmaps a window another rank may still be storing into)
         if comm is not None:

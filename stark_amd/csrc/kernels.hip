@@ -2940,6 +2940,30 @@ struct XDir
     }
 };
 __device__ __forceinline__ double row_dot_nostore(const XPlain& X, size_t r3, double y0, double y1, double y2) { return X.row_dot(r3, y0, y1, y2); }
+// Measurement only (spmv_variant 12; north_star names "SoA node/DoF arrays"): the vectors as three arrays x[n], y[n], z[n] instead of the
+// reference's interleaved (x, y, z) per node. A block's gather then touches three cache lines in three regions instead of one 24-byte run.
+struct XSoA
+{
+    const double* x;  // [3][n]: component-major copy of the vector
+    size_t n;
+    __device__ __forceinline__ void load(size_t c3, double& x0, double& x1, double& x2) const
+    {
+        const size_t c = c3 / 3;
+        x0 = x[c];
+        x1 = x[n + c];
+        x2 = x[2 * n + c];
+    }
+    __device__ __forceinline__ bool has_dot() const { return true; }
+    __device__ __forceinline__ double row_dot(size_t r3, double y0, double y1, double y2) const
+    {
+        double p0, p1, p2;
+        load(r3, p0, p1, p2);
+        return p0 * y0 + p1 * y1 + p2 * y2;
+    }
+    __device__ __forceinline__ void row_pre(size_t r3, double& p0, double& p1, double& p2) const { load(r3, p0, p1, p2); }
+    __device__ __forceinline__ double row_dot_pre(size_t, double p0, double p1, double p2, double y0, double y1, double y2) const { return p0 * y0 + p1 * y1 + p2 * y2; }
+};
+__device__ __forceinline__ double row_dot_nostore(const XSoA& X, size_t r3, double y0, double y1, double y2) { return X.row_dot(r3, y0, y1, y2); }
 __device__ __forceinline__ double row_dot_nostore(const XDir& X, size_t r3, double y0, double y1, double y2) { return X.row_dot_nostore(r3, y0, y1, y2); }
 
 // v_mov_b32_dpp on both halves; BOUND: lanes without a source receive 0, otherwise (and in rows the mask disables) 0 as well (old = 0)
@@ -3255,6 +3279,19 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_fused(int g0, int gr, int g1, St
         }
     }
 }
+// measurement only (spmv_variant 12): the static part with SoA input (see XSoA); y stays interleaved
+__global__ __launch_bounds__(BLOCK) void k_spmv_soa(int g0, StaticPart m, XSoA X, double* __restrict__ y, double* __restrict__ partials)
+{
+    spmv_chunked_static<0>((int)blockIdx.x, g0, m.vals, m.scol, m.tile_first_row, m.n_chunks, m.chunk_tiles, X, y, partials);
+}
+__global__ __launch_bounds__(BLOCK) void k_to_soa(const double* __restrict__ v, int64_t n, double* __restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    out[i] = v[3 * i];
+    out[n + i] = v[3 * i + 1];
+    out[2 * n + i] = v[3 * i + 2];
+}
 // The PCG's iteration k as the solver launches it: what k_pcg_dir did for iteration k-1 (sums of r.r and r.z, convergence test, beta) in the
 // prologue of every workgroup (all of them compute the same numbers from the same partial sums; workgroup 0 records them), then
 // q = A p with p = z + beta p_old formed on the fly and stored by the lanes that finish a row.
@@ -3431,6 +3468,15 @@ double spmv_bench(Context& c, int n)
             case 11: hipLaunchKernelGGL(k_spmv_products_only, dim3(c.spmv_grid_cap > 0 ? c.spmv_grid_cap : 1024), dim3(BLOCK), 0, c.stream, (const float*)c.part[0].vals.p, (const uint32_t*)c.part[0].scol.p, c.part[0].ntiles, (const double*)c.p.p, c.partials.p); break;
             case 9: hipLaunchKernelGGL(k_stream_ref, dim3(2048), dim3(BLOCK), 0, c.stream, (const float4*)c.part[0].vals.p, (size_t)c.part[0].ntiles * 144, c.partials.p); break;
             case 3: launch_spmv<3>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr, false); break;
+            case 12: {  // SoA input vector (static part only; compare with variant 0 on a contact-free matrix or read it as a lower bound)
+                int g0, gr, g1;
+                StaticPart sp;
+                DynPart d;
+                spmv_launch_shape(c, g0, gr, g1, sp, d);
+                if (i == 0) hipLaunchKernelGGL(k_to_soa, dim3(grid_for(c.nbr)), dim3(BLOCK), 0, c.stream, (const double*)c.p.p, c.nbr, c.tmp_a.p);
+                hipLaunchKernelGGL(k_spmv_soa, dim3(g0), dim3(BLOCK), 0, c.stream, g0, sp, XSoA{c.tmp_a.p, (size_t)c.nbr}, c.q.p, c.partials.p);
+                break;
+            }
             default: launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr, false);  // as inside the solver: k_pcg_step adds the contact rows
         }
     }

@@ -3,7 +3,8 @@ matrix (790 MB: out of reach of the Infinity Cache).
 
 Variants (mistark_set_option "spmv_variant"): 0 = the solver's launch (static chunks + contact part, contact rows left to the consumer),
 1 = the same without the row reduction (loads + block products), 3 = without the matrix value loads, 9 = plain float4 stream of the value
-buffer (floor of the memory system for this matrix), 11 = loads + gather + products in the simplest possible loop."""
+buffer (floor of the memory system for this matrix), 11 = loads + gather + products in the simplest possible loop, 12 = the solver's
+kernel on the static part with the input vector in SoA layout (x[n] | y[n] | z[n]) instead of interleaved (north_star's "SoA node/DoF arrays")."""
 import ctypes as C
 import os
 import sys
