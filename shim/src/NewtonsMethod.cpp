@@ -8,8 +8,20 @@
 //   every solve()            sizes and pointers re-read (the caller owns and may resize everything), host arrays uploaded, settings
 //                            translated, mistark_newton_solve, DoFs written back to the caller's arrays
 //   every Newton callback    the DoFs are brought to the caller's arrays first (STARK's callbacks read them there: contact detection,
-//                            validity checks), and after before_energy_evaluation the tables the callback may have refilled
-//                            (connectivity of every potential whose size or address changed, all arrays) go back to the device
+//                            validity checks), and after before_energy_evaluation what the callback may have refilled goes back to the
+//                            device — and only that (see "What is re-sent" below)
+// What is re-sent. The reference reads every table and array through its lambdas at every evaluation; sending everything at every evaluation
+// (round 2: mistark_upload(-1) + update_connectivity of all 35 contact tables per callback, tens of MB over PCIe and a layout rebuild per
+// line-search trial) is what made the drop-in slow. Now every connectivity table and every bound array carries a 64-bit fingerprint of its
+// bytes:
+//   solve()                  every table and array is fingerprinted (in parallel when OpenMP is on); what changed since the engine last saw it
+//                            is sent — an in-place edit at an unchanged address and size (re-targeted attachments, a swapped prescribed-point
+//                            list: ADVICE r02) is caught here
+//   before_energy_evaluation tables of contact_* / friction_* potentials and every array up to SMALL_ARRAY doubles are fingerprinted and sent
+//                            when changed (the callback's own products: contact tables, friction data, stiffness scalars); larger tables and
+//                            arrays are re-checked by address and size only (a callback that rewrites a LARGE array in place inside the
+//                            Newton loop needs MISTARK_SHIM_STRICT=1: everything fingerprinted at every evaluation)
+// The DoF vector itself never travels host -> device inside a solve: the engine owns it there.
 // MISTARK_SHIM_DRY=1: registration only on a registration-only context (no GPU; solve() returns Successful without touching the DoFs);
 // MISTARK_SHIM_DESCRIBE=<file>: the registration (mistark_describe) is written there after every solve.
 #include "mistark_symx/NewtonsMethod.h"
@@ -19,6 +31,8 @@
 
 #include <algorithm>
 
+#include <chrono>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -42,6 +56,10 @@ namespace symx
 			int id = -1;
 			const double* host = nullptr;
 			int64_t n = -1;
+			int stride = 0;
+			bool is_dof = false;
+			uint64_t print = 0;     // fingerprint of the bytes the engine holds
+			bool have_print = false;
 		};
 		std::map<std::pair<std::uintptr_t, int>, Arr> arrays;  // (DataMap id, stride) -> engine array
 		struct Pot
@@ -49,7 +67,70 @@ namespace symx
 			int id = -1;
 			const int32_t* conn = nullptr;
 			int32_t n_elem = -1;
+			int stride = 0;
+			bool dynamic = false;   // contact_* / friction_*: refilled inside the Newton loop
+			uint64_t print = 0;
 		};
+		static constexpr int64_t SMALL_ARRAY = 32768;  // doubles: arrays up to this size are fingerprinted at every evaluation
+		bool strict = false;        // MISTARK_SHIM_STRICT=1
+		int64_t n_uploads = 0, n_table_updates = 0, bytes_sent = 0;  // statistics (MISTARK_SHIM_STATS=1 prints them at destruction)
+		double t_callbacks = 0.0, t_sync = 0.0, t_dofs = 0.0, t_solve = 0.0;  // seconds: the caller's callbacks, sync(), DoF transfers, all of solve()
+		static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+		template <class F>
+		auto timed_cb(F&& f)
+		{
+			const double t0 = now();
+			dofs_to_host();
+			const double t1 = now();
+			t_dofs += t1 - t0;
+			struct Acc
+			{
+				double& t;
+				double t0;
+				~Acc() { t += now() - t0; }
+			} acc{t_callbacks, t1};
+			return f();
+		}
+
+		// 64-bit fingerprint of a byte range: four multiply-xorshift lanes over 32-byte blocks, folded; chunks of 1 MiB are hashed
+		// independently (OpenMP when the build has it) and combined in order
+		// (the reference's build recipes compile this file at low optimisation levels: the hash is forced inline and optimised by itself)
+		__attribute__((always_inline)) static inline uint64_t mix(uint64_t h, uint64_t v)
+		{
+			h ^= v;
+			h *= 0x9E3779B97F4A7C15ull;
+			return h ^ (h >> 29);
+		}
+		__attribute__((optimize("O3"))) static uint64_t fingerprint_chunk(const unsigned char* p, size_t n)
+		{
+			uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull, h2 = 0xA4093822299F31D0ull, h3 = 0x082EFA98EC4E6C89ull;
+			size_t i = 0;
+			for (; i + 32 <= n; i += 32) {
+				uint64_t w[4];
+				std::memcpy(w, p + i, 32);
+				h0 = mix(h0, w[0]);
+				h1 = mix(h1, w[1]);
+				h2 = mix(h2, w[2]);
+				h3 = mix(h3, w[3]);
+			}
+			uint64_t tail = 0;
+			for (; i < n; i++) tail = (tail << 8) | p[i];
+			return mix(mix(mix(mix(h0, h1), h2), h3), tail ^ (uint64_t)n);
+		}
+		static uint64_t fingerprint(const void* data, size_t bytes)
+		{
+			const unsigned char* p = static_cast<const unsigned char*>(data);
+			constexpr size_t CH = 1u << 20;
+			const long n_ch = (long)((bytes + CH - 1) / CH);
+			if (n_ch <= 1) return fingerprint_chunk(p, bytes);
+			std::vector<uint64_t> part((size_t)n_ch);
+			const int n_thr = (int)std::min<long>(n_ch, 16);
+#pragma omp parallel for schedule(static) num_threads(n_thr)
+			for (long c = 0; c < n_ch; c++) part[(size_t)c] = fingerprint_chunk(p + (size_t)c * CH, std::min(CH, bytes - (size_t)c * CH));
+			uint64_t h = 0x452821E638D01377ull;
+			for (uint64_t v : part) h = mix(h, v);
+			return h;
+		}
 		std::vector<Pot> pots;
 		std::vector<std::pair<const double*, int64_t>> dof_sets;
 
@@ -59,6 +140,9 @@ namespace symx
 		}
 		~Impl()
 		{
+			if (std::getenv("MISTARK_SHIM_STATS"))
+				std::cerr << "mistark shim: " << n_uploads << " array uploads, " << n_table_updates << " table updates, " << bytes_sent / 1e6 << " MB sent to the engine; of " << t_solve
+				          << " s in solve(): " << t_callbacks << " s in the caller's callbacks, " << t_sync << " s in sync(), " << t_dofs << " s bringing DoFs to the caller" << std::endl;
 			if (ctx) mistark_destroy(ctx);
 		}
 
@@ -66,6 +150,8 @@ namespace symx
 		{
 			const char* dry_env = std::getenv("MISTARK_SHIM_DRY");
 			dry = dry_env && dry_env[0] == '1';
+			const char* strict_env = std::getenv("MISTARK_SHIM_STRICT");
+			strict = strict_env && strict_env[0] == '1';
 			if (dry) {
 				check(mistark_create_dry(&ctx), "mistark_create_dry");
 			} else {
@@ -75,9 +161,11 @@ namespace symx
 			}
 		}
 
-		// DoF sets, arrays and potentials as the caller holds them right now. Returns true when anything changed on the engine side.
-		void sync(GlobalPotential& gp, bool upload)
+		// DoF sets, arrays and potentials as the caller holds them right now; what changed goes to the engine. full: fingerprint everything
+		// (solve()); otherwise (inside the Newton loop) only what a before_energy_evaluation callback produces (see the file header).
+		void sync(GlobalPotential& gp, bool full)
 		{
+			full = full || strict;
 			if (!ctx) create();
 			// ---- DoF sets (GlobalPotential::add_dof, GlobalPotential.h:55-61)
 			const auto& dof_maps = gp.get_dof_maps();
@@ -110,11 +198,15 @@ namespace symx
 					if (a.id < 0) {
 						a.id = dof_set >= 0 ? mistark_dof_array(ctx, dof_set, m.stride) : mistark_array(ctx, host, n, m.stride);
 						check(a.id, "mistark_array");
+						a.have_print = false;
 					} else if (dof_set < 0 && (a.host != host || a.n != n)) {
 						check(mistark_array_rebind(ctx, a.id, host, n), "mistark_array_rebind");
+						a.have_print = false;
 					}
 					a.host = host;
 					a.n = n;
+					a.stride = (int)m.stride;
+					a.is_dof = dof_set >= 0;
 					bs.push_back(mistark_binding{a.id, m.stride, m.connectivity_index});
 				}
 				const int32_t n_elem = mws->conn.n_elements();
@@ -149,15 +241,47 @@ namespace symx
 					if (name.rfind("contact_", 0) == 0 || name.rfind("friction_", 0) == 0) check(mistark_potential_set_dynamic(ctx, P.id, 1), "mistark_potential_set_dynamic");
 					P.conn = conn;
 					P.n_elem = n_elem;
+					P.stride = mws->conn.stride;
+					P.dynamic = name.rfind("contact_", 0) == 0 || name.rfind("friction_", 0) == 0;
+					P.print = n_elem > 0 ? fingerprint(conn, (size_t)n_elem * (size_t)P.stride * sizeof(int32_t)) : 0;
 					pots.push_back(P);
-				} else if (pots[pi].conn != conn || pots[pi].n_elem != n_elem || name.rfind("contact_", 0) == 0 || name.rfind("friction_", 0) == 0) {
-					// (the reference refills its contact tables in place: the same address may hold other rows)
-					check(mistark_potential_update_connectivity(ctx, pots[pi].id, conn, n_elem), "mistark_potential_update_connectivity");
-					pots[pi].conn = conn;
-					pots[pi].n_elem = n_elem;
+				} else {
+					// The reference refills tables in place: the same address and size may hold other rows. Tables the Newton loop refills are
+					// fingerprinted at every evaluation, the others at every solve(); only a table whose bytes changed is sent (each update
+					// makes the engine re-validate its indices and rebuild its incidence lists).
+					Pot& P = pots[pi];
+					bool changed = P.conn != conn || P.n_elem != n_elem;
+					if (!changed && n_elem > 0 && (full || P.dynamic)) {
+						const uint64_t h = fingerprint(conn, (size_t)n_elem * (size_t)P.stride * sizeof(int32_t));
+						changed = h != P.print;
+						P.print = h;
+					} else if (changed) {
+						P.print = n_elem > 0 ? fingerprint(conn, (size_t)n_elem * (size_t)P.stride * sizeof(int32_t)) : 0;
+					}
+					if (changed) {
+						check(mistark_potential_update_connectivity(ctx, P.id, conn, n_elem), "mistark_potential_update_connectivity");
+						n_table_updates++;
+						bytes_sent += (int64_t)n_elem * P.stride * 4;
+						P.conn = conn;
+						P.n_elem = n_elem;
+					}
 				}
 			}
-			if (upload && !dry) check(mistark_upload(ctx, -1), "mistark_upload");
+			if (dry) return;
+			// ---- arrays: what changed since the engine last saw it (DoF views never travel this way: mistark_dofs_from_host_arrays at solve())
+			for (auto& kv : arrays) {
+				Arr& a = kv.second;
+				if (a.id < 0 || a.is_dof || !a.host || a.n <= 0) continue;
+				const int64_t doubles = a.n * (int64_t)a.stride;
+				if (a.have_print && !full && doubles > SMALL_ARRAY) continue;
+				const uint64_t h = fingerprint(a.host, (size_t)doubles * sizeof(double));
+				if (a.have_print && h == a.print) continue;
+				check(mistark_upload(ctx, a.id), "mistark_upload");
+				a.print = h;
+				a.have_print = true;
+				n_uploads++;
+				bytes_sent += doubles * 8;
+			}
 		}
 
 		// ---- C callbacks of mistark_newton_solve -> SolverCallbacks (solver_utils.h:29-117). STARK's callbacks read the DoFs from the
@@ -167,17 +291,18 @@ namespace symx
 		static void cb_before_eval(void* u)
 		{
 			Impl& s = I(u);
-			s.dofs_to_host();
-			s.self->callbacks->run_before_energy_evaluation();
-			s.sync(*s.self->global_potential, /*upload=*/true);  // tables and data the callback refilled
+			s.timed_cb([&] { s.self->callbacks->run_before_energy_evaluation(); return 0; });
+			const double t0 = now();
+			s.sync(*s.self->global_potential, /*full=*/false);  // tables and data the callback refilled
+			s.t_sync += now() - t0;
 		}
-		static int cb_initial_valid(void* u) { I(u).dofs_to_host(); return I(u).self->callbacks->run_is_initial_state_valid() ? 1 : 0; }
-		static int cb_intermediate_valid(void* u) { I(u).dofs_to_host(); return I(u).self->callbacks->run_is_intermediate_state_valid() ? 1 : 0; }
-		static void cb_on_invalid(void* u) { I(u).dofs_to_host(); I(u).self->callbacks->run_on_intermediate_state_invalid(); }
-		static void cb_on_armijo(void* u) { I(u).dofs_to_host(); I(u).self->callbacks->run_on_armijo_fail(); }
-		static int cb_is_converged(void* u) { I(u).dofs_to_host(); return I(u).self->callbacks->run_is_converged() ? 1 : 0; }
-		static int cb_converged_valid(void* u) { I(u).dofs_to_host(); return I(u).self->callbacks->run_is_converged_state_valid() ? 1 : 0; }
-		static double cb_max_step(void* u) { I(u).dofs_to_host(); return I(u).self->callbacks->run_max_allowed_step(); }
+		static int cb_initial_valid(void* u) { return I(u).timed_cb([&] { return I(u).self->callbacks->run_is_initial_state_valid() ? 1 : 0; }); }
+		static int cb_intermediate_valid(void* u) { return I(u).timed_cb([&] { return I(u).self->callbacks->run_is_intermediate_state_valid() ? 1 : 0; }); }
+		static void cb_on_invalid(void* u) { I(u).timed_cb([&] { I(u).self->callbacks->run_on_intermediate_state_invalid(); return 0; }); }
+		static void cb_on_armijo(void* u) { I(u).timed_cb([&] { I(u).self->callbacks->run_on_armijo_fail(); return 0; }); }
+		static int cb_is_converged(void* u) { return I(u).timed_cb([&] { return I(u).self->callbacks->run_is_converged() ? 1 : 0; }); }
+		static int cb_converged_valid(void* u) { return I(u).timed_cb([&] { return I(u).self->callbacks->run_is_converged_state_valid() ? 1 : 0; }); }
+		static double cb_max_step(void* u) { return I(u).timed_cb([&] { return I(u).self->callbacks->run_max_allowed_step(); }); }
 	};
 
 	NewtonsMethod::NewtonsMethod(spGlobalPotential global_potential, spContext context, spSolverCallbacks callbacks)
@@ -197,7 +322,15 @@ namespace symx
 	{
 		auto _t = this->context->logger->time("newton_solve");
 		Impl& s = *impl;
-		s.sync(*global_potential, /*upload=*/true);
+		const double t_begin = Impl::now();
+		struct SolveTimer
+		{
+			Impl& s;
+			double t0;
+			~SolveTimer() { s.t_solve += Impl::now() - t0; }
+		} solve_timer{s, t_begin};
+		s.sync(*global_potential, /*full=*/true);
+		s.t_sync += Impl::now() - t_begin;
 		if (const char* path = std::getenv("MISTARK_SHIM_DESCRIBE")) {
 			const int64_t n = mistark_describe(s.ctx, nullptr, 0);
 			std::string buf((size_t)n, '\0');

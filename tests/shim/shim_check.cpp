@@ -5,6 +5,8 @@
 // Built by oracle/Makefile (target _ref/shim_check) only where /root/reference exists; test infrastructure, not shipped.
 #include <stark>
 
+#include <chrono>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 
@@ -23,7 +25,8 @@ int main(int argc, char** argv)
     settings.output.enable_output = with_output;
     settings.output.fps = 30;
     settings.execution.n_threads = 1;
-    settings.simulation.init_frictional_contact = scene == "blockbox" || scene == "mixed";
+    settings.simulation.init_frictional_contact = scene == "blockbox" || scene == "mixed" || scene == "benchblock";
+    if (const char* env = std::getenv("SHIM_THREADS")) settings.execution.n_threads = std::atoi(env);  // (the reference's host-side work: contact detection)
     stark::Simulation sim(settings);
     if (scene == "blockbox") {
         // the scene of tests/test_shim_cpu.py: rigid box (registered first) + fixed, 2 x 2 x 2 Soft_Rubber block, frictional contact
@@ -35,6 +38,27 @@ int main(int argc, char** argv)
         auto [sV, sT] = stark::generate_tet_grid({ 0.0, 0.0, 0.6 }, { 1.0, 1.0, 1.0 }, { 2, 2, 2 });
         auto block = sim.presets->deformables->add_volume("block", sV, sT, stark::Volume::Params::Soft_Rubber());
         sim.interactions->contact->set_friction(block.contact, box.contact, 0.5);
+    } else if (scene == "benchblock" || scene == "benchclamped") {
+        // bench.py's workload through the reference's own classes (SHIM_GRID=nx,ny,nz, default 10,10,10): benchblock = configs[3] (block 1.5 mm
+        // above a fixed rigid box {3,3,0.1}, thickness 1e-3, mu 0.5, kmin 1e8; the reference's host detection feeds the contact tables),
+        // benchclamped = the contact-free variant (bottom face clamped). For timing the drop-in path beside the engine's own scene mirror.
+        int g[3] = { 10, 10, 10 };
+        if (const char* env = std::getenv("SHIM_GRID")) std::sscanf(env, "%d,%d,%d", &g[0], &g[1], &g[2]);
+        if (scene == "benchblock") {
+            auto gp = stark::EnergyFrictionalContact::GlobalParams();
+            gp.default_contact_thickness = 1e-3;
+            gp.min_contact_stiffness = 1e8;
+            sim.interactions->contact->set_global_params(gp);
+            auto [bV, bT, box] = sim.presets->rigidbodies->add_box("box", 1.0, { 3.0, 3.0, 0.1 });
+            sim.rigidbodies->add_constraint_fix(box.rigidbody);
+            auto [sV, sT] = stark::generate_tet_grid({ 0.0, 0.0, 0.05 + 0.0015 + 0.5 }, { 1.0, 1.0, 1.0 }, { g[0], g[1], g[2] });
+            auto block = sim.presets->deformables->add_volume("block", sV, sT, stark::Volume::Params::Soft_Rubber());
+            sim.interactions->contact->set_friction(block.contact, box.contact, 0.5);
+        } else {
+            auto [sV, sT] = stark::generate_tet_grid({ 0.0, 0.0, 0.6 }, { 1.0, 1.0, 1.0 }, { g[0], g[1], g[2] });
+            auto block = sim.presets->deformables->add_volume("block", sV, sT, stark::Volume::Params::Soft_Rubber());
+            sim.deformables->prescribed_positions->add_inside_aabb(block.point_set, { 0.0, 0.0, 0.1 }, { 2.0, 2.0, 2e-3 }, stark::EnergyPrescribedPositions::Params().set_stiffness(1e7));
+        }
     } else if (scene == "mixed") {
         // BASELINE configs[4] in small (oracle/ref_harness.cpp scene_mixed; tests/test_gpu_scene.py _build_mixed): floor, chain of hinged
         // boxes, tet block, cloth; contact and friction between the layers
@@ -79,8 +103,27 @@ int main(int argc, char** argv)
         std::cerr << "unknown scene " << scene << std::endl;
         return 2;
     }
-    for (int s = 0; s < steps; s++) sim.run_one_time_step();
+    // the first step registers everything and builds the sparsity pattern: timed apart from the rest
+    const char* dry_env = std::getenv("MISTARK_SHIM_DRY");
+    const bool dry = dry_env && dry_env[0] == '1';
+    auto newton_total = [&] {
+        long n = 0;
+        if (dry) return n;  // (registration only: nothing is solved, the logger has no such series)
+        for (int v : sim.get_stark().context->logger->get_int_series("newton_iterations")) n += v;
+        return n;
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    if (steps > 0) sim.run_one_time_step();
+    const auto t1 = std::chrono::steady_clock::now();
+    const long n1 = newton_total();
+    for (int s = 1; s < steps; s++) sim.run_one_time_step();
+    const auto t2 = std::chrono::steady_clock::now();
+    const long n2 = newton_total();
+    const double first_s = std::chrono::duration<double>(t1 - t0).count(), rest_s = std::chrono::duration<double>(t2 - t1).count();
     std::cout << "shim_check: " << steps << " step(s) of '" << scene << "' done" << std::endl;
+    std::cout.precision(6);
+    std::cout << "{\"scene\":\"" << scene << "\",\"steps\":" << steps << ",\"first_step_s\":" << first_s << ",\"newton_first\":" << n1 << ",\"rest_s\":" << rest_s
+              << ",\"newton_rest\":" << (n2 - n1) << ",\"newton_steps_per_s_after_first\":" << (rest_s > 0 ? (n2 - n1) / rest_s : 0.0) << "}" << std::endl;
     if (with_output) sim.get_stark().print();  // run summary + final YAML log (Stark.cpp:254-282)
     if (argc > 3) {
         // what the run produced: Newton iterations per solve (the series the shim logs like the reference, NewtonsMethod.cpp:249) and the
