@@ -182,6 +182,7 @@ struct Potential
     int n_list = 0, n_eown_list = 0;  // length of the list and of its leading part (elements whose energy counts here)
     int n_eown = 0;                   // elements the energy-only kernels run over (n_elem, or n_eown_list)
     int n_key = 0;                    // elements in the key space / pools of this context (n_elem, or n_list when sharded with a list)
+    bool dyn_pool = false;       // its node gradients go to the context's pool of the device-resident tables (Context::dyn_gpool), summed by k_dyn_grad_gather
     bool lazy_capable = false;
     bool ti_projection = false;  // translation-invariant energy: PSD projection on the reduced matrix (k_project_eig_ti)
     size_t hf_off = 0;  // first float in the float pool
@@ -372,6 +373,21 @@ struct Context
     double spmv_empty_ms_sum = 0.0;  // empty event brackets recorded right behind the sampled launches
     int64_t spmv_n = 0;
     DevBuf<double> grad_aux;  // gradient contributions of the potentials evaluated on the auxiliary stream (eval())
+    // Gradient of the potentials whose tables live on the device (contact, friction): their kernels write node gradients to ONE pool
+    // (contribution g = offset of the potential + block * n_elem + element); the contributions are sorted by block row (stable: ties in
+    // contribution order) whenever the tables change, and one gather adds every row's sum in that order, once. No atomics: the gradient of
+    // contact scenes is bit-reproducible from run to run like that of contact-free ones.
+    DevBuf<double> dyn_gpool;
+    DevBuf<uint32_t> dyn_key, dyn_key_alt, dyn_val, dyn_val_alt;
+    DevBuf<unsigned char> dyn_desc;
+    DevBuf<uint8_t> dyn_cub_tmp;
+    DevBuf<uint32_t> dyn_long;      // [0]: number of long rows, then (first, end) pairs
+    const uint32_t* dyn_sorted_key = nullptr;
+    const uint32_t* dyn_sorted_val = nullptr;
+    int64_t dyn_total = 0;          // contributions of all such potentials
+    int dyn_n_desc = 0;
+    uint64_t dyn_tables_version = 1, dyn_inc_version = 0;  // bumped by prepare() / the version the sorted lists were built for
+    bool no_dyn_pool = false;       // option "no_dyn_pool": atomics instead (cross-check)
     std::vector<mistark_newton_iteration> newton_log;  // per-iteration records of the last newton_solve
     uint64_t* spmv_clk = nullptr;  // pinned: per-workgroup (start, end) of the sampled launches on the device's constant clock
     uint64_t* spmv_clk_sharded = nullptr;  // the same for pcg_sharded (up to 64 samples per solve)

@@ -400,9 +400,127 @@ __global__ __launch_bounds__(BLOCK) void k_eval_tri_closed(PotArgs a, double* __
             }
     }
 }
+// ---- gradient of the potentials with device-resident tables (Context::dyn_gpool) -----------------------------------------------------------
+__device__ __forceinline__ double block_sum(double v, double* sm /*[4]*/);  // ("Reductions and vector helpers" below)
+struct DynIncDesc
+{
+    const int32_t* conn;
+    int stride, n_elem, NB;
+    uint32_t g_off;  // first contribution
+    int dof_col[MAX_NB], dof_row_off[MAX_NB];
+};
+// contribution g -> (block row, g)
+__global__ __launch_bounds__(BLOCK) void k_dyn_inc_keys(const DynIncDesc* __restrict__ D, int n_desc, int64_t total, uint32_t* __restrict__ key, uint32_t* __restrict__ val)
+{
+    const int64_t g = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (g >= total) return;
+    int k = 0;
+    while (k + 1 < n_desc && g >= (int64_t)D[k + 1].g_off) k++;
+    const DynIncDesc& d = D[k];
+    const uint32_t l = (uint32_t)g - d.g_off;
+    const int b = (int)(l / (uint32_t)d.n_elem), e = (int)(l - (uint32_t)b * (uint32_t)d.n_elem);
+    key[g] = (uint32_t)(d.dof_row_off[b] + d.conn[(size_t)e * d.stride + d.dof_col[b]]);
+    val[g] = (uint32_t)g;
+}
+constexpr int DYN_LONG_ROW = 64;
+// one thread per sorted position; the thread at the head of a row's run adds the run, in order, to the gradient (runs beyond DYN_LONG_ROW:
+// recorded for k_dyn_grad_gather_long)
+__global__ __launch_bounds__(BLOCK) void k_dyn_grad_gather(const uint32_t* __restrict__ key, const uint32_t* __restrict__ val, int64_t total, const double* __restrict__ pool,
+                                                          double* __restrict__ grad, uint32_t* __restrict__ long_list, int long_cap)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t row = key[i];
+    if (i > 0 && key[i - 1] == row) return;
+    int64_t lo = i, hi = total;  // first position behind the run
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (key[mid] == row) lo = mid;
+        else hi = mid;
+    }
+    const int64_t end = hi;
+    if (end - i > DYN_LONG_ROW) {
+        const uint32_t at = atomicAdd(&long_list[0], 1u);
+        if ((int)at < long_cap) {
+            long_list[1 + 2 * at] = (uint32_t)i;
+            long_list[2 + 2 * at] = (uint32_t)end;
+        }
+        return;
+    }
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int64_t j = i; j < end; j++) {
+        const double* g = pool + 3 * (size_t)val[j];
+        a0 += g[0];
+        a1 += g[1];
+        a2 += g[2];
+    }
+    double* gr = grad + 3 * (size_t)row;
+    gr[0] += a0;
+    gr[1] += a1;
+    gr[2] += a2;
+}
+// long runs (a rigid body under tens of thousands of contacts): one workgroup per run, thread t takes the positions t, t + 256, ...; fixed
+// tree reduction: the same bits every time
+__global__ __launch_bounds__(BLOCK) void k_dyn_grad_gather_long(const uint32_t* __restrict__ key, const uint32_t* __restrict__ val, const double* __restrict__ pool,
+                                                               double* __restrict__ grad, const uint32_t* __restrict__ long_list, int long_cap)
+{
+    __shared__ double sm[4];
+    const int n_long = min((int)long_list[0], long_cap);
+    for (int t = blockIdx.x; t < n_long; t += gridDim.x) {
+        const uint32_t first = long_list[1 + 2 * t], end = long_list[2 + 2 * t];
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (uint32_t j = first + threadIdx.x; j < end; j += BLOCK) {
+            const double* g = pool + 3 * (size_t)val[j];
+            a0 += g[0];
+            a1 += g[1];
+            a2 += g[2];
+        }
+        a0 = block_sum(a0, sm);
+        __syncthreads();
+        a1 = block_sum(a1, sm);
+        __syncthreads();
+        a2 = block_sum(a2, sm);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double* gr = grad + 3 * (size_t)key[first];
+            gr[0] += a0;
+            gr[1] += a1;
+            gr[2] += a2;
+        }
+    }
+}
+constexpr int DYN_LONG_CAP = 4096;
+// (re)build the sorted contribution lists when the tables changed, then add every row's sum to `grad`; on c.stream
+static void dyn_grad_gather(Context& c, double* grad)
+{
+    if (c.dyn_total <= 0) return;
+    const int64_t n = c.dyn_total;
+    if (c.dyn_inc_version != c.dyn_tables_version) {
+        c.dyn_key.ensure((size_t)n);
+        c.dyn_key_alt.ensure((size_t)n);
+        c.dyn_val.ensure((size_t)n);
+        c.dyn_val_alt.ensure((size_t)n);
+        hipLaunchKernelGGL(k_dyn_inc_keys, dim3(grid_for(n)), dim3(BLOCK), 0, c.stream, (const DynIncDesc*)c.dyn_desc.p, c.dyn_n_desc, n, c.dyn_key.p, c.dyn_val.p);
+        int bits = 1;
+        while (bits < 32 && (1ll << bits) <= c.nbr) bits++;
+        size_t tmp = 0;
+        hipcub::DoubleBuffer<uint32_t> dk(c.dyn_key.p, c.dyn_key_alt.p), dv(c.dyn_val.p, c.dyn_val_alt.p);
+        MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, (int)n, 0, bits, c.stream));
+        c.dyn_cub_tmp.ensure(tmp);
+        MS_CHECK(hipcub::DeviceRadixSort::SortPairs(c.dyn_cub_tmp.p, tmp, dk, dv, (int)n, 0, bits, c.stream));  // (stable: equal rows keep the contribution order)
+        c.dyn_sorted_key = dk.Current();
+        c.dyn_sorted_val = dv.Current();
+        c.dyn_inc_version = c.dyn_tables_version;
+    }
+    c.dyn_long.ensure(1 + 2 * (size_t)DYN_LONG_CAP);
+    MS_CHECK(hipMemsetAsync(c.dyn_long.p, 0, sizeof(uint32_t), c.stream));
+    hipLaunchKernelGGL(k_dyn_grad_gather, dim3(grid_for(n)), dim3(BLOCK), 0, c.stream, c.dyn_sorted_key, c.dyn_sorted_val, n, (const double*)c.dyn_gpool.p, grad, c.dyn_long.p, DYN_LONG_CAP);
+    hipLaunchKernelGGL(k_dyn_grad_gather_long, dim3(64), dim3(BLOCK), 0, c.stream, c.dyn_sorted_key, c.dyn_sorted_val, (const double*)c.dyn_gpool.p, grad, (const uint32_t*)c.dyn_long.p,
+                       DYN_LONG_CAP);
+}
 static void launch_grad_gather(Context& c, Potential& P)
 {
-    if (!P.args.gpool || (c.kernel_dbg & 1)) return;
+    if (!P.args.gpool || P.dyn_pool || (c.kernel_dbg & 1)) return;  // (dyn_pool: one gather for all device-resident tables, dyn_grad_gather)
     hipLaunchKernelGGL(k_grad_gather, dim3(grid_for(3 * c.nbr)), dim3(BLOCK), 0, c.stream, (const double*)P.gpool.p, (const uint32_t*)P.inc_start.p, (const uint32_t*)P.inc.p, c.nbr,
                        c.grad.p);
     if (P.n_inc_long > 0)
@@ -1458,6 +1576,9 @@ void prepare(Context& c)
         // pass 2: pools (static potentials first, so their offsets do not move when only the contact tables change size); a potential's
         // pools hold n_key elements: all of them, or the rank's list
         size_t e_off = 0, h_off = 0, hf_off = 0;
+        std::vector<DynIncDesc> dyn_desc;
+        std::vector<std::pair<Potential*, int64_t>> dyn_goff;
+        int64_t dyn_total = 0;
         for (int part = 0; part < 2; part++) {
         for (auto& P : c.pots) {
             if (P.part != part) continue;
@@ -1485,6 +1606,22 @@ void prepare(Context& c)
             if (!P.grad_gather) {
                 A.gpool = nullptr;
                 P.inc_sig.clear();
+            }
+            P.dyn_pool = P.conn_ext != nullptr && P.kind != KIND_CUSTOM && !c.no_dyn_pool && !c.no_grad_gather;
+            if (P.dyn_pool && P.n_key > 0) {
+                DynIncDesc d{};
+                d.conn = P.conn_ext;
+                d.stride = P.conn_stride;
+                d.n_elem = P.n_key;
+                d.NB = P.NB;
+                d.g_off = (uint32_t)dyn_total;
+                for (int k = 0; k < P.NB; k++) {
+                    d.dof_col[k] = A.dof_col[k];
+                    d.dof_row_off[k] = A.dof_row_off[k];
+                }
+                dyn_desc.push_back(d);
+                dyn_goff.push_back({&P, dyn_total});
+                dyn_total += (int64_t)P.NB * P.n_key;
             }
             if (P.grad_gather && P.inc_sig == sig) {  // lists still valid (prepare() runs at every change of the contact sets)
                 A.gpool = P.gpool.p;
@@ -1523,6 +1660,21 @@ void prepare(Context& c)
                 A.n_gpool = n_gpool;
             }
         }
+        }
+        // pool of the device-resident tables' node gradients (dyn_grad_gather)
+        if (dyn_total >= (1ll << 31)) throw Error("too many contact contributions");
+        c.dyn_total = dyn_total;
+        c.dyn_n_desc = (int)dyn_desc.size();
+        c.dyn_tables_version++;
+        c.dyn_gpool.ensure(std::max<size_t>(3 * (size_t)dyn_total, 1));
+        for (auto& pg : dyn_goff) {
+            pg.first->args.gpool = c.dyn_gpool.p + 3 * (size_t)pg.second;
+            pg.first->args.n_gpool = pg.first->n_key;
+        }
+        if (!dyn_desc.empty()) {
+            c.dyn_desc.ensure(dyn_desc.size() * sizeof(DynIncDesc));
+            MS_CHECK(hipMemcpyAsync(c.dyn_desc.p, dyn_desc.data(), dyn_desc.size() * sizeof(DynIncDesc), hipMemcpyHostToDevice, c.stream));
+            MS_CHECK(hipStreamSynchronize(c.stream));  // (host vector is a temporary)
         }
         c.n_elem_total = e_off;
         c.hess_total = h_off;
@@ -1620,6 +1772,8 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         MS_CHECK(hipStreamWaitEvent(main_stream, c.aux_ev[1], 0));
         vec_axpby(c, c.grad.p, 1.0, c.grad.p, 1.0, c.grad_aux.p, c.ndofs);
     }
+    // the device-resident tables' node gradients (contact, friction), row by row in sorted order: behind everything else, one addition per row
+    if (mode != MISTARK_EVAL_P && !(c.kernel_dbg & 1)) dyn_grad_gather(c, c.grad.p);
     // The static part of the matrix can be gathered as soon as the element Hessians are there: on the auxiliary stream (idle by now),
     // beside this stream's gradient gather, reductions and the read-back the Newton loop takes its convergence decision from. assemble()
     // then waits for it and only adds the contact part. (Not for staged calls: their projection may run before the assembly.)

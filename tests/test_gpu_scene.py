@@ -869,3 +869,29 @@ def test_contact_free_runs_are_bit_reproducible():
     a, b = run(), run()
     assert a[2] == b[2] > 8 and a[3] == b[3]
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+
+
+@pytest.mark.parametrize("grid", [(10, 10, 10)])
+def test_contact_runs_are_bit_reproducible(grid):
+    """The same with frictional contact and a rigid body: a soft block on a fixed rigid box (device contact detection, barrier and friction
+    tables rebuilt at every evaluation, the box's two block rows under hundreds of contacts). The node gradients of the device-resident tables
+    go to a pool and are added row by row in sorted order (dyn_grad_gather), like those of the static potentials: twice the same bits in
+    positions, velocities and iteration counts."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from bench import build_scene
+    from stark_amd import sim as S
+
+    def run():
+        sim = build_scene(S, *grid, 0)
+        for _ in range(4):
+            assert sim.run_one_step()
+        i = sim.info()
+        out = (sim.points("x0").copy(), sim.points("v0").copy(), i.total_newton_iterations, i.total_linear_solves, i.total_cg_iterations)
+        sim.close()
+        return out
+
+    a, b = run(), run()
+    assert a[2:] == b[2:] and a[2] > 4
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
