@@ -623,7 +623,10 @@ int mistark_get_bsr(mistark_ctx* ctx, int64_t* n_block_rows, int64_t* nnzb, int6
         MS_CHECK(hipStreamSynchronize(c.stream));
         for (int64_t s = 0; s < m.nnzb; s++) {
             Blk b{};
-            b.key = (uint64_t)rw[s] * (uint64_t)c.nbr + (uint64_t)(cw[s] & 0x7fffffffu);
+            // (solver numbering -> the caller's block rows: Context::perm_active)
+            const uint64_t br = c.perm_active ? (uint64_t)c.iperm_h[(size_t)rw[s]] : (uint64_t)rw[s];
+            const uint64_t bc = c.perm_active ? (uint64_t)c.iperm_h[(size_t)(cw[s] & 0x7fffffffu)] : (uint64_t)(cw[s] & 0x7fffffffu);
+            b.key = br * (uint64_t)c.nbr + bc;
             if (vals) {
                 const size_t pos = store.empty() ? (size_t)s : (size_t)store[s];
                 const size_t base = (pos >> 6) * 576;
@@ -667,6 +670,10 @@ int mistark_spmv(mistark_ctx* ctx, const double* x_host, double* y_host)
         shard_to_local(c, c.tmp_a.p, c.p.p, true);
         spmv_device(c, c.p.p, c.q.p, nullptr, nullptr, true);
         shard_gather_global(c, c.q.p, c.tmp_b.p);
+    } else if (c.perm_active) {  // the matrix lives in solver numbering
+        rows_to_solver(c, c.tmp_a.p, c.p.p);
+        spmv_device(c, c.p.p, c.q.p, nullptr, nullptr, true);
+        rows_from_solver(c, c.q.p, c.tmp_b.p);
     } else {
         spmv_device(c, c.tmp_a.p, c.tmp_b.p, nullptr, nullptr, true);
     }
@@ -685,12 +692,14 @@ int mistark_apply_preconditioner(mistark_ctx* ctx, const double* x_host, double*
     std::vector<float> d((size_t)c.nbr * 9);
     MS_CHECK(hipMemcpyAsync(d.data(), c.dinv.p, d.size() * sizeof(float), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
-    for (int64_t r = 0; r < c.nbr; r++)
+    for (int64_t r = 0; r < c.nbr; r++) {
+        const int64_t sr = c.perm_active ? (int64_t)c.perm_h[(size_t)r] : r;  // (the inverse blocks are stored by solver row)
         for (int i = 0; i < 3; i++) {
             double s = 0.0;
-            for (int j = 0; j < 3; j++) s += (double)d[9 * r + 3 * i + j] * x_host[3 * r + j];
+            for (int j = 0; j < 3; j++) s += (double)d[9 * sr + 3 * i + j] * x_host[3 * r + j];
             z_host[3 * r + i] = s;
         }
+    }
     API_END(0)
 }
 
@@ -1074,6 +1083,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "spmv_variant") ctx->c.spmv_variant = value;
     else if (n == "proj_variant") ctx->c.proj_variant = value;
     else if (n == "no_contact_cache") ctx->c.no_contact_cache = value != 0;
+    else if (n == "no_row_order") { ctx->c.no_row_order = value != 0; ctx->c.perm_sig.clear(); ctx->c.layout_dirty = true; }  // one GPU: the caller's row numbering in the solver, too
     else if (n == "no_dyn_pool") { ctx->c.no_dyn_pool = value != 0; ctx->c.layout_dirty = true; }  // gradient of device-resident tables by atomics (arrival order) instead of the sorted gather
     else if (n == "no_fused_pcg") ctx->c.no_fused_pcg = value != 0;  // sharded runs over windows: the five-launch iteration with two all-gathers instead of the fused one
     else if (n == "spmv_chunk_tiles") {

@@ -475,10 +475,20 @@ bool direct_llt_blocktri(Context& c, const double* rhs_dev, double* x_dev)
 }  // namespace
 
 // du = A^-1 rhs with A = A_static + A_dynamic as assembled. Returns false when the factorisation meets a non-positive pivot.
+static bool direct_llt_solver_numbering(Context& c, const double* rhs_dev, double* x_dev);
 bool direct_llt(Context& c, const double* rhs_dev, double* x_dev)
 {
     if (!c.have_matrix) throw Error("direct_llt: matrix not assembled");
     if (c.world > 1) throw Error("DirectLLT is a single-rank solver (a sharded context holds its own rows only); use the block-Jacobi PCG");
+    if (!c.perm_active) return direct_llt_solver_numbering(c, rhs_dev, x_dev);
+    // the matrix lives in solver numbering (Context::perm_active): right-hand side in, solution out (the PCG's vectors are free here)
+    rows_to_solver(c, rhs_dev, c.p.p);
+    const bool ok = direct_llt_solver_numbering(c, c.p.p, c.q.p);
+    rows_from_solver(c, c.q.p, x_dev);
+    return ok;
+}
+static bool direct_llt_solver_numbering(Context& c, const double* rhs_dev, double* x_dev)
+{
     const int n = (int)c.ndofs;
     if (c.ndofs > MAX_DIRECT_DOFS) return direct_llt_blocktri(c, rhs_dev, x_dev);
     c.dense.ensure((size_t)n * n);

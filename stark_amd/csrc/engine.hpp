@@ -394,6 +394,16 @@ struct Context
     double spmv_clk_ticks = 0.0;
     int64_t spmv_clk_n = 0;
 
+    // Solver numbering on one GPU: the matrix and the PCG vectors use a permutation of the block rows — Morton order of
+    // the positions the caller handed over with mistark_dist_set_row_coords (rows without one, rigid bodies, at the end) — so that the 64 gathers
+    // of an SpMV tile fall into few cache lines whatever order the caller numbered its nodes in (the reference's grid generator numbers all
+    // hexahedron corners first and the centres behind them: mesh_generators.cpp:301-309). Applied where the keys of the sparsity pattern are
+    // formed (PotArgs::lrow, the mechanism of the sharded path), undone where a vector or the matrix leaves the solver (pcg(), get_bsr, spmv).
+    bool perm_active = false;
+    bool no_row_order = false;      // option "no_row_order": natural numbering (cross-check)
+    DevBuf<int32_t> perm, iperm;    // solver row of a block row / block row of a solver row
+    std::vector<int32_t> perm_h, iperm_h;
+    std::vector<int64_t> perm_sig;  // what the permutation was computed for
     // multi-GPU: elements of every potential are sharded by contiguous ranges; E, gradient and the assembled matrix
     // are summed over the ranks; everything else is replicated
     int rank = 0, world = 1;
@@ -459,6 +469,8 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
 void assemble(Context& c);
 void build_preconditioner(Context& c);
 double spmv_bench(Context& c, int n);
+void rows_from_solver(Context& c, const double* v_solver, double* v_caller);  // Context::perm_active: solver numbering <-> the caller's
+void rows_to_solver(Context& c, const double* v_caller, double* v_solver);
 void fused_pcg_replay(Context& c, int n_launches, double* s_us, double* r_us, double* v_us);
 void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed);
 // rhs_scale: the system solved is A x = rhs_scale * rhs (the Newton loop passes the gradient and -1; single GPU only)

@@ -91,35 +91,6 @@ inline void generate_tet_grid(std::vector<Vec3>& V, std::vector<std::array<int, 
                     for (auto& f : t) T.push_back({n[f[0]], n[f[1]], n[f[2]], n[8]});
                 }
             }
-    // EXPERIMENT (MISTARK_GRID_RENUMBER=B, measurement only: the scene no longer has the reference's node numbering): nodes renumbered in
-    // bricks of B x B x B cells, a cell's centre next to its corners, to measure what the locality of the numbering is worth to the SpMV's
-    // gathers before building a permutation into the engine.
-    if (const char* env = std::getenv("MISTARK_GRID_RENUMBER")) {
-        const int B = std::max(1, std::atoi(env));
-        std::vector<std::array<int64_t, 2>> key(V.size());
-        auto brick_key = [&](int i2, int j2, int k2) {  // doubled coordinates: corners even, centres odd
-            const int bi = i2 / (2 * B), bj = j2 / (2 * B), bk = k2 / (2 * B);
-            const int64_t brick = ((int64_t)bi * (nyh / B + 2) + bj) * (nzh / B + 2) + bk;
-            const int64_t local = ((int64_t)(i2 - 2 * B * bi) * (2 * B + 1) + (j2 - 2 * B * bj)) * (2 * B + 1) + (k2 - 2 * B * bk);
-            return brick * (int64_t)(2 * B + 1) * (2 * B + 1) * (2 * B + 1) + local;
-        };
-        for (int i = 0; i < nx; i++)
-            for (int j = 0; j < ny; j++)
-                for (int k = 0; k < nz; k++) key[(size_t)nz * ny * i + nz * j + k] = {brick_key(2 * i, 2 * j, 2 * k), (int64_t)(nz * ny * i + nz * j + k)};
-        for (int i = 0; i < nxh; i++)
-            for (int j = 0; j < nyh; j++)
-                for (int k = 0; k < nzh; k++) key[(size_t)co + nzh * nyh * i + nzh * j + k] = {brick_key(2 * i + 1, 2 * j + 1, 2 * k + 1), (int64_t)(co + nzh * nyh * i + nzh * j + k)};
-        std::sort(key.begin(), key.end());
-        std::vector<int> new_of(V.size());
-        std::vector<Vec3> V2(V.size());
-        for (size_t n2 = 0; n2 < key.size(); n2++) {
-            new_of[(size_t)key[n2][1]] = (int)n2;
-            V2[n2] = V[(size_t)key[n2][1]];
-        }
-        V.swap(V2);
-        for (auto& t : T)
-            for (auto& v : t) v = new_of[(size_t)v];
-    }
 }
 
 template <std::size_t N>

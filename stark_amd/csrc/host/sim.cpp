@@ -56,9 +56,9 @@ void Stark::ensure_registered()
     gravity_array_id = mistark_array(ctx, gravity.data(), 1, 3);
     check(gravity_array_id);
     for (auto* m : models) m->register_potentials(ctx);
-    if (settings.execution.world > 1) {
-        // sharded run: partition the block rows by the positions of the points (recursive coordinate bisection in the engine); rigid
-        // bodies (no position: NaN) keep the last rank
+    if (settings.execution.device >= 0) {
+        // the rest positions of the points per block row (rigid bodies: NaN). Sharded runs partition the rows by them (recursive coordinate
+        // bisection; rigid bodies keep the last rank), one GPU orders its solver's rows along a space-filling curve through them
         const int64_t nbr = mistark_ndofs(ctx) / 3;
         std::vector<double> xyz((size_t)(3 * nbr), std::numeric_limits<double>::quiet_NaN());
         for (auto* m : models)

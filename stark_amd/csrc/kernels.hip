@@ -1573,6 +1573,66 @@ void prepare(Context& c)
         }
         // sharded runs: row partition, local numbering, the elements this rank evaluates (shard.hip)
         if (c.world > 1) shard_prepare(c);
+        // one GPU: solver numbering by Morton order of the rows' positions (Context::perm_active)
+        {
+            const bool want = c.world == 1 && !c.no_row_order && (int64_t)c.sh.coords.size() == 3 * c.nbr && c.nbr > 0;
+            std::vector<int64_t> sig{want ? 1 : 0, c.nbr, c.sh.version};
+            if (sig != c.perm_sig) {
+                c.perm_sig = sig;
+                if (want != c.perm_active) c.part[0].dirty = c.part[1].dirty = true;
+                c.perm_active = want;
+                if (want) {
+                    const double* X = c.sh.coords.data();
+                    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                    for (int64_t r = 0; r < c.nbr; r++)
+                        if (X[3 * r] == X[3 * r])
+                            for (int d = 0; d < 3; d++) {
+                                lo[d] = std::min(lo[d], X[3 * r + d]);
+                                hi[d] = std::max(hi[d], X[3 * r + d]);
+                            }
+                    auto spread = [](uint64_t v) {  // 21 bits -> every third bit
+                        v &= 0x1fffff;
+                        v = (v | v << 32) & 0x1f00000000ffffull;
+                        v = (v | v << 16) & 0x1f0000ff0000ffull;
+                        v = (v | v << 8) & 0x100f00f00f00f00full;
+                        v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+                        v = (v | v << 2) & 0x1249249249249249ull;
+                        return v;
+                    };
+                    // cells of one common edge length (the bounding box's longest edge / 1024): neighbours in space share leading bits
+                    double ext = 0.0;
+                    for (int d = 0; d < 3; d++) ext = std::max(ext, hi[d] - lo[d]);
+                    const double inv = ext > 0.0 ? 1023.0 / ext : 0.0;
+                    std::vector<std::pair<uint64_t, int32_t>> order((size_t)c.nbr);
+                    for (int64_t r = 0; r < c.nbr; r++) {
+                        uint64_t code = ~0ull;  // rows without a position: behind everything, in their own order
+                        if (X[3 * r] == X[3 * r]) {
+                            code = 0;
+                            for (int d = 0; d < 3; d++) code |= spread((uint64_t)((X[3 * r + d] - lo[d]) * inv)) << d;
+                        }
+                        order[(size_t)r] = {code, (int32_t)r};
+                    }
+                    std::sort(order.begin(), order.end());
+                    c.perm_h.assign((size_t)c.nbr, 0);
+                    c.iperm_h.assign((size_t)c.nbr, 0);
+                    for (int64_t k = 0; k < c.nbr; k++) {
+                        c.iperm_h[(size_t)k] = order[(size_t)k].second;
+                        c.perm_h[(size_t)order[(size_t)k].second] = (int32_t)k;
+                    }
+                    c.perm.ensure((size_t)c.nbr);
+                    c.iperm.ensure((size_t)c.nbr);
+                    MS_CHECK(hipMemcpyAsync(c.perm.p, c.perm_h.data(), (size_t)c.nbr * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+                    MS_CHECK(hipMemcpyAsync(c.iperm.p, c.iperm_h.data(), (size_t)c.nbr * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+                    queued_uploads = true;
+                    c.part[0].dirty = c.part[1].dirty = true;
+                }
+            }
+            if (c.perm_active)
+                for (auto& P : c.pots) {
+                    P.args.lrow = c.perm.p;
+                    P.args.n_own = (int)c.nbr;
+                }
+        }
         // pass 2: pools (static potentials first, so their offsets do not move when only the contact tables change size); a potential's
         // pools hold n_key elements: all of them, or the rank's list
         size_t e_off = 0, h_off = 0, hf_off = 0;
@@ -3686,10 +3746,11 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_init(const double* __restrict__ b
 // block-Jacobi preconditioner of the rows (k_block_diag_inverse), x = 0, r = b, z = p = M^-1 r. Before: negation, preconditioner and
 // k_pcg_init as three launches with their boundaries. (Folding k_pcg_init2 in as well — the workgroup that draws the last ticket adds
 // the partial sums — was measured and is slower: 674 same-address atomics serialise at ~50 ns each.)
+// (src_row: the right-hand side is in the caller's numbering, the solve in the solver's: Context::perm_active)
 __global__ __launch_bounds__(BLOCK) void k_pcg_prologue(const double* __restrict__ rhs, double scale, const float* __restrict__ vals, const int32_t* __restrict__ diag_slot,
                                                         const float* __restrict__ vals_dyn, const int32_t* __restrict__ diag_slot_dyn, int64_t nbr, float* __restrict__ dinv,
                                                         double* __restrict__ x, double* __restrict__ r, double* __restrict__ z, double* __restrict__ p, double* __restrict__ part_bb,
-                                                        double* __restrict__ part_rz)
+                                                        double* __restrict__ part_rz, const int32_t* __restrict__ src_row)
 {
     __shared__ double sm[4];
     double bb = 0.0, rz = 0.0;
@@ -3708,7 +3769,8 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_prologue(const double* __restrict
         sym3_inverse(m, d);
 #pragma unroll
         for (int k = 0; k < 9; k++) dinv[9 * row + k] = d[k];
-        const double r0 = scale * rhs[3 * row], r1 = scale * rhs[3 * row + 1], r2 = scale * rhs[3 * row + 2];
+        const int64_t g = src_row ? (int64_t)src_row[row] : row;
+        const double r0 = scale * rhs[3 * g], r1 = scale * rhs[3 * g + 1], r2 = scale * rhs[3 * g + 2];
         const double z0 = (double)d[0] * r0 + (double)d[1] * r1 + (double)d[2] * r2;
         const double z1 = (double)d[3] * r0 + (double)d[4] * r1 + (double)d[5] * r2;
         const double z2 = (double)d[6] * r0 + (double)d[7] * r1 + (double)d[8] * r2;
@@ -3725,6 +3787,29 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_prologue(const double* __restrict
         part_bb[blockIdx.x] = bb;
         part_rz[blockIdx.x] = rz;
     }
+}
+// vector in solver numbering -> the caller's numbering (dst_row = Context::iperm), and back (k_rows_to_solver)
+__global__ __launch_bounds__(BLOCK) void k_rows_from_solver(const double* __restrict__ v, const int32_t* __restrict__ dst_row, int64_t nbr, double* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= 3 * nbr) return;
+    const int64_t row = t / 3;
+    out[3 * (int64_t)dst_row[row] + (t - 3 * row)] = v[t];
+}
+__global__ __launch_bounds__(BLOCK) void k_rows_to_solver(const double* __restrict__ v, const int32_t* __restrict__ src_row, int64_t nbr, double* __restrict__ out)
+{
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= 3 * nbr) return;
+    const int64_t row = t / 3;
+    out[t] = v[3 * (int64_t)src_row[row] + (t - 3 * row)];
+}
+void rows_from_solver(Context& c, const double* v_solver, double* v_caller)
+{
+    hipLaunchKernelGGL(k_rows_from_solver, dim3(grid_for(3 * c.nbr)), dim3(BLOCK), 0, c.stream, v_solver, (const int32_t*)c.iperm.p, c.nbr, v_caller);
+}
+void rows_to_solver(Context& c, const double* v_caller, double* v_solver)
+{
+    hipLaunchKernelGGL(k_rows_to_solver, dim3(grid_for(3 * c.nbr)), dim3(BLOCK), 0, c.stream, v_caller, (const int32_t*)c.iperm.p, c.nbr, v_solver);
 }
 __global__ __launch_bounds__(BLOCK) void k_pcg_init2(const double* __restrict__ part_bb, const double* __restrict__ part_rz, int nparts, double abs_tol, PcgCtrl* __restrict__ ctrl,
                                                      int stride)
@@ -4712,12 +4797,15 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     double* part_bb = c.partials.p + 3 * MAX_PARTIALS;
     const bool fuse_dir = !c.no_fuse_dir;
     c.p2.ensure((size_t)c.ndofs);
+    // (solver numbering: the solution accumulates in a scratch vector and is written to c.du in the caller's numbering at the end)
+    if (c.perm_active) c.xl.ensure((size_t)c.ndofs);
+    double* const xs = c.perm_active ? c.xl.p : c.du.p;
     // (fused: iteration 1 reads p_0 = buffer 0 with beta = 0; k_pcg_init leaves z there, so 0 * p_0 is finite)
     {
         const BsrPart& d1 = c.part[1];
         hipLaunchKernelGGL(k_pcg_prologue, dim3(gv), dim3(BLOCK), 0, c.stream, rhs_dev, rhs_scale, (const float*)c.part[0].vals.p, (const int32_t*)c.diag_slot[0].p,
-                           d1.nnzb ? (const float*)d1.vals.p : (const float*)nullptr, (const int32_t*)c.diag_slot[1].p, c.nbr, c.dinv.p, c.du.p, c.r.p, c.z.p, fuse_dir ? c.p2.p : c.p.p,
-                           part_bb, part_rz);
+                           d1.nnzb ? (const float*)d1.vals.p : (const float*)nullptr, (const int32_t*)c.diag_slot[1].p, c.nbr, c.dinv.p, xs, c.r.p, c.z.p, fuse_dir ? c.p2.p : c.p.p,
+                           part_bb, part_rz, c.perm_active ? (const int32_t*)c.iperm.p : (const int32_t*)nullptr);
     }
     hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, part_bb, part_rz, gv, abs_tol, c.ctrl.p, 1);
     // Iterations are launched in batches of PCG_BATCH; after each batch the control block is copied to a pinned slot and an
@@ -4777,7 +4865,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
                 MS_CHECK(hipEventRecord(c.ev[e0 + 2], c.stream));
                 sampled[slot].push_back(k);
             }
-            hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, (const double*)pk, c.q.p, c.du.p, c.r.p, c.z.p, part_rr,
+            hipLaunchKernelGGL(k_pcg_step, dim3(gv), dim3(BLOCK), 0, c.stream, k, stop_on_indef, part_pq, gs, c.dinv.p, c.nbr, (const double*)pk, c.q.p, xs, c.r.p, c.z.p, part_rr,
                                part_rz, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : nullptr, (const uint32_t*)m1.row_chunk0.p, (const double*)m1.yd.p,
                                (const double*)m1.chunk_partial.p);
             if (!fuse_dir)
@@ -4866,6 +4954,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         k_end_cur = k_end_next;
     }
     // (a look-ahead batch launched after convergence consists of device-side no-ops; later work queues behind it on the same stream)
+    if (c.perm_active) rows_from_solver(c, xs, c.du.p);
     const int n_it = h->done ? h->n_iter : max_iter;
     c.last_cg_iters = n_it;
     if (info) {
