@@ -401,6 +401,7 @@ struct Context
     // formed (PotArgs::lrow, the mechanism of the sharded path), undone where a vector or the matrix leaves the solver (pcg(), get_bsr, spmv).
     bool perm_active = false;
     bool no_row_order = false;      // option "no_row_order": natural numbering (cross-check)
+    int row_order_mode = 0;         // option "row_order": 0 = by positions when given, else breadth-first order of the element graph; 1 = breadth-first order even with positions (measurement)
     DevBuf<int32_t> perm, iperm;    // solver row of a block row / block row of a solver row
     std::vector<int32_t> perm_h, iperm_h;
     std::vector<int64_t> perm_sig;  // what the permutation was computed for
@@ -458,6 +459,7 @@ struct ElemTable  // block rows of the elements of one potential: rows[e * nb + 
 };
 void rcb_partition_rows(int64_t n_block_rows, int world, const double* xyz, const std::vector<int64_t>& weight, std::vector<int32_t>& owner);
 void graph_partition_rows(int64_t n_block_rows, int world, const std::vector<ElemTable>& tables, const uint8_t* hub, std::vector<int32_t>& owner);
+void static_graph_order(Context& c, std::vector<int32_t>& rows_in_order);  // shard.hip
 void ensure_pattern(Context& c);
 void contact_destroy(struct ContactSystem* cs);
 void contact_shared_rows(Context& c, std::vector<int32_t>& rows);  // contact.hip

@@ -1575,50 +1575,58 @@ void prepare(Context& c)
         if (c.world > 1) shard_prepare(c);
         // one GPU: solver numbering by Morton order of the rows' positions (Context::perm_active)
         {
-            const bool want = c.world == 1 && !c.no_row_order && (int64_t)c.sh.coords.size() == 3 * c.nbr && c.nbr > 0;
-            std::vector<int64_t> sig{want ? 1 : 0, c.nbr, c.sh.version};
+            const bool have_xyz = (int64_t)c.sh.coords.size() == 3 * c.nbr && c.row_order_mode == 0;
+            // (the breadth-first order needs the potentials' host connectivity; a context with a handful of rows gains nothing)
+            const bool want = c.world == 1 && !c.no_row_order && c.nbr >= 4096;
+            int64_t conn_sig = 0;
+            if (want && !have_xyz)
+                for (auto& P : c.pots)
+                    if (P.part == 0 && !P.conn_ext) conn_sig = conn_sig * 1000003 + (int64_t)P.conn_version * 31 + P.n_elem;
+            std::vector<int64_t> sig{want ? 1 : 0, c.nbr, have_xyz ? c.sh.version : -1, conn_sig, (int64_t)c.row_order_mode};
             if (sig != c.perm_sig) {
                 c.perm_sig = sig;
                 if (want != c.perm_active) c.part[0].dirty = c.part[1].dirty = true;
                 c.perm_active = want;
                 if (want) {
-                    const double* X = c.sh.coords.data();
-                    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-                    for (int64_t r = 0; r < c.nbr; r++)
-                        if (X[3 * r] == X[3 * r])
-                            for (int d = 0; d < 3; d++) {
-                                lo[d] = std::min(lo[d], X[3 * r + d]);
-                                hi[d] = std::max(hi[d], X[3 * r + d]);
+                    c.iperm_h.clear();
+                    if (have_xyz) {
+                        const double* X = c.sh.coords.data();
+                        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                        for (int64_t r = 0; r < c.nbr; r++)
+                            if (X[3 * r] == X[3 * r])
+                                for (int d = 0; d < 3; d++) {
+                                    lo[d] = std::min(lo[d], X[3 * r + d]);
+                                    hi[d] = std::max(hi[d], X[3 * r + d]);
+                                }
+                        auto spread = [](uint64_t v) {  // 21 bits -> every third bit
+                            v &= 0x1fffff;
+                            v = (v | v << 32) & 0x1f00000000ffffull;
+                            v = (v | v << 16) & 0x1f0000ff0000ffull;
+                            v = (v | v << 8) & 0x100f00f00f00f00full;
+                            v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+                            v = (v | v << 2) & 0x1249249249249249ull;
+                            return v;
+                        };
+                        // cells of one common edge length (the bounding box's longest edge / 1024): neighbours in space share leading bits
+                        double ext = 0.0;
+                        for (int d = 0; d < 3; d++) ext = std::max(ext, hi[d] - lo[d]);
+                        const double inv = ext > 0.0 ? 1023.0 / ext : 0.0;
+                        std::vector<std::pair<uint64_t, int32_t>> order((size_t)c.nbr);
+                        for (int64_t r = 0; r < c.nbr; r++) {
+                            uint64_t code = ~0ull;  // rows without a position: behind everything, in their own order
+                            if (X[3 * r] == X[3 * r]) {
+                                code = 0;
+                                for (int d = 0; d < 3; d++) code |= spread((uint64_t)((X[3 * r + d] - lo[d]) * inv)) << d;
                             }
-                    auto spread = [](uint64_t v) {  // 21 bits -> every third bit
-                        v &= 0x1fffff;
-                        v = (v | v << 32) & 0x1f00000000ffffull;
-                        v = (v | v << 16) & 0x1f0000ff0000ffull;
-                        v = (v | v << 8) & 0x100f00f00f00f00full;
-                        v = (v | v << 4) & 0x10c30c30c30c30c3ull;
-                        v = (v | v << 2) & 0x1249249249249249ull;
-                        return v;
-                    };
-                    // cells of one common edge length (the bounding box's longest edge / 1024): neighbours in space share leading bits
-                    double ext = 0.0;
-                    for (int d = 0; d < 3; d++) ext = std::max(ext, hi[d] - lo[d]);
-                    const double inv = ext > 0.0 ? 1023.0 / ext : 0.0;
-                    std::vector<std::pair<uint64_t, int32_t>> order((size_t)c.nbr);
-                    for (int64_t r = 0; r < c.nbr; r++) {
-                        uint64_t code = ~0ull;  // rows without a position: behind everything, in their own order
-                        if (X[3 * r] == X[3 * r]) {
-                            code = 0;
-                            for (int d = 0; d < 3; d++) code |= spread((uint64_t)((X[3 * r + d] - lo[d]) * inv)) << d;
+                            order[(size_t)r] = {code, (int32_t)r};
                         }
-                        order[(size_t)r] = {code, (int32_t)r};
+                        std::sort(order.begin(), order.end());
+                        for (auto& o : order) c.iperm_h.push_back(o.second);
+                    } else {
+                        static_graph_order(c, c.iperm_h);  // no positions (the SymX shim does not know which array holds them): breadth-first
                     }
-                    std::sort(order.begin(), order.end());
                     c.perm_h.assign((size_t)c.nbr, 0);
-                    c.iperm_h.assign((size_t)c.nbr, 0);
-                    for (int64_t k = 0; k < c.nbr; k++) {
-                        c.iperm_h[(size_t)k] = order[(size_t)k].second;
-                        c.perm_h[(size_t)order[(size_t)k].second] = (int32_t)k;
-                    }
+                    for (int64_t k = 0; k < c.nbr; k++) c.perm_h[(size_t)c.iperm_h[(size_t)k]] = (int32_t)k;
                     c.perm.ensure((size_t)c.nbr);
                     c.iperm.ensure((size_t)c.nbr);
                     MS_CHECK(hipMemcpyAsync(c.perm.p, c.perm_h.data(), (size_t)c.nbr * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));

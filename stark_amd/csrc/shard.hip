@@ -75,7 +75,8 @@ inline bool has_host_conn(const Potential& P) { return !P.conn_ext && P.n_elem >
 // Owner map from the connectivity graph: breadth-first order from a pseudo-peripheral row (two sweeps), components one after the other,
 // cut into `world` consecutive pieces of equal weight (element incidences). Hub rows (rows of small DoF sets: rigid bodies, which would
 // put the whole mesh within two hops) are left out of the graph and given to the last rank. Pure host code (mistark_partition_rows).
-void graph_partition_rows(int64_t nbr, int W, const std::vector<ElemTable>& tables, const uint8_t* hub, std::vector<int32_t>& owner)
+// (the traversal itself: rows in breadth-first order, hubs left out; weight[r] = 1 + element incidences of row r)
+void graph_bfs_order(int64_t nbr, const std::vector<ElemTable>& tables, const uint8_t* hub, std::vector<int64_t>& order, std::vector<int64_t>& weight)
 {
     auto is_hub = [&](int64_t r) { return hub && hub[(size_t)r]; };
     std::vector<int64_t> tab_base;
@@ -90,7 +91,7 @@ void graph_partition_rows(int64_t nbr, int W, const std::vector<ElemTable>& tabl
             if (T.rows[i] < 0 || T.rows[i] >= nbr) throw Error("partition: block row out of range");
             start[(size_t)T.rows[i] + 1]++;
         }
-    std::vector<int64_t> weight((size_t)nbr);
+    weight.assign((size_t)nbr, 0);
     for (int64_t r = 0; r < nbr; r++) {
         weight[(size_t)r] = 1 + start[(size_t)r + 1];
         start[(size_t)r + 1] += start[(size_t)r];
@@ -103,7 +104,7 @@ void graph_partition_rows(int64_t nbr, int W, const std::vector<ElemTable>& tabl
                 for (int k = 0; k < tables[ti].nb; k++) inc[(size_t)fill[(size_t)tables[ti].rows[e * tables[ti].nb + k]]++] = tab_base[ti] + e;
     }
     std::vector<int32_t> level((size_t)nbr, -1);
-    std::vector<int64_t> order;
+    order.clear();
     order.reserve((size_t)nbr);
     // breadth-first sweep from `root` over unvisited (level < 0) non-hub rows; appends to out; returns the last row reached
     auto bfs = [&](int64_t root, std::vector<int64_t>& out) {
@@ -139,6 +140,11 @@ void graph_partition_rows(int64_t nbr, int W, const std::vector<ElemTable>& tabl
         for (int64_t v : tmp) level[(size_t)v] = -1;
         bfs(far, order);
     }
+}
+void graph_partition_rows(int64_t nbr, int W, const std::vector<ElemTable>& tables, const uint8_t* hub, std::vector<int32_t>& owner)
+{
+    std::vector<int64_t> order, weight;
+    graph_bfs_order(nbr, tables, hub, order, weight);
     int64_t total = 0;
     for (int64_t v : order) total += weight[(size_t)v];
     owner.assign((size_t)nbr, (int32_t)(W - 1));  // hubs (and nothing else) keep the last rank
@@ -219,6 +225,38 @@ void graph_partition(Context& c, std::vector<int32_t>& owner)
     graph_partition_rows(nbr, c.world, tables, hub.data(), owner);
 }
 }  // namespace
+
+// block rows in breadth-first order of the graph of the potentials with fixed host connectivity (hubs — rows of small DoF sets — and rows no
+// element touches at the end): the solver numbering of one GPU when the caller handed over no positions (kernels.hip: prepare)
+void static_graph_order(Context& c, std::vector<int32_t>& rows_in_order)
+{
+    const int64_t nbr = c.nbr;
+    std::vector<uint8_t> hub((size_t)nbr, 0);
+    for (auto& s : c.dof_sets) {
+        const int64_t rows = s.n / 3;
+        if (rows > 0 && rows <= HOT_SET_ROWS)
+            for (int64_t r = 0; r < rows; r++) hub[(size_t)(s.offset / 3 + r)] = 1;
+    }
+    std::vector<std::vector<int32_t>> rows;
+    std::vector<ElemTable> tables;
+    for (auto& P : c.pots)
+        if (P.part == 0 && has_host_conn(P)) {
+            rows.emplace_back((size_t)P.n_elem * P.NB);
+            for (int e = 0; e < P.n_elem; e++)
+                for (int k = 0; k < P.NB; k++) rows.back()[(size_t)e * P.NB + k] = (int32_t)row_of(P, e, k);
+            tables.push_back(ElemTable{rows.back().data(), P.n_elem, P.NB});
+        }
+    std::vector<int64_t> order, weight;
+    graph_bfs_order(nbr, tables, hub.data(), order, weight);
+    rows_in_order.clear();
+    std::vector<uint8_t> seen((size_t)nbr, 0);
+    for (int64_t v : order) {
+        rows_in_order.push_back((int32_t)v);
+        seen[(size_t)v] = 1;
+    }
+    for (int64_t r = 0; r < nbr; r++)
+        if (!seen[(size_t)r]) rows_in_order.push_back((int32_t)r);
+}
 
 void shard_prepare(Context& c)
 {
