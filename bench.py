@@ -198,7 +198,7 @@ def pinned_placement_run(S, capi, nx, ny, nz, device, steps, warmup, with_cpu):
            "linear_solves": n_ls, "cg_iterations": n_cg, "newton_iterations": newton, "steps": steps, "warmup": warmup,
            "pinned_by": "tests/test_gpu_fullsize.py::test_full_size_first_time_steps_equal_the_reference_log_off_the_degenerate_placement"}
     if with_cpu:
-        out["cpu_baseline"] = cpu_baseline(nx, ny, nz, "contact", PINNED_OFFSET, sweep=(8,), steps=2)
+        out["cpu_baseline"] = cpu_baseline(nx, ny, nz, "contact", PINNED_OFFSET, sweep=(8, 16, 32), steps=2)
     return out
 
 
