@@ -1086,6 +1086,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "no_row_order") { ctx->c.no_row_order = value != 0; ctx->c.perm_sig.clear(); ctx->c.layout_dirty = true; }  // one GPU: the caller's row numbering in the solver, too
     else if (n == "row_order") { ctx->c.row_order_mode = value; ctx->c.perm_sig.clear(); ctx->c.layout_dirty = true; }
     else if (n == "no_dyn_pool") { ctx->c.no_dyn_pool = value != 0; ctx->c.layout_dirty = true; }  // gradient of device-resident tables by atomics (arrival order) instead of the sorted gather
+    else if (n == "cg_variant") ctx->c.cg_variant = value;
     else if (n == "no_fused_pcg") ctx->c.no_fused_pcg = value != 0;  // sharded runs over windows: the five-launch iteration with two all-gathers instead of the fused one
     else if (n == "spmv_chunk_tiles") {
         if (value < 0 || value > 64) throw Error("spmv_chunk_tiles: 0 (automatic) .. 64");

@@ -418,6 +418,7 @@ struct Context
     // sharded PCG through the windows (pcg_sharded_fused): the running tag of its messages, and the option to keep the unfused iteration
     uint32_t fused_tag = 0;
     bool no_fused_pcg = false;      // option "no_fused_pcg"
+    int cg_variant = 0;             // option "cg_variant": 1 = the Chronopoulos-Gear iteration on one GPU, too (pcg_cg; measurement / cross-check)
     int64_t n_fused_solves = 0, n_unfused_solves = 0;  // sharded solves by iteration kind (mistark_dist_info)
     struct FusedReplay  // the last converged fused solve, for fused_pcg_replay (kernels.hip)
     {

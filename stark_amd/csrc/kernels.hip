@@ -1460,7 +1460,7 @@ void prepare(Context& c)
         if (c.ndofs == 0) throw Error("no degrees of freedom");
         const size_t n = (size_t)c.ndofs;
         c.u.ensure(n); c.grad.ensure(n + 8); c.du.ensure(n); c.r.ensure(n); c.z.ensure(n); c.p.ensure(n); c.q.ensure(n); c.tmp_a.ensure(n); c.tmp_b.ensure(n);
-        c.partials.ensure(4 * MAX_PARTIALS);
+        c.partials.ensure(6 * MAX_PARTIALS);
         c.ctrl.ensure(1);
         c.counters.ensure(8);
         c.active_blocks.ensure((size_t)c.nbr);
@@ -4342,8 +4342,8 @@ __device__ __forceinline__ void vec_load(VecRow& v, int64_t row, const float* __
     v.r0 = r[i]; v.r1 = r[i + 1]; v.r2 = r[i + 2];
 #pragma unroll
     for (int k = 0; k < 9; k++) v.d[k] = dinv[9 * row + k];
-    v.sp = send_pos_of_row[row];
-    if (crow_of_row) dyn_row(crow_of_row, row_chunk0, yd, chunk_partial, row, v.w0, v.w1, v.w2);  // + contact part of w (k_spmv_halo left it in yd / chunk_partial)
+    v.sp = send_pos_of_row ? send_pos_of_row[row] : -1;
+    if (crow_of_row) dyn_row(crow_of_row, row_chunk0, yd, chunk_partial, row, v.w0, v.w1, v.w2);  // + contact part of w (the SpMV left it in yd / chunk_partial)
 }
 // V_k, k >= 1 (check_only: the convergence test of iteration k - 1 and nothing else, behind the last iteration the caller allows).
 // replay (mistark_dist_fused_bench): the kernel of a FINISHED solve launched again on the messages still in the window — every poll is
@@ -4353,8 +4353,11 @@ __global__ __launch_bounds__(BLOCK) void k_cg_vec(int k, int check_only, int sto
                                                   double* __restrict__ s, double* __restrict__ x, double* __restrict__ r, PcgCtrl* __restrict__ ctrl,
                                                   const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0, const double* __restrict__ yd,
                                                   const double* __restrict__ chunk_partial, const int32_t* __restrict__ send_pos_of_row, const uint32_t* __restrict__ send_mask,
-                                                  double* __restrict__ part_ru, double* __restrict__ part_rr, PcgCtrl* __restrict__ host_slot, int epoch, int replay)
+                                                  double* __restrict__ part_ru, double* __restrict__ part_rr, PcgCtrl* __restrict__ host_slot, int epoch, int replay,
+                                                  const double* __restrict__ loc_wu, int loc_gs, const double* __restrict__ loc_ru, const double* __restrict__ loc_rr, int loc_gv)
 {
+    // loc_*: ONE GPU (pcg_cg): the three sums come from the partial sums the previous SpMV (w.u) and vector kernel (r.u, r.r; the other
+    // parity's buffers than the ones this launch writes) left in local memory, re-reduced by every workgroup; no windows, no pushes
     const bool scribe = blockIdx.x == 0 && threadIdx.x == 0 && !replay;
     if (!replay && ctrl->done) {
         if (scribe && host_slot) publish_ctrl(host_slot, epoch, 1, ctrl->converged, ctrl->indef, ctrl->n_iter, ctrl->error);
@@ -4365,18 +4368,25 @@ __global__ __launch_bounds__(BLOCK) void k_cg_vec(int k, int check_only, int sto
     VecRow v;
     // (the thread's row is requested before the sums below: they wait for the slowest rank's reduction)
     if (!check_only && row < n_own) vec_load(v, row, dinv, u, w, p, s, x, r, crow_of_row, row_chunk0, yd, chunk_partial, send_pos_of_row);
-    __shared__ double sm[3 * MAX_IPC_RANKS + 4];
-    const int W = f.v.world;
-    if (threadIdx.x < (unsigned)(3 * W)) {  // one lane per (rank, component); added below in rank order
-        const unsigned long long* g = f.v.win[f.v.rank] + f.m2[par_in] + 2 * (size_t)threadIdx.x;  // (rank-major: 6 granules per rank)
-        sm[threadIdx.x] = granule_wait_f64(g, tag_m2_in, f.v.err, wall_clock64(), f.v.timeout_ticks, 2u | ((unsigned)k << 8));
-    }
-    __syncthreads();
+    __shared__ double sm[3 * MAX_IPC_RANKS + 8];
     double gamma = 0.0, rr = 0.0, delta = 0.0;
-    for (int q = 0; q < W; q++) {
-        gamma += sm[3 * q];
-        rr += sm[3 * q + 1];
-        delta += sm[3 * q + 2];
+    if (loc_wu) {
+        sum_partials2(loc_ru, loc_rr, loc_gv, sm, 1, gamma, rr);
+        __syncthreads();
+        delta = sum_partials(loc_wu, loc_gs, sm);
+        __syncthreads();
+    } else {
+        const int W = f.v.world;
+        if (threadIdx.x < (unsigned)(3 * W)) {  // one lane per (rank, component); added below in rank order
+            const unsigned long long* g = f.v.win[f.v.rank] + f.m2[par_in] + 2 * (size_t)threadIdx.x;  // (rank-major: 6 granules per rank)
+            sm[threadIdx.x] = granule_wait_f64(g, tag_m2_in, f.v.err, wall_clock64(), f.v.timeout_ticks, 2u | ((unsigned)k << 8));
+        }
+        __syncthreads();
+        for (int q = 0; q < W; q++) {
+            gamma += sm[3 * q];
+            rr += sm[3 * q + 1];
+            delta += sm[3 * q + 2];
+        }
     }
     double error = 1.0;
     if (replay) {
@@ -4573,7 +4583,7 @@ struct FusedSolve
         hipLaunchKernelGGL(k_cg_vec, dim3(gv), dim3(BLOCK), 0, c.stream, k, check_only ? 1 : 0, stop_on_indef, abs_tol, rel_tol, f, tag_m2(k - 1), tag_m1(k), (const float*)c.dinv.p, S.n_own,
                            u, (const double*)w, p, s, x, r, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : (const int32_t*)nullptr, (const uint32_t*)m1.row_chunk0.p,
                            (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, (const int32_t*)S.send_pos_of_row.p, (const uint32_t*)S.send_mask.p, part_ru, part_rr, host_slot,
-                           epoch, replay);
+                           epoch, replay, (const double*)nullptr, 0, (const double*)nullptr, (const double*)nullptr, 0);
     }
 };
 // false: no windows, too many ranks, or the halo does not fit the fast region
@@ -4781,6 +4791,99 @@ __global__ void k_copy_ctrl(const PcgCtrl* __restrict__ src, PcgCtrl* __restrict
     }
 }
 static double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// ---- option "cg_variant" = 1 on ONE GPU: the Chronopoulos-Gear iteration of the sharded solve without the windows -----------------------------
+// Two launches per iteration instead of three: S (the solver's SpMV on u = M^-1 r, partial w.u) and V (k_cg_vec in its local mode: every
+// workgroup re-reduces the partial sums, decides, updates p, s, x, r, u). Same iterates in exact arithmetic; p.Ap is delta - beta gamma /
+// alpha_prev instead of a dot product of its own, one SpMV more per solve (w_0 = A u_0). NOT the default: the reference's loop
+// (solve_pcg.h:170-225) is; kept as a measured alternative and as the one-GPU cross-check of the sharded iteration's arithmetic.
+static void pcg_cg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info, double rhs_scale)
+{
+    const int gv = grid_for(c.nbr, BLOCK, PCG_GRID);
+    BsrPart& m1 = c.part[1];
+    const bool dyn = m1.nnzb > 0;
+    double* part_wu = c.partials.p;
+    double* pr[2][2] = {{c.partials.p + 4 * MAX_PARTIALS, c.partials.p + 5 * MAX_PARTIALS}, {c.partials.p + 2 * MAX_PARTIALS, c.partials.p + 3 * MAX_PARTIALS}};  // (r.u, r.r) by parity of k
+    c.p2.ensure((size_t)c.ndofs);
+    if (c.perm_active) c.xl.ensure((size_t)c.ndofs);
+    double* const xs = c.perm_active ? c.xl.p : c.du.p;
+    double *u = c.z.p, *w = c.q.p, *p = c.p.p, *s = c.p2.p, *r = c.r.p;
+    {
+        // prologue as in pcg(): preconditioner, x = 0, r = b, u = M^-1 r; partial (r.r, r.u) where V_1 expects those of "V_0" (parity 0)
+        const BsrPart& d1 = c.part[1];
+        hipLaunchKernelGGL(k_pcg_prologue, dim3(gv), dim3(BLOCK), 0, c.stream, rhs_dev, rhs_scale, (const float*)c.part[0].vals.p, (const int32_t*)c.diag_slot[0].p,
+                           d1.nnzb ? (const float*)d1.vals.p : (const float*)nullptr, (const int32_t*)c.diag_slot[1].p, c.nbr, c.dinv.p, xs, r, u, p, pr[0][1], pr[0][0],
+                           c.perm_active ? (const int32_t*)c.iperm.p : (const int32_t*)nullptr);
+        hipLaunchKernelGGL(k_pcg_init2, dim3(1), dim3(BLOCK), 0, c.stream, pr[0][1], pr[0][0], gv, abs_tol, c.ctrl.p, 1);
+    }
+    constexpr int BATCH = 4;
+    PcgCtrl* hs[2] = {reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048), reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048 + 64)};
+    const int epoch = ++c.pcg_epoch;
+    int k = 1;
+    bool tail_done = false;
+    CgFast f{};
+    auto launch_batch = [&](int slot) {
+        hs[slot]->epoch = epoch - 1;
+        hs[slot]->done = 0;
+        hs[slot]->n_iter = -1;
+        const int k_end = std::min(max_iter + 1, k + BATCH - 1);
+        for (; k <= k_end; k++) {
+            const bool check_only = k == max_iter + 1;
+            const int gs = launch_spmv<0>(c, u, w, u, part_wu, c.ctrl.p, /*combine=*/false, nullptr);  // w_{k-1} = A u_{k-1}, partial w.u
+            hipLaunchKernelGGL(k_cg_vec, dim3(gv), dim3(BLOCK), 0, c.stream, k, check_only ? 1 : 0, stop_on_indef, abs_tol, rel_tol, f, 0u, 0u, (const float*)c.dinv.p, c.nbr, u,
+                               (const double*)w, p, s, xs, r, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : (const int32_t*)nullptr, (const uint32_t*)m1.row_chunk0.p,
+                               (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, (const int32_t*)nullptr, (const uint32_t*)nullptr, pr[k & 1][0], pr[k & 1][1],
+                               k == k_end ? hs[slot] : (PcgCtrl*)nullptr, epoch, 0, (const double*)part_wu, gs, (const double*)pr[(k - 1) & 1][0], (const double*)pr[(k - 1) & 1][1], gv);
+            if (check_only) tail_done = true;
+        }
+        return k_end;
+    };
+    PcgCtrl h{};
+    int slot = 0;
+    int k_end_cur = launch_batch(0);
+    for (;;) {
+        const bool more = !tail_done;
+        int k_end_next = 0;
+        if (more) k_end_next = launch_batch(slot ^ 1);
+        const volatile PcgCtrl* v = hs[slot];
+        const double t_wait = now_seconds();
+        auto reported = [&] { return v->epoch == epoch && (v->done || v->n_iter >= k_end_cur); };
+        for (uint64_t spins = 0; !reported(); spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xfffff) != 0xfffff) continue;
+            const hipError_t q = hipStreamQuery(c.stream);
+            if (q != hipErrorNotReady) {
+                MS_CHECK(q);
+                if (!reported()) {
+                    PcgCtrl dev{};
+                    MS_CHECK(hipMemcpy(&dev, c.ctrl.p, sizeof(PcgCtrl), hipMemcpyDeviceToHost));
+                    hs[slot]->converged = dev.converged;
+                    hs[slot]->indef = dev.indef;
+                    hs[slot]->error = dev.error;
+                    hs[slot]->n_iter = dev.done ? dev.n_iter : k_end_cur;
+                    hs[slot]->done = dev.done ? 1 : 0;
+                    hs[slot]->epoch = epoch;
+                }
+                break;
+            }
+            if (now_seconds() - t_wait > 60.0) throw Error("pcg: the device did not report iteration " + std::to_string(k_end_cur) + " within 60 s");
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        h = *hs[slot];
+        if (h.done || !more) break;
+        slot ^= 1;
+        k_end_cur = k_end_next;
+    }
+    if (c.perm_active) rows_from_solver(c, xs, c.du.p);
+    const int n_it = h.done ? h.n_iter : max_iter;
+    c.last_cg_iters = n_it;
+    if (info) {
+        info->converged = h.done ? h.converged : 0;
+        info->n_iterations = n_it;
+        info->found_indefiniteness = h.indef;
+        info->error = h.error;
+        info->reserved = 0;
+    }
+}
 // SpMV timing inside the solver: every SPMV_SAMPLE-th launch is bracketed by a pair of pooled HIP events on the engine's stream
 constexpr int SPMV_SAMPLE = 32;  // (a sampled launch costs the stream ~14 us of marker packets: 1.3 % of the timed region at every 16th launch, measured)
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info, double rhs_scale)
@@ -4794,6 +4897,10 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
             pcg_sharded(c, rhs_dev, abs_tol, rel_tol, max_iter, stop_on_indef, info);
             c.n_unfused_solves++;
         }
+        return;
+    }
+    if (c.cg_variant == 1) {
+        pcg_cg(c, rhs_dev, abs_tol, rel_tol, max_iter, stop_on_indef, info, rhs_scale);
         return;
     }
     const int gv = grid_for(c.nbr, BLOCK, PCG_GRID);  // one block row per thread up to 262 144 block rows

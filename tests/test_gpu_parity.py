@@ -514,3 +514,32 @@ def test_a_registration_only_context_does_not_disable_device_buffers_of_real_one
         eng.close()
     finally:
         L.mistark_destroy(dry)
+
+
+@pytest.mark.parametrize("name", ["tetbeam_softrubber_6x2x2", "contactmix_t1", "rbchain", "cloth_shells_6"])
+def test_chronopoulos_gear_iteration_on_one_gpu_matches_the_reference_loop(name):
+    """option cg_variant = 1: the arithmetic the sharded solve uses between processes (u = M^-1 r, w = A u, s = A p by recurrence, p.Ap by
+    expansion; kernels.hip pcg_cg / pcg_sharded_fused) on ONE GPU against the reference's loop (solve_pcg.h:170-225): same verdict, iteration
+    count within +-1, same solution — at the fixture's tolerance, at a tight one on the projected matrix, and at the iteration cap."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+
+    def solves(eng):
+        eng.eval(capi.EVAL_P_G_H)
+        eng.assemble()
+        a = eng.pcg(man["pcg"]["abs_tol"])
+        eng.project(1e-10)
+        b = eng.pcg(1e-8, 1e-6, 5000)
+        c = eng.pcg(1e-300, 1e-300, 9)
+        return a, b, c
+
+    eng = engine_from_problem(prob, man)
+    ref = solves(eng)
+    eng.set_option("cg_variant", 1)
+    got = solves(eng)
+    eng.close()
+    for (x, i), (xr, ir), slack in zip(got, ref, (1, 2, 0)):
+        assert i.converged == ir.converged and abs(i.n_iterations - ir.n_iterations) <= slack, (i.n_iterations, ir.n_iterations)
+        assert np.abs(x - xr).max() <= 1e-4 * max(np.abs(xr).max(), 1e-300)
