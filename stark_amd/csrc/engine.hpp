@@ -212,6 +212,7 @@ struct BsrPart
     DevBuf<int32_t> rowmap;         // compact row -> block row
     DevBuf<int64_t> row_ptr;        // compact rows
     DevBuf<float> vals;             // tiles of 64 blocks: float4 q0[64], float4 q1[64], float s[64]
+    DevBuf<uint8_t> slot_dirty;     // per block: a projection round replaced one of its contributions (re-gathered by project(), then cleared)
     DevBuf<uint32_t> long_slots;    // blocks with > LONG_SLOT contributions (summed by k_assemble_long)
     int n_long = 0;
     DevBuf<uint32_t> vlong_slots;   // blocks with > VERY_LONG_SLOT contributions (k_assemble_vlong_part / _fold)
@@ -388,6 +389,7 @@ struct Context
     int dyn_n_desc = 0;
     uint64_t dyn_tables_version = 1, dyn_inc_version = 0;  // bumped by prepare() / the version the sorted lists were built for
     bool no_dyn_pool = false;       // option "no_dyn_pool": atomics instead (cross-check)
+    bool atomic_projection = false; // option "atomic_projection": the projection adds float deltas to assembled blocks atomically (arrival order) instead of re-gathering the blocks
     std::vector<mistark_newton_iteration> newton_log;  // per-iteration records of the last newton_solve
     uint64_t* spmv_clk = nullptr;  // pinned: per-workgroup (start, end) of the sampled launches on the device's constant clock
     uint64_t* spmv_clk_sharded = nullptr;  // the same for pcg_sharded (up to 64 samples per solve)

@@ -2630,6 +2630,45 @@ __global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restric
     }
 }
 
+static void gather_part(Context& c, int part, const uint8_t* only_dirty);
+// Ordered update of the assembled matrix after a projection round (instead of float deltas added atomically in arrival order): every block
+// a selected element contributes to is flagged, and the flagged blocks are gathered again from the pools in sorted-key order (gather_part) —
+// the matrix equals the one assembled from the projected Hessians, bit for bit and run to run. For a lazy potential (float upper-triangle
+// pool, blocks recomputed into a compact double pool for the projection) the projected blocks go back to the float pool first; a block
+// whose floats did not change flags nothing. One thread per (selected element, block pair).
+__global__ __launch_bounds__(BLOCK) void k_proj_mark(const uint32_t* __restrict__ list, int nl, int NB, int n_key, const uint32_t* __restrict__ slot_of_src, uint8_t* __restrict__ dirty,
+                                                    const double* __restrict__ Hc, int n_pool_c, float* __restrict__ hf, int n_pool_f)
+{
+    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int nn = NB * NB;
+    if (t >= (int64_t)nl * nn) return;
+    const int li = (int)(t / nn), ab = (int)(t - (int64_t)li * nn), a = ab / NB, b = ab - a * NB;
+    const uint32_t le = list[li];
+    const uint32_t slot = slot_of_src[(size_t)ab * n_key + le];
+    if (!hf) {
+        if (slot != NO_SRC) dirty[slot] = 1;
+        return;
+    }
+    if (a > b) return;  // (the pool holds the upper block triangle; (b, a) is read as the transpose of (a, b))
+    const double* src = Hc + ((size_t)ab * n_pool_c + li) * 9;
+    float* dst = hf + ((size_t)tet_pair_index(a, b) * n_pool_f + le) * 9;
+    bool diff = false;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const float f = (float)src[k];
+        if (dst[k] != f) {
+            dst[k] = f;
+            diff = true;
+        }
+    }
+    if (!diff) return;
+    if (slot != NO_SRC) dirty[slot] = 1;
+    if (a != b) {
+        const uint32_t slot_t = slot_of_src[(size_t)(b * NB + a) * n_key + le];
+        if (slot_t != NO_SRC) dirty[slot_t] = 1;
+    }
+}
+
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active, int64_t* n_projected_now,
              int64_t* n_changed_now)
 {
@@ -2712,6 +2751,16 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     }
     if (c.proj_variant & 4) mirroring |= 2;
     constexpr int SHORT_LIST = 4096;  // lists up to this length share one launch (k_project_eig_multi)
+    struct Mark  // what k_proj_mark needs of a potential's list once the eigen-decompositions have run
+    {
+        Potential* P;
+        const uint32_t* list;
+        int nl;
+        const double* Hc;
+        int n_pool_c;
+    };
+    std::vector<Mark> marks;
+    bool mark_part[2] = {false, false};
     ProjBatch batch;
     batch.n = 0;
     int batch_waves = 0;
@@ -2743,6 +2792,11 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         }
         // patched in place where the matrix already holds these Hessians: all of it after assemble(), its static part after eval()'s early gather
         float* vals = (c.matrix_current || (c.static_assembled && P.part == 0)) ? c.part[P.part].vals.p : nullptr;
+        if (vals && !c.atomic_projection) {  // ordered update: the kernels leave the matrix alone, the touched blocks are gathered again below
+            marks.push_back(Mark{&P, list, nl, compact ? H : (const double*)nullptr, n_pool});
+            mark_part[P.part] = true;
+            vals = nullptr;
+        }
         const dim3 g((nl + 3) / 4), b(BLOCK);
         if (!(c.proj_variant & 1) && P.NB <= 6) {  // register-resident Jacobi, several elements per wavefront
             const int epw = 64 / ((3 * P.NB + 1) & ~1);
@@ -2786,6 +2840,30 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     }
     flush();
     (void)total;
+    if (!marks.empty()) {
+        for (int part = 0; part < 2; part++)
+            if (mark_part[part]) {
+                BsrPart& m = c.part[part];
+                const size_t n_pos = (size_t)std::max<int64_t>(m.ntiles * 64, m.nnzb) + 1;  // (flags are indexed like the values: by storage position)
+                if (m.slot_dirty.cap < n_pos) {
+                    m.slot_dirty.ensure(n_pos);
+                    MS_CHECK(hipMemsetAsync(m.slot_dirty.p, 0, m.slot_dirty.cap, c.stream));
+                }
+            }
+        for (const Mark& k : marks) {
+            Potential& P = *k.P;
+            BsrPart& m = c.part[P.part];
+            const bool lazy = k.Hc != nullptr;
+            hipLaunchKernelGGL(k_proj_mark, dim3(grid_for((int64_t)k.nl * P.NB * P.NB)), dim3(BLOCK), 0, c.stream, k.list, k.nl, P.NB, P.n_key, (const uint32_t*)(m.slot_of_src.p + P.kp_off),
+                               m.slot_dirty.p, k.Hc, k.n_pool_c, lazy ? c.elemHf.p + P.hf_off : (float*)nullptr, P.n_pool_f);
+        }
+        for (int part = 0; part < 2; part++)
+            if (mark_part[part]) {
+                BsrPart& m = c.part[part];
+                gather_part(c, part, m.slot_dirty.p);
+                MS_CHECK(hipMemsetAsync(m.slot_dirty.p, 0, (size_t)std::max<int64_t>(m.ntiles * 64, m.nnzb), c.stream));  // (clean for the next round)
+            }
+    }
     c.n_projected_total += n_selected;
     if (n_projected_now) *n_projected_now = n_selected;
     if (n_changed_now) {  // (sharded: this rank's count, interface elements included)
@@ -2867,12 +2945,13 @@ __device__ __forceinline__ double contrib(const double* __restrict__ elemH, cons
 // contributions k0 + lane, k0 + lane + 64, ... and the nine sums are reduced across the wave; the order is fixed by the sorted keys
 __global__ __launch_bounds__(BLOCK) void k_assemble_long(const double* __restrict__ elemH, const float* __restrict__ elemHf, const uint32_t* __restrict__ slot_start,
                                                         const uint32_t* __restrict__ sorted_src, const uint32_t* __restrict__ list, int n_long, const uint32_t* __restrict__ store_slot,
-                                                        float* __restrict__ vals)
+                                                        float* __restrict__ vals, const uint8_t* __restrict__ only_dirty)
 {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_long) return;
     const int lane = threadIdx.x & 63;
     const uint32_t slot = list[w];
+    if (only_dirty && !only_dirty[store_slot ? store_slot[slot] : slot]) return;  // (flags are indexed like the values: by storage position)
     const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1];
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (uint32_t k = k0 + lane; k < k1; k += 64) {
@@ -2891,13 +2970,15 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_long(const double* __restric
 // range order (deterministic like the one-wavefront version, 64 times the parallelism: 2.2 ms -> tens of us for the four diagonal blocks
 // of a floor under 136 k contact and friction rows)
 __global__ __launch_bounds__(BLOCK) void k_assemble_vlong_part(const double* __restrict__ elemH, const float* __restrict__ elemHf, const uint32_t* __restrict__ slot_start,
-                                                              const uint32_t* __restrict__ sorted_src, const uint32_t* __restrict__ list, int n_vlong, double* __restrict__ part)
+                                                              const uint32_t* __restrict__ sorted_src, const uint32_t* __restrict__ list, int n_vlong, double* __restrict__ part,
+                                                              const uint8_t* __restrict__ only_dirty, const uint32_t* __restrict__ store_slot)
 {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (w >= n_vlong * VLONG_SPLIT) return;
     const int lane = threadIdx.x & 63;
     const int b = w / VLONG_SPLIT, j = w - b * VLONG_SPLIT;
     const uint32_t slot = list[b];
+    if (only_dirty && !only_dirty[store_slot ? store_slot[slot] : slot]) return;
     const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1];
     const uint32_t chunk = (k1 - k0 + VLONG_SPLIT - 1) / VLONG_SPLIT;
     const uint32_t c0 = k0 + (uint32_t)j * chunk, c1 = min(k1, c0 + chunk);
@@ -2915,13 +2996,14 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_vlong_part(const double* __r
     }
 }
 __global__ __launch_bounds__(BLOCK) void k_assemble_vlong_fold(const double* __restrict__ part, const uint32_t* __restrict__ list, int n_vlong, const uint32_t* __restrict__ store_slot,
-                                                              float* __restrict__ vals)
+                                                              float* __restrict__ vals, const uint8_t* __restrict__ only_dirty)
 {
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= n_vlong) return;
     const int lane = threadIdx.x & 63;
     static_assert(VLONG_SPLIT == 64, "one lane per partial sum");
     const uint32_t slot = list[b];
+    if (only_dirty && !only_dirty[store_slot ? store_slot[slot] : slot]) return;
 #pragma unroll
     for (int c = 0; c < 9; c++) {
         const double v = wave_sum(part[((size_t)b * VLONG_SPLIT + lane) * 9 + c]);
@@ -2938,10 +3020,12 @@ struct F3
     float x, y, z;
 };
 __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restrict__ elemH, const float* __restrict__ elemHf, const uint32_t* __restrict__ slot_start,
-                                                           const uint32_t* __restrict__ sorted_src, int64_t nnzb, const uint32_t* __restrict__ store_slot, float* __restrict__ vals)
+                                                           const uint32_t* __restrict__ sorted_src, int64_t nnzb, const uint32_t* __restrict__ store_slot, float* __restrict__ vals,
+                                                           const uint8_t* __restrict__ only_dirty)
 {
     const int64_t slot = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (slot >= nnzb) return;
+    if (only_dirty && !only_dirty[store_slot ? store_slot[slot] : (uint32_t)slot]) return;  // (project(): only the blocks a projection round touched; flags by storage position)
     const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1];
     if (k1 - k0 > LONG_SLOT) return;  // k_assemble_long
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -3022,6 +3106,23 @@ static void make_descriptors(Context& c, int part)
     }
     m.desc_lazy = c.lazy_active ? 1 : 0;
 }
+// the blocks of a matrix part summed from the pools in sorted-key order; only_dirty: just the flagged blocks (BsrPart::slot_dirty)
+static void gather_part(Context& c, int part, const uint8_t* only_dirty)
+{
+    BsrPart& m = c.part[part];
+    make_descriptors(c, part);
+    const uint32_t* store = part == 0 ? m.store_slot.p : nullptr;
+    const uint32_t* desc = m.sorted_desc.p;
+    hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.nnzb, store, m.vals.p, only_dirty);
+    if (m.n_long > 0)
+        hipLaunchKernelGGL(k_assemble_long, dim3((m.n_long + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.long_slots.p, m.n_long, store, m.vals.p, only_dirty);
+    if (m.n_vlong > 0) {
+        c.vlong_part.ensure((size_t)m.n_vlong * VLONG_SPLIT * 9);
+        hipLaunchKernelGGL(k_assemble_vlong_part, dim3((m.n_vlong * VLONG_SPLIT + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.vlong_slots.p, m.n_vlong,
+                           c.vlong_part.p, only_dirty, store);
+        hipLaunchKernelGGL(k_assemble_vlong_fold, dim3((m.n_vlong + 3) / 4), dim3(BLOCK), 0, c.stream, (const double*)c.vlong_part.p, m.vlong_slots.p, m.n_vlong, store, m.vals.p, only_dirty);
+    }
+}
 static void assemble_part(Context& c, int part)
 {
     {
@@ -3035,18 +3136,7 @@ static void assemble_part(Context& c, int part)
                 hipLaunchKernelGGL(k_assemble, dim3(grid_for(nblk * 9)), dim3(BLOCK), 0, c.stream, c.elemH.p + P.h_off, nblk, m.slot_of_src.p + P.kp_off, m.vals.p);
             }
         } else {
-            make_descriptors(c, part);
-            const uint32_t* store = part == 0 ? m.store_slot.p : nullptr;
-            const uint32_t* desc = m.sorted_desc.p;
-            hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.nnzb, store, m.vals.p);
-            if (m.n_long > 0)
-                hipLaunchKernelGGL(k_assemble_long, dim3((m.n_long + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.long_slots.p, m.n_long, store, m.vals.p);
-            if (m.n_vlong > 0) {
-                c.vlong_part.ensure((size_t)m.n_vlong * VLONG_SPLIT * 9);
-                hipLaunchKernelGGL(k_assemble_vlong_part, dim3((m.n_vlong * VLONG_SPLIT + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.vlong_slots.p,
-                                   m.n_vlong, c.vlong_part.p);
-                hipLaunchKernelGGL(k_assemble_vlong_fold, dim3((m.n_vlong + 3) / 4), dim3(BLOCK), 0, c.stream, (const double*)c.vlong_part.p, m.vlong_slots.p, m.n_vlong, store, m.vals.p);
-            }
+            gather_part(c, part, nullptr);
         }
         m.have_matrix = true;
     }

@@ -543,3 +543,39 @@ def test_chronopoulos_gear_iteration_on_one_gpu_matches_the_reference_loop(name)
     for (x, i), (xr, ir), slack in zip(got, ref, (1, 2, 0)):
         assert i.converged == ir.converged and abs(i.n_iterations - ir.n_iterations) <= slack, (i.n_iterations, ir.n_iterations)
         assert np.abs(x - xr).max() <= 1e-4 * max(np.abs(xr).max(), 1e-300)
+
+
+@pytest.mark.parametrize("lazy", [0, 1])
+@pytest.mark.parametrize("name", ["tetbeam_eo_4x1x1_big", "contactmix_t1", "cloth_shells_6", "rbchain"])
+def test_projection_updates_the_matrix_in_order(name, lazy):
+    """The matrix after a projection round is the matrix assembled from the projected Hessians, BIT FOR BIT: project() flags the blocks its
+    elements contribute to and gathers them again from the pools in sorted-key order (ElementHessians.cpp:258-294 adds float deltas in thread
+    order; the engine's first version added them with float atomics in arrival order). Progressive round, then everything; on the double pool
+    and on the lazy float pool (projected blocks written back to it); twice the same bits. Option atomic_projection keeps the delta path:
+    within float rounding of it."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    act = (np.abs(z["grad"]).reshape(-1, 3).max(axis=1) >= 0.3 * np.abs(z["grad"]).max()).astype(np.uint8)
+
+    def run(atomic):
+        eng = engine_from_problem(prob, man)
+        eng.set_option("lazy_eval", lazy)
+        eng.set_option("atomic_projection", atomic)
+        eng.eval(capi.EVAL_P_G_H)
+        eng.assemble()
+        eng.project(1e-10, False, act)
+        v1 = eng.get_bsr()[2].copy()
+        eng.project(1e-10, False, None)
+        v2 = eng.get_bsr()[2].copy()
+        eng.assemble()                       # from the pools, which hold the projected Hessians
+        v3 = eng.get_bsr()[2].copy()
+        eng.close()
+        return v1, v2, v3
+
+    a, b, d = run(0), run(0), run(1)
+    assert (a[1] == a[2]).all()                                    # patched == re-assembled
+    assert all((x == y).all() for x, y in zip(a, b))               # run to run
+    scale = np.abs(a[2]).max()
+    assert np.abs(d[1] - a[1]).max() <= 64 * np.finfo(np.float32).eps * scale and np.abs(d[0] - a[0]).max() <= 64 * np.finfo(np.float32).eps * scale
