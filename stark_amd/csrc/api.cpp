@@ -1087,6 +1087,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "row_order") { ctx->c.row_order_mode = value; ctx->c.perm_sig.clear(); ctx->c.layout_dirty = true; }
     else if (n == "atomic_projection") ctx->c.atomic_projection = value != 0;
     else if (n == "no_dyn_pool") { ctx->c.no_dyn_pool = value != 0; ctx->c.layout_dirty = true; }  // gradient of device-resident tables by atomics (arrival order) instead of the sorted gather
+    else if (n == "no_halo_subset") { ctx->c.no_halo_subset = value != 0; ctx->c.cg_mask_pattern = 0; }
     else if (n == "cg_variant") ctx->c.cg_variant = value;
     else if (n == "no_fused_pcg") ctx->c.no_fused_pcg = value != 0;  // sharded runs over windows: the five-launch iteration with two all-gathers instead of the fused one
     else if (n == "spmv_chunk_tiles") {

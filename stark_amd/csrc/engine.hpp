@@ -419,6 +419,13 @@ struct Context
     DevBuf<double> xl;              // sharded PCG: the solution in local numbering
     // sharded PCG through the windows (pcg_sharded_fused): the running tag of its messages, and the option to keep the unfused iteration
     uint32_t fused_tag = 0;
+    // the ranks whose CURRENT matrix references a send row of mine as a column (a subset of Shard::send_mask, which lists every rank that
+    // holds the row as a ghost — all of them for a contact surface's vertices): the halo of the fused PCG goes to these only
+    DevBuf<uint32_t> cg_send_mask;
+    DevBuf<double> cg_want_s, cg_want_r;
+    uint64_t cg_mask_pattern = 0;
+    int64_t cg_mask_lists = -1;
+    bool no_halo_subset = false;    // option "no_halo_subset": push to every ghost holder
     bool no_fused_pcg = false;      // option "no_fused_pcg"
     int cg_variant = 0;             // option "cg_variant": 1 = the Chronopoulos-Gear iteration on one GPU, too (pcg_cg; measurement / cross-check)
     int64_t n_fused_solves = 0, n_unfused_solves = 0;  // sharded solves by iteration kind (mistark_dist_info)

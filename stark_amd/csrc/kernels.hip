@@ -4631,6 +4631,54 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_halo(int g0, int gr, int g1, Sta
 }
 static double now_seconds();
 namespace {
+// want[owner * send_stride + position] = 1 for every ghost column the matrix references
+__global__ __launch_bounds__(BLOCK) void k_mark_ghost_refs(const uint32_t* __restrict__ colw, int64_t n, int64_t n_own, const int32_t* __restrict__ ghost_src, double* __restrict__ want)
+{
+    const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t col = (int64_t)(colw[i] & 0x7fffffffu);
+    if (col >= n_own) want[ghost_src[col - n_own]] = 1.0;
+}
+// bit q of mask[pos]: rank q references my send row `pos` (all[q] is rank q's want table)
+__global__ __launch_bounds__(BLOCK) void k_build_send_mask(const double* __restrict__ all, int W, int me, int64_t send_stride, int64_t n_send, const uint32_t* __restrict__ holders,
+                                                          uint32_t* __restrict__ mask)
+{
+    const int64_t pos = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (pos >= n_send) return;
+    uint32_t m = 0;
+    for (int q = 0; q < W; q++)
+        if (q != me && all[(size_t)q * (size_t)W * (size_t)send_stride + (size_t)me * (size_t)send_stride + (size_t)pos] != 0.0) m |= 1u << q;
+    mask[pos] = m & holders[pos];
+}
+// The halo of the fused iteration goes only to the ranks whose matrix has the row as a column: every rank marks the ghosts its two matrix
+// parts reference, one all-gather carries the marks to the owners. Again whenever a pattern or the element lists changed (collective: every
+// rank builds its patterns at the same points of the same control flow).
+void fused_refresh_masks(Context& c)
+{
+    Shard& S = c.sh;
+    if (c.cg_mask_pattern == c.pattern_version && c.cg_mask_lists == S.version_lists) return;
+    const int W = c.world;
+    const size_t n = (size_t)W * (size_t)std::max<int64_t>(S.send_stride, 1);
+    c.cg_want_s.ensure(n);
+    c.cg_want_r.ensure(n * (size_t)W);
+    c.cg_send_mask.ensure((size_t)std::max<int64_t>(S.n_send, 1));
+    MS_CHECK(hipMemsetAsync(c.cg_want_s.p, 0, n * sizeof(double), c.stream));
+    if (S.n_ghost > 0) {
+        const BsrPart& m0 = c.part[0];
+        const BsrPart& m1 = c.part[1];
+        if (m0.ntiles > 0)
+            hipLaunchKernelGGL(k_mark_ghost_refs, dim3(grid_for(m0.ntiles * 64)), dim3(BLOCK), 0, c.stream, (const uint32_t*)m0.scol.p, m0.ntiles * 64, S.n_own, (const int32_t*)S.ghost_src.p,
+                               c.cg_want_s.p);
+        if (m1.nnzb > 0)
+            hipLaunchKernelGGL(k_mark_ghost_refs, dim3(grid_for(m1.nnzb)), dim3(BLOCK), 0, c.stream, (const uint32_t*)m1.colw.p, m1.nnzb, S.n_own, (const int32_t*)S.ghost_src.p, c.cg_want_s.p);
+    }
+    c.coll->allgather_f64(c.cg_want_s.p, c.cg_want_r.p, n, c.stream);
+    if (S.n_send > 0)
+        hipLaunchKernelGGL(k_build_send_mask, dim3(grid_for(S.n_send)), dim3(BLOCK), 0, c.stream, (const double*)c.cg_want_r.p, W, c.rank, std::max<int64_t>(S.send_stride, 1), S.n_send,
+                           (const uint32_t*)S.send_mask.p, c.cg_send_mask.p);
+    c.cg_mask_pattern = c.pattern_version;
+    c.cg_mask_lists = S.version_lists;
+}
 // everything the launches of one fused solve share
 struct FusedSolve
 {
@@ -4641,6 +4689,7 @@ struct FusedSolve
     DynPart d;
     uint32_t base;
     double *u, *w, *p, *s, *x, *r, *part_wu, *part_ru, *part_rr;
+    const uint32_t* send_mask;  // where the halo goes: the ranks that reference the row (fused_refresh_masks), or every holder
     uint32_t tag_m1(int i) const { return base + 2u * (uint32_t)i + 1u; }
     uint32_t tag_m2(int i) const { return base + 2u * (uint32_t)i + 2u; }
     void launch_S(int i, uint64_t* clk, int replay) const
@@ -4672,7 +4721,7 @@ struct FusedSolve
         const bool dyn = m1.nnzb > 0;
         hipLaunchKernelGGL(k_cg_vec, dim3(gv), dim3(BLOCK), 0, c.stream, k, check_only ? 1 : 0, stop_on_indef, abs_tol, rel_tol, f, tag_m2(k - 1), tag_m1(k), (const float*)c.dinv.p, S.n_own,
                            u, (const double*)w, p, s, x, r, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : (const int32_t*)nullptr, (const uint32_t*)m1.row_chunk0.p,
-                           (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, (const int32_t*)S.send_pos_of_row.p, (const uint32_t*)S.send_mask.p, part_ru, part_rr, host_slot,
+                           (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, (const int32_t*)S.send_pos_of_row.p, send_mask, part_ru, part_rr, host_slot,
                            epoch, replay, (const double*)nullptr, 0, (const double*)nullptr, (const double*)nullptr, 0);
     }
 };
@@ -4708,6 +4757,7 @@ bool fused_setup(Context& c, FusedSolve& F)
     F.part_ru = c.partials.p + MAX_PARTIALS;
     F.part_rr = c.partials.p + 2 * MAX_PARTIALS;
     F.base = c.fused_tag;
+    F.send_mask = c.no_halo_subset ? (const uint32_t*)S.send_mask.p : (const uint32_t*)c.cg_send_mask.p;
     return true;
 }
 }  // namespace
@@ -4718,6 +4768,10 @@ static bool pcg_sharded_fused(Context& c, const double* rhs_global, double abs_t
     if (!fused_setup(c, F)) return false;
     Shard& S = c.sh;
     const int me = c.rank;
+    if (!c.no_halo_subset) {
+        fused_refresh_masks(c);
+        F.send_mask = c.cg_send_mask.p;  // (the buffer may have been allocated just now)
+    }
     build_preconditioner(c);
     static const bool dbg = std::getenv("MISTARK_DEBUG_FUSED") != nullptr;
     if (dbg)
@@ -4727,7 +4781,7 @@ static bool pcg_sharded_fused(Context& c, const double* rhs_global, double abs_t
     double* b_l = c.tmp_b.p;
     shard_to_local(c, rhs_global, b_l, false);
     hipLaunchKernelGGL(k_cg_prologue, dim3(F.gv), dim3(BLOCK), 0, c.stream, F.f, F.tag_m1(0), (const double*)b_l, (const float*)c.dinv.p, S.n_own, F.x, F.r, F.u, F.p, F.s, c.ctrl.p,
-                       (const int32_t*)S.send_pos_of_row.p, (const uint32_t*)S.send_mask.p, F.part_ru, F.part_rr);
+                       (const int32_t*)S.send_pos_of_row.p, F.send_mask, F.part_ru, F.part_rr);
     std::vector<int> sampled_i;
     auto launch_S = [&](int i) {
         uint64_t* clk = nullptr;
