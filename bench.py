@@ -353,15 +353,15 @@ def main():
         capi.lib().mistark_set_option(sim.engine_handle(), b"spmv_grid_cap", 0)  # (a rank measuring alone needs no cap: the grid a GPU of its own would get)
         for turn in range(world):  # one rank at a time, the others idle on the host: solo kernel durations
             if turn == rank:
-                buf = (_C1.c_double * 3)()
+                buf = (_C1.c_double * 2)()
                 if capi.lib().mistark_dist_fused_bench(sim.engine_handle(), 200, buf) == 0:
-                    mine = [round(buf[i], 2) for i in range(3)]
+                    mine = [round(buf[i], 2) for i in range(2)]
                 else:
                     mine = capi.lib().mistark_last_error(sim.engine_handle()).decode()
             dist.barrier()
         every = allgather_bytes(mine)
         if all(isinstance(v, list) for v in every):
-            fused_kernels_us = {"spmv_with_halo": [v[0] for v in every], "reduce_and_push": [v[1] for v in every], "vector_kernel": [v[2] for v in every]}
+            fused_kernels_us = {"spmv_with_halo": [v[0] for v in every], "vector_kernel": [v[1] for v in every]}
         else:
             fused_kernels_us = {"unavailable": [v for v in every if not isinstance(v, list)][0]}
     spmv_b2b_ms = None
@@ -428,8 +428,8 @@ def main():
             "cg_iterations_per_solve": n_cg / max(n_ls, 1),
             "linear_solves": n_ls,
             "cg_iterations": n_cg,
-            # N > 1: what ONE CG iteration costs a rank in kernels (solo, microseconds, per rank): the iteration is these three launches, with one
-            # exposed wait (the vector kernel's for the slowest rank's reduction) and the halo hidden behind the SpMV's interior rows
+            # N > 1: what ONE CG iteration costs a rank in kernels (solo, microseconds, per rank): the iteration is these two launches, with one
+            # exposed wait (the vector kernel's for the slowest rank's three sums) and the halo hidden behind the SpMV's interior rows
             "sharded_cg_kernels_us": fused_kernels_us,
             "newton_iterations": newton,
             "host_timers_s": {k: round(v, 6) for k, v in stage.items()},

@@ -371,8 +371,8 @@ int mistark_dist_init_ipc(mistark_ctx* ctx, mistark_ipc_comm* comm);
 /* `iters` all-gathers of n doubles with predictable values, every received value checked; avg_us[0] = wall time of one exchange + stream
  * synchronisation, avg_us[1] = of one exchange in a train enqueued back to back. Collective: every rank calls it with the same arguments. */
 int mistark_ipc_comm_selftest(mistark_ipc_comm* comm, int64_t n, int iters, double avg_us[2]);
-/* Measurement: solo durations (microseconds) of the three kernels of the fused PCG iteration on THIS rank's rows — out[0] = the SpMV with its
- * halo polls, out[1] = the one-workgroup reduction that pushes the rank's three sums, out[2] = the vector kernel — replayed from the rank's
+/* Measurement: solo durations (microseconds) of the two kernels of the fused PCG iteration on THIS rank's rows — out[0] = the SpMV with its
+ * halo polls, out[1] = the vector kernel (whose workgroup 0 reduces and pushes the rank's three sums) — replayed from the rank's
  * last converged solve on the messages still in its window (every poll answered at once). Not a collective: the caller lets the ranks take
  * turns (a host barrier between them), so the figures are kernels running alone even when all ranks share one GPU; no rank may start a solve
  * in between. Needs ranks that exchange through windows and a converged solve on the current matrix. */

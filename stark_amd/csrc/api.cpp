@@ -1030,8 +1030,8 @@ int mistark_ipc_comm_selftest(mistark_ipc_comm* comm, int64_t n, int iters, doub
     }
     return 0;
 }
-// Solo durations (microseconds) of the fused PCG iteration's three kernels on THIS rank's shard: out[0] = S (SpMV with halo polls), out[1] = R
-// (one-workgroup reduction and push), out[2] = V (vector kernel), replayed from the last converged solve. Not a collective: the caller lets the
+// Solo durations (microseconds) of the fused PCG iteration's two kernels on THIS rank's shard: out[0] = S (SpMV with halo polls), out[1] = V
+// (vector kernel; its workgroup 0 reduces and pushes the rank's sums), replayed from the last converged solve. Not a collective: the caller lets the
 // ranks take turns (bench.py: torch.distributed barriers between them), so that on a box where all ranks share ONE GPU the other ranks' queues
 // are empty while one measures; no rank may start a solve in between.
 int mistark_dist_fused_bench(mistark_ctx* ctx, int n_launches, double* out)
@@ -1040,7 +1040,7 @@ int mistark_dist_fused_bench(mistark_ctx* ctx, int n_launches, double* out)
     Context& c = ctx->c;
     if (c.world < 2 || !c.coll || !c.coll->ipc()) throw Error("mistark_dist_fused_bench: ranks that exchange through windows only");
     if (!out || n_launches <= 0) throw Error("mistark_dist_fused_bench: bad arguments");
-    fused_pcg_replay(c, n_launches, &out[0], &out[1], &out[2]);
+    fused_pcg_replay(c, n_launches, &out[0], &out[1]);
     API_END(0)
 }
 mistark_local_group* mistark_local_group_create(int world)

@@ -483,7 +483,7 @@ void build_preconditioner(Context& c);
 double spmv_bench(Context& c, int n);
 void rows_from_solver(Context& c, const double* v_solver, double* v_caller);  // Context::perm_active: solver numbering <-> the caller's
 void rows_to_solver(Context& c, const double* v_caller, double* v_solver);
-void fused_pcg_replay(Context& c, int n_launches, double* s_us, double* r_us, double* v_us);
+void fused_pcg_replay(Context& c, int n_launches, double* s_us, double* v_us);
 void spmv_device(Context& c, const double* x, double* y, const double* pdot, double* partials, bool timed);
 // rhs_scale: the system solved is A x = rhs_scale * rhs (the Newton loop passes the gradient and -1; single GPU only)
 void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int max_iter, int stop_on_indef, mistark_pcg_info* info, double rhs_scale = 1.0);

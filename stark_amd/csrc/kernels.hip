@@ -4313,22 +4313,23 @@ static void pcg_sharded(Context& c, const double* rhs_global, double abs_tol, do
 }
 
 // ---- the row-sharded PCG with ONE exposed exchange per iteration, for ranks that exchange through windows (dist.hpp: IpcView) --------------
-// The five launches and two all-gathers of pcg_sharded become THREE launches whose workgroups push and poll the windows themselves. The
+// The five launches and two all-gathers of pcg_sharded become TWO launches whose workgroups push and poll the windows themselves. The
 // arithmetic is the preconditioned CG of Chronopoulos & Gear (u = M^-1 r, w = A u, s = A p by recurrence), in which both dot products of
 // an iteration are taken on the same vectors, so that p.Ap is not a reduction of its own (the three reductions of
 // solve_pcg.h:180,201,217 are gamma = r.u, rr = r.r, and p.Ap = delta - beta gamma / alpha_prev with delta = w.u):
-//   V_k  (k_cg_vec)    every workgroup adds, in rank order, the ranks' (gamma, rr, delta)_{k-1} (message M2_{k-1}: 3 doubles per rank):
-//                      convergence test of iteration k-1, beta, p.Ap (indefiniteness test), alpha; then p = u + beta p, s = w + beta s,
-//                      x += alpha p, r -= alpha s, u = M^-1 r on its rows; partial (r.u, r.r) per workgroup to local memory; the new u of the rows
-//                      other ranks hold as ghosts is pushed to exactly those ranks                                         [message M1_k]
+//   V_k  (k_cg_vec)    workgroup 0 first adds the rank's partial sums of iteration k-1 (r.u, r.r of V_{k-1}; w.u of S_{k-1}) and pushes the
+//                      three numbers to every rank (message M2_{k-1}); then every workgroup adds, in rank order, the ranks' three numbers
+//                      from its window: convergence test of iteration k-1, beta, p.Ap (indefiniteness test), alpha; p = u + beta p,
+//                      s = w + beta s, x += alpha p, r -= alpha s, u = M^-1 r on its rows; partial (r.u, r.r) per workgroup to local memory;
+//                      the new u of the rows other ranks reference as matrix columns is pushed to exactly those ranks           [message M1_k]
 //   S_k  (k_spmv_halo) w = A u: columns of its own rows from memory, ghost columns straight from the window (the lane polls the granules of
 //                      that ghost: rows without ghost columns never wait, so the halo hides behind the interior of the matrix); partial w.u per
 //                      workgroup to local memory
-//   R_k  (k_cg_reduce) one workgroup: the rank's (gamma, rr, delta)_k from the partial sums, pushed to every rank                   [message M2_k]
-// (First version: every workgroup of V and S pushed its partial sums to every rank and every workgroup of V added them all — thousands of
-// uncached 8-byte reads per workgroup: 15 us per V launch at 43 k rows, three times the kernel it was to replace. The one-workgroup
-// reduction costs a launch and brings V to the few microseconds its vector traffic takes.)
-// The only wait that is not hidden is V_{k+1}'s for the slowest rank's R_k. Every rank adds the same numbers in the same order: identical
+// (History: version 1 let every workgroup of V and S push its partial sums to every rank and every workgroup of V add them all — thousands
+// of uncached 8-byte reads per workgroup: 15 us per V launch at 43 k rows. Version 2 reduced them in a one-workgroup kernel R between S and V:
+// V 7.6 us, R 3.0 us, a third launch. Version 3, this one: the reduction is workgroup 0 of V itself — the other workgroups poll for its push
+// like for any other rank's; 6.4 + 7.8 us per rank and iteration at 8 ranks instead of 6.4 + 3.0 + 6.8.)
+// The only wait that is not hidden is V_k's for the slowest rank's workgroup 0. Every rank adds the same numbers in the same order: identical
 // bits, identical decisions, no all-reduce. Messages live in the fast region of the windows, two slots (parity of k) per message kind and
 // source rank; a slot is rewritten two iterations later, when every reader has passed it (see "slot reuse" in dist.hip; between solves
 // the all-gather of the solution separates the last readers from the next solve's first push).
@@ -4395,23 +4396,6 @@ __global__ __launch_bounds__(BLOCK) void k_cg_prologue(CgFast f, uint32_t tag_ou
         ctrl->error = 1.0;
     }
 }
-// R_k: this rank's (gamma, rr, delta) of iteration k, summed from the partial sums of its vector kernel and its SpMV, to every rank
-__global__ __launch_bounds__(BLOCK) void k_cg_reduce(CgFast f, int par, uint32_t tag_out, const double* __restrict__ part_ru, const double* __restrict__ part_rr, int gv,
-                                                     const double* __restrict__ part_wu, int gs, const PcgCtrl* __restrict__ ctrl, int replay)
-{
-    if (!replay && ctrl->done) return;
-    __shared__ double sm[8];
-    double gamma, rr;
-    sum_partials2(part_ru, part_rr, gv, sm, 1, gamma, rr);
-    __syncthreads();
-    const double delta = sum_partials(part_wu, gs, sm);
-    if (threadIdx.x < (unsigned)f.v.world) {
-        unsigned long long* g = f.v.win[threadIdx.x] + f.m2[par] + (size_t)f.v.rank * M2_STRIDE;
-        granule_store_f64(g, tag_out, gamma);
-        granule_store_f64(g + 2, tag_out, rr);
-        granule_store_f64(g + 4, tag_out, delta);
-    }
-}
 struct VecRow
 {
     double u0, u1, u2, w0, w1, w2, p0, p1, p2, s0, s1, s2, x0, x1, x2, r0, r1, r2;
@@ -4444,10 +4428,12 @@ __global__ __launch_bounds__(BLOCK) void k_cg_vec(int k, int check_only, int sto
                                                   const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0, const double* __restrict__ yd,
                                                   const double* __restrict__ chunk_partial, const int32_t* __restrict__ send_pos_of_row, const uint32_t* __restrict__ send_mask,
                                                   double* __restrict__ part_ru, double* __restrict__ part_rr, PcgCtrl* __restrict__ host_slot, int epoch, int replay,
-                                                  const double* __restrict__ loc_wu, int loc_gs, const double* __restrict__ loc_ru, const double* __restrict__ loc_rr, int loc_gv)
+                                                  const double* __restrict__ loc_wu, int loc_gs, const double* __restrict__ loc_ru, const double* __restrict__ loc_rr, int loc_gv,
+                                                  int windows)
 {
-    // loc_*: ONE GPU (pcg_cg): the three sums come from the partial sums the previous SpMV (w.u) and vector kernel (r.u, r.r; the other
-    // parity's buffers than the ones this launch writes) left in local memory, re-reduced by every workgroup; no windows, no pushes
+    // loc_*: the partial sums the previous SpMV (w.u) and vector kernel (r.u, r.r; the other parity's buffers than the ones this launch
+    // writes) left in local memory. ONE GPU (pcg_cg, windows == 0): every workgroup re-reduces them, no pushes. Ranks on windows: workgroup
+    // 0 reduces them and pushes the rank's three sums to every rank (message M2_{k-1}) before it polls like the others
     const bool scribe = blockIdx.x == 0 && threadIdx.x == 0 && !replay;
     if (!replay && ctrl->done) {
         if (scribe && host_slot) publish_ctrl(host_slot, epoch, 1, ctrl->converged, ctrl->indef, ctrl->n_iter, ctrl->error);
@@ -4460,13 +4446,26 @@ __global__ __launch_bounds__(BLOCK) void k_cg_vec(int k, int check_only, int sto
     if (!check_only && row < n_own) vec_load(v, row, dinv, u, w, p, s, x, r, crow_of_row, row_chunk0, yd, chunk_partial, send_pos_of_row);
     __shared__ double sm[3 * MAX_IPC_RANKS + 8];
     double gamma = 0.0, rr = 0.0, delta = 0.0;
-    if (loc_wu) {
+    if (!windows) {
         sum_partials2(loc_ru, loc_rr, loc_gv, sm, 1, gamma, rr);
         __syncthreads();
         delta = sum_partials(loc_wu, loc_gs, sm);
         __syncthreads();
     } else {
         const int W = f.v.world;
+        if (blockIdx.x == 0) {  // (uniform per workgroup)
+            double g1, r1;
+            sum_partials2(loc_ru, loc_rr, loc_gv, sm, 1, g1, r1);
+            __syncthreads();
+            const double d1 = sum_partials(loc_wu, loc_gs, sm);
+            __syncthreads();
+            if (threadIdx.x < (unsigned)W) {
+                unsigned long long* g = f.v.win[threadIdx.x] + f.m2[par_in] + (size_t)f.v.rank * M2_STRIDE;
+                granule_store_f64(g, tag_m2_in, g1);
+                granule_store_f64(g + 2, tag_m2_in, r1);
+                granule_store_f64(g + 4, tag_m2_in, d1);
+            }
+        }
         if (threadIdx.x < (unsigned)(3 * W)) {  // one lane per (rank, component); added below in rank order
             const unsigned long long* g = f.v.win[f.v.rank] + f.m2[par_in] + 2 * (size_t)threadIdx.x;  // (rank-major: 6 granules per rank)
             sm[threadIdx.x] = granule_wait_f64(g, tag_m2_in, f.v.err, wall_clock64(), f.v.timeout_ticks, 2u | ((unsigned)k << 8));
@@ -4688,7 +4687,8 @@ struct FusedSolve
     StaticPart sp;
     DynPart d;
     uint32_t base;
-    double *u, *w, *p, *s, *x, *r, *part_wu, *part_ru, *part_rr;
+    double *u, *w, *p, *s, *x, *r, *part_wu;
+    double* pr[2][2];  // partial (r.u, r.r) of the vector kernels by parity of k (V_k reads V_{k-1}'s while it writes its own)
     const uint32_t* send_mask;  // where the halo goes: the ranks that reference the row (fused_refresh_masks), or every holder
     uint32_t tag_m1(int i) const { return base + 2u * (uint32_t)i + 1u; }
     uint32_t tag_m2(int i) const { return base + 2u * (uint32_t)i + 2u; }
@@ -4709,11 +4709,6 @@ struct FusedSolve
         X.code = 5u | ((unsigned)i << 8);
         hipLaunchKernelGGL(k_spmv_halo, dim3(gs), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, X, w, part_wu, (const PcgCtrl*)c.ctrl.p, clk, replay);
     }
-    void launch_R(int i, int replay) const
-    {
-        hipLaunchKernelGGL(k_cg_reduce, dim3(1), dim3(BLOCK), 0, c.stream, f, i & 1, tag_m2(i), (const double*)part_ru, (const double*)part_rr, gv, (const double*)part_wu, gs,
-                           (const PcgCtrl*)c.ctrl.p, replay);
-    }
     void launch_V(int k, bool check_only, int stop_on_indef, double abs_tol, double rel_tol, PcgCtrl* host_slot, int epoch, int replay) const
     {
         const Shard& S = c.sh;
@@ -4721,8 +4716,8 @@ struct FusedSolve
         const bool dyn = m1.nnzb > 0;
         hipLaunchKernelGGL(k_cg_vec, dim3(gv), dim3(BLOCK), 0, c.stream, k, check_only ? 1 : 0, stop_on_indef, abs_tol, rel_tol, f, tag_m2(k - 1), tag_m1(k), (const float*)c.dinv.p, S.n_own,
                            u, (const double*)w, p, s, x, r, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : (const int32_t*)nullptr, (const uint32_t*)m1.row_chunk0.p,
-                           (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, (const int32_t*)S.send_pos_of_row.p, send_mask, part_ru, part_rr, host_slot,
-                           epoch, replay, (const double*)nullptr, 0, (const double*)nullptr, (const double*)nullptr, 0);
+                           (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, (const int32_t*)S.send_pos_of_row.p, send_mask, pr[k & 1][0], pr[k & 1][1], host_slot,
+                           epoch, replay, (const double*)part_wu, gs, (const double*)pr[(k - 1) & 1][0], (const double*)pr[(k - 1) & 1][1], gv, 1);
     }
 };
 // false: no windows, too many ranks, or the halo does not fit the fast region
@@ -4754,8 +4749,10 @@ bool fused_setup(Context& c, FusedSolve& F)
     F.x = c.xl.p;
     F.r = c.r.p;
     F.part_wu = c.partials.p;
-    F.part_ru = c.partials.p + MAX_PARTIALS;
-    F.part_rr = c.partials.p + 2 * MAX_PARTIALS;
+    F.pr[0][0] = c.partials.p + 4 * MAX_PARTIALS;
+    F.pr[0][1] = c.partials.p + 5 * MAX_PARTIALS;
+    F.pr[1][0] = c.partials.p + 2 * MAX_PARTIALS;
+    F.pr[1][1] = c.partials.p + 3 * MAX_PARTIALS;
     F.base = c.fused_tag;
     F.send_mask = c.no_halo_subset ? (const uint32_t*)S.send_mask.p : (const uint32_t*)c.cg_send_mask.p;
     return true;
@@ -4781,7 +4778,7 @@ static bool pcg_sharded_fused(Context& c, const double* rhs_global, double abs_t
     double* b_l = c.tmp_b.p;
     shard_to_local(c, rhs_global, b_l, false);
     hipLaunchKernelGGL(k_cg_prologue, dim3(F.gv), dim3(BLOCK), 0, c.stream, F.f, F.tag_m1(0), (const double*)b_l, (const float*)c.dinv.p, S.n_own, F.x, F.r, F.u, F.p, F.s, c.ctrl.p,
-                       (const int32_t*)S.send_pos_of_row.p, F.send_mask, F.part_ru, F.part_rr);
+                       (const int32_t*)S.send_pos_of_row.p, F.send_mask, F.pr[0][0], F.pr[0][1]);
     std::vector<int> sampled_i;
     auto launch_S = [&](int i) {
         uint64_t* clk = nullptr;
@@ -4808,7 +4805,6 @@ static bool pcg_sharded_fused(Context& c, const double* rhs_global, double abs_t
         for (; k <= k_end; k++) {
             const bool check_only = k == max_iter + 1;
             launch_S(k - 1);      // w_{k-1}
-            F.launch_R(k - 1, 0);  // (gamma, rr, delta)_{k-1} to every rank
             F.launch_V(k, check_only, stop_on_indef, abs_tol, rel_tol, k == k_end ? hs[slot] : (PcgCtrl*)nullptr, epoch, 0);
             if (check_only) tail_done = true;
         }
@@ -4892,39 +4888,35 @@ static bool pcg_sharded_fused(Context& c, const double* rhs_global, double abs_t
     c.fused_replay.pattern = c.pattern_version;
     return true;
 }
-// Solo durations of the three kernels of the fused iteration on this rank's shard: n launches each of S_n, R_n and V_{n+1} of the last
+// Solo durations of the two kernels of the fused iteration on this rank's shard: n launches each of S_n and V_{n+1} of the last
 // converged solve, back to back (see `replay` in k_cg_vec), between HIP events. NO other rank may start a solve meanwhile (the caller takes
 // turns: mistark_dist_fused_bench).
-void fused_pcg_replay(Context& c, int n_launches, double* s_us, double* r_us, double* v_us)
+void fused_pcg_replay(Context& c, int n_launches, double* s_us, double* v_us)
 {
     if (!c.fused_replay.valid || c.fused_replay.pattern != c.pattern_version) throw Error("fused replay: no converged fused solve on the current matrix to replay");
     FusedSolve F{c};
     if (!fused_setup(c, F)) throw Error("fused replay: the fused iteration is not available");
     F.base = c.fused_replay.base;
     const int n = c.fused_replay.n;
-    hipEvent_t e[4];
+    hipEvent_t e[3];
     for (auto& x : e) MS_CHECK(hipEventCreate(&x));
     for (int w = 0; w < 3; w++) {
         F.launch_S(n, nullptr, 1);
-        F.launch_R(n, 1);
         F.launch_V(n + 1, false, 0, 0.0, 0.0, nullptr, 0, 1);
     }
     MS_CHECK(hipEventRecord(e[0], c.stream));
     for (int i = 0; i < n_launches; i++) F.launch_S(n, nullptr, 1);
     MS_CHECK(hipEventRecord(e[1], c.stream));
-    for (int i = 0; i < n_launches; i++) F.launch_R(n, 1);
-    MS_CHECK(hipEventRecord(e[2], c.stream));
     for (int i = 0; i < n_launches; i++) F.launch_V(n + 1, false, 0, 0.0, 0.0, nullptr, 0, 1);
-    MS_CHECK(hipEventRecord(e[3], c.stream));
-    MS_CHECK(hipEventSynchronize(e[3]));
-    float ms[3] = {0.f, 0.f, 0.f};
-    for (int i = 0; i < 3; i++) MS_CHECK(hipEventElapsedTime(&ms[i], e[i], e[i + 1]));
+    MS_CHECK(hipEventRecord(e[2], c.stream));
+    MS_CHECK(hipEventSynchronize(e[2]));
+    float ms[2] = {0.f, 0.f};
+    for (int i = 0; i < 2; i++) MS_CHECK(hipEventElapsedTime(&ms[i], e[i], e[i + 1]));
     for (auto& x : e) (void)hipEventDestroy(x);
     c.coll->check();
     c.fused_replay.valid = false;  // (V has moved the vectors on)
     if (s_us) *s_us = 1e3 * ms[0] / n_launches;
-    if (r_us) *r_us = 1e3 * ms[1] / n_launches;
-    if (v_us) *v_us = 1e3 * ms[2] / n_launches;
+    if (v_us) *v_us = 1e3 * ms[1] / n_launches;
 }
 
 __global__ void k_copy_ctrl(const PcgCtrl* __restrict__ src, PcgCtrl* __restrict__ dst_host)
@@ -4976,7 +4968,7 @@ static void pcg_cg(Context& c, const double* rhs_dev, double abs_tol, double rel
             hipLaunchKernelGGL(k_cg_vec, dim3(gv), dim3(BLOCK), 0, c.stream, k, check_only ? 1 : 0, stop_on_indef, abs_tol, rel_tol, f, 0u, 0u, (const float*)c.dinv.p, c.nbr, u,
                                (const double*)w, p, s, xs, r, c.ctrl.p, dyn ? (const int32_t*)m1.crow_of_row.p : (const int32_t*)nullptr, (const uint32_t*)m1.row_chunk0.p,
                                (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, (const int32_t*)nullptr, (const uint32_t*)nullptr, pr[k & 1][0], pr[k & 1][1],
-                               k == k_end ? hs[slot] : (PcgCtrl*)nullptr, epoch, 0, (const double*)part_wu, gs, (const double*)pr[(k - 1) & 1][0], (const double*)pr[(k - 1) & 1][1], gv);
+                               k == k_end ? hs[slot] : (PcgCtrl*)nullptr, epoch, 0, (const double*)part_wu, gs, (const double*)pr[(k - 1) & 1][0], (const double*)pr[(k - 1) & 1][1], gv, 0);
             if (check_only) tail_done = true;
         }
         return k_end;
