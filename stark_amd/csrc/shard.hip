@@ -69,6 +69,11 @@ __global__ __launch_bounds__(TB) void k_scatter_all(const double* __restrict__ r
 // global block rows of element e of potential P (host connectivity)
 inline int64_t row_of(const Potential& P, int e, int k) { return (int64_t)P.args.dof_row_off[k] + P.conn_host[(size_t)e * P.conn_stride + P.args.dof_col[k]]; }
 inline bool has_host_conn(const Potential& P) { return !P.conn_ext && P.n_elem > 0 && !P.conn_host.empty(); }
+// What the partition, the ghost sets and the element lists are made from: potentials with FIXED host connectivity. A potential whose table is
+// refilled inside the Newton loop (part 1: contact tables handed over by a caller, e.g. through the SymX shim) is treated like the device-resident
+// tables: every rank evaluates all of its rows, the rows it references must be shared rows (mistark_dist_add_shared_rows) — its refills
+// neither move the owner map nor rebuild the static pattern.
+inline bool shards_by_list(const Potential& P) { return has_host_conn(P) && P.part == 0; }
 
 }  // namespace
 
@@ -267,11 +272,18 @@ void shard_prepare(Context& c)
     // ---- what the partition and the lists depend on
     std::vector<int32_t> shared = S.shared_rows;
     contact_shared_rows(c, shared);
-    std::vector<int64_t> sig{nbr, (int64_t)W, (int64_t)me, (int64_t)S.user_owner.size(), (int64_t)S.coords.size(), (int64_t)shared.size(), (int64_t)S.version};
+    auto hash_bytes = [](const void* p, size_t n) {  // (contents, not only sizes: shared rows that change at equal count must refresh the ghosts)
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        uint64_t h = 1469598103934665603ull;
+        for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+        return (int64_t)h;
+    };
+    std::vector<int64_t> sig{nbr, (int64_t)W, (int64_t)me, (int64_t)S.user_owner.size(), (int64_t)S.coords.size(), (int64_t)shared.size(), (int64_t)S.version,
+                             hash_bytes(shared.data(), shared.size() * sizeof(int32_t))};
     for (auto& P : c.pots) {
-        sig.push_back(has_host_conn(P) ? (int64_t)P.conn_version : -1);
+        sig.push_back(shards_by_list(P) ? (int64_t)P.conn_version : -1);
         sig.push_back(P.part);
-        sig.push_back(has_host_conn(P) ? P.n_elem : -1);
+        sig.push_back(shards_by_list(P) ? P.n_elem : -1);
         for (int k = 0; k < P.NB; k++) {
             sig.push_back(P.args.dof_col[k]);
             sig.push_back(P.args.dof_row_off[k]);
@@ -288,7 +300,7 @@ void shard_prepare(Context& c)
             if ((int64_t)S.coords.size() != 3 * nbr) throw Error("mistark_dist_set_row_coords: one position per block row (" + std::to_string(nbr) + ")");
             std::vector<int64_t> weight((size_t)nbr, 1);
             for (auto& P : c.pots)
-                if (has_host_conn(P))
+                if (shards_by_list(P))
                     for (int e = 0; e < P.n_elem; e++)
                         for (int k = 0; k < P.NB; k++) weight[(size_t)row_of(P, e, k)]++;
             rcb_partition_rows(nbr, W, S.coords.data(), weight, S.owner);
@@ -299,7 +311,7 @@ void shard_prepare(Context& c)
         std::vector<uint32_t> need((size_t)nbr, 0u);
         const uint32_t all = W >= 32 ? 0xffffffffu : ((1u << W) - 1u);
         for (auto& P : c.pots) {
-            if (!has_host_conn(P)) continue;
+            if (!shards_by_list(P)) continue;
             for (int e = 0; e < P.n_elem; e++) {
                 uint32_t m = 0;
                 for (int k = 0; k < P.NB; k++) m |= 1u << S.owner[(size_t)row_of(P, e, k)];
@@ -378,7 +390,7 @@ void shard_prepare(Context& c)
         // ---- element lists: [energy counts here | interface elements of other ranks]
         for (auto& P : c.pots) {
             P.n_list = P.n_eown_list = 0;
-            if (!has_host_conn(P)) continue;
+            if (!shards_by_list(P)) continue;
             std::vector<uint32_t> mine, halo;
             for (int e = 0; e < P.n_elem; e++) {
                 bool touch = false;
@@ -401,7 +413,7 @@ void shard_prepare(Context& c)
         PotArgs& A = P.args;
         A.lrow = S.lrow.p;
         A.n_own = (int)S.n_own;
-        if (has_host_conn(P)) {
+        if (shards_by_list(P)) {
             A.elem_list = P.elem_list.p;
             A.e_begin = 0;
             A.e_count = P.n_list;
