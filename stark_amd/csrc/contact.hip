@@ -518,7 +518,10 @@ __device__ __forceinline__ int wave_bound_f(const float* __restrict__ a, int lo,
 #define MISTARK_SWEEP_SUB 16
 #endif
 constexpr int SWEEP_SUB = MISTARK_SWEEP_SUB;  // lanes per sorted entry; measured 8 / 16 / 32: contact callbacks of configs[2] 1.63 / 1.73 / 1.90 ms per step, configs[3] equal within noise
-constexpr int SWEEP_SPLIT = 512;
+#ifndef MISTARK_SWEEP_SPLIT
+#define MISTARK_SWEEP_SPLIT 512
+#endif
+constexpr int SWEEP_SPLIT = MISTARK_SWEEP_SPLIT;
 constexpr int SWEEP_TASK_CAP = 1 << 16;
 constexpr int SWEEP_TASK_WAVES = 4096;
 struct SweepEntry
