@@ -383,6 +383,7 @@ struct Context
     DevBuf<unsigned char> dyn_desc;
     DevBuf<uint8_t> dyn_cub_tmp;
     DevBuf<uint32_t> dyn_long;      // [0]: number of long rows, then (first, end) pairs
+    DevBuf<double> dyn_long_part;   // chunk sums of the long rows (k_dyn_grad_gather_long)
     const uint32_t* dyn_sorted_key = nullptr;
     const uint32_t* dyn_sorted_val = nullptr;
     int64_t dyn_total = 0;          // contributions of all such potentials

@@ -459,35 +459,63 @@ __global__ __launch_bounds__(BLOCK) void k_dyn_grad_gather(const uint32_t* __res
     gr[1] += a1;
     gr[2] += a2;
 }
-// long runs (a rigid body under tens of thousands of contacts): one workgroup per run, thread t takes the positions t, t + 256, ...; fixed
-// tree reduction: the same bits every time
-__global__ __launch_bounds__(BLOCK) void k_dyn_grad_gather_long(const uint32_t* __restrict__ key, const uint32_t* __restrict__ val, const double* __restrict__ pool,
-                                                               double* __restrict__ grad, const uint32_t* __restrict__ long_list, int long_cap)
+// long runs (a rigid body under tens of thousands of contacts) in two steps: workgroups sum fixed chunks of DYN_CHUNK positions counted from the
+// run's start (thread t takes the positions t, t + 256, ... of the chunk; fixed tree reduction), then one thread per run adds the chunk sums in
+// order: the same bits every time, and a run of 10^5 contributions is spread over the chip instead of walked by one workgroup (0.31 ms for
+// configs[2]'s floor). Chunk c of the run starting at sorted position `first` owns slot first / 64 + c of `part`: runs are longer than 64 and
+// DYN_CHUNK >= 128, so the slots of different runs never meet.
+constexpr int DYN_CHUNK = 1024;
+__global__ __launch_bounds__(BLOCK) void k_dyn_grad_gather_long(const uint32_t* __restrict__ val, const double* __restrict__ pool, double* __restrict__ part,
+                                                               const uint32_t* __restrict__ long_list, int long_cap)
 {
     __shared__ double sm[4];
     const int n_long = min((int)long_list[0], long_cap);
-    for (int t = blockIdx.x; t < n_long; t += gridDim.x) {
+    for (int t = 0; t < n_long; t++) {
         const uint32_t first = long_list[1 + 2 * t], end = long_list[2 + 2 * t];
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-        for (uint32_t j = first + threadIdx.x; j < end; j += BLOCK) {
-            const double* g = pool + 3 * (size_t)val[j];
-            a0 += g[0];
-            a1 += g[1];
-            a2 += g[2];
-        }
-        a0 = block_sum(a0, sm);
-        __syncthreads();
-        a1 = block_sum(a1, sm);
-        __syncthreads();
-        a2 = block_sum(a2, sm);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double* gr = grad + 3 * (size_t)key[first];
-            gr[0] += a0;
-            gr[1] += a1;
-            gr[2] += a2;
+        const uint32_t nch = (end - first + DYN_CHUNK - 1) / DYN_CHUNK;
+        for (uint32_t ch = (blockIdx.x + gridDim.x - (uint32_t)t % gridDim.x) % gridDim.x; ch < nch; ch += gridDim.x) {
+            const uint32_t lo = first + ch * DYN_CHUNK, hi = min(end, lo + DYN_CHUNK);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (uint32_t j = lo + threadIdx.x; j < hi; j += BLOCK) {
+                const double* g = pool + 3 * (size_t)val[j];
+                a0 += g[0];
+                a1 += g[1];
+                a2 += g[2];
+            }
+            a0 = block_sum(a0, sm);
+            __syncthreads();
+            a1 = block_sum(a1, sm);
+            __syncthreads();
+            a2 = block_sum(a2, sm);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double* o = part + 3 * ((size_t)(first >> 6) + ch);
+                o[0] = a0;
+                o[1] = a1;
+                o[2] = a2;
+            }
         }
     }
+}
+__global__ __launch_bounds__(BLOCK) void k_dyn_grad_fold_long(const uint32_t* __restrict__ key, const double* __restrict__ part, double* __restrict__ grad,
+                                                             const uint32_t* __restrict__ long_list, int long_cap)
+{
+    const int n_long = min((int)long_list[0], long_cap);
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n_long) return;
+    const uint32_t first = long_list[1 + 2 * t], end = long_list[2 + 2 * t];
+    const uint32_t nch = (end - first + DYN_CHUNK - 1) / DYN_CHUNK;
+    const double* o = part + 3 * (size_t)(first >> 6);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (uint32_t ch = 0; ch < nch; ch++) {
+        a0 += o[3 * ch];
+        a1 += o[3 * ch + 1];
+        a2 += o[3 * ch + 2];
+    }
+    double* gr = grad + 3 * (size_t)key[first];
+    gr[0] += a0;
+    gr[1] += a1;
+    gr[2] += a2;
 }
 constexpr int DYN_LONG_CAP = 4096;
 // (re)build the sorted contribution lists when the tables changed, then add every row's sum to `grad`; on c.stream
@@ -515,8 +543,11 @@ static void dyn_grad_gather(Context& c, double* grad)
     c.dyn_long.ensure(1 + 2 * (size_t)DYN_LONG_CAP);
     MS_CHECK(hipMemsetAsync(c.dyn_long.p, 0, sizeof(uint32_t), c.stream));
     hipLaunchKernelGGL(k_dyn_grad_gather, dim3(grid_for(n)), dim3(BLOCK), 0, c.stream, c.dyn_sorted_key, c.dyn_sorted_val, n, (const double*)c.dyn_gpool.p, grad, c.dyn_long.p, DYN_LONG_CAP);
-    hipLaunchKernelGGL(k_dyn_grad_gather_long, dim3(64), dim3(BLOCK), 0, c.stream, c.dyn_sorted_key, c.dyn_sorted_val, (const double*)c.dyn_gpool.p, grad, (const uint32_t*)c.dyn_long.p,
+    c.dyn_long_part.ensure(3 * ((size_t)n / 64 + 2));
+    hipLaunchKernelGGL(k_dyn_grad_gather_long, dim3(256), dim3(BLOCK), 0, c.stream, c.dyn_sorted_val, (const double*)c.dyn_gpool.p, c.dyn_long_part.p, (const uint32_t*)c.dyn_long.p,
                        DYN_LONG_CAP);
+    hipLaunchKernelGGL(k_dyn_grad_fold_long, dim3(DYN_LONG_CAP / BLOCK), dim3(BLOCK), 0, c.stream, c.dyn_sorted_key, (const double*)c.dyn_long_part.p, grad,
+                       (const uint32_t*)c.dyn_long.p, DYN_LONG_CAP);
 }
 static void launch_grad_gather(Context& c, Potential& P)
 {
