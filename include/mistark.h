@@ -100,6 +100,8 @@ int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* 
 int mistark_potential_table(mistark_ctx* ctx, int potential, int32_t* conn, int64_t* n_elem, int32_t* conn_stride);
 int mistark_potential_binding_data(mistark_ctx* ctx, int potential, int binding, const double** host, int64_t* n_items, int32_t* stride);
 int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic);
+/* Id of the first potential registered under `name` (the ids mistark_potential returned, in registration order), -1 if there is none. */
+int mistark_find_potential(mistark_ctx* ctx, const char* name);
 /* LabelledConnectivity::clear() + push_back() (symx/src/compile/LabelledConnectivity.h): replaces the rows of a potential. */
 int mistark_potential_update_connectivity(mistark_ctx* ctx, int potential, const int32_t* conn, int32_t n_elem);
 /* Number of potentials known to the engine and their registry names (for the shim's "unknown name" error path). */
@@ -276,7 +278,10 @@ int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settin
 
 /* ---- options --------------------------------------------------------------------------------------------------------- */
 /* Engine switches (all default 0): "force_generic" = evaluate every potential through the generic hyper-dual kernels (the
- * closed-form tet kernels are then cross-checked against them); "atomic_assembly" = scatter assembly with float atomics
+ * closed-form kernels are then cross-checked against them; "generic_contact" = the same for the contact and friction potentials only;
+ * "contact_closed_min_lanes" = N: closed-form contact kernels for tables with at least N (contact, DoF pair) lanes, 0 = always, default
+ * -1 = by potential, see launch_eval);
+ * "atomic_assembly" = scatter assembly with float atomics
  * instead of the deterministic gather; "proj_variant" = PSD projection cross-checks, bits: 1 = eigen-decomposition with the
  * matrix in LDS instead of registers, 2 = one launch per potential instead of one for all short lists, 4 = IEEE division /
  * square root for the rotation angles, 8 = the full-size matrix for translation-invariant elements too (default: their reduced

@@ -116,6 +116,7 @@ def lib():
     L.mistark_project_by_gradient.argtypes = [p, dbl, C.c_int, dbl, C.POINTER(C.c_int), C.POINTER(i64)]
     L.mistark_assemble.argtypes = [p]
     L.mistark_potential_set_dynamic.argtypes = [p, C.c_int, C.c_int]
+    L.mistark_find_potential.argtypes = [p, C.c_char_p]
     L.mistark_potential_update_connectivity.argtypes = [p, C.c_int, p, C.c_int32]
     L.mistark_contact_init.argtypes = [p, C.POINTER(ContactArrays)]
     L.mistark_contact_add_mesh.argtypes = [p, C.c_int, C.c_int, p, C.c_int32, p, C.c_int32, p, C.c_int32]

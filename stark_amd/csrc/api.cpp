@@ -444,6 +444,13 @@ int mistark_potential_binding_data(mistark_ctx* ctx, int potential, int binding,
     if (stride) *stride = A.stride;
     API_END(0)
 }
+int mistark_find_potential(mistark_ctx* ctx, const char* name)
+{
+    if (!ctx || !name) return -1;
+    for (size_t i = 0; i < ctx->c.pots.size(); i++)
+        if (ctx->c.pots[i].name == name) return (int)i;
+    return -1;
+}
 int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)
 {
     API_BEGIN
@@ -550,9 +557,17 @@ int mistark_get_element_hessians(mistark_ctx* ctx, int potential, double* values
                         for (int j = 0; j < 3; j++)
                             values[((size_t)e * n + 3 * a + i) * n + 3 * b + j] = tmp[((size_t)(a * NB + b) * P.n_elem + e) * 9 + i * 3 + j];
     }
-    if (block_rows) {
+    if (block_rows && P.n_elem > 0) {
+        std::vector<int32_t> dev_conn;  // (tables of the device-side contact detector have no host copy)
+        const int32_t* conn = P.conn_host.data();
+        if (P.conn_ext) {
+            dev_conn.resize((size_t)P.n_elem * P.conn_stride);
+            MS_CHECK(hipMemcpyAsync(dev_conn.data(), P.conn_ext, dev_conn.size() * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+            MS_CHECK(hipStreamSynchronize(c.stream));
+            conn = dev_conn.data();
+        }
         for (int e = 0; e < P.n_elem; e++)
-            for (int k = 0; k < NB; k++) block_rows[(size_t)e * NB + k] = P.args.dof_row_off[k] + P.conn_host[(size_t)e * P.conn_stride + P.args.dof_col[k]];
+            for (int k = 0; k < NB; k++) block_rows[(size_t)e * NB + k] = P.args.dof_row_off[k] + conn[(size_t)e * P.conn_stride + P.args.dof_col[k]];
     }
     API_END(0)
 }
@@ -1067,6 +1082,8 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
         ctx->c.force_generic = value != 0;
         ctx->c.layout_dirty = true;  // (Potential::lazy_capable depends on it)
     }
+    else if (n == "generic_contact") ctx->c.generic_contact = value != 0;
+    else if (n == "contact_closed_min_lanes") ctx->c.contact_closed_min_lanes = value;
     else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;
     else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;
     else if (n == "lazy_hessians") ctx->c.lazy_allowed = value != 0;  // newton_solve: float upper-triangle pool for the closed-form tets

@@ -21,6 +21,7 @@
 #include "registry.hpp"
 #include "tet_closed.hpp"
 #include "tri_closed.hpp"
+#include "contact_closed.hpp"
 
 namespace mistark {
 
@@ -180,6 +181,57 @@ __global__ __launch_bounds__(BLOCK) void k_fold_hot(const double* __restrict__ g
     for (int w = 0; w < HOT_WAYS; w++) acc += grad_hot[(size_t)w * 3 * n_hot + t];
     const int r = t / 3;
     grad[3 * (size_t)hot_rows[r] + (t - 3 * r)] += acc;
+}
+
+// Contact and friction potentials in closed form (contact_closed.hpp): one lane per contact; output in k_eval_pgh's layout
+struct ClosedOut
+{
+    const PotArgs& a;
+    int e;
+    size_t pe;
+    double* elemH;
+    double* grad;
+    __device__ __forceinline__ void put_grad(int b, const V3<double>& g) const
+    {
+        if (a.gpool) {
+            double* o = a.gpool + ((size_t)b * a.n_gpool + pe) * 3;
+            o[0] = g.x; o[1] = g.y; o[2] = g.z;
+            return;
+        }
+        const int node = a.conn[(size_t)e * a.conn_stride + a.dof_col[b]];
+        double* o = a.hot_base[b] >= 0 ? &a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[b] + node) * 3] : &grad[3 * (size_t)(a.dof_row_off[b] + node)];
+        atomicAdd(o, g.x);
+        atomicAdd(o + 1, g.y);
+        atomicAdd(o + 2, g.z);
+    }
+    __device__ __forceinline__ void put_block(int NB, int ba, int bb, const M3<double>& B) const
+    {
+        double* o = elemH + ((size_t)(ba * NB + bb) * a.n_pool + pe) * 9;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) o[3 * i + j] = B.m[i][j];
+        if (ba != bb) {
+            double* t = elemH + ((size_t)(bb * NB + ba) * a.n_pool + pe) * 9;
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) t[3 * i + j] = B.m[j][i];
+        }
+    }
+};
+template <class En, bool STORE_H>
+__global__ __launch_bounds__(BLOCK) void k_eval_contact_closed(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
+{
+    static_assert(!HasCond<En>::value, "conditional potentials go through the generic kernel");
+    const int le = blockIdx.x * BLOCK + threadIdx.x;
+    if (le >= a.e_count) return;
+    const int e = elem_of(a, le), pe = pool_of(a, le);
+    double in[En::Layout::NIN];
+    gather_inputs<En>(a, e, in);
+    const ClosedOut out{a, e, (size_t)pe, elemH, grad};
+    const double E = closed_t<En>::template eval<STORE_H>(in, out);
+    elemE[pe] = energy_here(a, e) ? E : 0.0;
 }
 
 // grad[row] += sum of the pooled node gradients incident on the row, in list order (PotArgs::gpool). One lane per (block row, component),
@@ -672,6 +724,22 @@ static void launch_tet_closed_list(Context& c, Potential& P, const uint32_t* lis
         hipLaunchKernelGGL((k_eval_tet_closed<E_TetStrainEO, false, TET_H_LIST>), g, b, 0, c.stream, A, (double*)nullptr, H, (float*)nullptr, (double*)nullptr);
 }
 
+// One lane per contact (closed form) or one lane per (contact, pair of local DoFs) (generic)? A lane of the closed form walks 1500 (deformable
+// vertices only) to 4000 (rigid bodies: two jets through the quaternion update) dependent double-precision instructions: 18 to 48 us
+// however short the table is, and flat up to 65 k contacts (one wavefront per SIMD). The generic kernel starts at 12 to 20 us and grows
+// with the table (configs[2]: 187 us for 66 k point-triangle contacts against 48 us). Measured on configs[3], whose tables hold a few
+// hundred rows each: closed forms everywhere cost 7 Newton-steps/s of 154. So the table's size decides; contact_closed_min_lanes = 0
+// (tests: every table in closed form) or a lane count overrides.
+template <class En>
+static bool closed_contact_pays(const Context& c, int64_t n_elem)
+{
+    if constexpr (has_closed_contact<En>) {
+        constexpr int n = 3 * En::NB, NP = n * (n + 1) / 2;
+        const int64_t min_lanes = c.contact_closed_min_lanes >= 0 ? c.contact_closed_min_lanes : (En::NR > 0 ? 350000 : 100000);
+        return n_elem * NP >= min_lanes;
+    }
+    return false;
+}
 template <class En>
 static void launch_eval(Context& c, Potential& P, int mode)
 {
@@ -682,6 +750,12 @@ static void launch_eval(Context& c, Potential& P, int mode)
         PotArgs A = P.args;
         A.e_count = P.n_eown;  // (sharded: the elements whose energy counts here lead the list; P.args.e_count on one GPU)
         if (A.e_count > 0) hipLaunchKernelGGL((k_eval_p<En>), dim3(grid_for(A.e_count)), dim3(BLOCK), 0, c.stream, A, E);
+    } else if (has_closed_contact<En> && !c.force_generic && !c.generic_contact && closed_contact_pays<En>(c, P.n_elem)) {  // (the whole table's size: every rank of a sharded run decides alike)
+        if constexpr (has_closed_contact<En>) {
+            const dim3 g(grid_for(P.args.e_count)), b(BLOCK);
+            if (mode == MISTARK_EVAL_P_G) hipLaunchKernelGGL((k_eval_contact_closed<En, false>), g, b, 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
+            else hipLaunchKernelGGL((k_eval_contact_closed<En, true>), g, b, 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
+        }
     } else if (mode == MISTARK_EVAL_P_G) {
         hipLaunchKernelGGL((k_eval_pgh<En, false>), dim3(grid_for((int64_t)P.args.e_count * NP)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
     } else {

@@ -85,6 +85,12 @@ class Engine:
         self.potential_ids[name] = pid
         return pid
 
+    def potential_id(self, name: str) -> int:
+        pid = self.L.mistark_find_potential(self.h, name.encode())
+        if pid < 0:
+            raise KeyError(name)
+        return pid
+
     def set_dynamic(self, pid: int, dynamic: bool = True):
         """Routes the potential's Hessian blocks to the dynamic (contact) part of the split matrix."""
         self._ck(self.L.mistark_potential_set_dynamic(self.h, pid, int(dynamic)))

@@ -184,6 +184,61 @@ def test_full_size_stages_match_reference(name):
     sim.close()
 
 
+@pytest.mark.parametrize("name", ["slim_cfg2_clothbox_256", "slim_cfg4_mixed_26x26x25"])
+def test_full_size_contact_closed_forms_equal_the_generic_evaluator(name):
+    """contact_closed.hpp (hand-derived gradient / Hessian of the 35 contact and friction potentials, one lane per contact) against the
+    generic hyper-dual evaluation of the same expressions (option force_generic) on the contact sets of the full-size fixtures — 68 k
+    point-triangle contacts under configs[2]'s cloth, every table of configs[4]: every element Hessian, element energy and the gradient
+    at 1e-11 of the largest entry. (Against the reference itself: test_full_size_stages_match_reference above and the stage fixtures of
+    tests/test_gpu_parity.py, which hold all 35 potentials.)"""
+    import json
+
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"))
+    man = json.loads(bytes(z["slim_json"]).decode())
+    sim = _build_cfg(S, man["scene"])
+    sim.prepare()
+    if man["xamp"]:
+        x0 = sim.points("x0")
+        k = np.arange(x0.size).reshape(x0.shape)
+        sim.set_points("x0", x0 + man["xamp"] * np.sin(0.9 * k + 0.3))
+    sim.begin_time_step()
+    eng = _Eng(sim)
+    eng.set_dofs(man["amp"] * np.sin(1.3 * np.arange(eng.ndofs) + 0.7))
+    sim.before_energy_evaluation()
+    got = {}
+    eng.set_option("contact_closed_min_lanes", 0)  # (every table in closed form, whatever its size)
+    for generic in (0, 1):
+        eng.set_option("force_generic", generic)
+        E, g = eng.eval(capi.EVAL_P_G_H)
+        per = {}
+        for p in man["potentials"]:
+            if p["name"].startswith(("contact_", "friction_")) and p["n_elem"]:
+                pid = eng.potential_id(p["name"])
+                H, rows = eng.element_hessians(pid, p["n_elem"])
+                per[p["name"]] = (H, rows, eng.element_energies(pid, p["n_elem"]))
+        got[generic] = (E, g, per)
+    eng.set_option("force_generic", 0)
+    (E0, g0, per0), (E1, g1, per1) = got[0], got[1]
+    assert len(per0) >= 4 and sum(len(v[2]) for v in per0.values()) > 1000
+    assert abs(E0 - E1) <= 1e-12 * max(1.0, abs(E1))
+    assert np.abs(g0 - g1).max() <= 1e-11 * np.abs(g1).max()
+    for nm, (H, rows, Ee) in per0.items():
+        Hg, rows_g, Eg = per1[nm]
+        assert (rows == rows_g).all()
+        # point-line distances are evaluated as |u|^2 - (u.e)^2 / |e|^2 (distances.cpp:61-68): against a 2 m edge of the floor and a
+        # distance of 1e-3 the subtraction cancels 6-7 digits, so ANY two orderings of the same derivative expression (the reference's
+        # generated code, the hyper-dual pass, the closed form) differ by ~1e-16 (|u| / d)^2 = 4e-10 there
+        tol = 2e-9 if nm.split("_")[-2] in ("pe", "ep") else 1e-11
+        dev = np.abs(H - Hg).max() / np.abs(Hg).max()
+        print("%-32s %6d elements, closed form vs generic: %.1e" % (nm, len(Ee), dev))
+        assert dev <= tol, nm
+        assert np.abs(Ee - Eg).max() <= 1e-12 * max(np.abs(Eg).max(), 1e-300), nm
+    sim.close()
+
+
 def test_full_size_properties():
     import bench
     from stark_amd import capi

@@ -40,6 +40,8 @@ def test_stages_match_reference(path, variant):
     # custom_ops: no compiled kernel is used; every potential runs the reference's symx::Sequence through the device interpreter
     eng = engine_from_problem(prob, man, custom_ops=z if variant == "custom_ops" else None)
     assert eng.ndofs == man["ndofs"]
+    # closed-form kernels for every contact / friction table (by default the table's size decides: kernels.hip closed_contact_pays)
+    eng.set_option("contact_closed_min_lanes", 0)
     if variant == "generic_atomic":  # generic hyper-dual kernels for every potential + atomic scatter assembly
         eng.set_option("force_generic", 1)
         eng.set_option("atomic_assembly", 1)
