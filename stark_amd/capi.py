@@ -131,6 +131,18 @@ def lib():
     L.mistark_contact_get_friction_data.argtypes = [p, C.c_char_p, p, p, p, p, C.POINTER(C.c_int32)]
     L.mistark_contact_get_vertices.argtypes = [p, p, C.POINTER(i64)]
     L.mistark_contact_recipe.argtypes = [C.c_char_p, C.POINTER(C.c_int32), p, p, p]
+    L.mistark_cd_create.argtypes = [C.POINTER(p), C.c_int]
+    L.mistark_cd_destroy.argtypes = [p]
+    L.mistark_cd_destroy.restype = None
+    L.mistark_cd_last_error.argtypes = [p]
+    L.mistark_cd_last_error.restype = C.c_char_p
+    L.mistark_cd_add_mesh.argtypes = [p, p, i32, p, i32, p, i32]
+    L.mistark_cd_add_blacklist.argtypes = [p, i32, i32]
+    L.mistark_cd_activate.argtypes = [p, C.c_int, C.c_int]
+    L.mistark_cd_run_proximity.argtypes = [p, C.c_double, p]
+    L.mistark_cd_get_proximity.argtypes = [p, C.c_int, p, p]
+    L.mistark_cd_run_intersection.argtypes = [p, C.POINTER(i32)]
+    L.mistark_cd_get_intersections.argtypes = [p, p]
     L.mistark_shard_range.argtypes = [i64, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]
     L.mistark_dist_unique_id.argtypes = [p]
     L.mistark_dist_init_rccl.argtypes = [p, C.c_int, C.c_int, p]
@@ -220,3 +232,71 @@ def exported_symbols():
         out |= set(re.findall(r"\b(mistark_[a-z0-9_]+)\s*\(", hdr))
         out -= set(re.findall(r"struct\s+(mistark_[a-z0-9_]+)", hdr))  # (type names mentioned in comments)
     return sorted(out)
+
+
+class CollisionDetector:
+    """include/mistark_tmcd.h: the detector on host positions (what a replacement of the reference's tmcd::ProximityDetection /
+    tmcd::IntersectionDetection binds). Meshes keep a reference to the position arrays handed over: update them in place between runs."""
+    LISTS = ("pt_point_point", "pt_point_edge", "pt_point_triangle", "ee_point_point", "ee_point_edge", "ee_edge_edge")
+    COLS = (8, 9, 7, 10, 9, 8)
+
+    def __init__(self, device=0):
+        self.L = lib()
+        h = C.c_void_p()
+        rc = self.L.mistark_cd_create(C.byref(h), device)
+        if rc != 0:
+            raise RuntimeError("mistark_cd_create failed (%d): no usable GPU" % rc)
+        self.h = h
+        self._keep = []
+
+    def _ck(self, rc):
+        if rc < 0:
+            raise RuntimeError(self.L.mistark_cd_last_error(self.h).decode())
+        return rc
+
+    def add_mesh(self, x, triangles, edges):
+        import numpy as np
+        assert x.dtype == np.float64 and x.flags.c_contiguous
+        t = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        e = np.ascontiguousarray(edges, dtype=np.int32).reshape(-1, 2)
+        self._keep.append(x)
+        return self._ck(self.L.mistark_cd_add_mesh(self.h, x.ctypes.data, len(x), t.ctypes.data if len(t) else None, len(t), e.ctypes.data if len(e) else None, len(e)))
+
+    def add_blacklist(self, a, b):
+        self._ck(self.L.mistark_cd_add_blacklist(self.h, a, b))
+
+    def activate(self, point_triangle=True, edge_edge=True):
+        self._ck(self.L.mistark_cd_activate(self.h, int(point_triangle), int(edge_edge)))
+
+    def run_proximity(self, enlargement):
+        import numpy as np
+        counts = (C.c_int32 * 6)()
+        self._ck(self.L.mistark_cd_run_proximity(self.h, enlargement, counts))
+        out = {}
+        for l, name in enumerate(self.LISTS):
+            rows = np.zeros((counts[l], self.COLS[l]), dtype=np.int32)
+            dist = np.zeros(counts[l])
+            if counts[l]:
+                self._ck(self.L.mistark_cd_get_proximity(self.h, l, rows.ctypes.data, dist.ctypes.data))
+            out[name] = (rows, dist)
+        return out
+
+    def run_intersection(self):
+        import numpy as np
+        n = C.c_int32()
+        self._ck(self.L.mistark_cd_run_intersection(self.h, C.byref(n)))
+        rows = np.zeros((n.value, 9), dtype=np.int32)
+        if n.value:
+            self._ck(self.L.mistark_cd_get_intersections(self.h, rows.ctypes.data))
+        return rows
+
+    def close(self):
+        if self.h:
+            self.L.mistark_cd_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -28,6 +28,7 @@
 #include "contact_geom.hpp"
 #include "energies.hpp"
 #include "engine.hpp"
+#include "dist.hpp"
 
 #include <chrono>
 #include <cstdio>
@@ -421,7 +422,12 @@ __global__ __launch_bounds__(CB) void k_detect_et(ContactDev d, int chunk, int* 
 // contiguous run of boxes whose lo lies in [its lo, its hi]. One WAVEFRONT walks one entry's run, 64 candidates per step over a
 // sorted copy of the boxes (coalesced), so a box that spans the whole scene (a face of a large rigid body) costs long runs for a few
 // waves, not a stalled lane. Same pair set as the all-pairs kernels above (kept as cross-check / ablation).
-constexpr int NBANDS = 64;
+#ifndef MISTARK_NBANDS
+#define MISTARK_NBANDS 64
+#endif
+constexpr int NBANDS = MISTARK_NBANDS;
+constexpr int band_key_bits() { int b = 1; while ((1 << b) <= 3 * NBANDS) b++; return b; }  // (class, band) above the 32-bit sort coordinate; all ones = padding
+constexpr int BAND_KEY_BITS = band_key_bits();
 struct Bands
 {
     int axis, band_axis;
@@ -458,7 +464,7 @@ __global__ __launch_bounds__(CB) void k_bp_fill(ContactDev d, Bands B, const uin
     for (int k = b0; k <= b1; k++) {
         const uint32_t e = off[i] + (uint32_t)(k - b0);
         if (e < (uint32_t)cap) {
-            keys[e] = (cls << 38) | ((uint64_t)k << 32) | fk;
+            keys[e] = ((cls * NBANDS + (uint64_t)k) << 32) | fk;
             idx[e] = (uint32_t)i;
         }
     }
@@ -469,8 +475,8 @@ __global__ __launch_bounds__(CB) void k_bp_gather(ContactDev d, Bands B, const u
 {
     const int j = blockIdx.x * CB + threadIdx.x;
     if (j > cap) return;
-    const int here = j < cap ? (int)min((uint64_t)(3 * NBANDS), skeys[j] >> 32) : 3 * NBANDS;  // padding keys sort last
-    const int prev = j > 0 ? (int)min((uint64_t)(3 * NBANDS), skeys[j - 1] >> 32) : -1;
+    const int here = j < cap ? (int)min((uint64_t)(3 * NBANDS), (skeys[j] >> 32) & ((1ull << BAND_KEY_BITS) - 1)) : 3 * NBANDS;  // padding keys sort last
+    const int prev = j > 0 ? (int)min((uint64_t)(3 * NBANDS), (skeys[j - 1] >> 32) & ((1ull << BAND_KEY_BITS) - 1)) : -1;
     for (int t = prev + 1; t <= here; t++) seg[t] = j;
     if (j >= cap || here >= 3 * NBANDS) return;
     const float* b = d.aabb + 6 * (size_t)sidx[j];
@@ -579,7 +585,10 @@ __device__ __forceinline__ int sweep_scan(const ContactDev& d, const Bands& B, c
             const int v0 = d.edge[2 * e], v1 = d.edge[2 * e + 1], u0 = d.tri[3 * t], u1 = d.tri[3 * t + 1], u2 = d.tri[3 * t + 2];
             if (v0 == u0 || v0 == u1 || v0 == u2 || v1 == u0 || v1 == u1 || v1 == u2) continue;  // BroadPhaseET.cpp:161-165
             if (d.disabled[d.edge_mesh[e] * d.n_mesh + d.tri_mesh[t]]) continue;
-            if (edge_intersects_triangle(ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, u0), ldx(d.X, u1), ldx(d.X, u2))) hits++;
+            if (edge_intersects_triangle(ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, u0), ldx(d.X, u1), ldx(d.X, u2))) {
+                hits++;
+                if (enl2 < 0.0) push_key(pack_key(0, 0, 0, e, t), keys, counters, key_cap);  // (enl2 < 0: the caller wants the pairs, not only their number)
+            }
         }
     }
     return hits;
@@ -621,6 +630,10 @@ __global__ __launch_bounds__(CB) void k_sweep(ContactDev d, Bands B, const uint3
             if (!PROXIMITY && hits2) atomicAdd(&counters[1], hits2);
         }
     }
+#ifdef MISTARK_SWEEP_NOSCAN  // (measurement: the entry's setup and searches alone)
+    if (j_own == 0x7fffffff) counters[1] = j0;
+    return;
+#endif
     const int hits = sweep_scan<PROXIMITY, FRICTION, SUB>(d, B, sidx, s_aabb, E, j0, j_own, enl2, keys, counters, key_cap);
     if (!PROXIMITY && hits) atomicAdd(&counters[1], hits);
 }
@@ -858,6 +871,7 @@ struct ContactSystem
     uint64_t cache_version = 0;
     double cache_dt = 0.0;
     int64_t cache_n = 0;
+    DevBuf<double> thick_override;  // standalone detector (mistark_cd_*): no thickness filter, one huge value per mesh
     DevBuf<int> sweep_tasks;  // (entry, first candidate, end) of the split-off parts of long sweep ranges + their count
     DevBuf<uint8_t> cub_tmp;
     DevBuf<TableDev> tables_dev;
@@ -1031,7 +1045,7 @@ ContactDev dev_view(Context& c, ContactSystem& cs)
     ContactDev d{};
     d.cv_src = cs.cv_src.p; d.cv_mesh = cs.cv_mesh.p; d.tri = cs.tri.p; d.tri_mesh = cs.tri_mesh.p; d.edge = cs.edge.p; d.edge_mesh = cs.edge_mesh.p;
     d.mesh_kind = cs.mesh_kind.p; d.mesh_idx = cs.mesh_idx.p; d.disabled = cs.disabled.p; d.mu = cs.mu.p;
-    d.thick = arr_dev(c, cs.arr.thickness);
+    d.thick = cs.thick_override.p ? cs.thick_override.p : arr_dev(c, cs.arr.thickness);
     d.X = cs.X.p; d.aabb = cs.aabb.p;
     d.n_mesh = (int)cs.meshes.size(); d.n_v = cs.n_v; d.n_t = cs.n_t; d.n_e = cs.n_e;
     return d;
@@ -1103,9 +1117,9 @@ void sort_boxes(Context& c, ContactSystem& cs, const ContactDev& d)
     hipLaunchKernelGGL(k_bp_fill, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, (const uint32_t*)cs.bp_off.p, cs.bp_keys.p, cs.bp_idx.p, cap, cs.counters.p + 48);
     hipcub::DoubleBuffer<uint64_t> dk(cs.bp_keys.p, cs.bp_keys_alt.p);
     hipcub::DoubleBuffer<uint32_t> dv(cs.bp_idx.p, cs.bp_idx_alt.p);
-    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, cap, 0, 40, c.stream));
+    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, dk, dv, cap, 0, 32 + BAND_KEY_BITS, c.stream));
     cs.cub_tmp.ensure(tmp);
-    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(cs.cub_tmp.p, tmp, dk, dv, cap, 0, 40, c.stream));
+    MS_CHECK(hipcub::DeviceRadixSort::SortPairs(cs.cub_tmp.p, tmp, dk, dv, cap, 0, 32 + BAND_KEY_BITS, c.stream));
     cs.s_idx = dv.Current();
     hipLaunchKernelGGL(k_bp_gather, dim3((cap + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, (const uint64_t*)dk.Current(), cs.s_idx, cap, cs.s_aabb.p, cs.s_lo.p, cs.seg.p);
 }
@@ -1390,9 +1404,286 @@ int find_table(const char* name)
     return -1;
 }
 }  // namespace
+
+// ---- the detector as a standalone service (include/mistark_tmcd.h): host positions in, the reference's result lists out -----------------------
+// One private context with a contact system that has no tables: every mesh counts as deformable and nothing is filtered by thickness, so the
+// six barrier tables of the deformable family ARE tmcd's six lists (table_of(family, 0, 0)); the sorted keys come back to the host and are
+// expanded into rows there.
+struct StandaloneDetector
+{
+    Context c;
+    std::vector<const double*> xm;
+    std::vector<double> X;
+    std::vector<int32_t> rows[6], et_rows;
+    std::vector<double> dist[6];
+    std::vector<uint64_t> keys;
+    std::string last_error;
+};
+namespace {
+constexpr int CD_COLS[6] = {8, 9, 7, 10, 9, 8};
+void cd_upload_positions(StandaloneDetector& D)
+{
+    ContactSystem& cs = CS(D.c);
+    D.X.resize(3 * (size_t)cs.n_v);
+    for (size_t g = 0; g < cs.meshes.size(); g++) std::memcpy(D.X.data() + 3 * (size_t)cs.meshes[g].v_off, D.xm[g], 3 * (size_t)cs.meshes[g].n_v * sizeof(double));
+    cs.X.ensure(std::max<size_t>(D.X.size(), 1));
+    cs.aabb.ensure(6 * (size_t)std::max(cs.n_v + cs.n_t + cs.n_e, 1));
+    if (!D.X.empty()) MS_CHECK(hipMemcpyAsync(cs.X.p, D.X.data(), D.X.size() * sizeof(double), hipMemcpyHostToDevice, D.c.stream));
+}
+ContactDev cd_view(StandaloneDetector& D)
+{
+    Context& c = D.c;
+    ContactSystem& cs = CS(c);
+    upload_meshes(c, cs);
+    if (cs.thick_override.cap < cs.meshes.size()) {
+        const std::vector<double> big(cs.meshes.size(), 1e300);
+        upload(c, cs.thick_override, big);
+        MS_CHECK(hipStreamSynchronize(c.stream));
+    }
+    return dev_view(c, cs);
+}
+// searches until the box list and the key list fit; returns the number of keys (sorted when `sort`), h = the counters
+int cd_search(StandaloneDetector& D, const ContactDev& d, bool proximity, double enl, int* h)
+{
+    Context& c = D.c;
+    ContactSystem& cs = CS(c);
+    if (cs.key_cap == 0) {
+        cs.key_cap = initial_key_cap();
+        cs.keys.ensure(cs.key_cap);
+        cs.keys_alt.ensure(cs.key_cap);
+    }
+    for (;;) {
+        MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
+        sort_boxes(c, cs, d);
+        if (proximity) launch_sweep<true, false>(c, cs, d, enl * enl);
+        else launch_sweep<false, false>(c, cs, d, -1.0);
+        fetch(c, h, cs.counters.p, 64 * sizeof(int));
+        if (h[51] > cs.bp_cap) {
+            cs.bp_cap = h[51] + h[51] / 4;
+            continue;
+        }
+        if ((size_t)h[0] > cs.key_cap) {
+            cs.key_cap = (size_t)h[0] + h[0] / 2;
+            cs.keys.ensure(cs.key_cap);
+            cs.keys_alt.ensure(cs.key_cap);
+            continue;
+        }
+        return h[0];
+    }
+}
+}  // namespace
 }  // namespace mistark
 
 using namespace mistark;
+struct mistark_cd
+{
+    StandaloneDetector D;
+};
+#define CD_BEGIN          \
+    if (!cd) return -1;   \
+    try {
+#define CD_END(ret)                      \
+    }                                    \
+    catch (const std::exception& e)      \
+    {                                    \
+        cd->D.last_error = e.what();     \
+        return -1;                       \
+    }                                    \
+    return ret;
+extern "C" {
+int mistark_cd_create(mistark_cd** out, int device)
+{
+    if (!out) return -1;
+    *out = nullptr;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return -3;  // (no GPU: there is no host detector to fall back to)
+    if (device < 0 || device >= n_dev) return -2;
+    if (hipSetDevice(device) != hipSuccess) return -4;
+    mistark_cd* cd = new mistark_cd();
+    Context& c = cd->D.c;
+    c.device = device;
+    if (hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking) != hipSuccess) {
+        delete cd;
+        return -5;
+    }
+    auto* cs = new ContactSystem();
+    c.contact = cs;
+    const int32_t none[12] = {-1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
+    std::memcpy(&cs->arr, none, sizeof(none));
+    cs->counters.ensure(64);
+    *out = cd;
+    return 0;
+}
+void mistark_cd_destroy(mistark_cd* cd)
+{
+    if (!cd) return;
+    (void)hipSetDevice(cd->D.c.device);
+    (void)hipStreamSynchronize(cd->D.c.stream);
+    delete cd;  // (Context's destructor releases the contact system, the buffers and the stream)
+}
+const char* mistark_cd_last_error(mistark_cd* cd) { return cd ? cd->D.last_error.c_str() : "null detector"; }
+int mistark_cd_add_mesh(mistark_cd* cd, const double* xm, int32_t n_vertices, const int32_t* triangles, int32_t n_triangles, const int32_t* edges, int32_t n_edges)
+{
+    int g = -1;
+    CD_BEGIN
+    if (!xm || (n_triangles > 0 && !triangles) || (n_edges > 0 && !edges)) throw Error("cd: null mesh data");
+    std::vector<int32_t> src((size_t)std::max(n_vertices, 0));
+    for (int i = 0; i < n_vertices; i++) src[i] = i;
+    g = contact_add_mesh(cd->D.c, MISTARK_CONTACT_DEFORMABLE, 0, src.data(), n_vertices, triangles, n_triangles, edges, n_edges);
+    cd->D.xm.push_back(xm);
+    CD_END(g)
+}
+int mistark_cd_add_blacklist(mistark_cd* cd, int32_t a, int32_t b)
+{
+    CD_BEGIN
+    ContactSystem& cs = CS(cd->D.c);
+    if (a < 0 || b < 0 || a >= (int)cs.meshes.size() || b >= (int)cs.meshes.size()) throw Error("cd: bad mesh id");
+    cs.disabled_pairs.push_back({a, b});
+    cs.meshes_dirty = true;
+    CD_END(0)
+}
+int mistark_cd_activate(mistark_cd* cd, int point_triangle, int edge_edge)
+{
+    CD_BEGIN
+    ContactSystem& cs = CS(cd->D.c);
+    cs.pt_enabled = point_triangle != 0;
+    cs.ee_enabled = edge_edge != 0;
+    CD_END(0)
+}
+int mistark_cd_run_proximity(mistark_cd* cd, double enlargement, int32_t counts[6])
+{
+    CD_BEGIN
+    StandaloneDetector& D = cd->D;
+    Context& c = D.c;
+    ContactSystem& cs = CS(c);
+    MS_CHECK(hipSetDevice(c.device));
+    for (int l = 0; l < 6; l++) {
+        D.rows[l].clear();
+        D.dist[l].clear();
+        if (counts) counts[l] = 0;
+    }
+    if (cs.meshes.empty()) return 0;
+    if (!(enlargement >= 0.0)) throw Error("cd: negative enlargement");
+    cd_upload_positions(D);
+    const ContactDev d = cd_view(D);
+    const float enl_f = nextafterf((float)enlargement, INFINITY) + 1.1920929e-07f;  // (float)enl + eps (AABBs.cpp:38), rounded up
+    const int np = cs.n_v + cs.n_t + cs.n_e;
+    hipLaunchKernelGGL(k_contact_aabbs, dim3((np + CB - 1) / CB), dim3(CB), 0, c.stream, d, enl_f, cs.aabb.p);
+    int h[64];
+    const int n = cd_search(D, d, true, enlargement, h);
+    if (n == 0) return 0;
+    MS_CHECK(hipMemsetAsync(cs.counters.p + 2, 0, sizeof(int), c.stream));
+    const uint64_t* sorted = sort_and_bound(c, cs, n, nullptr, false);
+    D.keys.resize((size_t)n);
+    MS_CHECK(hipMemcpyAsync(D.keys.data(), sorted, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
+    fetch(c, h, cs.counters.p, 64 * sizeof(int));
+    const int* bounds = h + 8;
+    const uint64_t pmask = (1ull << PRIM_BITS) - 1;
+    auto X3 = [&](int v) { return d3(D.X[3 * (size_t)v], D.X[3 * (size_t)v + 1], D.X[3 * (size_t)v + 2]); };
+    for (int l = 0; l < 6; l++) {
+        const int k0 = bounds[l], k1 = bounds[l + 1], cols = CD_COLS[l];
+        D.rows[l].resize((size_t)(k1 - k0) * cols);
+        D.dist[l].resize((size_t)(k1 - k0));
+        if (counts) counts[l] = k1 - k0;
+        for (int k = k0; k < k1; k++) {
+            const uint64_t key = D.keys[(size_t)k];
+            const int type = (int)((key >> 53) & 0xF), a = (int)((key >> PRIM_BITS) & pmask), b = (int)(key & pmask);
+            int32_t* r = D.rows[l].data() + (size_t)(k - k0) * cols;
+            int ty;
+            if (l < 3) {  // (point a, triangle b): ProximityDetection.cpp:113-129
+                const int mp = cs.h_cv_mesh[a], mt = cs.h_tri_mesh[b];
+                const ContactSystem::Mesh &Mp = cs.meshes[mp], &Mt = cs.meshes[mt];
+                const int t[3] = {cs.h_tri[3 * (size_t)b], cs.h_tri[3 * (size_t)b + 1], cs.h_tri[3 * (size_t)b + 2]};
+                r[0] = mp; r[1] = a - Mp.v_off;
+                r[2] = mt; r[3] = b - Mt.t_off; r[4] = t[0] - Mt.v_off; r[5] = t[1] - Mt.v_off; r[6] = t[2] - Mt.v_off;
+                if (l == 0) r[7] = t[type - P_T0] - Mt.v_off;
+                if (l == 1) {
+                    r[7] = t[type - P_E0] - Mt.v_off;
+                    r[8] = t[(type - P_E0 + 1) % 3] - Mt.v_off;
+                }
+                D.dist[l][(size_t)(k - k0)] = std::sqrt(point_triangle_sq_distance(ty, X3(a), X3(t[0]), X3(t[1]), X3(t[2])));
+            } else {  // (edge a, edge b): ProximityDetection.cpp:166-186
+                const int ma = cs.h_edge_mesh[a], mb = cs.h_edge_mesh[b];
+                const ContactSystem::Mesh &Ma = cs.meshes[ma], &Mb = cs.meshes[mb];
+                const int ea[2] = {cs.h_edge[2 * (size_t)a], cs.h_edge[2 * (size_t)a + 1]}, eb[2] = {cs.h_edge[2 * (size_t)b], cs.h_edge[2 * (size_t)b + 1]};
+                const int32_t EA[4] = {ma, a - Ma.e_off, ea[0] - Ma.v_off, ea[1] - Ma.v_off}, EB[4] = {mb, b - Mb.e_off, eb[0] - Mb.v_off, eb[1] - Mb.v_off};
+                auto put = [&](int32_t* o, const int32_t* E, int point) {
+                    for (int i = 0; i < 4; i++) o[i] = E[i];
+                    if (point >= 0) o[4] = E[2 + point];
+                };
+                if (l == 3) {
+                    put(r, EA, type == EA0_EB0 || type == EA0_EB1 ? 0 : 1);
+                    put(r + 5, EB, type == EA0_EB0 || type == EA1_EB0 ? 0 : 1);
+                } else if (l == 4) {
+                    if (type == EA_EB0 || type == EA_EB1) {  // the point is on edge b: it comes first
+                        put(r, EB, type == EA_EB0 ? 0 : 1);
+                        put(r + 5, EA, -1);
+                    } else {
+                        put(r, EA, type == EA0_EB ? 0 : 1);
+                        put(r + 5, EB, -1);
+                    }
+                } else {
+                    put(r, EA, -1);
+                    put(r + 4, EB, -1);
+                }
+                D.dist[l][(size_t)(k - k0)] = std::sqrt(edge_edge_sq_distance(ty, X3(ea[0]), X3(ea[1]), X3(eb[0]), X3(eb[1])));
+            }
+        }
+    }
+    CD_END(0)
+}
+int mistark_cd_get_proximity(mistark_cd* cd, int list, int32_t* rows, double* distance)
+{
+    CD_BEGIN
+    if (list < 0 || list >= 6) throw Error("cd: bad list");
+    if (rows && !cd->D.rows[list].empty()) std::memcpy(rows, cd->D.rows[list].data(), cd->D.rows[list].size() * sizeof(int32_t));
+    if (distance && !cd->D.dist[list].empty()) std::memcpy(distance, cd->D.dist[list].data(), cd->D.dist[list].size() * sizeof(double));
+    CD_END(0)
+}
+int mistark_cd_run_intersection(mistark_cd* cd, int32_t* n_pairs)
+{
+    CD_BEGIN
+    StandaloneDetector& D = cd->D;
+    Context& c = D.c;
+    ContactSystem& cs = CS(c);
+    MS_CHECK(hipSetDevice(c.device));
+    D.et_rows.clear();
+    if (n_pairs) *n_pairs = 0;
+    if (cs.meshes.empty() || cs.n_e == 0 || cs.n_t == 0) return 0;
+    cd_upload_positions(D);
+    const ContactDev d = cd_view(D);
+    const int np = cs.n_v + cs.n_t + cs.n_e;
+    hipLaunchKernelGGL(k_contact_aabbs, dim3((np + CB - 1) / CB), dim3(CB), 0, c.stream, d, 0.f, cs.aabb.p);  // tight boxes (BroadPhaseET)
+    int h[64];
+    const int n = cd_search(D, d, false, 0.0, h);
+    if (n != h[1]) throw Error("cd: intersection list and count disagree");
+    if (n == 0) return 0;
+    D.keys.resize((size_t)n);
+    MS_CHECK(hipMemcpyAsync(D.keys.data(), cs.keys.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    std::sort(D.keys.begin(), D.keys.end());
+    const uint64_t pmask = (1ull << PRIM_BITS) - 1;
+    D.et_rows.resize(9 * (size_t)n);
+    for (int k = 0; k < n; k++) {
+        const int e = (int)((D.keys[(size_t)k] >> PRIM_BITS) & pmask), t = (int)(D.keys[(size_t)k] & pmask);
+        const int me = cs.h_edge_mesh[e], mt = cs.h_tri_mesh[t];
+        const ContactSystem::Mesh &Me = cs.meshes[me], &Mt = cs.meshes[mt];
+        int32_t* r = D.et_rows.data() + 9 * (size_t)k;
+        r[0] = me; r[1] = e - Me.e_off; r[2] = cs.h_edge[2 * (size_t)e] - Me.v_off; r[3] = cs.h_edge[2 * (size_t)e + 1] - Me.v_off;
+        r[4] = mt; r[5] = t - Mt.t_off;
+        for (int i = 0; i < 3; i++) r[6 + i] = cs.h_tri[3 * (size_t)t + i] - Mt.v_off;
+    }
+    if (n_pairs) *n_pairs = n;
+    CD_END(0)
+}
+int mistark_cd_get_intersections(mistark_cd* cd, int32_t* rows)
+{
+    CD_BEGIN
+    if (rows && !cd->D.et_rows.empty()) std::memcpy(rows, cd->D.et_rows.data(), cd->D.et_rows.size() * sizeof(int32_t));
+    CD_END(0)
+}
+}  // extern "C"
+
 
 #define CAPI_BEGIN       \
     if (!ctx) return -1; \

@@ -160,3 +160,92 @@ def test_key_list_and_padded_sort_grow_on_demand(cap, monkeypatch):
         ours = eng.contact_table(p["name"])
         assert ours.shape == ref.shape and (sorted_rows(ours) == sorted_rows(ref)).all(), p["name"]
     eng.close()
+
+
+def _oracle_lists(prox):
+    """oracle/contact.py: detect()'s classified pairs as the rows of include/mistark_tmcd.h (ProximityDetection.cpp:113-129, :166-186)."""
+    out = {k: [] for k in ("pt_point_point", "pt_point_edge", "pt_point_triangle", "ee_point_point", "ee_point_edge", "ee_edge_edge")}
+    dist = {k: [] for k in out}
+    pt = prox.get("pt")
+    if pt is not None:
+        for k in range(len(pt["ty"])):
+            ty, tv = int(pt["ty"][k]), [int(v) for v in pt["tv"][k]]
+            head = [int(pt["pm"][k]), int(pt["pi"][k]), int(pt["tm"][k]), int(pt["ti"][k])] + tv
+            if ty <= 2:
+                name, row = "pt_point_point", head + [tv[ty]]
+            elif ty <= 5:
+                name, row = "pt_point_edge", head + [tv[ty - 3], tv[(ty - 2) % 3]]
+            else:
+                name, row = "pt_point_triangle", head
+            out[name].append(row)
+            dist[name].append(float(pt["d"][k]))
+    ee = prox.get("ee")
+    if ee is not None:
+        for k in range(len(ee["ty"])):
+            ty = int(ee["ty"][k])
+            A = [int(ee["am"][k]), int(ee["ai"][k]), int(ee["av"][k][0]), int(ee["av"][k][1])]
+            B = [int(ee["bm"][k]), int(ee["bi"][k]), int(ee["bv"][k][0]), int(ee["bv"][k][1])]
+            if ty <= 3:     # EA0_EB0, EA0_EB1, EA1_EB0, EA1_EB1
+                name, row = "ee_point_point", A + [A[2 + ty // 2]] + B + [B[2 + ty % 2]]
+            elif ty <= 5:   # EA_EB0, EA_EB1: the point lies on edge b and comes first
+                name, row = "ee_point_edge", B + [B[2 + ty - 4]] + A
+            elif ty <= 7:   # EA0_EB, EA1_EB
+                name, row = "ee_point_edge", A + [A[2 + ty - 6]] + B
+            else:
+                name, row = "ee_edge_edge", A + B
+            out[name].append(row)
+            dist[name].append(float(ee["d"][k]))
+    return out, dist
+
+
+@pytest.mark.parametrize("name", ["contactmix_t0", "contactmix_t1", "contactrods_t0", "contactcorners_t0"])
+def test_standalone_detector_returns_the_references_lists(name):
+    """include/mistark_tmcd.h (the detector behind the reference's own tmcd::ProximityDetection / IntersectionDetection interface, host
+    positions in, result lists out) against the oracle's brute-force restatement of ProximityDetection::run, which tests/test_oracle_contact.py
+    pins to the reference's tables: the six lists as row sets, bit-exact, with their distances."""
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    st, _ = state_from_fixture(prob, man)
+    scene = oc.scene_from_fixture(man, z)
+    dt = float(np.asarray(st["dt"]).ravel()[0])
+    X = [np.ascontiguousarray(x, dtype=np.float64) for x in oc.mesh_vertices(scene, st, dt)]
+    cd = capi.CollisionDetector()
+    for m, x in zip(scene.meshes, X):
+        cd.add_mesh(x, m.tris, m.edges)
+    for (a, b) in scene.disabled:
+        cd.add_blacklist(a, b)
+    enl = 2.0 * oc.max_thickness(scene)
+    got = cd.run_proximity(enl)
+    ref, ref_d = _oracle_lists(oc.detect(scene, X, enl))
+    total = 0
+    for lname, (rows, d) in got.items():
+        r = np.array(ref[lname], dtype=np.int64).reshape(-1, rows.shape[1])
+        assert rows.shape == r.shape, (lname, rows.shape, r.shape)
+        if len(r) == 0:
+            continue
+        o1 = np.lexsort(rows.T[::-1])
+        o2 = np.lexsort(r.T[::-1])
+        assert (rows[o1] == r[o2]).all(), lname
+        assert np.abs(d[o1] - np.array(ref_d[lname])[o2]).max() <= 1e-15 * max(1.0, d.max()), lname
+        total += len(r)
+    assert total > 10
+    assert len(cd.run_intersection()) == 0
+    # move one mesh through the others (positions are re-read at every run): intersections appear, and a second proximity run follows the move
+    for x in X:
+        if len(x) > 8:
+            x[:, 2] -= 0.05
+            break
+    hits = cd.run_intersection()
+    assert oc.has_intersections(scene, X) == (len(hits) > 0)
+    got2 = cd.run_proximity(enl)
+    ref2, _ = _oracle_lists(oc.detect(scene, X, enl))
+    for lname, (rows, _) in got2.items():
+        r = np.array(ref2[lname], dtype=np.int64).reshape(-1, rows.shape[1])
+        assert rows.shape == r.shape, lname
+        if len(r):
+            assert (rows[np.lexsort(rows.T[::-1])] == r[np.lexsort(r.T[::-1])]).all(), lname
+    if len(hits):
+        e, t = hits[0, :4], hits[0, 4:]
+        assert oc.edge_intersects_triangle(X[e[0]][e[2]][None], X[e[0]][e[3]][None], X[t[0]][t[2]][None], X[t[0]][t[3]][None], X[t[0]][t[4]][None]).all()
+    cd.close()
