@@ -74,6 +74,7 @@ namespace symx
 		static constexpr int64_t SMALL_ARRAY = 32768;  // doubles: arrays up to this size are fingerprinted at every evaluation
 		bool strict = false;        // MISTARK_SHIM_STRICT=1
 		int64_t n_uploads = 0, n_table_updates = 0, bytes_sent = 0;  // statistics (MISTARK_SHIM_STATS=1 prints them at destruction)
+		double t_tables = 0.0, t_hash = 0.0, t_upload = 0.0;  // inside sync(): table updates in the engine, fingerprints, array uploads
 		double t_callbacks = 0.0, t_sync = 0.0, t_dofs = 0.0, t_solve = 0.0;  // seconds: the caller's callbacks, sync(), DoF transfers, all of solve()
 		static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 		template <class F>
@@ -142,7 +143,8 @@ namespace symx
 		{
 			if (std::getenv("MISTARK_SHIM_STATS"))
 				std::cerr << "mistark shim: " << n_uploads << " array uploads, " << n_table_updates << " table updates, " << bytes_sent / 1e6 << " MB sent to the engine; of " << t_solve
-				          << " s in solve(): " << t_callbacks << " s in the caller's callbacks, " << t_sync << " s in sync(), " << t_dofs << " s bringing DoFs to the caller" << std::endl;
+				          << " s in solve(): " << t_callbacks << " s in the caller's callbacks, " << t_sync << " s in sync() (" << t_tables << " table updates, " << t_hash << " array fingerprints, " << t_upload << " array uploads), " << t_dofs
+				          << " s bringing DoFs to the caller" << std::endl;
 			if (ctx) mistark_destroy(ctx);
 		}
 
@@ -259,7 +261,9 @@ namespace symx
 						P.print = n_elem > 0 ? fingerprint(conn, (size_t)n_elem * (size_t)P.stride * sizeof(int32_t)) : 0;
 					}
 					if (changed) {
+						const double tt = now();
 						check(mistark_potential_update_connectivity(ctx, P.id, conn, n_elem), "mistark_potential_update_connectivity");
+						t_tables += now() - tt;
 						n_table_updates++;
 						bytes_sent += (int64_t)n_elem * P.stride * 4;
 						P.conn = conn;
@@ -274,9 +278,14 @@ namespace symx
 				if (a.id < 0 || a.is_dof || !a.host || a.n <= 0) continue;
 				const int64_t doubles = a.n * (int64_t)a.stride;
 				if (a.have_print && !full && doubles > SMALL_ARRAY) continue;
+				const double th = now();
 				const uint64_t h = fingerprint(a.host, (size_t)doubles * sizeof(double));
+				t_hash += now() - th;
 				if (a.have_print && h == a.print) continue;
+				const double tu = now();
 				check(mistark_upload(ctx, a.id), "mistark_upload");
+				t_upload += now() - tu;
+				if (const char* v = std::getenv("MISTARK_SHIM_STATS"); v && v[0] == '2') std::cerr << "  upload " << doubles * 8 << " B " << (now() - tu) * 1e3 << " ms" << std::endl;
 				a.print = h;
 				a.have_print = true;
 				n_uploads++;

@@ -339,7 +339,7 @@ static void upload_one(Context& c, Array& a)
         if (s.n > 0) MS_CHECK(hipMemcpyAsync(c.u.p + s.offset, s.host, s.n * sizeof(double), hipMemcpyHostToDevice, c.stream));
     } else {
         const size_t n = (size_t)a.n_items * a.stride;
-        if (n > 0 && a.host) MS_CHECK(hipMemcpyAsync(a.dev, a.host, n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+        if (n > 0 && a.host) h2d_staged(c, a.dev, a.host, n * sizeof(double));
     }
     a.need_upload = false;
 }

@@ -358,6 +358,8 @@ struct Context
     DevBuf<int64_t> counters;
     double* h_scratch = nullptr;    // pinned host scratch
     void* h_pin = nullptr;          // pinned staging area of fetch()
+    void* h_stage[2] = {nullptr, nullptr};  // pinned staging areas of h2d_staged() (uploads of the caller's pageable arrays)
+    hipEvent_t h_stage_ev[2] = {nullptr, nullptr};
     size_t h_pin_bytes = 0;
     uint8_t* pub = nullptr;         // coherent pinned page small read-backs are published into (kernels.hip: publish)
     uint32_t pub_seq = 0;
@@ -454,6 +456,10 @@ struct Context
 // device -> host copy of a few scalars through pinned memory + stream synchronisation (a pageable destination would take HIP's
 // slow staged path: tens of microseconds of idle GPU per call, dozens of calls per Newton iteration)
 void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes);
+// host -> device copy of a caller's (pageable) array on c.stream through two pinned staging areas: HIP's own pageable path pins and unpins
+// the range inside every copy (1.5 ms for 4 MB measured); a memcpy into pinned memory and a DMA transfer take a quarter of that. The source
+// may be reused when the call returns; the copy is ordered on c.stream like any other.
+void h2d_staged(Context& c, void* dst_dev, const void* src_host, size_t bytes);
 void prepare(Context& c);
 // shard.hip
 void shard_prepare(Context& c);                                        // partition, local numbering, element lists, exchange tables (from prepare())

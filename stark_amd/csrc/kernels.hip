@@ -964,6 +964,28 @@ static bool publish(Context& c, void* dst_host, const void* src_dev, size_t byte
     std::memcpy(dst_host, c.pub, bytes);
     return true;
 }
+void h2d_staged(Context& c, void* dst_dev, const void* src_host, size_t bytes)
+{
+    constexpr size_t CHUNK = (size_t)4 << 20;
+    if (bytes < ((size_t)1 << 16)) {  // (small: HIP copies these through its own staging buffer without pinning anything)
+        MS_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c.stream));
+        return;
+    }
+    for (int k = 0; k < 2; k++)
+        if (!c.h_stage[k]) {
+            MS_CHECK(hipHostMalloc(&c.h_stage[k], CHUNK));
+            MS_CHECK(hipEventCreateWithFlags(&c.h_stage_ev[k], hipEventDisableTiming));
+            MS_CHECK(hipEventRecord(c.h_stage_ev[k], c.stream));
+        }
+    int k = 0;
+    for (size_t at = 0; at < bytes; at += CHUNK, k ^= 1) {
+        const size_t len = std::min(CHUNK, bytes - at);
+        MS_CHECK(hipEventSynchronize(c.h_stage_ev[k]));  // the transfer that last read this area has finished
+        std::memcpy(c.h_stage[k], (const char*)src_host + at, len);
+        MS_CHECK(hipMemcpyAsync((char*)dst_dev + at, c.h_stage[k], len, hipMemcpyHostToDevice, c.stream));
+        MS_CHECK(hipEventRecord(c.h_stage_ev[k], c.stream));
+    }
+}
 void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes)
 {
     if (bytes == 0) return;
@@ -1603,7 +1625,7 @@ void prepare(Context& c)
                 a.own.ensure(std::max<size_t>(na, 1));
                 a.dev = a.own.p;
                 if (a.need_upload && na > 0 && a.host) {
-                    MS_CHECK(hipMemcpyAsync(a.dev, a.host, na * sizeof(double), hipMemcpyHostToDevice, c.stream));
+                    h2d_staged(c, a.dev, a.host, na * sizeof(double));
                     a.need_upload = false;
                     queued_uploads = true;
                 }
@@ -5326,6 +5348,10 @@ Context::~Context()
 {
     contact_destroy(contact);
     if (dry) return;
+    for (int k = 0; k < 2; k++) {
+        if (h_stage[k]) (void)hipHostFree(h_stage[k]);
+        if (h_stage_ev[k]) (void)hipEventDestroy(h_stage_ev[k]);
+    }
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : pcg_ev) (void)hipEventDestroy(e);
     for (auto e : stage_ev) (void)hipEventDestroy(e);
