@@ -1083,6 +1083,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
         ctx->c.layout_dirty = true;  // (Potential::lazy_capable depends on it)
     }
     else if (n == "generic_contact") ctx->c.generic_contact = value != 0;
+    else if (n == "pcg_holdback") ctx->c.pcg_holdback = value != 0;
     else if (n == "contact_closed_min_lanes") ctx->c.contact_closed_min_lanes = value;
     else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;
     else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;

@@ -5290,10 +5290,23 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     PcgCtrl* h = nullptr;
     int slot = 0;
     int k_end_cur = launch_batch(0);
+    // The look-ahead batch is held back when the batch in flight is expected to converge: from the errors the last two finished batches
+    // reported, error_b ~ error_{b-1} * (error_{b-1} / error_{b-2}). A converged solve then wastes the rest of ONE batch instead of that
+    // plus a whole batch of no-op launches (4 to 7 iterations of three launches each were 4 % of a solve); a wrong guess costs one host
+    // round trip with the GPU idle. Same iterations either way. MEASURED on configs[3] (tools/ab_option.sh pcg_holdback 3): 1.150 ms per solve
+    // with it, 1.140 without — the no-op launches are 2 us each and the wrong guesses cost as much as the right ones save: option pcg_holdback,
+    // off by default.
+    const double tol = std::max(abs_tol, rel_tol);
+    double err1 = 1.0, err2 = -1.0;  // batch-end errors, newest first (error_0 = 1)
     for (;;) {
         const bool more = k <= max_iter;
         int k_end_next = 0;
-        if (more) k_end_next = launch_batch(slot ^ 1);  // keep the GPU fed while the host looks at the previous batch
+        bool hold = false;
+        if (more && c.pcg_holdback && !fuse_dir) {
+            const double shrink = err2 > 0.0 ? std::min(1.0, std::max(0.02, err1 / err2)) : 0.5;
+            hold = err1 * shrink < tol;
+        }
+        if (more && !hold) k_end_next = launch_batch(slot ^ 1);  // keep the GPU fed while the host looks at the previous batch
         if (fuse_dir) {
             MS_CHECK(hipEventSynchronize(c.pcg_ev[slot]));
         } else {
@@ -5328,6 +5341,9 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         h = hs[slot];
         if (c.time_spmv) drain(slot, h->done ? h->n_iter : k_end_cur);
         if (h->done || !more) break;
+        err2 = err1;
+        err1 = h->error;
+        if (hold) k_end_next = launch_batch(slot ^ 1);  // (the guess fell short)
         slot ^= 1;
         k_end_cur = k_end_next;
     }
