@@ -562,34 +562,105 @@ __device__ __forceinline__ bool sweep_entry(const ContactDev& d, const Bands& B,
     E.src = gi - src_start;
     return true;
 }
-// candidates [j0, j1) of one entry, 64 at a time; returns this lane's intersection count (!PROXIMITY)
+// The narrow phase runs out of a per-wavefront queue: the lanes that scan candidate boxes only ENQUEUE the pairs whose boxes overlap (30 % of
+// the candidates of a cloth), and whenever 64 pairs wait, all 64 lanes run the closest-feature classification and distance (or the
+// edge-triangle test) on one pair each. Run in place, the double-precision narrow phase was executed with a third of the lanes on every trip
+// of the scan loop: 190 of the intersection sweep's 345 us and 300 of the proximity sweep's 478 us on configs[2].
+constexpr int SWEEP_QUEUE = 128;  // per wavefront: at most 63 waiting + 64 new
+struct WaveQueue
+{
+    uint64_t* buf;  // LDS, SWEEP_QUEUE entries of this wavefront
+    int count;      // wave-uniform
+};
+// pair = kind[63:62] (0 point-triangle, 1 edge-edge, 2 edge-triangle intersection) | a[51:26] | b[25:0]
+__device__ __forceinline__ uint64_t pack_pair(int kind, int a, int b) { return ((uint64_t)kind << 62) | ((uint64_t)a << PRIM_BITS) | (uint64_t)b; }
+template <bool FRICTION>
+__device__ __forceinline__ int narrow_pair(const ContactDev& d, uint64_t pr, double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+{
+    const int kind = (int)(pr >> 62), a = (int)((pr >> PRIM_BITS) & ((1u << PRIM_BITS) - 1)), b = (int)(pr & ((1u << PRIM_BITS) - 1));
+    if (kind == 0) narrow_pt<FRICTION>(d, a, b, enl2, keys, counters, key_cap);
+    else if (kind == 1) narrow_ee<FRICTION>(d, a, b, enl2, keys, counters, key_cap);
+    else {
+        const int e = a, t = b;
+        const int v0 = d.edge[2 * e], v1 = d.edge[2 * e + 1], u0 = d.tri[3 * t], u1 = d.tri[3 * t + 1], u2 = d.tri[3 * t + 2];
+        if (v0 == u0 || v0 == u1 || v0 == u2 || v1 == u0 || v1 == u1 || v1 == u2) return 0;  // BroadPhaseET.cpp:161-165
+        if (d.disabled[d.edge_mesh[e] * d.n_mesh + d.tri_mesh[t]]) return 0;
+        if (edge_intersects_triangle(ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, u0), ldx(d.X, u1), ldx(d.X, u2))) {
+            if (enl2 < 0.0) push_key(pack_key(0, 0, 0, e, t), keys, counters, key_cap);  // (enl2 < 0: the caller wants the pairs, not only their number)
+            return 1;
+        }
+    }
+    return 0;
+}
+// every lane of the wavefront must call this (lanes without a pair pass has = false); returns the lane's intersection hits
+template <bool FRICTION>
+__device__ __forceinline__ int queue_push(WaveQueue& q, bool has, uint64_t pr, const ContactDev& d, double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned long long m = __ballot(has);
+    if (m == 0ull) return 0;
+    if (has) q.buf[q.count + __popcll(m & ((1ull << lane) - 1ull))] = pr;
+    q.count += __popcll(m);
+    int hits = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (q.count >= 64) {
+        const uint64_t mine = q.buf[lane];
+        const uint64_t tail = lane + 64 < q.count ? q.buf[lane + 64] : 0ull;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane + 64 < q.count) q.buf[lane] = tail;
+        q.count -= 64;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        hits = narrow_pair<FRICTION>(d, mine, enl2, keys, counters, key_cap);
+    }
+    return hits;
+}
+template <bool FRICTION>
+__device__ __forceinline__ int queue_flush(WaveQueue& q, const ContactDev& d, double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+{
+    const int lane = threadIdx.x & 63;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    int hits = 0;
+    if (lane < q.count) hits = narrow_pair<FRICTION>(d, q.buf[lane], enl2, keys, counters, key_cap);
+    q.count = 0;
+    return hits;
+}
+// candidates [j0, j1) of one entry (SUB lanes share an entry; `valid` = this lane's group has one), wave-uniform loop: every lane of the
+// wavefront takes part until the longest range of the wavefront is done. Returns this lane's intersection count (!PROXIMITY).
 template <bool PROXIMITY, bool FRICTION, int SUB>
-__device__ __forceinline__ int sweep_scan(const ContactDev& d, const Bands& B, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const SweepEntry& E, int j0, int j1,
-                                          double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap)
+__device__ __forceinline__ int sweep_scan(const ContactDev& d, const Bands& B, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const SweepEntry& E, bool valid, int j0,
+                                          int j1, double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap, WaveQueue& q)
 {
     const int sl = threadIdx.x & (SUB - 1);
     int hits = 0;
+    if (!valid) j1 = j0;
     // (no local arrays indexed at run time: they would live in scratch memory)
-    for (int j = j0 + sl; j < j1; j += SUB) {
-        const float* tb = s_aabb + 6 * (size_t)j;
-        if (!(E.lo1 <= tb[3 + E.a1] && tb[E.a1] <= E.hi1 && E.lo2 <= tb[3 + E.a2] && tb[E.a2] <= E.hi2)) continue;
-        const int tb_first = band_of(B, tb[B.band_axis]);
-        if (E.band != (E.b_first > tb_first ? E.b_first : tb_first)) continue;      // the pair is reported in its first common band only
-        const int tgt = (int)sidx[j] - E.tgt_start, src = E.src;
-        if (PROXIMITY) {
-            if (E.cls == 0) narrow_pt<FRICTION>(d, src, tgt, enl2, keys, counters, key_cap);
-            else if (E.cls == 1) narrow_pt<FRICTION>(d, tgt, src, enl2, keys, counters, key_cap);
-            else narrow_ee<FRICTION>(d, src < tgt ? src : tgt, src < tgt ? tgt : src, enl2, keys, counters, key_cap);
-        } else {
-            const int e = E.cls == 2 ? src : tgt, t = E.cls == 2 ? tgt : src;
-            const int v0 = d.edge[2 * e], v1 = d.edge[2 * e + 1], u0 = d.tri[3 * t], u1 = d.tri[3 * t + 1], u2 = d.tri[3 * t + 2];
-            if (v0 == u0 || v0 == u1 || v0 == u2 || v1 == u0 || v1 == u1 || v1 == u2) continue;  // BroadPhaseET.cpp:161-165
-            if (d.disabled[d.edge_mesh[e] * d.n_mesh + d.tri_mesh[t]]) continue;
-            if (edge_intersects_triangle(ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, u0), ldx(d.X, u1), ldx(d.X, u2))) {
-                hits++;
-                if (enl2 < 0.0) push_key(pack_key(0, 0, 0, e, t), keys, counters, key_cap);  // (enl2 < 0: the caller wants the pairs, not only their number)
+    for (int j = j0 + sl; __any(j < j1); j += SUB) {
+        bool has = false;
+        uint64_t pr = 0ull;
+        if (j < j1) {
+            const float* tb = s_aabb + 6 * (size_t)j;
+            if (E.lo1 <= tb[3 + E.a1] && tb[E.a1] <= E.hi1 && E.lo2 <= tb[3 + E.a2] && tb[E.a2] <= E.hi2) {
+                const int tb_first = band_of(B, tb[B.band_axis]);
+                if (E.band == (E.b_first > tb_first ? E.b_first : tb_first)) {  // the pair is reported in its first common band only
+                    const int tgt = (int)sidx[j] - E.tgt_start, src = E.src;
+                    has = true;
+                    if (PROXIMITY) {
+                        if (E.cls == 0) pr = pack_pair(0, src, tgt);
+                        else if (E.cls == 1) pr = pack_pair(0, tgt, src);
+                        else pr = pack_pair(1, src < tgt ? src : tgt, src < tgt ? tgt : src);
+                    } else {
+                        pr = E.cls == 2 ? pack_pair(2, src, tgt) : pack_pair(2, tgt, src);
+                    }
+                }
             }
         }
+        // (the intersection test is cheap and most box pairs of an edge and a triangle survive to it: run in place it is faster, 345 against 375 us)
+        if (PROXIMITY) hits += queue_push<FRICTION>(q, has, pr, d, enl2, keys, counters, key_cap);
+        else if (has) hits += narrow_pair<FRICTION>(d, pr, enl2, keys, counters, key_cap);
     }
     return hits;
 }
@@ -599,42 +670,44 @@ __global__ __launch_bounds__(CB) void k_sweep(ContactDev d, Bands B, const uint3
                                               int* __restrict__ task_count, int* __restrict__ tasks)
 {
     constexpr int SUB = SWEEP_SUB;
+    __shared__ uint64_t q_buf[CB / 64][SWEEP_QUEUE];
+    WaveQueue q{q_buf[threadIdx.x >> 6], 0};
     const int lane = threadIdx.x & 63, sl = lane & (SUB - 1), gb = lane & ~(SUB - 1);
     const int sp = blockIdx.x * (CB / SUB) + threadIdx.x / SUB;
-    if (sp >= seg[3 * NBANDS]) return;
-    SweepEntry E;
-    if (!sweep_entry<PROXIMITY>(d, B, sidx, s_aabb, seg, sp, pt_on, ee_on, E)) return;
-    const int t_begin = seg[E.tc * NBANDS + E.band], t_end = seg[E.tc * NBANDS + E.band + 1];
-    int j0;
-    if (E.cls == 2 && E.tc == 2) j0 = sp + 1;                                   // later edges of the same segment
-    else if (E.cls == 0 || (!PROXIMITY && E.cls == 2)) j0 = wave_bound_f<true, SUB>(s_lo, t_begin, t_end, E.lo);  // target lo in [lo, hi]
-    else j0 = wave_bound_f<false, SUB>(s_lo, t_begin, t_end, E.lo);                       // target lo in (lo, hi]: the other direction took ties
-    const int j1 = wave_bound_f<false, SUB>(s_lo, j0 > t_begin ? j0 : t_begin, t_end, E.hi);
-    int j_own = j1;
-    if (j1 - j0 > SWEEP_SPLIT) {  // long range: hand the rest out in tasks (those that fit the list; the remainder stays here)
-        const int first = j0 + SWEEP_SPLIT;
-        const int n_task = (j1 - first + SWEEP_SPLIT - 1) / SWEEP_SPLIT;
-        int base = 0;
-        if (sl == 0) base = atomicAdd(task_count, n_task);
-        base = __shfl(base, gb, 64);
-        const int n_fit = base >= SWEEP_TASK_CAP ? 0 : (n_task < SWEEP_TASK_CAP - base ? n_task : SWEEP_TASK_CAP - base);
-        for (int t = sl; t < n_fit; t += SUB) {
-            int* T = tasks + 3 * (size_t)(base + t);
-            T[0] = sp;
-            T[1] = first + t * SWEEP_SPLIT;
-            T[2] = first + (t + 1) * SWEEP_SPLIT < j1 ? first + (t + 1) * SWEEP_SPLIT : j1;
-        }
-        j_own = first;
-        if (n_fit < n_task) {  // (list full)
-            const int hits2 = sweep_scan<PROXIMITY, FRICTION, SUB>(d, B, sidx, s_aabb, E, first + n_fit * SWEEP_SPLIT, j1, enl2, keys, counters, key_cap);
-            if (!PROXIMITY && hits2) atomicAdd(&counters[1], hits2);
+    SweepEntry E{};
+    bool valid = sp < seg[3 * NBANDS];
+    if (valid) valid = sweep_entry<PROXIMITY>(d, B, sidx, s_aabb, seg, sp, pt_on, ee_on, E);
+    int j0 = 0, j_own = 0, r0 = 0, r1 = 0;  // own range [j0, j_own), remainder of a long range that found no room in the task list [r0, r1)
+    if (valid) {  // (uniform within a group of SUB lanes: the searches' ballots see whole groups)
+        const int t_begin = seg[E.tc * NBANDS + E.band], t_end = seg[E.tc * NBANDS + E.band + 1];
+        if (E.cls == 2 && E.tc == 2) j0 = sp + 1;                                   // later edges of the same segment
+        else if (E.cls == 0 || (!PROXIMITY && E.cls == 2)) j0 = wave_bound_f<true, SUB>(s_lo, t_begin, t_end, E.lo);  // target lo in [lo, hi]
+        else j0 = wave_bound_f<false, SUB>(s_lo, t_begin, t_end, E.lo);                       // target lo in (lo, hi]: the other direction took ties
+        const int j1 = wave_bound_f<false, SUB>(s_lo, j0 > t_begin ? j0 : t_begin, t_end, E.hi);
+        j_own = j1;
+        if (j1 - j0 > SWEEP_SPLIT) {  // long range: hand the rest out in tasks (those that fit the list; the remainder stays here)
+            const int first = j0 + SWEEP_SPLIT;
+            const int n_task = (j1 - first + SWEEP_SPLIT - 1) / SWEEP_SPLIT;
+            int base = 0;
+            if (sl == 0) base = atomicAdd(task_count, n_task);
+            base = __shfl(base, gb, 64);
+            const int n_fit = base >= SWEEP_TASK_CAP ? 0 : (n_task < SWEEP_TASK_CAP - base ? n_task : SWEEP_TASK_CAP - base);
+            for (int t = sl; t < n_fit; t += SUB) {
+                int* T = tasks + 3 * (size_t)(base + t);
+                T[0] = sp;
+                T[1] = first + t * SWEEP_SPLIT;
+                T[2] = first + (t + 1) * SWEEP_SPLIT < j1 ? first + (t + 1) * SWEEP_SPLIT : j1;
+            }
+            j_own = first;
+            if (n_fit < n_task) {  // (list full)
+                r0 = first + n_fit * SWEEP_SPLIT;
+                r1 = j1;
+            }
         }
     }
-#ifdef MISTARK_SWEEP_NOSCAN  // (measurement: the entry's setup and searches alone)
-    if (j_own == 0x7fffffff) counters[1] = j0;
-    return;
-#endif
-    const int hits = sweep_scan<PROXIMITY, FRICTION, SUB>(d, B, sidx, s_aabb, E, j0, j_own, enl2, keys, counters, key_cap);
+    int hits = sweep_scan<PROXIMITY, FRICTION, SUB>(d, B, sidx, s_aabb, E, valid, j0, j_own, enl2, keys, counters, key_cap, q);
+    if (__any(r1 > r0)) hits += sweep_scan<PROXIMITY, FRICTION, SUB>(d, B, sidx, s_aabb, E, valid, r0, r1, enl2, keys, counters, key_cap, q);
+    hits += queue_flush<FRICTION>(q, d, enl2, keys, counters, key_cap);
     if (!PROXIMITY && hits) atomicAdd(&counters[1], hits);
 }
 template <bool PROXIMITY, bool FRICTION>
@@ -642,15 +715,18 @@ __global__ __launch_bounds__(CB) void k_sweep_tasks(ContactDev d, Bands B, const
                                                     int ee_on, double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap,
                                                     const int* __restrict__ task_count, const int* __restrict__ tasks)
 {
+    __shared__ uint64_t q_buf[CB / 64][SWEEP_QUEUE];
+    WaveQueue q{q_buf[threadIdx.x >> 6], 0};
     const int w = blockIdx.x * (CB / 64) + (threadIdx.x >> 6);
     const int n = task_count[0] < SWEEP_TASK_CAP ? task_count[0] : SWEEP_TASK_CAP;
     int hits = 0;
-    for (int t = w; t < n; t += SWEEP_TASK_WAVES) {
+    for (int t = w; t < n; t += SWEEP_TASK_WAVES) {  // (wave-uniform: one task per wavefront and trip)
         const int* T = tasks + 3 * (size_t)t;
-        SweepEntry E;
-        if (!sweep_entry<PROXIMITY>(d, B, sidx, s_aabb, seg, T[0], pt_on, ee_on, E)) continue;
-        hits += sweep_scan<PROXIMITY, FRICTION, 64>(d, B, sidx, s_aabb, E, T[1], T[2], enl2, keys, counters, key_cap);
+        SweepEntry E{};
+        const bool valid = sweep_entry<PROXIMITY>(d, B, sidx, s_aabb, seg, T[0], pt_on, ee_on, E);
+        hits += sweep_scan<PROXIMITY, FRICTION, 64>(d, B, sidx, s_aabb, E, valid, T[1], T[2], enl2, keys, counters, key_cap, q);
     }
+    hits += queue_flush<FRICTION>(q, d, enl2, keys, counters, key_cap);
     if (!PROXIMITY && hits) atomicAdd(&counters[1], hits);
 }
 
