@@ -2763,10 +2763,34 @@ static void gather_part(Context& c, int part, const uint8_t* only_dirty);
 // the matrix equals the one assembled from the projected Hessians, bit for bit and run to run. For a lazy potential (float upper-triangle
 // pool, blocks recomputed into a compact double pool for the projection) the projected blocks go back to the float pool first; a block
 // whose floats did not change flags nothing. One thread per (selected element, block pair).
-__global__ __launch_bounds__(BLOCK) void k_proj_mark(const uint32_t* __restrict__ list, int nl, int NB, int n_key, const uint32_t* __restrict__ slot_of_src, uint8_t* __restrict__ dirty,
-                                                    const double* __restrict__ Hc, int n_pool_c, float* __restrict__ hf, int n_pool_f)
+struct MarkDesc
 {
-    const int64_t t = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t* list;
+    const uint32_t* slot_of_src;
+    uint8_t* dirty;
+    const double* Hc;
+    float* hf;
+    int nl, NB, n_key, n_pool_c, n_pool_f;
+    int first_block;  // of this list in the common grid
+};
+constexpr int MARK_BATCH = 16;
+struct MarkBatch  // every potential's list of one projection round in ONE launch (nine launches of 4.6 us each on configs[3])
+{
+    MarkDesc d[MARK_BATCH];
+    int n;
+};
+__global__ __launch_bounds__(BLOCK) void k_proj_mark(MarkBatch mb)
+{
+    int k = 0;
+    while (k + 1 < mb.n && (int)blockIdx.x >= mb.d[k + 1].first_block) k++;
+    const MarkDesc& D = mb.d[k];
+    const uint32_t* __restrict__ list = D.list;
+    const uint32_t* __restrict__ slot_of_src = D.slot_of_src;
+    uint8_t* __restrict__ dirty = D.dirty;
+    const double* __restrict__ Hc = D.Hc;
+    float* __restrict__ hf = D.hf;
+    const int nl = D.nl, NB = D.NB, n_key = D.n_key, n_pool_c = D.n_pool_c, n_pool_f = D.n_pool_f;
+    const int64_t t = (int64_t)((int)blockIdx.x - D.first_block) * BLOCK + threadIdx.x;
     const int nn = NB * NB;
     if (t >= (int64_t)nl * nn) return;
     const int li = (int)(t / nn), ab = (int)(t - (int64_t)li * nn), a = ab / NB, b = ab - a * NB;
@@ -2977,13 +3001,25 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
                     MS_CHECK(hipMemsetAsync(m.slot_dirty.p, 0, m.slot_dirty.cap, c.stream));
                 }
             }
+        MarkBatch mb;
+        mb.n = 0;
+        int blocks = 0;
+        auto flush_marks = [&]() {
+            if (mb.n > 0) hipLaunchKernelGGL(k_proj_mark, dim3(blocks), dim3(BLOCK), 0, c.stream, mb);
+            mb.n = 0;
+            blocks = 0;
+        };
         for (const Mark& k : marks) {
             Potential& P = *k.P;
             BsrPart& m = c.part[P.part];
             const bool lazy = k.Hc != nullptr;
-            hipLaunchKernelGGL(k_proj_mark, dim3(grid_for((int64_t)k.nl * P.NB * P.NB)), dim3(BLOCK), 0, c.stream, k.list, k.nl, P.NB, P.n_key, (const uint32_t*)(m.slot_of_src.p + P.kp_off),
-                               m.slot_dirty.p, k.Hc, k.n_pool_c, lazy ? c.elemHf.p + P.hf_off : (float*)nullptr, P.n_pool_f);
+            if (k.nl <= 0) continue;
+            if (mb.n == MARK_BATCH) flush_marks();
+            mb.d[mb.n++] = MarkDesc{k.list, (const uint32_t*)(m.slot_of_src.p + P.kp_off), m.slot_dirty.p, k.Hc, lazy ? c.elemHf.p + P.hf_off : (float*)nullptr, k.nl, P.NB, P.n_key,
+                                    k.n_pool_c, P.n_pool_f, blocks};
+            blocks += grid_for((int64_t)k.nl * P.NB * P.NB);
         }
+        flush_marks();
         for (int part = 0; part < 2; part++)
             if (mark_part[part]) {
                 BsrPart& m = c.part[part];
