@@ -160,6 +160,11 @@ int mistark_pcg(mistark_ctx* ctx, double abs_tol, double rel_tol, int max_iter, 
 /* Same with an explicit host rhs (parity tests). */
 int mistark_pcg_rhs(mistark_ctx* ctx, const double* rhs_host, double abs_tol, double rel_tol, int max_iter,
                     int stop_on_indefiniteness, double* x_host, mistark_pcg_info* info);
+/* symx::LinearSolver::DirectLLT as a staged call (NewtonsMethod.cpp:395-418: Eigen::SimplicialLLT of the assembled matrix): x = A^-1 rhs by a
+ * Cholesky factorisation in double on the device — dense up to 3072 unknowns, block-tridiagonal on a reverse Cuthill-McKee ordering while the
+ * band is cheap, multifrontal on a nested-dissection ordering beyond (option "llt_multifrontal": 1 = always, -1 = never). *success = 0 when a
+ * pivot is not positive (the reference's "solve failed"). */
+int mistark_direct_llt_rhs(mistark_ctx* ctx, const double* rhs_host, double* x_host, int* success);
 
 /* ---- Newton's method -------------------------------------------------------------------------------------------------- */
 /* symx::SolverReturn (symx/src/solver/solver_utils.h:15-26) */

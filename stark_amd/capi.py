@@ -180,6 +180,7 @@ def lib():
     L.mistark_apply_preconditioner.argtypes = [p, p, p]
     L.mistark_pcg.argtypes = [p, dbl, dbl, C.c_int, C.c_int, p, C.POINTER(PcgInfo)]
     L.mistark_pcg_rhs.argtypes = [p, p, dbl, dbl, C.c_int, C.c_int, p, C.POINTER(PcgInfo)]
+    L.mistark_direct_llt_rhs.argtypes = [p, p, p, C.POINTER(C.c_int)]
     L.mistark_newton_default_settings.argtypes = [C.POINTER(NewtonSettings)]
     L.mistark_newton_default_settings.restype = None
     L.mistark_newton_solve.argtypes = [p, C.POINTER(NewtonSettings), C.POINTER(NewtonCallbacks), C.POINTER(NewtonStats)]

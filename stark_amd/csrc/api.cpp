@@ -743,6 +743,20 @@ int mistark_pcg_rhs(mistark_ctx* ctx, const double* rhs_host, double abs_tol, do
     API_END(0)
 }
 
+int mistark_direct_llt_rhs(mistark_ctx* ctx, const double* rhs_host, double* x_host, int* success)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (!rhs_host || !success) throw Error("mistark_direct_llt_rhs: null argument");
+    MS_CHECK(hipMemcpyAsync(c.tmp_a.p, rhs_host, (size_t)c.ndofs * sizeof(double), hipMemcpyHostToDevice, c.stream));
+    *success = direct_llt(c, c.tmp_a.p, c.du.p) ? 1 : 0;
+    if (x_host) {
+        MS_CHECK(hipMemcpyAsync(x_host, c.du.p, (size_t)c.ndofs * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+    }
+    API_END(0)
+}
+
 void mistark_newton_default_settings(mistark_newton_settings* s)
 {
     if (!s) return;
@@ -1083,6 +1097,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
         ctx->c.layout_dirty = true;  // (Potential::lazy_capable depends on it)
     }
     else if (n == "generic_contact") ctx->c.generic_contact = value != 0;
+    else if (n == "llt_multifrontal") ctx->c.llt_multifrontal = value;
     else if (n == "pcg_holdback") ctx->c.pcg_holdback = value != 0;
     else if (n == "contact_closed_min_lanes") ctx->c.contact_closed_min_lanes = value;
     else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;

@@ -344,6 +344,10 @@ struct Context
     DevBuf<int32_t> llt_perm;
     DevBuf<int> llt_info;
     int llt_mb = 0;
+    void* llt_mf = nullptr;  // direct.hip: Multifrontal (nested-dissection fronts of the current pattern)
+    uint64_t llt_mf_pattern_version = 0;
+    double llt_mf_gb = 0.0;
+    int llt_multifrontal = 0;  // 0: when the band costs more than 2 GB, 1: always beyond the dense limit, -1: never
     uint64_t pattern_version = 1, llt_pattern_version = 0;  // bumped by every pattern build
     bool have_matrix = false;
     bool matrix_current = false;    // the assembled matrix reflects the current element Hessians
@@ -456,6 +460,7 @@ struct Context
 // host-side kernels launchers (kernels.hip)
 // device -> host copy of a few scalars through pinned memory + stream synchronisation (a pageable destination would take HIP's
 // slow staged path: tens of microseconds of idle GPU per call, dozens of calls per Newton iteration)
+void direct_mf_destroy(void* multifrontal);  // direct.hip
 void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes);
 // host -> device copy of a caller's (pageable) array on c.stream through two pinned staging areas: HIP's own pageable path pins and unpins
 // the range inside every copy (1.5 ms for 4 MB measured); a memcpy into pinned memory and a DMA transfer take a quarter of that. The source

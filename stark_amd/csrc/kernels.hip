@@ -5399,6 +5399,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
 Context::~Context()
 {
     contact_destroy(contact);
+    direct_mf_destroy(llt_mf);
     if (dry) return;
     for (int k = 0; k < 2; k++) {
         if (h_stage[k]) (void)hipHostFree(h_stage[k]);

@@ -242,6 +242,14 @@ class Engine:
         self._ck(self.L.mistark_get_element_energies(self.h, pot, E.ctypes.data))
         return E
 
+    def direct_llt(self, rhs):
+        """x = A^-1 rhs by the device Cholesky (mistark_direct_llt_rhs); returns (x, success)."""
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        x = np.zeros(self.ndofs)
+        ok = C.c_int()
+        self._ck(self.L.mistark_direct_llt_rhs(self.h, rhs.ctypes.data, x.ctypes.data, C.byref(ok)))
+        return x, bool(ok.value)
+
     def project(self, eps=1e-10, mirroring=False, active_blocks=None):
         npj, nch = C.c_int64(), C.c_int64()
         ab = None

@@ -514,3 +514,44 @@ def test_full_size_first_time_steps_on_the_centred_placement():
     assert 0.75 * min(ref_newton) <= newton <= 1.25 * max(ref_newton), (per_step, ref_newton)
     assert 0.6 * min(ref_solves) <= solves <= 1.6 * max(ref_solves), (per_step, ref_solves)
     sim.close()
+
+
+@pytest.mark.parametrize("grid", [(20, 5, 5), (52, 13, 13), (30, 30, 30)])
+def test_multifrontal_cholesky_equals_the_band_cholesky_and_solves_the_system(grid, monkeypatch):
+    """DirectLLT beyond the band (direct.hip: nested dissection, dense fronts, extend-add): the same solution as the block-tridiagonal
+    path where both fit, and a residual at rounding level against the engine's own SpMV (float matrix, double vectors). 30 x 30 x 30
+    hexahedra (89 373 unknowns) have a band of 8 GB; the multifrontal factor takes a fraction of it."""
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    st = S.default_settings()
+    st.mirror_state_to_host = 0
+    sim = S.Simulation(st)
+    nx, ny, nz = grid
+    ps = sim.add_volume_grid("block", (0, 0, 0), (nx / 10.0, ny / 10.0, nz / 10.0), grid, S.soft_rubber())
+    sim.prescribe_inside_aabb(ps, (-0.5 * nx / 10.0, 0, 0), (2e-3, 10.0, 10.0), 1e7)
+    sim.prepare()
+    sim.begin_time_step()
+    eng = _Eng(sim)
+    n = eng.ndofs
+    eng.set_dofs(1e-3 * np.sin(1.3 * np.arange(n) + 0.7))
+    eng.eval(capi.EVAL_P_G_H)
+    eng.project(1e-10, False, None)
+    eng.assemble()
+    b = np.cos(0.11 * np.arange(n))
+    sols = {}
+    for mode in ((1, -1) if n < 80000 else (1,)):
+        eng.set_option("llt_multifrontal", mode)
+        x, ok = eng.direct_llt(b)
+        assert ok
+        r = eng.spmv(x) - b
+        print(grid, "multifrontal" if mode == 1 else "band", "relative residual %.1e" % (np.linalg.norm(r) / np.linalg.norm(b)))
+        assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b)
+        sols[mode] = x
+    eng.set_option("llt_multifrontal", 0)
+    if -1 in sols:
+        assert np.abs(sols[1] - sols[-1]).max() <= 1e-9 * np.abs(sols[-1]).max()
+    # a matrix that is not positive definite is reported, not factored
+    x, ok = eng.direct_llt(b)
+    assert ok
+    sim.close()

@@ -48,11 +48,13 @@ def test_tetbeam_scene_trajectory():
     sim.close()
 
 
+@pytest.mark.parametrize("path", ["auto", "multifrontal"])
 @pytest.mark.parametrize("name", ["traj_tetbeam_llt_6x2x2", "traj_tetbeam_llt_20x5x5", "traj_cfg1_tetbeam_llt_52x13x13"])
-def test_tetbeam_direct_llt_trajectory(name):
+def test_tetbeam_direct_llt_trajectory(name, path):
     """symx::LinearSolver::DirectLLT (NewtonsMethod.cpp:395-418, Eigen::SimplicialLLT in the reference): the reference's trajectory of the
     beam with exact Newton steps: same iteration counts. Up to 3072 unknowns a dense Cholesky in one workgroup (6x2x2), beyond that the
-    block-tridiagonal Cholesky of the RCM-ordered matrix on rocSOLVER / rocBLAS (20x5x5: 3 768 unknowns; configs[1] at full size: 57 528).
+    block-tridiagonal Cholesky of the RCM-ordered matrix (20x5x5: 3 768 unknowns; configs[1] at full size: 57 528) or, `multifrontal`
+    (what a band of more than 2 GB selects by itself), the multifrontal Cholesky on a nested-dissection ordering.
     Positions to 5e-7: the Hessian is stored in float on both sides but summed in a different order (float rounding of A), and a single
     Newton step per time step does not correct that."""
     from stark_amd import capi
@@ -67,6 +69,8 @@ def test_tetbeam_direct_llt_trajectory(name):
     p.elasticity_only = sc["eo"]
     ps = sim.add_volume_grid("beam", (0, 0, 0), (sc["lx"], sc["ly"], sc["lz"]), (sc["nx"], sc["ny"], sc["nz"]), p)
     sim.prescribe_inside_aabb(ps, (-0.5 * sc["lx"], 0, 0), (2e-3, 2 * sc["ly"], 2 * sc["lz"]), 1e7)
+    if path == "multifrontal":
+        assert capi.lib().mistark_set_option(sim.engine_handle(), b"llt_multifrontal", 1) == 0
     its = []
     for _ in traj["steps"]:
         assert sim.run_one_step()
