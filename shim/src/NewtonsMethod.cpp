@@ -397,6 +397,8 @@ namespace symx
 		const int rc = mistark_newton_solve(s.ctx, &ns, &cb, &st);
 		s.check(rc, "mistark_newton_solve");
 		s.dofs_to_host();  // the reference leaves the solution in the caller's DoF arrays (NewtonsMethod.cpp:608-640)
+		if (const char* path = std::getenv("MISTARK_SHIM_SOLVELOG"))  // one line per solve(): Newton iterations, linear solves, CG iterations
+			std::ofstream(path, std::ios::app) << st.newton_iterations << " " << st.n_linear_solves << " " << st.cg_iterations << std::endl;
 		this->stats.newton_iterations = st.newton_iterations;
 		this->stats.cg_iterations = st.cg_iterations;
 		this->stats.ls_cap_iterations = st.ls_cap_iterations;

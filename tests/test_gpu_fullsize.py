@@ -481,6 +481,43 @@ def test_full_size_first_time_steps_equal_the_reference_log_off_the_degenerate_p
     sim.close()
 
 
+def test_full_size_centred_placement_with_the_references_own_tie_decisions(tmp_path):
+    """The centred placement bench.py times, with the reference's OWN classification of the pairs that sit on exact ties: oracle/_ref/shim_check
+    is the unmodified reference (its scene classes, its EnergyFrictionalContact, its host collision detector tmcd with its tie decisions and
+    edge orientations) on this engine through the SymX shim. With those decisions the engine takes the reference's Newton iterations and
+    linear solves in ALL five attempts of the reference's log — [5, 6], [4, 5], [3, 4], [3, 21], [6, 17] — and its CG iterations in the
+    first three (104, 67, 154; the fourth and fifth are where the reference's own runs differ from each other). The same
+    binary with the detector on the GPU (shim_check_cd: this repo's decisions on the ties, equal pair sets otherwise) leaves the log at the
+    first attempt's CG count: the ties are the only difference between the engine and the reference on this placement."""
+    import json
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "shim_check")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_check not built")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "steplog_cfg3_blockbox_44x44x43.npz"))
+    ref = [json.loads(bytes(z["time_t%d_json" % t]).decode())["per_step"] for t in (8, 4)]
+    assert ref[0] == ref[1] and len(ref[0]) == 5
+
+    def run(binary):
+        log = str(tmp_path / (os.path.basename(binary) + ".log"))
+        env = dict(os.environ, SHIM_GRID="44,44,43", SHIM_THREADS="32", MISTARK_SHIM_SOLVELOG=log)
+        r = subprocess.run([binary, "benchblock", "5"], capture_output=True, timeout=1200, env=env)
+        assert r.returncode == 0, (r.stdout.decode()[-1500:], r.stderr.decode()[-1500:])
+        return [[int(v) for v in line.split()] for line in open(log).read().split("\n") if line.strip()]
+
+    ours = run(exe)
+    print("reference log           ", ref[0])
+    print("engine, reference's ties", ours)
+    assert [o[:2] for o in ours[:5]] == [r[:2] for r in ref[0]]
+    assert [o[2] for o in ours[:3]] == [r[2] for r in ref[0][:3]]
+    cd = exe + "_cd"
+    if os.path.exists(cd):
+        mine = run(cd)
+        print("engine, its own ties    ", mine)
+        assert mine[0][:2] == ref[0][0][:2] and mine[0][2] != ref[0][0][2]
+
+
 def test_full_size_first_time_steps_on_the_centred_placement():
     """The placement bench.py measures (block centred on the box). Here the bottom-face nodes with x = -y lie EXACTLY above the diagonal
     edge of the box's top face, and 78 of the 264 edge-edge pairs have their closest point exactly at an edge endpoint: whether such a pair
