@@ -235,7 +235,7 @@ const char* mistark_supported_potential(int i) { return (i >= 0 && i < n_kinds()
 int mistark_add_dof_set(mistark_ctx* ctx, const char* label, double* host, int64_t n_scalars)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     if (n_scalars < 0 || n_scalars % 3 != 0) throw Error("DoF set size must be a non-negative multiple of 3");
     if (n_scalars > 0 && !host) throw Error("DoF set without a host array");
     DofSet s;
@@ -250,7 +250,7 @@ int mistark_add_dof_set(mistark_ctx* ctx, const char* label, double* host, int64
 int mistark_resize_dof_set(mistark_ctx* ctx, int set, double* host, int64_t n_scalars)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     if (set < 0 || set >= (int)ctx->c.dof_sets.size()) throw Error("bad DoF set");
     if (n_scalars < 0 || n_scalars % 3 != 0) throw Error("DoF set size must be a non-negative multiple of 3");
     if (n_scalars > 0 && !host) throw Error("DoF set without a host array");
@@ -272,7 +272,7 @@ int mistark_resize_dof_set(mistark_ctx* ctx, int set, double* host, int64_t n_sc
 int mistark_array(mistark_ctx* ctx, const double* host, int64_t n_items, int stride)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     Context& c = ctx->c;
     if (stride <= 0) throw Error("bad stride");
     if (n_items < 0) throw Error("negative item count");
@@ -321,7 +321,7 @@ int mistark_dof_array(mistark_ctx* ctx, int set, int stride)
 int mistark_array_rebind(mistark_ctx* ctx, int array, const double* host, int64_t n_items)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     Context& c = ctx->c;
     if (array < 0 || array >= (int)c.arrays.size()) throw Error("bad array id");
     Array& a = c.arrays[array];
@@ -346,7 +346,7 @@ static void upload_one(Context& c, Array& a)
 int mistark_upload(mistark_ctx* ctx, int array)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     Context& c = ctx->c;
     if (c.layout_dirty) {
         // sizes may have changed: mark and let prepare() do the copy
@@ -383,7 +383,7 @@ int mistark_download(mistark_ctx* ctx, int array)
 int mistark_array_axpby(mistark_ctx* ctx, int dst, double a, int x, double b, int y)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     Context& c = ctx->c;
     prepare(c);
     const int na = (int)c.arrays.size();
@@ -396,7 +396,7 @@ int mistark_array_axpby(mistark_ctx* ctx, int dst, double a, int x, double b, in
 int mistark_array_fill(mistark_ctx* ctx, int dst, double value)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     Context& c = ctx->c;
     prepare(c);
     if (dst < 0 || dst >= (int)c.arrays.size()) throw Error("bad array id");
@@ -407,7 +407,7 @@ int mistark_array_fill(mistark_ctx* ctx, int dst, double value)
 int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     _ret = register_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings);
     API_END(_ret)
 }
@@ -415,7 +415,7 @@ int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* 
                              const int32_t* ops, const double* constants, int32_t n_ops, int32_t n_inputs, const int32_t* cond_ops, const double* cond_constants, int32_t n_cond_ops)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     _ret = register_custom_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings, ops, constants, n_ops, n_inputs, cond_ops, cond_constants, n_cond_ops);
     API_END(_ret)
 }
@@ -454,7 +454,7 @@ int mistark_find_potential(mistark_ctx* ctx, const char* name)
 int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     Context& c = ctx->c;
     if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
     const int part = dynamic ? 1 : 0;
@@ -468,7 +468,7 @@ int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)
 int mistark_potential_update_connectivity(mistark_ctx* ctx, int potential, const int32_t* conn, int32_t n_elem)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     Context& c = ctx->c;
     if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
     if (n_elem < 0) throw Error("bad connectivity shape");
@@ -499,7 +499,7 @@ int mistark_get_dofs(mistark_ctx* ctx, double* u_host)
 int mistark_set_dofs(mistark_ctx* ctx, const double* u_host)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     Context& c = ctx->c;
     prepare(c);
     MS_CHECK(hipMemcpyAsync(c.u.p, u_host, (size_t)c.ndofs * sizeof(double), hipMemcpyHostToDevice, c.stream));
@@ -519,7 +519,7 @@ int mistark_dofs_to_host_arrays(mistark_ctx* ctx)
 int mistark_dofs_from_host_arrays(mistark_ctx* ctx)
 {
     API_BEGIN
-    ctx->c.data_version++;
+    ctx->c.touch();
     Context& c = ctx->c;
     prepare(c);
     for (auto& s : c.dof_sets)
@@ -1097,6 +1097,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
         ctx->c.layout_dirty = true;  // (Potential::lazy_capable depends on it)
     }
     else if (n == "generic_contact") ctx->c.generic_contact = value != 0;
+    else if (n == "no_eval_prelaunch") ctx->c.no_eval_prelaunch = value != 0;
     else if (n == "llt_multifrontal") ctx->c.llt_multifrontal = value;
     else if (n == "pcg_holdback") ctx->c.pcg_holdback = value != 0;
     else if (n == "contact_closed_min_lanes") ctx->c.contact_closed_min_lanes = value;

@@ -1778,7 +1778,7 @@ extern "C" {
 int mistark_contact_init(mistark_ctx* ctx, const mistark_contact_arrays* arrays)
 {
     CAPI_BEGIN
-    ctx->c.data_version++;  // (invalidates the cached detection)
+    ctx->c.touch();  // (invalidates the cached detection)
     if (!arrays) throw Error("contact: null arrays");
     const int32_t* ids = &arrays->v1;
     for (int i = 0; i < 12; i++)
@@ -1791,14 +1791,14 @@ int mistark_contact_add_mesh(mistark_ctx* ctx, int kind, int idx_in_ps, const in
 {
     int g = -1;
     CAPI_BEGIN
-    ctx->c.data_version++;  // (invalidates the cached detection)
+    ctx->c.touch();  // (invalidates the cached detection)
     g = contact_add_mesh(ctx->c, kind, idx_in_ps, vertex_index, n_vertices, triangles, n_triangles, edges, n_edges);
     CAPI_END(g)
 }
 int mistark_contact_set_friction(mistark_ctx* ctx, int a, int b, double mu)
 {
     CAPI_BEGIN
-    ctx->c.data_version++;  // (invalidates the cached detection)
+    ctx->c.touch();  // (invalidates the cached detection)
     ContactSystem& cs = CS(ctx->c);
     const int nm = (int)cs.meshes.size();
     if (a < 0 || b < 0 || a >= nm || b >= nm) throw Error("contact: bad group id");
@@ -1809,7 +1809,7 @@ int mistark_contact_set_friction(mistark_ctx* ctx, int a, int b, double mu)
 int mistark_contact_disable_collision(mistark_ctx* ctx, int a, int b)
 {
     CAPI_BEGIN
-    ctx->c.data_version++;  // (invalidates the cached detection)
+    ctx->c.touch();  // (invalidates the cached detection)
     ContactSystem& cs = CS(ctx->c);
     const int nm = (int)cs.meshes.size();
     if (a < 0 || b < 0 || a >= nm || b >= nm) throw Error("contact: bad group id");
@@ -1821,7 +1821,7 @@ int mistark_contact_disable_collision(mistark_ctx* ctx, int a, int b)
 int mistark_contact_set_broad_phase(mistark_ctx* ctx, int brute_force)
 {
     CAPI_BEGIN
-    ctx->c.data_version++;  // (invalidates the cached detection)
+    ctx->c.touch();  // (invalidates the cached detection)
     ContactSystem& cs = CS(ctx->c);
     cs.brute_force = brute_force != 0;
     cs.n_prev = -1;
@@ -1830,7 +1830,7 @@ int mistark_contact_set_broad_phase(mistark_ctx* ctx, int brute_force)
 int mistark_contact_enable(mistark_ctx* ctx, int point_triangle, int edge_edge)
 {
     CAPI_BEGIN
-    ctx->c.data_version++;  // (invalidates the cached detection)
+    ctx->c.touch();  // (invalidates the cached detection)
     ContactSystem& cs = CS(ctx->c);
     cs.pt_enabled = point_triangle != 0;
     cs.ee_enabled = edge_edge != 0;

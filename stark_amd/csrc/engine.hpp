@@ -371,6 +371,38 @@ struct Context
     // bumped by everything that can change what a contact detection sees (DoFs, bound arrays, layout): the detector skips a search whose
     // inputs are those of its previous one (the evaluation that opens a Newton iteration repeats the accepted line-search state)
     uint64_t data_version = 1;
+    // Evaluation kernels of the large closed-form potentials launched AHEAD of eval() (eval_prelaunch: while the callback that precedes an
+    // evaluation — contact search, a caller's host code — keeps the host and the main stream busy). eval() takes the results if nothing
+    // they depend on has changed (same kernel arguments, same pools), launches normally otherwise.
+    struct EvalPre
+    {
+        struct Item
+        {
+            int pot;
+            PotArgs args;
+            const void* E;
+            const void* H;
+        };
+        bool valid = false;
+        int mode = 0;
+        bool lazy_active = false;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_in = nullptr, ev_out = nullptr;
+        std::vector<Item> items;
+    } pre;
+    bool no_eval_prelaunch = false;
+    int64_t n_prelaunch_used = 0, n_prelaunch_dropped = 0;
+    // anything that changes what kernels read (arrays, DoFs, tables registered by the caller): contact detection caches and a prelaunched
+    // evaluation are void
+    void touch()
+    {
+        data_version++;
+        if (pre.valid) {
+            (void)hipStreamWaitEvent(stream, pre.ev_out, 0);  // (whatever comes next on the main stream must not overtake the kernels still reading)
+            pre.valid = false;
+            n_prelaunch_dropped++;
+        }
+    }
     bool no_contact_cache = false;  // option "no_contact_cache": every detection request runs the search (cross-check)
     size_t h_scratch_n = 0;
 
@@ -467,6 +499,7 @@ void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes);
 // may be reused when the call returns; the copy is ordered on c.stream like any other.
 void h2d_staged(Context& c, void* dst_dev, const void* src_host, size_t bytes);
 void prepare(Context& c);
+void eval_prelaunch(Context& c, int mode, bool lazy);  // kernels.hip: see Context::EvalPre
 // shard.hip
 void shard_prepare(Context& c);                                        // partition, local numbering, element lists, exchange tables (from prepare())
 void shard_halo(Context& c, double* v_local);                           // ghosts of a local vector (3 doubles per local row) from their owners

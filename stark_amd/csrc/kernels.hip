@@ -685,7 +685,7 @@ static void launch_bending_flat(Context& c, Potential& P, int mode)
     launch_grad_gather(c, P);
 }
 template <class En, bool FULL>
-static void launch_tet_closed(Context& c, Potential& P, int mode)
+static void launch_tet_closed(Context& c, Potential& P, int mode, bool kernel_only = false, bool gather_only = false)
 {
     if (P.args.e_count == 0) return;
     double* E = c.elemE.p + P.e_off;
@@ -694,11 +694,13 @@ static void launch_tet_closed(Context& c, Potential& P, int mode)
     {
         Context& c;
         Potential& P;
+        bool on;
         ~AfterLaunch()
         {
-            launch_grad_gather(c, P);
+            if (on) launch_grad_gather(c, P);
         }
-    } after{c, P};
+    } after{c, P, !kernel_only};
+    if (gather_only) return;  // (the kernel ran ahead of eval(): eval_prelaunch)
     if (mode == MISTARK_EVAL_P_G) {
         hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, TET_PG>), g, b, 0, c.stream, P.args, E, (double*)nullptr, (float*)nullptr, c.grad.p);
     } else if (c.lazy_active) {
@@ -1070,13 +1072,13 @@ static double reduce_sum(Context& c, const double* v, int64_t n)
 void vec_axpby(Context& c, double* dst, double a, const double* x, double b, const double* y, int64_t n)
 {
     if (n == 0) return;
-    c.data_version++;  // (dst may be the DoF vector or a bound array)
+    c.touch();  // (dst may be the DoF vector or a bound array)
     hipLaunchKernelGGL(k_axpby, dim3(grid_for(n, BLOCK, 2048)), dim3(BLOCK), 0, c.stream, dst, a, x, b, y, n);
 }
 void vec_fill(Context& c, double* dst, double v, int64_t n)
 {
     if (n == 0) return;
-    c.data_version++;
+    c.touch();
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, BLOCK, 2048)), dim3(BLOCK), 0, c.stream, dst, v, n);
 }
 void vec_neg(Context& c, double* dst, const double* x, int64_t n) { vec_axpby(c, dst, -1.0, x, 0.0, nullptr, n); }
@@ -1900,6 +1902,51 @@ void ensure_pattern(Context& c)
 static void build_pattern(Context& c, int part);
 static void build_pattern_part(Context& c, int part) { build_pattern(c, part); }
 static void assemble_part(Context& c, int part);
+void eval_prelaunch(Context& c, int mode, bool lazy)
+{
+    if (c.world != 1 || c.no_eval_prelaunch || c.no_eval_overlap || mode == MISTARK_EVAL_P || c.layout_dirty || c.force_generic || c.kernel_dbg || c.dry || c.pre.valid) return;
+    const bool lazy_active = mode == MISTARK_EVAL_P_G_H && lazy && !c.atomic_assembly && c.hf_total > 0;
+    if (mode == MISTARK_EVAL_P_G_H && (c.elemH.cap < std::max<size_t>(c.hess_total, 1) || c.elemHf.cap < std::max<size_t>(lazy_active ? c.hf_total : 0, 16))) return;  // (first evaluation: eval() allocates)
+    if (c.elemE.cap < std::max<size_t>(c.n_elem_total, 1)) return;
+    c.pre.items.clear();
+    for (size_t pi = 0; pi < c.pots.size(); pi++) {
+        Potential& P = c.pots[pi];
+        if (P.kind == KIND_CUSTOM || P.args.e_count == 0 || !P.args.gpool) continue;
+        if (P.name != E_TetStrain::name && P.name != E_TetStrainEO::name) continue;
+        if (mode == MISTARK_EVAL_P_G_H && lazy_active != (P.lazy_capable && lazy_active)) continue;  // (a tet potential outside the lazy pool: not here)
+        c.pre.items.push_back(Context::EvalPre::Item{(int)pi, P.args, (const void*)(c.elemE.p + P.e_off),
+                                                   mode == MISTARK_EVAL_P_G ? nullptr : (lazy_active ? (const void*)(c.elemHf.p + P.hf_off) : (const void*)(c.elemH.p + P.h_off))});
+    }
+    if (c.pre.items.empty()) return;
+    if (!c.pre.stream) {
+        MS_CHECK(hipStreamCreateWithFlags(&c.pre.stream, hipStreamNonBlocking));
+        MS_CHECK(hipEventCreateWithFlags(&c.pre.ev_in, hipEventDisableTiming));
+        MS_CHECK(hipEventCreateWithFlags(&c.pre.ev_out, hipEventDisableTiming));
+    }
+    MS_CHECK(hipEventRecord(c.pre.ev_in, c.stream));  // (the DoFs of this evaluation are final on the main stream)
+    MS_CHECK(hipStreamWaitEvent(c.pre.stream, c.pre.ev_in, 0));
+    hipStream_t main_stream = c.stream;
+    const bool lazy_before = c.lazy_active;
+    c.stream = c.pre.stream;
+    c.lazy_active = lazy_active;
+    try {
+        for (const Context::EvalPre::Item& it : c.pre.items) {
+            Potential& P = c.pots[(size_t)it.pot];
+            if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, true);
+            else launch_tet_closed<E_TetStrainEO, false>(c, P, mode, true);
+        }
+    } catch (...) {
+        c.stream = main_stream;
+        c.lazy_active = lazy_before;
+        throw;
+    }
+    c.stream = main_stream;
+    c.lazy_active = lazy_before;
+    MS_CHECK(hipEventRecord(c.pre.ev_out, c.pre.stream));
+    c.pre.valid = true;
+    c.pre.mode = mode;
+    c.pre.lazy_active = lazy_active;
+}
 void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs, bool lazy)
 {
     prepare(c);
@@ -1923,6 +1970,15 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
     if (mode != MISTARK_EVAL_P) {
         MS_CHECK(hipMemsetAsync(c.grad.p, 0, (size_t)c.ndofs * sizeof(double), c.stream));
         if (c.n_hot > 0) MS_CHECK(hipMemsetAsync(c.grad_hot.p, 0, (size_t)HOT_WAYS * 3 * c.n_hot * sizeof(double), c.stream));
+    }
+    // kernels launched ahead of this call (eval_prelaunch): whatever becomes of their results, nothing on this stream overtakes them
+    // (the wait sits in front of the first launch that touches their pools, below: the small potentials of this evaluation need not wait)
+    bool pre_ok = false, pre_pending = false;
+    if (c.pre.valid) {
+        pre_pending = true;
+        pre_ok = c.pre.mode == mode && (mode != MISTARK_EVAL_P_G_H || c.pre.lazy_active == c.lazy_active) && c.world == 1;
+        if (!pre_ok) c.n_prelaunch_dropped++;
+        c.pre.valid = false;
     }
     // The handful of large potentials (a million tets: 230 us) and the dozens of small ones (rigid bodies, the 35 contact and friction
     // tables: 5-12 us each, latency, one after the other) share nothing but the gradient, which both sides add to atomically: the small
@@ -1953,6 +2009,24 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
             const bool aux = split && P.n_elem < small;
             c.stream = aux ? c.aux_stream : main_stream;
             c.grad.p = aux ? c.grad_aux.p : grad_main;
+            if (pre_pending)
+                for (const Context::EvalPre::Item& it : c.pre.items)
+                    if (&c.pots[(size_t)it.pot] == &P) {
+                        MS_CHECK(hipStreamWaitEvent(c.stream, c.pre.ev_out, 0));
+                        break;
+                    }
+            if (pre_ok && !aux) {  // evaluated ahead (eval_prelaunch) with the arguments it has now: only its gradient gather is left
+                bool taken = false;
+                for (const Context::EvalPre::Item& it : c.pre.items)
+                    if (&c.pots[(size_t)it.pot] == &P && std::memcmp(&it.args, &P.args, sizeof(PotArgs)) == 0 && it.E == (const void*)(c.elemE.p + P.e_off) &&
+                        it.H == (mode == MISTARK_EVAL_P_G ? nullptr : (c.lazy_active ? (const void*)(c.elemHf.p + P.hf_off) : (const void*)(c.elemH.p + P.h_off)))) {
+                        if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, false, true);
+                        else launch_tet_closed<E_TetStrainEO, false>(c, P, mode, false, true);
+                        taken = true;
+                        c.n_prelaunch_used++;
+                    }
+                if (taken) continue;
+            }
             launch_eval_kind(c, P, mode);
         }
     } catch (...) {
@@ -5401,6 +5475,12 @@ Context::~Context()
     contact_destroy(contact);
     direct_mf_destroy(llt_mf);
     if (dry) return;
+    if (pre.stream) {
+        (void)hipStreamSynchronize(pre.stream);
+        (void)hipStreamDestroy(pre.stream);
+        (void)hipEventDestroy(pre.ev_in);
+        (void)hipEventDestroy(pre.ev_out);
+    }
     for (int k = 0; k < 2; k++) {
         if (h_stage[k]) (void)hipHostFree(h_stage[k]);
         if (h_stage_ev[k]) (void)hipEventDestroy(h_stage_ev[k]);

@@ -96,13 +96,15 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
             result = s.max_iterations_as_success ? MISTARK_SUCCESSFUL : MISTARK_TOO_MANY_ITERATIONS;
             break;
         }
+        // default residual: ||grad||_inf (solver_utils.h:28), read back with the energy. Progressive / no projection never reads the
+        // double blocks of an element it does not project: the closed-form tets write float blocks only (eval: lazy)
+        const bool lazy = c.lazy_allowed && (s.projection_mode == MISTARK_PROJ_PROGRESSIVE || s.projection_mode == MISTARK_PROJ_NEWTON) && s.linear_solver != MISTARK_SOLVER_DIRECT_LLT;
+        // the large potentials start now, beside the callback (the contact search: 0.4 ms of small launches and read-backs; a caller's host code)
+        if (cb && cb->before_energy_evaluation) eval_prelaunch(c, MISTARK_EVAL_P_G_H, lazy);
         call_void(cb ? cb->before_energy_evaluation : nullptr);
         double residual = 0.0;
         {
             gs.mark(ST_EVAL_PGH);
-            // default residual: ||grad||_inf (solver_utils.h:28), read back with the energy. Progressive / no projection never reads the
-            // double blocks of an element it does not project: the closed-form tets write float blocks only (eval: lazy)
-            const bool lazy = c.lazy_allowed && (s.projection_mode == MISTARK_PROJ_PROGRESSIVE || s.projection_mode == MISTARK_PROJ_NEWTON) && s.linear_solver != MISTARK_SOLVER_DIRECT_LLT;
             eval(c, MISTARK_EVAL_P_G_H, &E0, nullptr, &residual, lazy);
             st.n_evaluations++;
             gs.mark(ST_OTHER);

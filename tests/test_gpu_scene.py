@@ -70,6 +70,7 @@ def test_tetbeam_direct_llt_trajectory(name, path):
     ps = sim.add_volume_grid("beam", (0, 0, 0), (sc["lx"], sc["ly"], sc["lz"]), (sc["nx"], sc["ny"], sc["nz"]), p)
     sim.prescribe_inside_aabb(ps, (-0.5 * sc["lx"], 0, 0), (2e-3, 2 * sc["ly"], 2 * sc["lz"]), 1e7)
     if path == "multifrontal":
+        sim.prepare()
         assert capi.lib().mistark_set_option(sim.engine_handle(), b"llt_multifrontal", 1) == 0
     its = []
     for _ in traj["steps"]:
@@ -932,5 +933,32 @@ def test_contact_runs_are_bit_reproducible(grid):
         return out
 
     a, b = run(), run()
+    assert a[2:] == b[2:] and a[2] > 4
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+
+
+def test_evaluation_started_ahead_of_the_contact_callback_changes_no_bit():
+    """eval_prelaunch (kernels.hip): the Newton loop launches the large closed-form potentials' kernels on their own stream BEFORE the callback
+    that precedes an evaluation (contact search), and eval() takes their results when the kernel arguments and pools are still the ones they
+    ran with. Same kernels, same inputs: with the option off the run has the same bits in positions, velocities and iteration counts."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from bench import build_scene
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    def run(off):
+        sim = build_scene(S, 10, 10, 10, 0)
+        sim.prepare()
+        assert capi.lib().mistark_set_option(sim.engine_handle(), b"no_eval_prelaunch", off) == 0
+        for _ in range(4):
+            assert sim.run_one_step()
+        i = sim.info()
+        out = (sim.points("x0").copy(), sim.points("v0").copy(), i.total_newton_iterations, i.total_linear_solves, i.total_cg_iterations)
+        sim.close()
+        return out
+
+    a, b = run(0), run(1)
     assert a[2:] == b[2:] and a[2] > 4
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
