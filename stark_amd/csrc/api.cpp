@@ -321,7 +321,7 @@ int mistark_dof_array(mistark_ctx* ctx, int set, int stride)
 int mistark_array_rebind(mistark_ctx* ctx, int array, const double* host, int64_t n_items)
 {
     API_BEGIN
-    ctx->c.touch();
+    ctx->c.touch_array(array);
     Context& c = ctx->c;
     if (array < 0 || array >= (int)c.arrays.size()) throw Error("bad array id");
     Array& a = c.arrays[array];
@@ -346,7 +346,7 @@ static void upload_one(Context& c, Array& a)
 int mistark_upload(mistark_ctx* ctx, int array)
 {
     API_BEGIN
-    ctx->c.touch();
+    ctx->c.touch_array(array);
     Context& c = ctx->c;
     if (c.layout_dirty) {
         // sizes may have changed: mark and let prepare() do the copy
@@ -468,7 +468,7 @@ int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)
 int mistark_potential_update_connectivity(mistark_ctx* ctx, int potential, const int32_t* conn, int32_t n_elem)
 {
     API_BEGIN
-    ctx->c.touch();
+    ctx->c.touch_potential(potential);
     Context& c = ctx->c;
     if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
     if (n_elem < 0) throw Error("bad connectivity shape");

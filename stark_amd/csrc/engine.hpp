@@ -394,6 +394,24 @@ struct Context
     int64_t n_prelaunch_used = 0, n_prelaunch_dropped = 0;
     // anything that changes what kernels read (arrays, DoFs, tables registered by the caller): contact detection caches and a prelaunched
     // evaluation are void
+    // (an array / a table of its own: only a prelaunched kernel that reads it is void — the SymX shim re-sends the contact tables and their
+    // data between the callback and the evaluation)
+    void touch_array(int id)
+    {
+        bool read = id < 0 || id >= (int)arrays.size() || arrays[(size_t)id].dof_set >= 0;
+        if (pre.valid && !read)
+            for (const EvalPre::Item& it : pre.items)
+                for (const mistark_binding& b : pots[(size_t)it.pot].bindings) read = read || b.array == id;
+        if (read) touch();
+        else data_version++;
+    }
+    void touch_potential(int pot)
+    {
+        bool mine = false;
+        for (const EvalPre::Item& it : pre.items) mine = mine || it.pot == pot;
+        if (mine || !pre.valid) touch();
+        else data_version++;
+    }
     void touch()
     {
         data_version++;
