@@ -1904,7 +1904,7 @@ static void build_pattern_part(Context& c, int part) { build_pattern(c, part); }
 static void assemble_part(Context& c, int part);
 void eval_prelaunch(Context& c, int mode, bool lazy)
 {
-    if (c.world != 1 || c.no_eval_prelaunch || c.no_eval_overlap || mode == MISTARK_EVAL_P || c.layout_dirty || c.force_generic || c.kernel_dbg || c.dry || c.pre.valid) return;
+    if (c.world != 1 || c.no_eval_prelaunch || c.no_eval_overlap || c.layout_dirty || c.force_generic || c.kernel_dbg || c.dry || c.pre.valid) return;
     const bool lazy_active = mode == MISTARK_EVAL_P_G_H && lazy && !c.atomic_assembly && c.hf_total > 0;
     if (mode == MISTARK_EVAL_P_G_H && (c.elemH.cap < std::max<size_t>(c.hess_total, 1) || c.elemHf.cap < std::max<size_t>(lazy_active ? c.hf_total : 0, 16))) return;  // (first evaluation: eval() allocates)
     if (c.elemE.cap < std::max<size_t>(c.n_elem_total, 1)) return;
@@ -1915,7 +1915,7 @@ void eval_prelaunch(Context& c, int mode, bool lazy)
         if (P.name != E_TetStrain::name && P.name != E_TetStrainEO::name) continue;
         if (mode == MISTARK_EVAL_P_G_H && lazy_active != (P.lazy_capable && lazy_active)) continue;  // (a tet potential outside the lazy pool: not here)
         c.pre.items.push_back(Context::EvalPre::Item{(int)pi, P.args, (const void*)(c.elemE.p + P.e_off),
-                                                   mode == MISTARK_EVAL_P_G ? nullptr : (lazy_active ? (const void*)(c.elemHf.p + P.hf_off) : (const void*)(c.elemH.p + P.h_off))});
+                                                   mode != MISTARK_EVAL_P_G_H ? nullptr : (lazy_active ? (const void*)(c.elemHf.p + P.hf_off) : (const void*)(c.elemH.p + P.h_off))});
     }
     if (c.pre.items.empty()) return;
     if (!c.pre.stream) {
@@ -1932,7 +1932,8 @@ void eval_prelaunch(Context& c, int mode, bool lazy)
     try {
         for (const Context::EvalPre::Item& it : c.pre.items) {
             Potential& P = c.pots[(size_t)it.pot];
-            if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, true);
+            if (mode == MISTARK_EVAL_P) launch_eval_kind(c, P, mode);  // (energy only: one kernel, nothing to gather)
+            else if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, true);
             else launch_tet_closed<E_TetStrainEO, false>(c, P, mode, true);
         }
     } catch (...) {
@@ -2019,8 +2020,9 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
                 bool taken = false;
                 for (const Context::EvalPre::Item& it : c.pre.items)
                     if (&c.pots[(size_t)it.pot] == &P && std::memcmp(&it.args, &P.args, sizeof(PotArgs)) == 0 && it.E == (const void*)(c.elemE.p + P.e_off) &&
-                        it.H == (mode == MISTARK_EVAL_P_G ? nullptr : (c.lazy_active ? (const void*)(c.elemHf.p + P.hf_off) : (const void*)(c.elemH.p + P.h_off)))) {
-                        if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, false, true);
+                        it.H == (mode != MISTARK_EVAL_P_G_H ? nullptr : (c.lazy_active ? (const void*)(c.elemHf.p + P.hf_off) : (const void*)(c.elemH.p + P.h_off)))) {
+                        if (mode == MISTARK_EVAL_P) {
+                        } else if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, false, true);
                         else launch_tet_closed<E_TetStrainEO, false>(c, P, mode, false, true);
                         taken = true;
                         c.n_prelaunch_used++;

@@ -297,6 +297,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                 double E1 = 0.0;
                 int k = 0;
                 for (; k < s.max_backtracking_armijo_iterations; ++k) {
+                    if (cb && cb->before_energy_evaluation) eval_prelaunch(c, MISTARK_EVAL_P, false);
                     call_void(cb ? cb->before_energy_evaluation : nullptr);
                     {
                         gs.mark(ST_EVAL_P);
