@@ -432,6 +432,7 @@ struct Bands
 {
     int axis, band_axis;
     float band_lo, band_scale;
+    float shrink;  // intersection sweep over boxes that carry the proximity search's enlargement: twice that enlargement, minus a rounding margin
 };
 __device__ __forceinline__ uint32_t float_key(float f)
 {
@@ -653,6 +654,12 @@ __device__ __forceinline__ int sweep_scan(const ContactDev& d, const Bands& B, c
                         else if (E.cls == 1) pr = pack_pair(0, tgt, src);
                         else pr = pack_pair(1, src < tgt ? src : tgt, src < tgt ? tgt : src);
                     } else {
+                        // the boxes of this list are the proximity search's (enlarged by the contact thickness, so that both searches share one
+                        // sort): the intersection test needs the tight ones to overlap — 4 of 5 candidates of a cloth end here, before any index
+                        // or position is loaded
+                        const int ax = B.axis;
+                        has = E.lo + B.shrink <= tb[3 + ax] && tb[ax] + B.shrink <= E.hi && E.lo1 + B.shrink <= tb[3 + E.a1] && tb[E.a1] + B.shrink <= E.hi1 &&
+                              E.lo2 + B.shrink <= tb[3 + E.a2] && tb[E.a2] + B.shrink <= E.hi2;
                         pr = E.cls == 2 ? pack_pair(2, src, tgt) : pack_pair(2, tgt, src);
                     }
                 }
@@ -917,7 +924,7 @@ struct ContactSystem
     DevBuf<uint32_t> bp_cnt, bp_off;
     DevBuf<int> seg;
     const uint32_t* s_idx = nullptr;
-    Bands bands{-1, -1, 0.f, 1.f};
+    Bands bands{-1, -1, 0.f, 1.f, 0.f};
     int bp_cap = 0;
     int64_t n_updates = 0;
     bool brute_force = false;  // ablation / fallback: LDS-tiled all-pairs kernels
@@ -1428,6 +1435,7 @@ int64_t count_intersections(Context& c, double dt)
         const bool speculate = !c.no_contact_cache && c.contact_speculation;  // (option; off by default)
         for (bool first = true;; first = false) {
             if (!(first && boxes_current)) sort_boxes(c, cs, d);
+            cs.bands.shrink = enl_f > 0.f ? 2.f * enl_f * (1.f - 1e-3f) : 0.f;
             launch_sweep<false, false>(c, cs, d, 0.0);
             // ... and, behind it, the proximity search of the evaluation that follows an accepted candidate (same state, same boxes), up
             // to the table boundaries: its counts come back with the intersection count, detect_and_route then only routes
@@ -1532,7 +1540,10 @@ int cd_search(StandaloneDetector& D, const ContactDev& d, bool proximity, double
         MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
         sort_boxes(c, cs, d);
         if (proximity) launch_sweep<true, false>(c, cs, d, enl * enl);
-        else launch_sweep<false, false>(c, cs, d, -1.0);
+        else {
+            cs.bands.shrink = 0.f;  // (tight boxes: mistark_cd_run_intersection builds its own)
+            launch_sweep<false, false>(c, cs, d, -1.0);
+        }
         fetch(c, h, cs.counters.p, 64 * sizeof(int));
         if (h[51] > cs.bp_cap) {
             cs.bp_cap = h[51] + h[51] / 4;
