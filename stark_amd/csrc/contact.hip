@@ -945,6 +945,10 @@ struct ContactSystem
         const uint64_t* sorted = nullptr;
     } spec;
     bool cache_valid = false;
+    bool ix_valid = false;  // last intersection count (count_intersections)
+    uint64_t ix_version = 0;
+    double ix_dt = 0.0;
+    int64_t ix_n = 0;
     // the sorted box list of the last search: reused when the next search sees the same state with the same enlargement (the intersection
     // check of a line-search candidate and the proximity search of the energy evaluation that follows it)
     bool bp_valid = false;
@@ -1411,7 +1415,21 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     lap(6);
     return n;
 }
+int64_t count_intersections_uncached(Context& c, double dt);
+// (the check of an accepted line-search candidate and the check of the converged state one evaluation later see the same DoFs: answered from
+// the last count while nothing the vertices depend on has changed — Context::data_version)
 int64_t count_intersections(Context& c, double dt)
+{
+    ContactSystem& cs = CS(c);
+    if (cs.ix_valid && !c.no_contact_cache && cs.ix_version == c.data_version && cs.ix_dt == dt) return cs.ix_n;
+    const int64_t n = count_intersections_uncached(c, dt);
+    cs.ix_valid = true;
+    cs.ix_version = c.data_version;
+    cs.ix_dt = dt;
+    cs.ix_n = n;
+    return n;
+}
+int64_t count_intersections_uncached(Context& c, double dt)
 {
     ContactSystem& cs = CS(c);
     if (cs.meshes.empty() || cs.n_e == 0 || cs.n_t == 0) return 0;

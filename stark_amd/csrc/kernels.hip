@@ -1072,13 +1072,15 @@ static double reduce_sum(Context& c, const double* v, int64_t n)
 void vec_axpby(Context& c, double* dst, double a, const double* x, double b, const double* y, int64_t n)
 {
     if (n == 0) return;
-    c.touch();  // (dst may be the DoF vector or a bound array)
+    // (the DoF vector: contact caches and a prelaunched evaluation are void; work vectors are nobody's input. Bound arrays change through
+    // mistark_array_axpby / _fill, which say so themselves.)
+    if (dst >= c.u.p && dst < c.u.p + c.ndofs) c.touch();
     hipLaunchKernelGGL(k_axpby, dim3(grid_for(n, BLOCK, 2048)), dim3(BLOCK), 0, c.stream, dst, a, x, b, y, n);
 }
 void vec_fill(Context& c, double* dst, double v, int64_t n)
 {
     if (n == 0) return;
-    c.touch();
+    if (dst >= c.u.p && dst < c.u.p + c.ndofs) c.touch();
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, BLOCK, 2048)), dim3(BLOCK), 0, c.stream, dst, v, n);
 }
 void vec_neg(Context& c, double* dst, const double* x, int64_t n) { vec_axpby(c, dst, -1.0, x, 0.0, nullptr, n); }
