@@ -14,8 +14,8 @@
 //    227 s on another.) The fill-in of SimplicialLLT lives inside the band, so storing the band densely costs memory (2 m^2 doubles per
 //    block of m unknowns), not correctness;
 //  * when the band costs more than 2 GB (a 3-D mesh: a whole cross-section wide): a MULTIFRONTAL Cholesky on a nested-dissection ordering
-//    (second half of this file). configs[3]'s 517 044 unknowns: 23 GB of factor + 13 GB of update matrices, 3.0 s per factorisation, 1.1 s per
-//    pair of triangular solves, residual 1.4e-15 (the band would need 390 GB). The size is checked against MISTARK_DIRECT_MAX_GB (default 64).
+//    (second half of this file). configs[3]'s 517 044 unknowns: 7.1 GB of factor + 1.7 GB of update matrices, 1.9 s per factorisation, 0.9 s per
+//    pair of triangular solves, residual 1.3e-15 (the band would need 390 GB). The size is checked against MISTARK_DIRECT_MAX_GB (default 64).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -489,8 +489,9 @@ bool direct_llt_blocktri(Context& c, const double* rhs_dev, double* x_dev)
 // ======================================================================================================================================================
 // Beyond the band: a MULTIFRONTAL Cholesky on a nested-dissection ordering. The band of a 3-D mesh is a whole cross-section wide (configs[3]:
 // 12 k unknowns, 50 GB of dense blocks); SimplicialLLT's fill is O(n^(4/3)). Here:
-//  * ordering (host, once per sparsity pattern): recursive bisection of the block-row graph by breadth-first level sets from a pseudo-peripheral
-//    row (the middle level is the separator: levels only touch their neighbours, so the two sides share no edge); rows of very high degree (a
+//  * ordering (host, once per sparsity pattern): recursive bisection of the block-row graph — by the median plane across the rows' positions
+//    when the caller handed them over (the lower side's rows that touch the upper side are the separator), otherwise by breadth-first level
+//    sets from a pseudo-peripheral row (the middle level is the separator: levels only touch their neighbours, so the two sides share no edge); rows of very high degree (a
 //    rigid body every surface node is coupled to) leave the graph first and form the root. Parts of <= MF_LEAF rows are leaves.
 //  * every tree node is a FRONT: its own rows S (eliminated there) and the later rows B its subtree couples to. The dense front
 //    [F11; F21] (3(s+b) x 3s, column-major) receives the matrix entries of its columns and the update matrices of its children (extend-add
@@ -610,6 +611,7 @@ struct MfBuilder
     };
     std::vector<Node> nodes;
     int next_set = 1;
+    const double* xyz = nullptr;  // a position per vertex (NaN: none), or null
     MfBuilder(const std::vector<int64_t>& s, const std::vector<int32_t>& a, int64_t n) : start(s), adj(a), mark((size_t)n, 0), level((size_t)n, -1) {}
     // breadth-first levels of the vertices of set `id` reachable from root; returns them in visiting order
     void bfs(int32_t root, int id, std::vector<int32_t>& out)
@@ -640,6 +642,69 @@ struct MfBuilder
                 nodes.push_back(Node{comp, {}});
                 roots.push_back((int)nodes.size() - 1);
                 continue;
+            }
+            // with positions: the median plane across the longest extent; the rows of the lower side that touch the upper side are the
+            // separator (a layer of mesh nodes: a third of the size of a breadth-first level through a cube, a twentieth of the top fronts' work)
+            if (xyz) {
+                double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                bool all = true;
+                for (int32_t v : comp) {
+                    const double* x = xyz + 3 * (size_t)v;
+                    if (!(x[0] == x[0])) {
+                        all = false;
+                        break;
+                    }
+                    for (int d = 0; d < 3; d++) {
+                        lo[d] = std::min(lo[d], x[d]);
+                        hi[d] = std::max(hi[d], x[d]);
+                    }
+                }
+                int ax = 0;
+                for (int d = 1; d < 3; d++)
+                    if (hi[d] - lo[d] > hi[ax] - lo[ax]) ax = d;
+                if (all && hi[ax] > lo[ax]) {
+                    std::vector<double> key(comp.size());
+                    for (size_t k = 0; k < comp.size(); k++) key[k] = xyz[3 * (size_t)comp[k] + ax];
+                    std::nth_element(key.begin(), key.begin() + (long)(key.size() / 2), key.end());
+                    double med = key[key.size() / 2];
+                    if (!(med < hi[ax])) {  // (the upper half is one plane of equal coordinates: cut below it)
+                        double below = lo[ax];
+                        for (int32_t v : comp) {
+                            const double x = xyz[3 * (size_t)v + ax];
+                            if (x < med) below = std::max(below, x);
+                        }
+                        med = below;
+                    }
+                    const int ida = next_set++, idb = next_set++;
+                    std::vector<int32_t> S, A, Bv;
+                    for (int32_t v : comp) {
+                        mark[(size_t)v] = xyz[3 * (size_t)v + ax] <= med ? ida : idb;
+                        level[(size_t)v] = -1;
+                    }
+                    for (int32_t v : comp) {
+                        if (mark[(size_t)v] == idb) {
+                            Bv.push_back(v);
+                            continue;
+                        }
+                        bool touches = false;
+                        for (int64_t j = start[(size_t)v]; j < start[(size_t)v + 1] && !touches; j++) touches = mark[(size_t)adj[(size_t)j]] == idb;
+                        if (touches) S.push_back(v);
+                        else A.push_back(v);
+                    }
+                    if (!Bv.empty() && !S.empty()) {
+                        for (int32_t v : S) mark[(size_t)v] = -1;
+                        const int me = (int)nodes.size();
+                        nodes.push_back(Node{S, {}});
+                        roots.push_back(me);
+                        std::vector<int> kids;
+                        dissect(A, ida, kids);
+                        dissect(Bv, idb, kids);
+                        nodes[(size_t)me].children = kids;
+                        continue;
+                    }
+                    for (int32_t v : comp) mark[(size_t)v] = id;  // (degenerate: fall through to the level sets)
+                }
+                for (int32_t v : comp) level[(size_t)v] = 0;  // (as the component search left them)
             }
             // pseudo-peripheral start: twice from the far end
             for (int rep = 0; rep < 2; rep++) {
@@ -743,6 +808,16 @@ double mf_analyse(Context& c, Multifrontal& M, const std::vector<uint32_t>& rows
     std::vector<int32_t> adj;
     mf_graph(nbr, rows, cols, start, adj);
     MfBuilder Bd(start, adj, nbr);
+    // positions of the rows, if the caller handed them over (mistark_dist_set_row_coords; the matrix may live in solver numbering)
+    std::vector<double> xyz;
+    if ((int64_t)c.sh.coords.size() == 3 * nbr && !c.llt_no_coords) {
+        xyz.resize((size_t)(3 * nbr));
+        for (int64_t r = 0; r < nbr; r++) {
+            const int64_t o = c.perm_active ? (int64_t)c.iperm_h[(size_t)r] : r;
+            for (int d = 0; d < 3; d++) xyz[(size_t)(3 * r + d)] = c.sh.coords[(size_t)(3 * o + d)];
+        }
+        Bd.xyz = xyz.data();
+    }
     // hubs first: rows coupled to far more rows than a mesh node (a rigid body under a contact surface) would put everything within two levels
     const int64_t avg = std::max<int64_t>(1, (int64_t)adj.size() / std::max<int64_t>(nbr, 1));
     std::vector<int32_t> hubs, rest;

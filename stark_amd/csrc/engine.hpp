@@ -347,6 +347,7 @@ struct Context
     void* llt_mf = nullptr;  // direct.hip: Multifrontal (nested-dissection fronts of the current pattern)
     uint64_t llt_mf_pattern_version = 0;
     double llt_mf_gb = 0.0;
+    bool llt_no_coords = false;  // multifrontal ordering by breadth-first level sets even when positions are known (cross-check)
     int llt_multifrontal = 0;  // 0: when the band costs more than 2 GB, 1: always beyond the dense limit, -1: never
     uint64_t pattern_version = 1, llt_pattern_version = 0;  // bumped by every pattern build
     bool have_matrix = false;

@@ -577,15 +577,18 @@ def test_multifrontal_cholesky_equals_the_band_cholesky_and_solves_the_system(gr
     eng.assemble()
     b = np.cos(0.11 * np.arange(n))
     sols = {}
-    for mode in ((1, -1) if n < 80000 else (1,)):
-        eng.set_option("llt_multifrontal", mode)
+    for mode in ((1, 2, -1) if n < 80000 else (1, 2)):   # 1: separators from the positions, 2: from breadth-first level sets, -1: band
+        eng.set_option("llt_no_coords", int(mode == 2))
+        eng.set_option("llt_multifrontal", 1 if mode == 2 else mode)
         x, ok = eng.direct_llt(b)
         assert ok
         r = eng.spmv(x) - b
-        print(grid, "multifrontal" if mode == 1 else "band", "relative residual %.1e" % (np.linalg.norm(r) / np.linalg.norm(b)))
+        print(grid, {1: "multifrontal (positions)", 2: "multifrontal (level sets)", -1: "band"}[mode], "relative residual %.1e" % (np.linalg.norm(r) / np.linalg.norm(b)))
         assert np.linalg.norm(r) <= 1e-9 * np.linalg.norm(b)
         sols[mode] = x
     eng.set_option("llt_multifrontal", 0)
+    eng.set_option("llt_no_coords", 0)
+    assert np.abs(sols[1] - sols[2]).max() <= 1e-9 * np.abs(sols[2]).max()
     if -1 in sols:
         assert np.abs(sols[1] - sols[-1]).max() <= 1e-9 * np.abs(sols[-1]).max()
     # a matrix that is not positive definite is reported, not factored
