@@ -295,6 +295,7 @@ int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settin
  * keeps the double element-Hessian pool (default 1: float upper triangles, doubles recomputed for projected elements);
  * "lazy_eval" = staged mistark_eval calls take the lazy path too; "no_grad_gather" = gradient by atomics in arrival order instead of
  * the per-potential pools summed in list order;
+ * "no_multi_eval_p" = one launch per potential in energy-only evaluations (default: the small potentials share one launch);
  * "no_eval_prelaunch" = do not start the large potentials' kernels ahead of the callback that precedes an evaluation;
  * "no_pattern_overlap" / "no_eval_overlap" / "no_bounded_pattern" = switch off, one by one, the side stream for the contact part's
  * pattern, the auxiliary stream for small potentials, the device-side counts of the pattern build; "fuse_dir" = direction update

@@ -392,6 +392,10 @@ struct Context
         std::vector<Item> items;
     } pre;
     bool no_eval_prelaunch = false;
+    // energy-only evaluations: descriptors of the small potentials that share one launch (kernels.hip: k_eval_p_multi)
+    bool no_multi_eval_p = false;
+    std::vector<char> multi_p_sent;
+    DevBuf<char> multi_p_dev;
     int64_t n_prelaunch_used = 0, n_prelaunch_dropped = 0;
     // anything that changes what kernels read (arrays, DoFs, tables registered by the caller): contact detection caches and a prelaunched
     // evaluation are void

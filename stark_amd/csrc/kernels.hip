@@ -133,6 +133,51 @@ __global__ __launch_bounds__(BLOCK) void k_eval_p(PotArgs a, double* __restrict_
     elemE[pe] = energy_here(a, e) ? En::energy(L) : 0.0;
 }
 
+// The energies of ALL small potentials of a line-search evaluation in one launch (rigid-body terms, contact and friction tables: a dozen
+// kernels of 5-7 us each, one after the other, 66 of the 125 us of an energy evaluation of configs[3]): the workgroup index picks the potential.
+struct MultiP
+{
+    PotArgs a;
+    double* E;
+    int kind, pad;
+};
+constexpr int MULTI_P_MAX = 48;
+struct MultiFirst
+{
+    int b[MULTI_P_MAX + 1];
+    int n;
+};
+template <class En>
+__device__ __forceinline__ void eval_p_body(const PotArgs& a, double* __restrict__ elemE, int le)
+{
+    const int e = elem_of(a, le), pe = pool_of(a, le);
+    double in[En::Layout::NIN];
+    gather_inputs<En>(a, e, in);
+    if (!element_active<En>(in)) {
+        elemE[pe] = 0.0;
+        return;
+    }
+    Loader<double> L{in};
+    elemE[pe] = energy_here(a, e) ? En::energy(L) : 0.0;
+}
+__global__ __launch_bounds__(BLOCK) void k_eval_p_multi(const MultiP* __restrict__ descs, MultiFirst first)
+{
+    int d = 0;
+    while (d + 1 < first.n && (int)blockIdx.x >= first.b[d + 1]) d++;
+    const MultiP& D = descs[d];
+    const int le = ((int)blockIdx.x - first.b[d]) * BLOCK + threadIdx.x;
+    if (le >= D.a.e_count) return;
+    int k = 0;
+#define X(En)                              \
+    if (D.kind == k) {                     \
+        eval_p_body<En>(D.a, D.E, le);     \
+        return;                            \
+    }                                      \
+    k++;
+    MISTARK_FOR_EACH_ENERGY(X)
+#undef X
+}
+
 // Energy + gradient + Hessian: one lane per (element, i<=j) pair of local DoFs.
 // Element Hessians are stored per potential as H[a*NB+b][e][3][3]: one 72-byte row-major 3x3 block per (block pair, element);
 // consecutive elements are contiguous (coalescing-friendly stores) and assembly gathers whole 72-byte blocks.
@@ -2008,7 +2053,25 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         int64_t n_max = 0;
         for (auto& P : c.pots) n_max = std::max<int64_t>(n_max, P.n_elem);
         const int64_t small = std::max<int64_t>(EVAL_SMALL_POTENTIAL, n_max / 4);
+        // energy only: the small potentials share one launch (k_eval_p_multi)
+        std::vector<MultiP> multi;
+        MultiFirst mf;
+        mf.n = 0;
+        int multi_blocks = 0;
+        const bool batch_p = mode == MISTARK_EVAL_P && c.world == 1 && !c.no_multi_eval_p && !c.kernel_dbg;
         for (auto& P : c.pots) {
+            if (batch_p && P.kind != KIND_CUSTOM && P.kind >= 0 && P.n_elem < EVAL_SMALL_POTENTIAL && mf.n < MULTI_P_MAX) {
+                if (P.args.e_count == 0) continue;
+                MultiP m;
+                std::memset(&m, 0, sizeof(m));
+                m.a = P.args;
+                m.E = c.elemE.p + P.e_off;
+                m.kind = P.kind;
+                multi.push_back(m);
+                mf.b[mf.n++] = multi_blocks;
+                multi_blocks += grid_for(P.args.e_count);
+                continue;
+            }
             const bool aux = split && P.n_elem < small;
             c.stream = aux ? c.aux_stream : main_stream;
             c.grad.p = aux ? c.grad_aux.p : grad_main;
@@ -2032,6 +2095,18 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
                 if (taken) continue;
             }
             launch_eval_kind(c, P, mode);
+        }
+        if (mf.n > 0) {
+            c.stream = main_stream;
+            mf.b[mf.n] = multi_blocks;
+            const size_t bytes = multi.size() * sizeof(MultiP);
+            c.multi_p_dev.ensure(bytes);
+            // (the descriptors change whenever a contact table does: sent when they differ from what the device holds)
+            if (c.multi_p_sent.size() != bytes || std::memcmp(c.multi_p_sent.data(), multi.data(), bytes) != 0) {
+                c.multi_p_sent.assign((const char*)multi.data(), (const char*)multi.data() + bytes);
+                MS_CHECK(hipMemcpyAsync(c.multi_p_dev.p, c.multi_p_sent.data(), bytes, hipMemcpyHostToDevice, c.stream));
+            }
+            hipLaunchKernelGGL(k_eval_p_multi, dim3(multi_blocks), dim3(BLOCK), 0, c.stream, (const MultiP*)c.multi_p_dev.p, mf);
         }
     } catch (...) {
         c.stream = main_stream;
