@@ -222,10 +222,15 @@ def _run_and_compare(sim, z, traj, tol=1e-6, its_slack=0):
     return its
 
 
-def test_cloth_on_box_contact_trajectory():
+@pytest.mark.parametrize("closed_forms", [False, True])
+def test_cloth_on_box_contact_trajectory(closed_forms, monkeypatch):
     """cfg 1 (README hello world, no spin) at fixture size: IPC contact + friction between a cloth and a fixed rigid box, device
-    detection inside the Newton loop; same Newton iteration counts and end state as the reference."""
+    detection inside the Newton loop; same Newton iteration counts and end state as the reference — with the generic contact kernels
+    (what tables of this size get by default) and with the closed-form ones."""
     from stark_amd import sim as S
+
+    if closed_forms:
+        monkeypatch.setenv("MISTARK_OPTIONS", "contact_closed_min_lanes=1")
 
     z, traj, man = _load("traj_clothbox_8")
     sc = traj["scene"]
@@ -249,7 +254,11 @@ def test_cloth_on_box_contact_trajectory():
                                           # repeated-search caches): the reference's iteration counts either way
                                           ("traj_cfg3_blockbox_10", "no_eval_overlap"), ("traj_cfg3_blockbox_10", "no_bounded_pattern"),
                                           ("traj_cfg3_blockbox_10", "no_pattern_overlap"), ("traj_cfg3_blockbox_10", "no_contact_cache"),
-                                          ("traj_cfg3_blockbox_10", "contact_speculation"), ("traj_cfg3_blockbox_10", "no_eager_assembly")])
+                                          ("traj_cfg3_blockbox_10", "contact_speculation"), ("traj_cfg3_blockbox_10", "no_eager_assembly"),
+                                          # every contact / friction table through the closed-form kernels (contact_closed.hpp; by default only
+                                          # tables long enough to pay), and the evaluation not started ahead of the contact callback
+                                          ("traj_cfg3_blockbox_10", "contact_closed_min_lanes"), ("traj_blockbox_3", "contact_closed_min_lanes"),
+                                          ("traj_cfg3_blockbox_10", "no_eval_prelaunch"), ("traj_cfg3_blockbox_10", "no_multi_eval_p")])
 def test_block_on_box_contact_trajectory(name, options, monkeypatch):
     """configs[3] at fixture size (and at 12 k tets): Soft_Rubber tet block landing on a fixed rigid box (collision surface from
     find_surface), with friction (box registered first) and without (block first)."""
