@@ -469,6 +469,8 @@ __global__ __launch_bounds__(CB) void k_bp_fill(ContactDev d, Bands B, const uin
             idx[e] = (uint32_t)i;
         }
     }
+    // the unused tail of the list: padding entries that sort last (a fill command of its own was one more launch in every search)
+    for (uint32_t e = off[n] + (uint32_t)i; e < (uint32_t)cap; e += (uint32_t)n) keys[e] = ~0ull;
 }
 // sorted entries -> sorted copy of the boxes + segment starts seg[cls * NBANDS + band] (seg[3 * NBANDS] = number of entries)
 __global__ __launch_bounds__(CB) void k_bp_gather(ContactDev d, Bands B, const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ sidx, int cap,
@@ -1200,7 +1202,6 @@ void sort_boxes(Context& c, ContactSystem& cs, const ContactDev& d)
     MS_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cs.bp_cnt.p, cs.bp_off.p, n + 1, c.stream));
     cs.cub_tmp.ensure(tmp);
     MS_CHECK(hipcub::DeviceScan::ExclusiveSum(cs.cub_tmp.p, tmp, cs.bp_cnt.p, cs.bp_off.p, n + 1, c.stream));
-    MS_CHECK(hipMemsetAsync(cs.bp_keys.p, 0xFF, (size_t)cap * sizeof(uint64_t), c.stream));  // padding entries sort last
     hipLaunchKernelGGL(k_bp_fill, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, (const uint32_t*)cs.bp_off.p, cs.bp_keys.p, cs.bp_idx.p, cap, cs.counters.p + 48);
     hipcub::DoubleBuffer<uint64_t> dk(cs.bp_keys.p, cs.bp_keys_alt.p);
     hipcub::DoubleBuffer<uint32_t> dv(cs.bp_idx.p, cs.bp_idx_alt.p);
@@ -1220,11 +1221,13 @@ size_t initial_key_cap()
     return (size_t)1 << 18;
 }
 template <bool PROX, bool FR>
-void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, double enl2)
+void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, double enl2, bool reset_tasks = false)
 {
     cs.sweep_tasks.ensure(3 * (size_t)SWEEP_TASK_CAP + 4);
-    int* task_count = cs.sweep_tasks.p + 3 * (size_t)SWEEP_TASK_CAP;
-    MS_CHECK(hipMemsetAsync(task_count, 0, sizeof(int), c.stream));
+    // (the task counter lives among the search's counters, which every caller zeroes before the search: counters[56]; a second sweep behind
+    // the same fill — the speculative proximity search — resets it itself)
+    int* task_count = cs.counters.p + 56;
+    if (reset_tasks) MS_CHECK(hipMemsetAsync(task_count, 0, sizeof(int), c.stream));
     const int pt_on = (int)(cs.pt_enabled && cs.n_t > 0), ee_on = (int)(cs.ee_enabled && cs.n_e > 1);
     hipLaunchKernelGGL((k_sweep<PROX, FR>), dim3((cs.bp_cap + CB / SWEEP_SUB - 1) / (CB / SWEEP_SUB)), dim3(CB), 0, c.stream, d, cs.bands, cs.s_idx, (const float*)cs.s_aabb.p, (const float*)cs.s_lo.p,
                        (const int*)cs.seg.p, pt_on, ee_on, enl2, cs.keys.p, cs.counters.p, (int)cs.key_cap, task_count, cs.sweep_tasks.p);
@@ -1442,7 +1445,7 @@ int64_t count_intersections_uncached(Context& c, double dt)
     const float enl_f = cs.brute_force ? 0.f : nextafterf((float)enl, INFINITY) + 1.1920929e-07f;
     const bool boxes_current = cs.bp_valid && !cs.brute_force && !c.no_contact_cache && cs.bp_version == c.data_version && cs.bp_dt == dt && cs.bp_enl == enl_f;
     if (!boxes_current) update_vertices(c, cs, d, dt, enl_f);
-    MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 8 * sizeof(int), c.stream));
+    MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
     if (!cs.brute_force) {
         if (cs.key_cap == 0) {
             cs.key_cap = initial_key_cap();
@@ -1462,7 +1465,7 @@ int64_t count_intersections_uncached(Context& c, double dt)
             if (speculate) {
                 const bool compare = cs.n_prev >= 0;
                 if (compare) cs.prev.ensure(std::max<size_t>((size_t)cs.n_prev, 1));
-                launch_sweep<true, false>(c, cs, d, enl * enl);
+                launch_sweep<true, false>(c, cs, d, enl * enl, /*reset_tasks=*/true);
                 n_pad = padded_key_count(cs);
                 hipLaunchKernelGGL(k_pad_keys, dim3((n_pad + CB - 1) / CB), dim3(CB), 0, c.stream, cs.keys.p, (const int*)cs.counters.p, n_pad);
                 sorted = sort_and_bound(c, cs, n_pad, (const int*)cs.counters.p, compare);
@@ -1472,7 +1475,7 @@ int64_t count_intersections_uncached(Context& c, double dt)
             if (hb[51] > cs.bp_cap) {
                 cs.bp_cap = hb[51] + hb[51] / 4;
                 cs.bp_valid = false;
-                MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 8 * sizeof(int), c.stream));
+                MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
                 continue;
             }
             cs.bp_valid = true;
