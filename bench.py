@@ -311,6 +311,10 @@ def main():
         sim.prepare()
         if capi.lib().mistark_set_option(sim.engine_handle(), b"spmv_grid_cap", max(8, (1024 // world) // 8 * 8)) != 0:
             raise RuntimeError("spmv_grid_cap")
+        # ... and every further stream per process oversubscribes the ONE device's hardware queues (measured with two ranks: everything,
+        # the linear solves included, 2.7 times slower once each rank opens the stream of the early evaluation): off when ranks share a device
+        if capi.lib().mistark_set_option(sim.engine_handle(), b"no_eval_prelaunch", 1) != 0:
+            raise RuntimeError("no_eval_prelaunch")
     # warm-up (includes sparsity-pattern construction and first-touch allocations)
     if a.warmup > 0:
         run_newton_steps(sim, S, capi, a.warmup)

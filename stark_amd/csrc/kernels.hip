@@ -1926,7 +1926,26 @@ void prepare(Context& c)
         c.elemE.ensure(std::max<size_t>(e_off, 1));
         // (the element-Hessian pools are allocated by the first evaluation that writes them)
         c.is_projected.ensure(std::max<size_t>(e_off, 1));
-        if (c.world > 1) MS_CHECK(hipMemsetAsync(c.elemE.p, 0, std::max<size_t>(e_off, 1) * sizeof(double), c.stream));  // other ranks' elements count 0
+        if (c.world > 1) {  // other ranks' elements count 0
+            // (kernels started ahead of the evaluation — eval_prelaunch — may have written their energies already: the fill waits for them and
+            // leaves the ranges alone that still are where those kernels wrote; a kernel whose range has moved is launched again by eval())
+            std::vector<std::pair<size_t, size_t>> keep;
+            if (c.pre.valid) {
+                MS_CHECK(hipStreamWaitEvent(c.stream, c.pre.ev_out, 0));
+                for (const Context::EvalPre::Item& it : c.pre.items) {
+                    const Potential& P = c.pots[(size_t)it.pot];
+                    if (it.E == (const void*)(c.elemE.p + P.e_off) && (size_t)it.args.e_count <= (size_t)P.n_key) keep.push_back({P.e_off, (size_t)it.args.e_count});
+                }
+                std::sort(keep.begin(), keep.end());
+            }
+            size_t at = 0;
+            const size_t total = std::max<size_t>(e_off, 1);
+            for (const auto& k : keep) {
+                if (k.first > at) MS_CHECK(hipMemsetAsync(c.elemE.p + at, 0, (k.first - at) * sizeof(double), c.stream));
+                at = std::max(at, k.first + k.second);
+            }
+            if (total > at) MS_CHECK(hipMemsetAsync(c.elemE.p + at, 0, (total - at) * sizeof(double), c.stream));
+        }
         c.dinv.ensure((size_t)c.nbr * 9);
         // (a refresh that only followed new contact-table sizes copied nothing from the host: no reason to wait for the stream)
         if (queued_uploads) MS_CHECK(hipStreamSynchronize(c.stream));
@@ -1951,7 +1970,7 @@ static void build_pattern_part(Context& c, int part) { build_pattern(c, part); }
 static void assemble_part(Context& c, int part);
 void eval_prelaunch(Context& c, int mode, bool lazy)
 {
-    if (c.world != 1 || c.no_eval_prelaunch || c.no_eval_overlap || c.layout_dirty || c.force_generic || c.kernel_dbg || c.dry || c.pre.valid) return;
+    if (c.no_eval_prelaunch || c.no_eval_overlap || c.layout_dirty || c.force_generic || c.kernel_dbg || c.dry || c.pre.valid) return;
     const bool lazy_active = mode == MISTARK_EVAL_P_G_H && lazy && !c.atomic_assembly && c.hf_total > 0;
     if (mode == MISTARK_EVAL_P_G_H && (c.elemH.cap < std::max<size_t>(c.hess_total, 1) || c.elemHf.cap < std::max<size_t>(lazy_active ? c.hf_total : 0, 16))) return;  // (first evaluation: eval() allocates)
     if (c.elemE.cap < std::max<size_t>(c.n_elem_total, 1)) return;
@@ -2024,7 +2043,7 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
     bool pre_ok = false, pre_pending = false;
     if (c.pre.valid) {
         pre_pending = true;
-        pre_ok = c.pre.mode == mode && (mode != MISTARK_EVAL_P_G_H || c.pre.lazy_active == c.lazy_active) && c.world == 1;
+        pre_ok = c.pre.mode == mode && (mode != MISTARK_EVAL_P_G_H || c.pre.lazy_active == c.lazy_active);
         if (!pre_ok) c.n_prelaunch_dropped++;
         c.pre.valid = false;
     }
@@ -5551,6 +5570,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
 
 Context::~Context()
 {
+    if (std::getenv("MISTARK_PRELAUNCH_STATS")) std::fprintf(stderr, "mistark: rank %d of %d: evaluation kernels started ahead: %lld taken over, %lld dropped\n", rank, world, (long long)n_prelaunch_used, (long long)n_prelaunch_dropped);
     contact_destroy(contact);
     direct_mf_destroy(llt_mf);
     if (dry) return;
