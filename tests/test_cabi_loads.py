@@ -46,6 +46,9 @@ def test_no_silent_cpu_fallback():
     L = capi.lib()
     h = C.c_void_p()
     assert L.mistark_create(0, C.byref(h)) != 0
+    # ... nor behind the standalone collision detector (include/mistark_tmcd.h)
+    d = C.c_void_p()
+    assert L.mistark_cd_create(C.byref(d), 0) != 0 and not d.value
 
 
 def test_headers_are_plain_c():

@@ -124,3 +124,30 @@ def test_reference_classes_register_what_the_mirror_registers(scene, tmp_path):
                         seen.setdefault(arr, []).append((p["name"], k))
         return sorted(tuple(v) for v in seen.values())
     assert identity(ref) == identity(ours)
+
+
+@pytest.mark.parametrize("scene", ["blockbox", "mixed"])
+def test_the_collision_detection_stand_in_changes_nothing_that_is_registered(scene, tmp_path):
+    """oracle/_ref/shim_check_cd: the unmodified stark/src/** compiled against shim/include_cd/TriangleMeshCollisionDetection (the reference's
+    detector dependency replaced by include/mistark_tmcd.h) instead of the dependency's own header. In registration-only mode (no GPU: the
+    stand-in returns empty lists) EnergyFrictionalContact registers the same DoF sets and the same potentials with the same bindings as with
+    its own detector; only the number of rows its host detection had already found differs."""
+    exe = SHIM_CHECK + "_cd"
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_check_cd not built (make -C oracle shim_cd)")
+    got = []
+    for binary in (SHIM_CHECK, exe):
+        out = str(tmp_path / (os.path.basename(binary) + ".json"))
+        env = dict(os.environ, MISTARK_SHIM_DRY="1", MISTARK_SHIM_DESCRIBE=out)
+        r = subprocess.run([binary, scene], env=env, capture_output=True, timeout=300)
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        got.append(json.load(open(out)))
+    assert got[0]["dof_sets"] == got[1]["dof_sets"]
+    A, B = _normalise(got[0]), _normalise(got[1])
+    assert set(A) == set(B) and len(A) >= 35
+    strip = lambda bs: [(a, s, c) for a, s, c, _ in bs]
+    for name in A:
+        assert A[name]["conn_stride"] == B[name]["conn_stride"] and A[name]["dynamic"] == B[name]["dynamic"], name
+        assert strip(A[name]["bindings"]) == strip(B[name]["bindings"]), name
+        if not name.startswith(("contact_", "friction_")):
+            assert A[name]["n_elem"] == B[name]["n_elem"] and A[name]["bindings"] == B[name]["bindings"], name
