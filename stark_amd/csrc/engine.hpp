@@ -381,16 +381,17 @@ struct Context
         {
             int pot;
             PotArgs args;
-            const void* E;
+            const void* E;   // where the kernel wrote the element energies (slot 1: Context::elemE_pre, copied into place by eval())
             const void* H;
         };
         bool valid = false;
         int mode = 0;
         bool lazy_active = false;
-        hipStream_t stream = nullptr;
         hipEvent_t ev_in = nullptr, ev_out = nullptr;
         std::vector<Item> items;
-    } pre;
+    } pre[2];  // [0]: an energy-only evaluation, [1]: one with gradient (and Hessian) — the latter may be a whole line-search trial ahead
+    hipStream_t pre_stream = nullptr;
+    DevBuf<double> elemE_pre;  // element energies of slot 1's kernels (the energy-only evaluation of the same state sums elemE meanwhile)
     bool no_eval_prelaunch = false;
     // energy-only evaluations: descriptors of the small potentials that share one launch (kernels.hip: k_eval_p_multi)
     bool no_multi_eval_p = false;
@@ -404,27 +405,33 @@ struct Context
     void touch_array(int id)
     {
         bool read = id < 0 || id >= (int)arrays.size() || arrays[(size_t)id].dof_set >= 0;
-        if (pre.valid && !read)
-            for (const EvalPre::Item& it : pre.items)
-                for (const mistark_binding& b : pots[(size_t)it.pot].bindings) read = read || b.array == id;
+        for (const EvalPre& q : pre)
+            if (q.valid && !read)
+                for (const EvalPre::Item& it : q.items)
+                    for (const mistark_binding& b : pots[(size_t)it.pot].bindings) read = read || b.array == id;
         if (read) touch();
         else data_version++;
     }
     void touch_potential(int pot)
     {
-        bool mine = false;
-        for (const EvalPre::Item& it : pre.items) mine = mine || it.pot == pot;
-        if (mine || !pre.valid) touch();
+        bool mine = false, any = false;
+        for (const EvalPre& q : pre) {
+            any = any || q.valid;
+            if (q.valid)
+                for (const EvalPre::Item& it : q.items) mine = mine || it.pot == pot;
+        }
+        if (mine || !any) touch();
         else data_version++;
     }
     void touch()
     {
         data_version++;
-        if (pre.valid) {
-            (void)hipStreamWaitEvent(stream, pre.ev_out, 0);  // (whatever comes next on the main stream must not overtake the kernels still reading)
-            pre.valid = false;
-            n_prelaunch_dropped++;
-        }
+        for (EvalPre& q : pre)
+            if (q.valid) {
+                (void)hipStreamWaitEvent(stream, q.ev_out, 0);  // (whatever comes next on the main stream must not overtake the kernels still reading)
+                q.valid = false;
+                n_prelaunch_dropped++;
+            }
     }
     bool no_contact_cache = false;  // option "no_contact_cache": every detection request runs the search (cross-check)
     size_t h_scratch_n = 0;

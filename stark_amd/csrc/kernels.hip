@@ -730,10 +730,10 @@ static void launch_bending_flat(Context& c, Potential& P, int mode)
     launch_grad_gather(c, P);
 }
 template <class En, bool FULL>
-static void launch_tet_closed(Context& c, Potential& P, int mode, bool kernel_only = false, bool gather_only = false)
+static void launch_tet_closed(Context& c, Potential& P, int mode, bool kernel_only = false, bool gather_only = false, double* E_override = nullptr)
 {
     if (P.args.e_count == 0) return;
-    double* E = c.elemE.p + P.e_off;
+    double* E = E_override ? E_override : c.elemE.p + P.e_off;
     const dim3 g(grid_for(P.args.e_count)), b(BLOCK);
     struct AfterLaunch
     {
@@ -1930,9 +1930,9 @@ void prepare(Context& c)
             // (kernels started ahead of the evaluation — eval_prelaunch — may have written their energies already: the fill waits for them and
             // leaves the ranges alone that still are where those kernels wrote; a kernel whose range has moved is launched again by eval())
             std::vector<std::pair<size_t, size_t>> keep;
-            if (c.pre.valid) {
-                MS_CHECK(hipStreamWaitEvent(c.stream, c.pre.ev_out, 0));
-                for (const Context::EvalPre::Item& it : c.pre.items) {
+            if (c.pre[0].valid) {  // (slot 1 writes its energies elsewhere)
+                MS_CHECK(hipStreamWaitEvent(c.stream, c.pre[0].ev_out, 0));
+                for (const Context::EvalPre::Item& it : c.pre[0].items) {
                     const Potential& P = c.pots[(size_t)it.pot];
                     if (it.E == (const void*)(c.elemE.p + P.e_off) && (size_t)it.args.e_count <= (size_t)P.n_key) keep.push_back({P.e_off, (size_t)it.args.e_count});
                 }
@@ -1970,37 +1970,43 @@ static void build_pattern_part(Context& c, int part) { build_pattern(c, part); }
 static void assemble_part(Context& c, int part);
 void eval_prelaunch(Context& c, int mode, bool lazy)
 {
-    if (c.no_eval_prelaunch || c.no_eval_overlap || c.layout_dirty || c.force_generic || c.kernel_dbg || c.dry || c.pre.valid) return;
+    Context::EvalPre& pre = c.pre[mode == MISTARK_EVAL_P ? 0 : 1];
+    if (c.no_eval_prelaunch || c.no_eval_overlap || c.layout_dirty || c.force_generic || c.kernel_dbg || c.dry || pre.valid) return;
     const bool lazy_active = mode == MISTARK_EVAL_P_G_H && lazy && !c.atomic_assembly && c.hf_total > 0;
     if (mode == MISTARK_EVAL_P_G_H && (c.elemH.cap < std::max<size_t>(c.hess_total, 1) || c.elemHf.cap < std::max<size_t>(lazy_active ? c.hf_total : 0, 16))) return;  // (first evaluation: eval() allocates)
     if (c.elemE.cap < std::max<size_t>(c.n_elem_total, 1)) return;
-    c.pre.items.clear();
+    const bool apart = mode != MISTARK_EVAL_P;
+    if (apart && c.elemE_pre.cap < std::max<size_t>(c.n_elem_total, 1)) {
+        if (c.pre[0].valid) return;  // (no allocation while kernels are in flight)
+        c.elemE_pre.ensure(std::max<size_t>(c.n_elem_total, 1));
+    }
+    pre.items.clear();
     for (size_t pi = 0; pi < c.pots.size(); pi++) {
         Potential& P = c.pots[pi];
         if (P.kind == KIND_CUSTOM || P.args.e_count == 0 || !P.args.gpool) continue;
         if (P.name != E_TetStrain::name && P.name != E_TetStrainEO::name) continue;
         if (mode == MISTARK_EVAL_P_G_H && lazy_active != (P.lazy_capable && lazy_active)) continue;  // (a tet potential outside the lazy pool: not here)
-        c.pre.items.push_back(Context::EvalPre::Item{(int)pi, P.args, (const void*)(c.elemE.p + P.e_off),
-                                                   mode != MISTARK_EVAL_P_G_H ? nullptr : (lazy_active ? (const void*)(c.elemHf.p + P.hf_off) : (const void*)(c.elemH.p + P.h_off))});
+        pre.items.push_back(Context::EvalPre::Item{(int)pi, P.args, (const void*)((apart ? c.elemE_pre.p : c.elemE.p) + P.e_off),
+                                               mode != MISTARK_EVAL_P_G_H ? nullptr : (lazy_active ? (const void*)(c.elemHf.p + P.hf_off) : (const void*)(c.elemH.p + P.h_off))});
     }
-    if (c.pre.items.empty()) return;
-    if (!c.pre.stream) {
-        MS_CHECK(hipStreamCreateWithFlags(&c.pre.stream, hipStreamNonBlocking));
-        MS_CHECK(hipEventCreateWithFlags(&c.pre.ev_in, hipEventDisableTiming));
-        MS_CHECK(hipEventCreateWithFlags(&c.pre.ev_out, hipEventDisableTiming));
+    if (pre.items.empty()) return;
+    if (!c.pre_stream) MS_CHECK(hipStreamCreateWithFlags(&c.pre_stream, hipStreamNonBlocking));
+    if (!pre.ev_in) {
+        MS_CHECK(hipEventCreateWithFlags(&pre.ev_in, hipEventDisableTiming));
+        MS_CHECK(hipEventCreateWithFlags(&pre.ev_out, hipEventDisableTiming));
     }
-    MS_CHECK(hipEventRecord(c.pre.ev_in, c.stream));  // (the DoFs of this evaluation are final on the main stream)
-    MS_CHECK(hipStreamWaitEvent(c.pre.stream, c.pre.ev_in, 0));
+    MS_CHECK(hipEventRecord(pre.ev_in, c.stream));  // (the DoFs of this evaluation are final on the main stream)
+    MS_CHECK(hipStreamWaitEvent(c.pre_stream, pre.ev_in, 0));
     hipStream_t main_stream = c.stream;
     const bool lazy_before = c.lazy_active;
-    c.stream = c.pre.stream;
+    c.stream = c.pre_stream;
     c.lazy_active = lazy_active;
     try {
-        for (const Context::EvalPre::Item& it : c.pre.items) {
+        for (const Context::EvalPre::Item& it : pre.items) {
             Potential& P = c.pots[(size_t)it.pot];
             if (mode == MISTARK_EVAL_P) launch_eval_kind(c, P, mode);  // (energy only: one kernel, nothing to gather)
-            else if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, true);
-            else launch_tet_closed<E_TetStrainEO, false>(c, P, mode, true);
+            else if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, true, false, c.elemE_pre.p + P.e_off);
+            else launch_tet_closed<E_TetStrainEO, false>(c, P, mode, true, false, c.elemE_pre.p + P.e_off);
         }
     } catch (...) {
         c.stream = main_stream;
@@ -2009,10 +2015,10 @@ void eval_prelaunch(Context& c, int mode, bool lazy)
     }
     c.stream = main_stream;
     c.lazy_active = lazy_before;
-    MS_CHECK(hipEventRecord(c.pre.ev_out, c.pre.stream));
-    c.pre.valid = true;
-    c.pre.mode = mode;
-    c.pre.lazy_active = lazy_active;
+    MS_CHECK(hipEventRecord(pre.ev_out, c.pre_stream));
+    pre.valid = true;
+    pre.mode = mode;
+    pre.lazy_active = lazy_active;
 }
 void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs, bool lazy)
 {
@@ -2041,11 +2047,12 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
     // kernels launched ahead of this call (eval_prelaunch): whatever becomes of their results, nothing on this stream overtakes them
     // (the wait sits in front of the first launch that touches their pools, below: the small potentials of this evaluation need not wait)
     bool pre_ok = false, pre_pending = false;
-    if (c.pre.valid) {
+    Context::EvalPre& pre = c.pre[mode == MISTARK_EVAL_P ? 0 : 1];
+    if (pre.valid) {
         pre_pending = true;
-        pre_ok = c.pre.mode == mode && (mode != MISTARK_EVAL_P_G_H || c.pre.lazy_active == c.lazy_active);
+        pre_ok = pre.mode == mode && (mode != MISTARK_EVAL_P_G_H || pre.lazy_active == c.lazy_active);
         if (!pre_ok) c.n_prelaunch_dropped++;
-        c.pre.valid = false;
+        pre.valid = false;
     }
     // The handful of large potentials (a million tets: 230 us) and the dozens of small ones (rigid bodies, the 35 contact and friction
     // tables: 5-12 us each, latency, one after the other) share nothing but the gradient, which both sides add to atomically: the small
@@ -2095,16 +2102,19 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
             c.stream = aux ? c.aux_stream : main_stream;
             c.grad.p = aux ? c.grad_aux.p : grad_main;
             if (pre_pending)
-                for (const Context::EvalPre::Item& it : c.pre.items)
+                for (const Context::EvalPre::Item& it : pre.items)
                     if (&c.pots[(size_t)it.pot] == &P) {
-                        MS_CHECK(hipStreamWaitEvent(c.stream, c.pre.ev_out, 0));
+                        MS_CHECK(hipStreamWaitEvent(c.stream, pre.ev_out, 0));
                         break;
                     }
             if (pre_ok && !aux) {  // evaluated ahead (eval_prelaunch) with the arguments it has now: only its gradient gather is left
                 bool taken = false;
-                for (const Context::EvalPre::Item& it : c.pre.items)
-                    if (&c.pots[(size_t)it.pot] == &P && std::memcmp(&it.args, &P.args, sizeof(PotArgs)) == 0 && it.E == (const void*)(c.elemE.p + P.e_off) &&
+                for (const Context::EvalPre::Item& it : pre.items)
+                    if (&c.pots[(size_t)it.pot] == &P && std::memcmp(&it.args, &P.args, sizeof(PotArgs)) == 0 &&
+                        it.E == (const void*)((mode == MISTARK_EVAL_P ? c.elemE.p : c.elemE_pre.p) + P.e_off) &&
                         it.H == (mode != MISTARK_EVAL_P_G_H ? nullptr : (c.lazy_active ? (const void*)(c.elemHf.p + P.hf_off) : (const void*)(c.elemH.p + P.h_off)))) {
+                        if (mode != MISTARK_EVAL_P)  // the energies it wrote aside (the line search's energy evaluation summed elemE meanwhile)
+                            MS_CHECK(hipMemcpyAsync(c.elemE.p + P.e_off, c.elemE_pre.p + P.e_off, (size_t)P.args.e_count * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
                         if (mode == MISTARK_EVAL_P) {
                         } else if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, false, true);
                         else launch_tet_closed<E_TetStrainEO, false>(c, P, mode, false, true);
@@ -5574,12 +5584,15 @@ Context::~Context()
     contact_destroy(contact);
     direct_mf_destroy(llt_mf);
     if (dry) return;
-    if (pre.stream) {
-        (void)hipStreamSynchronize(pre.stream);
-        (void)hipStreamDestroy(pre.stream);
-        (void)hipEventDestroy(pre.ev_in);
-        (void)hipEventDestroy(pre.ev_out);
+    if (pre_stream) {
+        (void)hipStreamSynchronize(pre_stream);
+        (void)hipStreamDestroy(pre_stream);
     }
+    for (EvalPre& q : pre)
+        if (q.ev_in) {
+            (void)hipEventDestroy(q.ev_in);
+            (void)hipEventDestroy(q.ev_out);
+        }
     for (int k = 0; k < 2; k++) {
         if (h_stage[k]) (void)hipHostFree(h_stage[k]);
         if (h_stage_ev[k]) (void)hipEventDestroy(h_stage_ev[k]);

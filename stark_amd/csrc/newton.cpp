@@ -297,6 +297,8 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                 double E1 = 0.0;
                 int k = 0;
                 for (; k < s.max_backtracking_armijo_iterations; ++k) {
+                    // (Starting the NEXT iteration's gradient / Hessian kernel here as well, on the bet that the candidate is accepted, was
+                    // measured: the search chain slows down by what the evaluation gains — the GPU is busy either way.)
                     if (cb && cb->before_energy_evaluation) eval_prelaunch(c, MISTARK_EVAL_P, false);
                     call_void(cb ? cb->before_energy_evaluation : nullptr);
                     {
