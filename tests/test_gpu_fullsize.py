@@ -591,7 +591,19 @@ def test_multifrontal_cholesky_equals_the_band_cholesky_and_solves_the_system(gr
     assert np.abs(sols[1] - sols[2]).max() <= 1e-9 * np.abs(sols[2]).max()
     if -1 in sols:
         assert np.abs(sols[1] - sols[-1]).max() <= 1e-9 * np.abs(sols[-1]).max()
-    # a matrix that is not positive definite is reported, not factored
-    x, ok = eng.direct_llt(b)
-    assert ok
+    # a matrix that is not positive definite is reported by every path (SimplicialLLT's info() != Success), not factored: the unprojected
+    # Hessian of a badly distorted state (the PCG's own verdict on it: indefinite)
+    if n < 80000:
+        eng.set_dofs(8.0 * np.sin(1.3 * np.arange(n) + 0.7))
+        eng.eval(capi.EVAL_P_G_H)
+        eng.assemble()
+        _, info = eng.pcg(1e-8, 1e-8, 2000, stop_on_indef=True)
+        assert info.found_indefiniteness
+        for mode in (1, 2, -1):
+            eng.set_option("llt_no_coords", int(mode == 2))
+            eng.set_option("llt_multifrontal", 1 if mode == 2 else mode)
+            _, ok = eng.direct_llt(b)
+            assert not ok, mode
+        eng.set_option("llt_multifrontal", 0)
+        eng.set_option("llt_no_coords", 0)
     sim.close()
