@@ -220,6 +220,31 @@ def hbm_resident_pass(S, capi, device):
             "achieved": gbs, "unit": "GB/s", "frac": gbs / 8000.0, "timing": "HIP events around 50 back-to-back launches (mistark_spmv_bench)"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks ourselves (one process per GPU, torch.distributed.run on
+    127.0.0.1) with this very command line; rank 0's JSON line is the only thing on stdout. Refuses to pretend: fewer visible GPUs than ranks
+    is an error unless MISTARK_BENCH_DEVICE says that all ranks are to share one device (test boxes)."""
+    import socket
+
+    import torch
+
+    have = torch.cuda.device_count()
+    if have < n and os.environ.get("MISTARK_BENCH_DEVICE") is None:
+        print("bench.py: --gpus %d but only %d GPU(s) visible; set MISTARK_BENCH_DEVICE=<id> to run all ranks on one device (a path test, not a "
+              "scaling measurement)" % (n, have), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (window handles, RCCL)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["MISTARK_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,9 +260,13 @@ def main():
     nx, ny, nz = [int(v) for v in a.grid.split(",")]
     offset = tuple(float(v) for v in a.offset.split(","))
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
     import torch
 
     from stark_amd import capi
@@ -304,6 +333,21 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    ranks_seen = None
+    if world > 1:
+        # what actually runs, rank by rank, as the engine and the runtime report it (not what the command line asked for)
+        import ctypes as _Cd
+        sim.prepare()
+        di = (_Cd.c_int64 * 12)()
+        if capi.lib().mistark_dist_info(sim.engine_handle(), di, 12) != 0:
+            raise RuntimeError(capi.lib().mistark_last_error(sim.engine_handle()))
+        props = torch.cuda.get_device_properties(device)
+        mine = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "device": device, "device_name": props.name,
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "engine_world": int(di[8]), "engine_rank": int(di[9]),
+                "transport": {0: None, 1: "in-process", 2: "rccl", 3: "ipc"}.get(int(di[10])), "transport_ranks": int(di[11]),
+                "rows_owned": int(di[0]), "ghost_rows": int(di[1]), "elements_evaluated": int(di[3])}
+        ranks_seen = allgather_bytes(mine)
 
     if world > 1 and os.environ.get("MISTARK_BENCH_DEVICE") is not None:
         # all ranks on ONE device (test boxes): kernels that poll for a peer's data hold their workgroup slots, so the ranks' SpMV grids
@@ -385,12 +429,13 @@ def main():
         achieved_events = (spmv_bytes / (spmv_ms * 1e-3)) / 1e9 if spmv_ms > 0 else 0.0
         achieved_clock = (spmv_bytes / (spmv_clk_ms * 1e-3)) / 1e9 if spmv_clk_ms else None
         achieved_b2b = (spmv_bytes / (spmv_b2b_ms * 1e-3)) / 1e9 if spmv_b2b_ms else None
-        # The headline figure uses the duration a reader can reproduce: the SpMV launches that did work in the committed rocprofv3 kernel trace of
-        # THIS command (profiles/<tag>_kernel_stats.txt, last line). The live figures of this run are reported beside it: the device clock
-        # (first wavefront in to last wavefront out: shorter than the trace's dispatch-packet span), the HIP event bracket (longer: dispatch
-        # and marker packets inside), and the back-to-back batch. Other workloads (no committed trace): the device clock, else the events.
-        if default_workload and trace_ms:
-            achieved, basis, basis_ms, basis_n = (spmv_bytes / (trace_ms * 1e-3)) / 1e9, "rocprofv3 kernel trace of this command: " + trace_src, trace_ms, None
+        # The headline figure is MEASURED IN THIS RUN: HIP events on the engine's stream around 100 back-to-back SpMV launches on the matrix the
+        # timed region ended with (one event pair per batch: the 5 us an event pair costs the stream do not dilute a 20 us launch). Beside it, also
+        # live: the sampled launches INSIDE the timed region on the device clock (first wavefront in to last wavefront out) and between HIP events
+        # (dispatch and marker packets inside). The committed rocprofv3 kernel trace of this command is a side field
+        # (`rocprofv3_profile_launch_ms`); `profile_agreement` = live / profile duration: a build whose SpMV regressed, or a stale profile, shows there.
+        if world == 1 and achieved_b2b:
+            achieved, basis, basis_ms, basis_n = achieved_b2b, "live, this run: HIP events around 100 back-to-back launches on the engine's stream right after the timed region (same matrix, same vectors)", spmv_b2b_ms, 100
         elif achieved_clock:
             achieved, basis, basis_ms, basis_n = achieved_clock, "device clock of sampled launches inside the timed region", spmv_clk_ms, spmv_clk_n
         elif achieved_events > 0:
@@ -426,6 +471,11 @@ def main():
                 # kernel: two boundaries, the one-way latency and the ranks' skew), measured by the transport's self-test before the scene is built
                 "ipc_allgather_1024_doubles_us": ipc_selftest_us,
                 "ranks_on_one_device": bool(os.environ.get("MISTARK_BENCH_DEVICE")) if world > 1 else None,
+                # one entry per rank, as the engine and the runtime report it: device, the transport in use and the number of ranks the transport
+                # itself counts (RCCL: ncclCommCount of the communicator)
+                "ranks_seen": ranks_seen,
+                "distinct_devices": len({(r["device"], r["pci_bus_id"]) for r in ranks_seen}) if ranks_seen else None,
+                "launched_by": "bench.py itself (torch.distributed.run, one process per GPU)" if os.environ.get("MISTARK_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else None),
                 "projection": "Progressive",
             },
             "ms_per_linear_solve": 1000.0 * t_ls / max(n_ls, 1),
@@ -471,6 +521,7 @@ def main():
                 # the committed rocprofv3 kernel trace of this command (under the tracer; its duration spans the dispatch packet)
                 "rocprofv3_profile_launch_ms": trace_ms if default_workload else None,
                 "rocprofv3_profile_source": trace_src if default_workload else None,
+                "profile_agreement": (basis_ms / trace_ms) if (default_workload and trace_ms and basis_ms) else None,
             },
         }
         if default_workload and offset == (0.0, 0.0) and not a.no_extras:

@@ -17,10 +17,16 @@
 //   solve()                  every table and array is fingerprinted (in parallel when OpenMP is on); what changed since the engine last saw it
 //                            is sent — an in-place edit at an unchanged address and size (re-targeted attachments, a swapped prescribed-point
 //                            list: ADVICE r02) is caught here
-//   before_energy_evaluation tables of contact_* / friction_* potentials and every array up to SMALL_ARRAY doubles are fingerprinted and sent
-//                            when changed (the callback's own products: contact tables, friction data, stiffness scalars); larger tables and
-//                            arrays are re-checked by address and size only (a callback that rewrites a LARGE array in place inside the
-//                            Newton loop needs MISTARK_SHIM_STRICT=1: everything fingerprinted at every evaluation)
+//   before_energy_evaluation tables of contact_* / friction_* potentials and every array up to SMALL_ARRAY doubles are fingerprinted in full and
+//                            sent when changed (the callback's own products: contact tables, friction data, stiffness scalars). Larger tables
+//                            and arrays get a SAMPLED fingerprint at every evaluation (64 bytes of every 4 KiB + both ends: a callback that
+//                            recomputes such an array — re-targeted prescribed positions, a rewritten rest shape — is caught at 1/64 of the
+//                            cost of reading it), and are re-sent in full when the sample, the address or the size changed
+//   end of solve()           every large table and array is fingerprinted in full once more: bytes that changed INSIDE the Newton loop without
+//                            the sample noticing (a sparse in-place edit) mean the engine solved with stale data — reported once on stderr
+//                            with the name of the remedy, and sent, so that the next solve starts from the caller's data
+//   MISTARK_SHIM_STRICT=1    everything fingerprinted in full at every evaluation (the reference's semantics at the reference's cost);
+//   MISTARK_SHIM_FAST=1      the round-3 behaviour: large tables and arrays re-checked by address and size only inside the Newton loop
 // The DoF vector itself never travels host -> device inside a solve: the engine owns it there.
 // MISTARK_SHIM_DRY=1: registration only on a registration-only context (no GPU; solve() returns Successful without touching the DoFs);
 // MISTARK_SHIM_DESCRIBE=<file>: the registration (mistark_describe) is written there after every solve.
@@ -59,6 +65,7 @@ namespace symx
 			int stride = 0;
 			bool is_dof = false;
 			uint64_t print = 0;     // fingerprint of the bytes the engine holds
+			uint64_t sprint = 0;    // sampled fingerprint of the same bytes (large arrays)
 			bool have_print = false;
 		};
 		std::map<std::pair<std::uintptr_t, int>, Arr> arrays;  // (DataMap id, stride) -> engine array
@@ -69,10 +76,14 @@ namespace symx
 			int32_t n_elem = -1;
 			int stride = 0;
 			bool dynamic = false;   // contact_* / friction_*: refilled inside the Newton loop
-			uint64_t print = 0;
+			uint64_t print = 0, sprint = 0;
+			std::string name;
 		};
 		static constexpr int64_t SMALL_ARRAY = 32768;  // doubles: arrays up to this size are fingerprinted at every evaluation
 		bool strict = false;        // MISTARK_SHIM_STRICT=1
+		bool fast = false;          // MISTARK_SHIM_FAST=1
+		bool warned_stale = false;
+		int64_t n_sample_hits = 0, n_stale = 0;  // large tables / arrays re-sent because their sample changed inside the Newton loop; missed edits found at the end of a solve
 		int64_t n_uploads = 0, n_table_updates = 0, bytes_sent = 0;  // statistics (MISTARK_SHIM_STATS=1 prints them at destruction)
 		double t_tables = 0.0, t_hash = 0.0, t_upload = 0.0;  // inside sync(): table updates in the engine, fingerprints, array uploads
 		double t_callbacks = 0.0, t_sync = 0.0, t_dofs = 0.0, t_solve = 0.0;  // seconds: the caller's callbacks, sync(), DoF transfers, all of solve()
@@ -132,6 +143,22 @@ namespace symx
 			for (uint64_t v : part) h = mix(h, v);
 			return h;
 		}
+		// sampled fingerprint of a large byte range: 64 bytes of every 4 KiB and the last 64 bytes, with the length
+		static constexpr size_t SAMPLE_MIN_BYTES = (size_t)SMALL_ARRAY * 8;
+		__attribute__((optimize("O3"))) static uint64_t fingerprint_sampled(const void* data, size_t bytes)
+		{
+			const unsigned char* p = static_cast<const unsigned char*>(data);
+			uint64_t h = 0x3F84D5B5B5470917ull ^ (uint64_t)bytes;
+			auto take = [&](size_t at) {
+				uint64_t w[8];
+				std::memcpy(w, p + at, 64);
+				for (int i = 0; i < 8; i++) h = mix(h, w[i]);
+			};
+			if (bytes < 128) return fingerprint_chunk(p, bytes);
+			for (size_t at = 0; at + 64 <= bytes; at += 4096) take(at);
+			take(bytes - 64);
+			return h;
+		}
 		std::vector<Pot> pots;
 		std::vector<std::pair<const double*, int64_t>> dof_sets;
 
@@ -142,7 +169,8 @@ namespace symx
 		~Impl()
 		{
 			if (std::getenv("MISTARK_SHIM_STATS"))
-				std::cerr << "mistark shim: " << n_uploads << " array uploads, " << n_table_updates << " table updates, " << bytes_sent / 1e6 << " MB sent to the engine; of " << t_solve
+				std::cerr << "mistark shim: " << n_uploads << " array uploads, " << n_table_updates << " table updates (" << n_sample_hits << " found by the sampled check inside the Newton loop, " << n_stale
+				          << " in-loop edits it missed), " << bytes_sent / 1e6 << " MB sent to the engine; of " << t_solve
 				          << " s in solve(): " << t_callbacks << " s in the caller's callbacks, " << t_sync << " s in sync() (" << t_tables << " table updates, " << t_hash << " array fingerprints, " << t_upload << " array uploads), " << t_dofs
 				          << " s bringing DoFs to the caller" << std::endl;
 			if (ctx) mistark_destroy(ctx);
@@ -154,6 +182,8 @@ namespace symx
 			dry = dry_env && dry_env[0] == '1';
 			const char* strict_env = std::getenv("MISTARK_SHIM_STRICT");
 			strict = strict_env && strict_env[0] == '1';
+			const char* fast_env = std::getenv("MISTARK_SHIM_FAST");
+			fast = fast_env && fast_env[0] == '1' && !strict;
 			if (dry) {
 				check(mistark_create_dry(&ctx), "mistark_create_dry");
 			} else {
@@ -246,19 +276,33 @@ namespace symx
 					P.stride = mws->conn.stride;
 					P.dynamic = name.rfind("contact_", 0) == 0 || name.rfind("friction_", 0) == 0;
 					P.print = n_elem > 0 ? fingerprint(conn, (size_t)n_elem * (size_t)P.stride * sizeof(int32_t)) : 0;
+					P.sprint = n_elem > 0 ? fingerprint_sampled(conn, (size_t)n_elem * (size_t)P.stride * sizeof(int32_t)) : 0;
+					P.name = name;
 					pots.push_back(P);
 				} else {
 					// The reference refills tables in place: the same address and size may hold other rows. Tables the Newton loop refills are
 					// fingerprinted at every evaluation, the others at every solve(); only a table whose bytes changed is sent (each update
 					// makes the engine re-validate its indices and rebuild its incidence lists).
 					Pot& P = pots[pi];
+					const size_t tbytes = (size_t)std::max(n_elem, 0) * (size_t)P.stride * sizeof(int32_t);
 					bool changed = P.conn != conn || P.n_elem != n_elem;
-					if (!changed && n_elem > 0 && (full || P.dynamic)) {
-						const uint64_t h = fingerprint(conn, (size_t)n_elem * (size_t)P.stride * sizeof(int32_t));
+					if (!changed && n_elem > 0 && (full || P.dynamic || tbytes <= SAMPLE_MIN_BYTES)) {
+						const uint64_t h = fingerprint(conn, tbytes);
 						changed = h != P.print;
 						P.print = h;
+						if (changed) P.sprint = fingerprint_sampled(conn, tbytes);
+					} else if (!changed && n_elem > 0 && !fast) {
+						// a large static table inside the Newton loop: the sample decides whether it is read in full
+						const uint64_t hs = fingerprint_sampled(conn, tbytes);
+						if (hs != P.sprint) {
+							P.sprint = hs;
+							P.print = fingerprint(conn, tbytes);
+							changed = true;
+							n_sample_hits++;
+						}
 					} else if (changed) {
-						P.print = n_elem > 0 ? fingerprint(conn, (size_t)n_elem * (size_t)P.stride * sizeof(int32_t)) : 0;
+						P.print = n_elem > 0 ? fingerprint(conn, tbytes) : 0;
+						P.sprint = n_elem > 0 ? fingerprint_sampled(conn, tbytes) : 0;
 					}
 					if (changed) {
 						const double tt = now();
@@ -277,9 +321,17 @@ namespace symx
 				Arr& a = kv.second;
 				if (a.id < 0 || a.is_dof || !a.host || a.n <= 0) continue;
 				const int64_t doubles = a.n * (int64_t)a.stride;
-				if (a.have_print && !full && doubles > SMALL_ARRAY) continue;
 				const double th = now();
+				if (a.have_print && !full && doubles > SMALL_ARRAY) {
+					// a large array inside the Newton loop: the sample decides whether it is read (and sent) in full
+					if (fast) continue;
+					const uint64_t hs = fingerprint_sampled(a.host, (size_t)doubles * sizeof(double));
+					t_hash += now() - th;
+					if (hs == a.sprint) continue;
+					n_sample_hits++;
+				}
 				const uint64_t h = fingerprint(a.host, (size_t)doubles * sizeof(double));
+				if (doubles > SMALL_ARRAY) a.sprint = fingerprint_sampled(a.host, (size_t)doubles * sizeof(double));
 				t_hash += now() - th;
 				if (a.have_print && h == a.print) continue;
 				const double tu = now();
@@ -290,6 +342,46 @@ namespace symx
 				a.have_print = true;
 				n_uploads++;
 				bytes_sent += doubles * 8;
+			}
+		}
+
+		// End of a solve: what the sampled checks inside the Newton loop may have missed. A large table or array whose bytes differ from what
+		// the engine holds was edited in place during the loop without its sample changing: the engine evaluated stale data from that point on.
+		// Said once, with the remedy; the data is sent so that the next solve does not start stale as well.
+		void verify_after_solve(GlobalPotential& gp)
+		{
+			if (strict || fast || dry) return;
+			const double t0 = now();
+			std::string first;
+			const auto& potentials = gp.get_potentials();
+			for (size_t pi = 0; pi < pots.size() && pi < potentials.size(); pi++) {
+				Pot& P = pots[pi];
+				const size_t tbytes = (size_t)std::max(P.n_elem, 0) * (size_t)P.stride * sizeof(int32_t);
+				if (P.dynamic || tbytes <= SAMPLE_MIN_BYTES || !P.conn) continue;
+				auto mws = potentials[pi]->get_mws();
+				if (mws->conn.n_elements() != P.n_elem || mws->conn.data() != P.conn) continue;  // (resized since: the next solve's full pass sends it)
+				if (fingerprint(P.conn, tbytes) != P.print) {
+					n_stale++;
+					if (first.empty()) first = "connectivity of potential '" + P.name + "'";
+					P.n_elem = -1;  // (forces the update at the next sync)
+				}
+			}
+			for (auto& kv : arrays) {
+				Arr& a = kv.second;
+				const int64_t doubles = a.n * (int64_t)a.stride;
+				if (a.id < 0 || a.is_dof || !a.host || doubles <= SMALL_ARRAY || !a.have_print) continue;
+				if (fingerprint(a.host, (size_t)doubles * sizeof(double)) != a.print) {
+					n_stale++;
+					if (first.empty()) first = "an array of " + std::to_string(doubles) + " doubles";
+					a.have_print = false;
+				}
+			}
+			t_hash += now() - t0;
+			if (!first.empty() && !warned_stale) {
+				warned_stale = true;
+				std::cerr << "mistark shim: WARNING: " << first << " was modified in place inside the Newton loop without its sampled fingerprint changing; the engine evaluated the "
+				          << "previous contents for the rest of that solve. Set MISTARK_SHIM_STRICT=1 (every table and array read in full at every evaluation) for callbacks that "
+				          << "edit a few entries of a large array in place." << std::endl;
 			}
 		}
 
@@ -397,6 +489,7 @@ namespace symx
 		const int rc = mistark_newton_solve(s.ctx, &ns, &cb, &st);
 		s.check(rc, "mistark_newton_solve");
 		s.dofs_to_host();  // the reference leaves the solution in the caller's DoF arrays (NewtonsMethod.cpp:608-640)
+		s.verify_after_solve(*global_potential);
 		if (const char* path = std::getenv("MISTARK_SHIM_SOLVELOG"))  // one line per solve(): Newton iterations, linear solves, CG iterations
 			std::ofstream(path, std::ios::app) << st.newton_iterations << " " << st.n_linear_solves << " " << st.cg_iterations << std::endl;
 		this->stats.newton_iterations = st.newton_iterations;

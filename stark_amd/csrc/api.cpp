@@ -734,6 +734,10 @@ int mistark_pcg_rhs(mistark_ctx* ctx, const double* rhs_host, double abs_tol, do
 {
     API_BEGIN
     Context& c = ctx->c;
+    if (!rhs_host) throw Error("mistark_pcg_rhs: null right-hand side");
+    if (c.dry) throw Error("mistark_pcg_rhs: a dry context (mistark_create_dry) has no device");
+    if (!c.have_matrix) throw Error("mistark_pcg_rhs: matrix not assembled (mistark_assemble first)");
+    c.tmp_a.ensure((size_t)c.ndofs);
     MS_CHECK(hipMemcpyAsync(c.tmp_a.p, rhs_host, (size_t)c.ndofs * sizeof(double), hipMemcpyHostToDevice, c.stream));
     pcg(c, c.tmp_a.p, abs_tol, rel_tol, max_iter, stop_on_indefiniteness, info);
     if (x_host) {
@@ -748,6 +752,10 @@ int mistark_direct_llt_rhs(mistark_ctx* ctx, const double* rhs_host, double* x_h
     API_BEGIN
     Context& c = ctx->c;
     if (!rhs_host || !success) throw Error("mistark_direct_llt_rhs: null argument");
+    if (c.dry) throw Error("mistark_direct_llt_rhs: a dry context (mistark_create_dry) has no device");
+    if (!c.have_matrix) throw Error("mistark_direct_llt_rhs: matrix not assembled (mistark_assemble first)");
+    if (c.world > 1) throw Error("DirectLLT is a single-rank solver (a sharded context holds its own rows only); use the block-Jacobi PCG");
+    c.tmp_a.ensure((size_t)c.ndofs);
     MS_CHECK(hipMemcpyAsync(c.tmp_a.p, rhs_host, (size_t)c.ndofs * sizeof(double), hipMemcpyHostToDevice, c.stream));
     *success = direct_llt(c, c.tmp_a.p, c.du.p) ? 1 : 0;
     if (x_host) {
@@ -947,9 +955,9 @@ int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n)
     Context& c = ctx->c;
     if (!out && n > 0) throw Error("mistark_dist_info: null output");
     prepare(c);
-    const int64_t v[8] = {c.world > 1 ? c.sh.n_own : c.nbr, c.world > 1 ? c.sh.n_ghost : 0, c.world > 1 ? c.sh.n_send : 0, (int64_t)c.n_elem_total, c.part[0].nnzb, c.part[1].nnzb,
-                          c.n_fused_solves, c.n_unfused_solves};
-    for (int i = 0; i < n && i < 8; i++) out[i] = v[i];
+    const int64_t v[12] = {c.world > 1 ? c.sh.n_own : c.nbr, c.world > 1 ? c.sh.n_ghost : 0, c.world > 1 ? c.sh.n_send : 0, (int64_t)c.n_elem_total, c.part[0].nnzb, c.part[1].nnzb,
+                           c.n_fused_solves, c.n_unfused_solves, c.world, c.rank, c.coll ? c.coll->transport_id() : 0, c.coll ? c.coll->transport_ranks() : 1};
+    for (int i = 0; i < n && i < 12; i++) out[i] = v[i];
     API_END(0)
 }
 int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner)

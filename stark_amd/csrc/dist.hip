@@ -68,6 +68,8 @@ struct LocalCollective : Collective
         }
     }
     hipStream_t shared_stream() override { return g->stream; }
+    int transport_id() const override { return 1; }
+    int transport_ranks() const override { return g->world; }
     void allgather_f64(const double* send, double* recv, size_t n, hipStream_t stream) override
     {
         if (n == 0) return;
@@ -96,6 +98,7 @@ struct Rccl
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl& rccl()
@@ -117,6 +120,7 @@ Rccl& rccl()
         r.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))sym("ncclAllReduce");
         r.AllGather = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))sym("ncclAllGather");
         r.CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+        r.CommCount = (int (*)(void*, int*))sym("ncclCommCount");
         r.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
     }
     return r;
@@ -138,6 +142,13 @@ struct RcclCollective : Collective
     {
         if (comm) rccl().CommDestroy(comm);
     }
+    int transport_id() const override { return 2; }
+    int transport_ranks() const override
+    {
+        int n = 0;
+        nccl_check(rccl().CommCount(comm, &n), "ncclCommCount");
+        return n;
+    }
     // ncclDataType_t: ncclFloat64 = 8 (rccl.h)
     void allgather_f64(const double* send, double* recv, size_t n, hipStream_t s) override
     {
@@ -152,6 +163,8 @@ struct RcclCollective : Collective
 // Slot reuse. The exchange with sequence number s writes the slots of parity s & 1, so s + 2 overwrites what s delivered. Rank A pushes
 // s + 2 after its own wait for s + 1 has finished (stream order), i.e. after EVERY rank B has pushed s + 1, which B enqueued behind its
 // wait for s: when a granule of s + 2 lands on B, B has consumed s.
+constexpr size_t IPC_HDR = 8;                         // granules at the start of every window: {magic, granules, world, rank}
+constexpr unsigned long long IPC_MAGIC = 0x6d69737461726b31ull;  // "mistark1"
 struct IpcComm
 {
     int device = 0, rank = 0, world = 1;
@@ -206,6 +219,8 @@ struct IpcCollective : Collective
         if (!m->connected) throw Error("IPC communicator: connect it before use (mistark_ipc_comm_connect)");
     }
     const IpcView* ipc() override { return &m->view; }
+    int transport_id() const override { return 3; }
+    int transport_ranks() const override { return m->world; }
     void check() override
     {
         const unsigned int code = __atomic_load_n(m->err, __ATOMIC_ACQUIRE);
@@ -226,8 +241,9 @@ struct IpcCollective : Collective
         const size_t slot_g = 2 * m->cap;
         // (messages longer than a slot travel in pieces, each its own exchange; recv is laid out per rank with stride n)
         if (n <= m->cap) {
+            if (m->seq == 0xffffffffu) throw Error("IPC communicator: 2^32 exchanges issued; the tag would wrap to the windows' zero-filled state (create a new communicator)");
             const uint32_t tag = ++m->seq;
-            const size_t par = (size_t)(tag & 1u) * (size_t)W * slot_g;
+            const size_t par = IPC_HDR + (size_t)(tag & 1u) * (size_t)W * slot_g;
             const int gp = (int)std::min<size_t>((n + IPC_TB - 1) / IPC_TB, 256);
             hipLaunchKernelGGL(k_ipc_push, dim3(gp), dim3(IPC_TB), 0, s, send, n, pk, W, par + (size_t)m->rank * slot_g, tag);
             // the waiting grid stays small: polling workgroups must never crowd out the kernels they are waiting for when several ranks
@@ -259,15 +275,16 @@ struct IpcCollective : Collective
 };
 }  // namespace
 
-// general region: 3/4 of the window, 2 parities x world slots; the rest for kernels that exchange by themselves
+// header (IPC_HDR granules: what the peers check at connect) | general region: 3/4 of the window, 2 parities x world slots | the rest for
+// kernels that exchange by themselves
 static void ipc_layout(IpcComm& m)
 {
     const size_t fast = m.granules / 4;
-    const size_t gen = m.granules - fast;
+    const size_t gen = m.granules - fast - IPC_HDR;
     m.cap = gen / (2 * (size_t)m.world * 2);
     m.view.rank = m.rank;
     m.view.world = m.world;
-    m.view.fast_off = gen;
+    m.view.fast_off = m.granules - fast;
     m.view.fast_granules = fast;
     m.view.err = m.err;
     int khz = 0;
@@ -301,7 +318,11 @@ std::shared_ptr<IpcComm> ipc_comm_create(int device, int rank, int world, size_t
         MS_CHECK(hipIpcGetMemHandle(&h, m->mine));
     }
     MS_CHECK(hipMemset(m->mine, 0, m->granules * 8));
-    MS_CHECK(hipDeviceSynchronize());  // zeroed before anybody can learn the handle
+    // every rank derives the slot offsets from ITS window size and world: the header lets the peers refuse a mismatch at connect instead of
+    // misdelivering or timing out later
+    const unsigned long long hdr[4] = {IPC_MAGIC, (unsigned long long)m->granules, (unsigned long long)world, (unsigned long long)rank};
+    MS_CHECK(hipMemcpy(m->mine, hdr, sizeof(hdr), hipMemcpyHostToDevice));
+    MS_CHECK(hipDeviceSynchronize());  // zeroed and labelled before anybody can learn the handle
     MS_CHECK(hipHostMalloc((void**)&m->err, 64, hipHostMallocCoherent | hipHostMallocMapped));
     *m->err = 0;
     std::memcpy(handle_out, &h, 64);
@@ -324,6 +345,12 @@ void ipc_comm_connect(IpcComm& m, const char* handles)
         MS_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
         m.opened[(size_t)r] = p;
         m.view.win[r] = (unsigned long long*)p;
+        unsigned long long hdr[4] = {0, 0, 0, 0};
+        MS_CHECK(hipMemcpy(hdr, p, sizeof(hdr), hipMemcpyDeviceToHost));
+        if (hdr[0] != IPC_MAGIC || hdr[1] != (unsigned long long)m.granules || hdr[2] != (unsigned long long)m.world || hdr[3] != (unsigned long long)r)
+            throw Error("IPC communicator: rank " + std::to_string(r) + "'s window does not match this rank's layout (window of " + std::to_string(hdr[1] * 8) + " bytes, world " +
+                        std::to_string(hdr[2]) + ", rank " + std::to_string(hdr[3]) + "; here " + std::to_string(m.granules * 8) + " bytes, world " + std::to_string(m.world) +
+                        "): every rank must create its communicator with the same window size and world, handles in rank order");
     }
     m.connected = true;
 }

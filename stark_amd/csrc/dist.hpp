@@ -51,6 +51,10 @@ struct Collective
     virtual void allgather_f64(const double* send, double* recv, size_t n, hipStream_t stream) = 0;
     // != nullptr: every context of the group must run on this stream (LocalCollective)
     virtual hipStream_t shared_stream() { return nullptr; }
+    // 1 = in-process group, 2 = RCCL, 3 = IPC windows; and the number of ranks the transport itself reports (RCCL: ncclCommCount of the
+    // communicator; the others: the world they were created with) — what mistark_dist_info hands to the launcher's bench line
+    virtual int transport_id() const = 0;
+    virtual int transport_ranks() const = 0;
 };
 
 // contiguous ranges: [n*rank/world, n*(rank+1)/world)

@@ -1768,8 +1768,11 @@ void prepare(Context& c)
                     if (have_xyz) {
                         const double* X = c.sh.coords.data();
                         double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+                        // (a row has a position only if all three coordinates are finite: NaN marks rows without one, and an inf from the caller
+                        // would poison the bounding box and make the cell conversion below undefined)
+                        auto positioned = [&](int64_t r) { return std::isfinite(X[3 * r]) && std::isfinite(X[3 * r + 1]) && std::isfinite(X[3 * r + 2]); };
                         for (int64_t r = 0; r < c.nbr; r++)
-                            if (X[3 * r] == X[3 * r])
+                            if (positioned(r))
                                 for (int d = 0; d < 3; d++) {
                                     lo[d] = std::min(lo[d], X[3 * r + d]);
                                     hi[d] = std::max(hi[d], X[3 * r + d]);
@@ -1790,9 +1793,9 @@ void prepare(Context& c)
                         std::vector<std::pair<uint64_t, int32_t>> order((size_t)c.nbr);
                         for (int64_t r = 0; r < c.nbr; r++) {
                             uint64_t code = ~0ull;  // rows without a position: behind everything, in their own order
-                            if (X[3 * r] == X[3 * r]) {
+                            if (positioned(r)) {
                                 code = 0;
-                                for (int d = 0; d < 3; d++) code |= spread((uint64_t)((X[3 * r + d] - lo[d]) * inv)) << d;
+                                for (int d = 0; d < 3; d++) code |= spread((uint64_t)std::min(1023.0, std::max(0.0, (X[3 * r + d] - lo[d]) * inv))) << d;
                             }
                             order[(size_t)r] = {code, (int32_t)r};
                         }
@@ -5196,6 +5199,7 @@ static bool pcg_sharded_fused(Context& c, const double* rhs_global, double abs_t
     // the next solve's tags start behind the last one any rank can have used in this one (a rank launches at most two batches beyond the
     // iteration that ended the solve; computed from the iteration count, which is the same number on every rank)
     c.fused_tag = F.base + 2u * (uint32_t)((h.done ? h.n_iter : max_iter) + 2 * BATCH + 4);
+    if (c.fused_tag > 0xf0000000u) throw Error("sharded PCG: the window tags are about to wrap to the windows' zero-filled state after ~2^32 exchanges; create a new communicator");
     shard_gather_global(c, F.x, c.du.p);  // (also the barrier between this solve's last window readers and the next solve's first push)
     MS_CHECK(hipStreamSynchronize(c.stream));
     c.coll->check();

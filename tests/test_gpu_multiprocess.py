@@ -82,6 +82,41 @@ def test_bench_launch_path_with_n_processes_takes_the_single_rank_decisions(sing
     assert out["roofline"]["achieved"] > 0
 
 
+@pytest.mark.parametrize("n", [2, 4])
+def test_plain_bench_command_launches_its_own_ranks(single, n):
+    """`python bench.py --gpus N` with NO launcher around it (what the round-end driver runs): bench.py starts the N ranks itself and rank 0
+    prints the one line; the line says how many ranks really ran, on which devices, over which transport."""
+    env = _env()
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + ARGS, cwd=ROOT, env=env, capture_output=True, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == n and "bench.py itself" in out["config"]["launched_by"]
+    seen = out["config"]["ranks_seen"]
+    assert [s["rank"] for s in seen] == list(range(n)) and len({s["pid"] for s in seen}) == n
+    assert all(s["engine_world"] == n and s["engine_rank"] == s["rank"] and s["transport"] == "ipc" and s["transport_ranks"] == n for s in seen)
+    assert out["config"]["distinct_devices"] == 1 and out["config"]["ranks_on_one_device"]   # (this box has one GPU; the line says so)
+    assert sum(s["rows_owned"] for s in seen) == 13 ** 3 + 12 ** 3 + 2   # every block row has exactly one owner (nodes + hexahedron centres + the box's v, w)
+    assert out["newton_iterations"] == single["newton_iterations"] == 8
+    assert out["linear_solves"] == single["linear_solves"]
+    assert abs(out["cg_iterations"] - single["cg_iterations"]) <= single["linear_solves"]
+
+
+def test_plain_bench_command_refuses_more_ranks_than_gpus():
+    """without MISTARK_BENCH_DEVICE a box with fewer GPUs than --gpus is an error, not a one-rank run labelled N"""
+    env = _env()
+    env.pop("MISTARK_BENCH_DEVICE")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    import torch
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + ARGS, cwd=ROOT, env=env, capture_output=True, timeout=300)
+    assert r.returncode != 0 and b"GPU(s) visible" in r.stderr and not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+
+
 # ---- the cases of tests/test_gpu_sharded.py between real processes: the fused PCG iteration (kernels exchanging through the windows) -------
 @pytest.mark.parametrize("n", [2, 3, 8])
 @pytest.mark.parametrize("name", ["tetbeam_full_4x1x1", "tetbeam_eo_4x1x1_big", "cloth_shells_6", "contactmix_t1", "rbchain"])
