@@ -91,6 +91,11 @@ int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, i
 int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings,
                              const int32_t* ops, const double* constants, int32_t n_ops, int32_t n_inputs, const int32_t* cond_ops, const double* cond_constants,
                              int32_t n_cond_ops);
+/* Summation loop of a custom potential (MappedWorkspace::add_for_each, symx/src/compile/MappedWorkspace.h:123-130; used by SymX's fem
+ * integrators for quadrature rules): inputs [first_input, first_input + stride) — covered by a binding like any other input — take the
+ * n_iterations rows of `data` (copied) one after the other, and the element's energy, gradient and Hessian are the sums over the rows in
+ * that order (CompiledInLoop_run.h:375-400). One summation per potential, as in the reference (MappedWorkspace.h:525-530). */
+int mistark_potential_custom_set_summation(mistark_ctx* ctx, int potential, int32_t first_input, int32_t stride, int32_t n_iterations, const double* data);
 /* Marks a potential whose connectivity changes inside the Newton loop (the reference's contact tables are refilled in
  * before_energy_evaluation, EnergyFrictionalContact.cpp:117-119). Its Hessian blocks go to a second, small block-CSR part
  * (A = A_static + A_dynamic) so that a connectivity update only re-patterns that part, not the whole matrix. */

@@ -90,6 +90,7 @@ struct Scene
     std::vector<ContactMeshRecord> contact_meshes;
     std::vector<std::array<double, 3>> friction_pairs;  // (mesh a, mesh b, mu)
     int n_rb_collision_vertices = 0;
+    std::shared_ptr<void> keep;         // data a scene's user-defined potentials are bound to
     std::function<void()> before_step;  // the scene's script (Simulation::run(duration, callback) calls it before every time step)
     void step() { if (before_step) before_step(); sim->run_one_time_step(); }
     void record_deformable(const stark::PointSetHandler& ps, const std::vector<std::array<int, 3>>& tris, const std::vector<int>& map, double thickness)
@@ -776,8 +777,73 @@ static Scene scene_attachdist(const Args& a)
     return sc;
 }
 
+// User-defined potentials through GlobalPotential::add_potential, as README.md:109-126 / examples/main.cpp:666-692 show it: a clamped
+// Soft_Rubber block whose vertices are attracted by a magnet ("magnetic": EnergyMagneticAttraction, verbatim from the README) or by several
+// weighted poles through a summation loop ("foreach": MappedWorkspace::add_for_each, MappedWorkspace.h:123-130). Names the engine has no
+// kernel for: through the shim they run SymX's op sequence on the device interpreter (tests/shim/shim_check.cpp builds the same scenes).
+struct UserPotentialData
+{
+    double magnet_force = 100.0;
+    Eigen::Vector3d magnet_center = { 0.3, 0.2, 1.6 };
+    symx::LabelledConnectivity<1> vertices{ { "point" } };
+    std::vector<std::array<double, 4>> poles = { { 0.3, 0.2, 1.6, 0.6 }, { -0.4, 0.1, 1.7, 0.4 }, { 0.0, -0.5, 1.5, 0.5 } };
+};
+static Scene scene_userpot(const Args& a, const std::string& kind)
+{
+    Scene sc;
+    stark::Settings settings = base_settings(a, kind);
+    settings.simulation.init_frictional_contact = false;
+    sc.sim = std::make_unique<stark::Simulation>(settings);
+    auto& sim = *sc.sim;
+    const int n = a.i("n", 3);
+    auto [V, T] = stark::generate_tet_grid({ 0.0, 0.0, 0.6 }, { 1.0, 1.0, 1.0 }, { n, n, n });
+    auto block = sim.presets->deformables->add_volume("block", V, T, stark::Volume::Params::Soft_Rubber());
+    sim.deformables->prescribed_positions->add_inside_aabb(block.point_set, { 0.0, 0.0, 0.1 }, { 2.0, 2.0, 2e-3 }, stark::EnergyPrescribedPositions::Params().set_stiffness(1e7));
+    auto data = std::make_shared<UserPotentialData>();
+    data->magnet_force = a.d("k", 20.0);
+    sc.keep = data;
+    for (int v = 0; v < (int)block.point_set.size(); v++) data->vertices.push_back({ block.point_set.get_global_index(v) });
+    stark::core::Stark* stark_core = &sim.get_stark();
+    stark::PointDynamics* dyn = sim.deformables->point_sets.get();
+    UserPotentialData* d = data.get();
+    if (kind == "magnetic") {
+        stark_core->global_potential->add_potential("EnergyMagneticAttraction", d->vertices,
+            [stark_core, dyn, d](symx::MappedWorkspace<double>& mws, symx::Element& elem)
+            {
+                symx::Vector v1 = mws.make_vector(dyn->v1.data, elem["point"]);
+                symx::Vector x0 = mws.make_vector(dyn->x0.data, elem["point"]);
+                symx::Scalar dt = mws.make_scalar(stark_core->dt);
+                symx::Scalar k = mws.make_scalar(d->magnet_force);
+                symx::Vector m = mws.make_vector(d->magnet_center);
+                symx::Vector x1 = stark::time_integration(x0, v1, dt);
+                symx::Vector r = x1 - m;
+                symx::Scalar dist = r.norm();
+                return -k / dist;
+            });
+    } else {
+        stark_core->global_potential->add_potential("EnergyMultipoleAttraction", d->vertices,
+            [stark_core, dyn, d](symx::MappedWorkspace<double>& mws, symx::Element& elem)
+            {
+                symx::Vector v1 = mws.make_vector(dyn->v1.data, elem["point"]);
+                symx::Vector x0 = mws.make_vector(dyn->x0.data, elem["point"]);
+                symx::Scalar dt = mws.make_scalar(stark_core->dt);
+                symx::Scalar k = mws.make_scalar(d->magnet_force);
+                symx::Vector x1 = stark::time_integration(x0, v1, dt);
+                return mws.add_for_each(d->poles, [&](symx::Vector& pole) {
+                    symx::Vector r = x1 - symx::Vector({ pole[0], pole[1], pole[2] });
+                    return -k * pole[3] / r.norm();
+                });
+            });
+    }
+    std::ostringstream js;
+    js << "{\"kind\":\"" << kind << "\",\"n\":" << n << "}";
+    sc.json = js.str();
+    return sc;
+}
+
 static Scene make_scene(const std::string& name, const Args& a)
 {
+    if (name == "magnetic" || name == "foreach") return scene_userpot(a, name);
     if (name == "hangingnet") return scene_hangingnet(a);
     if (name == "attachzoo") return scene_attachzoo(a);
     if (name == "attachdist") return scene_attachdist(a);

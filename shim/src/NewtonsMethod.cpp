@@ -160,6 +160,12 @@ namespace symx
 			return h;
 		}
 		std::vector<Pot> pots;
+		struct SumSlot
+		{
+			int id = -1;
+			std::vector<double> row0;
+		};
+		std::map<size_t, SumSlot> sum_slots;  // potential index -> the engine array standing for its summation symbols
 		std::vector<std::pair<const double*, int64_t>> dof_sets;
 
 		void check(int rc, const char* what) const
@@ -217,9 +223,27 @@ namespace symx
 			for (size_t pi = 0; pi < potentials.size(); pi++) {
 				const Potential& pot = *potentials[pi];
 				auto mws = pot.get_mws();
-				if (mws->has_summation()) throw std::runtime_error("mistark shim: potential '" + pot.get_name() + "' uses a summation loop (fem integrators): not supported by the engine");
+				// A summation loop (MappedWorkspace::add_for_each, MappedWorkspace.h:123-130: SymX's fem integrators): its symbols sit among the
+				// workspace's symbols where the vector was made; they get a binding of their own (a shim-owned slot holding the first row) and
+				// the engine's interpreter runs the rows (mistark_potential_custom_set_summation). The data is fixed at definition time in the
+				// reference too (MappedWorkspace.h:549-550 copies it).
+				const bool has_sum = mws->has_summation();
+				int sum_first_input = -1, n_inputs_so_far = 0;
 				std::vector<mistark_binding> bs;
+				auto bind_summation = [&]() {
+					auto& slot = sum_slots[pi];
+					if (slot.id < 0) {
+						slot.row0.assign(mws->summation.data.begin(), mws->summation.data.begin() + mws->summation.stride);
+						slot.id = mistark_array(ctx, slot.row0.data(), 1, mws->summation.stride);
+						check(slot.id, "mistark_array (summation slot)");
+					}
+					sum_first_input = n_inputs_so_far;
+					bs.push_back(mistark_binding{slot.id, mws->summation.stride, -1});
+					n_inputs_so_far += mws->summation.stride;
+				};
 				for (const auto& m : mws->maps) {
+					if (has_sum && sum_first_input < 0 && m.first_symbol_idx > mws->summation.first_symbol_idx) bind_summation();
+					n_inputs_so_far += m.stride;
 					const auto key = std::make_pair(m.id(), (int)m.stride);
 					Arr& a = arrays[key];
 					const double* host = m.data();
@@ -241,6 +265,7 @@ namespace symx
 					a.is_dof = dof_set >= 0;
 					bs.push_back(mistark_binding{a.id, m.stride, m.connectivity_index});
 				}
+				if (has_sum && sum_first_input < 0) bind_summation();
 				const int32_t n_elem = mws->conn.n_elements();
 				const int32_t* conn = n_elem > 0 ? mws->conn.data() : nullptr;
 				const std::string& name = pot.get_name();
@@ -248,6 +273,7 @@ namespace symx
 					Pot P;
 					bool known = false;
 					for (int k = 0; k < mistark_n_supported_potentials() && !known; k++) known = name == mistark_supported_potential(k);
+					if (known && has_sum) throw std::runtime_error("mistark shim: potential '" + name + "' carries a summation loop, which the engine's kernel of that name does not expect");
 					if (known) {
 						P.id = mistark_potential(ctx, name.c_str(), conn, n_elem, mws->conn.stride, bs.data(), (int)bs.size());
 					} else {
@@ -269,6 +295,9 @@ namespace symx
 						                                cops.empty() ? nullptr : cops.data(), ccst.empty() ? nullptr : ccst.data(), (int)ccst.size());
 					}
 					check(P.id, ("potential '" + name + "'").c_str());
+					if (has_sum)
+						check(mistark_potential_custom_set_summation(ctx, P.id, sum_first_input, mws->summation.stride, mws->summation.n_iterations, mws->summation.data.data()),
+						      ("summation of potential '" + name + "'").c_str());
 					// tables refilled inside the Newton loop (EnergyFrictionalContact.cpp:117-119) go to the small dynamic matrix part
 					if (name.rfind("contact_", 0) == 0 || name.rfind("friction_", 0) == 0) check(mistark_potential_set_dynamic(ctx, P.id, 1), "mistark_potential_set_dynamic");
 					P.conn = conn;

@@ -419,6 +419,17 @@ int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* 
     _ret = register_custom_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings, ops, constants, n_ops, n_inputs, cond_ops, cond_constants, n_cond_ops);
     API_END(_ret)
 }
+int mistark_potential_custom_set_summation(mistark_ctx* ctx, int potential, int32_t first_input, int32_t stride, int32_t n_iterations, const double* data)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
+    Potential& P = c.pots[(size_t)potential];
+    if (!P.prog) throw Error("mistark_potential_custom_set_summation: '" + P.name + "' is not a custom potential");
+    custom_program_set_summation(*P.prog, P.name, first_input, stride, n_iterations, data);
+    c.touch();
+    API_END(0)
+}
 int mistark_potential_table(mistark_ctx* ctx, int potential, int32_t* conn, int64_t* n_elem, int32_t* conn_stride)
 {
     API_BEGIN

@@ -28,7 +28,12 @@ struct CustomProgram
     int n_in = 0, n_regs = 0, n_cregs = 0;
     std::vector<int32_t> strides;
     DevBuf<int32_t> d_ops, d_cops, d_strides, d_in_dof;
-    DevBuf<double> d_consts, d_cconsts;
+    DevBuf<double> d_consts, d_cconsts, d_sum;
+    // summation loop (MappedWorkspace::add_for_each, symx/src/compile/MappedWorkspace.h:123-130,519-553): inputs [sum_first, sum_first + sum_stride)
+    // take the rows of sum_data one after the other and the element's energy / gradient / Hessian is the SUM over the rows
+    // (CompiledInLoop_run.h:375-400), projected once like any other element
+    int sum_first = -1, sum_stride = 0, sum_n = 0;
+    std::vector<double> sum_data;
     bool uploaded = false;
 };
 
@@ -44,6 +49,8 @@ struct ProgDev
     const int32_t* strides;
     const int32_t* in_dof;  // per gathered input: local DoF component (3 * block + c) or -1
     int n_bind, n_in, NB;
+    int sum_first, sum_stride, sum_n;  // summation loop: sum_n == 0 = none
+    const double* sum_data;
 };
 
 __device__ __forceinline__ HDual powi(const HDual& x, int n)
@@ -184,7 +191,17 @@ __global__ __launch_bounds__(256) void k_eval_custom(PotArgs a, ProgDev p, doubl
     gather_custom(a, p, e, in);
     bool on = true;
     if (p.n_cops > 0) on = run_program(p.cops, p.cconsts, p.n_cops, in, p.in_dof, p.n_in, -1, -1).v > 0.0;  // SecondOrderCompiledPotential.cpp:185-197
-    const HDual r = on ? run_program(p.ops, p.consts, p.n_ops, in, p.in_dof, p.n_in, i, j) : HDual(0.0);
+    HDual r(0.0);
+    if (on) {
+        if (p.sum_n == 0) {
+            r = run_program(p.ops, p.consts, p.n_ops, in, p.in_dof, p.n_in, i, j);
+        } else {
+            for (int it = 0; it < p.sum_n; it++) {  // the reference accumulates the iterations in this order (CompiledInLoop_run.h:376)
+                for (int c = 0; c < p.sum_stride; c++) in[p.sum_first + c] = p.sum_data[(size_t)it * p.sum_stride + c];
+                r = r + run_program(p.ops, p.consts, p.n_ops, in, p.in_dof, p.n_in, i, j);
+            }
+        }
+    }
     if (MODE == 2) {
         const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;
         elemH[((size_t)(ba * NB + bb) * a.n_pool + pe) * 9 + ii * 3 + jj] = r.ab;
@@ -318,6 +335,17 @@ std::shared_ptr<CustomProgram> make_custom_program(const std::string& name, cons
     return P;
 }
 
+void custom_program_set_summation(CustomProgram& G, const std::string& name, int first_input, int stride, int n_iterations, const double* data)
+{
+    if (stride <= 0 || n_iterations <= 0 || !data) throw Error("custom potential '" + name + "': summation needs stride > 0, iterations > 0 and data");
+    if (first_input < 0 || first_input + stride > G.n_in) throw Error("custom potential '" + name + "': summation inputs outside the potential's " + std::to_string(G.n_in) + " inputs");
+    G.sum_first = first_input;
+    G.sum_stride = stride;
+    G.sum_n = n_iterations;
+    G.sum_data.assign(data, data + (size_t)stride * n_iterations);
+    G.uploaded = false;
+}
+
 // Evaluation of a custom potential (called by kernels.hip: launch_eval_kind for P.kind == KIND_CUSTOM)
 void launch_eval_custom(Context& c, Potential& P, int mode)
 {
@@ -337,6 +365,7 @@ void launch_eval_custom(Context& c, Potential& P, int mode)
         up_i(G.d_strides, G.strides);
         up_d(G.d_consts, G.consts);
         up_d(G.d_cconsts, G.cconsts);
+        up_d(G.d_sum, G.sum_data);
         MS_CHECK(hipStreamSynchronize(c.stream));
         G.uploaded = true;
     }
@@ -358,7 +387,8 @@ void launch_eval_custom(Context& c, Potential& P, int mode)
     G.d_in_dof.ensure(std::max<size_t>(in_dof.size(), 1));
     MS_CHECK(hipMemcpyAsync(G.d_in_dof.p, in_dof.data(), in_dof.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));  // (in_dof is a temporary)
-    const ProgDev pd{G.d_ops.p, G.d_consts.p, (int)G.consts.size(), G.d_cops.p, G.d_cconsts.p, (int)G.cconsts.size(), G.d_strides.p, G.d_in_dof.p, (int)G.strides.size(), G.n_in, P.NB};
+    const ProgDev pd{G.d_ops.p, G.d_consts.p, (int)G.consts.size(), G.d_cops.p, G.d_cconsts.p, (int)G.cconsts.size(), G.d_strides.p, G.d_in_dof.p, (int)G.strides.size(), G.n_in, P.NB,
+                     G.sum_first, G.sum_stride, G.sum_n, G.d_sum.p};
     double* E = c.elemE.p + P.e_off;
     const int n = 3 * P.NB;
     auto grid = [&](long long threads) { return dim3((unsigned)((threads + 255) / 256)); };

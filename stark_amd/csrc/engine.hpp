@@ -569,6 +569,7 @@ bool direct_llt(Context& c, const double* rhs_dev, double* x_dev);  // direct.hi
 // custom.hip
 std::shared_ptr<CustomProgram> make_custom_program(const std::string& name, const int32_t* strides, int n_bindings, const int32_t* ops, const double* consts, int n_ops, int n_inputs,
                                                    const int32_t* cond_ops, const double* cond_consts, int n_cond_ops);
+void custom_program_set_summation(CustomProgram& G, const std::string& name, int first_input, int stride, int n_iterations, const double* data);
 void launch_eval_custom(Context& c, Potential& P, int mode);
 double reduce_max_abs(Context& c, const double* v, int64_t n);
 double reduce_dot(Context& c, const double* a, const double* b, int64_t n);

@@ -85,6 +85,13 @@ class Engine:
         self.potential_ids[name] = pid
         return pid
 
+    def potential_custom_set_summation(self, pid: int, first_input: int, data: np.ndarray):
+        """Summation loop of a custom potential (MappedWorkspace::add_for_each): inputs [first_input, first_input + data.shape[1]) take the rows
+        of `data` one after the other; energy, gradient and Hessian are summed over the rows."""
+        d = np.ascontiguousarray(data, dtype=np.float64).reshape(len(data), -1)
+        self.L.mistark_potential_custom_set_summation.argtypes = [C.c_void_p, C.c_int, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        self._ck(self.L.mistark_potential_custom_set_summation(self.h, pid, int(first_input), d.shape[1], d.shape[0], d.ctypes.data))
+
     def potential_id(self, name: str) -> int:
         pid = self.L.mistark_find_potential(self.h, name.encode())
         if pid < 0:

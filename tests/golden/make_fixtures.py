@@ -97,6 +97,10 @@ FIXTURES = {
     "traj_clothbox_8": ("traj", "clothbox", "n=8 gap=0.004 steps=4"),
     "traj_blockbox_3": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=1"),
     # block registered first, no friction (with friction this order makes the reference's result depend on an unordered_map walk)
+    # user-defined potentials (README.md:109-126: EnergyMagneticAttraction; the same with a summation loop, MappedWorkspace::add_for_each):
+    # names the engine has no kernel for — through the shim they run SymX's op sequence on the device interpreter
+    "traj_user_magnetic_3": ("traj", "magnetic", "n=3 k=20 steps=5 slim=1"),
+    "traj_user_foreach_3": ("traj", "foreach", "n=3 k=20 steps=5 slim=1"),
     "traj_blockbox_3_nofriction": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=0 mu=0"),
 }
 

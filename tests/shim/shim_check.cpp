@@ -92,6 +92,8 @@ int main(int argc, char** argv)
         ct->set_friction(floor.contact, soft.contact, mu);
         ct->set_friction(soft.contact, cloth.contact, mu);
         for (int i = 0; i < nrb; i++) ct->set_friction(link_contacts[i], cloth.contact, mu);
+    } else if (scene == "magnetic" || scene == "inplace" || scene == "inplace_sparse" || scene == "foreach") {
+        // handled below (user-defined potentials need state that outlives this block)
     } else if (scene == "tetbeam") {
         auto [sV, sT] = stark::generate_tet_grid({ 0.0, 0.0, 0.0 }, { 4.0, 1.0, 1.0 }, { 4, 1, 1 });
         auto beam = sim.presets->deformables->add_volume("beam", sV, sT, stark::Volume::Params::Soft_Rubber());
@@ -102,6 +104,80 @@ int main(int argc, char** argv)
     } else {
         std::cerr << "unknown scene " << scene << std::endl;
         return 2;
+    }
+    // ---- user-defined potentials through GlobalPotential::add_potential, exactly as README.md:109-126 / examples/main.cpp:666-692 do it: a name
+    // the engine has no kernel for, so the shim hands SymX's op sequence of the expression to the device interpreter
+    double magnet_force = 20.0;
+    if (const char* env = std::getenv("SHIM_MAGNET_K")) magnet_force = std::atof(env);
+    Eigen::Vector3d magnet_center = { 0.3, 0.2, 1.6 };
+    symx::LabelledConnectivity<1> user_vertices{ { "point" } };
+    std::vector<Eigen::Vector3d> targets;   // "inplace": one target per vertex, rewritten by a Newton callback
+    double pull_stiffness = 2e3;
+    std::vector<std::array<double, 4>> poles = { { 0.3, 0.2, 1.6, 0.6 }, { -0.4, 0.1, 1.7, 0.4 }, { 0.0, -0.5, 1.5, 0.5 } };
+    long n_evaluations = 0;
+    if (scene == "magnetic" || scene == "inplace" || scene == "inplace_sparse" || scene == "foreach") {
+        int n = scene == "magnetic" || scene == "foreach" ? 3 : 18;
+        if (const char* env = std::getenv("SHIM_GRID")) n = std::atoi(env);
+        auto [sV, sT] = stark::generate_tet_grid({ 0.0, 0.0, 0.6 }, { 1.0, 1.0, 1.0 }, { n, n, n });
+        auto block = sim.presets->deformables->add_volume("block", sV, sT, stark::Volume::Params::Soft_Rubber());
+        sim.deformables->prescribed_positions->add_inside_aabb(block.point_set, { 0.0, 0.0, 0.1 }, { 2.0, 2.0, 2e-3 }, stark::EnergyPrescribedPositions::Params().set_stiffness(1e7));
+        for (int v = 0; v < (int)block.point_set.size(); v++) user_vertices.push_back({ block.point_set.get_global_index(v) });
+        stark::core::Stark& stark_core = sim.get_stark();
+        stark::PointDynamics* dyn = sim.deformables->point_sets.get();
+        if (scene == "magnetic") {
+            stark_core.global_potential->add_potential("EnergyMagneticAttraction", user_vertices,
+                [&, dyn](symx::MappedWorkspace<double>& mws, symx::Element& elem)
+                {
+                    symx::Vector v1 = mws.make_vector(dyn->v1.data, elem["point"]);
+                    symx::Vector x0 = mws.make_vector(dyn->x0.data, elem["point"]);
+                    symx::Scalar dt = mws.make_scalar(stark_core.dt);
+                    symx::Scalar k = mws.make_scalar(magnet_force);
+                    symx::Vector m = mws.make_vector(magnet_center);
+                    symx::Vector x1 = stark::time_integration(x0, v1, dt);
+                    symx::Vector r = x1 - m;
+                    symx::Scalar d = r.norm();
+                    return -k / d;
+                });
+        } else if (scene == "foreach") {
+            // a summation loop (MappedWorkspace::add_for_each, MappedWorkspace.h:123-130; what SymX's fem integrators use for quadrature rules):
+            // attraction to several poles {x, y, z, weight}, summed per vertex BEFORE the element's projection to PD
+            stark_core.global_potential->add_potential("EnergyMultipoleAttraction", user_vertices,
+                [&, dyn](symx::MappedWorkspace<double>& mws, symx::Element& elem)
+                {
+                    symx::Vector v1 = mws.make_vector(dyn->v1.data, elem["point"]);
+                    symx::Vector x0 = mws.make_vector(dyn->x0.data, elem["point"]);
+                    symx::Scalar dt = mws.make_scalar(stark_core.dt);
+                    symx::Scalar k = mws.make_scalar(magnet_force);
+                    symx::Vector x1 = stark::time_integration(x0, v1, dt);
+                    return mws.add_for_each(poles, [&](symx::Vector& pole) {
+                        symx::Vector r = x1 - symx::Vector({ pole[0], pole[1], pole[2] });
+                        return -k * pole[3] / r.norm();
+                    });
+                });
+        } else {
+            for (int v = 0; v < (int)block.point_set.size(); v++) targets.push_back(dyn->x0.data[(size_t)block.point_set.get_global_index(v)] + Eigen::Vector3d(0.0, 0.0, 0.02));
+            stark_core.global_potential->add_potential("EnergyPullToTargets", user_vertices,
+                [&, dyn](symx::MappedWorkspace<double>& mws, symx::Element& elem)
+                {
+                    symx::Vector v1 = mws.make_vector(dyn->v1.data, elem["point"]);
+                    symx::Vector x0 = mws.make_vector(dyn->x0.data, elem["point"]);
+                    symx::Vector t = mws.make_vector(targets, elem["point"]);
+                    symx::Scalar dt = mws.make_scalar(stark_core.dt);
+                    symx::Scalar k = mws.make_scalar(pull_stiffness);
+                    symx::Vector x1 = stark::time_integration(x0, v1, dt);
+                    return 0.5 * k * (x1 - t).squared_norm();
+                });
+            // a Newton callback that REWRITES the large target array in place (same address, same size) in the middle of a solve: at its 4th
+            // energy evaluation every target moves ("inplace"), or only three of them do ("inplace_sparse": what a sampled check cannot see)
+            stark_core.callbacks->newton->add_before_energy_evaluation([&, sparse = scene == "inplace_sparse"]() {
+                if (++n_evaluations != 4) return;
+                if (sparse) {
+                    for (size_t v : { (size_t)100, targets.size() / 2 + 7, targets.size() - 50 })   /* none of them inside a sampled window */ targets[v] += Eigen::Vector3d(0.3, 0.0, 0.0);
+                } else {
+                    for (auto& t : targets) t += Eigen::Vector3d(0.01, -0.005, 0.03);
+                }
+            });
+        }
     }
     // the first step registers everything and builds the sparsity pattern: timed apart from the rest
     const char* dry_env = std::getenv("MISTARK_SHIM_DRY");

@@ -151,3 +151,22 @@ def test_the_collision_detection_stand_in_changes_nothing_that_is_registered(sce
         assert strip(A[name]["bindings"]) == strip(B[name]["bindings"]), name
         if not name.startswith(("contact_", "friction_")):
             assert A[name]["n_elem"] == B[name]["n_elem"] and A[name]["bindings"] == B[name]["bindings"], name
+
+
+@pytest.mark.parametrize("scene,name,n_bindings", [("magnetic", "EnergyMagneticAttraction", 5), ("foreach", "EnergyMultipoleAttraction", 5)])
+def test_user_defined_potential_takes_the_sequence_branch_of_the_shim(scene, name, n_bindings, tmp_path):
+    """A name the engine has no kernel for (README.md:109-126 of the reference): the shim flattens the expression into SymX's op sequence and
+    registers it with mistark_potential_custom; `foreach` carries a summation loop (MappedWorkspace::add_for_each), whose symbols get a binding
+    of their own (a global slot of 4 doubles: the pole) at the place the summation vector was made."""
+    out = str(tmp_path / "shim.json")
+    env = dict(os.environ, MISTARK_SHIM_DRY="1", MISTARK_SHIM_DESCRIBE=out)
+    r = subprocess.run([SHIM_CHECK, scene], env=env, capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.load(open(out))
+    p = [q for q in d["potentials"] if q["name"] == name]
+    assert len(p) == 1 and p[0]["n_elem"] == 4 ** 3 + 3 ** 3 and p[0]["conn_stride"] == 1
+    bs = p[0]["bindings"]
+    assert len(bs) == n_bindings
+    assert bs[0][0].startswith("dof:") and bs[0][1:3] == [3, 0]           # v1 of the point
+    assert [b[1] for b in bs] == ([3, 3, 1, 1, 3] if scene == "magnetic" else [3, 3, 1, 1, 4])
+    assert [b[2] for b in bs][2:] == [-1, -1, -1]                          # dt, k and the magnet centre / the pole slot are global
