@@ -202,13 +202,46 @@ def pinned_placement_run(S, capi, nx, ny, nz, device, steps, warmup, with_cpu):
     return out
 
 
-def hbm_resident_pass(S, capi, device):
-    """SpMV-only pass on the same scene at HBM_GRID (one Newton step to have an assembled matrix, then 50 back-to-back launches between HIP
-    events): the roofline figure with the matrix streaming from HBM instead of the Infinity Cache."""
-    import ctypes as C
+def secondary_run(S, capi, device, steps, warmup, set_dist, barrier, dist, torch, one_device=False, world=1):
+    """The same scene at HBM_GRID on the ranks of this run: `steps` Newton iterations after `warmup`, timed like the headline figure (barrier
+    + synchronisation on both sides, maximum over the ranks). Returns (dict, sim) — the caller closes the scene."""
     nx, ny, nz = HBM_GRID
     sim = build_scene(S, nx, ny, nz, device, "contact")
-    run_newton_steps(sim, S, capi, 1)
+    if set_dist is not None:
+        set_dist(sim)
+    if one_device and world > 1:
+        sim.prepare()
+        capi.lib().mistark_set_option(sim.engine_handle(), b"spmv_grid_cap", max(8, (1024 // world) // 8 * 8))
+        capi.lib().mistark_set_option(sim.engine_handle(), b"no_eval_prelaunch", 1)
+    run_newton_steps(sim, S, capi, max(warmup, 1))
+    barrier()
+    t0 = time.perf_counter()
+    newton, n_ls, n_cg, t_ls = run_newton_steps(sim, S, capi, steps)
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    out = {"grid": "%d,%d,%d" % HBM_GRID, "tets": 12 * nx * ny * nz, "dofs": sim.info().ndofs, "n_gpus": world, "value": newton / el, "unit": "Newton-steps/s",
+           "ms_per_step": 1e3 * el / max(newton, 1), "steps": steps, "warmup": max(warmup, 1), "ms_per_linear_solve": 1e3 * t_ls / max(n_ls, 1), "linear_solves": n_ls,
+           "cg_iterations_per_solve": n_cg / max(n_ls, 1), "scaling": "strong"}
+    if set_dist is not None:
+        sim.close()
+        return out
+    return out, sim
+
+
+def hbm_resident_pass(S, capi, device, steps, warmup, torch):
+    """SpMV pass on the same scene at HBM_GRID (the secondary workload's Newton iterations first, then 50 back-to-back launches between HIP
+    events): the roofline figure with the matrix streaming from HBM instead of the Infinity Cache. Returns (roofline dict, secondary dict)."""
+    import ctypes as C
+    nx, ny, nz = HBM_GRID
+
+    def barrier():
+        torch.cuda.synchronize()
+
+    sec, sim = secondary_run(S, capi, device, steps, warmup, None, barrier, None, torch)
     _, _, nbytes = sim.spmv_timing(reset=-1)
     us = C.c_double()
     if capi.lib().mistark_spmv_bench(sim.engine_handle(), 50, C.byref(us)) != 0:
@@ -216,8 +249,8 @@ def hbm_resident_pass(S, capi, device):
     ndofs = sim.info().ndofs
     sim.close()
     gbs = nbytes / (us.value * 1e-6) / 1e9
-    return {"grid": "%d,%d,%d" % HBM_GRID, "tets": 12 * nx * ny * nz, "dofs": ndofs, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": us.value * 1e-3, "launches_timed": 50,
-            "achieved": gbs, "unit": "GB/s", "frac": gbs / 8000.0, "timing": "HIP events around 50 back-to-back launches (mistark_spmv_bench)"}
+    return ({"grid": "%d,%d,%d" % HBM_GRID, "tets": 12 * nx * ny * nz, "dofs": ndofs, "algorithmic_bytes_per_launch": nbytes, "avg_launch_ms": us.value * 1e-3, "launches_timed": 50,
+            "achieved": gbs, "unit": "GB/s", "frac": gbs / 8000.0, "timing": "HIP events around 50 back-to-back launches (mistark_spmv_bench)"}, sec)
 
 
 def self_launch(n):
@@ -242,7 +275,59 @@ def self_launch(n):
     env["MISTARK_BENCH_SELF_LAUNCHED"] = "1"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.run(cmd, env=env).returncode
+    # the ranks' stdout carries rank 0's JSON line — and whatever libraries print there (gloo announces its connections on stdout): only the
+    # JSON line goes to this process's stdout, the rest to stderr
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE)
+    for raw in p.stdout:
+        line = raw.decode(errors="replace")
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line)
+    sys.stdout.flush()
+    return p.wait()
+
+
+def drop_in_run(S, capi, nx, ny, nz, device, time_steps=16):
+    """The same workload through the actual drop-in (SURVEY 8b): oracle/_ref/shim_check_cd is the UNMODIFIED reference — its own stark::Simulation,
+    EnergyFrictionalContact, callbacks, time stepping — compiled against shim/include/symx and shim/include_cd and linked with libmistark.so, i.e.
+    what a STARK user gets by swapping the two headers. `value` = Newton iterations per second over time steps 2..time_steps (the first one
+    registers everything and builds the pattern); `mirror_same_window` = this repo's own scene mirror over the same time steps; `mirror_ratio` =
+    drop-in / mirror. The shim's own statistics (seconds inside the reference's callbacks, inside the shim's sync, bringing DoFs to the host) come
+    from MISTARK_SHIM_STATS=1."""
+    import re
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "shim_check_cd")
+    if not os.path.exists(exe):
+        return {"unavailable": "oracle/_ref/shim_check_cd not built (needs /root/reference in the build container: make -C oracle shim_cd)"}
+    env = dict(os.environ, SHIM_GRID="%d,%d,%d" % (nx, ny, nz), MISTARK_SHIM_STATS="1", MISTARK_DEVICE=str(device))
+    env.setdefault("SHIM_THREADS", "16")
+    r = subprocess.run([exe, "benchblock", str(time_steps)], env=env, capture_output=True, timeout=1200)
+    if r.returncode != 0:
+        return {"unavailable": "shim_check_cd failed: " + r.stderr.decode()[-300:]}
+    line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+    err = r.stderr.decode()
+    out = {"value": line["newton_steps_per_s_after_first"], "unit": "Newton-steps/s", "newton_iterations": line["newton_rest"], "time_steps": time_steps - 1,
+           "wall_s": line["rest_s"], "first_time_step_s": line["first_step_s"], "binary": "oracle/_ref/shim_check_cd benchblock (unmodified stark/src/** on shim/include/symx + shim/include_cd)"}
+    m = re.search(r"of ([0-9.e+-]+) s in solve\(\): ([0-9.e+-]+) s in the caller's callbacks, ([0-9.e+-]+) s in sync\(\) .*?, ([0-9.e+-]+) s bringing DoFs", err)
+    if m:
+        out.update(solve_s=float(m.group(1)), callbacks_s=float(m.group(2)), sync_s=float(m.group(3)), dofs_to_host_s=float(m.group(4)))
+    # the mirror over the same time steps
+    sim = build_scene(S, nx, ny, nz, device, "contact")
+    import torch
+    if not sim.run_one_step():
+        raise RuntimeError("mirror: simulation stopped")
+    torch.cuda.synchronize()
+    i0 = sim.info()
+    t0 = time.perf_counter()
+    for _ in range(time_steps - 1):
+        if not sim.run_one_step():
+            raise RuntimeError("mirror: simulation stopped")
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    i1 = sim.info()
+    sim.close()
+    n = i1.total_newton_iterations - i0.total_newton_iterations
+    out["mirror_same_window"] = {"value": n / el, "newton_iterations": n, "wall_s": el}
+    out["mirror_ratio"] = out["value"] / (n / el)
+    return out
 
 
 def main():
@@ -272,6 +357,10 @@ def main():
     from stark_amd import capi
     from stark_amd import sim as S
 
+    # N > 1 on the default workload also runs the same scene at HBM_GRID (7.99 M tets: each of 8 ranks then holds what one GPU holds at
+    # configs[3], the regime the row-sharded design is for) and reports it as config.secondary; N = 1 reports the same run beside the
+    # HBM-resident SpMV figure, so that a reader has the one-GPU number the N-GPU one divides by
+    secondary_wanted = a.scene == "contact" and (nx, ny, nz) == (44, 44, 43) and offset == (0.0, 0.0) and not a.no_extras
     dist = None
     uid = None
     comm = None
@@ -292,7 +381,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # one node: gloo must not go looking for an interface through a hostname that may not resolve
         torch.cuda.set_device(device)
-        dist.init_process_group(backend="gloo")
+        sys.stdout.flush()
+        saved_fd = os.dup(1)   # (gloo prints its connection report to the C stdout: keep this process's stdout for the one JSON line)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group(backend="gloo")
+            dist.barrier()
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
         def allgather_bytes(b):
             out = [None] * world
@@ -304,6 +401,8 @@ def main():
             err = None
             try:
                 n_rows = (nx + 1) * (ny + 1) * (nz + 1) + nx * ny * nz + 64
+                if secondary_wanted:   # the windows also carry the 8 M-tet secondary workload
+                    n_rows = max(n_rows, (HBM_GRID[0] + 1) * (HBM_GRID[1] + 1) * (HBM_GRID[2] + 1) + HBM_GRID[0] * HBM_GRID[1] * HBM_GRID[2] + 64)
                 comm = capi.IpcComm(device, rank, world, max(64 * 3 * n_rows, 32 << 20), allgather_bytes)
                 ipc_selftest_us = comm.selftest(1024, 50)[1]
             except Exception as e:  # noqa: BLE001
@@ -420,6 +519,19 @@ def main():
             spmv_b2b_ms = us.value * 1e-3
     info = sim.info()
     stage = {k: getattr(info, "total_" + k + "_time") - getattr(info0, "total_" + k + "_time") for k in ["newton", "linear_solve", "eval_pgh", "eval_p", "project", "assembly", "callback", "step"]}
+    contact_info = sim.contact_info() if a.scene == "contact" else None
+    secondary = None
+    if world > 1 and secondary_wanted:
+        if comm is None:
+            secondary = {"unavailable": "the secondary workload runs over the IPC windows only (an RCCL unique id serves one communicator)"}
+        else:
+            sim.close()
+            sim = None
+            try:
+                secondary = secondary_run(S, capi, device, a.steps, a.warmup, lambda s2: s2.set_dist_ipc(comm, rank, world), barrier, dist, torch,
+                                          one_device=os.environ.get("MISTARK_BENCH_DEVICE") is not None, world=world)
+            except Exception as e:  # noqa: BLE001
+                secondary = {"unavailable": repr(e)}
 
     if rank == 0:
         traffic, traffic_src = profile_traffic()
@@ -477,6 +589,8 @@ def main():
                 "distinct_devices": len({(r["device"], r["pci_bus_id"]) for r in ranks_seen}) if ranks_seen else None,
                 "launched_by": "bench.py itself (torch.distributed.run, one process per GPU)" if os.environ.get("MISTARK_BENCH_SELF_LAUNCHED") else ("torch.distributed.run" if world > 1 else None),
                 "projection": "Progressive",
+                # the same scene at 88 x 88 x 86 hexahedra (7.99 M tets / 4.1 M DoF) on the same ranks: Newton-steps/s of ONE problem 8 times the size
+                "secondary": secondary,
             },
             "ms_per_linear_solve": 1000.0 * t_ls / max(n_ls, 1),
             "cg_iterations_per_solve": n_cg / max(n_ls, 1),
@@ -487,7 +601,7 @@ def main():
             "sharded_cg_kernels_us": fused_kernels_us,
             "newton_iterations": newton,
             "host_timers_s": {k: round(v, 6) for k, v in stage.items()},
-            "contact": sim.contact_info() if a.scene == "contact" else None,
+            "contact": contact_info,
             "roofline": {
                 "kernel": "k_spmv_fused (3x3-block CSR in row-aligned chunks, float values, double vectors)" if world == 1 else
                           "k_spmv_halo (the same SpMV over rank 0's rows of the sharded matrix, ghost columns polled from the IPC window): bytes and duration of ONE GPU's launch",
@@ -528,9 +642,15 @@ def main():
             sim.close()
             sim = None
             try:
-                out["roofline"]["hbm_resident"] = hbm_resident_pass(S, capi, device)
+                hb, sec = hbm_resident_pass(S, capi, device, a.steps, a.warmup, torch)
+                out["roofline"]["hbm_resident"] = hb
+                out["config"]["secondary"] = sec
             except Exception as e:  # noqa: BLE001
                 out["roofline"]["hbm_resident"] = {"unavailable": repr(e)}
+            try:
+                out["drop_in"] = drop_in_run(S, capi, nx, ny, nz, device)
+            except Exception as e:  # noqa: BLE001
+                out["drop_in"] = {"unavailable": repr(e)}
             try:
                 out["pinned_placement"] = pinned_placement_run(S, capi, nx, ny, nz, device, a.steps, a.warmup, not a.no_cpu_baseline)
             except Exception as e:  # noqa: BLE001

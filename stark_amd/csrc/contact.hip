@@ -1227,7 +1227,7 @@ void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, double enl
     // (the task counter lives among the search's counters, which every caller zeroes before the search: counters[56]; a second sweep behind
     // the same fill — the speculative proximity search — resets it itself)
     int* task_count = cs.counters.p + 56;
-    if (reset_tasks) MS_CHECK(hipMemsetAsync(task_count, 0, sizeof(int), c.stream));
+    if (reset_tasks) fill_async(c.stream, task_count, 0, sizeof(int));
     const int pt_on = (int)(cs.pt_enabled && cs.n_t > 0), ee_on = (int)(cs.ee_enabled && cs.n_e > 1);
     hipLaunchKernelGGL((k_sweep<PROX, FR>), dim3((cs.bp_cap + CB / SWEEP_SUB - 1) / (CB / SWEEP_SUB)), dim3(CB), 0, c.stream, d, cs.bands, cs.s_idx, (const float*)cs.s_aabb.p, (const float*)cs.s_lo.p,
                        (const int*)cs.seg.p, pt_on, ee_on, enl2, cs.keys.p, cs.counters.p, (int)cs.key_cap, task_count, cs.sweep_tasks.p);
@@ -1298,7 +1298,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     }
     cs.spec.valid = false;  // (any search below reuses the key buffers)
     for (; !speculated;) {
-        MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
+        fill_async(c.stream, cs.counters.p, 0, 64 * sizeof(int));
         // One read-back per search: the key list is sorted over a padded length chosen from the previous search's count (padding keys sort
         // last and carry a table id no table has), the table boundaries are found with the count still on the device, and count,
         // boundaries and "same as before" flag come back together. A count beyond the padded length takes the two-step path below.
@@ -1351,7 +1351,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
                 cs.n_last = n;
                 continue;
             }
-            MS_CHECK(hipMemsetAsync(cs.counters.p + 2, 0, sizeof(int), c.stream));
+            fill_async(c.stream, cs.counters.p + 2, 0, sizeof(int));
             sorted = sort_and_bound(c, cs, n, nullptr, compare);
             lap(3);
             fetch(c, h, cs.counters.p, 64 * sizeof(int));
@@ -1408,7 +1408,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     }
     if (!friction) {
         cs.prev.ensure(std::max<size_t>((size_t)n, 1));
-        if (n > 0) MS_CHECK(hipMemcpyAsync(cs.prev.p, sorted, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToDevice, c.stream));
+        if (n > 0) copy_async(c.stream, cs.prev.p, sorted, (size_t)n * sizeof(uint64_t));
         cs.n_prev = n;
         cs.cache_valid = true;
         cs.cache_version = c.data_version;  // (after this function's own layout changes)
@@ -1445,7 +1445,7 @@ int64_t count_intersections_uncached(Context& c, double dt)
     const float enl_f = cs.brute_force ? 0.f : nextafterf((float)enl, INFINITY) + 1.1920929e-07f;
     const bool boxes_current = cs.bp_valid && !cs.brute_force && !c.no_contact_cache && cs.bp_version == c.data_version && cs.bp_dt == dt && cs.bp_enl == enl_f;
     if (!boxes_current) update_vertices(c, cs, d, dt, enl_f);
-    MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
+    fill_async(c.stream, cs.counters.p, 0, 64 * sizeof(int));
     if (!cs.brute_force) {
         if (cs.key_cap == 0) {
             cs.key_cap = initial_key_cap();
@@ -1475,7 +1475,7 @@ int64_t count_intersections_uncached(Context& c, double dt)
             if (hb[51] > cs.bp_cap) {
                 cs.bp_cap = hb[51] + hb[51] / 4;
                 cs.bp_valid = false;
-                MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
+                fill_async(c.stream, cs.counters.p, 0, 64 * sizeof(int));
                 continue;
             }
             cs.bp_valid = true;
@@ -1558,7 +1558,7 @@ int cd_search(StandaloneDetector& D, const ContactDev& d, bool proximity, double
         cs.keys_alt.ensure(cs.key_cap);
     }
     for (;;) {
-        MS_CHECK(hipMemsetAsync(cs.counters.p, 0, 64 * sizeof(int), c.stream));
+        fill_async(c.stream, cs.counters.p, 0, 64 * sizeof(int));
         sort_boxes(c, cs, d);
         if (proximity) launch_sweep<true, false>(c, cs, d, enl * enl);
         else {
@@ -1680,7 +1680,7 @@ int mistark_cd_run_proximity(mistark_cd* cd, double enlargement, int32_t counts[
     int h[64];
     const int n = cd_search(D, d, true, enlargement, h);
     if (n == 0) return 0;
-    MS_CHECK(hipMemsetAsync(cs.counters.p + 2, 0, sizeof(int), c.stream));
+    fill_async(c.stream, cs.counters.p + 2, 0, sizeof(int));
     const uint64_t* sorted = sort_and_bound(c, cs, n, nullptr, false);
     D.keys.resize((size_t)n);
     MS_CHECK(hipMemcpyAsync(D.keys.data(), sorted, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));

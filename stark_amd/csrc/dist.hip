@@ -176,6 +176,7 @@ struct IpcComm
     IpcView view;
     unsigned int* err = nullptr;  // pinned, device-visible
     uint32_t seq = 0;          // exchanges issued so far in the general region
+    uint32_t fast_tag = 0;     // tags used up in the fast region (IpcView::fast_tag)
     ~IpcComm()
     {
         (void)hipSetDevice(device);
@@ -287,6 +288,7 @@ static void ipc_layout(IpcComm& m)
     m.view.fast_off = m.granules - fast;
     m.view.fast_granules = fast;
     m.view.err = m.err;
+    m.view.fast_tag = &m.fast_tag;
     int khz = 0;
     MS_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m.device));
     double seconds = 30.0;

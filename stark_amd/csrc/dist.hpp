@@ -39,6 +39,10 @@ struct IpcView
     size_t fast_granules = 0;    // its size
     unsigned int* err = nullptr; // device-visible error word (pinned host memory): != 0 after a poll gave up
     unsigned long long timeout_ticks = 0;  // poll budget on the device's constant clock
+    // tags the fused kernels have used up in the fast region (host memory of the communicator): the windows outlive an engine context, so the
+    // NEXT context on the same communicator must continue behind the last tag a previous one wrote — a context that started again at tag 1
+    // would find its own tags in granules the previous context left there and take stale data for delivered
+    uint32_t* fast_tag = nullptr;
 };
 struct Collective
 {

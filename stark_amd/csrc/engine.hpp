@@ -528,6 +528,23 @@ void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes);
 // the range inside every copy (1.5 ms for 4 MB measured); a memcpy into pinned memory and a DMA transfer take a quarter of that. The source
 // may be reused when the call returns; the copy is ordered on c.stream like any other.
 void h2d_staged(Context& c, void* dst_dev, const void* src_host, size_t bytes);
+// fills and device-to-device copies as kernels of our own (kernels.hip: the runtime's blit path costs the host 10-25 us per call); a FillQueue
+// collects up to FILL_BATCH_MAX regions (4-byte aligned, multiples of 4 bytes) into ONE launch: add(), add(), ..., flush()
+constexpr int FILL_BATCH_MAX = 8;
+struct FillQueue
+{
+    hipStream_t stream;
+    void* ptr[FILL_BATCH_MAX];
+    size_t words[FILL_BATCH_MAX];
+    uint32_t value[FILL_BATCH_MAX];
+    int n = 0;
+    explicit FillQueue(hipStream_t s) : stream(s) {}
+    ~FillQueue() { flush(); }
+    void add(void* p, int byte_value, size_t bytes);
+    void flush();
+};
+void fill_async(hipStream_t stream, void* p, int byte_value, size_t bytes);
+void copy_async(hipStream_t stream, void* dst, const void* src, size_t bytes);
 void prepare(Context& c);
 void eval_prelaunch(Context& c, int mode, bool lazy);  // kernels.hip: see Context::EvalPre
 // shard.hip

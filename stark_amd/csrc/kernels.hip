@@ -638,7 +638,7 @@ static void dyn_grad_gather(Context& c, double* grad)
         c.dyn_inc_version = c.dyn_tables_version;
     }
     c.dyn_long.ensure(1 + 2 * (size_t)DYN_LONG_CAP);
-    MS_CHECK(hipMemsetAsync(c.dyn_long.p, 0, sizeof(uint32_t), c.stream));
+    fill_async(c.stream, c.dyn_long.p, 0, sizeof(uint32_t));
     hipLaunchKernelGGL(k_dyn_grad_gather, dim3(grid_for(n)), dim3(BLOCK), 0, c.stream, c.dyn_sorted_key, c.dyn_sorted_val, n, (const double*)c.dyn_gpool.p, grad, c.dyn_long.p, DYN_LONG_CAP);
     c.dyn_long_part.ensure(3 * ((size_t)n / 64 + 2));
     hipLaunchKernelGGL(k_dyn_grad_gather_long, dim3(256), dim3(BLOCK), 0, c.stream, c.dyn_sorted_val, (const double*)c.dyn_gpool.p, c.dyn_long_part.p, (const uint32_t*)c.dyn_long.p,
@@ -960,6 +960,98 @@ __global__ __launch_bounds__(BLOCK) void k_axpby(double* __restrict__ dst, doubl
 __global__ __launch_bounds__(BLOCK) void k_fill(double* __restrict__ dst, double v, int64_t n)
 {
     for (int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * BLOCK) dst[i] = v;
+}
+
+// Fills and device-to-device copies of the hot path as kernels of our own. hipMemsetAsync / hipMemcpyAsync(DeviceToDevice) go through the
+// runtime's blit path (__amd_rocclr_fillBufferAligned / copyBuffer): 10-25 us of HOST time per call (profiles/r03_v5_timeline.txt: 662 fills and
+// their gaps in 31 Newton iterations), which is what the launch-bound chains of a Newton iteration (contact search, contact-part pattern,
+// line search) are made of. A kernel launch costs the host 4 us; several regions share one launch.
+struct FillBatch
+{
+    uint32_t* p[FILL_BATCH_MAX];
+    uint32_t n_words[FILL_BATCH_MAX];
+    uint32_t value[FILL_BATCH_MAX];
+    int first_block[FILL_BATCH_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(BLOCK) void k_fill_batch(FillBatch fb)
+{
+    int k = 0;
+    while (k + 1 < fb.n && (int)blockIdx.x >= fb.first_block[k + 1]) k++;
+    uint32_t* __restrict__ p = fb.p[k];
+    const uint32_t n = fb.n_words[k], v = fb.value[k];
+    const uint32_t nb = (uint32_t)(fb.first_block[k + 1] - fb.first_block[k]);
+    // 16-byte stores where the region allows it
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        uint4* p4 = reinterpret_cast<uint4*>(p);
+        const uint32_t n4 = n >> 2;
+        const uint4 v4 = make_uint4(v, v, v, v);
+        for (uint32_t i = ((uint32_t)blockIdx.x - (uint32_t)fb.first_block[k]) * BLOCK + threadIdx.x; i < n4; i += nb * BLOCK) p4[i] = v4;
+        for (uint32_t i = (n4 << 2) + ((uint32_t)blockIdx.x - (uint32_t)fb.first_block[k]) * BLOCK + threadIdx.x; i < n; i += nb * BLOCK) p[i] = v;
+    } else {
+        for (uint32_t i = ((uint32_t)blockIdx.x - (uint32_t)fb.first_block[k]) * BLOCK + threadIdx.x; i < n; i += nb * BLOCK) p[i] = v;
+    }
+}
+void FillQueue::add(void* p, int byte_value, size_t bytes)
+{
+    if (bytes == 0) return;
+    if ((bytes & 3) || (reinterpret_cast<uintptr_t>(p) & 3) || bytes > ((size_t)1 << 33)) {  // (odd sizes: the runtime's fill)
+        flush();
+        MS_CHECK(hipMemsetAsync(p, byte_value, bytes, stream));
+        return;
+    }
+    if (n == FILL_BATCH_MAX) flush();
+    ptr[n] = p;
+    words[n] = bytes / 4;
+    const uint32_t b = (uint32_t)(byte_value & 0xff);
+    value[n] = b | (b << 8) | (b << 16) | (b << 24);
+    n++;
+}
+void FillQueue::flush()
+{
+    if (n == 0) return;
+    FillBatch fb;
+    fb.n = n;
+    int blocks = 0;
+    for (int k = 0; k < n; k++) {
+        fb.p[k] = (uint32_t*)ptr[k];
+        fb.n_words[k] = (uint32_t)words[k];
+        fb.value[k] = value[k];
+        fb.first_block[k] = blocks;
+        blocks += (int)std::min<size_t>((words[k] / 4 + BLOCK - 1) / BLOCK + 1, 1024);
+    }
+    fb.first_block[n] = blocks;
+    hipLaunchKernelGGL(k_fill_batch, dim3(blocks), dim3(BLOCK), 0, stream, fb);
+    n = 0;
+}
+void fill_async(hipStream_t stream, void* p, int byte_value, size_t bytes)
+{
+    FillQueue q(stream);
+    q.add(p, byte_value, bytes);
+    q.flush();
+}
+__global__ __launch_bounds__(BLOCK) void k_copy_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, size_t n_words)
+{
+    if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0) {
+        const size_t n4 = n_words >> 2;
+        const uint4* s4 = reinterpret_cast<const uint4*>(src);
+        uint4* d4 = reinterpret_cast<uint4*>(dst);
+        for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n4; i += (size_t)gridDim.x * BLOCK) d4[i] = s4[i];
+        for (size_t i = (n4 << 2) + (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n_words; i += (size_t)gridDim.x * BLOCK) dst[i] = src[i];
+    } else {
+        for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n_words; i += (size_t)gridDim.x * BLOCK) dst[i] = src[i];
+    }
+}
+void copy_async(hipStream_t stream, void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return;
+    if ((bytes & 3) || ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 3)) {
+        MS_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+        return;
+    }
+    const size_t n = bytes / 4;
+    const int grid = (int)std::min<size_t>((n / 4 + BLOCK - 1) / BLOCK + 1, 2048);
+    hipLaunchKernelGGL(k_copy_words, dim3(grid), dim3(BLOCK), 0, stream, (const uint32_t*)src, (uint32_t*)dst, n);
 }
 
 static double* host_scratch(Context& c, size_t n)
@@ -1484,8 +1576,8 @@ static void build_pattern(Context& c, int part)
         // 25-40 us each inside a chain of tiny kernels).
         const size_t cap = nk, cap_tiles = (nk + 63) / 64;
         uint32_t* cnt = (uint32_t*)c.counters.p;  // [0] long blocks, [1] very long blocks, [2] rows, [3] row chunks, [4] blocks
-        MS_CHECK(hipMemsetAsync(cnt, 0, 8 * sizeof(uint32_t), c.stream));
-        hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(1), 0, c.stream, (const uint32_t*)(m.scan.p + (nk - 1)), cnt + 4);
+        FillQueue fills(c.stream);  // (the chain's four fills in one launch, below)
+        fills.add(cnt, 0, 8 * sizeof(uint32_t));
         m.colw.ensure(cap_tiles * 64);
         m.slot_row.ensure(cap);
         m.tile_first_row.ensure(cap_tiles);
@@ -1500,9 +1592,12 @@ static void build_pattern(Context& c, int part)
         m.yd.ensure(3 * cap);
         m.chunk_partial.ensure(3 * (2 * cap + 1));
         m.crow_of_row.ensure((size_t)c.nbr);
-        MS_CHECK(hipMemsetAsync(m.colw.p, 0, cap_tiles * 64 * sizeof(uint32_t), c.stream));
+        fills.add(m.colw.p, 0, cap_tiles * 64 * sizeof(uint32_t));
         uint32_t* row_head = heads;  // (heads is dead after the scan; slots beyond the last block must read 0 in the row scan)
-        MS_CHECK(hipMemsetAsync(row_head, 0, (nk + 1) * sizeof(uint32_t), c.stream));
+        fills.add(row_head, 0, (nk + 1) * sizeof(uint32_t));
+        fills.add(m.crow_of_row.p, 0xFF, (size_t)c.mrows() * sizeof(int32_t));
+        fills.flush();
+        hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(1), 0, c.stream, (const uint32_t*)(m.scan.p + (nk - 1)), cnt + 4);
         hipLaunchKernelGGL(k_slots, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, skeys, sidx, m.scan.p, nk, ncols, sentinel, m.slot_of_src.p, m.colw.p, m.slot_row.p,
                            c.diag_slot[part].p, m.slot_start.p, row_head);
         m.sorted_src = sidx;
@@ -1522,7 +1617,6 @@ static void build_pattern(Context& c, int part)
         MS_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp5, ccnt, m.row_chunk0.p, (int)nk + 1, c.stream));
         c.cub_tmp.ensure(tmp5);
         MS_CHECK(hipcub::DeviceScan::ExclusiveSum(c.cub_tmp.p, tmp5, ccnt, m.row_chunk0.p, (int)nk + 1, c.stream));
-        MS_CHECK(hipMemsetAsync(m.crow_of_row.p, 0xFF, (size_t)c.mrows() * sizeof(int32_t), c.stream));
         hipLaunchKernelGGL(k_crow_of_row, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, m.rowmap.p, (int64_t)0, (const uint32_t*)(cnt + 2), m.crow_of_row.p);
         hipLaunchKernelGGL(k_chunk_fill, dim3(grid_for(nk)), dim3(BLOCK), 0, c.stream, m.row_ptr.p, m.row_chunk0.p, (int64_t)0, (const uint32_t*)(cnt + 2), m.chunk_row.p, cnt + 3);
         uint32_t h[5] = {0, 0, 0, 0, 0};
@@ -1928,7 +2022,7 @@ void prepare(Context& c)
         c.hf_total = hf_off;
         c.elemE.ensure(std::max<size_t>(e_off, 1));
         // (the element-Hessian pools are allocated by the first evaluation that writes them)
-        c.is_projected.ensure(std::max<size_t>(e_off, 1));
+        c.is_projected.ensure(std::max<size_t>(e_off, 1) + 4);  // (+4: the zero fill rounds up to whole words)
         if (c.world > 1) {  // other ranks' elements count 0
             // (kernels started ahead of the evaluation — eval_prelaunch — may have written their energies already: the fill waits for them and
             // leaves the ranges alone that still are where those kernels wrote; a kernel whose range has moved is launched again by eval())
@@ -1944,10 +2038,10 @@ void prepare(Context& c)
             size_t at = 0;
             const size_t total = std::max<size_t>(e_off, 1);
             for (const auto& k : keep) {
-                if (k.first > at) MS_CHECK(hipMemsetAsync(c.elemE.p + at, 0, (k.first - at) * sizeof(double), c.stream));
+                if (k.first > at) fill_async(c.stream, c.elemE.p + at, 0, (k.first - at) * sizeof(double));
                 at = std::max(at, k.first + k.second);
             }
-            if (total > at) MS_CHECK(hipMemsetAsync(c.elemE.p + at, 0, (total - at) * sizeof(double), c.stream));
+            if (total > at) fill_async(c.stream, c.elemE.p + at, 0, (total - at) * sizeof(double));
         }
         c.dinv.ensure((size_t)c.nbr * 9);
         // (a refresh that only followed new contact-table sizes copied nothing from the host: no reason to wait for the stream)
@@ -2044,8 +2138,9 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         MS_CHECK(hipEventRecord(c.side_ev[0], c.stream));  // (the contact tables were written on this stream)
     }
     if (mode != MISTARK_EVAL_P) {
-        MS_CHECK(hipMemsetAsync(c.grad.p, 0, (size_t)c.ndofs * sizeof(double), c.stream));
-        if (c.n_hot > 0) MS_CHECK(hipMemsetAsync(c.grad_hot.p, 0, (size_t)HOT_WAYS * 3 * c.n_hot * sizeof(double), c.stream));
+        FillQueue fills(c.stream);
+        fills.add(c.grad.p, 0, (size_t)c.ndofs * sizeof(double));
+        if (c.n_hot > 0) fills.add(c.grad_hot.p, 0, (size_t)HOT_WAYS * 3 * c.n_hot * sizeof(double));
     }
     // kernels launched ahead of this call (eval_prelaunch): whatever becomes of their results, nothing on this stream overtakes them
     // (the wait sits in front of the first launch that touches their pools, below: the small potentials of this evaluation need not wait)
@@ -2074,7 +2169,7 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         // the auxiliary stream's potentials add to their own copy of the gradient, folded in after the join: with one addition per row and
         // kernel (pooled potentials, single-node potentials) the sum of a row no longer depends on which stream got there first
         c.grad_aux.ensure((size_t)c.ndofs);
-        MS_CHECK(hipMemsetAsync(c.grad_aux.p, 0, (size_t)c.ndofs * sizeof(double), c.aux_stream));
+        fill_async(c.aux_stream, c.grad_aux.p, 0, (size_t)c.ndofs * sizeof(double));
     }
     double* const grad_main = c.grad.p;
     try {
@@ -2117,7 +2212,7 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
                         it.E == (const void*)((mode == MISTARK_EVAL_P ? c.elemE.p : c.elemE_pre.p) + P.e_off) &&
                         it.H == (mode != MISTARK_EVAL_P_G_H ? nullptr : (c.lazy_active ? (const void*)(c.elemHf.p + P.hf_off) : (const void*)(c.elemH.p + P.h_off)))) {
                         if (mode != MISTARK_EVAL_P)  // the energies it wrote aside (the line search's energy evaluation summed elemE meanwhile)
-                            MS_CHECK(hipMemcpyAsync(c.elemE.p + P.e_off, c.elemE_pre.p + P.e_off, (size_t)P.args.e_count * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
+                            copy_async(c.stream, c.elemE.p + P.e_off, c.elemE_pre.p + P.e_off, (size_t)P.args.e_count * sizeof(double));
                         if (mode == MISTARK_EVAL_P) {
                         } else if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, false, true);
                         else launch_tet_closed<E_TetStrainEO, false>(c, P, mode, false, true);
@@ -2194,7 +2289,7 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
     if (mode != MISTARK_EVAL_P && c.n_hot > 0)
         hipLaunchKernelGGL(k_fold_hot, dim3(grid_for(3 * (int64_t)c.n_hot)), dim3(BLOCK), 0, c.stream, (const double*)c.grad_hot.p, (const int32_t*)c.hot_rows.p, c.n_hot, c.grad.p);
     if (mode == MISTARK_EVAL_P_G_H) {
-        MS_CHECK(hipMemsetAsync(c.is_projected.p, 0, c.n_elem_total, c.stream));
+        fill_async(c.stream, c.is_projected.p, 0, (c.n_elem_total + 3) & ~(size_t)3);
         c.have_hessians = true;
         c.matrix_current = false;
         c.n_projected_total = 0;
@@ -3014,7 +3109,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
     const int np = (int)c.pots.size();
     if (np + 4 > 128) throw Error("project: too many potentials");
     c.counters.ensure(128);
-    MS_CHECK(hipMemsetAsync(c.counters.p, 0, 128 * sizeof(int64_t), c.stream));
+    fill_async(c.stream, c.counters.p, 0, 128 * sizeof(int64_t));
     const uint8_t* act = nullptr;
     const int32_t* lrow = c.world > 1 ? c.sh.lrow.p : nullptr;
     if (by_gradient) {
@@ -3180,7 +3275,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         for (int part = 0; part < 2; part++)
             if (mark_part[part]) {
                 BsrPart& m = c.part[part];
-                const size_t n_pos = (size_t)std::max<int64_t>(m.ntiles * 64, m.nnzb) + 1;  // (flags are indexed like the values: by storage position)
+                const size_t n_pos = (size_t)std::max<int64_t>(m.ntiles * 64, m.nnzb) + 4;  // (flags are indexed like the values: by storage position; + the fill's rounding to words)
                 if (m.slot_dirty.cap < n_pos) {
                     m.slot_dirty.ensure(n_pos);
                     MS_CHECK(hipMemsetAsync(m.slot_dirty.p, 0, m.slot_dirty.cap, c.stream));
@@ -3209,7 +3304,7 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
             if (mark_part[part]) {
                 BsrPart& m = c.part[part];
                 gather_part(c, part, m.slot_dirty.p);
-                MS_CHECK(hipMemsetAsync(m.slot_dirty.p, 0, (size_t)std::max<int64_t>(m.ntiles * 64, m.nnzb), c.stream));  // (clean for the next round)
+                fill_async(c.stream, m.slot_dirty.p, 0, ((size_t)std::max<int64_t>(m.ntiles * 64, m.nnzb) + 3) & ~(size_t)3);  // (clean for the next round)
             }
     }
     c.n_projected_total += n_selected;
@@ -3900,6 +3995,59 @@ __device__ __forceinline__ void dyn_row(const int32_t* __restrict__ crow_of_row,
         }
     }
 }
+// The same for rows whose chunk partials are many (a rigid body under 10^5 contacts: ~270 chunks): CALLED BY ALL LANES OF A WAVEFRONT (lanes
+// without a row pass row = -1). Rows up to DYN_FOLD_SERIAL chunks are folded by their own lane as in dyn_row; a longer row is folded by the
+// whole wavefront — lane l adds chunks l, l + 64, ... in ascending order, then the fixed-shape wave_sum: deterministic, the same bits in every
+// kernel that consumes the contact part (one lane walking 270 chunks held k_pcg_step at 30 us on configs[2]; the SpMV beside it takes 8).
+constexpr uint32_t DYN_FOLD_SERIAL = 8;
+__device__ __forceinline__ void dyn_row_wave(const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0, const double* __restrict__ yd,
+                                             const double* __restrict__ chunk_partial, int64_t row, double& q0, double& q1, double& q2)
+{
+    uint32_t c0 = 0, c1 = 0;
+    int32_t cr = -1;
+    if (row >= 0) {
+        cr = crow_of_row[row];
+        if (cr >= 0) {
+            c0 = row_chunk0[cr];
+            c1 = row_chunk0[cr + 1];
+        }
+    }
+    const bool lng = c1 - c0 > DYN_FOLD_SERIAL;
+    if (cr >= 0 && !lng) {
+        if (c1 - c0 <= 1) {
+            q0 += yd[3 * (size_t)cr];
+            q1 += yd[3 * (size_t)cr + 1];
+            q2 += yd[3 * (size_t)cr + 2];
+        } else {
+            for (uint32_t k = c0; k < c1; k++) {
+                q0 += chunk_partial[3 * (size_t)k];
+                q1 += chunk_partial[3 * (size_t)k + 1];
+                q2 += chunk_partial[3 * (size_t)k + 2];
+            }
+        }
+    }
+    unsigned long long mask = __ballot(lng);
+    const int lane = threadIdx.x & 63;
+    while (mask) {  // (wave-uniform)
+        const int src = __ffsll((long long)mask) - 1;
+        mask &= mask - 1;
+        const uint32_t b0 = (uint32_t)__shfl((int)c0, src, 64), b1 = (uint32_t)__shfl((int)c1, src, 64);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (uint32_t k = b0 + (uint32_t)lane; k < b1; k += 64) {
+            a0 += chunk_partial[3 * (size_t)k];
+            a1 += chunk_partial[3 * (size_t)k + 1];
+            a2 += chunk_partial[3 * (size_t)k + 2];
+        }
+        a0 = read_lane(wave_sum(a0), 0);
+        a1 = read_lane(wave_sum(a1), 0);
+        a2 = read_lane(wave_sum(a2), 0);
+        if (lane == src) {
+            q0 += a0;
+            q1 += a1;
+            q2 += a2;
+        }
+    }
+}
 struct StaticPart  // the static part as the fused SpMV kernel sees it
 {
     const float* vals;
@@ -4021,9 +4169,9 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_combine(int64_t nbr, const int32
                                                        const double* __restrict__ yd, const double* __restrict__ chunk_partial, double* __restrict__ y)
 {
     const int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (row >= nbr) return;
     double q0 = 0.0, q1 = 0.0, q2 = 0.0;
-    dyn_row(crow_of_row, row_chunk0, yd, chunk_partial, row, q0, q1, q2);
+    dyn_row_wave(crow_of_row, row_chunk0, yd, chunk_partial, row < nbr ? row : -1, q0, q1, q2);
+    if (row >= nbr) return;
     y[3 * row] += q0;
     y[3 * row + 1] += q1;
     y[3 * row + 2] += q2;
@@ -4301,7 +4449,7 @@ __device__ __forceinline__ void step_load(StepRow& w, int64_t row, const float* 
     w.p0 = p[i]; w.p1 = p[i + 1]; w.p2 = p[i + 2];
 #pragma unroll
     for (int u = 0; u < 9; u++) w.d[u] = dinv[9 * row + u];
-    if (crow_of_row) dyn_row(crow_of_row, row_chunk0, yd, chunk_partial, row, w.q0, w.q1, w.q2);  // + contact part (k_spmv_fused)
+    // (+ the contact part of q: dyn_row_wave, called by the whole wavefront behind this)
 }
 __global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, const double* __restrict__ part_pq, int n_pq, const float* __restrict__ dinv, int64_t nbr,
                                                     const double* __restrict__ p, const double* __restrict__ q, double* __restrict__ x, double* __restrict__ r,
@@ -4314,6 +4462,7 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, co
     int64_t row = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     StepRow w;
     if (row < nbr) step_load(w, row, dinv, p, q, x, r, crow_of_row, row_chunk0, yd, chunk_partial);
+    if (crow_of_row) dyn_row_wave(crow_of_row, row_chunk0, yd, chunk_partial, row < nbr ? row : -1, w.q0, w.q1, w.q2);  // + contact part (k_spmv_fused)
     if (done) return;
     __shared__ double sm[4];
     const double pAp = sum_partials(part_pq, n_pq, sm);
@@ -4336,22 +4485,25 @@ __global__ __launch_bounds__(BLOCK) void k_pcg_step(int k, int stop_on_indef, co
     }
     const double alpha = rz / pAp;
     double rr = 0.0, rzn = 0.0;
-    for (; row < nbr;) {
-        const size_t i = 3 * (size_t)row;
-        const double r0 = w.r0 - alpha * w.q0, r1 = w.r1 - alpha * w.q1, r2 = w.r2 - alpha * w.q2;
-        x[i] = w.x0 + alpha * w.p0;
-        x[i + 1] = w.x1 + alpha * w.p1;
-        x[i + 2] = w.x2 + alpha * w.p2;
-        r[i] = r0; r[i + 1] = r1; r[i + 2] = r2;
-        const float* d = w.d;
-        const double z0 = (double)d[0] * r0 + (double)d[1] * r1 + (double)d[2] * r2;
-        const double z1 = (double)d[3] * r0 + (double)d[4] * r1 + (double)d[5] * r2;
-        const double z2 = (double)d[6] * r0 + (double)d[7] * r1 + (double)d[8] * r2;
-        z[i] = z0; z[i + 1] = z1; z[i + 2] = z2;
-        rr += r0 * r0 + r1 * r1 + r2 * r2;
-        rzn += r0 * z0 + r1 * z1 + r2 * z2;
-        row += (int64_t)gridDim.x * BLOCK;
-        if (row < nbr) step_load(w, row, dinv, p, q, x, r, crow_of_row, row_chunk0, yd, chunk_partial);
+    for (; __any(row < nbr);) {  // (wave-uniform: dyn_row_wave needs the whole wavefront)
+        if (row < nbr) {
+            const size_t i = 3 * (size_t)row;
+            const double r0 = w.r0 - alpha * w.q0, r1 = w.r1 - alpha * w.q1, r2 = w.r2 - alpha * w.q2;
+            x[i] = w.x0 + alpha * w.p0;
+            x[i + 1] = w.x1 + alpha * w.p1;
+            x[i + 2] = w.x2 + alpha * w.p2;
+            r[i] = r0; r[i + 1] = r1; r[i + 2] = r2;
+            const float* d = w.d;
+            const double z0 = (double)d[0] * r0 + (double)d[1] * r1 + (double)d[2] * r2;
+            const double z1 = (double)d[3] * r0 + (double)d[4] * r1 + (double)d[5] * r2;
+            const double z2 = (double)d[6] * r0 + (double)d[7] * r1 + (double)d[8] * r2;
+            z[i] = z0; z[i + 1] = z1; z[i + 2] = z2;
+            rr += r0 * r0 + r1 * r1 + r2 * r2;
+            rzn += r0 * z0 + r1 * z1 + r2 * z2;
+            row += (int64_t)gridDim.x * BLOCK;
+            if (row < nbr) step_load(w, row, dinv, p, q, x, r, crow_of_row, row_chunk0, yd, chunk_partial);
+        }
+        if (crow_of_row && __any(row < nbr)) dyn_row_wave(crow_of_row, row_chunk0, yd, chunk_partial, row < nbr ? row : -1, w.q0, w.q1, w.q2);
     }
     rr = block_sum(rr, sm);
     rzn = block_sum(rzn, sm);
@@ -4765,7 +4917,7 @@ __device__ __forceinline__ void vec_load(VecRow& v, int64_t row, const float* __
 #pragma unroll
     for (int k = 0; k < 9; k++) v.d[k] = dinv[9 * row + k];
     v.sp = send_pos_of_row ? send_pos_of_row[row] : -1;
-    if (crow_of_row) dyn_row(crow_of_row, row_chunk0, yd, chunk_partial, row, v.w0, v.w1, v.w2);  // + contact part of w (the SpMV left it in yd / chunk_partial)
+    // (+ the contact part of w, which the SpMV left in yd / chunk_partial: dyn_row_wave, called by the whole wavefront behind this)
 }
 // V_k, k >= 1 (check_only: the convergence test of iteration k - 1 and nothing else, behind the last iteration the caller allows).
 // replay (mistark_dist_fused_bench): the kernel of a FINISHED solve launched again on the messages still in the window — every poll is
@@ -4792,6 +4944,7 @@ __global__ __launch_bounds__(BLOCK) void k_cg_vec(int k, int check_only, int sto
     VecRow v;
     // (the thread's row is requested before the sums below: they wait for the slowest rank's reduction)
     if (!check_only && row < n_own) vec_load(v, row, dinv, u, w, p, s, x, r, crow_of_row, row_chunk0, yd, chunk_partial, send_pos_of_row);
+    if (!check_only && crow_of_row) dyn_row_wave(crow_of_row, row_chunk0, yd, chunk_partial, row < n_own ? row : -1, v.w0, v.w1, v.w2);
     __shared__ double sm[3 * MAX_IPC_RANKS + 8];
     double gamma = 0.0, rr = 0.0, delta = 0.0;
     if (!windows) {
@@ -4882,7 +5035,8 @@ __global__ __launch_bounds__(BLOCK) void k_cg_vec(int k, int check_only, int sto
     }
     const double alpha = gamma / pAp;
     double ru = 0.0, rrn = 0.0;
-    while (row < n_own) {
+    while (__any(row < n_own)) {  // (wave-uniform: dyn_row_wave needs the whole wavefront)
+      if (row < n_own) {
         const size_t j = 3 * (size_t)row;
         const double p0 = beta == 0.0 ? v.u0 : v.u0 + beta * v.p0, p1 = beta == 0.0 ? v.u1 : v.u1 + beta * v.p1, p2 = beta == 0.0 ? v.u2 : v.u2 + beta * v.p2;
         const double s0 = beta == 0.0 ? v.w0 : v.w0 + beta * v.s0, s1 = beta == 0.0 ? v.w1 : v.w1 + beta * v.s1, s2 = beta == 0.0 ? v.w2 : v.w2 + beta * v.s2;
@@ -4901,6 +5055,8 @@ __global__ __launch_bounds__(BLOCK) void k_cg_vec(int k, int check_only, int sto
         if (v.sp >= 0) push_halo_row(f, par_out, tag_out, v.sp, send_mask[v.sp], u0, u1, u2);
         row += (int64_t)gridDim.x * BLOCK;
         if (row < n_own) vec_load(v, row, dinv, u, w, p, s, x, r, crow_of_row, row_chunk0, yd, chunk_partial, send_pos_of_row);
+      }
+      if (crow_of_row && __any(row < n_own)) dyn_row_wave(crow_of_row, row_chunk0, yd, chunk_partial, row < n_own ? row : -1, v.w0, v.w1, v.w2);
     }
     __syncthreads();
     rrn = block_sum(rrn, sm);
@@ -5101,6 +5257,7 @@ bool fused_setup(Context& c, FusedSolve& F)
     F.pr[0][1] = c.partials.p + 5 * MAX_PARTIALS;
     F.pr[1][0] = c.partials.p + 2 * MAX_PARTIALS;
     F.pr[1][1] = c.partials.p + 3 * MAX_PARTIALS;
+    if (view->fast_tag) c.fused_tag = std::max(c.fused_tag, *view->fast_tag);  // (an earlier context on the same windows: continue behind its tags)
     F.base = c.fused_tag;
     F.send_mask = c.no_halo_subset ? (const uint32_t*)S.send_mask.p : (const uint32_t*)c.cg_send_mask.p;
     return true;
@@ -5199,6 +5356,8 @@ static bool pcg_sharded_fused(Context& c, const double* rhs_global, double abs_t
     // the next solve's tags start behind the last one any rank can have used in this one (a rank launches at most two batches beyond the
     // iteration that ended the solve; computed from the iteration count, which is the same number on every rank)
     c.fused_tag = F.base + 2u * (uint32_t)((h.done ? h.n_iter : max_iter) + 2 * BATCH + 4);
+    if (const IpcView* v = c.coll->ipc())
+        if (v->fast_tag) *v->fast_tag = c.fused_tag;
     if (c.fused_tag > 0xf0000000u) throw Error("sharded PCG: the window tags are about to wrap to the windows' zero-filled state after ~2^32 exchanges; create a new communicator");
     shard_gather_global(c, F.x, c.du.p);  // (also the barrier between this solve's last window readers and the next solve's first push)
     MS_CHECK(hipStreamSynchronize(c.stream));

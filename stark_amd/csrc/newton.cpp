@@ -258,7 +258,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
         const int ls0[4] = {st.ls_cap_iterations, st.ls_max_iterations, st.ls_inv_iterations, st.ls_bt_iterations};
         {
             double* u0 = c.tmp_b.p;  // dofs_before_ls
-            MS_CHECK(hipMemcpyAsync(u0, c.u.p, (size_t)ndofs * sizeof(double), hipMemcpyDeviceToDevice, c.stream));
+            copy_async(c.stream, u0, c.u.p, (size_t)ndofs * sizeof(double));
             auto apply = [&](double step) { vec_axpby(c, c.u.p, 1.0, u0, step, c.du.p, ndofs); };
             double retraction = 1.0;
             if (du_max > s.step_cap) {

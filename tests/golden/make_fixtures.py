@@ -105,6 +105,11 @@ FIXTURES = {
 }
 
 
+# steplog_cfg3_nofma.npz is not made by this script's harness but by the SAME reference compiled with -ffp-contract=off (make -C oracle nofma;
+# the command is in the fixture's `recipe` entry): the time-step logs of configs[3] on the centred and on the offset placement, see
+# tests/test_oracle_golden.py::test_the_references_own_log_on_exact_ties_depends_on_its_compile_flags
+
+
 def run(cmd):
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
 
