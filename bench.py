@@ -273,6 +273,8 @@ def self_launch(n):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (window handles, RCCL)
     env.setdefault("OMP_NUM_THREADS", "1")
     env["MISTARK_BENCH_SELF_LAUNCHED"] = "1"
+    if env.get("MISTARK_BENCH_DEVICE") is not None:
+        env.setdefault("MISTARK_IPC_TIMEOUT_S", "10")   # (ranks sharing a device: a stalled exchange should fail the path test quickly)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.abspath(__file__)] + sys.argv[1:]
     # the ranks' stdout carries rank 0's JSON line — and whatever libraries print there (gloo announces its connections on stdout): only the

@@ -5234,6 +5234,9 @@ bool fused_setup(Context& c, FusedSolve& F)
     spmv_launch_shape(c, F.g0, F.gr, F.g1, F.sp, F.d);
     F.gs = F.g0 + F.gr + F.g1;
     F.gv = grid_for(std::max<int64_t>(S.n_own, 1), BLOCK, PCG_GRID);
+    // (ranks sharing ONE device — test boxes —: every rank's polling workgroups must leave room for the kernels they wait for; the same cap as the
+    // SpMV's. The vector kernel walks its rows with a grid stride, any grid is correct.)
+    if (c.spmv_grid_cap > 0) F.gv = std::min(F.gv, std::max(c.spmv_grid_cap / 2, 8));
     F.f = CgFast{};
     F.f.v = *view;
     F.f.send_stride = S.send_stride;
