@@ -119,6 +119,10 @@ int mistark_get_dofs(mistark_ctx* ctx, double* u_host);        /* GlobalPotentia
 int mistark_set_dofs(mistark_ctx* ctx, const double* u_host);  /* GlobalPotential::set_dofs (GlobalPotential.cpp:134-144) */
 /* device DoFs -> the host arrays registered with mistark_add_dof_set, and back */
 int mistark_dofs_to_host_arrays(mistark_ctx* ctx);
+/* The same, skipped when the DoF vector on the device has not changed since the last transfer to the caller's arrays (a drop-in's Newton
+ * callbacks all read the DoFs from the caller's arrays; several of them run at the same iterate: intersection check, contact update,
+ * convergence test). The caller must not have written its DoF arrays in between (mistark_dofs_from_host_arrays / mistark_set_dofs say so). */
+int mistark_dofs_to_host_arrays_if_changed(mistark_ctx* ctx);
 int mistark_dofs_from_host_arrays(mistark_ctx* ctx);
 
 /* ---- evaluation ----------------------------------------------------------------------------------------------------- */

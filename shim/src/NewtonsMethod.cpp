@@ -416,7 +416,8 @@ namespace symx
 
 		// ---- C callbacks of mistark_newton_solve -> SolverCallbacks (solver_utils.h:29-117). STARK's callbacks read the DoFs from the
 		//      caller's arrays: bring them there first.
-		void dofs_to_host() { check(mistark_dofs_to_host_arrays(ctx), "mistark_dofs_to_host_arrays"); }
+		// (inside the Newton loop the callbacks read the DoFs and never write them: several callbacks at one iterate share one transfer)
+		void dofs_to_host() { check(mistark_dofs_to_host_arrays_if_changed(ctx), "mistark_dofs_to_host_arrays_if_changed"); }
 		static Impl& I(void* u) { return *static_cast<Impl*>(u); }
 		static void cb_before_eval(void* u)
 		{
@@ -517,7 +518,7 @@ namespace symx
 		mistark_newton_stats st{};
 		const int rc = mistark_newton_solve(s.ctx, &ns, &cb, &st);
 		s.check(rc, "mistark_newton_solve");
-		s.dofs_to_host();  // the reference leaves the solution in the caller's DoF arrays (NewtonsMethod.cpp:608-640)
+		s.check(mistark_dofs_to_host_arrays(s.ctx), "mistark_dofs_to_host_arrays");  // the reference leaves the solution in the caller's DoF arrays (NewtonsMethod.cpp:608-640)
 		s.verify_after_solve(*global_potential);
 		if (const char* path = std::getenv("MISTARK_SHIM_SOLVELOG"))  // one line per solve(): Newton iterations, linear solves, CG iterations
 			std::ofstream(path, std::ios::app) << st.newton_iterations << " " << st.n_linear_solves << " " << st.cg_iterations << std::endl;

@@ -236,6 +236,7 @@ int mistark_add_dof_set(mistark_ctx* ctx, const char* label, double* host, int64
 {
     API_BEGIN
     ctx->c.touch();
+    ctx->c.u_version++;
     if (n_scalars < 0 || n_scalars % 3 != 0) throw Error("DoF set size must be a non-negative multiple of 3");
     if (n_scalars > 0 && !host) throw Error("DoF set without a host array");
     DofSet s;
@@ -251,6 +252,7 @@ int mistark_resize_dof_set(mistark_ctx* ctx, int set, double* host, int64_t n_sc
 {
     API_BEGIN
     ctx->c.touch();
+    ctx->c.u_version++;
     if (set < 0 || set >= (int)ctx->c.dof_sets.size()) throw Error("bad DoF set");
     if (n_scalars < 0 || n_scalars % 3 != 0) throw Error("DoF set size must be a non-negative multiple of 3");
     if (n_scalars > 0 && !host) throw Error("DoF set without a host array");
@@ -273,6 +275,7 @@ int mistark_array(mistark_ctx* ctx, const double* host, int64_t n_items, int str
 {
     API_BEGIN
     ctx->c.touch();
+    ctx->c.u_version++;
     Context& c = ctx->c;
     if (stride <= 0) throw Error("bad stride");
     if (n_items < 0) throw Error("negative item count");
@@ -384,6 +387,7 @@ int mistark_array_axpby(mistark_ctx* ctx, int dst, double a, int x, double b, in
 {
     API_BEGIN
     ctx->c.touch();
+    ctx->c.u_version++;
     Context& c = ctx->c;
     prepare(c);
     const int na = (int)c.arrays.size();
@@ -397,6 +401,7 @@ int mistark_array_fill(mistark_ctx* ctx, int dst, double value)
 {
     API_BEGIN
     ctx->c.touch();
+    ctx->c.u_version++;
     Context& c = ctx->c;
     prepare(c);
     if (dst < 0 || dst >= (int)c.arrays.size()) throw Error("bad array id");
@@ -408,6 +413,7 @@ int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, i
 {
     API_BEGIN
     ctx->c.touch();
+    ctx->c.u_version++;
     _ret = register_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings);
     API_END(_ret)
 }
@@ -416,6 +422,7 @@ int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* 
 {
     API_BEGIN
     ctx->c.touch();
+    ctx->c.u_version++;
     _ret = register_custom_potential(ctx->c, name, conn, n_elem, conn_stride, bindings, n_bindings, ops, constants, n_ops, n_inputs, cond_ops, cond_constants, n_cond_ops);
     API_END(_ret)
 }
@@ -428,6 +435,7 @@ int mistark_potential_custom_set_summation(mistark_ctx* ctx, int potential, int3
     if (!P.prog) throw Error("mistark_potential_custom_set_summation: '" + P.name + "' is not a custom potential");
     custom_program_set_summation(*P.prog, P.name, first_input, stride, n_iterations, data);
     c.touch();
+    c.u_version++;
     API_END(0)
 }
 int mistark_potential_table(mistark_ctx* ctx, int potential, int32_t* conn, int64_t* n_elem, int32_t* conn_stride)
@@ -466,6 +474,7 @@ int mistark_potential_set_dynamic(mistark_ctx* ctx, int potential, int dynamic)
 {
     API_BEGIN
     ctx->c.touch();
+    ctx->c.u_version++;
     Context& c = ctx->c;
     if (potential < 0 || potential >= (int)c.pots.size()) throw Error("bad potential id");
     const int part = dynamic ? 1 : 0;
@@ -511,6 +520,7 @@ int mistark_set_dofs(mistark_ctx* ctx, const double* u_host)
 {
     API_BEGIN
     ctx->c.touch();
+    ctx->c.u_version++;
     Context& c = ctx->c;
     prepare(c);
     MS_CHECK(hipMemcpyAsync(c.u.p, u_host, (size_t)c.ndofs * sizeof(double), hipMemcpyHostToDevice, c.stream));
@@ -525,12 +535,27 @@ int mistark_dofs_to_host_arrays(mistark_ctx* ctx)
     for (auto& s : c.dof_sets)
         if (s.n > 0) MS_CHECK(hipMemcpyAsync(s.host, c.u.p + s.offset, s.n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
+    c.u_host_version = c.u_version;
+    API_END(0)
+}
+int mistark_dofs_to_host_arrays_if_changed(mistark_ctx* ctx)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    prepare(c);
+    if (c.u_host_version != c.u_version) {
+        for (auto& s : c.dof_sets)
+            if (s.n > 0) MS_CHECK(hipMemcpyAsync(s.host, c.u.p + s.offset, s.n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));
+        c.u_host_version = c.u_version;
+    }
     API_END(0)
 }
 int mistark_dofs_from_host_arrays(mistark_ctx* ctx)
 {
     API_BEGIN
     ctx->c.touch();
+    ctx->c.u_version++;
     Context& c = ctx->c;
     prepare(c);
     for (auto& s : c.dof_sets)

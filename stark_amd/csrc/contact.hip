@@ -1523,14 +1523,46 @@ struct StandaloneDetector
     std::vector<double> dist[6];
     std::vector<uint64_t> keys;
     std::string last_error;
+    // A caller asks again at unchanged positions more often than not (the reference's contact class searches at every energy evaluation: the
+    // accepted line-search candidate's evaluation and the evaluation that opens the next Newton iteration see the same vertices): the
+    // lists of the previous run are the answer when positions, enlargement, activation and the mesh set are the same bytes.
+    uint64_t prox_print = 0, et_print = 0;
+    bool prox_valid = false, et_valid = false;
+    int32_t et_count = 0;
+    int64_t n_prox_cached = 0, n_et_cached = 0;
 };
 namespace {
 constexpr int CD_COLS[6] = {8, 9, 7, 10, 9, 8};
-void cd_upload_positions(StandaloneDetector& D)
+uint64_t cd_fingerprint(const StandaloneDetector& D, const ContactSystem& cs, double enlargement)
+{
+    auto mix = [](uint64_t h, uint64_t v) {
+        h ^= v;
+        h *= 0x9E3779B97F4A7C15ull;
+        return h ^ (h >> 29);
+    };
+    uint64_t h[4] = {0x243F6A8885A308D3ull, 0x13198A2E03707344ull, 0xA4093822299F31D0ull, 0x082EFA98EC4E6C89ull};
+    const uint64_t* w = reinterpret_cast<const uint64_t*>(D.X.data());
+    const size_t n = D.X.size();
+    size_t i = 0;
+    for (; i + 4 <= n; i += 4)
+        for (int k = 0; k < 4; k++) h[k] = mix(h[k], w[i + k]);
+    for (; i < n; i++) h[0] = mix(h[0], w[i]);
+    uint64_t e;
+    std::memcpy(&e, &enlargement, 8);
+    uint64_t r = mix(mix(mix(mix(h[0], h[1]), h[2]), h[3]), e);
+    r = mix(r, (uint64_t)cs.meshes.size() * 4 + (cs.pt_enabled ? 2 : 0) + (cs.ee_enabled ? 1 : 0));
+    r = mix(r, (uint64_t)cs.disabled_pairs.size());
+    return r;
+}
+void cd_gather_positions(StandaloneDetector& D)
 {
     ContactSystem& cs = CS(D.c);
     D.X.resize(3 * (size_t)cs.n_v);
     for (size_t g = 0; g < cs.meshes.size(); g++) std::memcpy(D.X.data() + 3 * (size_t)cs.meshes[g].v_off, D.xm[g], 3 * (size_t)cs.meshes[g].n_v * sizeof(double));
+}
+void cd_upload_positions(StandaloneDetector& D)
+{
+    ContactSystem& cs = CS(D.c);
     cs.X.ensure(std::max<size_t>(D.X.size(), 1));
     cs.aabb.ensure(6 * (size_t)std::max(cs.n_v + cs.n_t + cs.n_e, 1));
     if (!D.X.empty()) MS_CHECK(hipMemcpyAsync(cs.X.p, D.X.data(), D.X.size() * sizeof(double), hipMemcpyHostToDevice, D.c.stream));
@@ -1665,21 +1697,43 @@ int mistark_cd_run_proximity(mistark_cd* cd, double enlargement, int32_t counts[
     Context& c = D.c;
     ContactSystem& cs = CS(c);
     MS_CHECK(hipSetDevice(c.device));
+    if (cs.meshes.empty()) {
+        for (int l = 0; l < 6; l++) {
+            D.rows[l].clear();
+            D.dist[l].clear();
+            if (counts) counts[l] = 0;
+        }
+        return 0;
+    }
+    if (!(enlargement >= 0.0)) throw Error("cd: negative enlargement");
+    if (cs.meshes_dirty) upload_meshes(c, cs);  // (n_v of a mesh added since the last run)
+    cd_gather_positions(D);
+    const uint64_t print = cd_fingerprint(D, cs, enlargement);
+    static const bool no_cache = std::getenv("MISTARK_CD_NO_CACHE") != nullptr;
+    if (D.prox_valid && print == D.prox_print && !no_cache) {  // the same question as last time: the same lists
+        for (int l = 0; l < 6; l++)
+            if (counts) counts[l] = (int32_t)(D.rows[l].size() / (size_t)CD_COLS[l]);
+        D.n_prox_cached++;
+        return 0;
+    }
+    D.prox_valid = false;
     for (int l = 0; l < 6; l++) {
         D.rows[l].clear();
         D.dist[l].clear();
         if (counts) counts[l] = 0;
     }
-    if (cs.meshes.empty()) return 0;
-    if (!(enlargement >= 0.0)) throw Error("cd: negative enlargement");
     cd_upload_positions(D);
     const ContactDev d = cd_view(D);
+    D.prox_print = print;
     const float enl_f = nextafterf((float)enlargement, INFINITY) + 1.1920929e-07f;  // (float)enl + eps (AABBs.cpp:38), rounded up
     const int np = cs.n_v + cs.n_t + cs.n_e;
     hipLaunchKernelGGL(k_contact_aabbs, dim3((np + CB - 1) / CB), dim3(CB), 0, c.stream, d, enl_f, cs.aabb.p);
     int h[64];
     const int n = cd_search(D, d, true, enlargement, h);
-    if (n == 0) return 0;
+    if (n == 0) {
+        D.prox_valid = true;
+        return 0;
+    }
     fill_async(c.stream, cs.counters.p + 2, 0, sizeof(int));
     const uint64_t* sorted = sort_and_bound(c, cs, n, nullptr, false);
     D.keys.resize((size_t)n);
@@ -1738,6 +1792,7 @@ int mistark_cd_run_proximity(mistark_cd* cd, double enlargement, int32_t counts[
             }
         }
     }
+    D.prox_valid = true;
     CD_END(0)
 }
 int mistark_cd_get_proximity(mistark_cd* cd, int list, int32_t* rows, double* distance)
@@ -1755,9 +1810,24 @@ int mistark_cd_run_intersection(mistark_cd* cd, int32_t* n_pairs)
     Context& c = D.c;
     ContactSystem& cs = CS(c);
     MS_CHECK(hipSetDevice(c.device));
-    D.et_rows.clear();
     if (n_pairs) *n_pairs = 0;
-    if (cs.meshes.empty() || cs.n_e == 0 || cs.n_t == 0) return 0;
+    if (cs.meshes_dirty) upload_meshes(c, cs);
+    if (cs.meshes.empty() || cs.n_e == 0 || cs.n_t == 0) {
+        D.et_rows.clear();
+        return 0;
+    }
+    cd_gather_positions(D);
+    const uint64_t print = cd_fingerprint(D, cs, -1.0);
+    static const bool no_cache = std::getenv("MISTARK_CD_NO_CACHE") != nullptr;
+    if (D.et_valid && print == D.et_print && !no_cache) {
+        if (n_pairs) *n_pairs = D.et_count;
+        D.n_et_cached++;
+        return 0;
+    }
+    D.et_valid = false;
+    D.et_rows.clear();
+    D.et_print = print;
+    D.et_count = 0;
     cd_upload_positions(D);
     const ContactDev d = cd_view(D);
     const int np = cs.n_v + cs.n_t + cs.n_e;
@@ -1765,7 +1835,10 @@ int mistark_cd_run_intersection(mistark_cd* cd, int32_t* n_pairs)
     int h[64];
     const int n = cd_search(D, d, false, 0.0, h);
     if (n != h[1]) throw Error("cd: intersection list and count disagree");
-    if (n == 0) return 0;
+    if (n == 0) {
+        D.et_valid = true;
+        return 0;
+    }
     D.keys.resize((size_t)n);
     MS_CHECK(hipMemcpyAsync(D.keys.data(), cs.keys.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
@@ -1782,6 +1855,8 @@ int mistark_cd_run_intersection(mistark_cd* cd, int32_t* n_pairs)
         for (int i = 0; i < 3; i++) r[6 + i] = cs.h_tri[3 * (size_t)t + i] - Mt.v_off;
     }
     if (n_pairs) *n_pairs = n;
+    D.et_count = n;
+    D.et_valid = true;
     CD_END(0)
 }
 int mistark_cd_get_intersections(mistark_cd* cd, int32_t* rows)

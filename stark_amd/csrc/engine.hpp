@@ -372,6 +372,7 @@ struct Context
     // bumped by everything that can change what a contact detection sees (DoFs, bound arrays, layout): the detector skips a search whose
     // inputs are those of its previous one (the evaluation that opens a Newton iteration repeats the accepted line-search state)
     uint64_t data_version = 1;
+    uint64_t u_version = 1, u_host_version = 0;  // the DoF vector on the device / as last brought to the caller's arrays (mistark_dofs_to_host_arrays_if_changed)
     // Evaluation kernels of the large closed-form potentials launched AHEAD of eval() (eval_prelaunch: while the callback that precedes an
     // evaluation — contact search, a caller's host code — keeps the host and the main stream busy). eval() takes the results if nothing
     // they depend on has changed (same kernel arguments, same pools), launches normally otherwise.

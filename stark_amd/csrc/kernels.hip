@@ -1211,13 +1211,19 @@ void vec_axpby(Context& c, double* dst, double a, const double* x, double b, con
     if (n == 0) return;
     // (the DoF vector: contact caches and a prelaunched evaluation are void; work vectors are nobody's input. Bound arrays change through
     // mistark_array_axpby / _fill, which say so themselves.)
-    if (dst >= c.u.p && dst < c.u.p + c.ndofs) c.touch();
+    if (dst >= c.u.p && dst < c.u.p + c.ndofs) {
+        c.touch();
+        c.u_version++;
+    }
     hipLaunchKernelGGL(k_axpby, dim3(grid_for(n, BLOCK, 2048)), dim3(BLOCK), 0, c.stream, dst, a, x, b, y, n);
 }
 void vec_fill(Context& c, double* dst, double v, int64_t n)
 {
     if (n == 0) return;
-    if (dst >= c.u.p && dst < c.u.p + c.ndofs) c.touch();
+    if (dst >= c.u.p && dst < c.u.p + c.ndofs) {
+        c.touch();
+        c.u_version++;
+    }
     hipLaunchKernelGGL(k_fill, dim3(grid_for(n, BLOCK, 2048)), dim3(BLOCK), 0, c.stream, dst, v, n);
 }
 void vec_neg(Context& c, double* dst, const double* x, int64_t n) { vec_axpby(c, dst, -1.0, x, 0.0, nullptr, n); }
@@ -1715,6 +1721,7 @@ void prepare(Context& c)
     if (c.dry) throw Error("registration-only context (mistark_create_dry): nothing can be evaluated");
     if (!c.layout_dirty) return;
     c.data_version++;
+    c.u_version++;
     if (c.layout_dirty) {
         // DoF layout
         int64_t off = 0;
@@ -1938,7 +1945,12 @@ void prepare(Context& c)
             // ... and the generic kernels' potentials with several nodes per element (a single node per element: one addition per row, nothing to
             // order); the rows of rigid bodies attached to many points are summed by k_grad_gather_long
             const bool generic_pool = P.kind != KIND_CUSTOM && P.NB >= 2;
-            P.grad_gather = (P.lazy_capable || closed_tri || generic_pool) && !P.conn_ext && !P.conn_host.empty() && !c.no_grad_gather;
+            // Tables the CALLER refills inside the Newton loop (a drop-in's contact and friction potentials: part 1, host connectivity): the host-built
+            // incidence lists below cost a pass over all block rows and an upload per potential and table change — 1.2 ms per evaluation at 172 k rows,
+            // what made the drop-in's energy evaluations 30 times the mirror's. Their node gradients go through the pool of the device-resident
+            // tables instead (sorted by block row on the device, dyn_grad_gather): same fixed order of summation, no pass over the rows.
+            const bool host_dynamic = P.part == 1 && P.NB >= 2 && !P.conn_ext && !P.conn_host.empty() && P.kind != KIND_CUSTOM && !c.no_dyn_pool && !c.no_grad_gather && c.world == 1;
+            P.grad_gather = (P.lazy_capable || closed_tri || generic_pool) && !P.conn_ext && !host_dynamic && !P.conn_host.empty() && !c.no_grad_gather;
             std::vector<int64_t> sig{(int64_t)P.n_elem, c.nbr, (int64_t)P.n_key, (int64_t)P.conn_version, (int64_t)(c.world > 1 ? c.sh.version_lists : 0)};
             for (int k = 0; k < P.NB; k++) {
                 sig.push_back(A.dof_col[k]);
@@ -1948,10 +1960,10 @@ void prepare(Context& c)
                 A.gpool = nullptr;
                 P.inc_sig.clear();
             }
-            P.dyn_pool = P.conn_ext != nullptr && P.kind != KIND_CUSTOM && !c.no_dyn_pool && !c.no_grad_gather;
+            P.dyn_pool = (P.conn_ext != nullptr && P.kind != KIND_CUSTOM && !c.no_dyn_pool && !c.no_grad_gather) || host_dynamic;
             if (P.dyn_pool && P.n_key > 0) {
                 DynIncDesc d{};
-                d.conn = P.conn_ext;
+                d.conn = P.conn_ext ? P.conn_ext : A.conn;
                 d.stride = P.conn_stride;
                 d.n_elem = P.n_key;
                 d.NB = P.NB;
