@@ -300,7 +300,7 @@ def drop_in_run(S, capi, nx, ny, nz, device, time_steps=16):
     if not os.path.exists(exe):
         return {"unavailable": "oracle/_ref/shim_check_cd not built (needs /root/reference in the build container: make -C oracle shim_cd)"}
     env = dict(os.environ, SHIM_GRID="%d,%d,%d" % (nx, ny, nz), MISTARK_SHIM_STATS="1", MISTARK_DEVICE=str(device))
-    env.setdefault("SHIM_THREADS", "16")
+    env.setdefault("SHIM_THREADS", "1")   # (the reference's own host-side work per callback is small: one thread beats sixteen on it, measured 1.29 s against 1.79 s)
     r = subprocess.run([exe, "benchblock", str(time_steps)], env=env, capture_output=True, timeout=1200)
     if r.returncode != 0:
         return {"unavailable": "shim_check_cd failed: " + r.stderr.decode()[-300:]}
@@ -440,8 +440,8 @@ def main():
         # what actually runs, rank by rank, as the engine and the runtime report it (not what the command line asked for)
         import ctypes as _Cd
         sim.prepare()
-        di = (_Cd.c_int64 * 12)()
-        if capi.lib().mistark_dist_info(sim.engine_handle(), di, 12) != 0:
+        di = (_Cd.c_int64 * 13)()
+        if capi.lib().mistark_dist_info(sim.engine_handle(), di, 13) != 0:
             raise RuntimeError(capi.lib().mistark_last_error(sim.engine_handle()))
         props = torch.cuda.get_device_properties(device)
         mine = {"rank": rank, "local_rank": local_rank, "pid": os.getpid(), "device": device, "device_name": props.name,
@@ -522,6 +522,13 @@ def main():
     info = sim.info()
     stage = {k: getattr(info, "total_" + k + "_time") - getattr(info0, "total_" + k + "_time") for k in ["newton", "linear_solve", "eval_pgh", "eval_p", "project", "assembly", "callback", "step"]}
     contact_info = sim.contact_info() if a.scene == "contact" else None
+    if world > 1 and ranks_seen is not None:
+        import ctypes as _Cd2
+        di2 = (_Cd2.c_int64 * 13)()
+        capi.lib().mistark_dist_info(sim.engine_handle(), di2, 13)
+        counts = allgather_bytes((int(di2[12]), int(di2[6]), int(di2[7])))
+        for r, (ns, nf, nu) in zip(ranks_seen, counts):
+            r.update(contact_searches_with_the_sweep_dealt_out=ns, linear_solves_fused_iteration=nf, linear_solves_five_launch_iteration=nu)
     secondary = None
     if world > 1 and secondary_wanted:
         if comm is None:
@@ -578,7 +585,7 @@ def main():
                 "step": "one Newton iteration (contact detection, eval P+g+H, assembly, block-Jacobi PCG, intersection check, line search)",
                 "parallelism": "single GPU" if world == 1 else ("block rows partitioned over %d GPUs; every rank evaluates the elements touching its rows (interface elements on both sides) and assembles "
                                                                    "and solves its rows: row-sharded block-Jacobi PCG, ghosts of p and the dot products exchanged %s "
-                                                                   "in every iteration; state, line search and contact detection replicated" %
+                                                                   "in every iteration; the contact search's sweep dealt out to the ranks (keys all-gathered); state, line search, box sort and table routing replicated" %
                                                                    (world, "by stores into the peers' IPC windows (hipIpc; 8-byte tagged granules, no library call)" if transport == "ipc" else "by ncclAllGather (RCCL over xGMI)")),
                 "transport": transport,
                 # wall time of one all-gather of 1024 doubles through the windows in a train of 50 enqueued back to back (push kernel + polling

@@ -368,10 +368,10 @@ int mistark_dist_set_row_coords(mistark_ctx* ctx, const double* xyz, int64_t n_b
 /* Block rows that potentials with device-side connectivity may reference on any rank; every rank keeps them as ghosts. The contact system
  * registers the collision vertices of its deformable meshes itself; small DoF sets (rigid bodies) are always shared. */
 int mistark_dist_add_shared_rows(mistark_ctx* ctx, const int32_t* rows, int64_t n);
-/* out[0..12): block rows owned by this rank, ghosts, rows it sends, elements it evaluates, blocks of its static / contact matrix part, linear
+/* out[0..13): block rows owned by this rank, ghosts, rows it sends, elements it evaluates, blocks of its static / contact matrix part, linear
  * solves that took the fused iteration (one exposed exchange, ranks exchanging through windows) and the five-launch one; [8] world and [9] rank
  * of the context, [10] transport (0 none, 1 in-process group, 2 RCCL, 3 IPC windows), [11] ranks the transport itself counts (RCCL:
- * ncclCommCount of the communicator) */
+ * ncclCommCount of the communicator), [12] contact searches whose sweep was dealt out to the ranks (keys all-gathered and merged) */
 int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n);
 int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner);
 /* ---- IPC windows: one process per rank, no library in the data path -----------------------------------------------------------------

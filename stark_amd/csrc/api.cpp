@@ -991,9 +991,10 @@ int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n)
     Context& c = ctx->c;
     if (!out && n > 0) throw Error("mistark_dist_info: null output");
     prepare(c);
-    const int64_t v[12] = {c.world > 1 ? c.sh.n_own : c.nbr, c.world > 1 ? c.sh.n_ghost : 0, c.world > 1 ? c.sh.n_send : 0, (int64_t)c.n_elem_total, c.part[0].nnzb, c.part[1].nnzb,
-                           c.n_fused_solves, c.n_unfused_solves, c.world, c.rank, c.coll ? c.coll->transport_id() : 0, c.coll ? c.coll->transport_ranks() : 1};
-    for (int i = 0; i < n && i < 12; i++) out[i] = v[i];
+    const int64_t v[13] = {c.world > 1 ? c.sh.n_own : c.nbr, c.world > 1 ? c.sh.n_ghost : 0, c.world > 1 ? c.sh.n_send : 0, (int64_t)c.n_elem_total, c.part[0].nnzb, c.part[1].nnzb,
+                           c.n_fused_solves, c.n_unfused_solves, c.world, c.rank, c.coll ? c.coll->transport_id() : 0, c.coll ? c.coll->transport_ranks() : 1,
+                           contact_sharded_searches(c)};
+    for (int i = 0; i < n && i < 13; i++) out[i] = v[i];
     API_END(0)
 }
 int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner)
@@ -1163,6 +1164,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "spmv_variant") ctx->c.spmv_variant = value;
     else if (n == "proj_variant") ctx->c.proj_variant = value;
     else if (n == "no_contact_cache") ctx->c.no_contact_cache = value != 0;
+    else if (n == "no_sharded_search") ctx->c.no_sharded_search = value != 0;
     else if (n == "no_row_order") { ctx->c.no_row_order = value != 0; ctx->c.perm_sig.clear(); ctx->c.layout_dirty = true; }  // one GPU: the caller's row numbering in the solver, too
     else if (n == "row_order") { ctx->c.row_order_mode = value; ctx->c.perm_sig.clear(); ctx->c.layout_dirty = true; }
     else if (n == "atomic_projection") ctx->c.atomic_projection = value != 0;

@@ -676,13 +676,15 @@ __device__ __forceinline__ int sweep_scan(const ContactDev& d, const Bands& B, c
 template <bool PROXIMITY, bool FRICTION>
 __global__ __launch_bounds__(CB) void k_sweep(ContactDev d, Bands B, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const float* __restrict__ s_lo,
                                               const int* __restrict__ seg, int pt_on, int ee_on, double enl2, uint64_t* __restrict__ keys, int* __restrict__ counters, int key_cap,
-                                              int* __restrict__ task_count, int* __restrict__ tasks)
+                                              int* __restrict__ task_count, int* __restrict__ tasks, int shard_rank, int shard_world)
 {
     constexpr int SUB = SWEEP_SUB;
     __shared__ uint64_t q_buf[CB / 64][SWEEP_QUEUE];
     WaveQueue q{q_buf[threadIdx.x >> 6], 0};
     const int lane = threadIdx.x & 63, sl = lane & (SUB - 1), gb = lane & ~(SUB - 1);
-    const int sp = blockIdx.x * (CB / SUB) + threadIdx.x / SUB;
+    // (sharded search: the workgroups of the full grid are dealt out to the ranks round robin — neighbouring workgroups hold entries of the same
+    // class and band, so every rank gets its share of points, triangles and edges)
+    const int sp = (blockIdx.x * shard_world + shard_rank) * (CB / SUB) + threadIdx.x / SUB;
     SweepEntry E{};
     bool valid = sp < seg[3 * NBANDS];
     if (valid) valid = sweep_entry<PROXIMITY>(d, B, sidx, s_aabb, seg, sp, pt_on, ee_on, E);
@@ -913,6 +915,10 @@ struct ContactSystem
     std::vector<std::pair<int, int>> disabled_pairs;
     bool meshes_dirty = true;
     bool pt_enabled = true, ee_enabled = true;
+    // sharded search (merge_sharded_search): keys per rank in the exchange, its buffers, how many searches took it
+    int shard_k = 0;
+    DevBuf<double> shard_send, shard_recv;
+    int64_t n_sharded_searches = 0;
 
     DevBuf<int32_t> cv_src, cv_mesh, tri, tri_mesh, edge, edge_mesh, mesh_kind, mesh_idx;
     DevBuf<uint8_t> disabled;
@@ -978,6 +984,7 @@ struct ContactSystem
 };
 // sharded runs: the block rows contact potentials may reference (the collision vertices of the deformable meshes; rigid bodies are small DoF
 // sets, shared anyway). Every rank keeps them as ghosts (shard.hip).
+int64_t contact_sharded_searches(const Context& c) { return c.contact ? c.contact->n_sharded_searches : 0; }
 void contact_shared_rows(Context& c, std::vector<int32_t>& rows)
 {
     if (!c.contact) return;
@@ -1220,6 +1227,72 @@ size_t initial_key_cap()
     }
     return (size_t)1 << 18;
 }
+// ---- the search of a row-sharded problem (SURVEY 8e "shard by spatial cell") -----------------------------------------------
+// The box list is built and sorted by every rank (a dozen small launches over the collision surface), but the SWEEP — the narrow phase of every
+// candidate pair, the bulk of a search's kernel time — is dealt out: rank r runs every world-th workgroup of the sweep's grid and finds its share
+// of the pairs. One all-gather brings every rank's keys (and its intersection count) to every rank; merged in rank order and sorted like the
+// single rank's list, they give every rank the same tables. Per-rank capacity of the exchange: cs.shard_k keys (grown, and the search repeated,
+// when a rank finds more).
+bool search_is_sharded(const Context& c, const ContactSystem& cs) { return c.world > 1 && c.coll != nullptr && !c.no_sharded_search && !cs.brute_force; }
+__global__ __launch_bounds__(CB) void k_shard_pack(const uint64_t* __restrict__ keys, const int* __restrict__ counters, int K, int key_cap, double* __restrict__ send)
+{
+    const int n = min(min(counters[0], key_cap), K);
+    for (int i = blockIdx.x * CB + threadIdx.x; i < K + 2; i += gridDim.x * CB) {
+        if (i == 0) send[0] = (double)counters[0];
+        else if (i == 1) send[1] = (double)counters[1];
+        else send[i] = i - 2 < n ? __longlong_as_double((long long)keys[i - 2]) : 0.0;
+    }
+}
+// keys of all ranks, rank after rank, into the key list; counters[0] = their number, counters[1] = the ranks' intersection hits,
+// counters[57] = 1 when a rank had more keys than fit its slot
+__global__ __launch_bounds__(CB) void k_shard_merge(const double* __restrict__ recv, int W, int K, uint64_t* __restrict__ keys, int key_cap, int* __restrict__ counters)
+{
+    __shared__ int off[MAX_IPC_RANKS + 1];
+    __shared__ int over;
+    if (threadIdx.x == 0) {
+        int at = 0, hits = 0, ov = 0;
+        for (int r = 0; r < W; r++) {
+            off[r] = at;
+            const int cnt = (int)recv[(size_t)r * (K + 2)];
+            hits += (int)recv[(size_t)r * (K + 2) + 1];
+            if (cnt > K) ov = 1;
+            at += cnt;
+        }
+        off[W] = at;
+        over = ov;
+        if (blockIdx.x == 0) {
+            counters[0] = at;
+            counters[1] = hits;
+            counters[57] = ov;
+        }
+    }
+    __syncthreads();
+    if (over) return;
+    for (int t = blockIdx.x * CB + threadIdx.x; t < W * K; t += gridDim.x * CB) {
+        const int r = t / K, i = t - r * K;
+        if (i < off[r + 1] - off[r] && off[r] + i < key_cap) keys[off[r] + i] = (uint64_t)__double_as_longlong(recv[(size_t)r * (K + 2) + 2 + i]);
+    }
+}
+void merge_sharded_search(Context& c, ContactSystem& cs)
+{
+    if (!search_is_sharded(c, cs)) return;
+    if (c.world > MAX_IPC_RANKS) throw Error("sharded contact search: too many ranks");
+    if (cs.shard_k == 0) cs.shard_k = 8192;
+    const int K = cs.shard_k, W = c.world;
+    cs.shard_send.ensure((size_t)K + 2);
+    cs.shard_recv.ensure((size_t)W * (K + 2));
+    hipLaunchKernelGGL(k_shard_pack, dim3(std::min((K + 2 + CB - 1) / CB, 256)), dim3(CB), 0, c.stream, (const uint64_t*)cs.keys.p, (const int*)cs.counters.p, K, (int)cs.key_cap, cs.shard_send.p);
+    c.coll->allgather_f64(cs.shard_send.p, cs.shard_recv.p, (size_t)K + 2, c.stream);
+    hipLaunchKernelGGL(k_shard_merge, dim3(std::min((W * K + CB - 1) / CB, 256)), dim3(CB), 0, c.stream, (const double*)cs.shard_recv.p, W, K, cs.keys.p, (int)cs.key_cap, cs.counters.p);
+    cs.n_sharded_searches++;
+}
+// after the read-back of a search's counters: a rank's keys did not fit its slot of the exchange -> larger slots, search again
+bool sharded_search_overflowed(Context& c, ContactSystem& cs, const int* h)
+{
+    if (!search_is_sharded(c, cs) || !h[57]) return false;
+    cs.shard_k = std::max(2 * cs.shard_k, 2 * (h[0] / std::max(c.world, 1)) + 1024);
+    return true;
+}
 template <bool PROX, bool FR>
 void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, double enl2, bool reset_tasks = false)
 {
@@ -1229,8 +1302,11 @@ void launch_sweep(Context& c, ContactSystem& cs, const ContactDev& d, double enl
     int* task_count = cs.counters.p + 56;
     if (reset_tasks) fill_async(c.stream, task_count, 0, sizeof(int));
     const int pt_on = (int)(cs.pt_enabled && cs.n_t > 0), ee_on = (int)(cs.ee_enabled && cs.n_e > 1);
-    hipLaunchKernelGGL((k_sweep<PROX, FR>), dim3((cs.bp_cap + CB / SWEEP_SUB - 1) / (CB / SWEEP_SUB)), dim3(CB), 0, c.stream, d, cs.bands, cs.s_idx, (const float*)cs.s_aabb.p, (const float*)cs.s_lo.p,
-                       (const int*)cs.seg.p, pt_on, ee_on, enl2, cs.keys.p, cs.counters.p, (int)cs.key_cap, task_count, cs.sweep_tasks.p);
+    const bool sharded = search_is_sharded(c, cs);
+    const int W = sharded ? c.world : 1, me = sharded ? c.rank : 0;
+    const int wgs = (cs.bp_cap + CB / SWEEP_SUB - 1) / (CB / SWEEP_SUB);
+    hipLaunchKernelGGL((k_sweep<PROX, FR>), dim3((wgs + W - 1) / W), dim3(CB), 0, c.stream, d, cs.bands, cs.s_idx, (const float*)cs.s_aabb.p, (const float*)cs.s_lo.p,
+                       (const int*)cs.seg.p, pt_on, ee_on, enl2, cs.keys.p, cs.counters.p, (int)cs.key_cap, task_count, cs.sweep_tasks.p, me, W);
     hipLaunchKernelGGL((k_sweep_tasks<PROX, FR>), dim3(SWEEP_TASK_WAVES / (CB / 64)), dim3(CB), 0, c.stream, d, cs.bands, cs.s_idx, (const float*)cs.s_aabb.p, (const int*)cs.seg.p, pt_on,
                        ee_on, enl2, cs.keys.p, cs.counters.p, (int)cs.key_cap, (const int*)task_count, (const int*)cs.sweep_tasks.p);
 }
@@ -1312,6 +1388,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
             cs.bp_enl = enl_f;
             if (friction) launch_sweep<true, true>(c, cs, d, enl * enl);
             else launch_sweep<true, false>(c, cs, d, enl * enl);
+            merge_sharded_search(c, cs);
         } else {
         if (cs.pt_enabled && cs.n_t > 0) {
             const int chunk = chunk_for(cs.n_v, cs.n_t);
@@ -1334,6 +1411,7 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
         fetch(c, h, cs.counters.p, 64 * sizeof(int));
         lap(2);
         n = h[0];
+        if (sharded_search_overflowed(c, cs, h)) continue;
         if (!cs.brute_force && h[51] > cs.bp_cap) {  // (counters[48 + 3]) the banded box list did not fit: grow and search again
             cs.bp_cap = h[51] + h[51] / 4;
             cs.bp_valid = false;
@@ -1466,12 +1544,18 @@ int64_t count_intersections_uncached(Context& c, double dt)
                 const bool compare = cs.n_prev >= 0;
                 if (compare) cs.prev.ensure(std::max<size_t>((size_t)cs.n_prev, 1));
                 launch_sweep<true, false>(c, cs, d, enl * enl, /*reset_tasks=*/true);
+                merge_sharded_search(c, cs);
                 n_pad = padded_key_count(cs);
                 hipLaunchKernelGGL(k_pad_keys, dim3((n_pad + CB - 1) / CB), dim3(CB), 0, c.stream, cs.keys.p, (const int*)cs.counters.p, n_pad);
                 sorted = sort_and_bound(c, cs, n_pad, (const int*)cs.counters.p, compare);
             }
+            if (!speculate) merge_sharded_search(c, cs);  // (the ranks' intersection counts; with speculation the merge above carried them)
             int hb[64];
             fetch(c, hb, cs.counters.p, sizeof(hb));
+            if (sharded_search_overflowed(c, cs, hb)) {
+                fill_async(c.stream, cs.counters.p, 0, 64 * sizeof(int));
+                continue;
+            }
             if (hb[51] > cs.bp_cap) {
                 cs.bp_cap = hb[51] + hb[51] / 4;
                 cs.bp_valid = false;

@@ -434,6 +434,7 @@ struct Context
                 n_prelaunch_dropped++;
             }
     }
+    bool no_sharded_search = false; // option "no_sharded_search": every rank of a sharded problem sweeps all candidate pairs itself (cross-check)
     bool no_contact_cache = false;  // option "no_contact_cache": every detection request runs the search (cross-check)
     size_t h_scratch_n = 0;
 
@@ -568,6 +569,7 @@ void graph_partition_rows(int64_t n_block_rows, int world, const std::vector<Ele
 void static_graph_order(Context& c, std::vector<int32_t>& rows_in_order);  // shard.hip
 void ensure_pattern(Context& c);
 void contact_destroy(struct ContactSystem* cs);
+int64_t contact_sharded_searches(const Context& c);  // searches of a sharded problem whose sweep was dealt out to the ranks (contact.hip)
 void contact_shared_rows(Context& c, std::vector<int32_t>& rows);  // contact.hip
 int register_potential(Context& c, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings);
 void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs = nullptr, bool lazy = false);

@@ -99,6 +99,8 @@ def test_plain_bench_command_launches_its_own_ranks(single, n):
     assert [s["rank"] for s in seen] == list(range(n)) and len({s["pid"] for s in seen}) == n
     assert all(s["engine_world"] == n and s["engine_rank"] == s["rank"] and s["transport"] == "ipc" and s["transport_ranks"] == n for s in seen)
     assert out["config"]["distinct_devices"] == 1 and out["config"]["ranks_on_one_device"]   # (this box has one GPU; the line says so)
+    # every search's sweep was dealt out to the ranks, every solve took the fused iteration: and the counts below are the one-rank run's
+    assert all(s["contact_searches_with_the_sweep_dealt_out"] > 0 and s["linear_solves_five_launch_iteration"] == 0 for s in seen)
     assert sum(s["rows_owned"] for s in seen) == 13 ** 3 + 12 ** 3 + 2   # every block row has exactly one owner (nodes + hexahedron centres + the box's v, w)
     assert out["newton_iterations"] == single["newton_iterations"] == 8
     assert out["linear_solves"] == single["linear_solves"]
