@@ -113,8 +113,9 @@ def test_plain_bench_command_refuses_more_ranks_than_gpus():
     env.pop("MISTARK_BENCH_DEVICE")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    import torch
-    n = torch.cuda.device_count() + 1
+    # (the count comes from a child process: importing torch HERE would load its bundled ROCm libraries into the test process, and the RCCL
+    # round trip of tests/test_gpu_sharded.py, which dlopens librccl later in the same process, then fails)
+    n = int(subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, timeout=300).stdout.decode().strip().splitlines()[-1]) + 1
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + ARGS, cwd=ROOT, env=env, capture_output=True, timeout=300)
     assert r.returncode != 0 and b"GPU(s) visible" in r.stderr and not [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
 
