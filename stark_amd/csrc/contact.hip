@@ -428,6 +428,8 @@ __global__ __launch_bounds__(CB) void k_detect_et(ContactDev d, int chunk, int* 
 constexpr int NBANDS = MISTARK_NBANDS;
 constexpr int band_key_bits() { int b = 1; while ((1 << b) <= 3 * NBANDS) b++; return b; }  // (class, band) above the 32-bit sort coordinate; all ones = padding
 constexpr int BAND_KEY_BITS = band_key_bits();
+static_assert(NBANDS <= (1 << (32 - PRIM_BITS)), "the band of a sorted entry shares its 32-bit index word with the primitive");
+constexpr uint32_t SIDX_PRIM = (1u << PRIM_BITS) - 1u;
 struct Bands
 {
     int axis, band_axis;
@@ -466,7 +468,7 @@ __global__ __launch_bounds__(CB) void k_bp_fill(ContactDev d, Bands B, const uin
         const uint32_t e = off[i] + (uint32_t)(k - b0);
         if (e < (uint32_t)cap) {
             keys[e] = ((cls * NBANDS + (uint64_t)k) << 32) | fk;
-            idx[e] = (uint32_t)i;
+            idx[e] = (uint32_t)i | ((uint32_t)k << PRIM_BITS);  // (the entry's band rides along: sweep_entry needs it and would otherwise walk the segment starts)
         }
     }
     // the unused tail of the list: padding entries that sort last (a fill command of its own was one more launch in every search)
@@ -482,10 +484,142 @@ __global__ __launch_bounds__(CB) void k_bp_gather(ContactDev d, Bands B, const u
     const int prev = j > 0 ? (int)min((uint64_t)(3 * NBANDS), (skeys[j - 1] >> 32) & ((1ull << BAND_KEY_BITS) - 1)) : -1;
     for (int t = prev + 1; t <= here; t++) seg[t] = j;
     if (j >= cap || here >= 3 * NBANDS) return;
-    const float* b = d.aabb + 6 * (size_t)sidx[j];
+    const float* b = d.aabb + 6 * (size_t)(sidx[j] & SIDX_PRIM);
 #pragma unroll
     for (int k = 0; k < 6; k++) s_aabb[6 * (size_t)j + k] = b[k];
     s_lo[j] = b[B.axis];
+}
+// ---- the sorted box list without a general sort (round 4) ---------------------------------------------------------------------------------
+// The list is 3 * NBANDS segments (class, band), each sorted by the lower bound along the sweep axis. The radix sort of 41-bit keys that used to
+// produce it was ten launches of the sorting library plus two scans and two fills around it — the longest piece of a search's launch chain (a
+// search is ~35 dependent launches of ~5 us whatever their size). Three launches do the same: k_bp_hist counts the entries of every segment
+// (LDS histograms, one global atomic per workgroup and touched segment), k_bp_scatter drops every entry {order-preserving lower bound, primitive}
+// into its segment (positions from LDS ranks inside a range the workgroup reserved: any order), k_seg_sort sorts each segment in LDS by one
+// workgroup quartet (rank sort; the primitive index breaks ties, which is the order the stable radix sort left) and writes the sweep's inputs (sorted
+// boxes, lower bounds, index words, segment starts) itself. A segment beyond SEG_SORT_MAX entries raises counters[58]: the host falls back to
+// the library sort for good.
+// MEASURED (configs[3], 69 k boxes, segments of 700-2100 entries; option "seg_sort"): not a win, OFF by default. The rank sort reads n keys out
+// of LDS per entry — a broadcast read still occupies the LDS pipeline for a whole wavefront — 227 us; a bitonic network in LDS with 1024 threads
+// 78 us (55-105 barrier-separated steps); the library's radix sort chain ~70 us of kernels. And the search's wait did not move when the sort took
+// 78 instead of 70 us in a third of the launches (5.1 against 4.9 ms over 38 searches): the chain is bound by the sweeps (63-89 us + 10-20 us
+// each) and the read-back, not by launch count. Kept as a cross-check of the sorted list (identical tables, tests/test_gpu_contact.py).
+constexpr int N_SEG = 3 * NBANDS;
+constexpr int SEG_SORT_MAX = 8192;
+constexpr int SEG_SORT_THREADS = 1024;
+__device__ __forceinline__ int seg_of_box(const ContactDev& d, int i) { return i < d.n_v ? 0 : (i < d.n_v + d.n_t ? 1 : 2); }
+__global__ __launch_bounds__(CB) void k_bp_hist(ContactDev d, Bands B, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t sh[N_SEG];
+    for (int t = threadIdx.x; t < N_SEG; t += CB) sh[t] = 0u;
+    __syncthreads();
+    const int i = blockIdx.x * CB + threadIdx.x;
+    const int n = d.n_v + d.n_t + d.n_e;
+    if (i < n) {
+        const float* b = d.aabb + 6 * (size_t)i;
+        const int b0 = band_of(B, b[B.band_axis]), b1 = band_of(B, b[3 + B.band_axis]), cls = seg_of_box(d, i);
+        for (int k = b0; k <= b1; k++) atomicAdd(&sh[cls * NBANDS + k], 1u);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < N_SEG; t += CB)
+        if (sh[t]) atomicAdd(&hist[t], sh[t]);
+}
+// hist -> segment starts (every workgroup scans the 192 counts itself); cursor[seg] = entries handed out so far
+__global__ __launch_bounds__(CB) void k_bp_scatter(ContactDev d, Bands B, const uint32_t* __restrict__ hist, uint32_t* __restrict__ cursor, uint64_t* __restrict__ ekeys, int cap,
+                                                  int* __restrict__ counters)
+{
+    __shared__ uint32_t start[N_SEG + 1], cnt[N_SEG], rank[N_SEG], base[N_SEG];
+    // (every thread fetches one count, then sums the counts before its own out of LDS: a single thread walking the 192 counts in global memory
+    // was a chain of dependent loads at the head of every workgroup)
+    for (int t = threadIdx.x; t < N_SEG; t += CB) {
+        base[t] = hist[t];
+        cnt[t] = rank[t] = 0u;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t <= N_SEG; t += CB) {
+        uint32_t at = 0;
+        for (int u = 0; u < t; u++) at += base[u];
+        start[t] = at;
+        if (t == N_SEG && blockIdx.x == 0) counters[3] = (int)at;  // number of entries (the host checks it against the capacity)
+    }
+    __syncthreads();
+    const int i = blockIdx.x * CB + threadIdx.x;
+    const int n = d.n_v + d.n_t + d.n_e;
+    int b0 = 0, b1 = -1, cls = 0;
+    uint32_t fk = 0u;
+    if (i < n) {
+        const float* b = d.aabb + 6 * (size_t)i;
+        b0 = band_of(B, b[B.band_axis]);
+        b1 = band_of(B, b[3 + B.band_axis]);
+        cls = seg_of_box(d, i);
+        fk = float_key(b[B.axis]);
+    }
+    // the workgroup's entries per segment (LDS atomics), one global reservation per touched segment, then the stores at LDS ranks inside it
+    for (int k = b0; k <= b1; k++) atomicAdd(&cnt[cls * NBANDS + k], 1u);
+    __syncthreads();
+    for (int t = threadIdx.x; t < N_SEG; t += CB) base[t] = cnt[t] ? atomicAdd(&cursor[t], cnt[t]) : 0u;
+    __syncthreads();
+    for (int k = b0; k <= b1; k++) {
+        const int sg = cls * NBANDS + k;
+        const uint32_t pos = start[sg] + base[sg] + atomicAdd(&rank[sg], 1u);
+        if (pos < (uint32_t)cap) ekeys[pos] = ((uint64_t)fk << 32) | (uint64_t)(uint32_t)i;
+    }
+}
+constexpr int SEG_PARTS = 4;  // workgroups per segment: each ranks a quarter of the segment's entries against all of them
+__global__ __launch_bounds__(SEG_SORT_THREADS) void k_seg_sort(ContactDev d, Bands B, const uint32_t* __restrict__ hist, const uint64_t* __restrict__ ekeys, int cap,
+                                                             uint32_t* __restrict__ sidx, float* __restrict__ s_aabb, float* __restrict__ s_lo, int* __restrict__ seg,
+                                                             int* __restrict__ counters)
+{
+    __shared__ uint64_t sh[SEG_SORT_MAX];
+    __shared__ uint32_t hs[N_SEG];
+    __shared__ uint32_t s_start, s_n, s_total;
+    const int sg = blockIdx.x / SEG_PARTS, part = blockIdx.x % SEG_PARTS;
+    for (int t = threadIdx.x; t < N_SEG; t += SEG_SORT_THREADS) hs[t] = hist[t];
+    __syncthreads();
+    if (threadIdx.x < 64) {  // one wavefront adds the counts before this segment and all of them
+        uint32_t before = 0, all = 0;
+        for (int t = threadIdx.x; t < N_SEG; t += 64) {
+            all += hs[t];
+            if (t < sg) before += hs[t];
+        }
+        for (int dd = 32; dd >= 1; dd >>= 1) {
+            before += __shfl_down(before, dd, 64);
+            all += __shfl_down(all, dd, 64);
+        }
+        if (threadIdx.x == 0) {
+            s_start = before;
+            s_n = hs[sg];
+            s_total = all;
+            if (part == 0) seg[sg] = (int)before;
+            if (blockIdx.x == 0) seg[N_SEG] = all > (uint32_t)cap ? 0 : (int)all;  // (a list that did not fit is not swept: the host grows it and searches again)
+        }
+    }
+    __syncthreads();
+    const uint32_t start = s_start, n = s_n;
+    if (s_total > (uint32_t)cap) return;  // (the list did not fit: the host grows it and searches again)
+    if (n > (uint32_t)SEG_SORT_MAX) {
+        if (threadIdx.x == 0) counters[58 - 48] = 1;  // (counters = the search's counters + 48)
+        return;
+    }
+    if (n == 0) return;
+    // Rank sort: the whole segment in LDS, every thread counts the keys below its own (all lanes read the same LDS word: a broadcast, no
+    // barrier behind the load). The keys are distinct (the primitive breaks ties), so the rank is the sorted position — the order the stable
+    // radix sort left. A few hundred to a few thousand entries per segment: n^2 / 4096 LDS reads per thread.
+    for (uint32_t t = threadIdx.x; t < n; t += SEG_SORT_THREADS) sh[t] = ekeys[start + t];
+    __syncthreads();
+    const uint32_t band = (uint32_t)(sg % NBANDS);
+    const uint32_t per = (n + SEG_PARTS - 1) / SEG_PARTS, t_begin = (uint32_t)part * per, t_end = min(n, t_begin + per);
+    for (uint32_t t = t_begin + threadIdx.x; t < t_end; t += SEG_SORT_THREADS) {
+        const uint64_t mine = sh[t];
+        uint32_t r = 0;
+        for (uint32_t u = 0; u < n; u++) r += sh[u] < mine ? 1u : 0u;
+        const uint32_t prim = (uint32_t)(mine & 0xffffffffull);
+        const float* b = d.aabb + 6 * (size_t)prim;
+        const size_t j = (size_t)start + r;
+        sidx[j] = prim | (band << PRIM_BITS);
+#pragma unroll
+        for (int c = 0; c < 6; c++) s_aabb[6 * j + c] = b[c];
+        s_lo[j] = b[B.axis];
+    }
 }
 // Binary search of the sorted lower bounds by a whole wavefront: every step probes 64 evenly spaced positions at once, so a range of n entries is
 // narrowed in log64(n) dependent loads instead of log2(n) (a sweep entry spent most of its time in these chains). STRICT: count the
@@ -542,7 +676,8 @@ template <bool PROXIMITY>
 __device__ __forceinline__ bool sweep_entry(const ContactDev& d, const Bands& B, const uint32_t* __restrict__ sidx, const float* __restrict__ s_aabb, const int* __restrict__ seg, int sp,
                                             int pt_on, int ee_on, SweepEntry& E)
 {
-    const int gi = (int)sidx[sp];  // primitive (points | triangles | edges numbering)
+    const uint32_t sw = sidx[sp];
+    const int gi = (int)(sw & SIDX_PRIM);  // primitive (points | triangles | edges numbering)
     E.cls = gi < d.n_v ? 0 : (gi < d.n_v + d.n_t ? 1 : 2);
     if (PROXIMITY) {
         if (E.cls == 2 ? !ee_on : !pt_on) return false;
@@ -556,10 +691,9 @@ __device__ __forceinline__ bool sweep_entry(const ContactDev& d, const Bands& B,
     E.a1 = (ax + 1) % 3;
     E.a2 = (ax + 2) % 3;
     E.lo = sb[ax]; E.hi = sb[3 + ax]; E.lo1 = sb[E.a1]; E.hi1 = sb[3 + E.a1]; E.lo2 = sb[E.a2]; E.hi2 = sb[3 + E.a2];
-    // which band is this entry? the entries of a box are consecutive bands starting at its first one; recover it from the segment
+    // which band is this entry? the entries of a box are consecutive bands starting at its first one; k_bp_fill left it in the index word
     E.b_first = band_of(B, sb[B.band_axis]);
-    E.band = E.b_first;
-    while (E.band < NBANDS - 1 && sp >= seg[E.cls * NBANDS + E.band + 1]) E.band++;
+    E.band = (int)(sw >> PRIM_BITS);
     const int src_start = E.cls == 0 ? 0 : (E.cls == 1 ? d.n_v : d.n_v + d.n_t);
     E.tgt_start = E.tc == 0 ? 0 : (E.tc == 1 ? d.n_v : d.n_v + d.n_t);
     E.src = gi - src_start;
@@ -649,7 +783,7 @@ __device__ __forceinline__ int sweep_scan(const ContactDev& d, const Bands& B, c
             if (E.lo1 <= tb[3 + E.a1] && tb[E.a1] <= E.hi1 && E.lo2 <= tb[3 + E.a2] && tb[E.a2] <= E.hi2) {
                 const int tb_first = band_of(B, tb[B.band_axis]);
                 if (E.band == (E.b_first > tb_first ? E.b_first : tb_first)) {  // the pair is reported in its first common band only
-                    const int tgt = (int)sidx[j] - E.tgt_start, src = E.src;
+                    const int tgt = (int)(sidx[j] & SIDX_PRIM) - E.tgt_start, src = E.src;
                     has = true;
                     if (PROXIMITY) {
                         if (E.cls == 0) pr = pack_pair(0, src, tgt);
@@ -690,11 +824,40 @@ __global__ __launch_bounds__(CB) void k_sweep(ContactDev d, Bands B, const uint3
     if (valid) valid = sweep_entry<PROXIMITY>(d, B, sidx, s_aabb, seg, sp, pt_on, ee_on, E);
     int j0 = 0, j_own = 0, r0 = 0, r1 = 0;  // own range [j0, j_own), remainder of a long range that found no room in the task list [r0, r1)
     if (valid) {  // (uniform within a group of SUB lanes: the searches' ballots see whole groups)
+        const unsigned long long gmask = SUB == 64 ? ~0ull : ((1ull << SUB) - 1ull);
         const int t_begin = seg[E.tc * NBANDS + E.band], t_end = seg[E.tc * NBANDS + E.band + 1];
         if (E.cls == 2 && E.tc == 2) j0 = sp + 1;                                   // later edges of the same segment
-        else if (E.cls == 0 || (!PROXIMITY && E.cls == 2)) j0 = wave_bound_f<true, SUB>(s_lo, t_begin, t_end, E.lo);  // target lo in [lo, hi]
-        else j0 = wave_bound_f<false, SUB>(s_lo, t_begin, t_end, E.lo);                       // target lo in (lo, hi]: the other direction took ties
-        const int j1 = wave_bound_f<false, SUB>(s_lo, j0 > t_begin ? j0 : t_begin, t_end, E.hi);
+        else {
+            // Both segments — the entry's own and its targets' — are sorted by the lower bound along the sweep axis over the same band, so
+            // the entry's relative position in its segment is where its range starts in the other one, give or take a few entries: ONE probe of
+            // SUB consecutive lower bounds around that position finds the bound exactly (a[j - 1] < v <= a[j] is seen inside the window) for
+            // almost every entry of a mesh; the SUB-ary search (three dependent loads on a 3 k-entry segment) remains for the others.
+            const bool strict = E.cls == 0 || (!PROXIMITY && E.cls == 2);  // target lo in [lo, hi] / in (lo, hi]: the other direction took ties
+            const int o_begin = seg[E.cls * NBANDS + E.band], o_end = seg[E.cls * NBANDS + E.band + 1];
+            const int n_own = o_end - o_begin > 1 ? o_end - o_begin : 1;
+            int g = t_begin + (int)((long long)(sp - o_begin) * (long long)(t_end - t_begin) / n_own) - SUB / 2;
+            if (g > t_end - SUB) g = t_end - SUB;
+            if (g < t_begin) g = t_begin;
+            bool below = false;
+            if (g + sl < t_end) {
+                const float x = s_lo[g + sl];
+                below = strict ? (x < E.lo) : (x <= E.lo);
+            }
+            const int cb = __popcll((__ballot(below) >> gb) & gmask);
+            if ((cb > 0 || g == t_begin) && (cb < SUB || g + SUB >= t_end)) j0 = g + cb;
+            else if (strict) j0 = wave_bound_f<true, SUB>(s_lo, t_begin, t_end, E.lo);
+            else j0 = wave_bound_f<false, SUB>(s_lo, t_begin, t_end, E.lo);
+        }
+        // the end of the range: most ranges are shorter than SUB candidates — one probe of the SUB lower bounds behind j0 then holds it
+        int j1;
+        {
+            const int jb = j0 > t_begin ? j0 : t_begin;
+            bool inside = false;
+            if (jb + sl < t_end) inside = s_lo[jb + sl] <= E.hi;
+            const int ci = __popcll((__ballot(inside) >> gb) & gmask);
+            if (ci < SUB || jb + SUB >= t_end) j1 = jb + ci;
+            else j1 = wave_bound_f<false, SUB>(s_lo, jb + SUB, t_end, E.hi);
+        }
         j_own = j1;
         if (j1 - j0 > SWEEP_SPLIT) {  // long range: hand the rest out in tasks (those that fit the list; the remainder stays here)
             const int first = j0 + SWEEP_SPLIT;
@@ -930,6 +1093,8 @@ struct ContactSystem
     DevBuf<uint32_t> bp_idx, bp_idx_alt;
     DevBuf<float> s_aabb, s_lo;
     DevBuf<uint32_t> bp_cnt, bp_off;
+    DevBuf<uint32_t> bp_hist;   // entries per (class, band) segment | cursors (k_bp_hist / k_bp_scatter)
+    bool seg_sort_ok = true;    // false once a segment exceeded SEG_SORT_MAX entries (counters[58]): the library sort from then on
     DevBuf<int> seg;
     const uint32_t* s_idx = nullptr;
     Bands bands{-1, -1, 0.f, 1.f, 0.f};
@@ -1204,6 +1369,17 @@ void sort_boxes(Context& c, ContactSystem& cs, const ContactDev& d)
     cs.bp_cnt.ensure((size_t)n + 1); cs.bp_off.ensure((size_t)n + 1);
     cs.bp_keys.ensure(cap); cs.bp_keys_alt.ensure(cap); cs.bp_idx.ensure(cap); cs.bp_idx_alt.ensure(cap);
     cs.s_aabb.ensure(6 * (size_t)cap); cs.s_lo.ensure(cap); cs.seg.ensure(3 * NBANDS + 2);
+    if (cs.seg_sort_ok && c.seg_sort) {  // option: three launches instead of the library's sort and the scans around it (see k_seg_sort; measured slower)
+        cs.bp_hist.ensure(2 * (size_t)N_SEG);
+        fill_async(c.stream, cs.bp_hist.p, 0, 2 * (size_t)N_SEG * sizeof(uint32_t));
+        hipLaunchKernelGGL(k_bp_hist, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, cs.bp_hist.p);
+        hipLaunchKernelGGL(k_bp_scatter, dim3((n + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, (const uint32_t*)cs.bp_hist.p, cs.bp_hist.p + N_SEG, cs.bp_keys.p, cap,
+                           cs.counters.p + 48);
+        hipLaunchKernelGGL(k_seg_sort, dim3(N_SEG * SEG_PARTS), dim3(SEG_SORT_THREADS), 0, c.stream, d, cs.bands, (const uint32_t*)cs.bp_hist.p, (const uint64_t*)cs.bp_keys.p, cap, cs.bp_idx.p,
+                           cs.s_aabb.p, cs.s_lo.p, cs.seg.p, cs.counters.p + 48);
+        cs.s_idx = cs.bp_idx.p;
+        return;
+    }
     hipLaunchKernelGGL(k_bp_count, dim3((n + 1 + CB - 1) / CB), dim3(CB), 0, c.stream, d, cs.bands, cs.bp_cnt.p);
     size_t tmp = 0;
     MS_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, cs.bp_cnt.p, cs.bp_off.p, n + 1, c.stream));
@@ -1319,10 +1495,36 @@ int padded_key_count(const ContactSystem& cs)
 }
 // keys[0, n_sort) sorted (n_dev: the count on the device, the rest is padding), table boundaries and "same as the installed list" flag into
 // counters[8..] / counters[2]; returns the sorted list
+// The contact keys of a search (a few thousand, padded to n_sort) sorted in ONE launch: every workgroup stages all keys in LDS tile by tile and
+// every thread counts the keys that sort before its own (equal keys — the padding — by position): its rank is where it goes. The library's radix
+// sort of 64-bit keys took five launches for this.
+constexpr int RANK_SORT_MAX = 16384, RANK_TILE = 4096;
+__global__ __launch_bounds__(CB) void k_rank_sort_keys(const uint64_t* __restrict__ keys, int n, uint64_t* __restrict__ out)
+{
+    __shared__ uint64_t tile[RANK_TILE];
+    const int e = blockIdx.x * CB + threadIdx.x;
+    const uint64_t mine = e < n ? keys[e] : 0ull;
+    int r = 0;
+    for (int t0 = 0; t0 < n; t0 += RANK_TILE) {
+        const int len = min(RANK_TILE, n - t0);
+        __syncthreads();
+        for (int t = threadIdx.x; t < len; t += CB) tile[t] = keys[t0 + t];
+        __syncthreads();
+        // (keys before position e count when <=, keys behind it when <: equal keys keep their order)
+        for (int u = 0; u < len; u++) {
+            const uint64_t k = tile[u];
+            r += (k < mine || (k == mine && t0 + u < e)) ? 1 : 0;
+        }
+    }
+    if (e < n) out[r] = mine;
+}
 const uint64_t* sort_and_bound(Context& c, ContactSystem& cs, int n_sort, const int* n_dev, bool compare)
 {
     hipcub::DoubleBuffer<uint64_t> dk(cs.keys.p, cs.keys_alt.p);
-    if (n_sort > 1) {
+    if (n_sort > 1 && n_sort <= RANK_SORT_MAX && c.seg_sort) {
+        hipLaunchKernelGGL(k_rank_sort_keys, dim3((n_sort + CB - 1) / CB), dim3(CB), 0, c.stream, (const uint64_t*)cs.keys.p, n_sort, cs.keys_alt.p);
+        dk.selector = 1;
+    } else if (n_sort > 1) {
         size_t tmp = 0;
         MS_CHECK(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp, dk, n_sort, 0, 64, c.stream));
         cs.cub_tmp.ensure(tmp);
@@ -1412,6 +1614,11 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
         lap(2);
         n = h[0];
         if (sharded_search_overflowed(c, cs, h)) continue;
+        if (!cs.brute_force && h[58] && cs.seg_sort_ok) {  // a segment of the box list too long for the in-LDS sort: the library sort from now on
+            cs.seg_sort_ok = false;
+            cs.bp_valid = false;
+            continue;
+        }
         if (!cs.brute_force && h[51] > cs.bp_cap) {  // (counters[48 + 3]) the banded box list did not fit: grow and search again
             cs.bp_cap = h[51] + h[51] / 4;
             cs.bp_valid = false;
@@ -1556,6 +1763,12 @@ int64_t count_intersections_uncached(Context& c, double dt)
                 fill_async(c.stream, cs.counters.p, 0, 64 * sizeof(int));
                 continue;
             }
+            if (hb[58] && cs.seg_sort_ok) {
+                cs.seg_sort_ok = false;
+                cs.bp_valid = false;
+                fill_async(c.stream, cs.counters.p, 0, 64 * sizeof(int));
+                continue;
+            }
             if (hb[51] > cs.bp_cap) {
                 cs.bp_cap = hb[51] + hb[51] / 4;
                 cs.bp_valid = false;
@@ -1682,6 +1895,10 @@ int cd_search(StandaloneDetector& D, const ContactDev& d, bool proximity, double
             launch_sweep<false, false>(c, cs, d, -1.0);
         }
         fetch(c, h, cs.counters.p, 64 * sizeof(int));
+        if (h[58] && cs.seg_sort_ok) {
+            cs.seg_sort_ok = false;
+            continue;
+        }
         if (h[51] > cs.bp_cap) {
             cs.bp_cap = h[51] + h[51] / 4;
             continue;

@@ -434,6 +434,7 @@ struct Context
                 n_prelaunch_dropped++;
             }
     }
+    bool seg_sort = false;          // option "seg_sort": the contact search's box list and key list sorted by the engine's own kernels (k_seg_sort, k_rank_sort_keys: measured slower)
     bool no_sharded_search = false; // option "no_sharded_search": every rank of a sharded problem sweeps all candidate pairs itself (cross-check)
     bool no_contact_cache = false;  // option "no_contact_cache": every detection request runs the search (cross-check)
     size_t h_scratch_n = 0;

@@ -53,13 +53,17 @@ def build(name):
     return eng, prob, man, z, scene, st
 
 
-@pytest.mark.parametrize("broad_phase", ["sweep_and_prune", "all_pairs"])
+@pytest.mark.parametrize("broad_phase", ["sweep_and_prune", "all_pairs", "own_sorts"])
 @pytest.mark.parametrize("name", CONTACT_FIXTURES)
 def test_device_tables_match_reference(name, broad_phase):
+    """own_sorts: option seg_sort — the box list through k_bp_hist / k_bp_scatter / k_seg_sort and the contact keys through k_rank_sort_keys instead
+    of the sorting library (measured slower, off by default: a second implementation of the sorted lists the sweep walks)"""
     from stark_amd import capi
 
     eng, prob, man, z, scene, st = build(name)
     eng.contact_set_broad_phase(broad_phase == "all_pairs")
+    if broad_phase == "own_sorts":
+        assert capi.lib().mistark_set_option(eng.h, b"seg_sort", 1) == 0
     dt = float(np.asarray(st["dt"]).ravel()[0])
     n_fr = eng.contact_update_friction()
     n_ct = eng.contact_update(dt)
