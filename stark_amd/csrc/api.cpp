@@ -1166,6 +1166,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "no_contact_cache") ctx->c.no_contact_cache = value != 0;
     else if (n == "no_sharded_search") ctx->c.no_sharded_search = value != 0;
     else if (n == "seg_sort") ctx->c.seg_sort = value != 0;
+    else if (n == "proj_speculation") ctx->c.proj_speculation = value != 0;
     else if (n == "no_row_order") { ctx->c.no_row_order = value != 0; ctx->c.perm_sig.clear(); ctx->c.layout_dirty = true; }  // one GPU: the caller's row numbering in the solver, too
     else if (n == "row_order") { ctx->c.row_order_mode = value; ctx->c.perm_sig.clear(); ctx->c.layout_dirty = true; }
     else if (n == "atomic_projection") ctx->c.atomic_projection = value != 0;

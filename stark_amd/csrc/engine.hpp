@@ -371,6 +371,39 @@ struct Context
     uint32_t pub_seq = 0;
     // bumped by everything that can change what a contact detection sees (DoFs, bound arrays, layout): the detector skips a search whose
     // inputs are those of its previous one (the evaluation that opens a Newton iteration repeats the accepted line-search state)
+    // a projection round as it travels between its phases (kernels.hip: project_phase_a / _b / _c)
+    struct ProjRound
+    {
+        struct Mark  // what k_proj_mark needs of a potential's list once the eigen-decompositions have run
+        {
+            int pot;
+            const uint32_t* list;
+            int nl;
+            const double* Hc;
+            int n_pool_c;
+        };
+        std::vector<Mark> marks;
+        bool mark_part[2] = {false, false};
+    };
+    // ... and one started ahead of the solve that may need it (project_speculate)
+    struct ProjSpec
+    {
+        bool active = false;
+        int stage = 0;  // 1: phase A queued, counts on their way; 2: phase B queued
+        double threshold = 0.0, eps = 0.0;
+        int mirroring = 0;
+        hipStream_t stream = nullptr;
+        hipEvent_t ev_in = nullptr, ev_done = nullptr;
+        int64_t* pinned = nullptr;  // 128 counters + flag word, coherent host memory
+        uint32_t seq = 0;
+        int64_t h[128];
+        ProjRound round;
+        bool pending = false;  // a request pcg() takes up once its first batches are queued
+        double p_eps = 0.0, p_threshold = 0.0;
+        int p_mirroring = 0;
+    } spec;
+    bool proj_speculation = false;  // option "proj_speculation": the next projection round's selection and eigen kernels run beside the solve (measured: no gain)
+    int64_t n_proj_speculated = 0, n_proj_adopted = 0;
     uint64_t data_version = 1;
     uint64_t u_version = 1, u_host_version = 0;  // the DoF vector on the device / as last brought to the caller's arrays (mistark_dofs_to_host_arrays_if_changed)
     // Evaluation kernels of the large closed-form potentials launched AHEAD of eval() (eval_prelaunch: while the callback that precedes an
@@ -575,6 +608,13 @@ void contact_shared_rows(Context& c, std::vector<int32_t>& rows);  // contact.hi
 int register_potential(Context& c, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings);
 void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs = nullptr, bool lazy = false);
 void reduce_dot_and_max_abs(Context& c, const double* a, const double* b, int64_t n, double* dot, double* max_abs_a);
+bool project_can_speculate(const Context& c);
+void project_speculate(Context& c, double eps, int mirroring, double threshold, bool ev_in_recorded = false);
+void project_speculate_request(Context& c, double eps, int mirroring, double threshold);
+void project_speculate_pending(Context& c);
+void project_spec_poll(Context& c);
+bool project_spec_adopt(Context& c, double eps, int mirroring, double threshold, int* all_active, int64_t* n_projected_now);
+void project_spec_discard(Context& c);
 void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active,
              int64_t* n_projected_now, int64_t* n_changed_now);
 void assemble(Context& c);

@@ -3050,6 +3050,7 @@ __global__ __launch_bounds__(BLOCK) void k_active_blocks(const double* __restric
 }
 
 static void gather_part(Context& c, int part, const uint8_t* only_dirty);
+void project_spec_discard(Context& c);
 // Ordered update of the assembled matrix after a projection round (instead of float deltas added atomically in arrival order): every block
 // a selected element contributes to is flagged, and the flagged blocks are gathered again from the pools in sorted-key order (gather_part) —
 // the matrix equals the one assembled from the projected Hessians, bit for bit and run to run. For a lazy potential (float upper-triangle
@@ -3112,12 +3113,13 @@ __global__ __launch_bounds__(BLOCK) void k_proj_mark(MarkBatch mb)
     }
 }
 
-void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active, int64_t* n_projected_now,
-             int64_t* n_changed_now)
+// project() in three phases, so that a round can be started AHEAD of the solve that may need it (project_speculate below):
+//   A  selection: which rows are active (by the gradient), which elements touch them, the lists per potential — ends with the counts on the device
+//   B  (needs the counts on the host) the eigen-projections of the listed elements, in their pools; nothing of the assembled matrix is touched
+//      when the update is ordered (marks)
+//   C  the marks: projected blocks back into the float pool, the touched matrix blocks gathered again in sorted-key order; statistics
+static void project_phase_a(Context& c, const uint8_t* active_host, bool by_gradient, double threshold)
 {
-    if (c.static_assembled) MS_CHECK(hipStreamWaitEvent(c.stream, c.aux_ev[2], 0));  // (the deltas below go into the matrix the auxiliary stream is still gathering)
-    ensure_pattern(c);
-    if (!c.have_hessians) throw Error("project: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
     const int np = (int)c.pots.size();
     if (np + 4 > 128) throw Error("project: too many potentials");
     c.counters.ensure(128);
@@ -3131,79 +3133,64 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         MS_CHECK(hipMemcpyAsync(c.active_blocks.p, active_host, (size_t)c.nbr, hipMemcpyHostToDevice, c.stream));
         act = c.active_blocks.p;
     }
-    // 1) selection: per-potential lists (counter 4 + potential index); counter 3: selected elements whose energy counts on this rank
+    // selection: per-potential lists (counter 4 + potential index); counter 3: selected elements whose energy counts on this rank
     c.proj_list.ensure(2 * std::max<size_t>(c.n_elem_total, 1));
     uint32_t* list_e_base = c.proj_list.p + std::max<size_t>(c.n_elem_total, 1);
-    {
-        // (the table lives in the context: the copy below may still read it after this scope; the read-back that follows the selection
-        // orders it before the next round overwrites it)
-        c.sel_desc_host.resize((size_t)np * sizeof(SelDesc));
-        SelDesc* desc_h = reinterpret_cast<SelDesc*>(c.sel_desc_host.data());
-        int n_desc = 0;
-        int n_blocks = 0;
-        for (int pi = 0; pi < np; pi++) {
-            Potential& P = c.pots[pi];
-            if (P.args.e_count == 0) continue;
-            SelDesc d{};
-            d.conn = P.args.conn;
-            d.elem_list = P.args.elem_list;
-            d.lrow = lrow;
-            d.n_own = (int)c.sh.n_own;
-            d.is_projected = c.is_projected.p + P.e_off;
-            d.list = c.proj_list.p + P.e_off;
-            d.list_e = list_e_base + P.e_off;
-            d.conn_stride = P.args.conn_stride;
-            d.e_count = P.args.e_count;
-            d.NB = P.NB;
-            d.counter = 4 + pi;
-            d.first_block = n_blocks;
-            for (int k = 0; k < MAX_NB; k++) {
-                d.dof_col[k] = P.args.dof_col[k];
-                d.dof_row_off[k] = P.args.dof_row_off[k];
-            }
-            n_blocks += (P.args.e_count + BLOCK - 1) / BLOCK;
-            desc_h[n_desc++] = d;
+    // (the table lives in the context: the copy below may still read it after this scope; the read-back that follows the selection
+    // orders it before the next round overwrites it)
+    c.sel_desc_host.resize((size_t)np * sizeof(SelDesc));
+    SelDesc* desc_h = reinterpret_cast<SelDesc*>(c.sel_desc_host.data());
+    int n_desc = 0;
+    int n_blocks = 0;
+    for (int pi = 0; pi < np; pi++) {
+        Potential& P = c.pots[pi];
+        if (P.args.e_count == 0) continue;
+        SelDesc d{};
+        d.conn = P.args.conn;
+        d.elem_list = P.args.elem_list;
+        d.lrow = lrow;
+        d.n_own = (int)c.sh.n_own;
+        d.is_projected = c.is_projected.p + P.e_off;
+        d.list = c.proj_list.p + P.e_off;
+        d.list_e = list_e_base + P.e_off;
+        d.conn_stride = P.args.conn_stride;
+        d.e_count = P.args.e_count;
+        d.NB = P.NB;
+        d.counter = 4 + pi;
+        d.first_block = n_blocks;
+        for (int k = 0; k < MAX_NB; k++) {
+            d.dof_col[k] = P.args.dof_col[k];
+            d.dof_row_off[k] = P.args.dof_row_off[k];
         }
-        if (n_desc > 0) {
-            c.sel_desc.ensure((size_t)n_desc * sizeof(SelDesc));
-            MS_CHECK(hipMemcpyAsync(c.sel_desc.p, desc_h, (size_t)n_desc * sizeof(SelDesc), hipMemcpyHostToDevice, c.stream));
-            hipLaunchKernelGGL(k_project_select_multi, dim3(n_blocks), dim3(BLOCK), 0, c.stream, (const SelDesc*)c.sel_desc.p, n_desc, act, c.counters.p);
-        }
+        n_blocks += (P.args.e_count + BLOCK - 1) / BLOCK;
+        desc_h[n_desc++] = d;
     }
-    int64_t h[128];
-    fetch(c, h, c.counters.p, sizeof(h));
-    int64_t n_inactive = h[2], n_selected = h[3];
-    if (c.world > 1) {  // the counts of the whole problem (every rank takes the same decisions)
-        double mine[2] = {(double)h[2], (double)h[3]}, all[2 * 64];
-        shard_allgather_scalars(c, mine, 2, all);
-        n_inactive = n_selected = 0;
-        for (int r = 0; r < c.world; r++) {
-            n_inactive += (int64_t)all[2 * r];
-            n_selected += (int64_t)all[2 * r + 1];
-        }
+    if (n_desc > 0) {
+        c.sel_desc.ensure((size_t)n_desc * sizeof(SelDesc));
+        MS_CHECK(hipMemcpyAsync(c.sel_desc.p, desc_h, (size_t)n_desc * sizeof(SelDesc), hipMemcpyHostToDevice, c.stream));
+        hipLaunchKernelGGL(k_project_select_multi, dim3(n_blocks), dim3(BLOCK), 0, c.stream, (const SelDesc*)c.sel_desc.p, n_desc, act, c.counters.p);
     }
-    // 2) eigen-projection of the selected elements; deltas go straight into the assembled matrix if it is current (rows of other ranks:
-    //    their owners project the same element and get the same numbers)
-    int64_t total = 0;
+}
+// h: the counters of phase A on the host. ordered: the eigen kernels leave the matrix alone and the touched blocks are gathered again in phase C
+// (marks); otherwise they patch the matrix themselves where it is current (atomic deltas).
+static void project_phase_b(Context& c, const int64_t* h, double eps, int mirroring, Context::ProjRound& R)
+{
+    const int np = (int)c.pots.size();
+    uint32_t* list_e_base = c.proj_list.p + std::max<size_t>(c.n_elem_total, 1);
+    R.marks.clear();
+    R.mark_part[0] = R.mark_part[1] = false;
+    // eigen-projection of the selected elements; deltas go straight into the assembled matrix if it is current (rows of other ranks:
+    // their owners project the same element and get the same numbers)
     size_t lazy_off = 0;
     if (c.lazy_active) {  // compact double pool for the recomputed blocks of the lazy potentials' selections
         size_t need = 0;
         for (int pi = 0; pi < np; pi++)
             if (c.pots[pi].lazy_capable) need += (size_t)(((int)h[4 + pi] + 63) / 64 * 64) * 9 * c.pots[pi].NB * c.pots[pi].NB;
-        c.projH.ensure(std::max<size_t>(need, 1));
+        // (grown generously: a reallocation is a device-wide synchronisation — with a solve running beside this round it drains the solve's queue)
+        if (need > c.projH.cap) c.projH.ensure(std::max<size_t>(2 * need, (size_t)1 << 22));
     }
     if (c.proj_variant & 4) mirroring |= 2;
     constexpr int SHORT_LIST = 4096;  // lists up to this length share one launch (k_project_eig_multi)
-    struct Mark  // what k_proj_mark needs of a potential's list once the eigen-decompositions have run
-    {
-        Potential* P;
-        const uint32_t* list;
-        int nl;
-        const double* Hc;
-        int n_pool_c;
-    };
-    std::vector<Mark> marks;
-    bool mark_part[2] = {false, false};
     ProjBatch batch;
     batch.n = 0;
     int batch_waves = 0;
@@ -3217,7 +3204,6 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         Potential& P = c.pots[pi];
         const int nl = (int)h[4 + pi];
         if (nl == 0) continue;
-        total += nl;
         hipStream_t stream = c.stream;
         double* H = c.elemH.p + P.h_off;
         const uint32_t* list = c.proj_list.p + P.e_off;
@@ -3235,9 +3221,9 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         }
         // patched in place where the matrix already holds these Hessians: all of it after assemble(), its static part after eval()'s early gather
         float* vals = (c.matrix_current || (c.static_assembled && P.part == 0)) ? c.part[P.part].vals.p : nullptr;
-        if (vals && !c.atomic_projection) {  // ordered update: the kernels leave the matrix alone, the touched blocks are gathered again below
-            marks.push_back(Mark{&P, list, nl, compact ? H : (const double*)nullptr, n_pool});
-            mark_part[P.part] = true;
+        if (vals && !c.atomic_projection) {  // ordered update: the kernels leave the matrix alone, the touched blocks are gathered again in phase C
+            R.marks.push_back(Context::ProjRound::Mark{pi, list, nl, compact ? H : (const double*)nullptr, n_pool});
+            R.mark_part[P.part] = true;
             vals = nullptr;
         }
         const dim3 g((nl + 3) / 4), b(BLOCK);
@@ -3282,43 +3268,69 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         }
     }
     flush();
-    (void)total;
-    if (!marks.empty()) {
-        for (int part = 0; part < 2; part++)
-            if (mark_part[part]) {
-                BsrPart& m = c.part[part];
-                const size_t n_pos = (size_t)std::max<int64_t>(m.ntiles * 64, m.nnzb) + 4;  // (flags are indexed like the values: by storage position; + the fill's rounding to words)
-                if (m.slot_dirty.cap < n_pos) {
-                    m.slot_dirty.ensure(n_pos);
-                    MS_CHECK(hipMemsetAsync(m.slot_dirty.p, 0, m.slot_dirty.cap, c.stream));
-                }
+}
+static void project_phase_c(Context& c, Context::ProjRound& R)
+{
+    if (R.marks.empty()) return;
+    for (int part = 0; part < 2; part++)
+        if (R.mark_part[part]) {
+            BsrPart& m = c.part[part];
+            const size_t n_pos = (size_t)std::max<int64_t>(m.ntiles * 64, m.nnzb) + 4;  // (flags are indexed like the values: by storage position; + the fill's rounding to words)
+            if (m.slot_dirty.cap < n_pos) {
+                m.slot_dirty.ensure(n_pos);
+                MS_CHECK(hipMemsetAsync(m.slot_dirty.p, 0, m.slot_dirty.cap, c.stream));
             }
-        MarkBatch mb;
-        mb.n = 0;
-        int blocks = 0;
-        auto flush_marks = [&]() {
-            if (mb.n > 0) hipLaunchKernelGGL(k_proj_mark, dim3(blocks), dim3(BLOCK), 0, c.stream, mb);
-            mb.n = 0;
-            blocks = 0;
-        };
-        for (const Mark& k : marks) {
-            Potential& P = *k.P;
-            BsrPart& m = c.part[P.part];
-            const bool lazy = k.Hc != nullptr;
-            if (k.nl <= 0) continue;
-            if (mb.n == MARK_BATCH) flush_marks();
-            mb.d[mb.n++] = MarkDesc{k.list, (const uint32_t*)(m.slot_of_src.p + P.kp_off), m.slot_dirty.p, k.Hc, lazy ? c.elemHf.p + P.hf_off : (float*)nullptr, k.nl, P.NB, P.n_key,
-                                    k.n_pool_c, P.n_pool_f, blocks};
-            blocks += grid_for((int64_t)k.nl * P.NB * P.NB);
         }
-        flush_marks();
-        for (int part = 0; part < 2; part++)
-            if (mark_part[part]) {
-                BsrPart& m = c.part[part];
-                gather_part(c, part, m.slot_dirty.p);
-                fill_async(c.stream, m.slot_dirty.p, 0, ((size_t)std::max<int64_t>(m.ntiles * 64, m.nnzb) + 3) & ~(size_t)3);  // (clean for the next round)
-            }
+    MarkBatch mb;
+    mb.n = 0;
+    int blocks = 0;
+    auto flush_marks = [&]() {
+        if (mb.n > 0) hipLaunchKernelGGL(k_proj_mark, dim3(blocks), dim3(BLOCK), 0, c.stream, mb);
+        mb.n = 0;
+        blocks = 0;
+    };
+    for (const Context::ProjRound::Mark& k : R.marks) {
+        Potential& P = c.pots[(size_t)k.pot];
+        BsrPart& m = c.part[P.part];
+        const bool lazy = k.Hc != nullptr;
+        if (k.nl <= 0) continue;
+        if (mb.n == MARK_BATCH) flush_marks();
+        mb.d[mb.n++] = MarkDesc{k.list, (const uint32_t*)(m.slot_of_src.p + P.kp_off), m.slot_dirty.p, k.Hc, lazy ? c.elemHf.p + P.hf_off : (float*)nullptr, k.nl, P.NB, P.n_key,
+                                k.n_pool_c, P.n_pool_f, blocks};
+        blocks += grid_for((int64_t)k.nl * P.NB * P.NB);
     }
+    flush_marks();
+    for (int part = 0; part < 2; part++)
+        if (R.mark_part[part]) {
+            BsrPart& m = c.part[part];
+            gather_part(c, part, m.slot_dirty.p);
+            fill_async(c.stream, m.slot_dirty.p, 0, ((size_t)std::max<int64_t>(m.ntiles * 64, m.nnzb) + 3) & ~(size_t)3);  // (clean for the next round)
+        }
+    R.marks.clear();
+}
+void project(Context& c, double eps, int mirroring, const uint8_t* active_host, bool by_gradient, double threshold, int* all_active, int64_t* n_projected_now,
+             int64_t* n_changed_now)
+{
+    if (c.static_assembled) MS_CHECK(hipStreamWaitEvent(c.stream, c.aux_ev[2], 0));  // (the deltas below go into the matrix the auxiliary stream is still gathering)
+    ensure_pattern(c);
+    if (!c.have_hessians) throw Error("project: no element Hessians (call eval with MISTARK_EVAL_P_G_H first)");
+    project_spec_discard(c);  // (a round started ahead with other parameters: its kernels first)
+    project_phase_a(c, active_host, by_gradient, threshold);
+    int64_t h[128];
+    fetch(c, h, c.counters.p, sizeof(h));
+    int64_t n_inactive = h[2], n_selected = h[3];
+    if (c.world > 1) {  // the counts of the whole problem (every rank takes the same decisions)
+        double mine[2] = {(double)h[2], (double)h[3]}, all[2 * 64];
+        shard_allgather_scalars(c, mine, 2, all);
+        n_inactive = n_selected = 0;
+        for (int r = 0; r < c.world; r++) {
+            n_inactive += (int64_t)all[2 * r];
+            n_selected += (int64_t)all[2 * r + 1];
+        }
+    }
+    Context::ProjRound R;
+    project_phase_b(c, h, eps, mirroring, R);
+    project_phase_c(c, R);
     c.n_projected_total += n_selected;
     if (n_projected_now) *n_projected_now = n_selected;
     if (n_changed_now) {  // (sharded: this rank's count, interface elements included)
@@ -3327,6 +3339,157 @@ void project(Context& c, double eps, int mirroring, const uint8_t* active_host, 
         *n_changed_now = h2[1];
     }
     if (all_active) *all_active = by_gradient ? (n_inactive == 0) : (active_host == nullptr);
+}
+
+// ---- a projection round started AHEAD of the solve that may need it ------------------------------------------------------------------------
+// Progressive projection (NewtonsMethod.cpp:254-386) retries a failed solve with more elements projected, and what it will project is known
+// before the solve starts: the rows whose gradient exceeds the NEXT threshold (this one times the tightening factor), at the unchanged iterate.
+// On configs[3] 51 of 71 solves fail (indefinite barrier Hessians; the reference takes the same retries), and the round between two solves —
+// selection, read-back, the eigen kernels' dependent chains (116 us), marks, gather — was 0.27 ms of idle solver. project_speculate runs
+// phases A and B of that round on a stream of their own WHILE the solve runs (they touch pools, lists and counters, nothing the PCG reads);
+// pcg()'s wait loop calls project_spec_poll, which launches phase B once phase A's counts have reached the host (a kernel writes them to pinned
+// memory: no synchronisation). If the solve fails, project_spec_adopt lets the main stream wait for that work and runs phase C: the matrix the
+// next solve sees is the one project() would have produced, bit for bit (same selection, same projected blocks, same ordered gather). If the
+// solve succeeds, the round is dropped (its selection flags die with the next evaluation's reset).
+__global__ __launch_bounds__(128) void k_spec_publish(const int64_t* __restrict__ counters, int64_t* __restrict__ dst_host, uint32_t* __restrict__ flag_host, uint32_t seq)
+{
+    dst_host[threadIdx.x] = counters[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __atomic_store_n(flag_host, seq, __ATOMIC_RELEASE);
+        __threadfence_system();
+    }
+}
+// (the request is left by the Newton loop BEFORE the solve and taken up by pcg() once its first batches are queued: the host's work for
+// phase A — a dozen launches and a descriptor upload — then overlaps the solve's first iterations instead of delaying them)
+static void project_spec_init(Context& c);
+void project_speculate_request(Context& c, double eps, int mirroring, double threshold)
+{
+    Context::ProjSpec& S = c.spec;
+    project_spec_discard(c);
+    S.pending = threshold > 0.0 && project_can_speculate(c);
+    S.p_eps = eps;
+    S.p_mirroring = mirroring;
+    S.p_threshold = threshold;
+    if (S.pending) {
+        project_spec_init(c);
+        MS_CHECK(hipEventRecord(S.ev_in, c.stream));  // (what the round may start behind: the matrix, the pools and the gradient as they are NOW, before the solve's launches)
+    }
+}
+void project_speculate_pending(Context& c)
+{
+    Context::ProjSpec& S = c.spec;
+    if (!S.pending) return;
+    S.pending = false;
+    project_speculate(c, S.p_eps, S.p_mirroring, S.p_threshold, /*ev_in_recorded=*/true);
+}
+// MEASURED on configs[3] (51 of 71 solves fail and are retried) and OFF by default (option "proj_speculation"): the round's own time leaves the
+// projection stage (9.9 -> 4.0 ms over 20 Newton iterations) and comes back in the solves (82.0 -> 91.0 ms: +0.12 ms per solve, whichever
+// stream carries the round, also one of lowest priority) — a solve is a chain of dependent launches that each fill the chip; a kernel that runs
+// beside it delays the chain by about its own duration (single PCG kernels stretched to 200-330 us under the trace), so the 0.27 ms between two
+// solves are bought back at cost, and the 20 successful solves pay for rounds nobody needs: 153-155 against 156-159 Newton-steps/s. The bits are
+// the same either way (tests/test_gpu_scene.py::test_projection_round_started_beside_the_solve_changes_no_bit).
+bool project_can_speculate(const Context& c) { return c.world == 1 && c.proj_speculation && !c.atomic_projection && c.matrix_current && c.have_hessians && !c.dry; }
+static void project_spec_init(Context& c)
+{
+    Context::ProjSpec& S = c.spec;
+    if (!S.stream) {
+        // (the stream of the early evaluation, idle while a solve runs: a FIFTH stream of the process would share a hardware queue with the main
+        // stream — HIP maps streams onto four queues in creation order — and the solve's launches would queue up behind the round they are meant
+        // to run beside: measured, +0.12 ms per solve)
+        if (!c.pre_stream) MS_CHECK(hipStreamCreateWithFlags(&c.pre_stream, hipStreamNonBlocking));
+        S.stream = c.pre_stream;
+        MS_CHECK(hipEventCreateWithFlags(&S.ev_in, hipEventDisableTiming));
+        MS_CHECK(hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming));
+        MS_CHECK(hipHostMalloc((void**)&S.pinned, 130 * sizeof(int64_t), hipHostMallocCoherent | hipHostMallocMapped));
+        std::memset(S.pinned, 0, 130 * sizeof(int64_t));
+    }
+}
+void project_speculate(Context& c, double eps, int mirroring, double threshold, bool ev_in_recorded)
+{
+    Context::ProjSpec& S = c.spec;
+    if (!ev_in_recorded) project_spec_discard(c);
+    if (!project_can_speculate(c) || !(threshold > 0.0)) return;
+    project_spec_init(c);
+    if (!ev_in_recorded) MS_CHECK(hipEventRecord(S.ev_in, c.stream));  // (the matrix, the pools and the gradient as the main stream leaves them)
+    MS_CHECK(hipStreamWaitEvent(S.stream, S.ev_in, 0));
+    hipStream_t main_stream = c.stream;
+    c.stream = S.stream;
+    try {
+        project_phase_a(c, nullptr, true, threshold);
+        S.seq++;
+        hipLaunchKernelGGL(k_spec_publish, dim3(1), dim3(128), 0, c.stream, (const int64_t*)c.counters.p, S.pinned, reinterpret_cast<uint32_t*>(S.pinned + 128), S.seq);
+    } catch (...) {
+        c.stream = main_stream;
+        throw;
+    }
+    c.stream = main_stream;
+    S.active = true;
+    S.stage = 1;
+    S.threshold = threshold;
+    S.eps = eps;
+    S.mirroring = mirroring;
+    c.n_proj_speculated++;
+}
+// non-blocking: phase B as soon as phase A's counts are on the host
+void project_spec_poll(Context& c)
+{
+    Context::ProjSpec& S = c.spec;
+    if (!S.active || S.stage != 1) return;
+    if (__atomic_load_n(reinterpret_cast<uint32_t*>(S.pinned + 128), __ATOMIC_ACQUIRE) != S.seq) return;
+    std::memcpy(S.h, S.pinned, 128 * sizeof(int64_t));
+    hipStream_t main_stream = c.stream;
+    c.stream = S.stream;
+    try {
+        project_phase_b(c, S.h, S.eps, S.mirroring, S.round);
+    } catch (...) {
+        c.stream = main_stream;
+        throw;
+    }
+    c.stream = main_stream;
+    MS_CHECK(hipEventRecord(S.ev_done, S.stream));
+    S.stage = 2;
+}
+// the round the caller is about to run: taken over if it is the one started ahead (same threshold, eps and mirroring: same bits)
+bool project_spec_adopt(Context& c, double eps, int mirroring, double threshold, int* all_active, int64_t* n_projected_now)
+{
+    Context::ProjSpec& S = c.spec;
+    if (!S.active) return false;
+    if (S.threshold != threshold || S.eps != eps || S.mirroring != mirroring || !project_can_speculate(c)) {
+        project_spec_discard(c);
+        return false;
+    }
+    while (S.stage == 1) {  // (a solve shorter than phase A: wait for the counts here)
+        project_spec_poll(c);
+        if (S.stage == 1) {
+            __builtin_ia32_pause();
+            const hipError_t q = hipStreamQuery(S.stream);
+            if (q != hipErrorNotReady && q != hipSuccess) MS_CHECK(q);
+        }
+    }
+    MS_CHECK(hipStreamWaitEvent(c.stream, S.ev_done, 0));
+    project_phase_c(c, S.round);
+    const int64_t n_inactive = S.h[2], n_selected = S.h[3];
+    c.n_projected_total += n_selected;
+    if (n_projected_now) *n_projected_now = n_selected;
+    if (all_active) *all_active = n_inactive == 0;
+    S.active = false;
+    S.stage = 0;
+    c.n_proj_adopted++;
+    return true;
+}
+void project_spec_discard(Context& c)
+{
+    Context::ProjSpec& S = c.spec;
+    S.pending = false;
+    if (!S.active) return;
+    // whatever of it is still queued or running reads the pools and the DoFs: nothing on the main stream overtakes it
+    MS_CHECK(hipEventRecord(S.ev_done, S.stream));
+    MS_CHECK(hipStreamWaitEvent(c.stream, S.ev_done, 0));
+    S.round.marks.clear();
+    S.active = false;
+    S.stage = 0;
 }
 
 // ======================================================================================================================
@@ -5703,6 +5866,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
             hold = err1 * shrink < tol;
         }
         if (more && !hold) k_end_next = launch_batch(slot ^ 1);  // keep the GPU fed while the host looks at the previous batch
+        project_speculate_pending(c);  // (a projection round to run beside this solve: queued behind the solve's first batches)
         if (fuse_dir) {
             MS_CHECK(hipEventSynchronize(c.pcg_ev[slot]));
         } else {
@@ -5711,6 +5875,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
             auto reported = [&] { return v->epoch == epoch && (v->done || v->n_iter >= k_end_cur); };
             for (uint64_t spins = 0; !reported(); spins++) {
                 __builtin_ia32_pause();
+                if ((spins & 0x3f) == 0) project_spec_poll(c);  // (a projection round started ahead of this solve: its second phase once its counts are here)
                 if ((spins & 0xfffff) != 0xfffff) continue;
                 // now and then a real look at the stream, as publish() does: a failed launch surfaces as its error, and a stream that has
                 // drained without the slot being written (host memory the device's writes do not reach while kernels run) is answered from
@@ -5792,6 +5957,11 @@ Context::~Context()
         (void)hipStreamDestroy(side_stream);
         (void)hipEventDestroy(side_ev[0]);
         (void)hipEventDestroy(side_ev[1]);
+    }
+    if (spec.stream) {  // (= pre_stream, destroyed above)
+        (void)hipEventDestroy(spec.ev_in);
+        (void)hipEventDestroy(spec.ev_done);
+        (void)hipHostFree(spec.pinned);
     }
     if (stream && owns_stream) (void)hipStreamDestroy(stream);
 }

@@ -168,7 +168,9 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                             if (ppn_threshold < 1e-12) ppn_threshold = 0.0;
                             int all_active = 0;
                             int64_t np = 0;
-                            project(c, s.projection_eps, s.project_to_pd_use_mirroring, nullptr, true, ppn_threshold, &all_active, &np, nullptr);
+                            // (the round started beside the solve that has just failed, if this is it: only its last phase is left)
+                            if (!project_spec_adopt(c, s.projection_eps, s.project_to_pd_use_mirroring, ppn_threshold, &all_active, &np))
+                                project(c, s.projection_eps, s.project_to_pd_use_mirroring, nullptr, true, ppn_threshold, &all_active, &np, nullptr);
                             all_projected = all_active != 0;
                         }
                         break;
@@ -194,6 +196,15 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                     vec_neg(c, c.tmp_a.p, c.grad.p, ndofs);
                     pcg(c, c.tmp_a.p, abs_tol, s.cg_rel_tolerance, s.cg_max_iterations, s.cg_stop_on_indefiniteness, &info);
                 } else {
+                    // Should this solve fail, the retry projects the rows above the NEXT threshold (_increase_projection below): that round's
+                    // selection and eigen-projections start now, beside the solve (kernels.hip: project_speculate)
+                    if (s.projection_mode == MISTARK_PROJ_PROGRESSIVE && !all_projected) {
+                        double next = (ppn_threshold < 0.0 ? residual : ppn_threshold) * s.ppn_tightening_factor;
+                        if (next > 0.0) {
+                            if (next < 1e-12) next = 0.0;  // (what the retry would pass: see above)
+                            if (next > 0.0) project_speculate_request(c, s.projection_eps, s.project_to_pd_use_mirroring, next);
+                        }
+                    }
                     pcg(c, c.grad.p, abs_tol, s.cg_rel_tolerance, s.cg_max_iterations, s.cg_stop_on_indefiniteness, &info, -1.0);  // A du = -g
                 }
                 st.cg_iterations += info.n_iterations;
@@ -221,6 +232,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                 }
             }
             if (ok && descends) {
+                project_spec_discard(c);  // (the round started beside this solve is not needed)
                 solved = true;
                 break;
             }
@@ -231,6 +243,7 @@ int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_new
                 ppn_threshold *= s.ppn_tightening_factor;
             }
         }
+        project_spec_discard(c);
         if (result != MISTARK_RUNNING) break;
 
         // _decrease_projection

@@ -988,3 +988,32 @@ def test_evaluation_started_ahead_of_the_contact_callback_changes_no_bit():
     a, b = run(0), run(1)
     assert a[2:] == b[2:] and a[2] > 4
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+
+
+def test_projection_round_started_beside_the_solve_changes_no_bit():
+    """Option proj_speculation (kernels.hip: project_speculate): progressive projection retries a failed solve with the rows above the NEXT
+    threshold projected, and that round's selection and eigen-projections can run on another stream while the solve runs; a failed solve adopts
+    them (only the ordered matrix update is left), a successful one drops them. Same selection, same projected blocks, same gather order: the
+    run has the bits of the default path — and it must take retries for the option to mean anything (more linear solves than Newton iterations).
+    (Measured slower than the default on configs[3], hence an option: DESIGN.md section 8, "Round 4".)"""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from bench import build_scene
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    def run(on):
+        sim = build_scene(S, 10, 10, 10, 0)
+        sim.prepare()
+        assert capi.lib().mistark_set_option(sim.engine_handle(), b"proj_speculation", on) == 0
+        for _ in range(4):
+            assert sim.run_one_step()
+        i = sim.info()
+        out = (sim.points("x0").copy(), sim.points("v0").copy(), i.total_newton_iterations, i.total_linear_solves, i.total_cg_iterations)
+        sim.close()
+        return out
+
+    a, b = run(0), run(1)
+    assert a[2:] == b[2:] and a[3] > a[2] > 4
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
