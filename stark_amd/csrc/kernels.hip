@@ -3186,8 +3186,7 @@ static void project_phase_b(Context& c, const int64_t* h, double eps, int mirror
         size_t need = 0;
         for (int pi = 0; pi < np; pi++)
             if (c.pots[pi].lazy_capable) need += (size_t)(((int)h[4 + pi] + 63) / 64 * 64) * 9 * c.pots[pi].NB * c.pots[pi].NB;
-        // (grown generously: a reallocation is a device-wide synchronisation — with a solve running beside this round it drains the solve's queue)
-        if (need > c.projH.cap) c.projH.ensure(std::max<size_t>(2 * need, (size_t)1 << 22));
+        c.projH.ensure(std::max<size_t>(need, 1));
     }
     if (c.proj_variant & 4) mirroring |= 2;
     constexpr int SHORT_LIST = 4096;  // lists up to this length share one launch (k_project_eig_multi)
