@@ -541,6 +541,7 @@ def test_full_size_first_time_steps_on_the_centred_placement():
     assert [r["ndofs"] for r in ref] == [517050, 517050] and ref[0]["per_step"][:3] == ref[1]["per_step"][:3]
     sim = bench.build_scene(S, 44, 44, 43, 0)
     per_step, series, dev = _step_log(sim, 5, z)
+    print("centred placement, engine:", per_step)
     assert per_step[0][:2] == ref[0]["per_step"][0][:2] == [5, 6]
     assert series[0][:4] == traj["cg_iterations"][:4] == [3, 19, 22, 4]
     assert abs(per_step[1][0] - ref[0]["per_step"][1][0]) <= 1 and abs(per_step[1][1] - ref[0]["per_step"][1][1]) <= 1
