@@ -529,7 +529,12 @@ def test_full_size_first_time_steps_on_the_centred_placement():
     reproduces every later Newton step to 1e-5 (tools/steplog_cfg3.py). What is pinned here: the first attempt
     (6 Newton iterations, ends in "invalid converged state": the floor's constraint is hardened, the step redone) has the reference's
     counts and its first four solves the reference's CG iterations; the state after the first accepted step agrees to 1 % of the step
-    (measured 0.3 %); the totals over five attempts stay within the spread of the reference's own two runs, widened."""
+    (measured 0.3 %); the totals over five attempts stay within the spread of the reference's own two runs, widened.
+    Round 4: the reference's answer here is not even a property of its sources — built with -ffp-contract=off the same sources log
+    [5,6,101] [5,6,99] [3,16,173] [3,16,161] [9,24,557] instead of [5,6,104] [4,5,67] [3,4,154] [3,21,171] [6,17,357]
+    (tests/test_oracle_golden.py::test_the_references_own_log_on_exact_ties_depends_on_its_compile_flags); the engine with its own tie decisions logs
+    [5,6,97] [5,6,95] [3,12,159] [3,19,160] [3,20,202]: between the two builds in its first attempts, apart from both later — three answers to a
+    question that has none; the pinned placement (test above) is where the answer is unique."""
     import json
 
     import bench
