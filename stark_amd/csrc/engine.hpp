@@ -330,6 +330,7 @@ struct Context
     DevBuf<int32_t> hot_rows;      // global block row of every hot row
     int n_hot = 0;
     int proj_variant = 0;          // PSD projection, bits: 1 = matrix in LDS (k_project_eig) instead of registers, 2 = no batching of short lists, 4 = IEEE div/sqrt
+    int pcg_batch = 0;             // tuning: PCG iterations per launch batch (one batch is always queued ahead of the one the host waits for); 0 = by size
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather
     bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path

@@ -5747,7 +5747,11 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
     // Iterations are launched in batches of PCG_BATCH; after each batch the control block is copied to a pinned slot and an
     // event recorded. The host launches batch b+1 BEFORE it waits for batch b's event, so the GPU never idles on the host's
     // convergence check, and at most one batch of device-side no-op launches (ctrl->done) is wasted after convergence.
-    constexpr int PCG_BATCH = 4;
+    constexpr int PCG_BATCH_MAX = 8;  // (sizes of the sampling buffers)
+    // (option "pcg_batch"; 0 = by size: 3 for the large systems, whose iterations are long enough for the host to keep up with shorter batches and
+    // whose solves then queue fewer no-op launches behind the iteration that converged — configs[3]: 1.140 against 1.155 ms per solve, 2 / 3 / 4 / 6
+    // = 1.145 / 1.140 / 1.155 / 1.176 —, 4 for the small ones, whose 13 us iterations the host barely outruns: configs[0] 254 against 244-248)
+    const int PCG_BATCH = std::min(std::max(c.pcg_batch > 0 ? c.pcg_batch : (c.nbr >= 100000 ? 3 : 4), 1), PCG_BATCH_MAX);
     PcgCtrl* hs[2] = {reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048), reinterpret_cast<PcgCtrl*>(host_scratch(c, 4096) + 2048 + 64)};  // pinned
     while (c.pcg_ev.size() < 2) {
         hipEvent_t e;
@@ -5768,9 +5772,9 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         sampled[slot].clear();
         for (; k <= k_end; k++) {
             const bool sample = c.time_spmv && (k % SPMV_SAMPLE) == 0;
-            const size_t e0 = (size_t)slot * 3 * PCG_BATCH + 3 * sampled[slot].size();
+            const size_t e0 = (size_t)slot * 3 * PCG_BATCH_MAX + 3 * sampled[slot].size();
             if (sample) {
-                while (c.ev.size() < (size_t)6 * PCG_BATCH) {
+                while (c.ev.size() < (size_t)6 * PCG_BATCH_MAX) {
                     hipEvent_t e;
                     MS_CHECK(hipEventCreate(&e));
                     c.ev.push_back(e);
@@ -5787,8 +5791,8 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
                 pk = c.p.p;
                 uint64_t* clk = nullptr;
                 if (sample) {
-                    if (!c.spmv_clk) MS_CHECK(hipHostMalloc((void**)&c.spmv_clk, sizeof(uint64_t) * 2 * PCG_BATCH * 2 * MAX_PARTIALS, hipHostMallocDefault));
-                    clk = c.spmv_clk + ((size_t)slot * PCG_BATCH + sampled[slot].size()) * 2 * MAX_PARTIALS;
+                    if (!c.spmv_clk) MS_CHECK(hipHostMalloc((void**)&c.spmv_clk, sizeof(uint64_t) * 2 * PCG_BATCH_MAX * 2 * MAX_PARTIALS, hipHostMallocDefault));
+                    clk = c.spmv_clk + ((size_t)slot * PCG_BATCH_MAX + sampled[slot].size()) * 2 * MAX_PARTIALS;
                     std::memset(clk, 0, sizeof(uint64_t) * 2 * MAX_PARTIALS);
                 }
                 gs = launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, part_pq, c.ctrl.p, /*combine=*/false, clk);
@@ -5822,7 +5826,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
         for (size_t i = 0; i < sampled[slot].size(); i++) {
             if (sampled[slot][i] > last_real_iter) continue;  // early-exit launch after convergence
             float ms = 0.f;
-            const size_t e0 = (size_t)slot * 3 * PCG_BATCH + 3 * i;
+            const size_t e0 = (size_t)slot * 3 * PCG_BATCH_MAX + 3 * i;
             float ms_empty = 0.f;
             if (hipEventElapsedTime(&ms, c.ev[e0], c.ev[e0 + 1]) == hipSuccess && hipEventElapsedTime(&ms_empty, c.ev[e0 + 1], c.ev[e0 + 2]) == hipSuccess) {
                 c.spmv_ms_sum += ms;
@@ -5830,7 +5834,7 @@ void pcg(Context& c, const double* rhs_dev, double abs_tol, double rel_tol, int 
                 c.spmv_n++;
             }
             if (c.spmv_clk && clk_grid[slot] > 0) {  // the same launch on the device clock
-                const uint64_t* clk = c.spmv_clk + ((size_t)slot * PCG_BATCH + i) * 2 * MAX_PARTIALS;
+                const uint64_t* clk = c.spmv_clk + ((size_t)slot * PCG_BATCH_MAX + i) * 2 * MAX_PARTIALS;
                 uint64_t t0 = ~0ull, t1 = 0;
                 bool complete = true;
                 for (int b = 0; b < clk_grid[slot]; b++) {
