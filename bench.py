@@ -96,9 +96,10 @@ def host_cpu():
     return model, (len(cores) or logical), logical
 
 
-def cpu_baseline(nx, ny, nz, scene="contact", offset=(0.0, 0.0), sweep=(8, 16, 32, 64), steps=2):
+def cpu_baseline(nx, ny, nz, scene="contact", offset=(0.0, 0.0), sweep=(8, 16, 32, 64), steps=4):
     """The UNMODIFIED reference (oracle/_ref/ref_harness, built by oracle/Makefile) timed on this host's cores at several thread counts
-    (it does not scale monotonically: 8 threads beat 64 on this scene); `value` is the BEST of them, every leg is reported."""
+    (it does not scale monotonically: 8 threads beat 64 on this scene); `value` is the BEST of them, every leg is reported. `steps` time steps
+    after one warm-up step: four of them hold about the Newton iterations the GPU's timed window holds (iterations 5..24 of the run)."""
     harness = os.path.join(ROOT, "oracle", "_ref", "ref_harness")
     model, physical, logical = host_cpu()
     base = {"unit": "Newton-steps/s", "cores": None, "kind": "reference", "cpu_model": model, "physical_cores": physical, "logical_cpus": logical}
@@ -198,7 +199,7 @@ def pinned_placement_run(S, capi, nx, ny, nz, device, steps, warmup, with_cpu):
            "linear_solves": n_ls, "cg_iterations": n_cg, "newton_iterations": newton, "steps": steps, "warmup": warmup,
            "pinned_by": "tests/test_gpu_fullsize.py::test_full_size_first_time_steps_equal_the_reference_log_off_the_degenerate_placement"}
     if with_cpu:
-        out["cpu_baseline"] = cpu_baseline(nx, ny, nz, "contact", PINNED_OFFSET, sweep=(8, 16, 32), steps=2)
+        out["cpu_baseline"] = cpu_baseline(nx, ny, nz, "contact", PINNED_OFFSET, sweep=(8, 16, 32), steps=3)
     return out
 
 

@@ -300,7 +300,6 @@ struct Context
     size_t n_elem_total = 0, hess_total = 0;
     DevBuf<double> elemE, elemH;
     DevBuf<float> elemHf;           // float pool of the lazy potentials
-    DevBuf<double> projH;           // compact double pool of the elements a projection round recomputes (lazy potentials)
     size_t hf_total = 0;
     bool lazy_allowed = true;       // option "lazy_hessians": newton_solve may take the lazy path (progressive / no projection)
     bool lazy_eval = false;         // option "lazy_eval": staged mistark_eval calls take it too (tests)

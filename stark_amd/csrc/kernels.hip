@@ -1936,9 +1936,11 @@ void prepare(Context& c)
             P.h_off = h_off;
             P.k_off = h_off / 9;
             e_off += (size_t)P.n_key;
-            h_off += (size_t)P.n_key * 9 * P.NB * P.NB;
-            P.hf_off = hf_off;
             P.n_pool_f = (P.n_key + 63) / 64 * 64;
+            // (a lazy potential's share of the double pool is unused while the lazy path is on — except as the compact pool of its projection
+            // rounds, project_phase_b: whole wavefronts of 64 elements, hence the rounding)
+            h_off += (size_t)(P.lazy_capable ? P.n_pool_f : P.n_key) * 9 * P.NB * P.NB;
+            P.hf_off = hf_off;
             if (P.lazy_capable) hf_off += (size_t)P.n_pool_f * 9 * 10;
             // gradient pool + incidence lists (Potential::grad_gather)
             const bool closed_tri = P.kind != KIND_CUSTOM && !c.force_generic && (P.name == E_TriangleStrain::name || P.name == E_TriangleStrainEO::name);
@@ -3181,13 +3183,6 @@ static void project_phase_b(Context& c, const int64_t* h, double eps, int mirror
     R.mark_part[0] = R.mark_part[1] = false;
     // eigen-projection of the selected elements; deltas go straight into the assembled matrix if it is current (rows of other ranks:
     // their owners project the same element and get the same numbers)
-    size_t lazy_off = 0;
-    if (c.lazy_active) {  // compact double pool for the recomputed blocks of the lazy potentials' selections
-        size_t need = 0;
-        for (int pi = 0; pi < np; pi++)
-            if (c.pots[pi].lazy_capable) need += (size_t)(((int)h[4 + pi] + 63) / 64 * 64) * 9 * c.pots[pi].NB * c.pots[pi].NB;
-        c.projH.ensure(std::max<size_t>(need, 1));
-    }
     if (c.proj_variant & 4) mirroring |= 2;
     constexpr int SHORT_LIST = 4096;  // lists up to this length share one launch (k_project_eig_multi)
     ProjBatch batch;
@@ -3212,9 +3207,11 @@ static void project_phase_b(Context& c, const int64_t* h, double eps, int mirror
         if (c.lazy_active && P.lazy_capable) {
             // the double blocks of the selected elements were never stored: recompute them into a compact pool (the list is a small
             // fraction of the mesh except when PPN activates every element, and then the eigen-decompositions cost 20x this)
+            // The compact pool is the potential's own share of the double pool, which the lazy path leaves unused (prepare(): sized for whole
+            // wavefronts). A separate buffer sized by the round was a 1.15 GB allocation INSIDE the Newton loop the first time PPN activated every
+            // tet of configs[3] — 5 to 50 ms from box to box, up to a sixth of bench.py's timed window.
             n_pool = (nl + 63) / 64 * 64;
-            H = c.projH.p + lazy_off;
-            lazy_off += (size_t)n_pool * 9 * P.NB * P.NB;
+            H = c.elemH.p + P.h_off;
             compact = 1;
             launch_tet_closed_list(c, P, list_e_base + P.e_off, nl, H, n_pool);
         }
