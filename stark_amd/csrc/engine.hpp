@@ -1,5 +1,6 @@
 // engine.hpp — internal declarations of the MI355X engine (not part of the C ABI; see include/mistark.h).
 #pragma once
+#include <algorithm>
 #include <cstdlib>
 #include <hip/hip_runtime.h>
 
@@ -81,7 +82,9 @@ struct DevBuf
         if (dry_mode()) return;
         if (p) MS_CHECK(hipFree(p));
         p = nullptr;
-        size_t want = n + n / 8 + 64;
+        // (growth: an eighth, but small buffers double — a reallocation is a hipFree, i.e. a device-wide synchronisation, and the buffers sized by the
+        // contact sets grow by a few rows at a time inside the Newton loop)
+        size_t want = n + std::max(n / 8, std::min<size_t>(n, (size_t)1 << 20)) + 64;
         MS_CHECK(hipMalloc((void**)&p, want * sizeof(T)));
         cap = want;
         // MISTARK_POISON=1: fill fresh allocations with a NaN pattern, so that a read of memory nobody wrote shows up in the tests
