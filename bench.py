@@ -475,10 +475,14 @@ def main():
     sim.spmv_timing(reset=-1 if os.environ.get("MISTARK_BENCH_NO_SPMV_SAMPLING") else 1)  # start SpMV timing for the timed region (the variable: A/B of what the sampling itself costs)
     barrier()
     info0 = sim.info()
+    if os.environ.get("MISTARK_ALLOC_TRACE"):
+        print("[alloc] ---- timed region begins", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     newton, n_ls, n_cg, t_ls = run_newton_steps(sim, S, capi, a.steps)
     barrier()
     t1 = time.perf_counter()
+    if os.environ.get("MISTARK_ALLOC_TRACE"):
+        print("[alloc] ---- timed region ends", file=sys.stderr, flush=True)
     elapsed = t1 - t0
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64)

@@ -86,6 +86,9 @@ struct DevBuf
         // contact sets grow by a few rows at a time inside the Newton loop)
         size_t want = n + std::max(n / 8, std::min<size_t>(n, (size_t)1 << 20)) + 64;
         MS_CHECK(hipMalloc((void**)&p, want * sizeof(T)));
+        // MISTARK_ALLOC_TRACE=1: every (re)allocation on stderr — what still allocates inside a timed region shows up between the caller's markers
+        static const bool trace = std::getenv("MISTARK_ALLOC_TRACE") != nullptr;
+        if (trace) std::fprintf(stderr, "[alloc] %zu bytes (was %zu)\n", want * sizeof(T), cap * sizeof(T));
         cap = want;
         // MISTARK_POISON=1: fill fresh allocations with a NaN pattern, so that a read of memory nobody wrote shows up in the tests
         // instead of depending on what the allocator hands out (fresh processes get zero pages, long-lived ones do not)
