@@ -375,6 +375,8 @@ struct Context
     size_t h_pin_bytes = 0;
     uint8_t* pub = nullptr;         // coherent pinned page small read-backs are published into (kernels.hip: publish)
     uint32_t pub_seq = 0;
+    uint8_t* pub2 = nullptr;        // ... and a second one for a read-back left in flight while another runs (publish_begin2 / publish_end2)
+    uint32_t pub2_seq = 0;
     // bumped by everything that can change what a contact detection sees (DoFs, bound arrays, layout): the detector skips a search whose
     // inputs are those of its previous one (the evaluation that opens a Newton iteration repeats the accepted line-search state)
     // a projection round as it travels between its phases (kernels.hip: project_phase_a / _b / _c)

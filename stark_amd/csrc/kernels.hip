@@ -1078,6 +1078,34 @@ __global__ __launch_bounds__(256) void k_publish(const uint32_t* __restrict__ sr
         __threadfence_system();
     }
 }
+// (a second pinned area for a read-back that is started, then left in flight while ANOTHER read-back runs through publish(): eval()'s partial sums
+// around the contact part's pattern counts)
+static bool publish_begin2(Context& c, const void* src_dev, size_t bytes)
+{
+    if (bytes > PUBLISH_MAX_BYTES || (bytes & 3) || (reinterpret_cast<uintptr_t>(src_dev) & 3)) return false;
+    if (!c.pub2) {
+        MS_CHECK(hipHostMalloc((void**)&c.pub2, PUBLISH_MAX_BYTES + 64, hipHostMallocCoherent | hipHostMallocMapped));
+        std::memset(c.pub2, 0, PUBLISH_MAX_BYTES + 64);
+    }
+    uint32_t* flag = reinterpret_cast<uint32_t*>(c.pub2 + PUBLISH_MAX_BYTES);
+    const uint32_t seq = ++c.pub2_seq;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(256), 0, c.stream, (const uint32_t*)src_dev, (int)(bytes / 4), (uint32_t*)c.pub2, flag, seq);
+    return true;
+}
+static void publish_end2(Context& c, void* dst_host, size_t bytes)
+{
+    uint32_t* flag = reinterpret_cast<uint32_t*>(c.pub2 + PUBLISH_MAX_BYTES);
+    const uint32_t seq = c.pub2_seq;
+    for (uint64_t spins = 0;; spins++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spins & 0xFFFFF) == 0xFFFFF) {
+            MS_CHECK(hipStreamSynchronize(c.stream));
+            if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) throw Error("read-back kernel finished without publishing its data");
+            break;
+        }
+    }
+    std::memcpy(dst_host, c.pub2, bytes);
+}
 static bool publish(Context& c, void* dst_host, const void* src_dev, size_t bytes)
 {
     if (bytes > PUBLISH_MAX_BYTES || (bytes & 3) || (reinterpret_cast<uintptr_t>(src_dev) & 3)) return false;
@@ -1141,6 +1169,16 @@ void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes)
     MS_CHECK(hipStreamSynchronize(c.stream));
     std::memcpy(dst_host, c.h_pin, bytes);
     if (c.coll) c.coll->check();
+}
+static bool fetch_partials_begin(Context& c, int n, const double* part_dev) { return publish_begin2(c, part_dev, (size_t)n * sizeof(double)); }
+static void fetch_partials_end(Context& c, int n, double* out_host, const double* part_dev, bool published)
+{
+    if (published) {
+        publish_end2(c, out_host, (size_t)n * sizeof(double));
+        return;
+    }
+    MS_CHECK(hipMemcpyAsync(out_host, part_dev, n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
 }
 static void fetch_partials(Context& c, int n, double* out_host, const double* part_dev)
 {
@@ -2286,7 +2324,12 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         MS_CHECK(hipEventRecord(c.aux_ev[2], c.aux_stream));
         c.static_assembled = true;
     }
-    if (overlap_pattern) {
+    // (the contact part's pattern ends in a read-back of its counts, for which the host waits: the energy / residual reductions of THIS stream
+    // are queued first where they do not depend on it, so that they run while the host waits — see with_max below)
+    bool pattern_pending = overlap_pattern;
+    auto run_pattern = [&]() {
+        if (!pattern_pending) return;
+        pattern_pending = false;
         MS_CHECK(hipStreamWaitEvent(c.side_stream, c.side_ev[0], 0));
         hipStream_t main_stream = c.stream;
         c.stream = c.side_stream;  // (everything build_pattern launches and reads back goes through c.stream)
@@ -2299,7 +2342,9 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         c.stream = main_stream;
         MS_CHECK(hipEventRecord(c.side_ev[1], c.side_stream));
         MS_CHECK(hipStreamWaitEvent(c.stream, c.side_ev[1], 0));
-    }
+    };
+    const bool with_max_early = grad_max_abs && mode != MISTARK_EVAL_P && c.world == 1 && c.n_elem_total > 0;
+    if (!with_max_early) run_pattern();
     if (mode != MISTARK_EVAL_P && c.n_hot > 0)
         hipLaunchKernelGGL(k_fold_hot, dim3(grid_for(3 * (int64_t)c.n_hot)), dim3(BLOCK), 0, c.stream, (const double*)c.grad_hot.p, (const int32_t*)c.hot_rows.p, c.n_hot, c.grad.p);
     if (mode == MISTARK_EVAL_P_G_H) {
@@ -2309,13 +2354,17 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         c.n_projected_total = 0;
     }
     double e = 0.0;
-    const bool with_max = grad_max_abs && mode != MISTARK_EVAL_P && c.world == 1 && c.n_elem_total > 0;
+    const bool with_max = with_max_early;
     if (with_max) {  // energy and ||grad||_inf in one read-back
         const int g1 = grid_for((int64_t)c.n_elem_total, BLOCK, VEC_GRID), g2 = grid_for(c.ndofs, BLOCK, VEC_GRID);
         hipLaunchKernelGGL(k_sum, dim3(g1), dim3(BLOCK), 0, c.stream, (const double*)c.elemE.p, (int64_t)c.n_elem_total, c.partials.p);
         hipLaunchKernelGGL(k_max_abs, dim3(g2), dim3(BLOCK), 0, c.stream, (const double*)c.grad.p, c.ndofs, c.partials.p + g1);
         double* h = host_scratch(c, 2 * MAX_PARTIALS);
-        fetch_partials(c, g1 + g2, h, c.partials.p);
+        // the partial sums leave the device BEFORE this stream is made to wait for the pattern chain (the publish kernel is queued behind the
+        // reductions; the host picks the numbers up after the pattern's own read-back)
+        const bool published = fetch_partials_begin(c, g1 + g2, c.partials.p);
+        run_pattern();
+        fetch_partials_end(c, g1 + g2, h, c.partials.p, published);
         double m = 0.0;
         for (int i = 0; i < g1; i++) e += h[i];
         for (int i = 0; i < g2; i++) m = std::max(m, h[g1 + i]);
@@ -5946,6 +5995,7 @@ Context::~Context()
     if (h_scratch) (void)hipHostFree(h_scratch);
     if (h_pin) (void)hipHostFree(h_pin);
     if (pub) (void)hipHostFree(pub);
+    if (pub2) (void)hipHostFree(pub2);
     if (spmv_clk) (void)hipHostFree(spmv_clk);
     if (spmv_clk_sharded) (void)hipHostFree(spmv_clk_sharded);
     if (aux_stream) {
