@@ -368,10 +368,11 @@ int mistark_dist_set_row_coords(mistark_ctx* ctx, const double* xyz, int64_t n_b
 /* Block rows that potentials with device-side connectivity may reference on any rank; every rank keeps them as ghosts. The contact system
  * registers the collision vertices of its deformable meshes itself; small DoF sets (rigid bodies) are always shared. */
 int mistark_dist_add_shared_rows(mistark_ctx* ctx, const int32_t* rows, int64_t n);
-/* out[0..13): block rows owned by this rank, ghosts, rows it sends, elements it evaluates, blocks of its static / contact matrix part, linear
+/* out[0..15): block rows owned by this rank, ghosts, rows it sends, elements it evaluates, blocks of its static / contact matrix part, linear
  * solves that took the fused iteration (one exposed exchange, ranks exchanging through windows) and the five-launch one; [8] world and [9] rank
  * of the context, [10] transport (0 none, 1 in-process group, 2 RCCL, 3 IPC windows), [11] ranks the transport itself counts (RCCL:
- * ncclCommCount of the communicator), [12] contact searches whose sweep was dealt out to the ranks (keys all-gathered and merged) */
+ * ncclCommCount of the communicator), [12] contact searches whose sweep was dealt out to the ranks (keys all-gathered and merged), [13] elements
+ * of all potentials with fixed connectivity as registered (the unsharded problem) and [14] those of them this rank evaluates */
 int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n);
 int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner);
 /* ---- IPC windows: one process per rank, no library in the data path -----------------------------------------------------------------
@@ -394,6 +395,18 @@ int mistark_dist_init_ipc(mistark_ctx* ctx, mistark_ipc_comm* comm);
 /* `iters` all-gathers of n doubles with predictable values, every received value checked; avg_us[0] = wall time of one exchange + stream
  * synchronisation, avg_us[1] = of one exchange in a train enqueued back to back. Collective: every rank calls it with the same arguments. */
 int mistark_ipc_comm_selftest(mistark_ipc_comm* comm, int64_t n, int iters, double avg_us[2]);
+/* Pre-flight of the windows: one tagged granule over every ordered pair of ranks (ping-pong, `iters` >= 2 exchanges per pair, the first of a
+ * pair discarded), every wait bounded by timeout_s (clamped to 2 s). half_rtt_us[p] = half the best round trip with peer p in microseconds
+ * (0 for the own rank, < 0 where no granule came back). Returns the number of peers that answered (world - 1 = the windows deliver), < 0 on
+ * error. Collective: every rank calls it with the same arguments, a host barrier in front (the kernels must start within the time-out of each
+ * other). A launcher that sees fewer than world - 1 on any rank falls back to RCCL and says so (bench.py). */
+int mistark_ipc_comm_preflight(mistark_ipc_comm* comm, int iters, double timeout_s, double* half_rtt_us /* world */);
+/* The two all-reduces the reference's parallel reductions turn into on N GPUs, on RCCL whatever transport the engine runs on: ncclAllReduce
+ * (f64, sum) of n_big doubles (the gradient of the shared DoFs: symx SecondOrderCompiledGlobal.cpp:72-142) and of 3 doubles (the dot products of
+ * a CG iteration: BlockedSparseMatrix/solve_pcg.h:180,201,217), `reps` launches each back to back between HIP events, results checked.
+ * out[0] = ncclCommCount, out[1] = microseconds per all-reduce of n_big doubles, out[2] = of 3 doubles, out[3] = seconds in ncclCommInitRank.
+ * Collective; one rank per device (RCCL refuses two ranks on one device: the error text lands in err). No engine context involved. */
+int mistark_rccl_allreduce_bench(int device, int rank, int world, const char unique_id[128], int64_t n_big, int reps, double* out /* 4 */, char* err, int err_len);
 /* Measurement: solo durations (microseconds) of the two kernels of the fused PCG iteration on THIS rank's rows — out[0] = the SpMV with its
  * halo polls, out[1] = the vector kernel (whose workgroup 0 reduces and pushes the rank's three sums) — replayed from the rank's
  * last converged solve on the messages still in its window (every poll answered at once). Not a collective: the caller lets the ranks take

@@ -160,6 +160,8 @@ def lib():
     L.mistark_ipc_comm_destroy.argtypes = [p]
     L.mistark_ipc_comm_destroy.restype = None
     L.mistark_ipc_comm_selftest.argtypes = [p, i64, C.c_int, C.POINTER(dbl)]  # double[2]
+    L.mistark_ipc_comm_preflight.argtypes = [p, C.c_int, dbl, C.POINTER(dbl)]  # double[world]
+    L.mistark_rccl_allreduce_bench.argtypes = [C.c_int, C.c_int, C.c_int, p, i64, C.c_int, C.POINTER(dbl), p, C.c_int]  # double[4], char[err_len]
     L.mistark_dist_init_ipc.argtypes = [p, p]
     L.mistark_dist_fused_bench.argtypes = [p, C.c_int, C.POINTER(dbl)]
     L.mistark_dist_set_row_owner.argtypes = [p, p, i64]
@@ -196,19 +198,26 @@ class IpcComm:
     """One rank's end of the IPC-window transport (include/mistark.h "IPC windows"): create -> all-gather the 64-byte handles through the
     launcher -> connect. `allgather_bytes(b)` must return the list of every rank's bytes in rank order (torch.distributed.all_gather_object)."""
 
-    def __init__(self, device, rank, world, window_bytes, allgather_bytes):
+    def __init__(self, device, rank, world, window_bytes, allgather_bytes=None):
+        """With `allgather_bytes` the communicator is connected on return; without it the caller exchanges `self.handle` (64 bytes) itself
+        and calls connect(handles) — the two-phase form lets a launcher agree on a fallback when a rank's creation failed, before any rank
+        waits in the handle exchange (bench.py)."""
         L = lib()
         buf = C.create_string_buffer(64)
         self.h = L.mistark_ipc_comm_create(device, rank, world, int(window_bytes), buf)
         if not self.h:
             raise RuntimeError("mistark_ipc_comm_create failed (rank %d)" % rank)
         self.rank, self.world = rank, world
-        handles = allgather_bytes(buf.raw)
-        if len(handles) != world or any(len(x) != 64 for x in handles):
-            raise RuntimeError("IPC handles: expected %d x 64 bytes" % world)
+        self.handle = buf.raw
+        if allgather_bytes is not None:
+            self.connect(allgather_bytes(self.handle))
+
+    def connect(self, handles):
+        if len(handles) != self.world or any(not isinstance(x, (bytes, bytearray)) or len(x) != 64 for x in handles):
+            raise RuntimeError("IPC handles: expected %d x 64 bytes" % self.world)
         blob = b"".join(handles)
-        if L.mistark_ipc_comm_connect(self.h, blob, len(blob)) != 0:
-            raise RuntimeError("mistark_ipc_comm_connect: %s" % L.mistark_ipc_comm_last_error(self.h).decode())
+        if lib().mistark_ipc_comm_connect(self.h, blob, len(blob)) != 0:
+            raise RuntimeError("mistark_ipc_comm_connect: %s" % lib().mistark_ipc_comm_last_error(self.h).decode())
 
     def selftest(self, n=1024, iters=20):
         """Collective. Every value checked; returns (wall time of one all-gather of n doubles + stream synchronisation, of one all-gather in a
@@ -217,6 +226,15 @@ class IpcComm:
         if lib().mistark_ipc_comm_selftest(self.h, n, iters, us) != 0:
             raise RuntimeError("IPC self-test: %s" % lib().mistark_ipc_comm_last_error(self.h).decode())
         return us[0], us[1]
+
+    def preflight(self, iters=16, timeout_s=2.0):
+        """Collective (host barrier in front). One tagged granule over every ordered pair of ranks; returns (peers that answered, [half the best
+        round trip in microseconds per peer; 0 for the own rank, None where nothing came back])."""
+        us = (C.c_double * self.world)()
+        n = lib().mistark_ipc_comm_preflight(self.h, iters, float(timeout_s), us)
+        if n < 0:
+            raise RuntimeError("IPC pre-flight: %s" % lib().mistark_ipc_comm_last_error(self.h).decode())
+        return n, [None if v < 0 else float(v) for v in us]
 
     def close(self):
         if self.h:

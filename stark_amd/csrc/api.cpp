@@ -991,10 +991,16 @@ int mistark_dist_info(mistark_ctx* ctx, int64_t* out, int n)
     Context& c = ctx->c;
     if (!out && n > 0) throw Error("mistark_dist_info: null output");
     prepare(c);
-    const int64_t v[13] = {c.world > 1 ? c.sh.n_own : c.nbr, c.world > 1 ? c.sh.n_ghost : 0, c.world > 1 ? c.sh.n_send : 0, (int64_t)c.n_elem_total, c.part[0].nnzb, c.part[1].nnzb,
+    int64_t n_all = 0, n_here = 0;  // static potentials: elements registered / elements this rank evaluates (interface elements on every side)
+    for (const Potential& P : c.pots)
+        if (P.part == 0) {
+            n_all += P.n_elem;
+            n_here += c.world > 1 ? P.n_key : P.n_elem;
+        }
+    const int64_t v[15] = {c.world > 1 ? c.sh.n_own : c.nbr, c.world > 1 ? c.sh.n_ghost : 0, c.world > 1 ? c.sh.n_send : 0, (int64_t)c.n_elem_total, c.part[0].nnzb, c.part[1].nnzb,
                            c.n_fused_solves, c.n_unfused_solves, c.world, c.rank, c.coll ? c.coll->transport_id() : 0, c.coll ? c.coll->transport_ranks() : 1,
-                           contact_sharded_searches(c)};
-    for (int i = 0; i < n && i < 13; i++) out[i] = v[i];
+                           contact_sharded_searches(c), n_all, n_here};
+    for (int i = 0; i < n && i < 15; i++) out[i] = v[i];
     API_END(0)
 }
 int mistark_dist_get_row_owner(mistark_ctx* ctx, int32_t* owner)
@@ -1103,6 +1109,27 @@ int mistark_ipc_comm_selftest(mistark_ipc_comm* comm, int64_t n, int iters, doub
         return -1;
     }
     return 0;
+}
+int mistark_ipc_comm_preflight(mistark_ipc_comm* comm, int iters, double timeout_s, double* half_rtt_us)
+{
+    if (!comm || !comm->m || !half_rtt_us) return -1;
+    try {
+        return ipc_comm_preflight(*comm->m, iters, timeout_s, half_rtt_us);
+    } catch (const std::exception& e) {
+        comm->last_error = e.what();
+        return -1;
+    }
+}
+int mistark_rccl_allreduce_bench(int device, int rank, int world, const char unique_id[128], int64_t n_big, int reps, double* out, char* err, int err_len)
+{
+    if (!unique_id || !out) return -1;
+    try {
+        rccl_allreduce_bench(device, rank, world, unique_id, (size_t)std::max<int64_t>(n_big, 0), reps, out);
+        return 0;
+    } catch (const std::exception& e) {
+        if (err && err_len > 0) std::snprintf(err, (size_t)err_len, "%s", e.what());
+        return -1;
+    }
 }
 // Solo durations (microseconds) of the fused PCG iteration's two kernels on THIS rank's shard: out[0] = S (SpMV with halo polls), out[1] = V
 // (vector kernel; its workgroup 0 reduces and pushes the rank's sums), replayed from the last converged solve. Not a collective: the caller lets the

@@ -164,6 +164,7 @@ struct RcclCollective : Collective
 // s + 2 after its own wait for s + 1 has finished (stream order), i.e. after EVERY rank B has pushed s + 1, which B enqueued behind its
 // wait for s: when a granule of s + 2 lands on B, B has consumed s.
 constexpr size_t IPC_HDR = 8;                         // granules at the start of every window: {magic, granules, world, rank}
+constexpr size_t IPC_PRE = 2 * MAX_IPC_RANKS;         // granules of the pre-flight's ping / pong slots (one each per source rank), behind the general region
 constexpr unsigned long long IPC_MAGIC = 0x6d69737461726b31ull;  // "mistark1"
 struct IpcComm
 {
@@ -177,6 +178,8 @@ struct IpcComm
     unsigned int* err = nullptr;  // pinned, device-visible
     uint32_t seq = 0;          // exchanges issued so far in the general region
     uint32_t fast_tag = 0;     // tags used up in the fast region (IpcView::fast_tag)
+    size_t pre_off = 0;        // first granule of the pre-flight's slots
+    uint32_t pre_tag = 0;      // tags the pre-flights have used up
     ~IpcComm()
     {
         (void)hipSetDevice(device);
@@ -210,6 +213,44 @@ __global__ __launch_bounds__(IPC_TB) void k_ipc_wait(const unsigned long long* _
     for (size_t t = (size_t)blockIdx.x * IPC_TB + threadIdx.x; t < total; t += (size_t)gridDim.x * IPC_TB) {
         const size_t r = t / n, i = t - r * n;
         recv[t] = granule_wait_f64(mine + slot0 + r * slot_granules + 2 * i, tag, err, t0, budget, 1u | (tag << 8));
+    }
+}
+
+// ---- pre-flight: one tagged granule over every ordered pair of ranks, with a short time-out -----------------------------------------------
+// What a first run on N real GPUs has to find out before anything is built on the windows: does a system-scope store into a peer's mapped
+// window ARRIVE (over xGMI, or inside one device when the ranks share it), and how long does it take. One lane per rank plays ping-pong with
+// every peer in turn: in round k rank r pings p = r + k (mod W) and answers the ping of q = r - k; `iters` exchanges per round, each with
+// its own tag; the round trip is taken on the device's constant clock around ping store -> pong seen. Every wait is bounded by `budget`
+// ticks counted from the kernel's start: a granule that never arrives ends the kernel with rtt = 0 for that peer instead of hanging.
+// Slots (own region of the window, dist.hip "ipc_layout"): [pre_off + s] = ping of source s, [pre_off + MAX_IPC_RANKS + s] = pong of source s.
+__device__ __forceinline__ bool granule_poll_tag(const unsigned long long* g, uint32_t tag, unsigned long long t0, unsigned long long budget)
+{
+    for (unsigned spins = 0;; spins++) {
+        if ((uint32_t)(granule_load(g) >> 32) == tag) return true;
+        if ((spins & 63u) == 63u && wall_clock64() - t0 > budget) return false;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+__global__ void k_ipc_preflight(IpcPeers pk, int rank, int world, size_t pre_off, uint32_t tag0, int iters, unsigned long long budget, unsigned long long* rtt_min /* world */,
+                                unsigned int* failed /* 0, or 1 + the peer whose granule did not arrive */)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long t_start = wall_clock64();
+    const unsigned long long* mine = pk.win[rank];
+    for (int k = 1; k < world; k++) {
+        const int p = (rank + k) % world, q = (rank - k + world) % world;
+        unsigned long long best = ~0ull;
+        for (int it = 0; it < iters; it++) {
+            const uint32_t tag = tag0 + (uint32_t)((k - 1) * iters + it) + 1u;
+            const unsigned long long t0 = wall_clock64();
+            granule_store(pk.win[p] + pre_off + (size_t)rank, tag, (uint32_t)rank);                         // ping p
+            if (!granule_poll_tag(mine + pre_off + (size_t)q, tag, t_start, budget)) { *failed = 1u + (unsigned)q; return; }  // q's ping
+            granule_store(pk.win[q] + pre_off + MAX_IPC_RANKS + (size_t)rank, tag, (uint32_t)rank);         // pong to q
+            if (!granule_poll_tag(mine + pre_off + MAX_IPC_RANKS + (size_t)p, tag, t_start, budget)) { *failed = 1u + (unsigned)p; return; }  // p's pong
+            const unsigned long long dt = wall_clock64() - t0;
+            if (it > 0 && dt < best) best = dt;  // (the first exchange of a round holds the ranks' skew)
+        }
+        rtt_min[p] = best;
     }
 }
 struct IpcCollective : Collective
@@ -281,8 +322,9 @@ struct IpcCollective : Collective
 static void ipc_layout(IpcComm& m)
 {
     const size_t fast = m.granules / 4;
-    const size_t gen = m.granules - fast - IPC_HDR;
+    const size_t gen = m.granules - fast - IPC_HDR - IPC_PRE;
     m.cap = gen / (2 * (size_t)m.world * 2);
+    m.pre_off = m.granules - fast - IPC_PRE;
     m.view.rank = m.rank;
     m.view.world = m.world;
     m.view.fast_off = m.granules - fast;
@@ -356,6 +398,50 @@ void ipc_comm_connect(IpcComm& m, const char* handles)
     }
     m.connected = true;
 }
+
+// Collective (every rank, same arguments; the caller puts a host barrier in front so that the kernels start within the time-out of each other).
+// half_rtt_us[p] = half the best round trip with peer p in microseconds (0 for the own rank, < 0 where no granule came back);
+// returns the number of peers that answered.
+int ipc_comm_preflight(IpcComm& m, int iters, double timeout_s, double* half_rtt_us)
+{
+    if (!m.connected) throw Error("IPC communicator: connect it before the pre-flight");
+    if (iters < 2) iters = 2;
+    MS_CHECK(hipSetDevice(m.device));
+    int khz = 0;
+    MS_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m.device));
+    khz = std::max(khz, 1000);
+    const unsigned long long budget = (unsigned long long)(std::min(std::max(timeout_s, 0.01), 2.0) * 1e3 * (double)khz);
+    const int W = m.world;
+    if ((unsigned long long)m.pre_tag + (unsigned long long)W * (unsigned long long)iters + 1ull > 0xffffffffull) throw Error("IPC communicator: pre-flight tags used up");
+    IpcPeers pk{};
+    for (int r = 0; r < W; r++) pk.win[r] = m.view.win[r];
+    // (test hook: MISTARK_IPC_FAULT=drop_preflight makes rank 1's stores land in its OWN window instead of the peers' — what a mapping that does
+    // not reach the peer looks like from the outside: nothing ever arrives, and the pre-flight has to notice within its time-out)
+    if (const char* f = std::getenv("MISTARK_IPC_FAULT"))
+        if (std::strcmp(f, "drop_preflight") == 0 && m.rank == 1)
+            for (int r = 0; r < W; r++) pk.win[r] = m.mine - (r == m.rank ? 0 : IPC_PRE);  // (the general region's unused tail: the communicator is dropped afterwards)
+    unsigned long long* res = nullptr;  // [world] round trips in ticks | failed word
+    MS_CHECK(hipHostMalloc((void**)&res, (MAX_IPC_RANKS + 1) * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped));
+    for (int i = 0; i <= MAX_IPC_RANKS; i++) res[i] = 0;
+    hipStream_t s;
+    MS_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    hipLaunchKernelGGL(k_ipc_preflight, dim3(1), dim3(64), 0, s, pk, m.rank, W, m.pre_off, m.pre_tag, iters, budget, res, (unsigned int*)(res + MAX_IPC_RANKS));
+    const hipError_t e = hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+    m.pre_tag += (uint32_t)((W - 1) * iters);
+    int ok = 0;
+    for (int p = 0; p < W; p++) {
+        if (p == m.rank) half_rtt_us[p] = 0.0;
+        else if (res[p] == 0 || res[p] == ~0ull) half_rtt_us[p] = -1.0;
+        else {
+            half_rtt_us[p] = 0.5 * (double)res[p] / (double)khz * 1e3;
+            ok++;
+        }
+    }
+    (void)hipHostFree(res);
+    MS_CHECK(e);
+    return ok;
+}
 std::unique_ptr<Collective> make_ipc_collective(std::shared_ptr<IpcComm> comm) { return std::make_unique<IpcCollective>(std::move(comm)); }
 int ipc_comm_rank(const IpcComm& comm) { return comm.rank; }
 int ipc_comm_world(const IpcComm& comm) { return comm.world; }
@@ -371,6 +457,57 @@ void rccl_unique_id(char out[128])
     Id id;
     nccl_check(rccl().GetUniqueId(&id), "ncclGetUniqueId");
     std::memcpy(out, id.internal, 128);
+}
+
+// ---- RCCL leg of the N-GPU bench line: the two all-reduces north_star names, timed on THIS transport whatever the default one is ----------
+// ncclAllReduce (sum, f64) of `n_big` doubles — the gradient of the shared DoFs (SymX's reduction of the thread-local gradients,
+// SecondOrderCompiledGlobal.cpp:72-142) — and of 3 doubles — the dot products of one CG iteration (BlockedSparseMatrix/solve_pcg.h:180,201,217)
+// — `reps` launches each, back to back on one stream between HIP events, after 5 warm-up launches; every element of the first result is
+// checked against the closed-form sum over the ranks. out[0] = ncclCommCount of the communicator, out[1] = microseconds per all-reduce of
+// n_big doubles, out[2] = of 3 doubles, out[3] = seconds ncclCommInitRank took. Collective: every rank calls it with the same arguments and
+// rank 0's unique id; one rank per device (RCCL refuses two ranks on one).
+void rccl_allreduce_bench(int device, int rank, int world, const char uid[128], size_t n_big, int reps, double out[4])
+{
+    if (world < 1 || rank < 0 || rank >= world || n_big == 0 || reps <= 0) throw Error("rccl_allreduce_bench: bad arguments");
+    MS_CHECK(hipSetDevice(device));
+    const auto t_init = std::chrono::steady_clock::now();
+    RcclCollective coll(rank, world, uid);
+    out[3] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_init).count();
+    out[0] = (double)coll.transport_ranks();
+    hipStream_t s;
+    MS_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    DevBuf<double> send, recv;
+    send.ensure(n_big);
+    recv.ensure(n_big);
+    std::vector<double> h(n_big);
+    for (size_t i = 0; i < n_big; i++) h[i] = (double)(rank + 1) * (double)(1 + i % 7);  // (small integers: the sum is exact in any order)
+    MS_CHECK(hipMemcpy(send.p, h.data(), n_big * sizeof(double), hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    MS_CHECK(hipEventCreate(&e0));
+    MS_CHECK(hipEventCreate(&e1));
+    const double ranks_sum = 0.5 * (double)world * (double)(world + 1);
+    int slot = 1;
+    for (size_t n : {n_big, (size_t)3}) {
+        MS_CHECK(hipMemsetAsync(recv.p, 0, n * sizeof(double), s));
+        for (int w = 0; w < 5; w++) nccl_check(rccl().AllReduce(send.p, recv.p, n, 8 /* ncclFloat64 */, 0 /* ncclSum */, coll.comm, s), "ncclAllReduce(f64, sum)");
+        MS_CHECK(hipMemcpyAsync(h.data(), recv.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        MS_CHECK(hipStreamSynchronize(s));
+        for (size_t i = 0; i < n; i++)
+            if (h[i] != ranks_sum * (double)(1 + i % 7))
+                throw Error("RCCL all-reduce of " + std::to_string(n) + " doubles over " + std::to_string(world) + " ranks: entry " + std::to_string(i) + " is " + std::to_string(h[i]) +
+                            ", expected " + std::to_string(ranks_sum * (double)(1 + i % 7)));
+        MS_CHECK(hipEventRecord(e0, s));
+        for (int r = 0; r < reps; r++) nccl_check(rccl().AllReduce(send.p, recv.p, n, 8, 0, coll.comm, s), "ncclAllReduce(f64, sum)");
+        MS_CHECK(hipEventRecord(e1, s));
+        MS_CHECK(hipStreamSynchronize(s));
+        float ms = 0.f;
+        MS_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        out[slot++] = 1e3 * (double)ms / (double)reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    MS_CHECK(hipStreamSynchronize(s));
+    (void)hipStreamDestroy(s);
 }
 
 }  // namespace mistark

@@ -94,5 +94,9 @@ int ipc_comm_rank(const IpcComm& comm);
 int ipc_comm_world(const IpcComm& comm);
 int ipc_comm_device(const IpcComm& comm);
 void rccl_unique_id(char out[128]);
+// dist.hip: pre-flight of the windows (one tagged granule over every ordered pair of ranks, bounded by timeout_s <= 2 s) and the RCCL leg
+// of the N-GPU bench line (ncclAllReduce of n_big and of 3 doubles)
+int ipc_comm_preflight(IpcComm& comm, int iters, double timeout_s, double* half_rtt_us /* world */);
+void rccl_allreduce_bench(int device, int rank, int world, const char unique_id[128], size_t n_big, int reps, double out[4]);
 
 }  // namespace mistark

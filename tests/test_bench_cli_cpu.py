@@ -26,3 +26,53 @@ def test_more_ranks_than_visible_gpus_is_refused():
 def test_world_size_that_disagrees_with_gpus_is_refused():
     r = _run(["--gpus", "4", "--no-cpu-baseline"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and b"WORLD_SIZE=2" in r.stderr
+
+
+def _bench():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_model_column_is_designs_multi_gpu_table():
+    """DESIGN.md "Multi-GPU": 106 CG iterations and 3.6 solves per Newton iteration, 158 k of 1 M elements per rank at 8 ranks ->
+    1.7 + 0.4 + 0.34 + 0.4 ms; one GPU 4.1 + 0.4 + 1.5 + 0.8 ms; 2.3x."""
+    b = _bench()
+    m8 = b.model_ms_per_newton(8, 106.0, 3.6, 0.158)
+    m1 = b.model_ms_per_newton(1, 106.0, 3.6, 1.0)
+    assert abs(m8["linear_solve"] - 2.11) < 0.02 and abs(m8["evaluation_assembly_projection"] - 0.34) < 0.01 and abs(m8["contact_callbacks"] - 0.45) < 0.01
+    assert abs(m1["linear_solve"] - 4.5) < 0.02 and m1["evaluation_assembly_projection"] == 1.5 and m1["contact_callbacks"] == 0.8
+    assert 2.2 < m1["total"] / m8["total"] < 2.5
+    # a world between the measured points interpolates monotonically
+    assert b.model_ms_per_newton(2, 106.0, 3.6, 0.55)["total"] > b.model_ms_per_newton(3, 106.0, 3.6, 0.4)["total"] > b.model_ms_per_newton(4, 106.0, 3.6, 0.3)["total"]
+
+
+def test_stage_table_and_refused_rccl_leg_have_the_pinned_keys():
+    """The N > 1 parts of the JSON line, built from made-up rank reports (no GPU): the stage table beside the model and the RCCL leg of ranks
+    that share a device (refused before any RCCL call, keys present and null)."""
+    b = _bench()
+    per_rank = [{"newton": 6.0, "linear_solve": 3.0 + r, "eval_pgh": 0.5, "eval_p": 0.1, "project": 0.2, "assembly": 0.3, "callback": 0.7, "step": 6.5} for r in range(4)]
+    seen = [{"rank": r, "device": 0, "pci_bus_id": "0000:05:00.0", "elements_evaluated": 300_000, "elements_total": 1_000_000} for r in range(4)]
+    t = b.stage_table(per_rank, 4, 20, 72, 2100, seen, 7.5)
+    assert all(k in t for k in b.STAGE_TABLE_KEYS)
+    for col in ("measured", "model", "model_one_gpu"):
+        assert all(k in t[col] for k in b.STAGE_KEYS), col
+    assert t["measured"]["linear_solve"] == 6.0 and t["measured"]["evaluation_assembly_projection"] == 1.1 and t["measured"]["total"] == 7.5   # slowest rank per stage
+    assert t["largest_element_share"] == 0.3 and t["model_speedup"] > 1.0
+
+    called = []
+    leg, hung = b.rccl_allreduce_leg(None, None, 0, 4, 0, seen, lambda: called.append("uid"), lambda x: called.append("gather"), 517050)
+    assert not hung and not called                      # refused before any collective or library call
+    assert all(k in leg for k in b.RCCL_LEG_KEYS) and leg["ranks"] is None and "share a device" in leg["refused"]
+
+
+def test_line_keys_are_what_the_source_prints():
+    """Every key of LINE_KEYS is a top-level key of the dict bench.py prints (source check: the line itself needs a GPU)."""
+    b = _bench()
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src[src.index("        out = {\n            \"metric\""):src.index("        print(json.dumps(out))")]
+    for k in b.LINE_KEYS:
+        assert ('            "%s":' % k) in body or ('out["%s"]' % k) in body, k

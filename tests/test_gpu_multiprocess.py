@@ -105,6 +105,40 @@ def test_plain_bench_command_launches_its_own_ranks(single, n):
     assert out["newton_iterations"] == single["newton_iterations"] == 8
     assert out["linear_solves"] == single["linear_solves"]
     assert abs(out["cg_iterations"] - single["cg_iterations"]) <= single["linear_solves"]
+    # the N > 1 parts of the line: the windows' pre-flight with its peer-latency matrix, the RCCL leg (refused here: the ranks
+    # share the one device, and the line says so instead of skipping it silently), measured stage times beside DESIGN.md's model
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert all(k in out for k in b.LINE_KEYS), [k for k in b.LINE_KEYS if k not in out]
+    pf = out["preflight"]
+    assert all(k in pf for k in b.PREFLIGHT_KEYS) and pf["ok"] and pf["timeout_s"] <= 2.0 and pf["wall_s"] < 10.0
+    lat = out["peer_latency_us"]
+    assert len(lat) == n and all(len(row) == n for row in lat)
+    assert all(lat[a][a] == 0.0 and all(0.0 < lat[a][c] < 5e4 for c in range(n) if c != a) for a in range(n)), lat
+    assert out["config"]["transport"] == "ipc" and out["config"]["transport_fallback_reason"] is None
+    assert all(k in out["rccl"] for k in b.RCCL_LEG_KEYS) and out["rccl"]["ranks"] is None and "share a device" in out["rccl"]["refused"]
+    st = out["stages_ms_per_newton_iteration"]
+    assert all(k in st for k in b.STAGE_TABLE_KEYS) and all(k in st[c] for c in ("measured", "model", "model_one_gpu") for k in b.STAGE_KEYS)
+    assert st["measured"]["total"] == pytest.approx(out["ms_per_step"], rel=1e-2) and 0 < st["measured"]["linear_solve"] < st["measured"]["total"]
+    assert 1.0 / n <= st["largest_element_share"] < 1.0
+
+
+def test_preflight_that_times_out_falls_back_and_says_so():
+    """A window that never delivers (MISTARK_IPC_FAULT=drop_preflight: rank 1's pre-flight stores go nowhere) must cost the run no more than the
+    pre-flight's 2 s time-out and be REPORTED: every rank takes RCCL — which refuses ranks sharing a device, so on this box the run ends with that
+    error rather than with numbers from a transport that does not work."""
+    env = _env()
+    env["MISTARK_IPC_FAULT"] = "drop_preflight"
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = __import__("time").perf_counter()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + ARGS, cwd=ROOT, env=env, capture_output=True, timeout=600)
+    err = r.stderr.decode()
+    assert "falling back to RCCL" in err and "pre-flight" in err, err[-3000:]
+    assert r.returncode != 0 and ("Duplicate GPU" in err or "RCCL" in err), err[-3000:]   # (one device: RCCL refuses; on N devices the run continues on it)
+    assert __import__("time").perf_counter() - t0 < 240
 
 
 def test_plain_bench_command_refuses_more_ranks_than_gpus():

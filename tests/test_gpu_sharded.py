@@ -203,6 +203,25 @@ def test_rccl_transport_single_rank_roundtrip():
     eng.close()
 
 
+def test_rccl_allreduce_leg_single_rank():
+    """The RCCL leg of an N > 1 bench line (mistark_rccl_allreduce_bench: ncclCommInitRank, ncclAllReduce(f64, sum) of ndofs and of 3 doubles,
+    results checked against the closed-form sum, ncclCommCount) with a one-rank communicator on the test box's GPU — the same entry points,
+    argument order and enum values the N-rank call uses."""
+    import ctypes as C
+
+    from stark_amd import capi
+
+    L = capi.lib()
+    uid = C.create_string_buffer(128)
+    assert L.mistark_dist_unique_id(uid) == 0
+    out = (C.c_double * 4)()
+    err = C.create_string_buffer(512)
+    assert L.mistark_rccl_allreduce_bench(0, 0, 1, uid.raw, 517050, 50, out, err, 512) == 0, err.value
+    assert out[0] == 1.0 and 0.0 < out[1] < 1e5 and 0.0 < out[2] < 1e5 and out[3] >= 0.0
+    # a rank outside the world is an argument error with a message, not a crash
+    assert L.mistark_rccl_allreduce_bench(0, 2, 1, uid.raw, 8, 1, out, err, 512) != 0 and b"bad arguments" in err.value
+
+
 @pytest.mark.parametrize("world", [3, 8])
 def test_sharded_contact_scene_real_partition(world):
     """A block large enough for a real partition (2 331 block rows, recursive coordinate bisection from the scene's rest positions) on a
