@@ -181,6 +181,9 @@ int mistark_sim_set_dist_ipc(mistark_sim* sim, mistark_ipc_comm* comm, int rank,
 
 /* Replace the Newton settings used by the following steps (stark::core::Settings::newton). */
 int mistark_sim_set_newton_settings(mistark_sim* sim, const mistark_newton_settings* s);
+/* symx::SolverCallbacks::add_max_allowed_step (solver_utils.h:73; the hook a CCD would use): every registered callback is asked once per line
+ * search, the smallest answer < 1 scales the step ([max] stage, NewtonsMethod.cpp:494-506). Runs on the calling thread. */
+int mistark_sim_add_max_allowed_step(mistark_sim* sim, double (*f)(void* user), void* user);
 /* Stark::run_one_step: 1 = continue, 0 = stop */
 int mistark_sim_run_one_step(mistark_sim* sim);
 

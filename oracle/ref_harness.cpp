@@ -151,6 +151,11 @@ static stark::Settings base_settings(const Args& a, const std::string& name)
     else if (proj == "ProjectedNewton") settings.newton.projection_mode = symx::ProjectionToPD::ProjectedNewton;
     else if (proj == "Newton") settings.newton.projection_mode = symx::ProjectionToPD::Newton;
     else if (proj == "ProjectOnDemand") settings.newton.projection_mode = symx::ProjectionToPD::ProjectOnDemand;
+    // the rest of the Newton driver's knobs (solver_utils.h:173-259), for the fixtures that pin its non-default branches
+    settings.newton.project_to_pd_use_mirroring = a.i("mirroring", settings.newton.project_to_pd_use_mirroring ? 1 : 0) != 0;
+    settings.newton.project_on_demand_countdown = a.i("countdown", settings.newton.project_on_demand_countdown);
+    settings.newton.step_cap = a.d("step_cap", settings.newton.step_cap);
+    settings.simulation.gravity[2] = a.d("gz", settings.simulation.gravity[2]);
     return settings;
 }
 
@@ -1319,15 +1324,40 @@ int main(int argc, char** argv)
             iterates.push_back(u);
             iter_step.push_back(cur_step);
         });
+        // `maxstep`: a user callback of SolverCallbacks::add_max_allowed_step (the hook a CCD would use; no STARK model registers one) that
+        // allows this fraction of every step: the [max] stage of the line search (NewtonsMethod.cpp:494-506)
+        // `vamp`: start velocities v0_i[d] = vamp sin(1.3 (3 i + d) + 0.7) on every point (a violent first step: inverted and indefinite
+        // elements, invalid line-search candidates), set before the first time step
+        const double vamp = a.d("vamp", 0.0);
+        if (vamp != 0.0) {
+            auto& pts = *sc.sim->deformables->point_sets;
+            for (int i = 0; i < pts.size(); i++)
+                for (int d = 0; d < 3; d++) pts.v0.data[(size_t)i][d] = vamp * std::sin(1.3 * (3.0 * i + d) + 0.7);
+        }
+        const double maxstep = a.d("maxstep", 1.0);
+        if (maxstep < 1.0) st.callbacks->newton->add_max_allowed_step([maxstep]() { return maxstep; });
         std::ostringstream man;
         man.precision(17);
         man << "{\"scene\":" << sc.json << ",\"steps\":[";
+        auto& lg = *st.context->logger;
         for (cur_step = 0; cur_step < steps; cur_step++) {
             const double dt_used = st.dt;
+            const bool have = cur_step > 0;
+            const int n_a = have ? lg.get_int("newton_iterations") : 0, l_a = have ? lg.get_timer_count("linear_system_solve") : 0;
             sc.step();
-            man << (cur_step ? "," : "") << "{\"dt\":" << dt_used << ",\"time\":" << st.current_time << "}";
+            man << (cur_step ? "," : "") << "{\"dt\":" << dt_used << ",\"time\":" << st.current_time << ",\"newton\":" << lg.get_int("newton_iterations") - n_a
+                << ",\"linear_solves\":" << lg.get_timer_count("linear_system_solve") - l_a << "}";
         }
-        auto& lg = *st.context->logger;
+        for (const char* key : {"ls_cap", "ls_max", "ls_inv"}) {
+            man << "],\n\"" << key << "\":[";
+            const auto& v = lg.get_int_series(key);
+            for (size_t i = 0; i < v.size(); i++) man << (i ? "," : "") << v[i];
+        }
+        for (const char* key : {"n_projected_hessians", "n_hessians"}) {  // (logged as doubles, NewtonsMethod.cpp:199-203)
+            man << "],\n\"" << key << "\":[";
+            const auto& v = lg.get_double_series(key);
+            for (size_t i = 0; i < v.size(); i++) man << (i ? "," : "") << (long long)v[i];
+        }
         man << "],\n\"newton_iterations\":[";
         { const auto& v = lg.get_int_series("newton_iterations"); for (size_t i = 0; i < v.size(); i++) man << (i ? "," : "") << v[i]; }
         man << "],\n\"cg_iterations\":[";

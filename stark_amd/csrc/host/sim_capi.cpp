@@ -699,6 +699,14 @@ int mistark_sim_set_newton_settings(mistark_sim* s, const mistark_newton_setting
     s->sim->get_stark().settings.newton = *ns;
     SIM_END
 }
+int mistark_sim_add_max_allowed_step(mistark_sim* s, double (*f)(void* user), void* user)
+{
+    // symx::SolverCallbacks::add_max_allowed_step (solver_utils.h:73): the [max] stage of the line search, NewtonsMethod.cpp:494-506
+    SIM_BEGIN
+    if (!f) throw std::runtime_error("mistark_sim_add_max_allowed_step: null callback");
+    s->sim->get_stark().callbacks->newton->add_max_allowed_step([f, user]() { return f(user); });
+    SIM_END
+}
 int mistark_sim_run_one_step(mistark_sim* s)
 {
     SIM_BEGIN

@@ -90,6 +90,7 @@ def _lib():
         L.mistark_sim_attachment_stiffness.argtypes = [p, C.c_int, C.POINTER(C.c_double)]
         L.mistark_sim_run_one_step.argtypes = [p]
         L.mistark_sim_set_newton_settings.argtypes = [p, C.POINTER(capi.NewtonSettings)]
+        L.mistark_sim_add_max_allowed_step.argtypes = [p, capi.DBLCB, C.c_void_p]
         L.mistark_sim_prepare.argtypes = [p]
         L.mistark_sim_begin_time_step.argtypes = [p]
         L.mistark_sim_before_energy_evaluation.argtypes = [p]
@@ -415,6 +416,14 @@ class Simulation:
 
     def set_newton_settings(self, s: capi.NewtonSettings):
         self._ck(self.L.mistark_sim_set_newton_settings(self.h, C.byref(s)))
+
+    def add_max_allowed_step(self, fn):
+        """fn() -> fraction of the Newton step the line search may take (symx::SolverCallbacks::add_max_allowed_step)."""
+        from . import capi
+
+        cb = capi.DBLCB(lambda _u: float(fn()))
+        self._keep_cb = getattr(self, "_keep_cb", []) + [cb]
+        self._ck(self.L.mistark_sim_add_max_allowed_step(self.h, cb, None))
 
     def run_one_step(self) -> bool:
         return self._ck(self.L.mistark_sim_run_one_step(self.h)) == 1

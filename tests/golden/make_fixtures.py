@@ -101,6 +101,24 @@ FIXTURES = {
     # names the engine has no kernel for — through the shim they run SymX's op sequence on the device interpreter
     "traj_user_magnetic_3": ("traj", "magnetic", "n=3 k=20 steps=5 slim=1"),
     "traj_user_foreach_3": ("traj", "foreach", "n=3 k=20 steps=5 slim=1"),
+    # The Newton driver's non-default branches (NewtonsMethod.cpp:254-386 _increase/_decrease_projection, :459-641 line search): the same beam
+    # thrown about by start velocities of 40 m/s (`vamp`: inverted / indefinite elements in the first steps) under each projection mode —
+    # Newton fails its steps and halves dt, ProjectedNewton projects everything, ProjectOnDemand counts down 4 iterations after a failure,
+    # Progressive tightens and releases —, with mirroring, with a step cap ([cap]) and with a max_allowed_step callback ([max]); an
+    # elasticity-only beam at dt = 0.2 that runs ProjectOnDemand through several countdown cycles; the block on the box under ProjectedNewton /
+    # ProjectOnDemand / Newton, and thrown at the box (3 m/s: an invalid line-search candidate, [inv])
+    "traj_tetbeam_big_progressive": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=0 steps=3 slim=1 vamp=40 projection=Progressive"),
+    "traj_tetbeam_big_newton": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=0 steps=3 slim=1 vamp=40 projection=Newton"),
+    "traj_tetbeam_big_projected": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=0 steps=3 slim=1 vamp=40 projection=ProjectedNewton"),
+    "traj_tetbeam_big_ondemand": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=0 steps=3 slim=1 vamp=40 projection=ProjectOnDemand"),
+    "traj_tetbeam_big_mirror": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=0 steps=3 slim=1 vamp=40 projection=ProjectedNewton mirroring=1"),
+    "traj_tetbeam_big_ondemand_eo": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=1 steps=3 slim=1 vamp=15 dt=0.2 projection=ProjectOnDemand"),
+    "traj_tetbeam_big_cap": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=0 steps=3 slim=1 vamp=40 step_cap=8"),
+    "traj_tetbeam_big_max": ("traj", "tetbeam", "nx=8 ny=2 nz=2 eo=0 steps=3 slim=1 vamp=40 maxstep=0.6"),
+    "traj_blockbox_3_projected": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=1 slim=1 projection=ProjectedNewton"),
+    "traj_blockbox_3_ondemand": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=1 slim=1 projection=ProjectOnDemand"),
+    "traj_blockbox_3_newton": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=1 slim=1 projection=Newton"),
+    "traj_blockbox_3_thrown": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=4 boxfirst=1 slim=1 vamp=3"),
     "traj_blockbox_3_nofriction": ("traj", "blockbox", "nx=3 ny=3 nz=3 L=0.2 gap=0.004 thickness=0.005 bx=0.5 kmin=1e5 steps=6 boxfirst=0 mu=0"),
 }
 
@@ -119,7 +137,7 @@ def pack(name):
     args = args.split()
     tmp = tempfile.mkdtemp(prefix="mistark_fx_")
     try:
-        scene_args = [a for a in args if not a.startswith(("steps=", "amp=", "xamp=", "frames="))]
+        scene_args = [a for a in args if not a.startswith(("steps=", "amp=", "xamp=", "frames=", "vamp=", "maxstep="))]
         if mode != "geom":
             run([HARNESS, "prime", scene] + scene_args)
         if mode == "steplog":

@@ -297,6 +297,87 @@ def test_block_on_box_contact_trajectory(name, options, monkeypatch):
     sim.close()
 
 
+NEWTON_BRANCH_FIXTURES = ["traj_tetbeam_big_progressive", "traj_tetbeam_big_newton", "traj_tetbeam_big_projected", "traj_tetbeam_big_ondemand", "traj_tetbeam_big_mirror",
+                          "traj_tetbeam_big_ondemand_eo", "traj_tetbeam_big_cap", "traj_tetbeam_big_max", "traj_blockbox_3_projected", "traj_blockbox_3_ondemand",
+                          "traj_blockbox_3_newton", "traj_blockbox_3_thrown"]
+
+
+@pytest.mark.parametrize("name", NEWTON_BRANCH_FIXTURES)
+def test_newton_driver_branches_equal_the_reference_log(name):
+    """The Newton driver's non-default branches against the reference's own log (NewtonsMethod.cpp:254-386 _increase/_decrease_projection,
+    :459-641 line search): projection modes Newton / ProjectedNewton / ProjectOnDemand / Progressive on a beam whose first steps hold inverted and
+    indefinite elements (start velocities of 40 m/s), eigenvalue mirroring, the [cap] stage (step_cap), the [max] stage (a max_allowed_step callback),
+    several ProjectOnDemand countdown cycles, the three modes on the contact scene, and an invalid line-search candidate ([inv]).
+    Per time-step attempt: Newton iterations and linear solves `==` (a failed attempt and its halved dt included: the time stamps must agree);
+    per Newton iteration: the ls_cap / ls_max / ls_inv / ls_bt series and the projected-Hessian counts `==`, CG iterations of the last solve
+    within the parity rule; end state 1e-6 (1e-4 with contact, as everywhere)."""
+    from stark_amd import capi
+    from stark_amd import sim as S
+
+    z, traj, man = _load(name)
+    sc = traj["scene"]
+    args = dict(kv.split("=") for kv in bytes(z["harness_args"]).decode().split()[2:])
+    st = S.default_settings()
+    st.init_frictional_contact = 1 if sc["kind"] == "blockbox" else 0
+    if "dt" in args:
+        st.max_time_step_size = float(args["dt"])
+    sim = S.Simulation(st)
+    if sc["kind"] == "tetbeam":
+        p = S.soft_rubber()
+        p.elasticity_only = sc["eo"]
+        ps = sim.add_volume_grid("beam", (0, 0, 0), (sc["lx"], sc["ly"], sc["lz"]), (sc["nx"], sc["ny"], sc["nz"]), p)
+        sim.prescribe_inside_aabb(ps, (-0.5 * sc["lx"], 0, 0), (2e-3, 2 * sc["ly"], 2 * sc["lz"]), 1e7)
+        tol = 1e-6
+    else:
+        gp = S.contact_global_params()
+        gp.default_contact_thickness = sc["thickness"]
+        gp.min_contact_stiffness = sc["kmin"]
+        sim.set_contact_global_params(gp)
+        rb = sim.add_rigid_box("box", 1.0, (sc["bx"], sc["bx"], sc["bz"]))
+        sim.rb_add_constraint("fix", rb)
+        L = sc["L"]
+        ps = sim.add_volume_grid("block", (0.0, 0.0, 0.5 * sc["bz"] + sc["gap"] + 0.5 * L), (L, L, L), (sc["nx"], sc["ny"], sc["nz"]), S.soft_rubber())
+        sim.set_friction(sim.contact_group("d", ps), sim.contact_group("rb", rb), sc["mu"])
+        tol = 1e-4
+    ns = S.default_settings().newton
+    ns.projection_mode = {"Progressive": capi.PROJ_PROGRESSIVE, "Newton": capi.PROJ_NEWTON, "ProjectedNewton": capi.PROJ_PROJECTED_NEWTON,
+                          "ProjectOnDemand": capi.PROJ_ON_DEMAND}[args.get("projection", "Progressive")]
+    ns.project_to_pd_use_mirroring = int(args.get("mirroring", 0))
+    if "step_cap" in args:
+        ns.step_cap = float(args["step_cap"])
+    sim.set_newton_settings(ns)
+    if "maxstep" in args:
+        sim.add_max_allowed_step(lambda: float(args["maxstep"]))
+    if "vamp" in args:
+        v = sim.points("v0")
+        i = np.arange(v.shape[0])[:, None]
+        d = np.arange(3)[None, :]
+        sim.set_points("v0", float(args["vamp"]) * np.sin(1.3 * (3.0 * i + d) + 0.7))
+    rec = {k: [] for k in ("ls_cap", "ls_max", "ls_inv", "ls_bt", "n_projected_hessians", "cg_iterations")}
+    for step, ref in enumerate(traj["steps"]):
+        sim.run_one_step()   # (a failed attempt returns False when the run stops, True otherwise: the time stamp below says what happened)
+        i = sim.info()
+        assert abs(i.current_time - ref["time"]) < 1e-12, (step, i.current_time, ref["time"], i.last_newton_result)
+        assert (i.last_stats.newton_iterations, i.last_stats.n_linear_solves) == (ref["newton"], ref["linear_solves"]), (step, i.last_stats.newton_iterations, i.last_stats.n_linear_solves, ref)
+        for r in sim.newton_iteration_log():
+            if r.logged:
+                rec["n_projected_hessians"].append(int(r.n_projected_hessians))
+                rec["cg_iterations"].append(int(r.cg_iterations_last))
+            if r.line_search:
+                for k in ("ls_cap", "ls_max", "ls_inv", "ls_bt"):
+                    rec[k].append(int(getattr(r, k)))
+    for k in ("ls_cap", "ls_max", "ls_inv", "ls_bt", "n_projected_hessians"):
+        assert rec[k] == traj[k], (k, rec[k], traj[k])
+    assert len(rec["cg_iterations"]) == len(traj["cg_iterations"]) and all(abs(a - b) <= max(2, 0.15 * b) for a, b in zip(rec["cg_iterations"], traj["cg_iterations"])), (rec["cg_iterations"], traj["cg_iterations"])
+    x, vv = sim.points("x0"), sim.points("v0")
+    assert np.abs(x - z["x_end"]).max() <= tol * np.abs(z["x_end"]).max()
+    assert np.abs(vv - z["v_end"]).max() <= 10 * tol * max(np.abs(z["v_end"]).max(), 1.0)
+    # the fixtures do exercise what they are named for
+    want = {"traj_tetbeam_big_cap": "ls_cap", "traj_tetbeam_big_max": "ls_max", "traj_blockbox_3_thrown": "ls_inv", "traj_tetbeam_big_progressive": "ls_bt"}.get(name)
+    assert want is None or sum(traj[want]) > 0
+    sim.close()
+
+
 def _attachzoo(S, sc):
     """The attachzoo scene of oracle/ref_harness.cpp through the host layer: cloth hanging from two rods (point-point and point-edge
     attachments), a free rod riding on it (point-triangle, edge-edge) and a free rigid box hanging from its far edge (rigid-deformable)."""
