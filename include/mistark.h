@@ -333,6 +333,10 @@ int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us);
 /* Waits until everything queued on the engine's stream has finished (entry points that return values already do; assemble / project /
  * axpby only enqueue). For timing from the host. */
 int mistark_sync(mistark_ctx* ctx);
+/* Event counters of the context, by name (tests assert that a feature under test actually ran): "proj_speculated" / "proj_adopted" (projection
+ * rounds started beside a solve / taken over by the retry, option proj_speculation), "dof_skips_verified" (MISTARK_VERIFY_DOF_SKIP=1: DoF
+ * transfers skipped at an unchanged iterate and checked against a real transfer), "fused_solves" / "unfused_solves" (sharded PCG). */
+int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out);
 
 /* ---- multi-GPU: one problem sharded over `world` ranks, one engine context (and one process) per GPU ------------------------
  * Block rows are partitioned over the ranks (owner map: mistark_dist_set_row_owner, or a graph partition of the potentials' connectivity).

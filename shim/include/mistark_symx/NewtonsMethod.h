@@ -46,6 +46,7 @@ namespace symx
 		void print_summary(double total_time = -1.0) const;
 
 		mistark_ctx* engine() const;                                           // extension: nullptr before the first solve
+		long mistark_stale_solves() const;                                     // extension: solves that had to be redone because a callback edited a large input in place unseen by the sampled checks (0 in a healthy run; also the logger entry "mistark_stale_solves")
 
 	private:
 		struct Impl;

@@ -82,7 +82,8 @@ namespace symx
 		static constexpr int64_t SMALL_ARRAY = 32768;  // doubles: arrays up to this size are fingerprinted at every evaluation
 		bool strict = false;        // MISTARK_SHIM_STRICT=1
 		bool fast = false;          // MISTARK_SHIM_FAST=1
-		bool warned_stale = false;
+		bool resolve_stale = true;  // a solve that ran on stale inputs is redone in strict mode (MISTARK_SHIM_NO_RESOLVE=1: warn only)
+		int64_t n_stale_solves = 0; // solves whose end-of-solve check found inputs the engine had not seen
 		int64_t n_sample_hits = 0, n_stale = 0;  // large tables / arrays re-sent because their sample changed inside the Newton loop; missed edits found at the end of a solve
 		int64_t n_uploads = 0, n_table_updates = 0, bytes_sent = 0;  // statistics (MISTARK_SHIM_STATS=1 prints them at destruction)
 		double t_tables = 0.0, t_hash = 0.0, t_upload = 0.0;  // inside sync(): table updates in the engine, fingerprints, array uploads
@@ -179,6 +180,10 @@ namespace symx
 				          << " in-loop edits it missed), " << bytes_sent / 1e6 << " MB sent to the engine; of " << t_solve
 				          << " s in solve(): " << t_callbacks << " s in the caller's callbacks, " << t_sync << " s in sync() (" << t_tables << " table updates, " << t_hash << " array fingerprints, " << t_upload << " array uploads), " << t_dofs
 				          << " s bringing DoFs to the caller" << std::endl;
+			if (ctx && std::getenv("MISTARK_SHIM_STATS") && std::getenv("MISTARK_VERIFY_DOF_SKIP")) {
+				int64_t n = 0;
+				if (mistark_get_counter(ctx, "dof_skips_verified", &n) == 0) std::cerr << "mistark shim: " << n << " skipped DoF transfers verified against a real transfer" << std::endl;
+			}
 			if (ctx) mistark_destroy(ctx);
 		}
 
@@ -187,6 +192,7 @@ namespace symx
 			const char* dry_env = std::getenv("MISTARK_SHIM_DRY");
 			dry = dry_env && dry_env[0] == '1';
 			const char* strict_env = std::getenv("MISTARK_SHIM_STRICT");
+			if (const char* nr = std::getenv("MISTARK_SHIM_NO_RESOLVE")) resolve_stale = !(nr[0] == '1');
 			strict = strict_env && strict_env[0] == '1';
 			const char* fast_env = std::getenv("MISTARK_SHIM_FAST");
 			fast = fast_env && fast_env[0] == '1' && !strict;
@@ -377,9 +383,10 @@ namespace symx
 		// End of a solve: what the sampled checks inside the Newton loop may have missed. A large table or array whose bytes differ from what
 		// the engine holds was edited in place during the loop without its sample changing: the engine evaluated stale data from that point on.
 		// Said once, with the remedy; the data is sent so that the next solve does not start stale as well.
-		void verify_after_solve(GlobalPotential& gp)
+		int verify_after_solve(GlobalPotential& gp)
 		{
-			if (strict || fast || dry) return;
+			if (strict || fast || dry) return 0;
+			const int64_t stale_before = n_stale;
 			const double t0 = now();
 			std::string first;
 			const auto& potentials = gp.get_potentials();
@@ -406,12 +413,18 @@ namespace symx
 				}
 			}
 			t_hash += now() - t0;
-			if (!first.empty() && !warned_stale) {
-				warned_stale = true;
-				std::cerr << "mistark shim: WARNING: " << first << " was modified in place inside the Newton loop without its sampled fingerprint changing; the engine evaluated the "
-				          << "previous contents for the rest of that solve. Set MISTARK_SHIM_STRICT=1 (every table and array read in full at every evaluation) for callbacks that "
-				          << "edit a few entries of a large array in place." << std::endl;
+			const int missed = (int)(n_stale - stale_before);
+			if (missed > 0) {  // (every occurrence is said: a stale solve is never silent)
+				n_stale_solves++;
+				std::cerr << "mistark shim: WARNING: " << first << (missed > 1 ? " (and " + std::to_string(missed - 1) + " more)" : std::string())
+				          << " was modified in place inside the Newton loop without its sampled fingerprint changing; the engine evaluated the previous contents for the "
+				          << "rest of that solve (" << n_stale_solves << " such solve(s) so far). "
+				          << (resolve_stale ? "The solve is REDONE from its initial DoFs with every table and array read in full at every evaluation, and this solver stays "
+				                              "in that mode (MISTARK_SHIM_STRICT=1 selects it from the start; MISTARK_SHIM_NO_RESOLVE=1 keeps the stale result and only warns)."
+				                            : "MISTARK_SHIM_NO_RESOLVE=1: the stale result is kept. Set MISTARK_SHIM_STRICT=1 for callbacks that edit a few entries of a large array in place.")
+				          << std::endl;
 			}
+			return missed;
 		}
 
 		// ---- C callbacks of mistark_newton_solve -> SolverCallbacks (solver_utils.h:29-117). STARK's callbacks read the DoFs from the
@@ -448,6 +461,7 @@ namespace symx
 		return std::make_shared<NewtonsMethod>(global_potential, context, callbacks);
 	}
 	mistark_ctx* NewtonsMethod::engine() const { return impl->ctx; }
+	long NewtonsMethod::mistark_stale_solves() const { return (long)impl->n_stale_solves; }
 
 	SolverReturn NewtonsMethod::solve()
 	{
@@ -515,11 +529,30 @@ namespace symx
 		cb.is_converged_state_valid = Impl::cb_converged_valid;
 		cb.max_allowed_step = Impl::cb_max_step;
 
+		// (the DoFs the solve starts from, for the one case it has to be redone: inputs edited in place that the sampled checks missed)
+		std::vector<double> initial_dofs;
+		if (!s.strict && !s.fast && s.resolve_stale) {
+			initial_dofs.resize((size_t)global_potential->get_total_n_dofs());
+			global_potential->get_dofs(initial_dofs.data());
+		}
 		mistark_newton_stats st{};
-		const int rc = mistark_newton_solve(s.ctx, &ns, &cb, &st);
-		s.check(rc, "mistark_newton_solve");
-		s.check(mistark_dofs_to_host_arrays(s.ctx), "mistark_dofs_to_host_arrays");  // the reference leaves the solution in the caller's DoF arrays (NewtonsMethod.cpp:608-640)
-		s.verify_after_solve(*global_potential);
+		int rc = 0;
+		for (int attempt = 0;; attempt++) {
+			st = mistark_newton_stats{};
+			rc = mistark_newton_solve(s.ctx, &ns, &cb, &st);
+			s.check(rc, "mistark_newton_solve");
+			s.check(mistark_dofs_to_host_arrays(s.ctx), "mistark_dofs_to_host_arrays");  // the reference leaves the solution in the caller's DoF arrays (NewtonsMethod.cpp:608-640)
+			const int missed = s.verify_after_solve(*global_potential);
+			if (missed == 0 || !s.resolve_stale || initial_dofs.empty() || attempt > 0) break;
+			// the result above came from stale inputs: never hand it out. From here on this solver reads everything in full at every
+			// evaluation (the reference's semantics), and the solve starts again where it started (as the reference itself restarts a solve
+			// from `initial_dofs`, NewtonsMethod.cpp:616-619).
+			s.strict = true;
+			global_potential->set_dofs(initial_dofs.data());
+			s.sync(*global_potential, /*full=*/true);
+			s.check(mistark_dofs_from_host_arrays(s.ctx), "mistark_dofs_from_host_arrays");
+		}
+		this->context->logger->set("mistark_stale_solves", (int)s.n_stale_solves);
 		if (const char* path = std::getenv("MISTARK_SHIM_SOLVELOG"))  // one line per solve(): Newton iterations, linear solves, CG iterations
 			std::ofstream(path, std::ios::app) << st.newton_iterations << " " << st.n_linear_solves << " " << st.cg_iterations << std::endl;
 		this->stats.newton_iterations = st.newton_iterations;

@@ -108,6 +108,7 @@ def lib():
     L.mistark_get_dofs.argtypes = [p, p]
     L.mistark_set_dofs.argtypes = [p, p]
     L.mistark_dofs_to_host_arrays.argtypes = [p]
+    L.mistark_get_counter.argtypes = [p, C.c_char_p, C.POINTER(i64)]
     L.mistark_dofs_from_host_arrays.argtypes = [p]
     L.mistark_eval.argtypes = [p, C.c_int, C.POINTER(dbl), p]
     L.mistark_get_element_hessians.argtypes = [p, C.c_int, p, p, C.POINTER(i32)]

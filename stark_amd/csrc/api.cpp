@@ -527,6 +527,20 @@ int mistark_set_dofs(mistark_ctx* ctx, const double* u_host)
     MS_CHECK(hipStreamSynchronize(c.stream));
     API_END(0)
 }
+int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out)
+{
+    API_BEGIN
+    Context& c = ctx->c;
+    if (!name || !out) throw Error("mistark_get_counter: null argument");
+    const std::string n = name;
+    if (n == "proj_speculated") *out = c.n_proj_speculated;
+    else if (n == "proj_adopted") *out = c.n_proj_adopted;
+    else if (n == "dof_skips_verified") *out = c.n_dof_skips_verified;
+    else if (n == "fused_solves") *out = c.n_fused_solves;
+    else if (n == "unfused_solves") *out = c.n_unfused_solves;
+    else throw Error("mistark_get_counter: unknown counter '" + n + "'");
+    API_END(0)
+}
 int mistark_dofs_to_host_arrays(mistark_ctx* ctx)
 {
     API_BEGIN
@@ -548,6 +562,24 @@ int mistark_dofs_to_host_arrays_if_changed(mistark_ctx* ctx)
             if (s.n > 0) MS_CHECK(hipMemcpyAsync(s.host, c.u.p + s.offset, s.n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
         MS_CHECK(hipStreamSynchronize(c.stream));
         c.u_host_version = c.u_version;
+    } else {
+        // The skip is only right if EVERY device-side writer of the DoF vector bumped u_version. MISTARK_VERIFY_DOF_SKIP=1 (tests) does the
+        // transfer anyway into a scratch buffer and compares it with what the caller's arrays hold: a writer that forgot shows up as an error
+        // at the first skipped transfer instead of as callbacks silently reading old DoFs.
+        static const bool verify = [] { const char* e = std::getenv("MISTARK_VERIFY_DOF_SKIP"); return e && e[0] == '1'; }();
+        if (verify) {
+            std::vector<double> tmp;
+            for (auto& s : c.dof_sets) {
+                if (s.n <= 0) continue;
+                tmp.resize((size_t)s.n);
+                MS_CHECK(hipMemcpyAsync(tmp.data(), c.u.p + s.offset, s.n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+                MS_CHECK(hipStreamSynchronize(c.stream));
+                if (std::memcmp(tmp.data(), s.host, (size_t)s.n * sizeof(double)) != 0)
+                    throw Error("mistark_dofs_to_host_arrays_if_changed: the transfer was skipped (version " + std::to_string(c.u_version) + ") but DoF set '" + s.label +
+                                "' differs between the device and the caller's array: a writer of the DoF vector did not bump Context::u_version");
+            }
+            c.n_dof_skips_verified++;
+        }
     }
     API_END(0)
 }

@@ -1258,7 +1258,10 @@ int contact_add_mesh(Context& c, int kind, int idx_in_ps, const int32_t* vidx, i
     cs.n_v += nv;
     cs.n_t += nt;
     cs.n_e += ne;
-    if (std::max(cs.n_v, std::max(cs.n_t, cs.n_e)) >= (1 << PRIM_BITS)) throw Error("contact: too many collision primitives");
+    // (a sorted box entry packs the GLOBAL primitive index — vertices, then triangles, then edges — into PRIM_BITS bits beside its band: the
+    // sum has to fit, not only each class)
+    if ((long long)cs.n_v + (long long)cs.n_t + (long long)cs.n_e >= (1ll << PRIM_BITS))
+        throw Error("contact: too many collision primitives (vertices + triangles + edges must stay below 2^" + std::to_string(PRIM_BITS) + ")");
     cs.meshes.push_back(m);
     if (kind == MISTARK_CONTACT_RIGIDBODY) cs.disabled_pairs.push_back({g, g});
     cs.meshes_dirty = true;

@@ -190,7 +190,20 @@ __global__ __launch_bounds__(256) void k_eval_custom(PotArgs a, ProgDev p, doubl
     double in[CUSTOM_MAX_IN];
     gather_custom(a, p, e, in);
     bool on = true;
-    if (p.n_cops > 0) on = run_program(p.cops, p.cconsts, p.n_cops, in, p.in_dof, p.n_in, -1, -1).v > 0.0;  // SecondOrderCompiledPotential.cpp:185-197
+    if (p.n_cops > 0) {  // SecondOrderCompiledPotential.cpp:185-197: element active iff the condition's value is > 0
+        if (p.sum_n == 0) {
+            on = run_program(p.cops, p.cconsts, p.n_cops, in, p.in_dof, p.n_in, -1, -1).v > 0.0;
+        } else {
+            // the condition is compiled over the same workspace, so the reference runs IT through the summation loop as well
+            // (CompiledInLoop_run.h:375-400): its value is the sum over the rows of the summation data, accumulated in row order
+            double cv = 0.0;
+            for (int it = 0; it < p.sum_n; it++) {
+                for (int c = 0; c < p.sum_stride; c++) in[p.sum_first + c] = p.sum_data[(size_t)it * p.sum_stride + c];
+                cv += run_program(p.cops, p.cconsts, p.n_cops, in, p.in_dof, p.n_in, -1, -1).v;
+            }
+            on = cv > 0.0;
+        }
+    }
     HDual r(0.0);
     if (on) {
         if (p.sum_n == 0) {
@@ -384,6 +397,11 @@ void launch_eval_custom(Context& c, Potential& P, int mode)
             }
         }
     }
+    // (the summation loop overwrites its inputs with constants in every iteration: they cannot be DoFs, whose derivative seeds in_dof carries)
+    for (int k = 0; G.sum_n > 0 && k < G.sum_stride; k++)
+        if (in_dof[(size_t)(G.sum_first + k)] >= 0)
+            throw Error("custom potential '" + P.name + "': the summation inputs [" + std::to_string(G.sum_first) + ", " + std::to_string(G.sum_first + G.sum_stride) +
+                        ") overlap a binding on a DoF set (input " + std::to_string(G.sum_first + k) + ")");
     G.d_in_dof.ensure(std::max<size_t>(in_dof.size(), 1));
     MS_CHECK(hipMemcpyAsync(G.d_in_dof.p, in_dof.data(), in_dof.size() * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));  // (in_dof is a temporary)

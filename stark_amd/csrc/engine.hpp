@@ -413,6 +413,7 @@ struct Context
     bool proj_speculation = false;  // option "proj_speculation": the next projection round's selection and eigen kernels run beside the solve (measured: no gain)
     int64_t n_proj_speculated = 0, n_proj_adopted = 0;
     uint64_t data_version = 1;
+    int64_t n_dof_skips_verified = 0;  // MISTARK_VERIFY_DOF_SKIP=1: skipped transfers checked against a real one
     uint64_t u_version = 1, u_host_version = 0;  // the DoF vector on the device / as last brought to the caller's arrays (mistark_dofs_to_host_arrays_if_changed)
     // Evaluation kernels of the large closed-form potentials launched AHEAD of eval() (eval_prelaunch: while the callback that precedes an
     // evaluation — contact search, a caller's host code — keeps the host and the main stream busy). eval() takes the results if nothing

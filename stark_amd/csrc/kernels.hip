@@ -3500,6 +3500,9 @@ void project_spec_poll(Context& c)
 bool project_spec_adopt(Context& c, double eps, int mirroring, double threshold, int* all_active, int64_t* n_projected_now)
 {
     Context::ProjSpec& S = c.spec;
+    static const bool dbg = std::getenv("MISTARK_DEBUG_SPEC") != nullptr;
+    if (dbg) std::fprintf(stderr, "[spec] adopt? active %d pending %d threshold %.17g (round: %.17g) can %d (matrix_current %d have_hessians %d)\n", (int)S.active, (int)S.pending, threshold, S.threshold,
+                          (int)project_can_speculate(c), (int)c.matrix_current, (int)c.have_hessians);
     if (!S.active) return false;
     if (S.threshold != threshold || S.eps != eps || S.mirroring != mirroring || !project_can_speculate(c)) {
         project_spec_discard(c);
@@ -4196,27 +4199,10 @@ __device__ __forceinline__ void spmv_chunks(const int bid, const int nblk, const
         if (threadIdx.x == 0) partials[bid] = dot;
     }
 }
-// contribution of the contact part to block row `row` (written by spmv_chunks)
-__device__ __forceinline__ void dyn_row(const int32_t* __restrict__ crow_of_row, const uint32_t* __restrict__ row_chunk0, const double* __restrict__ yd,
-                                        const double* __restrict__ chunk_partial, int64_t row, double& q0, double& q1, double& q2)
-{
-    const int32_t cr = crow_of_row[row];
-    if (cr < 0) return;
-    const uint32_t c0 = row_chunk0[cr], c1 = row_chunk0[cr + 1];
-    if (c1 - c0 <= 1) {  // short rows (no chunk) and single-chunk rows: the row sum itself
-        q0 += yd[3 * (size_t)cr];
-        q1 += yd[3 * (size_t)cr + 1];
-        q2 += yd[3 * (size_t)cr + 2];
-    } else {
-        for (uint32_t k = c0; k < c1; k++) {  // fixed order: deterministic
-            q0 += chunk_partial[3 * (size_t)k];
-            q1 += chunk_partial[3 * (size_t)k + 1];
-            q2 += chunk_partial[3 * (size_t)k + 2];
-        }
-    }
-}
-// The same for rows whose chunk partials are many (a rigid body under 10^5 contacts: ~270 chunks): CALLED BY ALL LANES OF A WAVEFRONT (lanes
-// without a row pass row = -1). Rows up to DYN_FOLD_SERIAL chunks are folded by their own lane as in dyn_row; a longer row is folded by the
+// contribution of the contact part to block row `row` (written by spmv_chunks): short rows (no chunk) and single-chunk rows are the row sum itself,
+// longer rows the sum of their chunk partials in ascending order.
+// Rows may have many chunk partials (a rigid body under 10^5 contacts: ~270 chunks): CALLED BY ALL LANES OF A WAVEFRONT (lanes
+// without a row pass row = -1). Rows up to DYN_FOLD_SERIAL chunks are folded by their own lane; a longer row is folded by the
 // whole wavefront — lane l adds chunks l, l + 64, ... in ascending order, then the fixed-shape wave_sum: deterministic, the same bits in every
 // kernel that consumes the contact part (one lane walking 270 chunks held k_pcg_step at 30 us on configs[2]; the SpMV beside it takes 8).
 constexpr uint32_t DYN_FOLD_SERIAL = 8;

@@ -91,6 +91,9 @@ FIXTURES = {
     # edge-edge or edge-point is decided by the last bit of a product). Off the axes the reference's 8- and 4-thread logs are identical
     # and reproducible.
     "steplog_cfg3_offset_44x44x43": ("steplog", "blockbox", "nx=44 ny=44 nz=43 L=1 gap=0.0015 thickness=0.001 mu=0.5 kmin=1e8 bx=3 bz=0.1 boxfirst=1 ox=0.00137 oy=-0.00053 steps=8"),
+    # configs[2] as BASELINE describes it — a 256 x 256 Cotton_Fabric cloth DROPPED on a fixed floor from 5 cm (z = 0.05, 60 time
+    # steps; free fall, impact around the fourth step, settling under IPC contact + friction): the reference's per-step log with 8 and with 4 threads
+    "steplog_cfg2_clothbox_drop_256": ("steplog", "clothbox", "n=256 size=1 box=2 gap=0.05 thickness=0.001 mu=0.5 steps=60"),
     # what the reference WRITES for a run: its VTK frames, its YAML log and its run summary (tet beam, 2 time steps)
     "frames_tetbeam_4x1x1": ("frames", "tetbeam", "nx=4 ny=1 nz=1 eo=0 steps=2 frames=1"),
     # contact scenes (cfg 1 / cfg 4 at fixture size): cloth resting on a fixed rigid box, soft block pressed on a fixed rigid box

@@ -169,8 +169,12 @@ int main(int argc, char** argv)
                 });
             // a Newton callback that REWRITES the large target array in place (same address, same size) in the middle of a solve: at its 4th
             // energy evaluation every target moves ("inplace"), or only three of them do ("inplace_sparse": what a sampled check cannot see)
-            stark_core.callbacks->newton->add_before_energy_evaluation([&, sparse = scene == "inplace_sparse"]() {
-                if (++n_evaluations != 4) return;
+            // (SHIM_EDIT_AT: the evaluation at which the edit happens; 1 = before anything has been evaluated: every evaluation of the run sees the
+            // edited targets — the run a solve REDONE after a missed edit must reproduce)
+            long edit_at = 4;
+            if (const char* env = std::getenv("SHIM_EDIT_AT")) edit_at = std::atol(env);
+            stark_core.callbacks->newton->add_before_energy_evaluation([&, edit_at, sparse = scene == "inplace_sparse"]() {
+                if (++n_evaluations != edit_at) return;
                 if (sparse) {
                     for (size_t v : { (size_t)100, targets.size() / 2 + 7, targets.size() - 50 })   /* none of them inside a sampled window */ targets[v] += Eigen::Vector3d(0.3, 0.0, 0.0);
                 } else {

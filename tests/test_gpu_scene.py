@@ -859,6 +859,28 @@ def test_shim_with_the_collision_detector_on_the_gpu_equals_the_reference_detect
         assert dev <= 1e-3
 
 
+def test_dof_transfers_skipped_at_an_unchanged_iterate_would_have_moved_no_byte(tmp_path):
+    """mistark_dofs_to_host_arrays_if_changed skips the transfer when no writer of the DoF vector has bumped its version since the last one
+    (correct only if EVERY writer bumps it). MISTARK_VERIFY_DOF_SKIP=1 does the transfer anyway whenever the skip is taken and
+    compares it with the caller's arrays — a writer that forgot ends the run with an error. The contact scene through the drop-in (callbacks at
+    every evaluation, line-search candidates, rejected candidates) takes the skip many times and stays on the reference-detector run's counts."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "shim_check_cd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_check_cd not built")
+    res = []
+    for k, extra in enumerate(({}, {"MISTARK_VERIFY_DOF_SKIP": "1", "MISTARK_SHIM_STATS": "1"})):
+        out = str(tmp_path / ("skip%d.json" % k))
+        r = subprocess.run([exe, "blockbox", "4", out], capture_output=True, timeout=900, env=dict(os.environ, **extra))
+        assert r.returncode == 0, (r.stdout.decode()[-1500:], r.stderr.decode()[-1500:])
+        res.append((json.load(open(out)), r.stderr.decode()))
+    assert res[0][0]["newton_iterations"] == res[1][0]["newton_iterations"] and res[0][0]["x"] == res[1][0]["x"]
+    import re
+    m = re.search(r"(\d+) skipped DoF transfers verified", res[1][1])
+    assert m and int(m.group(1)) > 0, res[1][1][-1500:]
+
+
 def _read_vtk(raw):
     """Legacy binary VTK unstructured grid -> (points float32 [n, 3], cell rows [m, 1 + nodes], cell types [m])."""
     head, rest = raw.split(b"POINTS ", 1)
@@ -1075,26 +1097,37 @@ def test_projection_round_started_beside_the_solve_changes_no_bit():
     """Option proj_speculation (kernels.hip: project_speculate): progressive projection retries a failed solve with the rows above the NEXT
     threshold projected, and that round's selection and eigen-projections can run on another stream while the solve runs; a failed solve adopts
     them (only the ordered matrix update is left), a successful one drops them. Same selection, same projected blocks, same gather order: the
-    run has the bits of the default path — and it must take retries for the option to mean anything (more linear solves than Newton iterations).
+    run has the bits of the default path. The scene must take retries for the option to mean anything: the beam of `traj_tetbeam_big_progressive`
+    (start velocities of 40 m/s: 9 linear solves in the 7 Newton iterations of its first step) — and the engine's counters must say that rounds
+    WERE started beside solves and WERE taken over by retries (with the block-on-box scene used before, no solve ever failed).
     (Measured slower than the default on configs[3], hence an option: DESIGN.md section 8, "Round 4".)"""
-    import sys
+    import ctypes as C
 
-    sys.path.insert(0, ROOT)
-    from bench import build_scene
     from stark_amd import capi
     from stark_amd import sim as S
 
     def run(on):
-        sim = build_scene(S, 10, 10, 10, 0)
+        st = S.default_settings()
+        st.init_frictional_contact = 0
+        sim = S.Simulation(st)
+        ps = sim.add_volume_grid("beam", (0, 0, 0), (4.0, 1.0, 1.0), (8, 2, 2), S.soft_rubber())
+        sim.prescribe_inside_aabb(ps, (-2.0, 0, 0), (2e-3, 2.0, 2.0), 1e7)
+        n = sim.points("v0").shape[0]
+        sim.set_points("v0", 40.0 * np.sin(1.3 * (3.0 * np.arange(n)[:, None] + np.arange(3)[None, :]) + 0.7))
         sim.prepare()
         assert capi.lib().mistark_set_option(sim.engine_handle(), b"proj_speculation", on) == 0
-        for _ in range(4):
+        for _ in range(3):
             assert sim.run_one_step()
         i = sim.info()
-        out = (sim.points("x0").copy(), sim.points("v0").copy(), i.total_newton_iterations, i.total_linear_solves, i.total_cg_iterations)
+        spec, adopted = C.c_int64(), C.c_int64()
+        assert capi.lib().mistark_get_counter(sim.engine_handle(), b"proj_speculated", C.byref(spec)) == 0
+        assert capi.lib().mistark_get_counter(sim.engine_handle(), b"proj_adopted", C.byref(adopted)) == 0
+        out = (sim.points("x0").copy(), sim.points("v0").copy(), i.total_newton_iterations, i.total_linear_solves, i.total_cg_iterations, spec.value, adopted.value)
         sim.close()
         return out
 
     a, b = run(0), run(1)
-    assert a[2:] == b[2:] and a[3] > a[2] > 4
+    assert a[2:5] == b[2:5] and a[2:4] == (15, 19)                      # the reference's counts (fixture traj_tetbeam_big_progressive)
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    # the feature under test did run: rounds were started beside solves and failed solves took them over (and never with the option off)
+    assert a[5:] == (0, 0) and b[5] > 0 and b[6] > 0, (a[5:], b[5:])

@@ -64,15 +64,21 @@ def test_large_array_rewritten_in_place_by_a_newton_callback_reaches_the_engine(
 
 
 @needs_exe
-def test_sparse_in_place_edit_is_reported_not_silently_lost(tmp_path):
-    """scene `inplace_sparse`: the callback moves only three of the 12 691 targets. The sampled check cannot see that; the full pass at the end
-    of the solve does: the shim says so once on stderr (naming MISTARK_SHIM_STRICT=1) and re-sends the array, so from the next solve on the
-    engine is back on the caller's data; under MISTARK_SHIM_STRICT=1 nothing is missed and nothing is said."""
+def test_sparse_in_place_edit_is_reported_and_the_solve_redone(tmp_path):
+    """scene `inplace_sparse`: the callback moves only three of the 12 691 targets, at the 4th evaluation of the run (in the middle of the first
+    solve's second line search). The sampled check cannot see that; the full pass at the end of the solve does. A result computed from stale
+    inputs is never handed out: the shim says so on stderr, switches this solver to reading everything in full at every evaluation
+    (what MISTARK_SHIM_STRICT=1 selects from the start) and REDOES the solve from its initial DoFs on the caller's data as it is now. That is
+    the run in which the targets were moved before anything was evaluated (SHIM_EDIT_AT=1, strict): same Newton iterations, same end state.
+    MISTARK_SHIM_NO_RESOLVE=1 keeps the stale result and only warns; under MISTARK_SHIM_STRICT=1 nothing is missed and nothing is said."""
     default, err = _run("inplace_sparse", 2, tmp_path, None, "_default")
-    assert "WARNING" in err and "MISTARK_SHIM_STRICT=1" in err and err.count("WARNING") == 1
-    strict, err_s = _run("inplace_sparse", 2, tmp_path, {"MISTARK_SHIM_STRICT": "1"}, "_strict")
+    assert "WARNING" in err and "REDONE" in err and err.count("WARNING") == 1      # (once: the solver is in strict mode from then on)
+    consistent, err_s = _run("inplace_sparse", 2, tmp_path, {"MISTARK_SHIM_STRICT": "1", "SHIM_EDIT_AT": "1"}, "_consistent")
     assert "WARNING" not in err_s
-    xd, xs = np.array(default["x"]), np.array(strict["x"])
-    # after the second step (solved on the re-sent array) the two runs are close again: the three targets pull the same way in both
-    moved = np.abs(xs - xd).max()
-    assert moved < 5e-2, moved
+    warn_only, err_w = _run("inplace_sparse", 2, tmp_path, {"MISTARK_SHIM_NO_RESOLVE": "1"}, "_noresolve")
+    assert "WARNING" in err_w and "REDONE" not in err_w and "stale result is kept" in err_w
+    xd, xs, xw = np.array(default["x"]), np.array(consistent["x"]), np.array(warn_only["x"])
+    assert default["newton_iterations"] == consistent["newton_iterations"]
+    assert np.abs(xd - xs).max() < 1e-9, np.abs(xd - xs).max()
+    # the warn-only run solved its first step against the old targets
+    assert np.abs(xw - xs).max() > 1e-4
