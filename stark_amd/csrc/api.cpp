@@ -1209,6 +1209,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "contact_closed_min_lanes") ctx->c.contact_closed_min_lanes = value;
     else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;
     else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;
+    else if (n == "spmv_nt") ctx->c.spmv_nt = value;
     else if (n == "pcg_batch") ctx->c.pcg_batch = value;
     else if (n == "lazy_hessians") ctx->c.lazy_allowed = value != 0;  // newton_solve: float upper-triangle pool for the closed-form tets
     else if (n == "kernel_dbg") { ctx->c.kernel_dbg = value; ctx->c.layout_dirty = true; }  // measurement only

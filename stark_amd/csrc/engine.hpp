@@ -337,6 +337,7 @@ struct Context
     int proj_variant = 0;          // PSD projection, bits: 1 = matrix in LDS (k_project_eig) instead of registers, 2 = no batching of short lists, 4 = IEEE div/sqrt
     int pcg_batch = 0;             // tuning: PCG iterations per launch batch (one batch is always queued ahead of the one the host waits for); 0 = by size
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
+    int spmv_nt = -1;              // non-temporal loads of the matrix values in the SpMV: -1 = when the matrix is beyond the Infinity Cache, 0 = never, 1 = always
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather
     bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path
     bool pcg_holdback = false;     // pcg(): no look-ahead batch while the batch in flight is expected to converge (measured: 1.150 against 1.140 ms per solve, off)

@@ -3972,19 +3972,53 @@ __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nbl
     // every XCD one contiguous eighth of the chunks so that the x entries its rows gather are shared through that die's L2
     const int pbid = ((nblk & 7) == 0) ? (bid & 7) * (nblk >> 3) + (bid >> 3) : bid;
     const int64_t n_waves = (int64_t)nblk * 4;
-    for (int64_t ch = (int64_t)pbid * 4 + wave; ch < n_chunks; ch += n_waves) {
+    // The column words (and the first row) of the NEXT tile this wavefront will process are requested behind the current tile's loads: a tile's
+    // gather of x then does not wait for a load issued in the same iteration (one memory latency per tile instead of two dependent ones).
+    // V & 4: the matrix values come with the non-temporal hint (streamed once per launch: they should not displace x in the L2) — pays when
+    // the matrix streams from HBM, costs while it fits the Infinity Cache: chosen by the matrix' size (launch_spmv). Same arithmetic, same bits.
+    constexpr bool NT = (V & 4) != 0;
+    typedef float nt_f4 __attribute__((ext_vector_type(4)));
+    const int64_t ch0 = (int64_t)pbid * 4 + wave;
+    const int64_t n_tiles_chunked = n_chunks * chunk_tiles;
+    uint32_t w_next = 0;
+    int32_t tfr_next = 0;
+    if (ch0 < n_chunks) {
+        w_next = scol[ch0 * chunk_tiles * 64 + lane];
+        tfr_next = tile_first_row[ch0 * chunk_tiles];
+    }
+    for (int64_t ch = ch0; ch < n_chunks; ch += n_waves) {
         const int64_t t_begin = ch * chunk_tiles;
         double k0 = 0.0, k1 = 0.0, k2 = 0.0;  // carry into the first segment of the next tile (wave-uniform)
         for (int u = 0; u < chunk_tiles; u++) {
             const int64_t t = t_begin + u;
-            const uint32_t w = scol[t * 64 + lane];
-            const float4* q = reinterpret_cast<const float4*>(vals + (size_t)t * 576);
-            const float4 a = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[lane], b = (V == 3) ? make_float4(1.f, 2.f, 3.f, 4.f) : q[64 + lane];
-            const float cc = (V == 3) ? 1.f : vals[(size_t)t * 576 + 512 + lane];
+            const uint32_t w = w_next;
+            const int32_t tfr_w = tfr_next;  // bit 31: the tile starts inside a row begun in the previous tile
             const size_t c3 = 3 * (size_t)(w & 0x7fffffffu);
-            const int32_t tfr_w = tile_first_row[t];  // bit 31: the tile starts inside a row begun in the previous tile
             double x0, x1, x2;
             X.load(c3, x0, x1, x2);
+            const float4* q = reinterpret_cast<const float4*>(vals + (size_t)t * 576);
+            float4 a, b;
+            float cc;
+            if (V == 3) {
+                a = b = make_float4(1.f, 2.f, 3.f, 4.f);
+                cc = 1.f;
+            } else if (NT) {
+                const nt_f4 ta = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(q + lane)), tb = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(q + 64 + lane));
+                a = make_float4(ta.x, ta.y, ta.z, ta.w);
+                b = make_float4(tb.x, tb.y, tb.z, tb.w);
+                cc = __builtin_nontemporal_load(vals + (size_t)t * 576 + 512 + lane);
+            } else {
+                a = q[lane];
+                b = q[64 + lane];
+                cc = vals[(size_t)t * 576 + 512 + lane];
+            }
+            {
+                const int64_t tn = (u + 1 == chunk_tiles) ? (ch + n_waves) * chunk_tiles : t + 1;
+                if (tn < n_tiles_chunked) {
+                    w_next = scol[tn * 64 + lane];
+                    tfr_next = tile_first_row[tn];
+                }
+            }
             // which lanes end a row, and which row: known from the column words alone, so the row's entries of the dot-product vector are
             // requested NOW, with the gathers (issued after the row sums they were a dependent load at the tail of every tile: 30 us of a
             // 217 us launch on the 8 M-tet matrix, where they come from HBM)
@@ -4016,6 +4050,10 @@ __device__ __forceinline__ void spmv_chunked_static(const int bid, const int nbl
                 const double u0 = dpp_mov<CTRL, RM, BOUND>(y0), u1 = dpp_mov<CTRL, RM, BOUND>(y1), u2 = dpp_mov<CTRL, RM, BOUND>(y2); \
                 y0 += u0; y1 += u1; y2 += u2;       \
             }
+            // (Measured and not kept, round 5: the same six steps with the data moved by ds_bpermute instead of v_mov_b32_dpp — the LDS crossbar is
+            // idle in this kernel and rocprofv3 shows the VALU 60 % busy with 55 % of the wave cycles in SQ_WAIT_INST_ANY — give identical bits and
+            // no gain for the two cross-row steps (165.5 against 166 us at 8 M tets on the same box), a loss for all six (182 us; 23.7 against
+            // 20.7 us at 1 M): the crossbar's latency, six dependent round trips per tile, costs more than the issue slots it frees.)
             MS_SCAN_STEP(0x111, 0xf, true)
             MS_SCAN_STEP(0x112, 0xf, true)
             MS_SCAN_STEP(0x114, 0xf, true)
@@ -4407,7 +4445,10 @@ static int launch_spmv(Context& c, const double* x, double* y, const double* pdo
     StaticPart sp;
     DynPart d;
     spmv_launch_shape(c, g0, gr, g1, sp, d);
-    hipLaunchKernelGGL(k_spmv_fused<V>, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, x, y, pdot, partials, ctrl, clk);
+    // non-temporal value loads once the matrix cannot stay in the 256 MiB Infinity Cache beside the vectors (option spmv_nt: -1 = by size, 0 / 1)
+    const bool nt = V == 0 && (c.spmv_nt >= 0 ? c.spmv_nt != 0 : (size_t)c.part[0].ntiles * 2304 + (size_t)c.part[0].ntiles * 256 > ((size_t)160 << 20));
+if (nt) hipLaunchKernelGGL(k_spmv_fused<4>, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, x, y, pdot, partials, ctrl, clk);
+    else hipLaunchKernelGGL(k_spmv_fused<V>, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, x, y, pdot, partials, ctrl, clk);
     if (g1 > 0 && combine)
         hipLaunchKernelGGL(k_spmv_combine, dim3(grid_for(c.mrows())), dim3(BLOCK), 0, c.stream, c.mrows(), (const int32_t*)m1.crow_of_row.p, (const uint32_t*)m1.row_chunk0.p,
                            (const double*)m1.yd.p, (const double*)m1.chunk_partial.p, y);

@@ -24,6 +24,8 @@ for variant in [int(v) for v in os.environ.get("VARIANTS", "0,1,3,9,11").split("
   for cap in [int(a) for a in sys.argv[1:]] or [512, 1024, 2048, 4096]:
     L.mistark_set_option(h, b"spmv_grid_cap", cap)
     L.mistark_set_option(h, b"spmv_variant", variant)
-    us = C.c_double()
-    L.mistark_spmv_bench(h, 200, C.byref(us))
-    print("variant=%d grid_cap=%d  %.2f us  %.0f GB/s  (%.1f%% of 8 TB/s)" % (variant, cap, us.value, nbytes / us.value / 1e3, 100 * nbytes / us.value / 1e3 / 8000))
+    for nt in [int(v) for v in os.environ.get("NT", "-1").split(",")]:
+     L.mistark_set_option(h, b"spmv_nt", nt)
+     us = C.c_double()
+     L.mistark_spmv_bench(h, 200, C.byref(us))
+     print("variant=%d nt=%d grid_cap=%d  %.2f us  %.0f GB/s  (%.1f%% of 8 TB/s)" % (variant, nt, cap, us.value, nbytes / us.value / 1e3, 100 * nbytes / us.value / 1e3 / 8000))
