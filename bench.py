@@ -96,7 +96,7 @@ def host_cpu():
     return model, (len(cores) or logical), logical
 
 
-def cpu_baseline(nx, ny, nz, scene="contact", offset=(0.0, 0.0), sweep=(8, 16, 32, 64), steps=4):
+def cpu_baseline(nx, ny, nz, scene="contact", offset=(0.0, 0.0), sweep=(8, 16, 32, 64, "physical"), steps=4):
     """The UNMODIFIED reference (oracle/_ref/ref_harness, built by oracle/Makefile) timed on this host's cores at several thread counts
     (it does not scale monotonically: 8 threads beat 64 on this scene); `value` is the BEST of them, every leg is reported. `steps` time steps
     after one warm-up step: four of them hold about the Newton iterations the GPU's timed window holds (iterations 5..24 of the run)."""
@@ -116,7 +116,9 @@ def cpu_baseline(nx, ny, nz, scene="contact", offset=(0.0, 0.0), sweep=(8, 16, 3
         out = subprocess.run([harness, "time", name] + common + ["threads=%d" % n_threads, "steps=%d" % n_steps, "warmup=1"], check=True, capture_output=True, timeout=1500).stdout.decode()
         return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
 
-    threads = sorted({max(1, min(t, logical)) for t in sweep})
+    # ("physical": one thread per physical core, what SURVEY 8d asks for beside the 8-thread figure; the reference scales negatively past 16
+    # threads on this scene, so the best leg is a small one — cores_swept says what was tried)
+    threads = sorted({max(1, min(physical if t == "physical" else t, logical)) for t in sweep})
     try:
         subprocess.run([harness, "prime", name, "nx=2", "ny=2", "nz=2"] + common[3:] + ["threads=%d" % threads[0]], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
     except Exception as e:  # noqa: BLE001
@@ -133,7 +135,8 @@ def cpu_baseline(nx, ny, nz, scene="contact", offset=(0.0, 0.0), sweep=(8, 16, 3
     if not ok:
         return dict(base, value=None, cores=0, sample="failed", by_threads=legs)
     best = max(ok, key=lambda t: ok[t]["value"])
-    return dict(base, value=ok[best]["value"], cores=int(best), ms_per_linear_solve=ok[best]["ms_per_linear_solve"], newton_iterations=ok[best]["newton_iterations"],
+    return dict(base, value=ok[best]["value"], cores=int(best), cores_swept=threads, value_at_physical_cores=legs.get(str(min(physical, logical)), {}).get("value"),
+                ms_per_linear_solve=ok[best]["ms_per_linear_solve"], newton_iterations=ok[best]["newton_iterations"],
                 linear_solves=ok[best]["linear_solves"], wall_s=ok[best]["wall_s"], by_threads=legs,
                 sample="same scene, %d time steps after 1 warm-up step (pattern build + JIT excluded) at %s threads; value = the best leg (%s threads)" % (steps, "/".join(str(t) for t in threads), best))
 

@@ -91,6 +91,16 @@ int mistark_potential(mistark_ctx* ctx, const char* name, const int32_t* conn, i
 int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings,
                              const int32_t* ops, const double* constants, int32_t n_ops, int32_t n_inputs, const int32_t* cond_ops, const double* cond_constants,
                              int32_t n_cond_ops);
+/* A custom potential does not stay interpreted: at its first evaluation the op sequence is EMITTED as HIP source (one statement per op, the
+ * temporaries local variables, Branch markers real branches, the gather unrolled — the mirror of the reference's scalar emitter,
+ * symx/src/compile/Compilation.cpp:381-469), compiled for gfx950 by hipRTC and cached on disk by a hash of the source (MISTARK_RTC_CACHE,
+ * default /tmp/mistark_rtc_cache). The interpreter remains the fallback (no libhiprtc, a failed build, sequences of more than
+ * MISTARK_RTC_MAX_OPS = 3000 ops, option "custom_rtc" = 0). mistark_custom_emit returns what the emitter writes for a sequence — the source
+ * in `out` (truncated to cap) and its length — and, with compile != 0, runs hipRTC on it and returns the size of the code object; < 0 with the
+ * message in `out` on failure. in_dof[k]: the local DoF component (3 * block + c) input k seeds, -1 for inputs that are not DoFs. Needs no
+ * context and no GPU. */
+int64_t mistark_custom_emit(const char* name, const int32_t* strides, int32_t n_bindings, const int32_t* in_dof, const int32_t* ops, const double* constants, int32_t n_ops,
+                            int32_t n_inputs, const int32_t* cond_ops, const double* cond_constants, int32_t n_cond_ops, int32_t n_blocks, int32_t compile, char* out, int64_t cap);
 /* Summation loop of a custom potential (MappedWorkspace::add_for_each, symx/src/compile/MappedWorkspace.h:123-130; used by SymX's fem
  * integrators for quadrature rules): inputs [first_input, first_input + stride) — covered by a binding like any other input — take the
  * n_iterations rows of `data` (copied) one after the other, and the element's energy, gradient and Hessian are the sums over the rows in
@@ -335,7 +345,8 @@ int mistark_spmv_bench(mistark_ctx* ctx, int n_launches, double* avg_us);
 int mistark_sync(mistark_ctx* ctx);
 /* Event counters of the context, by name (tests assert that a feature under test actually ran): "proj_speculated" / "proj_adopted" (projection
  * rounds started beside a solve / taken over by the retry, option proj_speculation), "dof_skips_verified" (MISTARK_VERIFY_DOF_SKIP=1: DoF
- * transfers skipped at an unchanged iterate and checked against a real transfer), "fused_solves" / "unfused_solves" (sharded PCG). */
+ * transfers skipped at an unchanged iterate and checked against a real transfer), "fused_solves" / "unfused_solves" (sharded PCG),
+ * "rtc_builds" / "rtc_launches" / "rtc_build_ms" (user-defined potentials: kernels emitted and compiled by hipRTC, their launches, build time). */
 int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out);
 
 /* ---- multi-GPU: one problem sharded over `world` ranks, one engine context (and one process) per GPU ------------------------

@@ -527,6 +527,21 @@ int mistark_set_dofs(mistark_ctx* ctx, const double* u_host)
     MS_CHECK(hipStreamSynchronize(c.stream));
     API_END(0)
 }
+int64_t mistark_custom_emit(const char* name, const int32_t* strides, int32_t n_bindings, const int32_t* in_dof, const int32_t* ops, const double* constants, int32_t n_ops,
+                            int32_t n_inputs, const int32_t* cond_ops, const double* cond_constants, int32_t n_cond_ops, int32_t n_blocks, int32_t compile, char* out, int64_t cap)
+{
+    // (no context: errors go to `out`)
+    try {
+        if (!name || !strides || !in_dof || !ops || !constants) throw Error("mistark_custom_emit: null argument");
+        size_t code = 0;
+        const std::string src = custom_emit_source(name, strides, n_bindings, in_dof, ops, constants, n_ops, n_inputs, cond_ops, cond_constants, n_cond_ops, n_blocks, compile != 0, &code);
+        if (out && cap > 0) std::snprintf(out, (size_t)cap, "%s", src.c_str());
+        return compile ? (int64_t)code : (int64_t)src.size();
+    } catch (const std::exception& e) {
+        if (out && cap > 0) std::snprintf(out, (size_t)cap, "%s", e.what());
+        return -1;
+    }
+}
 int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out)
 {
     API_BEGIN
@@ -536,6 +551,10 @@ int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out)
     if (n == "proj_speculated") *out = c.n_proj_speculated;
     else if (n == "proj_adopted") *out = c.n_proj_adopted;
     else if (n == "dof_skips_verified") *out = c.n_dof_skips_verified;
+    else if (n == "rtc_builds") *out = c.n_rtc_builds;
+    else if (n == "custom_kernel_us") *out = (int64_t)c.custom_kernel_us;
+    else if (n == "rtc_launches") *out = c.n_rtc_launches;
+    else if (n == "rtc_build_ms") *out = (int64_t)(1e3 * c.t_rtc_builds);
     else if (n == "fused_solves") *out = c.n_fused_solves;
     else if (n == "unfused_solves") *out = c.n_unfused_solves;
     else throw Error("mistark_get_counter: unknown counter '" + n + "'");
@@ -1210,6 +1229,8 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;
     else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;
     else if (n == "spmv_nt") ctx->c.spmv_nt = value;
+    else if (n == "custom_rtc") ctx->c.custom_rtc = value;
+    else if (n == "custom_timing") ctx->c.custom_timing = value;
     else if (n == "pcg_batch") ctx->c.pcg_batch = value;
     else if (n == "lazy_hessians") ctx->c.lazy_allowed = value != 0;  // newton_solve: float upper-triangle pool for the closed-form tets
     else if (n == "kernel_dbg") { ctx->c.kernel_dbg = value; ctx->c.layout_dirty = true; }  // measurement only

@@ -6,11 +6,17 @@
 // fast (register file in scratch memory), and every potential a stock stark::Simulation registers has a compiled kernel instead.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 
 #include "engine.hpp"
 #include "hdual.hpp"
+#include "custom_math.hpp"
 
 namespace mistark {
 
@@ -35,6 +41,11 @@ struct CustomProgram
     int sum_first = -1, sum_stride = 0, sum_n = 0;
     std::vector<double> sum_data;
     bool uploaded = false;
+    // kernels emitted for this program (hipRTC; see "the emitter" below): built at the first evaluation, rebuilt when what the source depends on
+    // (DoF bindings, block count, summation layout) changes; `rtc_failed` keeps the interpreter for good after a failed build
+    std::shared_ptr<struct RtcKernels> rtc;
+    std::string rtc_key;
+    bool rtc_failed = false;
 };
 
 namespace {
@@ -53,21 +64,6 @@ struct ProgDev
     const double* sum_data;
 };
 
-__device__ __forceinline__ HDual powi(const HDual& x, int n)
-{
-    if (n == 0) return HDual(1.0);
-    const double p2 = ::pow(x.v, (double)(n - 2)), p1 = p2 * x.v;  // x^(n-2), x^(n-1)
-    if (n == 1) return x;
-    if (n == 2) return x * x;
-    return chain(x, p1 * x.v, n * p1, (double)n * (n - 1) * p2);
-}
-__device__ __forceinline__ HDual powf_h(const HDual& x, const HDual& y)
-{
-    // x^y = exp(y ln x)
-    const HDual t = y * log(x);
-    const double e = ::exp(t.v);
-    return chain(t, e, e, e);
-}
 // Runs one op sequence; returns the value bound to output 0.
 __device__ HDual run_program(const int32_t* __restrict__ ops, const double* __restrict__ consts, int n_ops, const double* in, const int32_t* __restrict__ in_dof, int n_in, int si, int sj)
 {
@@ -113,39 +109,16 @@ __device__ HDual run_program(const int32_t* __restrict__ ops, const double* __re
             case OP_SUB: r = get(a) - get(b); break;
             case OP_MUL: r = get(a) * get(b); break;
             case OP_RECIP: r = inv(get(a)); break;
-            case OP_POWN: r = powi(get(a), b); break;
-            case OP_POWF: r = powf_h(get(a), get(b)); break;
+            case OP_POWN: r = cop_pown(get(a), b); break;
+            case OP_POWF: r = cop_powf(get(a), get(b)); break;
             case OP_SQRT: r = sqrt(get(a)); break;
-            case OP_LN: {
-                const HDual x = get(a);
-                r = x.v <= 0.0 ? HDual(-INFINITY) : log(x);
-                break;
-            }
-            case OP_LOG10: {
-                const HDual x = get(a);
-                r = x.v <= 0.0 ? HDual(-INFINITY) : (1.0 / ::log(10.0)) * log(x);
-                break;
-            }
-            case OP_EXP: {
-                const HDual x = get(a);
-                const double e = ::exp(x.v);
-                r = chain(x, e, e, e);
-                break;
-            }
+            case OP_LN: r = cop_ln(get(a)); break;
+            case OP_LOG10: r = cop_log10(get(a)); break;
+            case OP_EXP: r = cop_exp(get(a)); break;
             case OP_SIN: r = sin(get(a)); break;
             case OP_COS: r = cos(get(a)); break;
-            case OP_TAN: {
-                const HDual x = get(a);
-                const double t = ::tan(x.v), s = 1.0 + t * t;
-                r = chain(x, t, s, 2.0 * t * s);
-                break;
-            }
-            case OP_ASIN: {
-                const HDual x = get(a);
-                const double s = 1.0 / ::sqrt(1.0 - x.v * x.v);
-                r = chain(x, ::asin(x.v), s, x.v * s * s * s);
-                break;
-            }
+            case OP_TAN: r = cop_tan(get(a)); break;
+            case OP_ASIN: r = cop_asin(get(a)); break;
             case OP_ACOS: r = acos(get(a)); break;
             case OP_ATAN: r = atan(get(a)); break;
             default: r = HDual(0.0); break;  // Print
@@ -359,8 +332,382 @@ void custom_program_set_summation(CustomProgram& G, const std::string& name, int
     G.uploaded = false;
 }
 
+
+// ======================================================================================================================================
+// The emitter ("a small expression -> HIP emitter consuming SymX's op Sequence ... compiled with hipcc / hipRTC"; the scalar
+// emitter it mirrors: symx/src/compile/Compilation.cpp:381-469). The op sequence of a user-defined potential becomes straight-line HIP source
+// — one statement per op, the temporaries local variables, if / else / endif as real branches, the gather of the bound arrays unrolled with
+// the strides and DoF seeds known at emission — compiled for gfx950 by hipRTC at the potential's first evaluation and cached on disk by a hash
+// of the source (MISTARK_RTC_CACHE, default /tmp/mistark_rtc_cache; the reference caches its JIT-compiled .so files the same way,
+// Compilation.cpp:243-336). Same decomposition (one lane per (element, i <= j)), same hyper-dual operations (custom_math.hpp is compiled into
+// both) and same output layout as the interpreter k_eval_custom, which stays as the fallback (no hipRTC library, a failed build, programs
+// beyond MISTARK_RTC_MAX_OPS, option custom_rtc = 0) and as the cross-check (tests/test_gpu_custom_rtc.py).
+// ======================================================================================================================================
+struct RtcKernels
+{
+    hipModule_t mod = nullptr;
+    hipFunction_t fn[3] = {nullptr, nullptr, nullptr};
+    ~RtcKernels()
+    {
+        if (mod) (void)hipModuleUnload(mod);
+    }
+};
+namespace {
+static const char* RTC_POTARGS_SRC =
+#include "rtc_potargs.inc"
+    ;
+static const char* RTC_HDUAL_SRC =
+#include "rtc_hdual.inc"
+    ;
+static const char* RTC_MATH_SRC =
+#include "rtc_custom_math.inc"
+    ;
+struct HipRtc
+{
+    void* lib = nullptr;
+    bool tried = false;
+    int (*CreateProgram)(void**, const char*, const char*, int, const char**, const char**) = nullptr;
+    int (*CompileProgram)(void*, int, const char**) = nullptr;
+    int (*GetProgramLogSize)(void*, size_t*) = nullptr;
+    int (*GetProgramLog)(void*, char*) = nullptr;
+    int (*GetCodeSize)(void*, size_t*) = nullptr;
+    int (*GetCode)(void*, char*) = nullptr;
+    int (*DestroyProgram)(void**) = nullptr;
+};
+HipRtc& hiprtc()
+{
+    static HipRtc r;
+    if (!r.tried) {
+        r.tried = true;
+        for (const char* name : {"libhiprtc.so", "libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+            bool ok = true;
+            auto sym = [&](const char* n) {
+                void* p = dlsym(r.lib, n);
+                if (!p) ok = false;
+                return p;
+            };
+            r.CreateProgram = (int (*)(void**, const char*, const char*, int, const char**, const char**))sym("hiprtcCreateProgram");
+            r.CompileProgram = (int (*)(void*, int, const char**))sym("hiprtcCompileProgram");
+            r.GetProgramLogSize = (int (*)(void*, size_t*))sym("hiprtcGetProgramLogSize");
+            r.GetProgramLog = (int (*)(void*, char*))sym("hiprtcGetProgramLog");
+            r.GetCodeSize = (int (*)(void*, size_t*))sym("hiprtcGetCodeSize");
+            r.GetCode = (int (*)(void*, char*))sym("hiprtcGetCode");
+            r.DestroyProgram = (int (*)(void**))sym("hiprtcDestroyProgram");
+            if (!ok) {
+                dlclose(r.lib);
+                r.lib = nullptr;
+            }
+        }
+    }
+    return r;
+}
+std::string rtc_double(double v)
+{
+    // exact bits (the interpreter reads the same doubles from memory)
+    long long b;
+    std::memcpy(&b, &v, 8);
+    char buf[64];
+    std::snprintf(buf, sizeof(buf), "__longlong_as_double(%lldLL)", b);
+    return buf;
+}
+// one op sequence as a device function: HDual NAME(const double (&in)[n_in], int si, int sj)
+void emit_program(std::string& out, const char* fname, const std::vector<int32_t>& ops, const std::vector<double>& consts, int n_in, int n_regs, const std::vector<int32_t>& in_dof)
+{
+    const int n_ops = (int)consts.size();
+    std::vector<char> used((size_t)n_in, 0);
+    auto mark = [&](int v) {
+        if (v >= 0 && v < n_in) used[(size_t)v] = 1;
+    };
+    for (int k = 0; k < n_ops; k++) {
+        const int32_t* op = &ops[5 * (size_t)k];
+        const int type = op[0];
+        if (type == OP_BRANCH) {
+            if (op[4] != -2 && op[2] == 0) mark(op[4]);
+        } else if (type == OP_SYMBOL || type == OP_RECIP || type == OP_POWN || (type >= OP_SQRT && type <= OP_PRINT)) mark(op[2]);
+        else if (type == OP_ADD || type == OP_SUB || type == OP_MUL || type == OP_POWF) {
+            mark(op[2]);
+            mark(op[3]);
+        }
+    }
+    out += "__device__ __forceinline__ HDual ";
+    out += fname;
+    out += "(const double (&in)[" + std::to_string(std::max(n_in, 1)) + "], const int si, const int sj)\n{\n";
+    for (int i = 0; i < n_in; i++) {
+        if (!used[(size_t)i]) continue;
+        const int d = in_dof[(size_t)i];
+        if (d >= 0) out += "    const HDual x" + std::to_string(i) + "(in[" + std::to_string(i) + "], si == " + std::to_string(d) + " ? 1.0 : 0.0, sj == " + std::to_string(d) + " ? 1.0 : 0.0, 0.0);\n";
+        else out += "    const HDual x" + std::to_string(i) + "(in[" + std::to_string(i) + "]);\n";
+    }
+    for (int r = 0; r < n_regs; r++) out += "    HDual r" + std::to_string(r) + ";\n";
+    out += "    HDual out(0.0);\n";
+    auto V = [&](int idx) { return idx < n_in ? "x" + std::to_string(idx) : "r" + std::to_string(idx - n_in); };
+    std::string ind = "    ";
+    for (int k = 0; k < n_ops; k++) {
+        const int32_t* op = &ops[5 * (size_t)k];
+        const int type = op[0], dst = op[1], a = op[2], b = op[3], cond = op[4];
+        if (type == OP_BRANCH) {
+            if (cond == -2) {
+                ind.resize(ind.size() - 4);
+                out += ind + "}\n";
+            } else if (a == 0) {
+                out += ind + "if (" + V(cond) + ".v > 0.0) {\n";
+                ind += "    ";
+            } else {
+                out += ind.substr(4) + "} else {\n";
+            }
+            continue;
+        }
+        if (type == OP_SYMBOL) {
+            out += ind + "out = " + V(a) + ";\n";
+            continue;
+        }
+        std::string e;
+        switch (type) {
+            case OP_ZERO: e = "HDual(0.0)"; break;
+            case OP_ONE: e = "HDual(1.0)"; break;
+            case OP_CONST: e = "HDual(" + rtc_double(consts[(size_t)k]) + ")"; break;
+            case OP_ADD: e = V(a) + " + " + V(b); break;
+            case OP_SUB: e = V(a) + " - " + V(b); break;
+            case OP_MUL: e = V(a) + " * " + V(b); break;
+            case OP_RECIP: e = "inv(" + V(a) + ")"; break;
+            case OP_POWN: e = "cop_pown(" + V(a) + ", " + std::to_string(b) + ")"; break;
+            case OP_POWF: e = "cop_powf(" + V(a) + ", " + V(b) + ")"; break;
+            case OP_SQRT: e = "sqrt(" + V(a) + ")"; break;
+            case OP_LN: e = "cop_ln(" + V(a) + ")"; break;
+            case OP_LOG10: e = "cop_log10(" + V(a) + ")"; break;
+            case OP_EXP: e = "cop_exp(" + V(a) + ")"; break;
+            case OP_SIN: e = "sin(" + V(a) + ")"; break;
+            case OP_COS: e = "cos(" + V(a) + ")"; break;
+            case OP_TAN: e = "cop_tan(" + V(a) + ")"; break;
+            case OP_ASIN: e = "cop_asin(" + V(a) + ")"; break;
+            case OP_ACOS: e = "acos(" + V(a) + ")"; break;
+            case OP_ATAN: e = "atan(" + V(a) + ")"; break;
+            default: e = "HDual(0.0)"; break;  // Print
+        }
+        out += ind + V(dst) + " = " + e + ";\n";
+    }
+    out += "    return out;\n}\n";
+}
+std::string emit_source(const CustomProgram& G, const std::vector<int32_t>& in_dof, int NB)
+{
+    std::string s;
+    s.reserve(1 << 16);
+    s += "// emitted by libmistark (custom.hip) for hipRTC\n";
+    s += RTC_POTARGS_SRC;
+    s += RTC_HDUAL_SRC;
+    s += RTC_MATH_SRC;
+    s += "using namespace mistark;\n";
+    emit_program(s, "prog_energy", G.ops, G.consts, G.n_in, G.n_regs, in_dof);
+    const bool has_cond = !G.cconsts.empty();
+    if (has_cond) emit_program(s, "prog_condition", G.cops, G.cconsts, G.n_in, G.n_cregs, in_dof);
+    const int n = 3 * NB;
+    for (int MODE = 0; MODE < 3; MODE++) {
+        const int NP = MODE == 0 ? 1 : (MODE == 1 ? n : n * (n + 1) / 2);
+        s += "extern \"C\" __global__ __launch_bounds__(256) void mistark_custom_k" + std::to_string(MODE) +
+             "(PotArgs a, const double* __restrict__ sum_data, int sum_n, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)\n{\n";
+        s += "    constexpr int NB = " + std::to_string(NB) + ", n = 3 * NB, NP = " + std::to_string(NP) + ";\n";
+        s += "    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;\n"
+             "    if (t >= (long long)a.e_count * NP) return;\n"
+             "    const int le = (int)(t / NP);\n"
+             "    const int e = a.elem_list ? (int)a.elem_list[le] : a.e_begin + le;\n"
+             "    const int pe = a.elem_list ? le : e;\n"
+             "    int rem = (int)(t - (long long)le * NP);\n"
+             "    const bool first = rem == 0;\n"
+             "    int i = -1, j = -1;\n";
+        if (MODE == 1) s += "    i = j = rem;\n";
+        if (MODE == 2) s += "    i = 0;\n    while (rem >= n - i) { rem -= n - i; i++; }\n    j = i + rem;\n";
+        s += "    (void)n; (void)first;\n    const int32_t* ce = a.conn + (size_t)e * a.conn_stride;\n";
+        s += "    double in[" + std::to_string(std::max(G.n_in, 1)) + "];\n";
+        int o = 0;
+        for (size_t b = 0; b < G.strides.size(); b++) {
+            const int S = G.strides[b];
+            s += "    {\n        const int col = a.conn_col[" + std::to_string(b) + "];\n        const double* src = a.arr[" + std::to_string(b) + "] + (col < 0 ? 0 : (size_t)ce[col]) * " +
+                 std::to_string(S) + ";\n";
+            for (int c = 0; c < S; c++) s += "        in[" + std::to_string(o + c) + "] = src[" + std::to_string(c) + "];\n";
+            s += "    }\n";
+            o += S;
+        }
+        auto sum_set = [&](const char* ind) {
+            std::string r;
+            for (int c = 0; c < G.sum_stride; c++)
+                r += std::string(ind) + "in[" + std::to_string(G.sum_first + c) + "] = sum_data[(size_t)it * " + std::to_string(G.sum_stride) + " + " + std::to_string(c) + "];\n";
+            return r;
+        };
+        s += "    bool on = true;\n";
+        if (has_cond) {
+            if (G.sum_n == 0) s += "    on = prog_condition(in, -1, -1).v > 0.0;\n";
+            else s += "    {\n        double cv = 0.0;\n        for (int it = 0; it < sum_n; it++) {\n" + sum_set("            ") + "            cv += prog_condition(in, -1, -1).v;\n        }\n        on = cv > 0.0;\n    }\n";
+        }
+        s += "    HDual r(0.0);\n    if (on) {\n";
+        if (G.sum_n == 0) s += "        r = prog_energy(in, i, j);\n";
+        else s += "        for (int it = 0; it < sum_n; it++) {\n" + sum_set("            ") + "            r = r + prog_energy(in, i, j);\n        }\n";
+        s += "    }\n";
+        if (MODE == 2)
+            s += "    {\n        const int ba = i / 3, ii = i - 3 * ba, bb = j / 3, jj = j - 3 * bb;\n"
+                 "        elemH[((size_t)(ba * NB + bb) * a.n_pool + pe) * 9 + ii * 3 + jj] = r.ab;\n"
+                 "        elemH[((size_t)(bb * NB + ba) * a.n_pool + pe) * 9 + jj * 3 + ii] = r.ab;\n    }\n";
+        if (MODE >= 1)
+            s += "    if (i == j && on) {\n        const int ba = i / 3, ii = i - 3 * ba;\n"
+                 "        const int node = a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];\n"
+                 "        if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);\n"
+                 "        else atomicAdd(&grad[3 * (size_t)(a.dof_row_off[ba] + node) + ii], r.a);\n    }\n";
+        s += "    if (first) elemE[pe] = r.v;\n}\n";
+    }
+    return s;
+}
+double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+uint64_t fnv1a(const std::string& s)
+{
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char ch : s) {
+        h ^= ch;
+        h *= 1099511628211ull;
+    }
+    return h;
+}
+// compiled code object of `src` (from the disk cache, or built now); empty + why on failure
+std::vector<char> rtc_build(const std::string& src, std::string& why)
+{
+    const char* dir_env = std::getenv("MISTARK_RTC_CACHE");
+    const std::string dir = dir_env && dir_env[0] ? dir_env : "/tmp/mistark_rtc_cache";
+    char name[64];
+    std::snprintf(name, sizeof(name), "/%016llx_gfx950.hsaco", (unsigned long long)fnv1a(src));
+    const std::string path = dir + name;
+    if (FILE* f = std::fopen(path.c_str(), "rb")) {
+        std::vector<char> code;
+        char buf[65536];
+        size_t got;
+        while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) code.insert(code.end(), buf, buf + got);
+        std::fclose(f);
+        if (code.size() > 64) return code;
+    }
+    HipRtc& R = hiprtc();
+    if (!R.lib) {
+        why = "libhiprtc.so not available";
+        return {};
+    }
+    void* prog = nullptr;
+    if (R.CreateProgram(&prog, src.c_str(), "mistark_custom.hip", 0, nullptr, nullptr) != 0) {
+        why = "hiprtcCreateProgram failed";
+        return {};
+    }
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-pragma-once-outside-header"};
+    const int rc = R.CompileProgram(prog, 5, opts);
+    std::vector<char> code;
+    if (rc != 0) {
+        size_t n = 0;
+        R.GetProgramLogSize(prog, &n);
+        std::string log(n, '\0');
+        if (n) R.GetProgramLog(prog, &log[0]);
+        why = "hipRTC compile failed: " + log.substr(0, 2000);
+    } else {
+        size_t n = 0;
+        R.GetCodeSize(prog, &n);
+        code.resize(n);
+        R.GetCode(prog, code.data());
+    }
+    R.DestroyProgram(&prog);
+    if (!code.empty()) {  // (cache: best effort, written under a temporary name and renamed)
+        (void)::mkdir(dir.c_str(), 0777);
+        const std::string tmp = path + "." + std::to_string((long long)getpid());
+        if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
+            const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
+            std::fclose(f);
+            if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
+        }
+    }
+    return code;
+}
+int rtc_max_ops()
+{
+    static const int v = [] {
+        const char* e = std::getenv("MISTARK_RTC_MAX_OPS");
+        return e ? std::atoi(e) : 3000;
+    }();
+    return v;
+}
+}  // namespace
+// the emitted kernels of P's program for the bindings as they are now; nullptr: use the interpreter
+RtcKernels* rtc_kernels(Context& c, Potential& P, const std::vector<int32_t>& in_dof)
+{
+    CustomProgram& G = *P.prog;
+    if (!c.custom_rtc || G.rtc_failed) return nullptr;
+    if ((int)(G.consts.size() + G.cconsts.size()) > rtc_max_ops()) return nullptr;  // (hyper-dual straight-line code of 10^4 ops compiles for minutes: interpreted)
+    std::string key = std::to_string(P.NB) + "|" + std::to_string(G.sum_first) + "," + std::to_string(G.sum_stride) + "," + (G.sum_n > 0 ? "s" : "-") + "|";
+    for (int32_t d : in_dof) key += std::to_string(d) + ",";
+    if (G.rtc && G.rtc_key == key) return G.rtc.get();
+    const double t0 = now_seconds();
+    std::string why;
+    const std::string src = emit_source(G, in_dof, P.NB);
+    if (const char* dump = std::getenv("MISTARK_RTC_DUMP")) {
+        if (FILE* f = std::fopen((std::string(dump) + "/" + P.name + ".hip").c_str(), "w")) {
+            std::fputs(src.c_str(), f);
+            std::fclose(f);
+        }
+    }
+    const std::vector<char> code = rtc_build(src, why);
+    auto k = std::make_shared<RtcKernels>();
+    if (!code.empty()) {
+        if (hipModuleLoadData(&k->mod, code.data()) != hipSuccess) why = "hipModuleLoadData failed";
+        else
+            for (int m = 0; m < 3 && why.empty(); m++)
+                if (hipModuleGetFunction(&k->fn[m], k->mod, ("mistark_custom_k" + std::to_string(m)).c_str()) != hipSuccess) why = "emitted kernel not found in the module";
+    }
+    if (!why.empty() || code.empty()) {
+        (void)hipGetLastError();
+        G.rtc_failed = true;
+        std::fprintf(stderr, "mistark: user-defined potential '%s': no emitted kernel (%s); the device interpreter runs it\n", P.name.c_str(), why.c_str());
+        return nullptr;
+    }
+    G.rtc = k;
+    G.rtc_key = key;
+    c.n_rtc_builds++;
+    c.t_rtc_builds += now_seconds() - t0;
+    return k.get();
+}
+
+// What the emitter writes for an op sequence, and whether hipRTC compiles it — no context, no GPU (the CPU-side test of the emitter;
+// mistark_custom_emit in api.cpp). in_dof: per input the local DoF component it seeds, or -1.
+std::string custom_emit_source(const std::string& name, const int32_t* strides, int n_bindings, const int32_t* in_dof, const int32_t* ops, const double* consts, int n_ops, int n_inputs,
+                               const int32_t* cond_ops, const double* cond_consts, int n_cond_ops, int NB, bool compile, size_t* code_bytes)
+{
+    std::shared_ptr<CustomProgram> G = make_custom_program(name, strides, n_bindings, ops, consts, n_ops, n_inputs, cond_ops, cond_consts, n_cond_ops);
+    const std::vector<int32_t> dof(in_dof, in_dof + n_inputs);
+    const std::string src = emit_source(*G, dof, NB);
+    if (code_bytes) *code_bytes = 0;
+    if (compile) {
+        std::string why;
+        const std::vector<char> code = rtc_build(src, why);
+        if (code.empty()) throw Error("custom potential '" + name + "': " + why);
+        if (code_bytes) *code_bytes = code.size();
+    }
+    return src;
+}
+
 // Evaluation of a custom potential (called by kernels.hip: launch_eval_kind for P.kind == KIND_CUSTOM)
+static void launch_eval_custom_impl(Context& c, Potential& P, int mode);
 void launch_eval_custom(Context& c, Potential& P, int mode)
+{
+    if (!c.custom_timing) return launch_eval_custom_impl(c, P, mode);
+    // option custom_timing (measurement): HIP events around the potential's own launch, synchronised; counter "custom_kernel_us"
+    hipEvent_t e0, e1;
+    MS_CHECK(hipEventCreate(&e0));
+    MS_CHECK(hipEventCreate(&e1));
+    MS_CHECK(hipEventRecord(e0, c.stream));
+    launch_eval_custom_impl(c, P, mode);
+    MS_CHECK(hipEventRecord(e1, c.stream));
+    MS_CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MS_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    c.custom_kernel_us += 1e3 * (double)ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+}
+static void launch_eval_custom_impl(Context& c, Potential& P, int mode)
 {
     if (P.args.e_count == 0) return;
     CustomProgram& G = *P.prog;
@@ -410,6 +757,20 @@ void launch_eval_custom(Context& c, Potential& P, int mode)
     double* E = c.elemE.p + P.e_off;
     const int n = 3 * P.NB;
     auto grid = [&](long long threads) { return dim3((unsigned)((threads + 255) / 256)); };
+    if (RtcKernels* K = rtc_kernels(c, P, in_dof)) {  // the kernels emitted for this op sequence (hipRTC)
+        const int m = mode == MISTARK_EVAL_P ? 0 : (mode == MISTARK_EVAL_P_G ? 1 : 2);
+        const long long threads = (long long)P.args.e_count * (m == 0 ? 1 : (m == 1 ? n : n * (n + 1) / 2));
+        if (threads <= 0) return;
+        PotArgs a = P.args;
+        const double* sum_data = G.d_sum.p;
+        int sum_n = G.sum_n;
+        double* H = m == 2 ? c.elemH.p + P.h_off : nullptr;
+        double* g = m >= 1 ? c.grad.p : nullptr;
+        void* params[] = {&a, &sum_data, &sum_n, &E, &H, &g};
+        MS_CHECK(hipModuleLaunchKernel(K->fn[m], grid(threads).x, 1, 1, 256, 1, 1, 0, c.stream, params, nullptr));
+        c.n_rtc_launches++;
+        return;
+    }
     if (mode == MISTARK_EVAL_P)
         hipLaunchKernelGGL(k_eval_custom<0>, grid(P.args.e_count), dim3(256), 0, c.stream, P.args, pd, E, (double*)nullptr, (double*)nullptr);
     else if (mode == MISTARK_EVAL_P_G)

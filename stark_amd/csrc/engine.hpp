@@ -14,6 +14,8 @@
 
 #include "../../include/mistark.h"
 
+#include "potargs.hpp"
+
 namespace mistark {
 
 struct Error : std::runtime_error
@@ -100,37 +102,6 @@ struct DevBuf
     }
 };
 
-constexpr int MAX_BIND = 40;
-constexpr int MAX_NB = 8;
-
-// Kernel argument block of one potential (device pointers)
-struct PotArgs
-{
-    const double* arr[MAX_BIND];
-    int conn_col[MAX_BIND];
-    const int32_t* conn;
-    int conn_stride;
-    int n_elem;
-    int e_begin, e_count;     // this rank's contiguous element range (multi-GPU sharding; the whole table on one GPU)
-    const uint32_t* elem_list;  // != nullptr: the kernel's element le is elem_list[le] (le < e_count) and pools are indexed by le
-    int n_pool;               // elements per block pair in the element-Hessian pool (pool stride)
-    double* gpool;            // != nullptr: gradient contributions go to gpool[(k * n_gpool + pool position) * 3 + i] (summed by k_grad_gather) instead of atomics
-    int n_gpool;
-    // sharded runs (shard.hip): local index of a global block row ([0, n_own): owned, then ghosts, -1: neither); nullptr on one GPU.
-    // An element's energy counts on the rank that owns the row of its first DoF block.
-    const int32_t* lrow;
-    int n_own;
-    int dbg;                  // measurement switches (option "kernel_dbg"; results are wrong when set)
-    int dof_col[MAX_NB];      // connectivity column providing the node of local DoF block k
-    int dof_row_off[MAX_NB];  // first block row of the DoF set of local DoF block k
-    // Gradient rows of SMALL DoF sets (a handful of rigid bodies touched by tens of thousands of contacts) are not accumulated in place:
-    // 68 k atomics on the same six addresses serialise (1.6 ms per contact kind on configs[2]). Their contributions go to one of
-    // HOT_WAYS copies chosen by the workgroup index and are folded into the gradient after the last potential (k_fold_hot).
-    int hot_base[MAX_NB];     // index of the set's first row among the hot rows, -1: accumulate in place
-    double* grad_hot;         // [HOT_WAYS][n_hot][3]
-    int n_hot;
-};
-constexpr int HOT_WAYS = 64;
 constexpr int64_t HOT_SET_ROWS = 1024;  // DoF sets up to this many block rows take the hot path
 
 struct DofSet
@@ -337,6 +308,11 @@ struct Context
     int proj_variant = 0;          // PSD projection, bits: 1 = matrix in LDS (k_project_eig) instead of registers, 2 = no batching of short lists, 4 = IEEE div/sqrt
     int pcg_batch = 0;             // tuning: PCG iterations per launch batch (one batch is always queued ahead of the one the host waits for); 0 = by size
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
+    int custom_rtc = 1;            // user-defined potentials: kernels emitted from the op sequence and compiled by hipRTC (0: the device interpreter only)
+    int custom_timing = 0;         // measurement: HIP events around every launch of a user-defined potential (synchronises), counter "custom_kernel_us"
+    double custom_kernel_us = 0.0;
+    int64_t n_rtc_builds = 0, n_rtc_launches = 0;
+    double t_rtc_builds = 0.0;
     int spmv_nt = -1;              // non-temporal loads of the matrix values in the SpMV: -1 = when the matrix is beyond the Infinity Cache, 0 = never, 1 = always
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather
     bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path
@@ -656,6 +632,9 @@ int n_kinds();
 
 int newton_solve(Context& c, const mistark_newton_settings& s, const mistark_newton_callbacks* cb, mistark_newton_stats& st);
 
+// custom.hip: what the emitter writes for an op sequence (and, with `compile`, the size of the code object hipRTC makes of it); no context, no GPU
+std::string custom_emit_source(const std::string& name, const int32_t* strides, int n_bindings, const int32_t* in_dof, const int32_t* ops, const double* consts, int n_ops, int n_inputs,
+                               const int32_t* cond_ops, const double* cond_consts, int n_cond_ops, int NB, bool compile, size_t* code_bytes);
 }  // namespace mistark
 
 struct mistark_ctx

@@ -7,7 +7,9 @@
 // spilling of n x n Hessians), and the n(n+1)/2 pairs of an element are spread over the lanes of a wavefront.
 // The hot volumetric potentials additionally have hand-derived closed-form kernels (tet_closed.hpp).
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <cmath>
+#endif
 
 #if defined(__HIPCC__)
 #define MS_HD __host__ __device__ __forceinline__

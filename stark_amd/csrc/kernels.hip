@@ -4331,6 +4331,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_fused(int g0, int gr, int g1, St
         }
     }
 }
+#ifdef MISTARK_BENCH_VARIANTS  // measurement-only kernels (tools/spmv_sweep.py): make BENCH_VARIANTS=1
 // measurement only (spmv_variant 12): the static part with SoA input (see XSoA); y stays interleaved
 __global__ __launch_bounds__(BLOCK) void k_spmv_soa(int g0, StaticPart m, XSoA X, double* __restrict__ y, double* __restrict__ partials)
 {
@@ -4344,6 +4345,7 @@ __global__ __launch_bounds__(BLOCK) void k_to_soa(const double* __restrict__ v, 
     out[n + i] = v[3 * i + 1];
     out[2 * n + i] = v[3 * i + 2];
 }
+#endif
 // The PCG's iteration k as the solver launches it: what k_pcg_dir did for iteration k-1 (sums of r.r and r.z, convergence test, beta) in the
 // prologue of every workgroup (all of them compute the same numbers from the same partial sums; workgroup 0 records them), then
 // q = A p with p = z + beta p_old formed on the fly and stored by the lanes that finish a row.
@@ -4470,6 +4472,7 @@ static int launch_spmv_dir(Context& c, const DirArgs& a, double* y, double* part
     hipLaunchKernelGGL(k_spmv_dir, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, a, y, partials, c.ctrl.p);
     return g0 + gr + g1;
 }
+#ifdef MISTARK_BENCH_VARIANTS
 // reference point for the micro-benchmark (variant 9): a plain grid-stride float4 read of the matrix values, i.e. what streaming the
 // matrix costs at best on this box (measured 16.2 us for the 1M-tet block = 6.3 TB/s)
 __global__ __launch_bounds__(BLOCK) void k_stream_ref(const float4* __restrict__ v, size_t n4, double* __restrict__ partials)
@@ -4506,6 +4509,7 @@ __global__ __launch_bounds__(BLOCK) void k_spmv_products_only(const float* __res
     acc = block_sum(acc, sm);
     if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
+#endif
 // Micro-benchmark of the SpMV kernel on the assembled matrix: n back-to-back launches of q = A p (+ fused dot), HIP events
 // around the whole batch on the engine's stream. Returns the average launch duration in microseconds.
 double spmv_bench(Context& c, int n)
@@ -4519,6 +4523,7 @@ double spmv_bench(Context& c, int n)
     MS_CHECK(hipEventRecord(e0, c.stream));
     for (int i = 0; i < n; i++) {
         switch (c.spmv_variant) {
+#ifdef MISTARK_BENCH_VARIANTS
             case 1: launch_spmv<1>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr, false); break;
             case 11: hipLaunchKernelGGL(k_spmv_products_only, dim3(c.spmv_grid_cap > 0 ? c.spmv_grid_cap : 1024), dim3(BLOCK), 0, c.stream, (const float*)c.part[0].vals.p, (const uint32_t*)c.part[0].scol.p, c.part[0].ntiles, (const double*)c.p.p, c.partials.p); break;
             case 9: hipLaunchKernelGGL(k_stream_ref, dim3(2048), dim3(BLOCK), 0, c.stream, (const float4*)c.part[0].vals.p, (size_t)c.part[0].ntiles * 144, c.partials.p); break;
@@ -4532,6 +4537,9 @@ double spmv_bench(Context& c, int n)
                 hipLaunchKernelGGL(k_spmv_soa, dim3(g0), dim3(BLOCK), 0, c.stream, g0, sp, XSoA{c.tmp_a.p, (size_t)c.nbr}, c.q.p, c.partials.p);
                 break;
             }
+#else
+            case 1: case 3: case 9: case 11: case 12: throw Error("spmv_bench: the measurement-only variants are not in this build (make -C stark_amd/csrc BENCH_VARIANTS=1)");
+#endif
             default: launch_spmv<0>(c, c.p.p, c.q.p, c.p.p, c.partials.p, nullptr, false);  // as inside the solver: k_pcg_step adds the contact rows
         }
     }

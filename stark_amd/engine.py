@@ -318,6 +318,12 @@ class Engine:
         self._ck(self.L.mistark_newton_iteration_log(self.h, rec, n.value, C.byref(n)))
         return list(rec)[:n.value]
 
+    def counter(self, name: str) -> int:
+        """mistark_get_counter: event counters of the context (tests assert that a feature under test actually ran)."""
+        v = C.c_int64()
+        self._ck(self.L.mistark_get_counter(self.h, name.encode(), C.byref(v)))
+        return int(v.value)
+
     def set_option(self, name: str, value: int):
         self._ck(self.L.mistark_set_option(self.h, name.encode(), int(value)))
 

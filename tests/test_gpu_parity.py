@@ -30,7 +30,7 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-@pytest.mark.parametrize("variant", ["default", "generic_atomic", "split_matrix", "split_matrix_atomic", "custom_ops"])
+@pytest.mark.parametrize("variant", ["default", "generic_atomic", "split_matrix", "split_matrix_atomic", "custom_ops", "custom_rtc"])
 @pytest.mark.parametrize("path", DUMPS, ids=[os.path.basename(p)[:-4] for p in DUMPS])
 def test_stages_match_reference(path, variant):
     from gpu_util import engine_from_problem
@@ -38,7 +38,11 @@ def test_stages_match_reference(path, variant):
 
     prob, man, z = ev.load_fixture(path)
     # custom_ops: no compiled kernel is used; every potential runs the reference's symx::Sequence through the device interpreter
-    eng = engine_from_problem(prob, man, custom_ops=z if variant == "custom_ops" else None)
+    # custom_rtc: the same sequences EMITTED as HIP source and compiled by hipRTC (what a user-defined potential gets by default; the
+    # interpreter is its fallback): every stage output below must hold for both
+    eng = engine_from_problem(prob, man, custom_ops=z if variant.startswith("custom_") else None)
+    if variant.startswith("custom_"):
+        eng.set_option("custom_rtc", 1 if variant == "custom_rtc" else 0)
     assert eng.ndofs == man["ndofs"]
     # closed-form kernels for every contact / friction table (by default the table's size decides: kernels.hip closed_contact_pays)
     eng.set_option("contact_closed_min_lanes", 0)
@@ -69,6 +73,8 @@ def test_stages_match_reference(path, variant):
     assert abs(E_pg - man["E"]) <= 1e-12 * max(1.0, scale)
     assert _rel(grad_pg, z["grad"]) < gtol
     eng.eval(capi.EVAL_P_G_H)
+    if variant.startswith("custom_"):   # the path under test did run: emitted kernels launched (or, for the interpreter variant, none built)
+        assert (eng.counter("rtc_launches") > 0) == (variant == "custom_rtc"), (eng.counter("rtc_builds"), eng.counter("rtc_launches"))
 
     for pi, pid in eng.pot_ids.items():
         ref = man["potentials"][pi]
