@@ -308,6 +308,7 @@ struct Context
     int proj_variant = 0;          // PSD projection, bits: 1 = matrix in LDS (k_project_eig) instead of registers, 2 = no batching of short lists, 4 = IEEE div/sqrt
     int pcg_batch = 0;             // tuning: PCG iterations per launch batch (one batch is always queued ahead of the one the host waits for); 0 = by size
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
+    int hf_layout = 0;             // float pool of the lazy tets: 0 = pair-major Hf[pair][element][9]; 1 = element-major Hf[element][pair][9] (round 5: measured, 2 % slower overall — the tet kernel's strided stores cost more than the gather gains — kept as an option and cross-check)
     int custom_rtc = 1;            // user-defined potentials: kernels emitted from the op sequence and compiled by hipRTC (0: the device interpreter only)
     int custom_timing = 0;         // measurement: HIP events around every launch of a user-defined potential (synchronises), counter "custom_kernel_us"
     double custom_kernel_us = 0.0;

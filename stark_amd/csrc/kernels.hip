@@ -386,6 +386,15 @@ struct TetBlockFloatSink
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         float* dst = Hwave + (size_t)tet_pair_index(a, b) * hstride;
         if (dbg & 2) {  // measurement switch: no global stores
+        } else if (dbg & 4) {
+            // ELEMENT-major pool Hf[element][pair][9] (option hf_layout = 1): the ten blocks of a tet are 360 contiguous bytes, so the blocks a
+            // BSR tile gathers — those of the few dozen tets around its rows' nodes — share cache lines instead of lying in ten pair pools.
+            // A wavefront's stores of one pair are 36-byte pieces 360 bytes apart; its ten puts fill the same lines within the kernel.
+            if (lane < n_valid) {
+                float* d = Hwave + ((size_t)lane * 10 + tet_pair_index(a, b)) * 9;
+#pragma unroll
+                for (int c = 0; c < 9; c++) d[c] = stage[lane * 9 + c];
+            }
         } else if (n_valid == 64) {
             const float4* s4 = reinterpret_cast<const float4*>(stage);
             float4* d4 = reinterpret_cast<float4*>(dst);
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __
         TetBlockStagedSink sink{stage + wave * 9 * 64, elemH + (size_t)pe_wave * 9, (size_t)a.n_pool * 9, lane, min(64, a.e_count - le_wave)};
         tet_closed_eval_to<FULL>(in, E, g, sink, true);
     } else if (MODE == TET_PGH_F) {
-        TetBlockFloatSink sink{reinterpret_cast<float*>(stage) + wave * 9 * 64, elemHf + (size_t)pe_wave * 9, (size_t)a.n_pool * 9, lane, min(64, a.e_count - le_wave), a.dbg};
+        TetBlockFloatSink sink{reinterpret_cast<float*>(stage) + wave * 9 * 64, elemHf + (size_t)pe_wave * ((a.dbg & 4) ? 90 : 9), (size_t)a.n_pool * 9, lane, min(64, a.e_count - le_wave), a.dbg};
         tet_closed_eval_to<FULL>(in, E, g, sink, true);
     } else {
         tet_closed_eval<FULL>(in, E, g, nullptr, 0, false);
@@ -751,6 +760,7 @@ static void launch_tet_closed(Context& c, Potential& P, int mode, bool kernel_on
     } else if (c.lazy_active) {
         PotArgs A = P.args;
         A.n_pool = P.n_pool_f;
+        if (c.hf_layout) A.dbg |= 4;  // element-major float pool
         hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, TET_PGH_F>), g, b, 0, c.stream, A, E, (double*)nullptr, c.elemHf.p + P.hf_off, c.grad.p);
     } else {
         hipLaunchKernelGGL((k_eval_tet_closed<En, FULL, TET_PGH>), g, b, 0, c.stream, P.args, E, c.elemH.p + P.h_off, (float*)nullptr, c.grad.p);
@@ -1408,7 +1418,8 @@ __device__ __forceinline__ uint32_t make_desc(uint32_t kp, const DescRange* __re
         if (e >= r.e_begin && e < r.e_begin + r.e_count) {
             if (r.lazy) {
                 const uint32_t a = ab / r.NB, b = ab - a * r.NB;
-                d = DESC_FLOAT | (a > b ? DESC_TRANS : 0u) | (r.pool_blk + (uint32_t)(a > b ? tet_pair_index((int)b, (int)a) : tet_pair_index((int)a, (int)b)) * r.n_pool + e);
+                const uint32_t pr = (uint32_t)(a > b ? tet_pair_index((int)b, (int)a) : tet_pair_index((int)a, (int)b));
+                d = DESC_FLOAT | (a > b ? DESC_TRANS : 0u) | (r.lazy == 2u ? r.pool_blk + e * 10u + pr : r.pool_blk + pr * r.n_pool + e);  // (2: element-major pool)
             } else {
                 d = r.pool_blk + ab * r.n_pool + e;
             }
@@ -3116,6 +3127,7 @@ struct MarkDesc
     float* hf;
     int nl, NB, n_key, n_pool_c, n_pool_f;
     int first_block;  // of this list in the common grid
+    int hf_element_major;
 };
 constexpr int MARK_BATCH = 16;
 struct MarkBatch  // every potential's list of one projection round in ONE launch (nine launches of 4.6 us each on configs[3])
@@ -3146,7 +3158,7 @@ __global__ __launch_bounds__(BLOCK) void k_proj_mark(MarkBatch mb)
     }
     if (a > b) return;  // (the pool holds the upper block triangle; (b, a) is read as the transpose of (a, b))
     const double* src = Hc + ((size_t)ab * n_pool_c + li) * 9;
-    float* dst = hf + ((size_t)tet_pair_index(a, b) * n_pool_f + le) * 9;
+    float* dst = hf + (D.hf_element_major ? (size_t)le * 10 + tet_pair_index(a, b) : (size_t)tet_pair_index(a, b) * n_pool_f + le) * 9;
     bool diff = false;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -3341,7 +3353,7 @@ static void project_phase_c(Context& c, Context::ProjRound& R)
         if (k.nl <= 0) continue;
         if (mb.n == MARK_BATCH) flush_marks();
         mb.d[mb.n++] = MarkDesc{k.list, (const uint32_t*)(m.slot_of_src.p + P.kp_off), m.slot_dirty.p, k.Hc, lazy ? c.elemHf.p + P.hf_off : (float*)nullptr, k.nl, P.NB, P.n_key,
-                                k.n_pool_c, P.n_pool_f, blocks};
+                                k.n_pool_c, P.n_pool_f, blocks, c.hf_layout};
         blocks += grid_for((int64_t)k.nl * P.NB * P.NB);
     }
     flush_marks();
@@ -3755,7 +3767,7 @@ static void make_descriptors(Context& c, int part)
         const bool lazy = c.lazy_active && P.lazy_capable;
         // (key space and pools hold the n_key elements this context evaluates: all of them, or the rank's list)
         rg.push_back(DescRange{(uint32_t)P.kp_off, (uint32_t)P.n_key, (uint32_t)P.NB, 0u, (uint32_t)P.n_key, lazy ? (uint32_t)(P.hf_off / 9) : (uint32_t)P.k_off,
-                               lazy ? (uint32_t)P.n_pool_f : (uint32_t)P.n_key, lazy ? 1u : 0u});
+                               lazy ? (uint32_t)P.n_pool_f : (uint32_t)P.n_key, lazy ? (c.hf_layout ? 2u : 1u) : 0u});
     }
     if (c.hess_total / 9 > DESC_MASK || c.hf_total / 9 > DESC_MASK) throw Error("element-Hessian pool too large for the gather descriptors");
     m.sorted_desc.ensure(m.n_keys);
