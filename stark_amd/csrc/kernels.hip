@@ -4459,6 +4459,7 @@ static int launch_spmv(Context& c, const double* x, double* y, const double* pdo
     StaticPart sp;
     DynPart d;
     spmv_launch_shape(c, g0, gr, g1, sp, d);
+    if (c.spmv_variant == 30) g1 = gr = 0;  // (measurement: the static chunks alone through the same kernel)
     // non-temporal value loads once the matrix cannot stay in the 256 MiB Infinity Cache beside the vectors (option spmv_nt: -1 = by size, 0 / 1)
     const bool nt = V == 0 && (c.spmv_nt >= 0 ? c.spmv_nt != 0 : (size_t)c.part[0].ntiles * 2304 + (size_t)c.part[0].ntiles * 256 > ((size_t)160 << 20));
 if (nt) hipLaunchKernelGGL(k_spmv_fused<4>, dim3(g0 + gr + g1), dim3(BLOCK), 0, c.stream, g0, gr, g1, sp, d, x, y, pdot, partials, ctrl, clk);
