@@ -94,7 +94,7 @@ int mistark_potential_custom(mistark_ctx* ctx, const char* name, const int32_t* 
 /* A custom potential does not stay interpreted: at its first evaluation the op sequence is EMITTED as HIP source (one statement per op, the
  * temporaries local variables, Branch markers real branches, the gather unrolled — the mirror of the reference's scalar emitter,
  * symx/src/compile/Compilation.cpp:381-469), compiled for gfx950 by hipRTC and cached on disk by a hash of the source (MISTARK_RTC_CACHE,
- * default /tmp/mistark_rtc_cache). The interpreter remains the fallback (no libhiprtc, a failed build, sequences of more than
+ * default /tmp/mistark_rtc_cache_<uid>). The interpreter remains the fallback (no libhiprtc, a failed build, sequences of more than
  * MISTARK_RTC_MAX_OPS = 3000 ops, option "custom_rtc" = 0). mistark_custom_emit returns what the emitter writes for a sequence — the source
  * in `out` (truncated to cap) and its length — and, with compile != 0, runs hipRTC on it and returns the size of the code object; < 0 with the
  * message in `out` on failure. in_dof[k]: the local DoF component (3 * block + c) input k seeds, -1 for inputs that are not DoFs. Needs no

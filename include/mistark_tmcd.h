@@ -37,6 +37,10 @@ const char* mistark_cd_last_error(mistark_cd* cd);
 int mistark_cd_add_mesh(mistark_cd* cd, const double* xm, int32_t n_vertices, const int32_t* triangles, int32_t n_triangles, const int32_t* edges, int32_t n_edges);
 /* add_blacklist(mesh a, mesh b): no pairs between the two meshes (a == b: none inside the mesh) */
 int mistark_cd_add_blacklist(mistark_cd* cd, int32_t mesh_a, int32_t mesh_b);
+/* add_blacklist_range_point_triangle (edge_edge = 0: points [a0, a1) of mesh_a never pair with triangles [b0, b1) of mesh_b) and
+ * add_blacklist_range_edge_edge (edge_edge = 1: edges [a0, a1) of mesh_a with edges [b0, b1) of mesh_b; the first interval must be the lower one in
+ * the detector's global edge numbering = registration order, as the reference demands): ProximityDetection.h:24-25, half-open local intervals. */
+int mistark_cd_add_blacklist_range(mistark_cd* cd, int32_t edge_edge, int32_t mesh_a, int32_t a0, int32_t a1, int32_t mesh_b, int32_t b0, int32_t b1);
 /* activate_point_triangle / activate_edge_edge */
 int mistark_cd_activate(mistark_cd* cd, int point_triangle, int edge_edge);
 /* ProximityDetection::run(enlargement): counts[l] = rows of list l. (Edge pairs whose |ea x eb|^2 is at most 1e-30 never reach a list:

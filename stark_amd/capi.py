@@ -285,6 +285,12 @@ class CollisionDetector:
     def add_blacklist(self, a, b):
         self._ck(self.L.mistark_cd_add_blacklist(self.h, a, b))
 
+    def add_blacklist_range(self, edge_edge, mesh_a, interval_a, mesh_b, interval_b):
+        """tmcd add_blacklist_range_point_triangle (edge_edge False: points interval_a of mesh_a x triangles interval_b of mesh_b) /
+        add_blacklist_range_edge_edge (True: edges x edges, the lower interval first); half-open local intervals."""
+        self.L.mistark_cd_add_blacklist_range.argtypes = [C.c_void_p] + [C.c_int32] * 7
+        self._ck(self.L.mistark_cd_add_blacklist_range(self.h, int(bool(edge_edge)), mesh_a, interval_a[0], interval_a[1], mesh_b, interval_b[0], interval_b[1]))
+
     def activate(self, point_triangle=True, edge_edge=True):
         self._ck(self.L.mistark_cd_activate(self.h, int(point_triangle), int(edge_edge)))
 

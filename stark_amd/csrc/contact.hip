@@ -172,6 +172,11 @@ struct ContactDev
     const double* X;           // 3 per collision vertex
     const float* aabb;         // 6 per primitive: points | triangles | edges
     int n_mesh, n_v, n_t, n_e;
+    // range blacklists (tmcd add_blacklist_range_point_triangle / _edge_edge, BroadPhasePTEEBase.cpp:19-41,176-262): half-open intervals of
+    // GLOBAL primitive indices, 4 ints each — {triangle begin, end, point begin, end} and {lower edge begin, end, higher edge begin, end}
+    const int32_t* bl_pt;
+    const int32_t* bl_ee;
+    int n_bl_pt, n_bl_ee;
 };
 struct TableDev
 {
@@ -277,6 +282,8 @@ __device__ __forceinline__ void narrow_pt(const ContactDev& d, int p, int t, dou
     if (p == v0 || p == v1 || p == v2) return;  // point of its own triangle (BroadPhasePTEEBase.cpp:193)
     const int mp = d.cv_mesh[p], mt = d.tri_mesh[t];
     if (d.disabled[mp * d.n_mesh + mt]) return;
+    for (int k = 0; k < d.n_bl_pt; k++)  // BroadPhasePTEEBase.cpp:181-205
+        if (d.bl_pt[4 * k] <= t && t < d.bl_pt[4 * k + 1] && d.bl_pt[4 * k + 2] <= p && p < d.bl_pt[4 * k + 3]) return;
     int type;
     const double d2 = point_triangle_sq_distance(type, ldx(d.X, p), ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, v2));
     if (!(d2 < enl2)) return;                                           // ProximityDetection.cpp:105
@@ -292,6 +299,10 @@ __device__ __forceinline__ void narrow_ee(const ContactDev& d, int ea, int eb, d
     if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) return;  // edges sharing a vertex (BroadPhasePTEEBase.cpp:246)
     const int ma = d.edge_mesh[ea], mb = d.edge_mesh[eb];
     if (d.disabled[ma * d.n_mesh + mb]) return;
+    for (int k = 0; k < d.n_bl_ee; k++) {  // (the pair is looked up as (lower, higher) global edge: BroadPhasePTEEBase.cpp:229-258)
+        const int lo = ea < eb ? ea : eb, hi = ea < eb ? eb : ea;
+        if (d.bl_ee[4 * k] <= lo && lo < d.bl_ee[4 * k + 1] && d.bl_ee[4 * k + 2] <= hi && hi < d.bl_ee[4 * k + 3]) return;
+    }
     const D3 xa0 = ldx(d.X, a0), xa1 = ldx(d.X, a1), xb0 = ldx(d.X, b0), xb1 = ldx(d.X, b1);
     if (sq3(cross3(xa1 - xa0, xb1 - xb0)) <= 1e-30) return;  // (nearly) parallel edges never reach a table (ProximityDetection.cpp:152-155)
     int type;
@@ -1076,6 +1087,8 @@ struct ContactSystem
     std::vector<int32_t> h_cv_src, h_cv_mesh, h_tri, h_tri_mesh, h_edge, h_edge_mesh;
     std::map<std::pair<int, int>, double> friction;
     std::vector<std::pair<int, int>> disabled_pairs;
+    std::vector<int32_t> h_bl_pt, h_bl_ee;  // range blacklists, 4 ints each (ContactDev::bl_pt / bl_ee)
+    DevBuf<int32_t> bl_pt, bl_ee;
     bool meshes_dirty = true;
     bool pt_enabled = true, ee_enabled = true;
     // sharded search (merge_sharded_search): keys per rank in the exchange, its buffers, how many searches took it
@@ -1298,6 +1311,8 @@ void upload_meshes(Context& c, ContactSystem& cs)
     upload(c, cs.mesh_idx, idx);
     upload(c, cs.disabled, dis);
     upload(c, cs.mu, mu);
+    if (!cs.h_bl_pt.empty()) upload(c, cs.bl_pt, cs.h_bl_pt);
+    if (!cs.h_bl_ee.empty()) upload(c, cs.bl_ee, cs.h_bl_ee);
     cs.X.ensure(3 * (size_t)cs.n_v);
     cs.aabb.ensure(6 * (size_t)(cs.n_v + cs.n_t + cs.n_e));
     MS_CHECK(hipStreamSynchronize(c.stream));  // (the staging vectors above are temporaries)
@@ -1312,6 +1327,8 @@ ContactDev dev_view(Context& c, ContactSystem& cs)
     d.thick = cs.thick_override.p ? cs.thick_override.p : arr_dev(c, cs.arr.thickness);
     d.X = cs.X.p; d.aabb = cs.aabb.p;
     d.n_mesh = (int)cs.meshes.size(); d.n_v = cs.n_v; d.n_t = cs.n_t; d.n_e = cs.n_e;
+    d.bl_pt = cs.bl_pt.p; d.bl_ee = cs.bl_ee.p;
+    d.n_bl_pt = (int)(cs.h_bl_pt.size() / 4); d.n_bl_ee = (int)(cs.h_bl_ee.size() / 4);
     return d;
 }
 double max_thickness(Context& c, ContactSystem& cs)
@@ -1851,7 +1868,7 @@ uint64_t cd_fingerprint(const StandaloneDetector& D, const ContactSystem& cs, do
     std::memcpy(&e, &enlargement, 8);
     uint64_t r = mix(mix(mix(mix(h[0], h[1]), h[2]), h[3]), e);
     r = mix(r, (uint64_t)cs.meshes.size() * 4 + (cs.pt_enabled ? 2 : 0) + (cs.ee_enabled ? 1 : 0));
-    r = mix(r, (uint64_t)cs.disabled_pairs.size());
+    r = mix(r, (uint64_t)cs.disabled_pairs.size() + 1000003ull * (uint64_t)(cs.h_bl_pt.size() + cs.h_bl_ee.size()));
     return r;
 }
 void cd_gather_positions(StandaloneDetector& D)
@@ -1984,6 +2001,28 @@ int mistark_cd_add_blacklist(mistark_cd* cd, int32_t a, int32_t b)
     if (a < 0 || b < 0 || a >= (int)cs.meshes.size() || b >= (int)cs.meshes.size()) throw Error("cd: bad mesh id");
     cs.disabled_pairs.push_back({a, b});
     cs.meshes_dirty = true;
+    CD_END(0)
+}
+int mistark_cd_add_blacklist_range(mistark_cd* cd, int32_t edge_edge, int32_t mesh_a, int32_t a0, int32_t a1, int32_t mesh_b, int32_t b0, int32_t b1)
+{
+    // tmcd::ProximityDetection::add_blacklist_range_point_triangle (edge_edge = 0: points [a0, a1) of mesh_a against triangles [b0, b1) of mesh_b) and
+    // add_blacklist_range_edge_edge (edge_edge = 1: edges [a0, a1) of mesh_a against edges [b0, b1) of mesh_b; the first interval must be the lower
+    // one in the global edge numbering, as in the reference, BroadPhasePTEEBase.cpp:37-40)
+    CD_BEGIN
+    ContactSystem& cs = CS(cd->D.c);
+    const int nm = (int)cs.meshes.size();
+    if (mesh_a < 0 || mesh_b < 0 || mesh_a >= nm || mesh_b >= nm) throw Error("cd: bad mesh id");
+    const ContactSystem::Mesh &A = cs.meshes[(size_t)mesh_a], &B = cs.meshes[(size_t)mesh_b];
+    if (edge_edge) {
+        if (a0 < 0 || a1 > A.n_e || a0 > a1 || b0 < 0 || b1 > B.n_e || b0 > b1) throw Error("cd: edge interval outside its mesh");
+        if (A.e_off + a0 > B.e_off + b0) throw Error("cd: add_blacklist_range_edge_edge: the first edge interval must be the lower one (as in the reference)");
+        for (int v : {A.e_off + a0, A.e_off + a1, B.e_off + b0, B.e_off + b1}) cs.h_bl_ee.push_back(v);
+    } else {
+        if (a0 < 0 || a1 > A.n_v || a0 > a1 || b0 < 0 || b1 > B.n_t || b0 > b1) throw Error("cd: point / triangle interval outside its mesh");
+        for (int v : {B.t_off + b0, B.t_off + b1, A.v_off + a0, A.v_off + a1}) cs.h_bl_pt.push_back(v);
+    }
+    cs.meshes_dirty = true;
+    cd->D.prox_valid = false;
     CD_END(0)
 }
 int mistark_cd_activate(mistark_cd* cd, int point_triangle, int edge_edge)

@@ -338,7 +338,7 @@ void custom_program_set_summation(CustomProgram& G, const std::string& name, int
 // emitter it mirrors: symx/src/compile/Compilation.cpp:381-469). The op sequence of a user-defined potential becomes straight-line HIP source
 // — one statement per op, the temporaries local variables, if / else / endif as real branches, the gather of the bound arrays unrolled with
 // the strides and DoF seeds known at emission — compiled for gfx950 by hipRTC at the potential's first evaluation and cached on disk by a hash
-// of the source (MISTARK_RTC_CACHE, default /tmp/mistark_rtc_cache; the reference caches its JIT-compiled .so files the same way,
+// of the source (MISTARK_RTC_CACHE, default /tmp/mistark_rtc_cache_<uid>; the reference caches its JIT-compiled .so files the same way,
 // Compilation.cpp:243-336). Same decomposition (one lane per (element, i <= j)), same hyper-dual operations (custom_math.hpp is compiled into
 // both) and same output layout as the interpreter k_eval_custom, which stays as the fallback (no hipRTC library, a failed build, programs
 // beyond MISTARK_RTC_MAX_OPS, option custom_rtc = 0) and as the cross-check (tests/test_gpu_custom_rtc.py).
@@ -573,7 +573,8 @@ uint64_t fnv1a(const std::string& s)
 std::vector<char> rtc_build(const std::string& src, std::string& why)
 {
     const char* dir_env = std::getenv("MISTARK_RTC_CACHE");
-    const std::string dir = dir_env && dir_env[0] ? dir_env : "/tmp/mistark_rtc_cache";
+    // (default: a directory of this user's own, created 0700 — code objects found there are loaded and run)
+    const std::string dir = dir_env && dir_env[0] ? dir_env : "/tmp/mistark_rtc_cache_" + std::to_string((long long)getuid());
     char name[64];
     std::snprintf(name, sizeof(name), "/%016llx_gfx950.hsaco", (unsigned long long)fnv1a(src));
     const std::string path = dir + name;
@@ -612,7 +613,7 @@ std::vector<char> rtc_build(const std::string& src, std::string& why)
     }
     R.DestroyProgram(&prog);
     if (!code.empty()) {  // (cache: best effort, written under a temporary name and renamed)
-        (void)::mkdir(dir.c_str(), 0777);
+        (void)::mkdir(dir.c_str(), 0700);
         const std::string tmp = path + "." + std::to_string((long long)getpid());
         if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
             const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();

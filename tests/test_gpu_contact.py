@@ -253,3 +253,70 @@ def test_standalone_detector_returns_the_references_lists(name):
         e, t = hits[0, :4], hits[0, 4:]
         assert oc.edge_intersects_triangle(X[e[0]][e[2]][None], X[e[0]][e[3]][None], X[t[0]][t[2]][None], X[t[0]][t[3]][None], X[t[0]][t[4]][None]).all()
     cd.close()
+
+
+def test_standalone_detector_range_blacklists():
+    """tmcd::ProximityDetection::add_blacklist_range_point_triangle / _edge_edge (ProximityDetection.h:24-25; BroadPhasePTEEBase.cpp:19-41,176-262:
+    half-open intervals of local primitive indices, a pair is dropped when its triangle lies in the first and its point in the second interval —
+    for edges: the lower edge in the first, the higher in the second): the lists with ranges registered are the lists without them minus
+    exactly the pairs inside a range (filtered on the host from the unrestricted run), for point-triangle and edge-edge ranges between two
+    meshes and inside one mesh."""
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, "contactmix_t0.npz"))
+    st, _ = state_from_fixture(prob, man)
+    scene = oc.scene_from_fixture(man, z)
+    dt = float(np.asarray(st["dt"]).ravel()[0])
+    X = [np.ascontiguousarray(x, dtype=np.float64) for x in oc.mesh_vertices(scene, st, dt)]
+    enl = 2.0 * oc.max_thickness(scene)
+
+    def detector():
+        cd = capi.CollisionDetector()
+        for m, x in zip(scene.meshes, X):
+            cd.add_mesh(x, m.tris, m.edges)
+        for (a, b) in scene.disabled:
+            cd.add_blacklist(a, b)
+        return cd
+
+    cd = detector()
+    full = cd.run_proximity(enl)
+    cd.close()
+    # ranges chosen from the pairs that exist: half of the points / edges of the busiest mesh pairs
+    pt = np.concatenate([full[n][0][:, [0, 1, 2, 3]] for n in ("pt_point_point", "pt_point_edge", "pt_point_triangle") if len(full[n][0])])
+    ee = np.concatenate([full[n][0][:, [0, 1, 5 if n != "ee_edge_edge" else 4, 6 if n != "ee_edge_edge" else 5]] for n in ("ee_point_point", "ee_point_edge", "ee_edge_edge")
+                         if len(full[n][0])])
+    assert len(pt) > 5 and len(ee) > 5
+    pm, tm = [int(v) for v in pt[np.argmax(np.bincount(pt[:, 0] * 64 + pt[:, 2]) [pt[:, 0] * 64 + pt[:, 2]])][[0, 2]]]
+    p_mid = int(np.median(pt[(pt[:, 0] == pm) & (pt[:, 2] == tm), 1])) + 1
+    r_pt = (pm, (0, p_mid), tm, (0, len(scene.meshes[tm].tris)))
+    # edge pairs come as (lower global edge, higher global edge): take the busiest (first mesh, second mesh) with first <= second
+    swap = ee[:, 0] > ee[:, 2]
+    ee = np.where(swap[:, None], ee[:, [2, 3, 0, 1]], ee)
+    key = ee[:, 0] * 64 + ee[:, 2]
+    ea, eb = divmod(int(np.bincount(key).argmax()), 64)
+    e_mid = int(np.median(ee[(ee[:, 0] == ea) & (ee[:, 2] == eb), 1])) + 1
+    r_ee = (ea, (0, e_mid), eb, (e_mid if ea == eb else 0, len(scene.meshes[eb].edges)))
+    cd = detector()
+    cd.add_blacklist_range(False, r_pt[0], r_pt[1], r_pt[2], r_pt[3])
+    cd.add_blacklist_range(True, r_ee[0], r_ee[1], r_ee[2], r_ee[3])
+    got = cd.run_proximity(enl)
+    cd.close()
+    dropped = 0
+    for name, (rows, d) in full.items():
+        if name.startswith("pt_"):
+            out = (rows[:, 0] == r_pt[0]) & (rows[:, 1] >= r_pt[1][0]) & (rows[:, 1] < r_pt[1][1]) & (rows[:, 2] == r_pt[2]) & (rows[:, 3] >= r_pt[3][0]) & (rows[:, 3] < r_pt[3][1])
+        else:
+            # (a row lists its two edges by ROLE — the one holding the closest point first —, the blacklist looks the pair up as (lower, higher)
+            # edge of the detector's global numbering = meshes in registration order)
+            j = 4 if name == "ee_edge_edge" else 5
+            e_off = np.concatenate([[0], np.cumsum([len(m.edges) for m in scene.meshes])])
+            ga, gb = e_off[rows[:, 0]] + rows[:, 1], e_off[rows[:, j]] + rows[:, j + 1]
+            lo, hi = np.minimum(ga, gb), np.maximum(ga, gb)
+            out = (lo >= e_off[r_ee[0]] + r_ee[1][0]) & (lo < e_off[r_ee[0]] + r_ee[1][1]) & (hi >= e_off[r_ee[2]] + r_ee[3][0]) & (hi < e_off[r_ee[2]] + r_ee[3][1])
+        want = rows[~out]
+        have = got[name][0]
+        dropped += int(out.sum())
+        assert have.shape == want.shape, (name, have.shape, want.shape)
+        if len(want):
+            assert (have[np.lexsort(have.T[::-1])] == want[np.lexsort(want.T[::-1])]).all(), name
+    assert dropped > 2
