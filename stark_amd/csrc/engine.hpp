@@ -309,6 +309,7 @@ struct Context
     int pcg_batch = 0;             // tuning: PCG iterations per launch batch (one batch is always queued ahead of the one the host waits for); 0 = by size
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
     int hf_layout = 0;             // float pool of the lazy tets: 0 = pair-major Hf[pair][element][9]; 1 = element-major Hf[element][pair][9] (round 5: measured, 2 % slower overall — the tet kernel's strided stores cost more than the gather gains — kept as an option and cross-check)
+    int key_rank_sort = 0;         // the contact keys of a search (a few thousand) sorted by the one-launch rank sort instead of the library's radix sort (measurement)
     int custom_rtc = 1;            // user-defined potentials: kernels emitted from the op sequence and compiled by hipRTC (0: the device interpreter only)
     int custom_timing = 0;         // measurement: HIP events around every launch of a user-defined potential (synchronises), counter "custom_kernel_us"
     double custom_kernel_us = 0.0;
@@ -349,6 +350,9 @@ struct Context
     double* h_scratch = nullptr;    // pinned host scratch
     void* h_pin = nullptr;          // pinned staging area of fetch()
     void* h_stage[2] = {nullptr, nullptr};  // pinned staging areas of h2d_staged() (uploads of the caller's pageable arrays)
+    void* h_small[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned slots of small uploads of host temporaries (kernels.hip: h2d_small)
+    hipEvent_t h_small_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned h_small_next = 0;
     hipEvent_t h_stage_ev[2] = {nullptr, nullptr};
     size_t h_pin_bytes = 0;
     uint8_t* pub = nullptr;         // coherent pinned page small read-backs are published into (kernels.hip: publish)
@@ -619,6 +623,7 @@ std::shared_ptr<CustomProgram> make_custom_program(const std::string& name, cons
                                                    const int32_t* cond_ops, const double* cond_consts, int n_cond_ops);
 void custom_program_set_summation(CustomProgram& G, const std::string& name, int first_input, int stride, int n_iterations, const double* data);
 void launch_eval_custom(Context& c, Potential& P, int mode);
+void h2d_small(Context& c, void* dst_dev, const void* src_host, size_t bytes);
 double reduce_max_abs(Context& c, const double* v, int64_t n);
 double reduce_dot(Context& c, const double* a, const double* b, int64_t n);
 void vec_axpby(Context& c, double* dst, double a, const double* x, double b, const double* y, int64_t n);

@@ -1072,6 +1072,29 @@ void h2d_staged(Context& c, void* dst_dev, const void* src_host, size_t bytes)
         MS_CHECK(hipEventRecord(c.h_stage_ev[k], c.stream));
     }
 }
+// Small host -> device uploads of host TEMPORARIES (descriptor tables a few hundred bytes long) without waiting for the stream: the bytes are
+// copied into one of four pinned slots that outlive the call, the transfer reads the slot; a slot is reused after its transfer's event (four
+// uploads later: long done). The stream synchronisation this replaces drained every queued kernel at each change of the contact tables.
+void h2d_small(Context& c, void* dst_dev, const void* src_host, size_t bytes)
+{
+    constexpr size_t SLOT = 16384;
+    if (bytes == 0) return;
+    if (bytes > SLOT) {
+        MS_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c.stream));
+        MS_CHECK(hipStreamSynchronize(c.stream));  // (the caller's buffer is a temporary)
+        return;
+    }
+    const int k = c.h_small_next++ & 3;
+    if (!c.h_small[k]) {
+        MS_CHECK(hipHostMalloc(&c.h_small[k], SLOT));
+        MS_CHECK(hipEventCreateWithFlags(&c.h_small_ev[k], hipEventDisableTiming));
+    } else {
+        MS_CHECK(hipEventSynchronize(c.h_small_ev[k]));
+    }
+    std::memcpy(c.h_small[k], src_host, bytes);
+    MS_CHECK(hipMemcpyAsync(dst_dev, c.h_small[k], bytes, hipMemcpyHostToDevice, c.stream));
+    MS_CHECK(hipEventRecord(c.h_small_ev[k], c.stream));
+}
 void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes)
 {
     if (bytes == 0) return;
@@ -1925,8 +1948,7 @@ void prepare(Context& c)
         }
         if (!dyn_desc.empty()) {
             c.dyn_desc.ensure(dyn_desc.size() * sizeof(DynIncDesc));
-            MS_CHECK(hipMemcpyAsync(c.dyn_desc.p, dyn_desc.data(), dyn_desc.size() * sizeof(DynIncDesc), hipMemcpyHostToDevice, c.stream));
-            MS_CHECK(hipStreamSynchronize(c.stream));  // (host vector is a temporary)
+            h2d_small(c, c.dyn_desc.p, dyn_desc.data(), dyn_desc.size() * sizeof(DynIncDesc));  // (the host vector is a temporary: through a pinned slot, no stream synchronisation)
         }
         c.n_elem_total = e_off;
         c.hess_total = h_off;

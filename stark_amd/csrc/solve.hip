@@ -2545,6 +2545,10 @@ Context::~Context()
         if (h_stage[k]) (void)hipHostFree(h_stage[k]);
         if (h_stage_ev[k]) (void)hipEventDestroy(h_stage_ev[k]);
     }
+    for (int k = 0; k < 4; k++) {
+        if (h_small[k]) (void)hipHostFree(h_small[k]);
+        if (h_small_ev[k]) (void)hipEventDestroy(h_small_ev[k]);
+    }
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : pcg_ev) (void)hipEventDestroy(e);
     for (auto e : stage_ev) (void)hipEventDestroy(e);
