@@ -1230,7 +1230,6 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;
     else if (n == "spmv_nt") ctx->c.spmv_nt = value;
     else if (n == "custom_rtc") ctx->c.custom_rtc = value;
-    else if (n == "key_rank_sort") ctx->c.key_rank_sort = value;
     else if (n == "hf_layout") {  // (the pool is rewritten by the next evaluation; the gather's descriptors follow the layout)
         ctx->c.hf_layout = value;
         ctx->c.part[0].desc_lazy = ctx->c.part[1].desc_lazy = -1;

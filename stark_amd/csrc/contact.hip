@@ -1541,7 +1541,9 @@ __global__ __launch_bounds__(CB) void k_rank_sort_keys(const uint64_t* __restric
 const uint64_t* sort_and_bound(Context& c, ContactSystem& cs, int n_sort, const int* n_dev, bool compare)
 {
     hipcub::DoubleBuffer<uint64_t> dk(cs.keys.p, cs.keys_alt.p);
-    if (n_sort > 1 && n_sort <= RANK_SORT_MAX && (c.seg_sort || c.key_rank_sort)) {
+    // (the one-launch rank sort alone, beside the library's box sort, was measured in round 5: contact callbacks 12 -> 25 ms per 20 iterations —
+    // every thread reads all n keys out of LDS; it stays part of option seg_sort only)
+    if (n_sort > 1 && n_sort <= RANK_SORT_MAX && c.seg_sort) {
         hipLaunchKernelGGL(k_rank_sort_keys, dim3((n_sort + CB - 1) / CB), dim3(CB), 0, c.stream, (const uint64_t*)cs.keys.p, n_sort, cs.keys_alt.p);
         dk.selector = 1;
     } else if (n_sort > 1) {

@@ -309,7 +309,6 @@ struct Context
     int pcg_batch = 0;             // tuning: PCG iterations per launch batch (one batch is always queued ahead of the one the host waits for); 0 = by size
     int spmv_grid_cap = 0;         // tuning: max workgroups of the SpMV kernel (0 = default)
     int hf_layout = 0;             // float pool of the lazy tets: 0 = pair-major Hf[pair][element][9]; 1 = element-major Hf[element][pair][9] (round 5: measured, 2 % slower overall — the tet kernel's strided stores cost more than the gather gains — kept as an option and cross-check)
-    int key_rank_sort = 0;         // the contact keys of a search (a few thousand) sorted by the one-launch rank sort instead of the library's radix sort (measurement)
     int custom_rtc = 1;            // user-defined potentials: kernels emitted from the op sequence and compiled by hipRTC (0: the device interpreter only)
     int custom_timing = 0;         // measurement: HIP events around every launch of a user-defined potential (synchronises), counter "custom_kernel_us"
     double custom_kernel_us = 0.0;
