@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 tag=${1:-r05_final}
 mkdir -p gpurun_out
-timeout 2700 python -m pytest tests -m gpu -q 2>&1 | tail -3
+timeout 2700 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|error" | tail -3
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 bash tools/profile_round.sh $tag 2>&1 | tail -3
 # HBM-resident SpMV: kernel trace, then FETCH_SIZE / WRITE_SIZE in their own passes
