@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_eval_custom(PotArgs a, ProgDev p, doubl
         if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);  // (k_eval_pgh)
         else atomicAdd(&grad[3 * (size_t)(a.dof_row_off[ba] + node) + ii], r.a);
     }
-    if (first) elemE[pe] = r.v;
+    if (first) elemE[pe] = energy_here(a, e) ? r.v : 0.0;  // (sharded runs: an interface element is evaluated by every rank that owns one of its rows; its energy counts once)
 }
 
 // Linear-scan register allocation of the temporaries of one op sequence (values >= n_in). A value defined in both arms of a branch
@@ -555,7 +555,7 @@ std::string emit_source(const CustomProgram& G, const std::vector<int32_t>& in_d
                  "        const int node = a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];\n"
                  "        if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);\n"
                  "        else atomicAdd(&grad[3 * (size_t)(a.dof_row_off[ba] + node) + ii], r.a);\n    }\n";
-        s += "    if (first) elemE[pe] = r.v;\n}\n";
+        s += "    if (first) elemE[pe] = energy_here(a, e) ? r.v : 0.0;\n}\n";
     }
     return s;
 }

@@ -78,18 +78,6 @@ __device__ __forceinline__ void gather_inputs(const PotArgs& a, int e, double* i
     });
 }
 
-// element of a kernel's local index le, and its position in the pools (element energies, element Hessians)
-__device__ __forceinline__ int elem_of(const PotArgs& a, int le) { return a.elem_list ? (int)a.elem_list[le] : a.e_begin + le; }
-__device__ __forceinline__ int pool_of(const PotArgs& a, int le) { return a.elem_list ? le : a.e_begin + le; }
-// sharded runs: an element on an interface is evaluated by every rank that owns one of its rows; its energy counts where the row of its
-// first DoF block lives
-__device__ __forceinline__ bool energy_here(const PotArgs& a, int e)
-{
-    if (!a.lrow) return true;
-    const int l = a.lrow[a.dof_row_off[0] + a.conn[(size_t)e * a.conn_stride + a.dof_col[0]]];
-    return l >= 0 && l < a.n_own;
-}
-
 // Energy only: one lane per element
 template <class En>
 __global__ __launch_bounds__(BLOCK) void k_eval_p(PotArgs a, double* __restrict__ elemE)

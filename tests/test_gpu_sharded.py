@@ -3,6 +3,7 @@ solves its rows of the system) run with several engine contexts in ON
 thread per rank): 2, 3 and 8 ranks must reproduce the single-rank results, and every rank must hold identical bits of everything that is
 replicated. The RCCL transport differs only in who carries the all-gather (tests/test_dist_cpu.py covers the partition, halo and
 fused-dot arithmetic with gloo on CPU)."""
+import ctypes as C
 import json
 import os
 import sys
@@ -104,6 +105,55 @@ def test_sharded_stages_equal_single_rank(name, world):
     for r in res[1:]:
         assert r["E"] == res[0]["E"] and r["Ep"] == res[0]["Ep"] and (r["g"] == res[0]["g"]).all() and (r["y"] == res[0]["y"]).all()
         assert (r["yp"] == res[0]["yp"]).all() and (r["du"] == res[0]["du"]).all() and (r["du0"] == res[0]["du0"]).all() and r["its"] == res[0]["its"]
+
+
+@pytest.mark.parametrize("rtc", [0, 1])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_user_defined_potentials_count_interface_energies_once(world, rtc):
+    """Every potential of the beam registered as a USER-DEFINED potential (its symx::Sequence: the device interpreter, rtc = 0, or the kernels
+    emitted from it, rtc = 1) on sharded ranks: interface elements are evaluated by every rank that owns one of their rows, and their energy
+    must count on one of them only (energy_here) — round 5 found the custom kernels adding it on both sides (energy-only evaluations were right,
+    evaluations with gradient / Hessian counted interface elements twice: a line search comparing the two kinds would have been off)."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, "tetbeam_full_4x1x1.npz"))
+
+    def stages(eng):
+        eng.set_option("custom_rtc", rtc)
+        E, g = eng.eval(capi.EVAL_P_G_H)
+        Ep, _ = eng.eval(capi.EVAL_P)
+        Eg, gg = eng.eval(capi.EVAL_P_G)
+        return dict(E=E, Ep=Ep, Eg=Eg, g=g, gg=gg)
+
+    single = engine_from_problem(prob, man, custom_ops=z)
+    ref = stages(single)
+    single.close()
+    assert abs(ref["E"] - man["E"]) <= 1e-12 * max(1.0, abs(man["E"]))
+    L = capi.lib()
+    group = L.mistark_local_group_create(world)
+
+    def rank_fn(r):
+        eng = engine_from_problem(prob, man, custom_ops=z)
+        eng.dist_init_local(group, r)
+        nbr = eng.ndofs // 3
+        eng.dist_set_row_owner(np.arange(nbr, dtype=np.int32) * world // nbr)   # (the partitioner keeps a problem this small on one rank)
+        res = stages(eng)
+        info = (C.c_int64 * 15)()
+        assert L.mistark_dist_info(eng.h, info, 15) == 0
+        res["info"] = list(info)
+        eng.close()
+        return res
+
+    res = run_ranks(world, rank_fn)
+    L.mistark_local_group_destroy(group)
+    assert all(r["info"][14] > 0 for r in res)
+    assert sum(r["info"][14] for r in res) > res[0]["info"][13]   # (interface elements exist: evaluated by more than one rank)
+    for r in res:
+        for k in ("E", "Ep", "Eg"):
+            assert abs(r[k] - ref[k]) <= 1e-12 * max(1.0, abs(ref[k])), (k, r[k], ref[k])
+        assert np.abs(r["g"] - ref["g"]).max() <= 1e-12 * np.abs(ref["g"]).max()
+        assert np.abs(r["gg"] - ref["gg"]).max() <= 1e-12 * np.abs(ref["gg"]).max()
 
 
 @pytest.mark.parametrize("world", [2, 8])
