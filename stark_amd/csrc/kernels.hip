@@ -299,8 +299,50 @@ __global__ __launch_bounds__(BLOCK) void k_grad_gather_long(const double* __rest
 // (H[pair][element][9]); a lane storing its own 72 bytes would make every store instruction touch 64 separate segments, so each block
 // goes through LDS: the wavefront's 64 blocks of one pair are 4608 contiguous bytes and leave as nine fully coalesced stores (and nine
 // more for the transposed pair).
+// Energy and node gradients of a lane's tet, stored as soon as the closed form has them (before its Hessian blocks: 26 registers less to carry through
+// the block loop): node gradients to the gradient pool, summed per block row by k_grad_gather, or, without a pool, 12 atomics
+struct TetEarlyOut
+{
+    const PotArgs* a;
+    double* elemE;
+    double* grad;
+    int e, le;
+    bool valid;
+    __device__ __forceinline__ void store(double E, const double* g) const
+    {
+        if (!valid) return;
+        const PotArgs& A = *a;
+        const int pe = pool_of(A, le);
+        elemE[pe] = energy_here(A, e) ? E : 0.0;
+        if (A.dbg & 1) return;  // measurement switch: no gradient output
+        if (A.gpool) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                double* gp = A.gpool + ((size_t)k * A.n_gpool + pe) * 3;
+                gp[0] = g[3 * k];
+                gp[1] = g[3 * k + 1];
+                gp[2] = g[3 * k + 2];
+            }
+            return;
+        }
+        const int32_t* ce = A.conn + (size_t)e * A.conn_stride;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const size_t row = (size_t)(A.dof_row_off[k] + ce[A.dof_col[k]]);
+            atomicAdd(&grad[3 * row], g[3 * k]);
+            atomicAdd(&grad[3 * row + 1], g[3 * k + 1]);
+            atomicAdd(&grad[3 * row + 2], g[3 * k + 2]);
+        }
+    }
+};
 struct TetBlockStagedSink
 {
+    TetEarlyOut early;
+    bool with_early;
+    __device__ __forceinline__ void energy_and_gradient(double E, const double* g) const
+    {
+        if (with_early) early.store(E, g);
+    }
     double* stage;    // [9][64] of this wavefront
     double* Hwave;    // pool position of the wavefront's first element (pair 0)
     size_t hstride;   // doubles between pair pools
@@ -334,6 +376,8 @@ struct TetBlockStagedSink
 // element-major (stride 9 floats: conflict-free) and stored as three 16-byte-per-lane instructions.
 struct TetBlockFloatSink
 {
+    TetEarlyOut early;
+    __device__ __forceinline__ void energy_and_gradient(double E, const double* g) const { early.store(E, g); }
     float* stage;     // [64 * 9] of this wavefront
     float* Hwave;     // pool position of the wavefront's first element (pair 0); 16-byte aligned (pool stride is a multiple of 64 elements)
     size_t hstride;   // floats between pair pools
@@ -379,7 +423,7 @@ struct TetBlockFloatSink
 //         projection round selected: a.elem_list = that list, pools indexed by list position)
 constexpr int TET_PG = 0, TET_PGH = 1, TET_PGH_F = 2, TET_H_LIST = 3;
 template <class En, bool FULL, int MODE>
-__global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, float* __restrict__ elemHf, double* __restrict__ grad)
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(2))) void k_eval_tet_closed(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, float* __restrict__ elemHf, double* __restrict__ grad)
 {
     __shared__ double stage[MODE == TET_PG ? 1 : (BLOCK / 64) * 9 * 64];
     const int le = blockIdx.x * BLOCK + threadIdx.x;
@@ -392,36 +436,16 @@ __global__ __launch_bounds__(BLOCK) void k_eval_tet_closed(PotArgs a, double* __
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int le_wave = le - lane;
     const int pe_wave = pool_of(a, le_wave);
+    const TetEarlyOut early{&a, elemE, grad, e, le, valid};
     if (MODE == TET_PGH || MODE == TET_H_LIST) {
-        TetBlockStagedSink sink{stage + wave * 9 * 64, elemH + (size_t)pe_wave * 9, (size_t)a.n_pool * 9, lane, min(64, a.e_count - le_wave)};
+        TetBlockStagedSink sink{early, MODE == TET_PGH, stage + wave * 9 * 64, elemH + (size_t)pe_wave * 9, (size_t)a.n_pool * 9, lane, min(64, a.e_count - le_wave)};
         tet_closed_eval_to<FULL>(in, E, g, sink, true);
     } else if (MODE == TET_PGH_F) {
-        TetBlockFloatSink sink{reinterpret_cast<float*>(stage) + wave * 9 * 64, elemHf + (size_t)pe_wave * ((a.dbg & 4) ? 90 : 9), (size_t)a.n_pool * 9, lane, min(64, a.e_count - le_wave), a.dbg};
+        TetBlockFloatSink sink{early, reinterpret_cast<float*>(stage) + wave * 9 * 64, elemHf + (size_t)pe_wave * ((a.dbg & 4) ? 90 : 9), (size_t)a.n_pool * 9, lane, min(64, a.e_count - le_wave), a.dbg};
         tet_closed_eval_to<FULL>(in, E, g, sink, true);
     } else {
         tet_closed_eval<FULL>(in, E, g, nullptr, 0, false);
-    }
-    if (!valid || MODE == TET_H_LIST) return;
-    elemE[pool_of(a, le)] = energy_here(a, e) ? E : 0.0;
-    if (a.dbg & 1) return;  // measurement switch: no gradient output
-    if (a.gpool) {  // node gradients to the pool, summed per block row by k_grad_gather (no atomics)
-        const int pe = pool_of(a, le);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            double* gp = a.gpool + ((size_t)k * a.n_gpool + pe) * 3;
-            gp[0] = g[3 * k];
-            gp[1] = g[3 * k + 1];
-            gp[2] = g[3 * k + 2];
-        }
-        return;
-    }
-    const int32_t* ce = a.conn + (size_t)e * a.conn_stride;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const size_t row = (size_t)(a.dof_row_off[k] + ce[a.dof_col[k]]);
-        atomicAdd(&grad[3 * row], g[3 * k]);
-        atomicAdd(&grad[3 * row + 1], g[3 * k + 1]);
-        atomicAdd(&grad[3 * row + 2], g[3 * k + 2]);
+        early.store(E, g);
     }
 }
 // Membrane triangles through their invariants (tri_closed.hpp): one lane per triangle, six hyper-dual evaluations of psi(C) instead of 45 of

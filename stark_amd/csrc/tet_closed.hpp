@@ -91,7 +91,7 @@ MS_HD void tet_closed_eval_to(const double* in, double& E_out, double* g, Sink& 
     // phi(E): damping + strain limiting
     double T[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};  // dphi/dE
     double G[3][3], D[3][3];
-    double kap1 = 0.0, kap2 = 0.0, kap3 = 0.0, kap4 = 0.0;
+    double kap1 = 0.0, kap2 = 0.0, kap3 = 0.0, kap4 = 0.0, gam_n = 0.0;
     bool limiting = false;
     if (FULL) {
         double E1[3][3], E0[3][3];
@@ -137,30 +137,26 @@ MS_HD void tet_closed_eval_to(const double* in, double& E_out, double* g, Sink& 
             kap2 = 2.0 * sl_k * dl;
             kap3 = sl_k * dl * dl * gam * in_;
             kap4 = kap3 * in_ * in_;
+            gam_n = gam * in_;
             kap1 += kap3;
         }
     }
     E_out = vol * psi;
 
     // per-node vectors
-    double fa[4][3], ca[4][3], ta[4][3], ga[4][3], da[4][3];
+    double fa[4][3], ca[4][3], ta[4][3], da[4][3];
     for (int a = 0; a < 4; a++)
         for (int i = 0; i < 3; i++) {
             fa[a][i] = F[i][0] * w[a][0] + F[i][1] * w[a][1] + F[i][2] * w[a][2];
             ca[a][i] = C[i][0] * w[a][0] + C[i][1] * w[a][1] + C[i][2] * w[a][2];
             if (FULL) ta[a][i] = T[i][0] * w[a][0] + T[i][1] * w[a][1] + T[i][2] * w[a][2];
         }
+    // strain limiting: d_a = F D w_a; g_a = F G w_a = f_a / 3 + (gam / n) d_a is formed per block from f_a and d_a (G = I / 3 + gam D / n)
     if (FULL && limiting) {
         for (int a = 0; a < 4; a++) {
-            double gw[3], dw[3];
-            for (int i = 0; i < 3; i++) {
-                gw[i] = G[i][0] * w[a][0] + G[i][1] * w[a][1] + G[i][2] * w[a][2];
-                dw[i] = D[i][0] * w[a][0] + D[i][1] * w[a][1] + D[i][2] * w[a][2];
-            }
-            for (int i = 0; i < 3; i++) {
-                ga[a][i] = F[i][0] * gw[0] + F[i][1] * gw[1] + F[i][2] * gw[2];
-                da[a][i] = F[i][0] * dw[0] + F[i][1] * dw[1] + F[i][2] * dw[2];
-            }
+            double dw[3];
+            for (int i = 0; i < 3; i++) dw[i] = D[i][0] * w[a][0] + D[i][1] * w[a][1] + D[i][2] * w[a][2];
+            for (int i = 0; i < 3; i++) da[a][i] = F[i][0] * dw[0] + F[i][1] * dw[1] + F[i][2] * dw[2];
         }
     }
     // gradient: g_a = V dt (P w_a),  P w_a = c1 F w_a + c3 C w_a + F (T w_a)
@@ -172,12 +168,13 @@ MS_HD void tet_closed_eval_to(const double* in, double& E_out, double* g, Sink& 
             g[3 * a + i] = sg * v;
         }
     if (!want_h) return;
+    sink.energy_and_gradient(E_out, g);  // (a sink that stores them here frees their registers for the block loop)
 
     double FFt[3][3];
     if (FULL)
         for (int i = 0; i < 3; i++)
             for (int k = 0; k < 3; k++) FFt[i][k] = F[i][0] * F[k][0] + F[i][1] * F[k][1] + F[i][2] * F[k][2];
-    const double sh = vol * dt * dt;
+    const double sh = vol * dt * dt, third = 1.0 / 3.0;
     for (int a = 0; a < 4; a++)
         for (int b = a; b < 4; b++) {
             const double wab = w[a][0] * w[b][0] + w[a][1] * w[b][1] + w[a][2] * w[b][2];
@@ -193,7 +190,7 @@ MS_HD void tet_closed_eval_to(const double* in, double& E_out, double* g, Sink& 
                     double v = c2 * fa[a][i] * fa[b][k] + lambda_ * ca[a][i] * ca[b][k];
                     if (FULL) {
                         v += 0.5 * kap1 * (FFt[i][k] * wab + fa[b][i] * fa[a][k]);
-                        if (limiting) v += kap2 * ga[a][i] * ga[b][k] - (kap3 / 3.0) * fa[a][i] * fa[b][k] - kap4 * da[a][i] * da[b][k];
+                        if (limiting) v += kap2 * (third * fa[a][i] + gam_n * da[a][i]) * (third * fa[b][k] + gam_n * da[b][k]) - (kap3 / 3.0) * fa[a][i] * fa[b][k] - kap4 * da[a][i] * da[b][k];
                     }
                     M[i][k] = v;
                 }
@@ -218,6 +215,7 @@ struct TetBlockMemSink
 {
     double* H;
     size_t hstride;
+    MS_HD void energy_and_gradient(double, const double*) {}
     MS_HD void put(int a, int b, const double* blk)
     {
         double* Hab = H + (size_t)(a * 4 + b) * hstride;
