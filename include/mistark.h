@@ -346,7 +346,8 @@ int mistark_sync(mistark_ctx* ctx);
 /* Event counters of the context, by name (tests assert that a feature under test actually ran): "proj_speculated" / "proj_adopted" (projection
  * rounds started beside a solve / taken over by the retry, option proj_speculation), "dof_skips_verified" (MISTARK_VERIFY_DOF_SKIP=1: DoF
  * transfers skipped at an unchanged iterate and checked against a real transfer), "fused_solves" / "unfused_solves" (sharded PCG),
- * "rtc_builds" / "rtc_launches" / "rtc_build_ms" (user-defined potentials: kernels emitted and compiled by hipRTC, their launches, build time). */
+ * "rtc_builds" / "rtc_launches" / "rtc_build_ms" (user-defined potentials: kernels emitted and compiled by hipRTC, their launches, build time),
+ * "multi_pgh_launches" (evaluations whose contact / friction tables shared one launch; option no_multi_eval_pgh = 1: one launch per table). */
 int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out);
 
 /* ---- multi-GPU: one problem sharded over `world` ranks, one engine context (and one process) per GPU ------------------------

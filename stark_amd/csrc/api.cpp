@@ -550,6 +550,7 @@ int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out)
     const std::string n = name;
     if (n == "proj_speculated") *out = c.n_proj_speculated;
     else if (n == "proj_adopted") *out = c.n_proj_adopted;
+    else if (n == "multi_pgh_launches") *out = c.n_multi_pgh;
     else if (n == "dof_skips_verified") *out = c.n_dof_skips_verified;
     else if (n == "rtc_builds") *out = c.n_rtc_builds;
     else if (n == "custom_kernel_us") *out = (int64_t)c.custom_kernel_us;
@@ -1222,6 +1223,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "generic_contact") ctx->c.generic_contact = value != 0;
     else if (n == "no_eval_prelaunch") ctx->c.no_eval_prelaunch = value != 0;
     else if (n == "no_multi_eval_p") ctx->c.no_multi_eval_p = value != 0;
+    else if (n == "no_multi_eval_pgh") ctx->c.no_multi_eval_pgh = value != 0;
     else if (n == "llt_multifrontal") ctx->c.llt_multifrontal = value;
     else if (n == "llt_no_coords") { ctx->c.llt_no_coords = value != 0; ctx->c.llt_mf_pattern_version = 0; }
     else if (n == "pcg_holdback") ctx->c.pcg_holdback = value != 0;

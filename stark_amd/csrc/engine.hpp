@@ -421,6 +421,10 @@ struct Context
     bool no_multi_eval_p = false;
     std::vector<char> multi_p_sent;
     DevBuf<char> multi_p_dev;
+    bool no_multi_eval_pgh = false;  // option: every contact / friction table in a launch of its own (k_eval_pgh) instead of one shared launch (k_eval_pgh_multi)
+    std::vector<char> multi_h_sent;
+    DevBuf<char> multi_h_dev;
+    int64_t n_multi_pgh = 0;         // counter "multi_pgh_launches"
     int64_t n_prelaunch_used = 0, n_prelaunch_dropped = 0;
     // anything that changes what kernels read (arrays, DoFs, tables registered by the caller): contact detection caches and a prelaunched
     // evaluation are void

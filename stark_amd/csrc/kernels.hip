@@ -144,10 +144,9 @@ __global__ __launch_bounds__(BLOCK) void k_eval_p_multi(const MultiP* __restrict
 // Element Hessians are stored per potential as H[a*NB+b][e][3][3]: one 72-byte row-major 3x3 block per (block pair, element);
 // consecutive elements are contiguous (coalescing-friendly stores) and assembly gathers whole 72-byte blocks.
 template <class En, bool STORE_H>
-__global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
+__device__ __forceinline__ void eval_pgh_body(const PotArgs& a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad, long long t, int hot_way)
 {
     constexpr int NB = En::NB, n = 3 * NB, NP = n * (n + 1) / 2;
-    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= (long long)a.e_count * NP) return;
     const int le = (int)(t / NP);
     const int e = elem_of(a, le), pe = pool_of(a, le);
@@ -174,10 +173,47 @@ __global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restric
         a.gpool[((size_t)ba * a.n_gpool + pe) * 3 + ii] = on ? r.a : 0.0;
     } else if (i == j && on) {
         const int node = a.conn[(size_t)e * a.conn_stride + a.dof_col[ba]];
-        if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);
+        if (a.hot_base[ba] >= 0) atomicAdd(&a.grad_hot[((size_t)hot_way * a.n_hot + a.hot_base[ba] + node) * 3 + ii], r.a);
         else atomicAdd(&grad[3 * (size_t)(a.dof_row_off[ba] + node) + ii], r.a);
     }
     if (first) elemE[pe] = energy_here(a, e) ? r.v : 0.0;
+}
+template <class En, bool STORE_H>
+__global__ __launch_bounds__(BLOCK) void k_eval_pgh(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
+{
+    eval_pgh_body<En, STORE_H>(a, elemE, elemH, grad, (long long)blockIdx.x * BLOCK + threadIdx.x, (int)(blockIdx.x & (HOT_WAYS - 1)));
+}
+// Energy, gradient and Hessian of ALL contact and friction tables of an evaluation in one launch (configs[3]: seven tables of a few hundred rows,
+// 11-22 us each — latency of one dependent hyper-dual chain — one after the other on the auxiliary stream: 112 us, the longer leg of the
+// evaluation once the tet kernel runs at two waves per SIMD). The workgroup index picks the table, as in k_eval_p_multi. Only tables: their node
+// gradients go to pools (dyn_grad_gather sums them in sorted order), so nothing here adds to a row another table adds to.
+struct MultiPGH
+{
+    PotArgs a;
+    double* E;
+    double* H;
+    int kind, pad;
+};
+constexpr int FIRST_CONTACT_KIND = 0
+#define X(En) +1
+    MISTARK_FOR_EACH_ENERGY(X) - (0 MISTARK_FOR_EACH_CONTACT_ENERGY(X));
+#undef X
+__global__ __launch_bounds__(BLOCK) void k_eval_pgh_multi(const MultiPGH* __restrict__ descs, MultiFirst first, double* __restrict__ grad)
+{
+    int d = 0;
+    while (d + 1 < first.n && (int)blockIdx.x >= first.b[d + 1]) d++;
+    const MultiPGH& D = descs[d];
+    const int lb = (int)blockIdx.x - first.b[d];
+    const long long t = (long long)lb * BLOCK + threadIdx.x;
+    int k = FIRST_CONTACT_KIND;
+#define X(En)                                                                       \
+    if (D.kind == k) {                                                              \
+        eval_pgh_body<En, true>(D.a, D.E, D.H, grad, t, lb & (HOT_WAYS - 1));       \
+        return;                                                                     \
+    }                                                                               \
+    k++;
+    MISTARK_FOR_EACH_CONTACT_ENERGY(X)
+#undef X
 }
 // hot rows: the HOT_WAYS partial sums in fixed order, added to what the in-place accumulating kernels (closed-form tets) left there
 __global__ __launch_bounds__(BLOCK) void k_fold_hot(const double* __restrict__ grad_hot, const int32_t* __restrict__ hot_rows, int n_hot, double* __restrict__ grad)
@@ -806,6 +842,22 @@ static void launch_eval(Context& c, Potential& P, int mode)
     if (mode != MISTARK_EVAL_P) launch_grad_gather(c, P);
 }
 
+// a contact / friction table that eval() may put into the shared launch (k_eval_pgh_multi): generic kernel, Hessian wanted; *np = lanes per row
+static bool joins_multi_pgh(const Context& c, const Potential& P, int* np)
+{
+    if (P.kind < FIRST_CONTACT_KIND) return false;
+    int k = FIRST_CONTACT_KIND;
+#define X(En)                                                                                                                      \
+    if (P.kind == k) {                                                                                                             \
+        constexpr int n = 3 * En::NB;                                                                                              \
+        *np = n * (n + 1) / 2;                                                                                                     \
+        return !(has_closed_contact<En> && !c.force_generic && !c.generic_contact && closed_contact_pays<En>(c, P.n_elem));       \
+    }                                                                                                                              \
+    k++;
+    MISTARK_FOR_EACH_CONTACT_ENERGY(X)
+#undef X
+    return false;
+}
 static void launch_eval_kind(Context& c, Potential& P, int mode)
 {
     if (P.kind == KIND_CUSTOM) {  // no compiled kernel under this name: the caller supplied the expression (custom.hip)
@@ -2127,7 +2179,32 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         mf.n = 0;
         int multi_blocks = 0;
         const bool batch_p = mode == MISTARK_EVAL_P && c.world == 1 && !c.no_multi_eval_p && !c.kernel_dbg;
+        // energy + gradient + Hessian: the contact and friction tables share one launch (k_eval_pgh_multi)
+        std::vector<MultiPGH> multi_h;
+        MultiFirst mfh;
+        mfh.n = 0;
+        int multi_h_blocks = 0;
+        const bool batch_h = mode == MISTARK_EVAL_P_G_H && c.world == 1 && !c.no_multi_eval_pgh && !c.kernel_dbg;
+        hipStream_t multi_h_stream = main_stream;
+        double* multi_h_grad = grad_main;
         for (auto& P : c.pots) {
+            int np = 0;
+            if (batch_h && P.dyn_pool && P.n_elem < EVAL_SMALL_POTENTIAL && mfh.n < MULTI_P_MAX && joins_multi_pgh(c, P, &np)) {
+                if (P.args.e_count == 0) continue;
+                MultiPGH m;
+                std::memset(&m, 0, sizeof(m));
+                m.a = P.args;
+                m.E = c.elemE.p + P.e_off;
+                m.H = c.elemH.p + P.h_off;
+                m.kind = P.kind;
+                multi_h.push_back(m);
+                mfh.b[mfh.n++] = multi_h_blocks;
+                multi_h_blocks += grid_for((int64_t)P.args.e_count * np);
+                const bool aux = split && P.n_elem < small;
+                multi_h_stream = aux ? c.aux_stream : main_stream;
+                multi_h_grad = aux ? c.grad_aux.p : grad_main;
+                continue;
+            }
             if (batch_p && P.kind != KIND_CUSTOM && P.kind >= 0 && P.n_elem < EVAL_SMALL_POTENTIAL && mf.n < MULTI_P_MAX) {
                 if (P.args.e_count == 0) continue;
                 MultiP m;
@@ -2166,6 +2243,18 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
                 if (taken) continue;
             }
             launch_eval_kind(c, P, mode);
+        }
+        if (mfh.n > 0) {
+            mfh.b[mfh.n] = multi_h_blocks;
+            const size_t bytes = multi_h.size() * sizeof(MultiPGH);
+            c.multi_h_dev.ensure(bytes);
+            if (c.multi_h_sent.size() != bytes || std::memcmp(c.multi_h_sent.data(), multi_h.data(), bytes) != 0) {
+                c.stream = multi_h_stream;
+                h2d_small(c, c.multi_h_dev.p, multi_h.data(), bytes);  // (through a pinned slot, on the stream of the launch below)
+                c.multi_h_sent.assign((const char*)multi_h.data(), (const char*)multi_h.data() + bytes);
+            }
+            hipLaunchKernelGGL(k_eval_pgh_multi, dim3(multi_h_blocks), dim3(BLOCK), 0, multi_h_stream, (const MultiPGH*)c.multi_h_dev.p, mfh, multi_h_grad);
+            c.n_multi_pgh++;
         }
         if (mf.n > 0) {
             c.stream = main_stream;

@@ -258,7 +258,9 @@ def test_cloth_on_box_contact_trajectory(closed_forms, monkeypatch):
                                           # every contact / friction table through the closed-form kernels (contact_closed.hpp; by default only
                                           # tables long enough to pay), and the evaluation not started ahead of the contact callback
                                           ("traj_cfg3_blockbox_10", "contact_closed_min_lanes"), ("traj_blockbox_3", "contact_closed_min_lanes"),
-                                          ("traj_cfg3_blockbox_10", "no_eval_prelaunch"), ("traj_cfg3_blockbox_10", "no_multi_eval_p")])
+                                          ("traj_cfg3_blockbox_10", "no_eval_prelaunch"), ("traj_cfg3_blockbox_10", "no_multi_eval_p"),
+                                          # every contact / friction table in a launch of its own instead of the shared one (k_eval_pgh_multi)
+                                          ("traj_cfg3_blockbox_10", "no_multi_eval_pgh")])
 def test_block_on_box_contact_trajectory(name, options, monkeypatch):
     """configs[3] at fixture size (and at 12 k tets): Soft_Rubber tet block landing on a fixed rigid box (collision surface from
     find_surface), with friction (box registered first) and without (block first)."""
@@ -294,6 +296,13 @@ def test_block_on_box_contact_trajectory(name, options, monkeypatch):
         # integrate freely (observed 2e-4 m lateral vs 2.5e-5 m vertical after 6 steps) and convergence tests sit on the threshold
         _run_and_compare(sim, z, traj, tol=1e-3, its_slack=2)
     assert sim.contact_info()["n_contacts"] > 0
+    if name == "traj_cfg3_blockbox_10":  # (the tables' shared launch ran unless it was switched off: the parametrisation compares the two ways)
+        from stark_amd import capi
+        import ctypes as C
+        v = C.c_int64()
+        assert capi.lib().mistark_get_counter(sim.engine_handle(), b"multi_pgh_launches", C.byref(v)) == 0
+        # (contact_closed_min_lanes = 1 sends every table through its closed-form kernel: nothing is left for the shared launch)
+        assert (v.value == 0) == (options in ("no_multi_eval_pgh", "contact_closed_min_lanes")), (options, v.value)
     sim.close()
 
 
