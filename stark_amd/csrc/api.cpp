@@ -1224,6 +1224,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "no_eval_prelaunch") ctx->c.no_eval_prelaunch = value != 0;
     else if (n == "no_multi_eval_p") ctx->c.no_multi_eval_p = value != 0;
     else if (n == "no_multi_eval_pgh") ctx->c.no_multi_eval_pgh = value != 0;
+    else if (n == "late_eager_assembly") ctx->c.late_eager_assembly = value != 0;
     else if (n == "llt_multifrontal") ctx->c.llt_multifrontal = value;
     else if (n == "llt_no_coords") { ctx->c.llt_no_coords = value != 0; ctx->c.llt_mf_pattern_version = 0; }
     else if (n == "pcg_holdback") ctx->c.pcg_holdback = value != 0;

@@ -421,6 +421,7 @@ struct Context
     bool no_multi_eval_p = false;
     std::vector<char> multi_p_sent;
     DevBuf<char> multi_p_dev;
+    bool late_eager_assembly = false;  // option (measurement): the static part's gather queued behind the gradient gathers and the join, as through round 4
     bool no_multi_eval_pgh = false;  // option: every contact / friction table in a launch of its own (k_eval_pgh) instead of one shared launch (k_eval_pgh_multi)
     std::vector<char> multi_h_sent;
     DevBuf<char> multi_h_dev;

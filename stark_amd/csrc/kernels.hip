@@ -2168,6 +2168,34 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         fill_async(c.aux_stream, c.grad_aux.p, 0, (size_t)c.ndofs * sizeof(double));
     }
     double* const grad_main = c.grad.p;
+    // The static part of the matrix can be gathered as soon as the element Hessians are there: on the auxiliary stream, behind its small
+    // potentials, beside this stream's gradient gathers, reductions and the read-back the Newton loop takes its convergence decision from.
+    // assemble() then waits for it and only adds the contact part. (Not for staged calls: their projection may run before the assembly.)
+    // The event it waits for is recorded behind the LAST ELEMENT KERNEL of this stream, in front of the tets' gradient gathers (round 5: it used to
+    // sit behind every gradient gather and the join, and 150-180 us of the 275 us gather ended up in front of the linear solve).
+    c.static_assembled = false;
+    const bool eager_asm = split && mode == MISTARK_EVAL_P_G_H && lazy && !c.atomic_assembly && !c.no_eager_assembly && !c.part[0].dirty && c.part[0].nnzb > 0;
+    const bool early_asm = eager_asm && !c.late_eager_assembly;
+    std::vector<Potential*> deferred_gathers;
+    auto static_assembly = [&]() {
+        if (!c.aux_ev[2]) {
+            MS_CHECK(hipEventCreateWithFlags(&c.aux_ev[2], hipEventDisableTiming));
+            MS_CHECK(hipEventCreateWithFlags(&c.aux_ev[3], hipEventDisableTiming));
+        }
+        MS_CHECK(hipEventRecord(c.aux_ev[3], main_stream));  // (every element kernel of this stream is in its queue; the auxiliary stream's own are in front of the gather)
+        MS_CHECK(hipStreamWaitEvent(c.aux_stream, c.aux_ev[3], 0));
+        c.have_hessians = true;
+        c.stream = c.aux_stream;
+        try {
+            assemble_part(c, 0);
+        } catch (...) {
+            c.stream = main_stream;
+            throw;
+        }
+        c.stream = main_stream;
+        MS_CHECK(hipEventRecord(c.aux_ev[2], c.aux_stream));
+        c.static_assembled = true;
+    };
     try {
         // "small" = below EVAL_SMALL_POTENTIAL elements, or below a quarter of the largest potential (a million tets hide 172 k inertia nodes, too)
         int64_t n_max = 0;
@@ -2235,12 +2263,20 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
                         if (mode != MISTARK_EVAL_P)  // the energies it wrote aside (the line search's energy evaluation summed elemE meanwhile)
                             copy_async(c.stream, c.elemE.p + P.e_off, c.elemE_pre.p + P.e_off, (size_t)P.args.e_count * sizeof(double));
                         if (mode == MISTARK_EVAL_P) {
-                        } else if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, false, true);
+                        } else if (early_asm) deferred_gathers.push_back(&P);
+                        else if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, false, true);
                         else launch_tet_closed<E_TetStrainEO, false>(c, P, mode, false, true);
                         taken = true;
                         c.n_prelaunch_used++;
                     }
                 if (taken) continue;
+            }
+            if (early_asm && !aux && !c.force_generic && P.kind != KIND_CUSTOM && (P.name == E_TetStrain::name || P.name == E_TetStrainEO::name)) {
+                // the kernel now, its gradient gather behind the event the static assembly waits for (below)
+                if (P.name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, P, mode, true);
+                else launch_tet_closed<E_TetStrainEO, false>(c, P, mode, true);
+                deferred_gathers.push_back(&P);
+                continue;
             }
             launch_eval_kind(c, P, mode);
         }
@@ -2275,36 +2311,21 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
     }
     c.stream = main_stream;
     c.grad.p = grad_main;
+    if (split) MS_CHECK(hipEventRecord(c.aux_ev[1], c.aux_stream));  // (the join below waits for the small potentials, not for the gather queued behind them)
+    if (early_asm) {
+        static_assembly();
+        for (Potential* P : deferred_gathers) {
+            if (P->name == E_TetStrain::name) launch_tet_closed<E_TetStrain, true>(c, *P, mode, false, true);
+            else launch_tet_closed<E_TetStrainEO, false>(c, *P, mode, false, true);
+        }
+    }
     if (split) {
-        MS_CHECK(hipEventRecord(c.aux_ev[1], c.aux_stream));
         MS_CHECK(hipStreamWaitEvent(main_stream, c.aux_ev[1], 0));
         vec_axpby(c, c.grad.p, 1.0, c.grad.p, 1.0, c.grad_aux.p, c.ndofs);
     }
     // the device-resident tables' node gradients (contact, friction), row by row in sorted order: behind everything else, one addition per row
     if (mode != MISTARK_EVAL_P && !(c.kernel_dbg & 1)) dyn_grad_gather(c, c.grad.p);
-    // The static part of the matrix can be gathered as soon as the element Hessians are there: on the auxiliary stream (idle by now),
-    // beside this stream's gradient gather, reductions and the read-back the Newton loop takes its convergence decision from. assemble()
-    // then waits for it and only adds the contact part. (Not for staged calls: their projection may run before the assembly.)
-    c.static_assembled = false;
-    if (split && mode == MISTARK_EVAL_P_G_H && lazy && !c.atomic_assembly && !c.no_eager_assembly && !c.part[0].dirty && c.part[0].nnzb > 0) {
-        if (!c.aux_ev[2]) {
-            MS_CHECK(hipEventCreateWithFlags(&c.aux_ev[2], hipEventDisableTiming));
-            MS_CHECK(hipEventCreateWithFlags(&c.aux_ev[3], hipEventDisableTiming));
-        }
-        MS_CHECK(hipEventRecord(c.aux_ev[3], main_stream));  // (every element kernel is in this stream's queue, or joined into it)
-        MS_CHECK(hipStreamWaitEvent(c.aux_stream, c.aux_ev[3], 0));
-        c.have_hessians = true;
-        c.stream = c.aux_stream;
-        try {
-            assemble_part(c, 0);
-        } catch (...) {
-            c.stream = main_stream;
-            throw;
-        }
-        c.stream = main_stream;
-        MS_CHECK(hipEventRecord(c.aux_ev[2], c.aux_stream));
-        c.static_assembled = true;
-    }
+    if (eager_asm && !early_asm) static_assembly();  // (option late_eager_assembly: where it sat through round 4, for A/B runs)
     // (the contact part's pattern ends in a read-back of its counts, for which the host waits: the energy / residual reductions of THIS stream
     // are queued first where they do not depend on it, so that they run while the host waits — see with_max below)
     bool pattern_pending = overlap_pattern;
