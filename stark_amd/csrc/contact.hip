@@ -1095,6 +1095,11 @@ struct ContactSystem
     int shard_k = 0;
     DevBuf<double> shard_send, shard_recv;
     int64_t n_sharded_searches = 0;
+    // barrier-table searches that ran / that ran at the very state (Context::data_version, dt) the previous one had searched (counter
+    // "contact_repeated_searches": 0 since the cache is refreshed by a search that finds the installed tables unchanged)
+    int64_t n_searches = 0, n_repeated_searches = 0;
+    uint64_t searched_version = 0;
+    double searched_dt = -1.0;
 
     DevBuf<int32_t> cv_src, cv_mesh, tri, tri_mesh, edge, edge_mesh, mesh_kind, mesh_idx;
     DevBuf<uint8_t> disabled;
@@ -1163,6 +1168,7 @@ struct ContactSystem
 // sharded runs: the block rows contact potentials may reference (the collision vertices of the deformable meshes; rigid bodies are small DoF
 // sets, shared anyway). Every rank keeps them as ghosts (shard.hip).
 int64_t contact_sharded_searches(const Context& c) { return c.contact ? c.contact->n_sharded_searches : 0; }
+int64_t contact_searches(const Context& c, bool repeated) { return !c.contact ? 0 : (repeated ? c.contact->n_repeated_searches : c.contact->n_searches); }
 void contact_shared_rows(Context& c, std::vector<int32_t>& rows)
 {
     if (!c.contact) return;
@@ -1562,8 +1568,16 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
 {
     ContactSystem& cs = CS(c);
     if (cs.meshes.empty()) return 0;
+    static const bool trace = getenv("MISTARK_CONTACT_TRACE") != nullptr;
+    if (trace)
+        std::fprintf(stderr, "[contact] detect fr=%d cache_valid=%d layout_dirty=%d cache_v=%llu data_v=%llu bp_v=%llu dt_same=%d\n", (int)friction, (int)cs.cache_valid, (int)c.layout_dirty,
+                     (unsigned long long)cs.cache_version, (unsigned long long)c.data_version, (unsigned long long)cs.bp_version, (int)(cs.cache_dt == dt));
     if (friction) cs.cache_valid = false;
     else if (cs.cache_valid && !c.no_contact_cache && !c.layout_dirty && cs.cache_version == c.data_version && cs.cache_dt == dt) return cs.cache_n;
+    if (!friction) {
+        cs.n_searches++;
+        if (cs.searched_version == c.data_version && cs.searched_dt == dt && !c.no_contact_cache) cs.n_repeated_searches++;
+    }
     double tp = now_s();
     auto lap = [&](int k) {
         const double t = now_s();
@@ -1669,7 +1683,20 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
     cs.n_last = n;
     const int* bounds = h + 8;
     const bool unchanged = compare && n == cs.n_prev && h[2] == 0;
-    if (unchanged) return n;
+    if (trace) std::fprintf(stderr, "[contact]   searched: n=%d n_prev=%d differs=%d unchanged=%d speculated=%d\n", n, (int)cs.n_prev, h[2], (int)unchanged, (int)speculated);
+    if (unchanged) {
+        // the installed tables ARE this state's: the evaluation that opens the next Newton iteration asks again at the same state (round 5: the
+        // cache used to be refreshed only by an installation, and every search that found the tables unchanged was followed by a second one)
+        if (!friction) {
+            cs.cache_valid = true;
+            cs.cache_version = c.data_version;
+            cs.cache_dt = dt;
+            cs.cache_n = n;
+            cs.searched_version = c.data_version;
+            cs.searched_dt = dt;
+        }
+        return n;
+    }
     // install the new row counts; buffers are (re)allocated before the routing kernel writes them
     if (!cs.td_pinned) MS_CHECK(hipHostMalloc((void**)&cs.td_pinned, N_TABLES * sizeof(TableDev)));
     TableDev* td = cs.td_pinned;  // pinned: the upload below is truly asynchronous and needs no trailing synchronisation
@@ -1721,6 +1748,8 @@ int64_t detect_and_route(Context& c, double dt, bool friction)
         cs.cache_version = c.data_version;  // (after this function's own layout changes)
         cs.cache_dt = dt;
         cs.cache_n = n;
+        cs.searched_version = c.data_version;
+        cs.searched_dt = dt;
     }
     lap(6);
     return n;
@@ -1731,6 +1760,8 @@ int64_t count_intersections_uncached(Context& c, double dt);
 int64_t count_intersections(Context& c, double dt)
 {
     ContactSystem& cs = CS(c);
+    static const bool trace = getenv("MISTARK_CONTACT_TRACE") != nullptr;
+    if (trace) std::fprintf(stderr, "[contact] intersections: ix_valid=%d ix_v=%llu data_v=%llu bp_v=%llu\n", (int)cs.ix_valid, (unsigned long long)cs.ix_version, (unsigned long long)c.data_version, (unsigned long long)cs.bp_version);
     if (cs.ix_valid && !c.no_contact_cache && cs.ix_version == c.data_version && cs.ix_dt == dt) return cs.ix_n;
     const int64_t n = count_intersections_uncached(c, dt);
     cs.ix_valid = true;

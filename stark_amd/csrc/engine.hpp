@@ -598,6 +598,7 @@ void graph_partition_rows(int64_t n_block_rows, int world, const std::vector<Ele
 void static_graph_order(Context& c, std::vector<int32_t>& rows_in_order);  // shard.hip
 void ensure_pattern(Context& c);
 void contact_destroy(struct ContactSystem* cs);
+int64_t contact_searches(const Context& c, bool repeated);  // counters "contact_searches" / "contact_repeated_searches"
 int64_t contact_sharded_searches(const Context& c);  // searches of a sharded problem whose sweep was dealt out to the ranks (contact.hip)
 void contact_shared_rows(Context& c, std::vector<int32_t>& rows);  // contact.hip
 int register_potential(Context& c, const char* name, const int32_t* conn, int32_t n_elem, int32_t conn_stride, const mistark_binding* bindings, int32_t n_bindings);

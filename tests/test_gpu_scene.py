@@ -303,6 +303,16 @@ def test_block_on_box_contact_trajectory(name, options, monkeypatch):
         assert capi.lib().mistark_get_counter(sim.engine_handle(), b"multi_pgh_launches", C.byref(v)) == 0
         # (contact_closed_min_lanes = 1 sends every table through its closed-form kernel: nothing is left for the shared launch)
         assert (v.value == 0) == (options in ("no_multi_eval_pgh", "contact_closed_min_lanes")), (options, v.value)
+    # No barrier-table search runs twice at one state: a search that finds the installed tables unchanged answers the next request at the same
+    # state, too (round 5: it did not, and the evaluation opening a Newton iteration searched again behind every such line-search evaluation).
+    from stark_amd import capi as _capi
+    import ctypes as _C
+    ran, again = _C.c_int64(), _C.c_int64()
+    assert _capi.lib().mistark_get_counter(sim.engine_handle(), b"contact_searches", _C.byref(ran)) == 0
+    assert _capi.lib().mistark_get_counter(sim.engine_handle(), b"contact_repeated_searches", _C.byref(again)) == 0
+    assert ran.value > 0
+    if options != "no_contact_cache":
+        assert again.value == 0, (ran.value, again.value)
     sim.close()
 
 
