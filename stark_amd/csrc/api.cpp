@@ -558,6 +558,8 @@ int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out)
     else if (n == "rtc_build_ms") *out = (int64_t)(1e3 * c.t_rtc_builds);
     else if (n == "fused_solves") *out = c.n_fused_solves;
     else if (n == "unfused_solves") *out = c.n_unfused_solves;
+    else if (n == "eval_pgh_issue_us") *out = (int64_t)(1e6 * c.t_eval_issue);
+    else if (n == "eval_pgh_wait_us") *out = (int64_t)(1e6 * c.t_eval_wait);
     else if (n == "contact_searches") *out = contact_searches(c, false);
     else if (n == "contact_repeated_searches") *out = contact_searches(c, true);
     else throw Error("mistark_get_counter: unknown counter '" + n + "'");

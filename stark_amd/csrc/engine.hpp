@@ -356,6 +356,7 @@ struct Context
     size_t h_pin_bytes = 0;
     uint8_t* pub = nullptr;         // coherent pinned page small read-backs are published into (kernels.hip: publish)
     uint32_t pub_seq = 0;
+    double t_eval_issue = 0.0, t_eval_wait = 0.0;  // host seconds of eval(P+g+H): issuing launches / waiting for the read-backs (counters eval_pgh_issue_us, eval_pgh_wait_us)
     uint8_t* pub2 = nullptr;        // ... and a second one for a read-back left in flight while another runs (publish_begin2 / publish_end2)
     uint32_t pub2_seq = 0;
     // bumped by everything that can change what a contact detection sees (DoFs, bound arrays, layout): the detector skips a search whose

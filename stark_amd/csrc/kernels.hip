@@ -9,6 +9,8 @@
 //   PSD projection       : per-element cyclic Jacobi eigen-decomposition; sharded runs exchange the matrix deltas
 
 
+#include <chrono>
+
 #include "kernels_common.hpp"
 #include "registry.hpp"
 #include "tet_closed.hpp"
@@ -2113,8 +2115,10 @@ void eval_prelaunch(Context& c, int mode, bool lazy)
     pre.mode = mode;
     pre.lazy_active = lazy_active;
 }
+static double host_now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_abs, bool lazy)
 {
+    const double t_enter = host_now_s();  // (counters eval_pgh_issue_us / eval_pgh_wait_us: where an evaluation's wall time goes on the host)
     prepare(c);
     if (mode == MISTARK_EVAL_P_G_H) {
         // lazy: float upper-triangle blocks for the potentials that can recompute their double blocks on demand (Potential::lazy_capable)
@@ -2365,8 +2369,13 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         // the partial sums leave the device BEFORE this stream is made to wait for the pattern chain (the publish kernel is queued behind the
         // reductions; the host picks the numbers up after the pattern's own read-back)
         const bool published = fetch_partials_begin(c, g1 + g2, c.partials.p);
+        const double t_issued = host_now_s();
         run_pattern();
         fetch_partials_end(c, g1 + g2, h, c.partials.p, published);
+        if (mode == MISTARK_EVAL_P_G_H) {
+            c.t_eval_issue += t_issued - t_enter;
+            c.t_eval_wait += host_now_s() - t_issued;
+        }
         double m = 0.0;
         for (int i = 0; i < g1; i++) e += h[i];
         for (int i = 0; i < g2; i++) m = std::max(m, h[g1 + i]);
