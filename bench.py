@@ -686,6 +686,14 @@ def main():
     info = sim.info()
     stage = {k: getattr(info, "total_" + k + "_time") - getattr(info0, "total_" + k + "_time") for k in ["newton", "linear_solve", "eval_pgh", "eval_p", "project", "assembly", "callback", "step"]}
     contact_info = sim.contact_info() if a.scene == "contact" else None
+    if contact_info is not None:
+        # barrier-table searches that ran on the device (requests answered from the installed tables are not counted) and how many of them ran at
+        # the very state the previous one had searched (0 since round 5: DESIGN.md section 8, "A search that found the tables unchanged was run twice")
+        import ctypes as _C3
+        for key in ("contact_searches", "contact_repeated_searches"):
+            v = _C3.c_int64()
+            if capi.lib().mistark_get_counter(sim.engine_handle(), key.encode(), _C3.byref(v)) == 0:
+                contact_info[key + "_since_start"] = int(v.value)
     if world > 1 and ranks_seen is not None:
         import ctypes as _Cd2
         di2 = (_Cd2.c_int64 * 13)()

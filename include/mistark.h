@@ -347,7 +347,10 @@ int mistark_sync(mistark_ctx* ctx);
  * rounds started beside a solve / taken over by the retry, option proj_speculation), "dof_skips_verified" (MISTARK_VERIFY_DOF_SKIP=1: DoF
  * transfers skipped at an unchanged iterate and checked against a real transfer), "fused_solves" / "unfused_solves" (sharded PCG),
  * "rtc_builds" / "rtc_launches" / "rtc_build_ms" (user-defined potentials: kernels emitted and compiled by hipRTC, their launches, build time),
- * "multi_pgh_launches" (evaluations whose contact / friction tables shared one launch; option no_multi_eval_pgh = 1: one launch per table). */
+ * "multi_pgh_launches" (evaluations whose contact / friction tables shared one launch; option no_multi_eval_pgh = 1: one launch per table),
+ * "contact_searches" / "contact_repeated_searches" (barrier-table searches that ran on the device / that ran at the state the previous one had
+ * searched: 0 unless the option no_contact_cache is set), "eval_pgh_issue_us" / "eval_pgh_wait_us" (host microseconds of the P+g+H evaluations:
+ * issuing their launches / waiting for their read-backs). */
 int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out);
 
 /* ---- multi-GPU: one problem sharded over `world` ranks, one engine context (and one process) per GPU ------------------------
