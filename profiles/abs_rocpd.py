@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
 """One Newton iteration with ABSOLUTE times: start and end of every dispatch in microseconds from the iteration's first kernel, and the HSA queue
 it ran on (the engine's streams: main, auxiliary, early evaluation, pattern side stream), PCG launches collapsed per solve.
-usage: python profiles/abs_rocpd.py <db> [which]"""
+usage: [ABS_MARK=<kernel name part>] python profiles/abs_rocpd.py <db> [which]"""
 import sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
 rows = list(db.execute("select name, start, end%s from kernels order by start" % ((", " + qcol) if qcol else ", 0")))
 def sh(x): return x.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("mistark::", "")[:56] or "<unnamed>"
-marks = [i for i, r in enumerate(rows) if "k_eval_tet" in r[0] and ", true" in r[0].split("(")[0]]
+import os
+mark = os.environ.get("ABS_MARK")  # (another scene: the kernel that opens a unit, e.g. ABS_MARK="k_sweep<true, true>" = the friction search of a time step)
+marks = [i for i, r in enumerate(rows) if (mark in r[0] if mark else ("k_eval_tet" in r[0] and ", true" in r[0].split("(")[0]))]
 w = int(sys.argv[2]) if len(sys.argv) > 2 else len(marks) // 2
 a, b = marks[w], marks[w + 1]
 t0 = rows[a][1]
