@@ -1252,6 +1252,8 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "no_eval_overlap") ctx->c.no_eval_overlap = value != 0;
     else if (n == "contact_speculation") ctx->c.contact_speculation = value != 0;
     else if (n == "no_eager_assembly") ctx->c.no_eager_assembly = value != 0;
+    else if (n == "no_sym_gather") ctx->c.no_sym_gather = value != 0;
+    else if (n == "no_split_gather") ctx->c.no_split_gather = value != 0;
     else if (n == "no_bounded_pattern") { ctx->c.no_bounded_pattern = value != 0; ctx->c.part[1].dirty = true; }
     else if (n == "fuse_dir") ctx->c.no_fuse_dir = value == 0;
     else if (n == "no_grad_gather") { ctx->c.no_grad_gather = value != 0; ctx->c.layout_dirty = true; }         // staged mistark_eval calls take the lazy path too (tests)

@@ -181,6 +181,9 @@ struct BsrPart
     DevBuf<uint32_t> slot_of_src;   // per key of this part (potential P: kp_off + (a*NB+b)*n_elem + e) -> BSR slot
     const uint32_t* sorted_src = nullptr;  // key positions in sorted key order (one of kidx / kidx_alt); NO_SRC for structural diagonal keys
     DevBuf<uint32_t> sorted_desc;   // per sorted key: where the gather assembly reads the contribution (make_descriptors)
+    DevBuf<uint32_t> sym;           // static part, lazy float pool: per CSR slot SYM_NONE (summed from its own list), SYM_SKIP (written by its transpose's lane) or
+                                    // the storage position of the transpose the slot's lane also writes (k_sym_classify / k_assemble_gather)
+    bool sym_valid = false;         // ... built for the current descriptors
     int desc_lazy = -1;             // lazy state the descriptors were made for (-1: none)
     int64_t nnzb = 0, ntiles = 0, n_rows = 0;
     DevBuf<uint32_t> colw;          // bit31 = last block of its row, bits 0..30 = block column
@@ -337,6 +340,8 @@ struct Context
     bool have_matrix = false;
     bool matrix_current = false;    // the assembled matrix reflects the current element Hessians
     bool static_assembled = false;  // eval() has gathered the static part already, on the auxiliary stream (aux_ev[2] marks its end)
+    bool no_split_gather = false;   // option "no_split_gather": whole-part assemblies through k_assemble_gather (one lane per block whatever the list length) instead of k_assemble_gather_split
+    bool no_sym_gather = false;     // option "no_sym_gather": every block of the static part summed from its own list (k_assemble_gather without the mirror table)
     bool no_eager_assembly = false; // option "no_eager_assembly"
     int pcg_epoch = 0;              // solves started (PcgCtrl::epoch)
     std::vector<int32_t> hot_rows_host;  // what hot_rows holds (prepare uploads it only when it changes)

@@ -8,6 +8,7 @@ namespace mistark {
 // (elemH), bit 30: read the stored block transposed (lazy potentials keep the upper block triangle only), bits 0..29: 3x3 block index in that
 // pool. NO_SRC: no data (structural diagonal keys; multi-GPU: elements of other ranks, the sum over ranks restores them).
 constexpr uint32_t DESC_FLOAT = 0x80000000u, DESC_TRANS = 0x40000000u, DESC_MASK = 0x3fffffffu;
+constexpr uint32_t SYM_NONE = 0xFFFFFFFFu, SYM_SKIP = 0xFFFFFFFEu;  // BsrPart::sym
 struct DescRange  // keys [kp_off, kp_off + nn * n_elem) of one potential
 {
     uint32_t kp_off, n_elem, NB, e_begin, e_count;
@@ -205,13 +206,33 @@ struct F3
 {
     float x, y, z;
 };
+// a summed block into the tile layout at storage position pos, and — mirror != SYM_NONE — its transpose at the transposed block's position
+__device__ __forceinline__ void store_block(float* __restrict__ vals, uint32_t pos, uint32_t mirror, const double* acc)
+{
+    float* tile = vals + (size_t)(pos >> 6) * 576;
+    const uint32_t lane = pos & 63u;
+    reinterpret_cast<float4*>(tile)[lane] = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
+    reinterpret_cast<float4*>(tile)[64 + lane] = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
+    tile[512 + lane] = (float)acc[8];
+    if (mirror != SYM_NONE) {
+        float* t2 = vals + (size_t)(mirror >> 6) * 576;
+        const uint32_t l2 = mirror & 63u;
+        reinterpret_cast<float4*>(t2)[l2] = make_float4((float)acc[0], (float)acc[3], (float)acc[6], (float)acc[1]);
+        reinterpret_cast<float4*>(t2)[64 + l2] = make_float4((float)acc[4], (float)acc[7], (float)acc[2], (float)acc[5]);
+        t2[512 + l2] = (float)acc[8];
+    }
+}
 __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restrict__ elemH, const float* __restrict__ elemHf, const uint32_t* __restrict__ slot_start,
                                                            const uint32_t* __restrict__ sorted_src, int64_t nnzb, const uint32_t* __restrict__ store_slot, float* __restrict__ vals,
-                                                           const uint8_t* __restrict__ only_dirty)
+                                                           const uint8_t* __restrict__ only_dirty, const uint32_t* __restrict__ sym)
 {
     const int64_t slot = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (slot >= nnzb) return;
     if (only_dirty && !only_dirty[store_slot ? store_slot[slot] : (uint32_t)slot]) return;  // (project(): only the blocks a projection round touched; flags by storage position)
+    // (sym: block (i, j) of the static part whose contributions all come from the tets' float pool is the transpose of block (j, i) — the same pool
+    // blocks, read the other way round: the lane of the upper one writes both, the lower one's lane leaves at once; see k_sym_classify)
+    const uint32_t mirror = sym ? sym[slot] : SYM_NONE;
+    if (mirror == SYM_SKIP) return;
     const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1];
     if (k1 - k0 > LONG_SLOT) return;  // k_assemble_long
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -257,11 +278,175 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_gather(const double* __restr
         }
     }
     const uint32_t pos = store_slot ? store_slot[slot] : (uint32_t)slot;
-    float* tile = vals + (size_t)(pos >> 6) * 576;
-    const uint32_t lane = pos & 63u;
-    reinterpret_cast<float4*>(tile)[lane] = make_float4((float)acc[0], (float)acc[1], (float)acc[2], (float)acc[3]);
-    reinterpret_cast<float4*>(tile)[64 + lane] = make_float4((float)acc[4], (float)acc[5], (float)acc[6], (float)acc[7]);
-    tile[512 + lane] = (float)acc[8];
+    store_block(vals, pos, mirror, acc);
+}
+// ---- the same sums with the wavefront's long lists dealt out (round 5) ----------------------------------------------------------------------
+// k_assemble_gather is bound by instruction issue, not by memory: a wavefront of 64 consecutive blocks holds about four diagonal blocks whose
+// lists are 24 contributions long (every tet around the node) beside sixty lists of 4-6, so it runs six rounds of the four-way loop — ~500
+// instructions each with the conversions to double — although 1.6 would do for the average lane (ablation on the 1M-tet matrix: without pool loads
+// AND without stores the launch still takes 204 of 320 us; halving the pool reads through the mirror table gains 4 %, eight loads in flight per lane
+// nothing). Here a lane sums its own list only when it is short (<= SPLIT_LEN: two rounds); the longer lists of the wavefront are then
+// taken eight at a time by groups of eight lanes: lane s of a group adds the contributions s, s + 8, ... of the group's list, the eight partial sums
+// are folded by three xor-shuffles (every lane adds the same pair of numbers, so all eight end with the same bits) and lane 0 of the group stores the
+// block. A fixed order of additions per block as before — a DIFFERENT one for the long lists, so those sums may differ from k_assemble_gather's in
+// the last bit of the double before it is rounded to float.
+constexpr uint32_t SPLIT_LEN = 8;
+__device__ __forceinline__ void add_contribution(uint32_t d, const double* __restrict__ elemH, const float* __restrict__ elemHf, double* acc)
+{
+    if (d == NO_SRC) return;
+    if (d & DESC_FLOAT) {
+        const F3* src = reinterpret_cast<const F3*>(elemHf + (size_t)(d & DESC_MASK) * 9);
+        const F3 a = src[0], b = src[1], c = src[2];
+        const bool t = (d & DESC_TRANS) != 0u;
+        acc[0] += (double)a.x;
+        acc[1] += (double)(t ? b.x : a.y);
+        acc[2] += (double)(t ? c.x : a.z);
+        acc[3] += (double)(t ? a.y : b.x);
+        acc[4] += (double)b.y;
+        acc[5] += (double)(t ? c.y : b.z);
+        acc[6] += (double)(t ? a.z : c.x);
+        acc[7] += (double)(t ? b.z : c.y);
+        acc[8] += (double)c.z;
+    } else {
+        const double* h = elemH + (size_t)d * 9;
+#pragma unroll
+        for (int c = 0; c < 9; c++) acc[c] += h[c];
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_assemble_gather_split(const double* __restrict__ elemH, const float* __restrict__ elemHf, const uint32_t* __restrict__ slot_start,
+                                                                 const uint32_t* __restrict__ sorted_src, int64_t nnzb, const uint32_t* __restrict__ store_slot,
+                                                                 float* __restrict__ vals, const uint32_t* __restrict__ sym)
+{
+    // (no lane leaves before the cooperative part: the shuffles below need the whole wavefront)
+    const int64_t slot = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    uint32_t k0 = 0, k1 = 0, mirror = SYM_NONE;
+    bool active = slot < nnzb;
+    if (active) {
+        mirror = sym ? sym[slot] : SYM_NONE;
+        active = mirror != SYM_SKIP;
+    }
+    if (active) {
+        k0 = slot_start[slot];
+        k1 = slot_start[slot + 1];
+        active = k1 - k0 <= LONG_SLOT;  // (beyond: k_assemble_long / the very long lists' two passes)
+    }
+    const uint32_t len = active ? k1 - k0 : 0u;
+    const bool is_long = len > SPLIT_LEN;
+    if (active && !is_long) {  // own short list: the four-way loop of k_assemble_gather
+        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (uint32_t kb = k0; kb < k1; kb += 4) {
+            uint32_t d[4];
+            F3 v[4][3];
+#pragma unroll
+            for (int u = 0; u < 4; u++) d[u] = kb + u < k1 ? sorted_src[kb + u] : NO_SRC;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool f = d[u] != NO_SRC && (d[u] & DESC_FLOAT) != 0u;
+                const F3* src = reinterpret_cast<const F3*>(elemHf + (f ? (size_t)(d[u] & DESC_MASK) * 9 : (size_t)0));
+                v[u][0] = src[0];
+                v[u][1] = src[1];
+                v[u][2] = src[2];
+            }
+            bool any_double = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool f = d[u] != NO_SRC && (d[u] & DESC_FLOAT) != 0u;
+                const bool t = (d[u] & DESC_TRANS) != 0u;
+                any_double = any_double || (d[u] != NO_SRC && !f);
+                if (f) {
+                    acc[0] += (double)v[u][0].x;
+                    acc[1] += (double)(t ? v[u][1].x : v[u][0].y);
+                    acc[2] += (double)(t ? v[u][2].x : v[u][0].z);
+                    acc[3] += (double)(t ? v[u][0].y : v[u][1].x);
+                    acc[4] += (double)v[u][1].y;
+                    acc[5] += (double)(t ? v[u][2].y : v[u][1].z);
+                    acc[6] += (double)(t ? v[u][0].z : v[u][2].x);
+                    acc[7] += (double)(t ? v[u][1].z : v[u][2].y);
+                    acc[8] += (double)v[u][2].z;
+                }
+            }
+            if (any_double) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (d[u] == NO_SRC || (d[u] & DESC_FLOAT)) continue;
+                    const double* h = elemH + (size_t)d[u] * 9;
+#pragma unroll
+                    for (int c = 0; c < 9; c++) acc[c] += h[c];
+                }
+            }
+        }
+        store_block(vals, store_slot ? store_slot[slot] : (uint32_t)slot, mirror, acc);
+    }
+    // the wavefront's long lists, eight at a time
+    unsigned long long todo = __ballot(is_long);
+    const int sub = lane & 7, grp = lane >> 3;
+    while (todo != 0ull) {  // (wave-uniform)
+        int src = -1;
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            if (todo == 0ull) break;
+            const int bit = __ffsll((long long)todo) - 1;
+            if (g == grp) src = bit;
+            todo &= todo - 1ull;
+        }
+        const bool has = src >= 0;
+        const int from = has ? src : lane;
+        const uint32_t g_k0 = (uint32_t)__shfl((int)k0, from, 64), g_k1 = (uint32_t)__shfl((int)k1, from, 64), g_mirror = (uint32_t)__shfl((int)mirror, from, 64);
+        double a[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (has)
+            for (uint32_t k = g_k0 + (uint32_t)sub; k < g_k1; k += 8u) add_contribution(sorted_src[k], elemH, elemHf, a);
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 9; c++) a[c] += __shfl_xor(a[c], o, 64);
+        }
+        if (has && sub == 0) {
+            const int64_t gs = slot - lane + src;
+            store_block(vals, store_slot ? store_slot[gs] : (uint32_t)gs, g_mirror, a);
+        }
+    }
+}
+// Which blocks of the static part are written by their transpose's lane (k_assemble_gather, `sym`). Block (i, j), i != j, qualifies when every
+// contribution of it AND of block (j, i) is a block of the lazy tets' float pool: that pool holds the upper-triangle block pairs of an element once,
+// so the two lists name the same pool blocks with opposite transposition flags (checked: equal length, equal sum and xor of the pool indices, the
+// flags add up) and the two sums are transposes of each other up to the order of the additions (double accumulators, one rounding to float at the
+// end). The lane of the upper block (i < j) then stores both; the gather reads 10 instead of 16 pool blocks per tet. Everything else — diagonal
+// blocks, blocks with a contribution from the double pool, long lists — keeps its own lane (SYM_NONE).
+__global__ __launch_bounds__(BLOCK) void k_sym_classify(const uint32_t* __restrict__ slot_start, const uint32_t* __restrict__ desc, const uint32_t* __restrict__ colw,
+                                                        const uint32_t* __restrict__ slot_row, const int64_t* __restrict__ row_ptr, int64_t nnzb, const uint32_t* __restrict__ store_slot,
+                                                        uint32_t* __restrict__ sym)
+{
+    const int64_t slot = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (slot >= nnzb) return;
+    uint32_t out = SYM_NONE;
+    const uint32_t r = slot_row[slot], c = colw[slot] & 0x7fffffffu;
+    const uint32_t k0 = slot_start[slot], k1 = slot_start[slot + 1], len = k1 - k0;
+    if (r != c && len > 0 && len <= LONG_SLOT) {
+        int64_t lo = row_ptr[c], hi = row_ptr[c + 1];  // (the static part holds every block row: compact row = row)
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((colw[mid] & 0x7fffffffu) < r) lo = mid + 1;
+            else hi = mid;
+        }
+        const int64_t t = lo;
+        if (t < row_ptr[c + 1] && (colw[t] & 0x7fffffffu) == r && slot_row[t] == c) {
+            const uint32_t t0 = slot_start[t], t1 = slot_start[t + 1];
+            if (t1 - t0 == len) {
+                bool pure = true;
+                uint32_t sum_a = 0, sum_b = 0, xor_a = 0, xor_b = 0, n_trans = 0;
+                for (uint32_t k = 0; k < len; k++) {
+                    const uint32_t a = desc[k0 + k], b = desc[t0 + k];
+                    pure = pure && a != NO_SRC && b != NO_SRC && (a & DESC_FLOAT) && (b & DESC_FLOAT);
+                    sum_a += a & DESC_MASK; sum_b += b & DESC_MASK;
+                    xor_a ^= a & DESC_MASK; xor_b ^= b & DESC_MASK;
+                    n_trans += ((a & DESC_TRANS) ? 1u : 0u) + ((b & DESC_TRANS) ? 1u : 0u);
+                }
+                if (pure && sum_a == sum_b && xor_a == xor_b && n_trans == len) out = r < c ? (store_slot ? store_slot[t] : (uint32_t)t) : SYM_SKIP;
+            }
+        }
+    }
+    sym[slot] = out;
 }
 
 // descriptors of the gather lists for the current state of the pools (lazy or not): once per pattern and lazy state
@@ -291,6 +476,7 @@ static void make_descriptors(Context& c, int part)
         MS_CHECK(hipStreamSynchronize(c.stream));  // rg is a temporary
     }
     m.desc_lazy = c.lazy_active ? 1 : 0;
+    m.sym_valid = false;
 }
 // the blocks of a matrix part summed from the pools in sorted-key order; only_dirty: just the flagged blocks (BsrPart::slot_dirty)
 void gather_part(Context& c, int part, const uint8_t* only_dirty)
@@ -299,7 +485,21 @@ void gather_part(Context& c, int part, const uint8_t* only_dirty)
     make_descriptors(c, part);
     const uint32_t* store = part == 0 ? m.store_slot.p : nullptr;
     const uint32_t* desc = m.sorted_desc.p;
-    hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.nnzb, store, m.vals.p, only_dirty);
+    // the whole static part from the lazy float pool, one GPU: blocks that are each other's transposes are summed once (k_sym_classify)
+    const uint32_t* sym = nullptr;
+    if (part == 0 && !only_dirty && c.world == 1 && c.lazy_active && !c.no_sym_gather && !c.hf_layout && m.n_keys > 0) {
+        if (!m.sym_valid) {
+            m.sym.ensure((size_t)m.nnzb);
+            hipLaunchKernelGGL(k_sym_classify, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, m.slot_start.p, desc, m.colw.p, m.slot_row.p, m.row_ptr.p, m.nnzb, store, m.sym.p);
+            m.sym_valid = true;
+        }
+        sym = m.sym.p;
+    }
+    // a whole part: the wavefront's long lists dealt out (k_assemble_gather_split); the blocks a projection round touched: one lane per block
+    if (!only_dirty && !c.no_split_gather)
+        hipLaunchKernelGGL(k_assemble_gather_split, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.nnzb, store, m.vals.p, sym);
+    else
+        hipLaunchKernelGGL(k_assemble_gather, dim3(grid_for(m.nnzb)), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.nnzb, store, m.vals.p, only_dirty, sym);
     if (m.n_long > 0)
         hipLaunchKernelGGL(k_assemble_long, dim3((m.n_long + 3) / 4), dim3(BLOCK), 0, c.stream, c.elemH.p, c.elemHf.p, m.slot_start.p, desc, m.long_slots.p, m.n_long, store, m.vals.p, only_dirty);
     if (m.n_vlong > 0) {

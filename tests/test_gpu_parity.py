@@ -343,6 +343,39 @@ def test_lazy_hessian_path_matches_full(name):
     assert np.abs(b[5] - a[5]).max() <= 64 * eps32 * scale
 
 
+@pytest.mark.parametrize("lazy", [0, 1])
+@pytest.mark.parametrize("name", ["tetbeam_softrubber_6x2x2", "tetbeam_eo_8x2x2", "contactmix_t1", "rbchain", "cloth_shells_6", "attachzoo"])
+def test_split_and_mirrored_gather_equal_the_lane_per_block_gather(name, lazy):
+    """Whole-part assemblies deal a wavefront's long lists out to groups of eight lanes (k_assemble_gather_split) and, with the lazy float pool,
+    write a block and its transpose from ONE sum (k_sym_classify): the same contributions in another order of additions. Against the kernel that
+    sums every block in list order (options no_split_gather, no_sym_gather): identical pattern; every entry within ONE float rounding step of it
+    (double accumulators: the sums differ in the last bits of a double, which the rounding to float sees only when a sum sits on a rounding
+    boundary), almost every entry identical, and the matrix within the usual bound of the reference's."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    out = []
+    for opts in ((), ("no_split_gather", "no_sym_gather")):
+        eng = engine_from_problem(prob, man)
+        eng.set_option("lazy_eval", lazy)
+        for o in opts:
+            eng.set_option(o, 1)
+        eng.eval(capi.EVAL_P_G_H)
+        eng.assemble()
+        out.append(eng.get_bsr())
+        eng.close()
+    (rp, cols, a), (rp2, cols2, b) = out
+    assert (rp == rp2).all() and (cols == cols2).all()
+    a64, b64 = a.astype(np.float64), b.astype(np.float64)
+    step = np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64)
+    assert (np.abs(a64 - b64) <= step).all()
+    assert (a != b).mean() < 1e-3
+    Sref = sp.coo_matrix((z["A_vals"], (z["A_rows"], z["A_cols"])), shape=(prob.ndofs, prob.ndofs)).tocsr()
+    S = sp.bsr_matrix((a64, cols, rp), shape=(prob.ndofs, prob.ndofs)).tocsr()
+    assert abs(S - Sref).max() <= 64 * np.finfo(np.float32).eps * abs(Sref).max()
+
+
 @pytest.mark.parametrize("name", ["tetbeam_softrubber_6x2x2", "contactmix_t1", "rbchain"])
 def test_pcg_fused_direction_variant(name):
     """Option fuse_dir: the search direction p = z + beta p formed inside the SpMV instead of by k_pcg_dir (a measured-slower variant kept as a
