@@ -558,6 +558,12 @@ int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out)
     else if (n == "rtc_build_ms") *out = (int64_t)(1e3 * c.t_rtc_builds);
     else if (n == "fused_solves") *out = c.n_fused_solves;
     else if (n == "unfused_solves") *out = c.n_unfused_solves;
+    else if (n == "evt_tet_us") *out = (int64_t)c.evt_sum[1];
+    else if (n == "evt_small_us") *out = (int64_t)c.evt_sum[2];
+    else if (n == "evt_gather_us") *out = (int64_t)c.evt_sum[3];
+    else if (n == "evt_main_us") *out = (int64_t)c.evt_sum[4];
+    else if (n == "evt_pattern_us") *out = (int64_t)c.evt_sum[5];
+    else if (n == "evt_n") *out = c.evt_n;
     else if (n == "eval_pgh_issue_us") *out = (int64_t)(1e6 * c.t_eval_issue);
     else if (n == "eval_pgh_wait_us") *out = (int64_t)(1e6 * c.t_eval_wait);
     else if (n == "contact_searches") *out = contact_searches(c, false);

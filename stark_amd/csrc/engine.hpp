@@ -362,6 +362,12 @@ struct Context
     uint8_t* pub = nullptr;         // coherent pinned page small read-backs are published into (kernels.hip: publish)
     uint32_t pub_seq = 0;
     double t_eval_issue = 0.0, t_eval_wait = 0.0;  // host seconds of eval(P+g+H): issuing launches / waiting for the read-backs (counters eval_pgh_issue_us, eval_pgh_wait_us)
+    // MISTARK_EVAL_EVENTS=1 (measurement): GPU time stamps inside a P+g+H evaluation, microseconds from the start of the tets' kernel, summed over
+    // the evaluations (counters evt_tet_us / evt_small_us / evt_gather_us / evt_main_us / evt_pattern_us / evt_n); read at the next evaluation's entry
+    hipEvent_t evt[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool evt_armed[6] = {false, false, false, false, false, false};
+    double evt_sum[6] = {0, 0, 0, 0, 0, 0};
+    int64_t evt_n = 0;
     uint8_t* pub2 = nullptr;        // ... and a second one for a read-back left in flight while another runs (publish_begin2 / publish_end2)
     uint32_t pub2_seq = 0;
     // bumped by everything that can change what a contact detection sees (DoFs, bound arrays, layout): the detector skips a search whose

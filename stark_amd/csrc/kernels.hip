@@ -2063,6 +2063,29 @@ void ensure_pattern(Context& c)
 // ======================================================================================================================
 static void build_pattern(Context& c, int part);
 static void build_pattern_part(Context& c, int part) { build_pattern(c, part); }
+static const bool g_eval_events = std::getenv("MISTARK_EVAL_EVENTS") != nullptr;
+static void evt_mark(Context& c, int k, hipStream_t s)
+{
+    if (!g_eval_events) return;
+    if (!c.evt[k]) MS_CHECK(hipEventCreate(&c.evt[k]));
+    MS_CHECK(hipEventRecord(c.evt[k], s));
+    c.evt_armed[k] = true;
+}
+static void evt_collect(Context& c)  // (the previous evaluation's stamps: all of them are long past)
+{
+    if (!g_eval_events || !c.evt_armed[0]) return;
+    bool any = false;
+    for (int k = 1; k < 6; k++) {
+        if (!c.evt_armed[k]) continue;
+        float ms = 0.f;
+        if (hipEventSynchronize(c.evt[k]) == hipSuccess && hipEventElapsedTime(&ms, c.evt[0], c.evt[k]) == hipSuccess) {
+            c.evt_sum[k] += 1e3 * ms;
+            any = true;
+        }
+    }
+    if (any) c.evt_n++;
+    for (int k = 0; k < 6; k++) c.evt_armed[k] = false;
+}
 void eval_prelaunch(Context& c, int mode, bool lazy)
 {
     Context::EvalPre& pre = c.pre[mode == MISTARK_EVAL_P ? 0 : 1];
@@ -2092,6 +2115,10 @@ void eval_prelaunch(Context& c, int mode, bool lazy)
     }
     MS_CHECK(hipEventRecord(pre.ev_in, c.stream));  // (the DoFs of this evaluation are final on the main stream)
     MS_CHECK(hipStreamWaitEvent(c.pre_stream, pre.ev_in, 0));
+    if (mode == MISTARK_EVAL_P_G_H) {
+        evt_collect(c);
+        evt_mark(c, 0, c.pre_stream);
+    }
     hipStream_t main_stream = c.stream;
     const bool lazy_before = c.lazy_active;
     c.stream = c.pre_stream;
@@ -2111,6 +2138,7 @@ void eval_prelaunch(Context& c, int mode, bool lazy)
     c.stream = main_stream;
     c.lazy_active = lazy_before;
     MS_CHECK(hipEventRecord(pre.ev_out, c.pre_stream));
+    if (mode == MISTARK_EVAL_P_G_H) evt_mark(c, 1, c.pre_stream);
     pre.valid = true;
     pre.mode = mode;
     pre.lazy_active = lazy_active;
@@ -2198,6 +2226,7 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         }
         c.stream = main_stream;
         MS_CHECK(hipEventRecord(c.aux_ev[2], c.aux_stream));
+        if (c.evt_armed[0]) evt_mark(c, 3, c.aux_stream);
         c.static_assembled = true;
     };
     try {
@@ -2316,6 +2345,7 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
     c.stream = main_stream;
     c.grad.p = grad_main;
     if (split) MS_CHECK(hipEventRecord(c.aux_ev[1], c.aux_stream));  // (the join below waits for the small potentials, not for the gather queued behind them)
+    if (split && mode == MISTARK_EVAL_P_G_H && c.evt_armed[0]) evt_mark(c, 2, c.aux_stream);
     if (early_asm) {
         static_assembly();
         for (Potential* P : deferred_gathers) {
@@ -2347,6 +2377,7 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         }
         c.stream = main_stream;
         MS_CHECK(hipEventRecord(c.side_ev[1], c.side_stream));
+        if (c.evt_armed[0]) evt_mark(c, 5, c.side_stream);
         MS_CHECK(hipStreamWaitEvent(c.stream, c.side_ev[1], 0));
     };
     const bool with_max_early = grad_max_abs && mode != MISTARK_EVAL_P && c.world == 1 && c.n_elem_total > 0;
@@ -2368,6 +2399,7 @@ void eval(Context& c, int mode, double* E, double* grad_host, double* grad_max_a
         double* h = host_scratch(c, 2 * MAX_PARTIALS);
         // the partial sums leave the device BEFORE this stream is made to wait for the pattern chain (the publish kernel is queued behind the
         // reductions; the host picks the numbers up after the pattern's own read-back)
+        if (mode == MISTARK_EVAL_P_G_H && c.evt_armed[0]) evt_mark(c, 4, c.stream);
         const bool published = fetch_partials_begin(c, g1 + g2, c.partials.p);
         const double t_issued = host_now_s();
         run_pattern();
