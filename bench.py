@@ -327,7 +327,9 @@ def rccl_allreduce_leg(capi, dist, rank, world, device, ranks_seen, broadcast_ui
     if len(devices) < world:
         return ({"ranks": None, "refused": "ranks share a device (%d distinct device(s) for %d ranks): RCCL needs one device per rank" % (len(devices), world),
                  "allreduce_ndofs_us": None, "allreduce_3_us": None}, False)
-    uid = broadcast_uid()
+    uid = broadcast_uid(required=False)   # (None on EVERY rank when rank 0 could not make one: a refused leg, not an exception on one rank)
+    if uid is None:
+        return ({"ranks": None, "refused": "rank 0 could not create an ncclUniqueId", "allreduce_ndofs_us": None, "allreduce_3_us": None}, False)
     out = (C.c_double * 4)()
     err = C.create_string_buffer(512)
     box = {}
@@ -570,16 +572,22 @@ def main():
                     except Exception:  # noqa: BLE001
                         pass
                 comm, transport = None, "rccl"
-        def broadcast_uid():
-            """A fresh ncclUniqueId from rank 0 (one per communicator: an id is single-use)."""
-            box = [None]
+        def broadcast_uid(required=True):
+            """A fresh ncclUniqueId from rank 0 (one per communicator: an id is single-use). Rank 0's failure travels through the SAME
+            broadcast as the id, so every rank learns of it together: all raise (required) or all get None (the caller refuses its leg)."""
+            box = [(None, None)]
             if rank == 0:
                 buf = C.create_string_buffer(128)
-                if capi.lib().mistark_dist_unique_id(buf) != 0:
-                    raise RuntimeError("ncclGetUniqueId failed")
-                box[0] = buf.raw
+                try:
+                    rc = capi.lib().mistark_dist_unique_id(buf)
+                    box[0] = (buf.raw, None) if rc == 0 else (None, "ncclGetUniqueId failed (rc %d)" % rc)
+                except Exception as e:  # noqa: BLE001
+                    box[0] = (None, "ncclGetUniqueId: %r" % (e,))
             dist.broadcast_object_list(box, src=0)
-            return box[0]
+            uid_raw, uid_err = box[0]
+            if uid_raw is None and required:
+                raise RuntimeError(uid_err or "no ncclUniqueId from rank 0")
+            return uid_raw
 
         if transport == "rccl":
             uid = broadcast_uid()

@@ -7,8 +7,11 @@
 #include <hip/hip_runtime.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
+
+#include <cerrno>
 
 #include <algorithm>
 #include <chrono>
@@ -373,6 +376,7 @@ struct HipRtc
     int (*GetCodeSize)(void*, size_t*) = nullptr;
     int (*GetCode)(void*, char*) = nullptr;
     int (*DestroyProgram)(void**) = nullptr;
+    int (*Version)(int*, int*) = nullptr;  // (optional: part of the cache key)
 };
 HipRtc& hiprtc()
 {
@@ -400,7 +404,7 @@ HipRtc& hiprtc()
             if (!ok) {
                 dlclose(r.lib);
                 r.lib = nullptr;
-            }
+            } else r.Version = (int (*)(int*, int*))dlsym(r.lib, "hiprtcVersion");
         }
     }
     return r;
@@ -569,24 +573,148 @@ uint64_t fnv1a(const std::string& s)
     }
     return h;
 }
+// ---- disk cache of emitted kernels' code objects ----------------------------------------------------------------------------------------
+// A code object found in the cache is loaded and RUN on the device, so the cache is only used when it is provably this user's own:
+// the directory is created (0700) BEFORE any lookup and must then be a real directory (no symlink) owned by getuid() that neither group
+// nor others can write; files are opened O_NOFOLLOW, must be regular files of this user, and carry a header that binds them to the
+// source text (length + a second, independent 64-bit hash besides the one in the file name), the target architecture, the compile
+// options and the hipRTC version. Anything else: the cache is skipped (one line on stderr) and the kernel is compiled.
+uint64_t hash2(const std::string& s)  // (independent of fnv1a: another multiplier, the bytes taken in reverse, a final avalanche)
+{
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)s.size();
+    for (size_t i = s.size(); i-- > 0;) {
+        h ^= (unsigned char)s[i];
+        h *= 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+    }
+    h ^= h >> 33;
+    h *= 0xc4ceb9fe1a85ec53ull;
+    return h ^ (h >> 32);
+}
+// the architecture the emitted kernels are compiled for: the current device's when there is one, else the one this library was built for
+std::string rtc_arch()
+{
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.gcnArchName[0]) {
+        std::string a = prop.gcnArchName;  // "gfx950:sramecc+:xnack-" -> "gfx950"
+        const size_t colon = a.find(':');
+        return colon == std::string::npos ? a : a.substr(0, colon);
+    }
+    (void)hipGetLastError();
+#ifdef MISTARK_ARCH
+    return MISTARK_ARCH;
+#else
+    return "gfx950";
+#endif
+}
+bool make_private_dir(const std::string& d)
+{
+    if (::mkdir(d.c_str(), 0700) != 0 && errno != EEXIST) return false;
+    struct stat st;
+    if (::lstat(d.c_str(), &st) != 0) return false;
+    return S_ISDIR(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+// the cache directory, or "" when there is none that can be trusted
+std::string rtc_cache_dir()
+{
+    std::string d;
+    if (const char* e = std::getenv("MISTARK_RTC_CACHE")) {
+        if (!e[0] || std::string(e) == "0" || std::string(e) == "off") return std::string();
+        d = e;
+    } else {
+        std::string base;
+        const char* x = std::getenv("XDG_CACHE_HOME");
+        const char* h = std::getenv("HOME");
+        if (x && x[0] == '/') base = x;
+        else if (h && h[0] == '/') {
+            base = std::string(h) + "/.cache";
+            (void)::mkdir(base.c_str(), 0700);
+        }
+        d = !base.empty() ? base + "/mistark_rtc" : "/tmp/mistark_rtc_cache_" + std::to_string((long long)getuid());
+    }
+    if (!make_private_dir(d)) {
+        static std::string warned;
+        if (warned != d) {
+            warned = d;
+            std::fprintf(stderr, "mistark: hipRTC cache directory '%s' is not a directory of uid %ld closed to group / others: cache not used\n", d.c_str(), (long)getuid());
+        }
+        return std::string();
+    }
+    return d;
+}
+struct RtcCacheHeader
+{
+    char magic[8];  // "MISRTC02"
+    uint64_t src_len, src_hash2, key_hash, code_len;
+};
+std::vector<char> rtc_cache_load(const std::string& path, const std::string& src, uint64_t key_hash)
+{
+    const int fd = ::open(path.c_str(), O_RDONLY | O_NOFOLLOW | O_CLOEXEC);
+    if (fd < 0) return {};
+    std::vector<char> code;
+    struct stat st;
+    RtcCacheHeader h;
+    if (::fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_uid == getuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0 && st.st_size > (off_t)sizeof(h) &&
+        ::read(fd, &h, sizeof(h)) == (ssize_t)sizeof(h) && std::memcmp(h.magic, "MISRTC02", 8) == 0 && h.src_len == src.size() && h.src_hash2 == hash2(src) &&
+        h.key_hash == key_hash && h.code_len > 64 && h.code_len == (uint64_t)st.st_size - sizeof(h)) {
+        code.resize(h.code_len);
+        size_t got = 0;
+        while (got < code.size()) {
+            const ssize_t n = ::read(fd, code.data() + got, code.size() - got);
+            if (n <= 0) break;
+            got += (size_t)n;
+        }
+        if (got != code.size() || std::memcmp(code.data(), "\x7f" "ELF", 4) != 0) code.clear();
+    }
+    ::close(fd);
+    return code;
+}
+void rtc_cache_store(const std::string& path, const std::string& src, uint64_t key_hash, const std::vector<char>& code)
+{  // best effort: written under a temporary name of this process (O_EXCL, 0600) and renamed
+    const std::string tmp = path + "." + std::to_string((long long)getpid());
+    const int fd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return;
+    RtcCacheHeader h;
+    std::memcpy(h.magic, "MISRTC02", 8);
+    h.src_len = src.size();
+    h.src_hash2 = hash2(src);
+    h.key_hash = key_hash;
+    h.code_len = code.size();
+    bool ok = ::write(fd, &h, sizeof(h)) == (ssize_t)sizeof(h);
+    size_t put = 0;
+    while (ok && put < code.size()) {
+        const ssize_t n = ::write(fd, code.data() + put, code.size() - put);
+        if (n <= 0) ok = false;
+        else put += (size_t)n;
+    }
+    ok = ::close(fd) == 0 && ok;
+    if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)::unlink(tmp.c_str());
+}
 // compiled code object of `src` (from the disk cache, or built now); empty + why on failure
 std::vector<char> rtc_build(const std::string& src, std::string& why)
 {
-    const char* dir_env = std::getenv("MISTARK_RTC_CACHE");
-    // (default: a directory of this user's own, created 0700 — code objects found there are loaded and run)
-    const std::string dir = dir_env && dir_env[0] ? dir_env : "/tmp/mistark_rtc_cache_" + std::to_string((long long)getuid());
-    char name[64];
-    std::snprintf(name, sizeof(name), "/%016llx_gfx950.hsaco", (unsigned long long)fnv1a(src));
-    const std::string path = dir + name;
-    if (FILE* f = std::fopen(path.c_str(), "rb")) {
-        std::vector<char> code;
-        char buf[65536];
-        size_t got;
-        while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) code.insert(code.end(), buf, buf + got);
-        std::fclose(f);
-        if (code.size() > 64) return code;
-    }
     HipRtc& R = hiprtc();
+    const std::string arch = rtc_arch();
+    const std::string arch_opt = "--offload-arch=" + arch;
+    const char* opts[] = {arch_opt.c_str(), "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-pragma-once-outside-header"};
+    constexpr int n_opts = 5;
+    // what besides the source decides the code object: target, options, compiler version
+    std::string key = arch;
+    for (const char* o : opts) key += std::string("|") + o;
+    int vmaj = 0, vmin = 0;
+    if (R.lib && R.Version) (void)R.Version(&vmaj, &vmin);
+    key += "|hiprtc " + std::to_string(vmaj) + "." + std::to_string(vmin);
+    const uint64_t key_hash = fnv1a(key);
+    const std::string dir = rtc_cache_dir();
+    std::string path;
+    if (!dir.empty()) {
+        char name[96];
+        std::snprintf(name, sizeof(name), "/%016llx_%016llx_%s.hsaco", (unsigned long long)fnv1a(src), (unsigned long long)key_hash, arch.c_str());
+        path = dir + name;
+        std::vector<char> code = rtc_cache_load(path, src, key_hash);
+        if (!code.empty()) return code;
+    }
     if (!R.lib) {
         why = "libhiprtc.so not available";
         return {};
@@ -596,15 +724,14 @@ std::vector<char> rtc_build(const std::string& src, std::string& why)
         why = "hiprtcCreateProgram failed";
         return {};
     }
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-Wno-pragma-once-outside-header"};
-    const int rc = R.CompileProgram(prog, 5, opts);
+    const int rc = R.CompileProgram(prog, n_opts, opts);
     std::vector<char> code;
     if (rc != 0) {
         size_t n = 0;
         R.GetProgramLogSize(prog, &n);
         std::string log(n, '\0');
         if (n) R.GetProgramLog(prog, &log[0]);
-        why = "hipRTC compile failed: " + log.substr(0, 2000);
+        why = "hipRTC compile failed (" + arch + "): " + log.substr(0, 2000);
     } else {
         size_t n = 0;
         R.GetCodeSize(prog, &n);
@@ -612,15 +739,7 @@ std::vector<char> rtc_build(const std::string& src, std::string& why)
         R.GetCode(prog, code.data());
     }
     R.DestroyProgram(&prog);
-    if (!code.empty()) {  // (cache: best effort, written under a temporary name and renamed)
-        (void)::mkdir(dir.c_str(), 0700);
-        const std::string tmp = path + "." + std::to_string((long long)getpid());
-        if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
-            const bool ok = std::fwrite(code.data(), 1, code.size(), f) == code.size();
-            std::fclose(f);
-            if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) (void)std::remove(tmp.c_str());
-        }
-    }
+    if (!code.empty() && !path.empty()) rtc_cache_store(path, src, key_hash, code);
     return code;
 }
 int rtc_max_ops()
@@ -695,18 +814,24 @@ void launch_eval_custom(Context& c, Potential& P, int mode)
 {
     if (!c.custom_timing) return launch_eval_custom_impl(c, P, mode);
     // option custom_timing (measurement): HIP events around the potential's own launch, synchronised; counter "custom_kernel_us"
-    hipEvent_t e0, e1;
-    MS_CHECK(hipEventCreate(&e0));
-    MS_CHECK(hipEventCreate(&e1));
-    MS_CHECK(hipEventRecord(e0, c.stream));
+    struct Events  // (destroyed on every way out: launch_eval_custom_impl and MS_CHECK throw)
+    {
+        hipEvent_t e[2] = {nullptr, nullptr};
+        ~Events()
+        {
+            for (hipEvent_t x : e)
+                if (x) (void)hipEventDestroy(x);
+        }
+    } ev;
+    MS_CHECK(hipEventCreate(&ev.e[0]));
+    MS_CHECK(hipEventCreate(&ev.e[1]));
+    MS_CHECK(hipEventRecord(ev.e[0], c.stream));
     launch_eval_custom_impl(c, P, mode);
-    MS_CHECK(hipEventRecord(e1, c.stream));
-    MS_CHECK(hipEventSynchronize(e1));
+    MS_CHECK(hipEventRecord(ev.e[1], c.stream));
+    MS_CHECK(hipEventSynchronize(ev.e[1]));
     float ms = 0.f;
-    MS_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    MS_CHECK(hipEventElapsedTime(&ms, ev.e[0], ev.e[1]));
     c.custom_kernel_us += 1e3 * (double)ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
 }
 static void launch_eval_custom_impl(Context& c, Potential& P, int mode)
 {

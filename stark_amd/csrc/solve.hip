@@ -2749,6 +2749,8 @@ Context::~Context()
         if (h_small[k]) (void)hipHostFree(h_small[k]);
         if (h_small_ev[k]) (void)hipEventDestroy(h_small_ev[k]);
     }
+    for (hipEvent_t e : evt)  // (MISTARK_EVAL_EVENTS marks, kernels.hip evt_mark)
+        if (e) (void)hipEventDestroy(e);
     for (auto e : ev) (void)hipEventDestroy(e);
     for (auto e : pcg_ev) (void)hipEventDestroy(e);
     for (auto e : stage_ev) (void)hipEventDestroy(e);

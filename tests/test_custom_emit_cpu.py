@@ -65,9 +65,63 @@ def test_emitted_source_has_one_statement_per_op_and_compiles(fixture, name, tmp
     size, msg, _, _ = _emit(prob.potentials[pi], prob, z, pi, True)
     assert size > 4096, msg                                               # a gfx950 code object came out of hipRTC
     assert len(os.listdir(tmp_path)) == 1 and os.listdir(tmp_path)[0].endswith("_gfx950.hsaco")
+    # the cached file is bound to its source: magic, source length, then hashes; the code object (ELF) follows the 40-byte header
+    raw = open(os.path.join(tmp_path, os.listdir(tmp_path)[0]), "rb").read()
+    assert raw[:8] == b"MISRTC02" and int.from_bytes(raw[8:16], "little") > 1000 and raw[40:44] == b"\x7fELF"
+    assert int.from_bytes(raw[32:40], "little") == len(raw) - 40 == size
     # the same source again is answered from the cache
     size2, _, _, _ = _emit(prob.potentials[pi], prob, z, pi, True)
     assert size2 == size
+
+
+def test_the_code_object_cache_only_trusts_what_is_provably_the_users_own(tmp_path, monkeypatch):
+    """ADVICE r05 (custom.hip rtc_build): a code object found in the cache is run on the device. A planted file under the predictable name (no
+    valid header / another source), a symlink in its place, or a cache directory that group or others can write must never be loaded."""
+    import stat
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, "cloth_shells_6.npz"))
+    pi = [p.name for p in prob.potentials].index("EnergyDiscreteShells")
+    pot = prob.potentials[pi]
+    good = tmp_path / "good"
+    monkeypatch.setenv("MISTARK_RTC_CACHE", str(good))
+    size, msg, _, _ = _emit(pot, prob, z, pi, True)                     # (creates the directory 0700 before the lookup)
+    assert size > 4096, msg
+    assert stat.S_IMODE(os.stat(good).st_mode) == 0o700
+    (name,) = os.listdir(good)
+    real = (good / name).read_bytes()
+    assert stat.S_IMODE(os.stat(good / name).st_mode) == 0o600
+    # 1. a planted file under the right name: garbage, an ELF without the header, a header of another source -> ignored, rebuilt, replaced
+    other = bytearray(real)
+    other[8:16] = (int.from_bytes(real[8:16], "little") + 1).to_bytes(8, "little")        # another source length
+    for planted in (b"\x7fELF" + b"\0" * 5000, real[40:], bytes(other)):
+        (good / name).write_bytes(planted)
+        size2, msg, _, _ = _emit(pot, prob, z, pi, True)
+        assert size2 == size, msg
+        assert (good / name).read_bytes()[:8] == b"MISRTC02" and (good / name).read_bytes() != planted
+    # 2. a symlink in the file's place is not followed
+    target = tmp_path / "elsewhere.hsaco"
+    target.write_bytes(real)
+    os.remove(good / name)
+    os.symlink(target, good / name)
+    size3, msg, _, _ = _emit(pot, prob, z, pi, True)
+    assert size3 == size, msg
+    assert not os.path.islink(good / name)                                # (rename() replaced the link by the freshly built file)
+    # 3. a directory open to others is not used at all: nothing is read from it and nothing written into it
+    loose = tmp_path / "loose"
+    loose.mkdir()
+    os.chmod(loose, 0o777)
+    (loose / name).write_bytes(b"\x7fELF" + b"\0" * 5000)
+    monkeypatch.setenv("MISTARK_RTC_CACHE", str(loose))
+    size4, msg, _, _ = _emit(pot, prob, z, pi, True)
+    assert size4 == size, msg
+    assert os.listdir(loose) == [name] and (loose / name).read_bytes()[:8] != b"MISRTC02"
+    # 4. a symlinked directory likewise
+    link = tmp_path / "link"
+    os.symlink(good, link)
+    monkeypatch.setenv("MISTARK_RTC_CACHE", str(link))
+    before = sorted(os.listdir(good))
+    size5, msg, _, _ = _emit(pot, prob, z, pi, True)
+    assert size5 == size and sorted(os.listdir(good)) == before
 
 
 def test_a_sequence_that_overwrites_an_input_is_refused_with_a_message():
