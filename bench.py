@@ -209,6 +209,40 @@ def pinned_placement_run(S, capi, nx, ny, nz, device, steps, warmup, with_cpu):
     return out
 
 
+EXTRA_WINDOWS = 2   # further windows of `steps` Newton iterations behind the headline one (N = 1), each from the same start state
+
+
+def extra_windows(S, capi, nx, ny, nz, device, scene, offset, steps, warmup, first):
+    """`value` is the FIRST window (the contract's W warm-up + K timed iterations). A window of 20 iterations is 0.12 s against a box-to-box and
+    run-to-run spread of a few percent, so the line also carries EXTRA_WINDOWS more windows measured the same way, each on a freshly
+    built scene (the same start state: the run is deterministic, every window executes the same Newton iterations) and their median."""
+    import statistics
+
+    import torch
+    vals, iters = [first["value"]], [first["newton_iterations"]]
+    ms_solve = [first["ms_per_linear_solve"]]
+    for _ in range(EXTRA_WINDOWS):
+        sim = build_scene(S, nx, ny, nz, device, scene, offset=offset)
+        if warmup > 0:
+            run_newton_steps(sim, S, capi, warmup)
+        else:
+            sim.prepare()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        newton, n_ls, n_cg, t_ls = run_newton_steps(sim, S, capi, steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        sim.close()
+        vals.append(newton / el)
+        iters.append(newton)
+        ms_solve.append(1e3 * t_ls / max(n_ls, 1))
+    return {"values": [round(v, 3) for v in vals], "median": round(statistics.median(vals), 3), "min": round(min(vals), 3), "max": round(max(vals), 3),
+            "spread_rel": round((max(vals) - min(vals)) / statistics.median(vals), 4), "newton_iterations": iters,
+            "ms_per_linear_solve": [round(v, 4) for v in ms_solve], "windows": len(vals),
+            "what": "window 0 is `value` (driver-timed contract); windows 1.. = the same W warm-up + K timed Newton iterations on a freshly built scene "
+                    "(same start state, same iterations), timed between device synchronisations"}
+
+
 def secondary_run(S, capi, device, steps, warmup, set_dist, barrier, dist, torch, one_device=False, world=1):
     """The same scene at HBM_GRID on the ranks of this run: `steps` Newton iterations after `warmup`, timed like the headline figure (barrier
     + synchronisation on both sides, maximum over the ranks). Returns (dict, sim) — the caller closes the scene."""
@@ -264,7 +298,8 @@ def hbm_resident_pass(S, capi, device, steps, warmup, torch):
 # Keys of the one JSON line (tests/test_bench_cli_cpu.py pins them; tests/test_gpu_multiprocess.py checks a real N > 1 line against them).
 LINE_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
              "preflight", "peer_latency_us", "rccl", "stages_ms_per_newton_iteration", "ms_per_linear_solve", "cg_iterations_per_solve", "linear_solves",
-             "cg_iterations", "sharded_cg_kernels_us", "newton_iterations", "host_timers_s", "contact", "roofline", "cpu_baseline"]
+             "cg_iterations", "sharded_cg_kernels_us", "newton_iterations", "host_timers_s", "contact", "roofline", "cpu_baseline", "value_windows"]
+VALUE_WINDOWS_KEYS = ["values", "median", "min", "max", "spread_rel", "newton_iterations", "ms_per_linear_solve", "windows"]
 RCCL_LEG_KEYS = ["ranks", "allreduce_ndofs_us", "allreduce_3_us"]                      # always present, null when the leg was refused or failed
 STAGE_TABLE_KEYS = ["measured", "model", "model_one_gpu", "model_speedup", "measured_over_model"]
 STAGE_KEYS = ["linear_solve", "evaluation_assembly_projection", "contact_callbacks", "total"]
@@ -727,6 +762,9 @@ def main():
     rccl_leg = None
     stages_table = None
     rccl_hung = False
+    if world == 1:
+        # the one-GPU column of the scaling table, measured (GPU-event stage timers of this run) beside DESIGN.md's model of it
+        stages_table = stage_table([{k: 1e3 * v / max(newton, 1) for k, v in stage.items()}], 1, newton, n_ls, n_cg, None, 1e3 * elapsed / max(newton, 1))
     if world > 1:
         # per-stage milliseconds per Newton iteration as measured in this run (GPU-event stage timers of every rank, the slowest rank counts)
         # beside the model DESIGN.md ("Multi-GPU") derives the expected scaling from
@@ -848,8 +886,17 @@ def main():
                 "profile_agreement": (basis_ms / trace_ms) if (default_workload and trace_ms and basis_ms) else None,
             },
         }
-        if default_workload and offset == (0.0, 0.0) and not a.no_extras:
+        out["value_windows"] = None
+        if world == 1 and not a.no_extras:
             sim.close()
+            sim = None
+            try:
+                out["value_windows"] = extra_windows(S, capi, nx, ny, nz, device, a.scene, offset, a.steps, a.warmup, out)
+            except Exception as e:  # noqa: BLE001
+                out["value_windows"] = {"unavailable": repr(e)}
+        if default_workload and offset == (0.0, 0.0) and not a.no_extras:
+            if sim is not None:
+                sim.close()
             sim = None
             try:
                 hb, sec = hbm_resident_pass(S, capi, device, a.steps, a.warmup, torch)

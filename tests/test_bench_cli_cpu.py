@@ -76,3 +76,35 @@ def test_line_keys_are_what_the_source_prints():
     body = src[src.index("        out = {\n            \"metric\""):src.index("        print(json.dumps(out))")]
     for k in b.LINE_KEYS:
         assert ('            "%s":' % k) in body or ('out["%s"]' % k) in body, k
+
+
+def test_one_gpu_line_has_a_measured_stage_column_and_value_windows(monkeypatch):
+    """N = 1 fills `stages_ms_per_newton_iteration.measured` (the one-GPU column of the scaling table exists as a measurement,
+    not only as a model) and carries `value_windows` — window 0 is `value`, further windows on freshly built scenes, and their median."""
+    b = _bench()
+    stage = {"newton": 0.12, "linear_solve": 0.08, "eval_pgh": 0.012, "eval_p": 0.004, "project": 0.003, "assembly": 0.002, "callback": 0.012, "step": 0.121}
+    t = b.stage_table([{k: 1e3 * v / 20 for k, v in stage.items()}], 1, 20, 71, 2100, None, 6.0)
+    assert all(k in t for k in b.STAGE_TABLE_KEYS) and all(k in t["measured"] for k in b.STAGE_KEYS)
+    assert t["model_speedup"] == 1.0 and t["largest_element_share"] == 1.0 and abs(t["measured"]["linear_solve"] - 4.0) < 1e-9
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "if world == 1:\n        # the one-GPU column of the scaling table, measured" in src
+
+    # value_windows from a stand-in scene (no GPU): three windows, the first is the headline's
+    class Info:
+        total_newton_iterations = 0
+    calls = []
+
+    class Sim:
+        def close(self):
+            calls.append("close")
+
+    monkeypatch.setattr(b, "build_scene", lambda *a, **k: Sim())
+    seq = iter([(20, 70, 2000, 0.07), (5, 1, 1, 0.0), (20, 72, 2100, 0.08)] * 2)
+    monkeypatch.setattr(b, "run_newton_steps", lambda sim, S, capi, n: (n, 70, 2000, 0.07))
+    import types
+    fake_torch = types.SimpleNamespace(cuda=types.SimpleNamespace(synchronize=lambda: None))
+    monkeypatch.setitem(sys.modules, "torch", fake_torch)
+    w = b.extra_windows(None, None, 44, 44, 43, 0, "contact", (0.0, 0.0), 20, 5, {"value": 160.0, "newton_iterations": 20, "ms_per_linear_solve": 1.13})
+    assert all(k in w for k in b.VALUE_WINDOWS_KEYS)
+    assert w["windows"] == 1 + b.EXTRA_WINDOWS == len(w["values"]) and w["values"][0] == 160.0 and w["min"] <= w["median"] <= w["max"]
+    assert calls == ["close"] * b.EXTRA_WINDOWS
