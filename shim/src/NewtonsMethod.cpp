@@ -180,6 +180,11 @@ namespace symx
 				          << " in-loop edits it missed), " << bytes_sent / 1e6 << " MB sent to the engine; of " << t_solve
 				          << " s in solve(): " << t_callbacks << " s in the caller's callbacks, " << t_sync << " s in sync() (" << t_tables << " table updates, " << t_hash << " array fingerprints, " << t_upload << " array uploads), " << t_dofs
 				          << " s bringing DoFs to the caller" << std::endl;
+			if (ctx && std::getenv("MISTARK_SHIM_STATS")) {
+				int64_t ok = 0, bad = 0;
+				if (mistark_get_counter(ctx, "host_ranges_pinned", &ok) == 0 && mistark_get_counter(ctx, "host_ranges_not_pinned", &bad) == 0)
+					std::cerr << "mistark shim: " << ok << " host arrays page-locked in place, " << bad << " left pageable" << std::endl;
+			}
 			if (ctx && std::getenv("MISTARK_SHIM_STATS") && std::getenv("MISTARK_VERIFY_DOF_SKIP")) {
 				int64_t n = 0;
 				if (mistark_get_counter(ctx, "dof_skips_verified", &n) == 0) std::cerr << "mistark shim: " << n << " skipped DoF transfers verified against a real transfer" << std::endl;
@@ -202,6 +207,11 @@ namespace symx
 				const char* dev = std::getenv("MISTARK_DEVICE");
 				const int rc = mistark_create(dev ? std::atoi(dev) : 0, &ctx);
 				if (rc != 0) throw std::runtime_error("mistark shim: mistark_create failed (" + std::to_string(rc) + "): no MI355X visible; the hot path has no CPU fallback");
+				// MISTARK_SHIM_PIN=1: the caller's DoF and state arrays are page-locked where they are (engine option pin_host_arrays: checked
+				// hipHostRegister, released on rebind and with the context). Measured at 1 M tets (round 6, profiles/r06_dropin_pin{0,1}.txt): no gain —
+				// 4.1 MB of DoFs reach the caller in 0.18 ms either way (23 GB/s: the link, not the staging copy, is the limit) — so it stays off.
+				const char* pin = std::getenv("MISTARK_SHIM_PIN");
+				if (pin && pin[0] == '1') check(mistark_set_option(ctx, "pin_host_arrays", 1), "pin_host_arrays");
 			}
 		}
 

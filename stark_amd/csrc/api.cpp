@@ -258,6 +258,7 @@ int mistark_resize_dof_set(mistark_ctx* ctx, int set, double* host, int64_t n_sc
     if (n_scalars > 0 && !host) throw Error("DoF set without a host array");
     Context& c = ctx->c;
     const double* old = c.dof_sets[set].host;
+    if (old != host || c.dof_sets[set].n != n_scalars) host_range_unpin(c, old);
     c.dof_sets[set].host = host;
     c.dof_sets[set].n = n_scalars;
     for (auto& a : c.arrays)
@@ -329,6 +330,11 @@ int mistark_array_rebind(mistark_ctx* ctx, int array, const double* host, int64_
     if (array < 0 || array >= (int)c.arrays.size()) throw Error("bad array id");
     Array& a = c.arrays[array];
     if (a.dof_set >= 0) throw Error("use mistark_resize_dof_set for DoF arrays");
+    if (a.host != host || a.n_items != n_items) {
+        bool shared = false;  // (another array — the same container bound at another stride — may still be on the old range)
+        for (const Array& o : c.arrays) shared = shared || (&o != &a && o.host == a.host);
+        if (!shared) host_range_unpin(c, a.host);
+    }
     a.host = host;
     a.n_items = n_items;
     a.need_upload = true;
@@ -552,6 +558,8 @@ int mistark_get_counter(mistark_ctx* ctx, const char* name, int64_t* out)
     else if (n == "proj_adopted") *out = c.n_proj_adopted;
     else if (n == "multi_pgh_launches") *out = c.n_multi_pgh;
     else if (n == "dof_skips_verified") *out = c.n_dof_skips_verified;
+    else if (n == "host_ranges_pinned") *out = c.n_pin_ok;
+    else if (n == "host_ranges_not_pinned") *out = c.n_pin_failed;
     else if (n == "rtc_builds") *out = c.n_rtc_builds;
     else if (n == "custom_kernel_us") *out = (int64_t)c.custom_kernel_us;
     else if (n == "rtc_launches") *out = c.n_rtc_launches;
@@ -577,7 +585,10 @@ int mistark_dofs_to_host_arrays(mistark_ctx* ctx)
     Context& c = ctx->c;
     prepare(c);
     for (auto& s : c.dof_sets)
-        if (s.n > 0) MS_CHECK(hipMemcpyAsync(s.host, c.u.p + s.offset, s.n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        if (s.n > 0) {
+            (void)host_range_pinned(c, s.host, (size_t)s.n * sizeof(double));
+            MS_CHECK(hipMemcpyAsync(s.host, c.u.p + s.offset, s.n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+        }
     MS_CHECK(hipStreamSynchronize(c.stream));
     c.u_host_version = c.u_version;
     API_END(0)
@@ -589,7 +600,10 @@ int mistark_dofs_to_host_arrays_if_changed(mistark_ctx* ctx)
     prepare(c);
     if (c.u_host_version != c.u_version) {
         for (auto& s : c.dof_sets)
-            if (s.n > 0) MS_CHECK(hipMemcpyAsync(s.host, c.u.p + s.offset, s.n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+            if (s.n > 0) {
+                (void)host_range_pinned(c, s.host, (size_t)s.n * sizeof(double));
+                MS_CHECK(hipMemcpyAsync(s.host, c.u.p + s.offset, s.n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+            }
         MS_CHECK(hipStreamSynchronize(c.stream));
         c.u_host_version = c.u_version;
     } else {
@@ -621,7 +635,10 @@ int mistark_dofs_from_host_arrays(mistark_ctx* ctx)
     Context& c = ctx->c;
     prepare(c);
     for (auto& s : c.dof_sets)
-        if (s.n > 0) MS_CHECK(hipMemcpyAsync(c.u.p + s.offset, s.host, s.n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+        if (s.n > 0) {
+            (void)host_range_pinned(c, s.host, (size_t)s.n * sizeof(double));
+            MS_CHECK(hipMemcpyAsync(c.u.p + s.offset, s.host, s.n * sizeof(double), hipMemcpyHostToDevice, c.stream));
+        }
     MS_CHECK(hipStreamSynchronize(c.stream));
     API_END(0)
 }
@@ -1238,6 +1255,8 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "llt_multifrontal") ctx->c.llt_multifrontal = value;
     else if (n == "llt_no_coords") { ctx->c.llt_no_coords = value != 0; ctx->c.llt_mf_pattern_version = 0; }
     else if (n == "pcg_holdback") ctx->c.pcg_holdback = value != 0;
+    else if (n == "pin_host_arrays") ctx->c.pin_host_arrays = value != 0;
+    else if (n == "generic_inertia") ctx->c.generic_inertia = value != 0;
     else if (n == "contact_closed_min_lanes") ctx->c.contact_closed_min_lanes = value;
     else if (n == "atomic_assembly") ctx->c.atomic_assembly = value != 0;
     else if (n == "spmv_grid_cap") ctx->c.spmv_grid_cap = value;

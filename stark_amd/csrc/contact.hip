@@ -1864,14 +1864,48 @@ int find_table(const char* name)
 // One private context with a contact system that has no tables: every mesh counts as deformable and nothing is filtered by thickness, so the
 // six barrier tables of the deformable family ARE tmcd's six lists (table_of(family, 0, 0)); the sorted keys come back to the host and are
 // expanded into rows there.
+// A host buffer the device transfers into / out of directly: page-locked (hipHostMalloc), grown geometrically, contents NOT kept across a
+// growth. The standalone detector gathers the caller's positions into one (the upload is then a single DMA instead of a copy through HIP's
+// staging buffer) and reads its key list back into another.
+template <class T>
+struct PinnedBuf
+{
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    ~PinnedBuf()
+    {
+        if (p) (void)hipHostFree(p);
+    }
+    void resize(size_t m)
+    {
+        if (m > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            cap = std::max(m + m / 4, (size_t)1024);
+            MS_CHECK(hipHostMalloc((void**)&p, cap * sizeof(T)));
+        }
+        n = m;
+    }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    T* begin() { return p; }
+    T* end() { return p + n; }
+};
 struct StandaloneDetector
 {
     Context c;
     std::vector<const double*> xm;
-    std::vector<double> X;
+    PinnedBuf<double> X;
     std::vector<int32_t> rows[6], et_rows;
     std::vector<double> dist[6];
-    std::vector<uint64_t> keys;
+    PinnedBuf<uint64_t> keys;
     std::string last_error;
     // A caller asks again at unchanged positions more often than not (the reference's contact class searches at every energy evaluation: the
     // accepted line-search candidate's evaluation and the evaluation that opens the next Newton iteration see the same vertices): the

@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <stdexcept>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -321,6 +322,7 @@ struct Context
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather
     bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path
     bool pcg_holdback = false;     // pcg(): no look-ahead batch while the batch in flight is expected to converge (measured: 1.150 against 1.140 ms per solve, off)
+    bool generic_inertia = false;  // ... EnergyLumpedInertia only (its closed form: k_eval_lumped_inertia)
     bool generic_contact = false;  // ... the contact / friction potentials only (their closed forms: contact_closed.hpp)
     int contact_closed_min_lanes = -1;  // closed forms for tables with at least this many (element, DoF pair) lanes; -1: by potential (launch_eval)
     DevBuf<uint8_t> cub_tmp;
@@ -354,6 +356,18 @@ struct Context
     double* h_scratch = nullptr;    // pinned host scratch
     void* h_pin = nullptr;          // pinned staging area of fetch()
     void* h_stage[2] = {nullptr, nullptr};  // pinned staging areas of h2d_staged() (uploads of the caller's pageable arrays)
+    // Option "pin_host_arrays" (a drop-in's shim turns it on): the caller's large arrays — DoF sets and bound arrays, whose addresses the engine keeps
+    // anyway — are page-locked in place (hipHostRegister, checked) so that transfers to and from them are direct DMA instead of copies through a
+    // staging buffer (4 MB of DoFs to the caller before every callback: 0.2 ms pageable). Registered once per (address, size); released when the
+    // array is rebound / resized and at destruction; a range that cannot be registered stays pageable (ok = false, not retried).
+    struct PinnedRange
+    {
+        size_t bytes = 0;
+        bool ok = false;
+    };
+    std::map<const void*, PinnedRange> pinned;
+    bool pin_host_arrays = false;
+    int64_t n_pin_ok = 0, n_pin_failed = 0;
     void* h_small[4] = {nullptr, nullptr, nullptr, nullptr};  // pinned slots of small uploads of host temporaries (kernels.hip: h2d_small)
     hipEvent_t h_small_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned h_small_next = 0;
@@ -571,6 +585,9 @@ void fetch(Context& c, void* dst_host, const void* src_dev, size_t bytes);
 // the range inside every copy (1.5 ms for 4 MB measured); a memcpy into pinned memory and a DMA transfer take a quarter of that. The source
 // may be reused when the call returns; the copy is ordered on c.stream like any other.
 void h2d_staged(Context& c, void* dst_dev, const void* src_host, size_t bytes);
+// option pin_host_arrays: is [host, host + bytes) page-locked (registering it now if it is large enough and not yet known)?
+bool host_range_pinned(Context& c, const void* host, size_t bytes);
+void host_range_unpin(Context& c, const void* host);
 // fills and device-to-device copies as kernels of our own (kernels.hip: the runtime's blit path costs the host 10-25 us per call); a FillQueue
 // collects up to FILL_BATCH_MAX regions (4-byte aligned, multiples of 4 bytes) into ONE launch: add(), add(), ..., flush()
 constexpr int FILL_BATCH_MAX = 8;

@@ -761,6 +761,59 @@ static void launch_bending_flat(Context& c, Potential& P, int mode)
         hipLaunchKernelGGL((k_eval_bending_flat<true>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
     launch_grad_gather(c, P);
 }
+// EnergyLumpedInertia, one lane per node (EnergyLumpedInertia.cpp:12-49). The energy is quadratic in v1 and its Hessian diagonal
+// (d2E/dv1^2 = m (1 + damping dt) I3; nothing for a quasi-static group), so the six (i <= j) lanes of the generic kernel — each gathering the
+// node's 23 inputs — compute three zeros and three times the same work. Here a lane gathers once and runs the SAME hyper-dual expression for
+// (i, i), i = 0, 1, 2 (seeds at run time, one loop body: the instruction sequence of the generic kernel's diagonal lanes, hence its bits — a
+// hand-derived gradient differs in the last bit, which the long contact / attachment runs amplify into other Newton counts, see
+// tests/test_attach_by_distance.py); the off-diagonal entries are the zeros the generic lanes computed. configs[3]: 172 k nodes, 59 -> ~10 us
+// inside an evaluation.
+template <bool STORE_H>
+__global__ __launch_bounds__(BLOCK) void k_eval_lumped_inertia(PotArgs a, double* __restrict__ elemE, double* __restrict__ elemH, double* __restrict__ grad)
+{
+    using En = E_LumpedInertia;
+    const int le = blockIdx.x * BLOCK + threadIdx.x;
+    if (le >= a.e_count) return;
+    const int e = elem_of(a, le), pe = pool_of(a, le);
+    double in[En::Layout::NIN];
+    gather_inputs<En>(a, e, in);
+    double g[3], h[3], E = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < 3; i++) {
+        Loader<HDual> L{in, i, i};
+        const HDual r = En::energy(L);
+        g[i] = r.a;
+        h[i] = r.ab;
+        if (i == 0) E = r.v;
+    }
+    elemE[pe] = energy_here(a, e) ? E : 0.0;
+    if (a.gpool) {
+        double* gp = a.gpool + (size_t)pe * 3;
+        gp[0] = g[0]; gp[1] = g[1]; gp[2] = g[2];
+    } else {
+        const int node = a.conn[(size_t)e * a.conn_stride + a.dof_col[0]];
+        double* o = a.hot_base[0] >= 0 ? &a.grad_hot[((size_t)(blockIdx.x & (HOT_WAYS - 1)) * a.n_hot + a.hot_base[0] + node) * 3] : &grad[3 * (size_t)(a.dof_row_off[0] + node)];
+        atomicAdd(o, g[0]);
+        atomicAdd(o + 1, g[1]);
+        atomicAdd(o + 2, g[2]);
+    }
+    if (STORE_H) {
+        double* H = elemH + (size_t)pe * 9;
+        H[0] = h[0]; H[1] = 0.0;  H[2] = 0.0;
+        H[3] = 0.0;  H[4] = h[1]; H[5] = 0.0;
+        H[6] = 0.0;  H[7] = 0.0;  H[8] = h[2];
+    }
+}
+static void launch_lumped_inertia(Context& c, Potential& P, int mode)
+{
+    if (P.args.e_count == 0) return;
+    double* E = c.elemE.p + P.e_off;
+    if (mode == MISTARK_EVAL_P_G)
+        hipLaunchKernelGGL((k_eval_lumped_inertia<false>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, (double*)nullptr, c.grad.p);
+    else
+        hipLaunchKernelGGL((k_eval_lumped_inertia<true>), dim3(grid_for(P.args.e_count)), dim3(BLOCK), 0, c.stream, P.args, E, c.elemH.p + P.h_off, c.grad.p);
+    launch_grad_gather(c, P);
+}
 template <class En, bool FULL>
 static void launch_tet_closed(Context& c, Potential& P, int mode, bool kernel_only = false, bool gather_only = false, double* E_override = nullptr)
 {
@@ -870,6 +923,7 @@ static void launch_eval_kind(Context& c, Potential& P, int mode)
         if (P.name == E_TetStrain::name) { launch_tet_closed<E_TetStrain, true>(c, P, mode); return; }
         if (P.name == E_TetStrainEO::name) { launch_tet_closed<E_TetStrainEO, false>(c, P, mode); return; }
         if (P.name == E_BendingFlat::name) { launch_bending_flat(c, P, mode); return; }
+        if (P.name == E_LumpedInertia::name && !c.generic_inertia) { launch_lumped_inertia(c, P, mode); return; }
         if (P.name == E_TriangleStrain::name) { launch_tri_closed<E_TriangleStrain, true>(c, P, mode); return; }
         if (P.name == E_TriangleStrainEO::name) { launch_tri_closed<E_TriangleStrainEO, false>(c, P, mode); return; }
     }
@@ -1116,9 +1170,40 @@ static bool publish(Context& c, void* dst_host, const void* src_dev, size_t byte
     std::memcpy(dst_host, c.pub, bytes);
     return true;
 }
+bool host_range_pinned(Context& c, const void* host, size_t bytes)
+{
+    constexpr size_t MIN_BYTES = (size_t)128 << 10;  // (below: HIP's own staging path costs less than a registration is worth)
+    if (!c.pin_host_arrays || c.dry || !host || bytes < MIN_BYTES) return false;
+    auto it = c.pinned.find(host);
+    if (it != c.pinned.end()) {
+        if (it->second.bytes == bytes) return it->second.ok;
+        if (it->second.ok) (void)hipHostUnregister(const_cast<void*>(host));  // (the same address at another size: registered anew)
+        (void)hipGetLastError();
+        c.pinned.erase(it);
+    }
+    const hipError_t e = hipHostRegister(const_cast<void*>(host), bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) (void)hipGetLastError();  // (overlaps another registration, not the caller's to lock, limits: the range stays pageable)
+    c.pinned[host] = Context::PinnedRange{bytes, e == hipSuccess};
+    (e == hipSuccess ? c.n_pin_ok : c.n_pin_failed)++;
+    return e == hipSuccess;
+}
+void host_range_unpin(Context& c, const void* host)
+{
+    auto it = c.pinned.find(host);
+    if (it == c.pinned.end()) return;
+    if (it->second.ok) {
+        (void)hipHostUnregister(const_cast<void*>(host));  // (the caller may have freed the range already: the error is not ours to report)
+        (void)hipGetLastError();
+    }
+    c.pinned.erase(it);
+}
 void h2d_staged(Context& c, void* dst_dev, const void* src_host, size_t bytes)
 {
     constexpr size_t CHUNK = (size_t)4 << 20;
+    if (host_range_pinned(c, src_host, bytes)) {  // page-locked in place: one direct transfer
+        MS_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c.stream));
+        return;
+    }
     if (bytes < ((size_t)1 << 16)) {  // (small: HIP copies these through its own staging buffer without pinning anything)
         MS_CHECK(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c.stream));
         return;

@@ -2749,6 +2749,9 @@ Context::~Context()
         if (h_small[k]) (void)hipHostFree(h_small[k]);
         if (h_small_ev[k]) (void)hipEventDestroy(h_small_ev[k]);
     }
+    for (auto& kv : pinned)  // (option pin_host_arrays: the caller's arrays are the caller's again)
+        if (kv.second.ok) (void)hipHostUnregister(const_cast<void*>(kv.first));
+    (void)hipGetLastError();
     for (hipEvent_t e : evt)  // (MISTARK_EVAL_EVENTS marks, kernels.hip evt_mark)
         if (e) (void)hipEventDestroy(e);
     for (auto e : ev) (void)hipEventDestroy(e);

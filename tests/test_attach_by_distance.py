@@ -191,6 +191,7 @@ def test_add_by_distance_scene_trajectory_with_the_lane_per_block_gather_takes_t
     tri = z["p%d_conn" % names.index("EnergyTriangleStrain")]
     cloth_tri = tri[tri[:, 2:5].max(axis=1) < (sc["n"] + 1) ** 2][:, 2:5]
     sim, box, h3, hb = build(S, sc, cloth_tri, 0)
+    sim.prepare()                      # (the engine exists from here on)
     L = sim.L
     L.mistark_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
     for opt in (b"no_split_gather", b"no_sym_gather"):

@@ -620,3 +620,32 @@ def test_projection_updates_the_matrix_in_order(name, lazy):
     assert all((x == y).all() for x, y in zip(a, b))               # run to run
     scale = np.abs(a[2]).max()
     assert np.abs(d[1] - a[1]).max() <= 64 * np.finfo(np.float32).eps * scale and np.abs(d[0] - a[0]).max() <= 64 * np.finfo(np.float32).eps * scale
+
+
+@pytest.mark.parametrize("name", ["tetbeam_softrubber_6x2x2", "tetbeam_eo_8x2x2", "cloth_shells_6", "attachzoo"])
+def test_lumped_inertia_one_lane_per_node_has_the_generic_kernels_bits(name):
+    """k_eval_lumped_inertia (one lane per node: inputs gathered once, the hyper-dual expression run for the three diagonal pairs) against the
+    generic kernel (six lanes per node; option generic_inertia): the SAME element energies, element Hessians and — on a problem holding only
+    that potential's contribution per row beside others summed identically — the same energy and gradient, bit for bit. A hand-derived gradient
+    differs in its last bit, and the attachment / contact trajectories amplify that into other Newton counts (round 6)."""
+    from gpu_util import engine_from_problem
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    pi = [p.name for p in prob.potentials].index("EnergyLumpedInertia")
+    n_elem = prob.potentials[pi].conn.shape[0]
+    out = []
+    for generic in (0, 1):
+        eng = engine_from_problem(prob, man)
+        eng.set_option("generic_inertia", generic)
+        E, g = eng.eval(capi.EVAL_P_G_H)
+        H, rows = eng.element_hessians(eng.pot_ids[pi] if hasattr(eng, "pot_ids") else pi, n_elem)
+        E2, g2 = eng.eval(capi.EVAL_P_G)
+        out.append((E, g, H, rows, E2, g2))
+        eng.close()
+    a, b = out
+    assert (a[3] == b[3]).all() and (a[2] == b[2]).all() and np.abs(a[2]).max() > 0
+    # energy and gradient: the inertia's node gradients are single additions per row; the other potentials' sums are the same kernels in both runs
+    assert a[0] == b[0] and a[4] == b[4]
+    assert np.abs(a[1] - b[1]).max() <= 4 * np.finfo(np.float64).eps * np.abs(b[1]).max()
+    assert np.abs(a[5] - b[5]).max() <= 4 * np.finfo(np.float64).eps * np.abs(b[5]).max()
