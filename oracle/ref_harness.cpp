@@ -569,6 +569,14 @@ static Scene scene_clothbox(const Args& a)
     gp.min_contact_stiffness = a.d("kmin", gp.min_contact_stiffness);
     sim.interactions->contact->set_global_params(gp);
     auto [cV, cT, cloth] = sim.presets->deformables->add_surface_grid("cloth", { size, size }, { n, n }, stark::Surface::Params::Cotton_Fabric());
+    // tilt (degrees about y through the cloth's centre; round 6): the cloth's lowest edge stays `gap` above the box's top face, the rest rises to
+    // gap + size sin(tilt). A flat cloth dropped parallel to the floor can pass through it between two steps unnoticed (no CCD in this contact
+    // model; the intersection check only sees edges that cross the surface); a tilted one straddles the surface whenever it penetrates.
+    const double tilt = a.d("tilt", 0.0);
+    if (tilt != 0.0) {
+        cloth.point_set.add_rotation(tilt, Eigen::Vector3d::UnitY());
+        cloth.point_set.add_displacement({ 0.0, 0.0, 0.5 * size * std::sin(std::abs(tilt) * M_PI / 180.0) });
+    }
     sc.record_deformable(cloth.point_set, cT, cloth.point_set.all(), th);
     auto [bV, bT, box] = sim.presets->rigidbodies->add_box("box", 1.0, bs);
     sc.record_rigid(box.rigidbody, (int)bV.size(), bT, th);
@@ -587,7 +595,7 @@ static Scene scene_clothbox(const Args& a)
     }
     std::ostringstream js;
     js << "{\"kind\":\"clothbox\",\"spin\":" << spin << ",\"n\":" << n << ",\"thickness\":" << th << ",\"gap\":" << gap << ",\"mu\":" << mu << ",\"size\":" << size << ",\"box\":" << bs
-       << ",\"kmin\":" << gp.min_contact_stiffness << ",\"ox\":" << ox << ",\"oy\":" << oy << "}";
+       << ",\"kmin\":" << gp.min_contact_stiffness << ",\"ox\":" << ox << ",\"oy\":" << oy << ",\"tilt\":" << tilt << "}";
     sc.json = js.str();
     return sc;
 }

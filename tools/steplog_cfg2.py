@@ -9,7 +9,7 @@ sys.path.insert(0, ".")
 from stark_amd import sim as S
 
 
-def build(gap=0.05, n=256, size=1.0, box=2.0, thickness=1e-3, mu=0.5, dt=None):
+def build(gap=0.05, n=256, size=1.0, box=2.0, thickness=1e-3, mu=0.5, dt=None, tilt=0.0):
     st = S.default_settings()
     if dt is not None:
         st.max_time_step_size = dt
@@ -20,6 +20,10 @@ def build(gap=0.05, n=256, size=1.0, box=2.0, thickness=1e-3, mu=0.5, dt=None):
     gp.default_contact_thickness = thickness
     sim.set_contact_global_params(gp)
     ps = sim.add_surface_grid("cloth", (size, size), (n, n), S.cotton_fabric())
+    if tilt != 0.0:   # (oracle/ref_harness.cpp scene_clothbox `tilt`: lowest edge `gap` above the floor, the cloth rising from there)
+        import math
+        sim.point_set_add_rotation(ps, tilt, (0.0, 1.0, 0.0))
+        sim.point_set_add_displacement(ps, (0.0, 0.0, 0.5 * size * math.sin(abs(tilt) * math.pi / 180.0)))
     rb = sim.add_rigid_box("box", 1.0, (box, box, box))
     sim.rb_add_translation(rb, (0.0, 0.0, -0.5 * box - gap))
     sim.rb_add_constraint("fix", rb)
