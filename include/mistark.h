@@ -305,6 +305,9 @@ int mistark_newton_solve(mistark_ctx* ctx, const mistark_newton_settings* settin
  * closed-form kernels are then cross-checked against them; "generic_contact" = the same for the contact and friction potentials only;
  * "contact_closed_min_lanes" = N: closed-form contact kernels for tables with at least N (contact, DoF pair) lanes, 0 = always, default
  * -1 = by potential, see launch_eval);
+ * "generic_inertia" = EnergyLumpedInertia through the generic kernel (six lanes per node; default: one lane per node, the same bits);
+ * "pin_host_arrays" = page-lock the caller's large DoF and bound arrays where they are (hipHostRegister, checked; released when an array is
+ * rebound or resized and with the context; a range that cannot be locked stays pageable) so that transfers to and from them are direct DMA;
  * "atomic_assembly" = scatter assembly with float atomics
  * instead of the deterministic gather; "proj_variant" = PSD projection cross-checks, bits: 1 = eigen-decomposition with the
  * matrix in LDS instead of registers, 2 = one launch per potential instead of one for all short lists, 4 = IEEE division /

@@ -94,6 +94,13 @@ FIXTURES = {
     # configs[2] as BASELINE describes it — a 256 x 256 Cotton_Fabric cloth DROPPED on a fixed floor from 5 cm (z = 0.05, 60 time
     # steps; free fall, impact around the fourth step, settling under IPC contact + friction): the reference's per-step log with 8 and with 4 threads
     "steplog_cfg2_clothbox_drop_256": ("steplog", "clothbox", "n=256 size=1 box=2 gap=0.05 thickness=0.001 mu=0.5 steps=60"),
+    # configs[2] as a WELL-POSED dynamic scene (round 6): the same cloth tilted 3 degrees about y, its lowest edge 2 mm above the
+    # floor (the contact distance), released. A tilted cloth straddles the floor's surface whenever it penetrates, so the reference's intersection
+    # check sees it (the flat cloth of the 5 cm drop passes through between two steps). Logs of the reference with 8 and with 4 threads and the
+    # sampled state after 10 steps of a third run (4 threads). The reference's runs of this scene are NOT reproducible: they either land in three
+    # steps of 32 / 56-61 / 45-59 Newton iterations and rest from the ninth step on, or take 37-38 iterations in the first step and then fail
+    # attempts and halve dt — which one a run takes changed between two invocations with the same thread count. The fixture holds both kinds.
+    "steplog_cfg2_tilted_256": ("steplog", "clothbox", "n=256 size=1 box=2 gap=0.002 tilt=3 thickness=0.001 mu=0.5 steps=30 traj_steps=10 traj_threads=4"),
     # what the reference WRITES for a run: its VTK frames, its YAML log and its run summary (tet beam, 2 time steps)
     "frames_tetbeam_4x1x1": ("frames", "tetbeam", "nx=4 ny=1 nz=1 eo=0 steps=2 frames=1"),
     # contact scenes (cfg 1 / cfg 4 at fixture size): cloth resting on a fixed rigid box, soft block pressed on a fixed rigid box
@@ -144,13 +151,18 @@ def pack(name):
         if mode != "geom":
             run([HARNESS, "prime", scene] + scene_args)
         if mode == "steplog":
+            # (traj_steps / traj_threads: how many steps, with how many threads, the run that dumps the sampled end state takes; default 2 / 8)
+            traj_steps = next((a.split("=")[1] for a in args if a.startswith("traj_steps=")), "2")
+            traj_threads = next((a.split("=")[1] for a in args if a.startswith("traj_threads=")), "8")
+            args = [a for a in args if not a.startswith("traj_")]
+            scene_args = [a for a in scene_args if not a.startswith("traj_")]
             data = {}
             for threads in (8, 4):
                 out = subprocess.run([HARNESS, "time", scene] + args + ["warmup=0", "threads=%d" % threads, "outdir=" + tmp], check=True, capture_output=True).stdout.decode()
                 txt = [l for l in out.splitlines() if l.startswith("{")][-1]
                 json.loads(txt)
                 data["time_t%d_json" % threads] = np.frombuffer(txt.encode(), dtype=np.uint8)
-            run([HARNESS, "traj", scene] + scene_args + ["steps=2", "slim=1", "threads=8", "out=" + tmp])  # (the first attempt ends in an invalid converged state: constraint hardening, the step is redone)
+            run([HARNESS, "traj", scene] + scene_args + ["steps=" + traj_steps, "slim=1", "threads=" + traj_threads, "out=" + tmp])  # (the first attempt ends in an invalid converged state: constraint hardening, the step is redone)
             txt = open(os.path.join(tmp, "traj.json")).read()
             json.loads(txt)
             data["traj_json"] = np.frombuffer(txt.encode(), dtype=np.uint8)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Newton-steps/s and host stage timers of the BASELINE configs other than the bench's (configs[0], [1], [2], [4]) on one GPU.
-Usage (GPU box): python tools/config_rates.py [cfg0] [cfg1] [cfg2] [cfg4]   -> one JSON line per config."""
+Usage (GPU box): python tools/config_rates.py [cfg0] [cfg1] [cfg2] [cfg2tilt] [cfg4]   -> one JSON line per config."""
 import json
 import os
 import sys
@@ -58,6 +58,15 @@ def cfg2():
     return sim, 10
 
 
+def cfg2tilt():
+    """configs[2] as a well-posed dynamic scene (round 6): the cloth tilted 3 degrees, lowest edge at the contact distance, released; the warm-up
+    step is the first landing step, the timed ones the two that follow and the settling (fixture steplog_cfg2_tilted_256)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from steplog_cfg2 import build
+
+    return build(0.002, tilt=3.0), 7
+
+
 def cfg4():
     from test_gpu_scene import _build_mixed
 
@@ -67,7 +76,7 @@ def cfg4():
 
 
 def main():
-    names = sys.argv[1:] or ["cfg0", "cfg1", "cfg2", "cfg4"]
+    names = sys.argv[1:] or ["cfg0", "cfg1", "cfg2", "cfg2tilt", "cfg4"]
     for name in names:
         sim, steps = globals()[name]()
         script = getattr(sim, "script", lambda: None)
@@ -87,6 +96,9 @@ def main():
             "newton_steps_per_s": round(d("total_newton_iterations") / wall, 2), "linear_solves": d("total_linear_solves"),
             "cg_iterations_per_solve": round(d("total_cg_iterations") / max(d("total_linear_solves"), 1), 1),
             "ms_per_linear_solve": round(1e3 * d("total_linear_solve_time") / max(d("total_linear_solves"), 1), 3),
+            # per-iteration costs: what stays comparable from round to round when another summation order sends a long contact run down another path
+            "ms_per_newton_iteration": round(1e3 * wall / n, 3), "us_per_cg_iteration": round(1e6 * d("total_linear_solve_time") / max(d("total_cg_iterations"), 1), 2),
+            "cg_iterations": d("total_cg_iterations"),
             "ms_per_newton": {k: round(1e3 * d("total_%s_time" % k) / n, 3) for k in ("newton", "linear_solve", "eval_pgh", "eval_p", "project", "assembly", "callback", "step")},
             "evaluations": d("total_evaluations"), "contact": sim.contact_info() if name != "cfg1" else None}))
         sim.close()
