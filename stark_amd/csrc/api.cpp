@@ -1255,6 +1255,7 @@ int mistark_set_option(mistark_ctx* ctx, const char* name, int value)
     else if (n == "llt_multifrontal") ctx->c.llt_multifrontal = value;
     else if (n == "llt_no_coords") { ctx->c.llt_no_coords = value != 0; ctx->c.llt_mf_pattern_version = 0; }
     else if (n == "pcg_holdback") ctx->c.pcg_holdback = value != 0;
+    else if (n == "sweep_axis_by_extent") ctx->c.sweep_axis_by_extent = value != 0;
     else if (n == "pin_host_arrays") ctx->c.pin_host_arrays = value != 0;
     else if (n == "generic_inertia") ctx->c.generic_inertia = value != 0;
     else if (n == "contact_closed_min_lanes") ctx->c.contact_closed_min_lanes = value;

@@ -1364,20 +1364,34 @@ void update_vertices(Context& c, ContactSystem& cs, const ContactDev& d, double 
 }
 void choose_axes(Context& c, ContactSystem& cs)
 {
-    // sweep axis = largest extent of the collision vertices, band axis = second largest; re-evaluated now and then (a stale choice
-    // only costs speed: band indices are clamped, monotone functions of the coordinate)
+    // sweep axis = the axis along which the collision vertices are spread widest, band axis = the second; re-evaluated now and then (a stale
+    // choice only costs speed: band indices are clamped, monotone functions of the coordinate). "Spread" is the VARIANCE of the vertices, not the
+    // extent of their bounding box (round 6): a 256 x 256 cloth over a 2 m cube has its largest extent along z — the cube's eight vertices —
+    // while 66 k of its 66 k + 8 vertices lie within 5 cm of one z; swept along z every cloth primitive met a thousand candidates per band
+    // (2.3-2.8 ms per sweep, 74 % of that scene's kernel time; along x: what the flat floor box of round 4's configs[2] took, 0.3-0.4 ms).
+    // The bands still cover the whole extent of their axis.
     if (cs.bands.axis >= 0 && (cs.n_updates % 256) != 0) return;
     std::vector<double> X(3 * (size_t)cs.n_v);
     MS_CHECK(hipMemcpyAsync(X.data(), cs.X.p, X.size() * sizeof(double), hipMemcpyDeviceToHost, c.stream));
     MS_CHECK(hipStreamSynchronize(c.stream));
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, sum[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
     for (int i = 0; i < cs.n_v; i++)
         for (int k = 0; k < 3; k++) {
-            lo[k] = std::min(lo[k], X[3 * (size_t)i + k]);
-            hi[k] = std::max(hi[k], X[3 * (size_t)i + k]);
+            const double v = X[3 * (size_t)i + k];
+            lo[k] = std::min(lo[k], v);
+            hi[k] = std::max(hi[k], v);
+            sum[k] += v;
+            sq[k] += v * v;
         }
+    double var[3];
+    for (int k = 0; k < 3; k++) {
+        const double m = sum[k] / std::max(cs.n_v, 1);
+        var[k] = std::max(sq[k] / std::max(cs.n_v, 1) - m * m, 0.0);
+        if (!(var[k] == var[k])) var[k] = 0.0;
+    }
     int order[3] = {0, 1, 2};
-    std::sort(order, order + 3, [&](int a, int b) { return hi[a] - lo[a] > hi[b] - lo[b]; });
+    if (c.sweep_axis_by_extent) std::sort(order, order + 3, [&](int a, int b) { return hi[a] - lo[a] > hi[b] - lo[b]; });
+    else std::stable_sort(order, order + 3, [&](int a, int b) { return var[a] > var[b]; });
     cs.bands.axis = order[0];
     cs.bands.band_axis = order[1];
     const double ext = std::max(hi[order[1]] - lo[order[1]], 1e-12);

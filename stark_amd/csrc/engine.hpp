@@ -322,6 +322,7 @@ struct Context
     bool atomic_assembly = false;  // debug switch: scatter with float atomics instead of the deterministic gather
     bool force_generic = false;    // debug switch: evaluate every potential through the generic hyper-dual path
     bool pcg_holdback = false;     // pcg(): no look-ahead batch while the batch in flight is expected to converge (measured: 1.150 against 1.140 ms per solve, off)
+    bool sweep_axis_by_extent = false;  // contact search: sweep / band axes by the extent of the vertices' bounding box (through round 5) instead of their variance
     bool generic_inertia = false;  // ... EnergyLumpedInertia only (its closed form: k_eval_lumped_inertia)
     bool generic_contact = false;  // ... the contact / friction potentials only (their closed forms: contact_closed.hpp)
     int contact_closed_min_lanes = -1;  // closed forms for tables with at least this many (element, DoF pair) lanes; -1: by potential (launch_eval)

@@ -16,4 +16,6 @@ for n in 2 8; do
   MISTARK_BENCH_DEVICE=0 timeout 900 python bench.py --gpus $n --no-cpu-baseline --no-extras > gpurun_out/r06_shard${n}_bench.json 2> gpurun_out/r06_shard${n}_bench.err
 done
 python tools/config_rates.py cfg0 cfg1 cfg2 cfg2tilt cfg4 2>&1 | grep "^{" > gpurun_out/r06_config_rates.jsonl
+rm -rf /tmp/pc2; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/pc2 -o r -- python tools/config_rates.py cfg2tilt > /dev/null 2>&1
+db=$(find /tmp/pc2 -name "*.db" | head -1); python profiles/summarize_rocpd.py $db | head -40 > gpurun_out/r06_cfg2tilt_kernel_stats.txt
 ls -la gpurun_out/r06_* gpurun_out/${tag}_*
