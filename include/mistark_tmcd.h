@@ -48,6 +48,13 @@ int mistark_cd_activate(mistark_cd* cd, int point_triangle, int edge_edge);
 int mistark_cd_run_proximity(mistark_cd* cd, double enlargement, int32_t counts[6]);
 /* rows (counts[list] x columns of the list, see above) and distances of the last run; either pointer may be NULL */
 int mistark_cd_get_proximity(mistark_cd* cd, int list, int32_t* rows, double* distance);
+/* ProximityDetection::get_broad_phase_results() (ProximityDetection.h:31, types.h:24-33): the candidate pairs of a run at the CURRENT positions —
+ * every (point, triangle) and (edge a < edge b) pair whose boxes as the reference builds them (floats to nearest, enlarged by (float)enlargement +
+ * eps, AABBs.cpp:7-45) overlap, minus points of their own triangle, edges sharing a vertex, blacklisted meshes and ranges
+ * (BroadPhasePTEEBase.cpp:176-262). counts[0] = point-triangle pairs, counts[1] = edge-edge pairs; rows of 4: first.set first.idx second.set
+ * second.idx, sorted. The proximity lists of the previous run are invalidated (the next mistark_cd_run_proximity searches again). */
+int mistark_cd_run_broad_phase(mistark_cd* cd, double enlargement, int32_t counts[2]);
+int mistark_cd_get_broad_phase(mistark_cd* cd, int list, int32_t* rows);
 /* IntersectionDetection::run(): number of intersecting (edge, triangle) pairs; their rows with mistark_cd_get_intersections */
 int mistark_cd_run_intersection(mistark_cd* cd, int32_t* n_pairs);
 int mistark_cd_get_intersections(mistark_cd* cd, int32_t* rows);

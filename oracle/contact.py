@@ -400,6 +400,49 @@ def detect(scene, X, enlargement):
     return res
 
 
+def broad_phase(scene, X, enlargement):
+    """The candidate pairs of ProximityDetection::run by brute force: boxes as AABBs.cpp:7-45 builds them (vertices cast to float, minimum /
+    maximum, minus / plus `(float)enlargement + epsilon` in float arithmetic), overlap = `<=` both ways on every axis, minus points of their own
+    triangle, edges sharing a vertex (same mesh) and blacklisted mesh pairs (BroadPhasePTEEBase.cpp:176-262, the Bruteforce strategy's loops).
+    Returns (point_triangle, edge_edge): sorted arrays of rows (first.set, first.idx, second.set, second.idx); edge pairs with the lower
+    global edge first. No fixture holds the reference's own list (nothing in stark/src reads it); it is pinned indirectly: every pair of
+    the narrow-phase lists, which ARE pinned (tests/test_oracle_contact.py), must be among these candidates (tests/test_gpu_contact.py)."""
+    M = scene.meshes
+    extra = np.float32(np.float32(enlargement) + np.finfo(np.float32).eps)
+
+    def boxes(prims):  # prims: list of (mesh, local vertex indices)
+        lo = np.empty((len(prims), 3), dtype=np.float32)
+        hi = np.empty((len(prims), 3), dtype=np.float32)
+        for n, (k, vs) in enumerate(prims):
+            x = np.asarray(X[k], dtype=np.float64)[list(vs)].astype(np.float32)
+            lo[n] = x.min(axis=0) - extra
+            hi[n] = x.max(axis=0) + extra
+        return lo, hi
+
+    pts = [(k, i) for k, m in enumerate(M) for i in range(len(m.verts))]
+    tris = [(k, i) for k, m in enumerate(M) for i in range(len(m.tris))]
+    eds = [(k, i) for k, m in enumerate(M) for i in range(len(m.edges))]
+    pt_rows, ee_rows = [], []
+    if pts and tris:
+        plo, phi = boxes([(k, [i]) for k, i in pts])
+        tlo, thi = boxes([(k, M[k].tris[i]) for k, i in tris])
+        ov = ((plo[:, None, :] <= thi[None, :, :]) & (tlo[None, :, :] <= phi[:, None, :])).all(axis=2)
+        for ip, it in zip(*np.nonzero(ov)):
+            (pm, pi), (tm, ti) = pts[ip], tris[it]
+            if scene.is_disabled(pm, tm) or (pm == tm and pi in M[tm].tris[ti]):
+                continue
+            pt_rows.append((pm, pi, tm, ti))
+    if len(eds) > 1:
+        elo, ehi = boxes([(k, M[k].edges[i]) for k, i in eds])
+        ov = ((elo[:, None, :] <= ehi[None, :, :]) & (elo[None, :, :] <= ehi[:, None, :])).all(axis=2)
+        for ia, ib in zip(*np.nonzero(np.triu(ov, 1))):
+            (am, ai), (bm, bi) = eds[ia], eds[ib]
+            if scene.is_disabled(am, bm) or (am == bm and set(M[am].edges[ai]) & set(M[bm].edges[bi])):
+                continue
+            ee_rows.append((am, ai, bm, bi))
+    return (np.array(sorted(pt_rows), dtype=np.int64).reshape(-1, 4), np.array(sorted(ee_rows), dtype=np.int64).reshape(-1, 4))
+
+
 def has_intersections(scene, X):
     """IntersectionDetection::run: any edge-triangle pair (not sharing a vertex, not disabled) that intersects."""
     M = scene.meshes

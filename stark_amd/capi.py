@@ -247,7 +247,7 @@ def exported_symbols():
     """Every entry point include/*.h declares (used by the CPU-side load test)."""
     import re
     out = set()
-    for h in ("mistark.h", "mistark_contact.h", "mistark_sim.h"):
+    for h in ("mistark.h", "mistark_contact.h", "mistark_sim.h", "mistark_tmcd.h"):
         hdr = open(os.path.join(os.path.dirname(_HERE), "include", h)).read()
         out |= set(re.findall(r"\b(mistark_[a-z0-9_]+)\s*\(", hdr))
         out -= set(re.findall(r"struct\s+(mistark_[a-z0-9_]+)", hdr))  # (type names mentioned in comments)
@@ -306,6 +306,21 @@ class CollisionDetector:
                 self._ck(self.L.mistark_cd_get_proximity(self.h, l, rows.ctypes.data, dist.ctypes.data))
             out[name] = (rows, dist)
         return out
+
+    def run_broad_phase(self, enlargement):
+        """(point-triangle pairs, edge-edge pairs): rows of (first.set, first.idx, second.set, second.idx) — tmcd get_broad_phase_results()."""
+        import numpy as np
+        self.L.mistark_cd_run_broad_phase.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_int32)]
+        self.L.mistark_cd_get_broad_phase.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        counts = (C.c_int32 * 2)()
+        self._ck(self.L.mistark_cd_run_broad_phase(self.h, enlargement, counts))
+        out = []
+        for l in range(2):
+            rows = np.zeros((counts[l], 4), dtype=np.int32)
+            if counts[l]:
+                self._ck(self.L.mistark_cd_get_broad_phase(self.h, l, rows.ctypes.data))
+            out.append(rows)
+        return tuple(out)
 
     def run_intersection(self):
         import numpy as np

@@ -177,6 +177,10 @@ struct ContactDev
     const int32_t* bl_pt;
     const int32_t* bl_ee;
     int n_bl_pt, n_bl_ee;
+    // broad_only (mistark_cd_run_broad_phase): the sweep emits the candidate pairs themselves — those whose boxes AS THE REFERENCE BUILDS THEM
+    // overlap (broad_extra = its enlargement, AABBs.cpp:38) — instead of classifying them
+    int broad_only;
+    float broad_extra;
 };
 struct TableDev
 {
@@ -275,6 +279,30 @@ __device__ __forceinline__ void push_key(uint64_t key, uint64_t* __restrict__ ke
     const int slot = atomicAdd(&counters[0], 1);
     if (slot < key_cap) keys[slot] = key;
 }
+// The reference's own box of a primitive along one axis (AABBs.cpp:7-21): the vertices cast to float (to nearest), their minimum / maximum, minus /
+// plus the float enlargement. The search's boxes (k_contact_aabbs) are rounded outwards and a superset of these; a broad-phase LISTING has to
+// hold exactly the pairs the reference's overlap test (BroadPhasePTEEBase.cpp: <= both ways on every axis) accepts.
+__device__ __forceinline__ void ref_box(const double* X, const int* v, int nv, int k, float extra, float& lo, float& hi)
+{
+    lo = hi = __double2float_rn(X[3 * v[0] + k]);
+    for (int j = 1; j < nv; j++) {
+        const float x = __double2float_rn(X[3 * v[j] + k]);
+        lo = fminf(lo, x);
+        hi = fmaxf(hi, x);
+    }
+    lo = __fsub_rn(lo, extra);
+    hi = __fadd_rn(hi, extra);
+}
+__device__ __forceinline__ bool ref_boxes_overlap(const ContactDev& d, const int* va, int na, const int* vb, int nb)
+{
+    for (int k = 0; k < 3; k++) {
+        float alo, ahi, blo, bhi;
+        ref_box(d.X, va, na, k, d.broad_extra, alo, ahi);
+        ref_box(d.X, vb, nb, k, d.broad_extra, blo, bhi);
+        if (!(alo <= bhi && blo <= ahi)) return false;
+    }
+    return true;
+}
 template <bool FRICTION>
 __device__ __forceinline__ void narrow_pt(const ContactDev& d, int p, int t, double enl2, uint64_t* keys, int* counters, int key_cap)
 {
@@ -284,6 +312,11 @@ __device__ __forceinline__ void narrow_pt(const ContactDev& d, int p, int t, dou
     if (d.disabled[mp * d.n_mesh + mt]) return;
     for (int k = 0; k < d.n_bl_pt; k++)  // BroadPhasePTEEBase.cpp:181-205
         if (d.bl_pt[4 * k] <= t && t < d.bl_pt[4 * k + 1] && d.bl_pt[4 * k + 2] <= p && p < d.bl_pt[4 * k + 3]) return;
+    if (d.broad_only) {  // BroadPhasePTEEBase.cpp:190-214: the pair itself
+        const int vt[3] = {v0, v1, v2};
+        if (ref_boxes_overlap(d, &p, 1, vt, 3)) push_key(pack_key(0, 0, 0, p, t), keys, counters, key_cap);
+        return;
+    }
     int type;
     const double d2 = point_triangle_sq_distance(type, ldx(d.X, p), ldx(d.X, v0), ldx(d.X, v1), ldx(d.X, v2));
     if (!(d2 < enl2)) return;                                           // ProximityDetection.cpp:105
@@ -302,6 +335,11 @@ __device__ __forceinline__ void narrow_ee(const ContactDev& d, int ea, int eb, d
     for (int k = 0; k < d.n_bl_ee; k++) {  // (the pair is looked up as (lower, higher) global edge: BroadPhasePTEEBase.cpp:229-258)
         const int lo = ea < eb ? ea : eb, hi = ea < eb ? eb : ea;
         if (d.bl_ee[4 * k] <= lo && lo < d.bl_ee[4 * k + 1] && d.bl_ee[4 * k + 2] <= hi && hi < d.bl_ee[4 * k + 3]) return;
+    }
+    if (d.broad_only) {  // BroadPhasePTEEBase.cpp:236-262 (the parallel-edge cutoff belongs to the narrow phase)
+        const int va[2] = {a0, a1}, vb[2] = {b0, b1};
+        if (ref_boxes_overlap(d, va, 2, vb, 2)) push_key(pack_key(1, 1, 0, ea < eb ? ea : eb, ea < eb ? eb : ea), keys, counters, key_cap);
+        return;
     }
     const D3 xa0 = ldx(d.X, a0), xa1 = ldx(d.X, a1), xb0 = ldx(d.X, b0), xb1 = ldx(d.X, b1);
     if (sq3(cross3(xa1 - xa0, xb1 - xb0)) <= 1e-30) return;  // (nearly) parallel edges never reach a table (ProximityDetection.cpp:152-155)
@@ -1917,7 +1955,7 @@ struct StandaloneDetector
     Context c;
     std::vector<const double*> xm;
     PinnedBuf<double> X;
-    std::vector<int32_t> rows[6], et_rows;
+    std::vector<int32_t> rows[6], et_rows, bp_rows[2];  // (bp_rows: the last broad-phase listing, point-triangle | edge-edge, 4 columns)
     std::vector<double> dist[6];
     PinnedBuf<uint64_t> keys;
     std::string last_error;
@@ -2225,6 +2263,60 @@ int mistark_cd_get_proximity(mistark_cd* cd, int list, int32_t* rows, double* di
     if (list < 0 || list >= 6) throw Error("cd: bad list");
     if (rows && !cd->D.rows[list].empty()) std::memcpy(rows, cd->D.rows[list].data(), cd->D.rows[list].size() * sizeof(int32_t));
     if (distance && !cd->D.dist[list].empty()) std::memcpy(distance, cd->D.dist[list].data(), cd->D.dist[list].size() * sizeof(double));
+    CD_END(0)
+}
+int mistark_cd_run_broad_phase(mistark_cd* cd, double enlargement, int32_t counts[2])
+{
+    CD_BEGIN
+    StandaloneDetector& D = cd->D;
+    Context& c = D.c;
+    ContactSystem& cs = CS(c);
+    MS_CHECK(hipSetDevice(c.device));
+    for (int l = 0; l < 2; l++) {
+        D.bp_rows[l].clear();
+        if (counts) counts[l] = 0;
+    }
+    if (cs.meshes.empty()) return 0;
+    if (!(enlargement >= 0.0)) throw Error("cd: negative enlargement");
+    if (cs.meshes_dirty) upload_meshes(c, cs);
+    cd_gather_positions(D);
+    cd_upload_positions(D);
+    ContactDev d = cd_view(D);
+    d.broad_only = 1;
+    d.broad_extra = (float)enlargement + 1.1920929e-07f;  // AABBs.cpp:38
+    // the search itself runs on the engine's outward-rounded boxes (a superset: every pair the reference's boxes accept is among its candidates)
+    const float enl_f = nextafterf((float)enlargement, INFINITY) + 1.1920929e-07f;
+    const int np = cs.n_v + cs.n_t + cs.n_e;
+    hipLaunchKernelGGL(k_contact_aabbs, dim3((np + CB - 1) / CB), dim3(CB), 0, c.stream, d, enl_f, cs.aabb.p);
+    int h[64];
+    const int n = cd_search(D, d, true, enlargement, h);
+    D.prox_valid = false;  // (the key buffers and counters of the proximity lists were reused)
+    if (n == 0) return 0;
+    D.keys.resize((size_t)n);
+    MS_CHECK(hipMemcpyAsync(D.keys.data(), cs.keys.p, (size_t)n * sizeof(uint64_t), hipMemcpyDeviceToHost, c.stream));
+    MS_CHECK(hipStreamSynchronize(c.stream));
+    std::sort(D.keys.begin(), D.keys.end());
+    const uint64_t pmask = (1ull << PRIM_BITS) - 1;
+    for (int k = 0; k < n; k++) {
+        const uint64_t key = D.keys[(size_t)k];
+        const int l = (int)(key >> 58), a = (int)((key >> PRIM_BITS) & pmask), b = (int)(key & pmask);
+        if (l == 0) {  // {point.set, point.idx}, {triangle.set, triangle.idx}
+            const int mp = cs.h_cv_mesh[a], mt = cs.h_tri_mesh[b];
+            for (int v : {mp, a - cs.meshes[mp].v_off, mt, b - cs.meshes[mt].t_off}) D.bp_rows[0].push_back(v);
+        } else {       // {edge_a.set, edge_a.idx}, {edge_b.set, edge_b.idx}, a before b in the global edge order
+            const int ma = cs.h_edge_mesh[a], mb = cs.h_edge_mesh[b];
+            for (int v : {ma, a - cs.meshes[ma].e_off, mb, b - cs.meshes[mb].e_off}) D.bp_rows[1].push_back(v);
+        }
+    }
+    for (int l = 0; l < 2; l++)
+        if (counts) counts[l] = (int32_t)(D.bp_rows[l].size() / 4);
+    CD_END(0)
+}
+int mistark_cd_get_broad_phase(mistark_cd* cd, int list, int32_t* rows)
+{
+    CD_BEGIN
+    if (list < 0 || list >= 2) throw Error("cd: bad broad-phase list");
+    if (rows && !cd->D.bp_rows[list].empty()) std::memcpy(rows, cd->D.bp_rows[list].data(), cd->D.bp_rows[list].size() * sizeof(int32_t));
     CD_END(0)
 }
 int mistark_cd_run_intersection(mistark_cd* cd, int32_t* n_pairs)

@@ -100,6 +100,9 @@ FIXTURES = {
     # sampled state after 10 steps of a third run (4 threads). The reference's runs of this scene are NOT reproducible: they either land in three
     # steps of 32 / 56-61 / 45-59 Newton iterations and rest from the ninth step on, or take 37-38 iterations in the first step and then fail
     # attempts and halve dt — which one a run takes changed between two invocations with the same thread count. The fixture holds both kinds.
+    # tmcd::ProximityDetection::get_broad_phase_results() of the reference's OWN detector (tests/shim/shim_check.cpp `tmcd_broad`, the plain shim build
+    # links the unmodified TriangleMeshCollisionDetection): candidate pairs of a tilted 7 x 7 cloth patch over a box, enlargement 4 mm, as sorted rows
+    "tmcd_broad_phase_listing": ("shimcheck", "tmcd_broad", ""),
     "steplog_cfg2_tilted_256": ("steplog", "clothbox", "n=256 size=1 box=2 gap=0.002 tilt=3 thickness=0.001 mu=0.5 steps=30 traj_steps=10 traj_threads=4"),
     # what the reference WRITES for a run: its VTK frames, its YAML log and its run summary (tet beam, 2 time steps)
     "frames_tetbeam_4x1x1": ("frames", "tetbeam", "nx=4 ny=1 nz=1 eo=0 steps=2 frames=1"),
@@ -145,6 +148,14 @@ def run(cmd):
 def pack(name):
     mode, scene, args = FIXTURES[name]
     args = args.split()
+    if mode == "shimcheck":   # output of oracle/_ref/shim_check <scene> (the reference's classes driven directly), one JSON line
+        exe = os.path.join(os.path.dirname(HARNESS), "shim_check")
+        txt = subprocess.run([exe, scene] + args, check=True, capture_output=True).stdout.decode().strip().splitlines()[-1]
+        json.loads(txt)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), listing_json=np.frombuffer(txt.encode(), dtype=np.uint8),
+                            harness_args=np.frombuffer(("shim_check " + scene).encode(), dtype=np.uint8))
+        print(name, "%.1f KB" % (os.path.getsize(os.path.join(OUT, name + ".npz")) / 1024))
+        return
     tmp = tempfile.mkdtemp(prefix="mistark_fx_")
     try:
         scene_args = [a for a in args if not a.startswith(("steps=", "amp=", "xamp=", "frames=", "vamp=", "maxstep="))]

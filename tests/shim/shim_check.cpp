@@ -5,14 +5,77 @@
 // Built by oracle/Makefile (target _ref/shim_check) only where /root/reference exists; test infrastructure, not shipped.
 #include <stark>
 
+#include <algorithm>
+#include <array>
 #include <chrono>
+#include <cmath>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <set>
+#include <vector>
+
+// `shim_check tmcd_broad`: tmcd::ProximityDetection used directly — in the shim_cd build that is the stand-in on the device detector, in the
+// plain shim build the reference's own detector — on a tilted 7 x 7 cloth patch over a box: run(), then get_broad_phase_results(), printed as
+// sorted rows. tests/test_gpu_contact.py lays the two binaries' outputs side by side.
+static int tmcd_broad_phase_listing()
+{
+    std::vector<std::array<double, 3>> cv, bv;
+    std::vector<std::array<int32_t, 3>> ct, bt;
+    const int n = 6;
+    for (int j = 0; j <= n; j++)
+        for (int i = 0; i <= n; i++) cv.push_back({ -0.3 + 0.1 * i, -0.3 + 0.1 * j + 0.013 * i, 0.002 + 0.003 * i + 0.0011 * j * j });
+    for (int j = 0; j < n; j++)
+        for (int i = 0; i < n; i++) {
+            const int a = j * (n + 1) + i, b = a + 1, c = a + n + 1, d = c + 1;
+            ct.push_back({ a, b, d });
+            ct.push_back({ a, d, c });
+        }
+    for (int k = 0; k < 8; k++) bv.push_back({ (k & 1) ? 0.5 : -0.5, (k & 2) ? 0.5 : -0.5, (k & 4) ? 0.0 : -0.2 });
+    const int quads[6][4] = { { 0, 1, 3, 2 }, { 4, 6, 7, 5 }, { 0, 4, 5, 1 }, { 2, 3, 7, 6 }, { 0, 2, 6, 4 }, { 1, 5, 7, 3 } };
+    for (auto& q : quads) {
+        bt.push_back({ q[0], q[1], q[2] });
+        bt.push_back({ q[0], q[2], q[3] });
+    }
+    auto edges_of = [](const std::vector<std::array<int32_t, 3>>& T) {
+        std::set<std::array<int32_t, 2>> S;
+        for (auto& t : T)
+            for (int k = 0; k < 3; k++) S.insert({ std::min(t[k], t[(k + 1) % 3]), std::max(t[k], t[(k + 1) % 3]) });
+        return std::vector<std::array<int32_t, 2>>(S.begin(), S.end());
+    };
+    const auto ce = edges_of(ct), be = edges_of(bt);
+    tmcd::ProximityDetection pd;
+    pd.set_n_threads(1);
+    pd.add_mesh(&cv[0][0], (int32_t)cv.size(), &ct[0][0], (int32_t)ct.size(), &ce[0][0], (int32_t)ce.size());
+    pd.add_mesh(&bv[0][0], (int32_t)bv.size(), &bt[0][0], (int32_t)bt.size(), &be[0][0], (int32_t)be.size());
+    pd.add_blacklist(1, 1);
+    pd.activate_point_triangle(true);
+    pd.activate_edge_edge(true);
+    const auto& res = pd.run(0.004);
+    const size_t n_narrow = res.point_triangle.point_point.size() + res.point_triangle.point_edge.size() + res.point_triangle.point_triangle.size() +
+                            res.edge_edge.point_point.size() + res.edge_edge.point_edge.size() + res.edge_edge.edge_edge.size();
+    const auto& bp = pd.get_broad_phase_results();
+    auto rows = [](const std::vector<std::pair<tmcd::SetIndex, tmcd::SetIndex>>& v) {
+        std::vector<std::array<int32_t, 4>> r;
+        for (auto& p : v) r.push_back({ p.first.set, p.first.idx, p.second.set, p.second.idx });
+        std::sort(r.begin(), r.end());
+        return r;
+    };
+    std::cout << "{\"narrow_pairs\":" << n_narrow;
+    for (int l = 0; l < 2; l++) {
+        const auto r = rows(l == 0 ? bp.point_triangle : bp.edge_edge);
+        std::cout << ",\"" << (l == 0 ? "point_triangle" : "edge_edge") << "\":[";
+        for (size_t k = 0; k < r.size(); k++) std::cout << (k ? "," : "") << "[" << r[k][0] << "," << r[k][1] << "," << r[k][2] << "," << r[k][3] << "]";
+        std::cout << "]";
+    }
+    std::cout << "}" << std::endl;
+    return 0;
+}
 
 int main(int argc, char** argv)
 {
     const std::string scene = argc > 1 ? argv[1] : "blockbox";
+    if (scene == "tmcd_broad") return tmcd_broad_phase_listing();
     const int steps = argc > 2 ? std::atoi(argv[2]) : 1;
     stark::Settings settings = stark::Settings();
     settings.output.output_directory = "/tmp/mistark_shim_out";

@@ -255,6 +255,88 @@ def test_standalone_detector_returns_the_references_lists(name):
     cd.close()
 
 
+@pytest.mark.parametrize("name", ["contactmix_t0", "contactmix_t1", "contactrods_t0", "contactcorners_t0"])
+def test_standalone_detector_broad_phase_list(name):
+    """mistark_cd_run_broad_phase (what tmcd::ProximityDetection::get_broad_phase_results() hands out, ProximityDetection.h:31): the candidate pairs
+    as row sets against the oracle's brute force over boxes built the way the reference builds them (oracle/contact.py broad_phase) — bit-exact;
+    every pair of the pinned narrow-phase lists is among them; and a proximity run behind it still returns its lists (the listing invalidates the
+    detector's cache of the previous run)."""
+    from stark_amd import capi
+
+    prob, man, z = ev.load_fixture(os.path.join(GOLDEN, name + ".npz"))
+    st, _ = state_from_fixture(prob, man)
+    scene = oc.scene_from_fixture(man, z)
+    dt = float(np.asarray(st["dt"]).ravel()[0])
+    X = [np.ascontiguousarray(x, dtype=np.float64) for x in oc.mesh_vertices(scene, st, dt)]
+    cd = capi.CollisionDetector()
+    for m, x in zip(scene.meshes, X):
+        cd.add_mesh(x, m.tris, m.edges)
+    for (a, b) in scene.disabled:
+        cd.add_blacklist(a, b)
+    enl = 2.0 * oc.max_thickness(scene)
+    before = cd.run_proximity(enl)
+    pt, ee = cd.run_broad_phase(enl)
+    rpt, ree = oc.broad_phase(scene, X, enl)
+    for got, ref in ((pt, rpt), (ee, ree)):
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        if len(ref):
+            assert (got[np.lexsort(got.T[::-1])] == ref).all()
+    assert len(rpt) + len(ree) > 20
+    # the narrow phase only sees broad-phase candidates: every proximity pair is in the list
+    spt = {tuple(r) for r in pt.tolist()}
+    see = {tuple(r) for r in ee.tolist()}
+    n_checked = 0
+    for lname, (rows, _) in before.items():
+        for r in rows.tolist():
+            if lname.startswith("pt_"):
+                assert (r[0], r[1], r[2], r[3]) in spt, (lname, r)
+            else:
+                second = r[5:7] if lname != "ee_edge_edge" else r[4:6]
+                a, b = (r[0], r[1]), tuple(second)
+                assert (a + b) in see or (b + a) in see, (lname, r)
+            n_checked += 1
+    assert n_checked > 10
+    after = cd.run_proximity(enl)
+    for lname in before:
+        assert (before[lname][0] == after[lname][0]).all() and (before[lname][1] == after[lname][1]).all(), lname
+    # only one family active: the other list stays empty
+    cd.activate(point_triangle=True, edge_edge=False)
+    pt2, ee2 = cd.run_broad_phase(enl)
+    assert len(ee2) == 0 and pt2.shape == pt.shape
+    cd.close()
+
+
+def test_stand_in_get_broad_phase_results_equals_the_references_detector():
+    """tmcd::ProximityDetection::get_broad_phase_results() of the stand-in header (shim/include_cd, on mistark_cd_run_broad_phase) against the
+    reference's own detector: the same program (`shim_check tmcd_broad`) built once against each header; the reference's output is the
+    committed fixture, the stand-in's comes from oracle/_ref/shim_check_cd on this GPU. And the same geometry straight through the C ABI."""
+    import json
+    import subprocess
+
+    from contact_util import tmcd_broad_scene
+    from stark_amd import capi
+
+    z = np.load(os.path.join(GOLDEN, "tmcd_broad_phase_listing.npz"))
+    ref = json.loads(bytes(z["listing_json"]).decode())
+    scene, X, enl = tmcd_broad_scene()
+    cd = capi.CollisionDetector()
+    for m, x in zip(scene.meshes, X):
+        cd.add_mesh(x, m.tris, m.edges)
+    cd.add_blacklist(1, 1)
+    pt, ee = cd.run_broad_phase(enl)
+    cd.close()
+    assert pt[np.lexsort(pt.T[::-1])].tolist() == ref["point_triangle"]
+    assert ee[np.lexsort(ee.T[::-1])].tolist() == ref["edge_edge"]
+    exe = os.path.join(ROOT, "oracle", "_ref", "shim_check_cd")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/shim_check_cd not built (needs /root/reference in the build container)")
+    r = subprocess.run([exe, "tmcd_broad"], capture_output=True, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    got = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert got["narrow_pairs"] == ref["narrow_pairs"] > 0
+    assert got["point_triangle"] == ref["point_triangle"] and got["edge_edge"] == ref["edge_edge"]
+
+
 def test_standalone_detector_range_blacklists():
     """tmcd::ProximityDetection::add_blacklist_range_point_triangle / _edge_edge (ProximityDetection.h:24-25; BroadPhasePTEEBase.cpp:19-41,176-262:
     half-open intervals of local primitive indices, a pair is dropped when its triangle lies in the first and its point in the second interval —

@@ -1059,6 +1059,40 @@ def test_contact_free_runs_are_bit_reproducible():
     assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
 
 
+def test_page_locked_caller_arrays_change_nothing_but_the_transfer_path(monkeypatch):
+    """Engine option pin_host_arrays (round 6; the shim's MISTARK_SHIM_PIN=1): the caller's large DoF and bound arrays are page-locked where they
+    are (checked hipHostRegister), transfers to and from them are direct; released with the context. Same Newton / CG counts and the same bits
+    as with pageable arrays, and the counter says that ranges were really locked. (The mirror keeps its state host-side with
+    mirror_state_to_host: DoFs come back and state arrays go up at every step — the paths the option changes.)"""
+    import ctypes as C
+
+    from stark_amd import sim as S
+
+    def run(pin):
+        monkeypatch.setenv("MISTARK_OPTIONS", "pin_host_arrays=1" if pin else "")
+        st = S.default_settings()
+        st.init_frictional_contact = 0
+        st.mirror_state_to_host = 1
+        sim = S.Simulation(st)
+        cloth = sim.add_surface_grid("cloth", (1.0, 1.0), (96, 96), S.cotton_fabric())     # 9409 nodes: arrays of 226 KB
+        sim.prescribe_inside_aabb(cloth, (0.5, 0.5, 0.0), (0.001, 0.001, 0.001), 1e3)
+        sim.prescribe_inside_aabb(cloth, (0.5, -0.5, 0.0), (0.001, 0.001, 0.001), 1e3)
+        for _ in range(4):
+            assert sim.run_one_step()
+        n = C.c_int64()
+        sim.L.mistark_get_counter.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64)]
+        assert sim.L.mistark_get_counter(sim.engine_handle(), b"host_ranges_pinned", C.byref(n)) == 0
+        i = sim.info()
+        out = (sim.points("x0").copy(), sim.points("v0").copy(), i.total_newton_iterations, i.total_cg_iterations, n.value)
+        sim.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert a[4] == 0 and b[4] >= 1, (a[4], b[4])
+    assert a[2] == b[2] > 4 and a[3] == b[3]
+    assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+
+
 @pytest.mark.parametrize("grid", [(10, 10, 10)])
 def test_contact_runs_are_bit_reproducible(grid):
     """The same with frictional contact and a rigid body: a soft block on a fixed rigid box (device contact detection, barrier and friction

@@ -128,3 +128,20 @@ def test_friction_tables_match_reference(name):
             scale = max(np.abs(rd).max(), 1e-300)
             assert np.abs(od - rd[ref[o2, 0]]).max() <= 1e-9 * scale, (p["name"], role)
     assert total > 0
+
+
+def test_broad_phase_restatement_equals_the_references_own_candidate_list():
+    """oracle/contact.py broad_phase (boxes as AABBs.cpp builds them, overlap and exclusions of BroadPhasePTEEBase.cpp) against
+    tmcd::ProximityDetection::get_broad_phase_results() of the reference's own detector on the same geometry (fixture tmcd_broad_phase_listing,
+    made by `oracle/_ref/shim_check tmcd_broad`): the same pairs, row for row."""
+    import json
+
+    from contact_util import tmcd_broad_scene
+
+    z = np.load(os.path.join(GOLDEN, "tmcd_broad_phase_listing.npz"))
+    ref = json.loads(bytes(z["listing_json"]).decode())
+    scene, X, enl = tmcd_broad_scene()
+    pt, ee = oc.broad_phase(scene, X, enl)
+    assert ref["narrow_pairs"] > 0 and len(ref["point_triangle"]) > 50 and len(ref["edge_edge"]) > 100
+    assert pt.tolist() == ref["point_triangle"]
+    assert ee.tolist() == ref["edge_edge"]
