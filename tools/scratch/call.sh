@@ -1,3 +1,4 @@
 export TMPDIR=/tmp
 cd "$(dirname "$0")/../.."
-timeout 900 python -m pytest tests/test_gpu_contact.py -m gpu -q 2>&1 | tail -12
+bash tools/r06_final.sh r06_final > gpurun_out/r06_final.log 2>&1
+grep -E "passed|failed|smoke" gpurun_out/r06_final.log | head
