@@ -80,6 +80,12 @@ int main(int argc, char** argv)
     stark::Settings settings = stark::Settings();
     settings.output.output_directory = "/tmp/mistark_shim_out";
     settings.output.codegen_directory = "/tmp/mistark_shim_codegen";
+    // SHIM_SCRATCH=<dir>: a directory of this run's own for both (tests running several of these side by side, pytest -n: two runs writing the
+    // shared defaults at once is what made tests/test_shim_cpu.py fail now and then under xdist)
+    if (const char* scratch = std::getenv("SHIM_SCRATCH")) {
+        settings.output.output_directory = std::string(scratch) + "/out";
+        settings.output.codegen_directory = std::string(scratch) + "/codegen";
+    }
     // argv[4]: an output directory; the reference then writes its frames (VTK), its YAML log and its run summary there, fed by the shim
     const bool with_output = argc > 4;
     if (with_output) settings.output.output_directory = argv[4];

@@ -85,7 +85,7 @@ def _normalise(d):
 @pytest.mark.parametrize("scene", ["blockbox", "mixed", "tetbeam", "cloth"])
 def test_reference_classes_register_what_the_mirror_registers(scene, tmp_path):
     out = str(tmp_path / "shim.json")
-    env = dict(os.environ, MISTARK_SHIM_DRY="1", MISTARK_SHIM_DESCRIBE=out)
+    env = dict(os.environ, MISTARK_SHIM_DRY="1", MISTARK_SHIM_DESCRIBE=out, SHIM_SCRATCH=str(tmp_path))
     r = subprocess.run([SHIM_CHECK, scene], env=env, capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     ref = json.load(open(out))
@@ -138,7 +138,7 @@ def test_the_collision_detection_stand_in_changes_nothing_that_is_registered(sce
     got = []
     for binary in (SHIM_CHECK, exe):
         out = str(tmp_path / (os.path.basename(binary) + ".json"))
-        env = dict(os.environ, MISTARK_SHIM_DRY="1", MISTARK_SHIM_DESCRIBE=out)
+        env = dict(os.environ, MISTARK_SHIM_DRY="1", MISTARK_SHIM_DESCRIBE=out, SHIM_SCRATCH=str(tmp_path))
         r = subprocess.run([binary, scene], env=env, capture_output=True, timeout=300)
         assert r.returncode == 0, r.stderr.decode()[-2000:]
         got.append(json.load(open(out)))
@@ -159,7 +159,7 @@ def test_user_defined_potential_takes_the_sequence_branch_of_the_shim(scene, nam
     registers it with mistark_potential_custom; `foreach` carries a summation loop (MappedWorkspace::add_for_each), whose symbols get a binding
     of their own (a global slot of 4 doubles: the pole) at the place the summation vector was made."""
     out = str(tmp_path / "shim.json")
-    env = dict(os.environ, MISTARK_SHIM_DRY="1", MISTARK_SHIM_DESCRIBE=out)
+    env = dict(os.environ, MISTARK_SHIM_DRY="1", MISTARK_SHIM_DESCRIBE=out, SHIM_SCRATCH=str(tmp_path))
     r = subprocess.run([SHIM_CHECK, scene], env=env, capture_output=True, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     d = json.load(open(out))
