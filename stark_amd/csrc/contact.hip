@@ -707,9 +707,12 @@ __device__ __forceinline__ int wave_bound_f(const float* __restrict__ a, int lo,
 // points in its interval) becomes tasks of SWEEP_SPLIT candidates that k_sweep_tasks spreads over the chip; one wavefront walking such a
 // range alone was 0.9 ms of a 1 ms detection.
 #ifndef MISTARK_SWEEP_SUB
-#define MISTARK_SWEEP_SUB 16
+#define MISTARK_SWEEP_SUB 8
 #endif
-constexpr int SWEEP_SUB = MISTARK_SWEEP_SUB;  // lanes per sorted entry; measured 8 / 16 / 32: contact callbacks of configs[2] 1.63 / 1.73 / 1.90 ms per step, configs[3] equal within noise
+// lanes per sorted entry; measured 8 / 16 / 32: contact callbacks of configs[2] 1.63 / 1.73 / 1.90 ms per step, configs[3] equal within noise; round 6,
+// A/B of 4 / 8 / 16 / 32 on one box (variant libraries): configs[2] tilted 144 / 145.5 / 139 / 133 Newton-steps/s, configs[4] 110 / 112.7 / 108.5 / 110,
+// configs[3] 162 / 165 / 165 / 165: 8 (16 through round 5)
+constexpr int SWEEP_SUB = MISTARK_SWEEP_SUB;
 #ifndef MISTARK_SWEEP_SPLIT
 #define MISTARK_SWEEP_SPLIT 512
 #endif
